@@ -1,0 +1,99 @@
+"""ctypes binding of libcslam_hip.so (the C ABI declared in include/cslam_hip.h).
+
+There is no CPU fallback: every product entry point raises CslamHipError when the
+library is missing or no MI355X is visible.  Build with `python __graft_entry__.py`
+(or `make -C cslam_amd/csrc`).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcslam_hip.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+F32, F64 = 0, 1
+MODE_AUTO, MODE_SCAN, MODE_MFMA = 0, 1, 2
+
+
+class CslamHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_SIGNATURES = {
+    "cslam_last_error": (C.c_char_p, []),
+    "cslam_version": (_i, []),
+    "cslam_device_count": (_i, [C.POINTER(_i)]),
+    "cslam_device_info": (_i, [_i, C.c_char_p, _i, C.POINTER(_i64), C.POINTER(_i)]),
+    "cslam_bank_create": (_i, [_i, _i, _i64, C.POINTER(_vp)]),
+    "cslam_bank_destroy": (_i, [_vp]),
+    "cslam_bank_size": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i)]),
+    "cslam_bank_clear": (_i, [_vp]),
+    "cslam_bank_add_host": (_i, [_vp, _vp, _i, _i64]),
+    "cslam_bank_add_dev": (_i, [_vp, _vp, _i64, _i64, _vp]),
+    "cslam_bank_read_host": (_i, [_vp, _i64, _i64, _vp]),
+    "cslam_bank_device_ptr": (_i, [_vp, C.POINTER(_vp), C.POINTER(_i64)]),
+    "cslam_bank_search_host": (_i, [_vp, _vp, _i, _i64, _i, _vp, _i, _vp, _vp, _vp]),
+    "cslam_bank_search_dev": (_i, [_vp, _vp, _i, _i64, _i64, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "cslam_bank_last_stats": (_i, [_vp, C.POINTER(_i64 * 4)]),
+    "cslam_bank_last_kernel_ms": (_i, [_vp, C.POINTER(_f)]),
+    "cslam_l2_normalize_dev": (_i, [_vp, _i64, _i, _i64, _f, _i, _vp]),
+    "cslam_vlad_aggregate_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "cslam_gem_fc_head_dev": (_i, [_vp, _f, _f, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "cslam_pca_project_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "cslam_preprocess_dev": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(_f * 3), C.POINTER(_f * 3), _vp, _vp]),
+    "cslam_mac_grad_dev": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "cslam_laplacian_spmm_dev": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def build(verbose=False):
+    """Compile libcslam_hip.so for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    r = subprocess.run(["make", "-C", CSRC_DIR, "-j", "4"], capture_output=True, text=True)
+    if verbose or r.returncode != 0:
+        print(r.stdout[-4000:])
+        print(r.stderr[-4000:])
+    if r.returncode != 0:
+        raise CslamHipError("building libcslam_hip.so failed")
+    return LIB_PATH
+
+
+def load():
+    """dlopen the library and bind every symbol of include/cslam_hip.h (no GPU needed)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CslamHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built "
+            "(run `python __graft_entry__.py` or `make -C cslam_amd/csrc`); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if a declared symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().cslam_last_error()
+        raise CslamHipError(f"libcslam_hip error {rc}: {msg.decode() if msg else ''}")
+
+
+def require_gpu():
+    """Fail loudly when no HIP device is visible (the product path never runs on the CPU)."""
+    lib = load()
+    n = C.c_int(0)
+    rc = lib.cslam_device_count(C.byref(n))
+    if rc != 0 or n.value < 1:
+        msg = lib.cslam_last_error()
+        raise CslamHipError("no HIP device visible: cslam_amd needs an MI355X (gfx950); "
+                            f"no CPU fallback exists ({msg.decode() if msg else ''})")
+    return n.value

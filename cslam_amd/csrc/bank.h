@@ -1,0 +1,38 @@
+// Descriptor bank object shared by bank.hip (storage + exact scan) and sim_topk_mfma.hip.
+#pragma once
+#include "common.h"
+
+struct cslam_bank {
+    int device;
+    int dim;        // logical descriptor dimension
+    int ld;         // row stride in floats: dim rounded up to 32 (zero padded)
+    int64_t n;      // rows stored
+    int64_t cap;    // rows allocated
+    float *rows;    // [cap, ld]  float32 descriptors (reference: nns_matching.py:21)
+    double *vv;     // [cap]      sum of squares of each row, float64
+    float *invn;    // [cap]      (float)(1/sqrt(vv)); used by the fp32 candidate stage only
+    // grow-on-demand workspace
+    char *ws[2];          // [0] MFMA path, [1] scan path (the scan is also the MFMA fallback)
+    size_t ws_bytes[2];
+    char *stage;    // device staging for host->device adds
+    size_t stage_bytes;
+    hipStream_t last_stream;
+    hipEvent_t ev0, ev1;
+    bool ev_valid;
+    int64_t stats[4];
+    int num_cu;
+};
+
+int bank_ws_reserve(cslam_bank *b, int slot, size_t bytes);
+
+// exact fp64 scan over selected queries (bank.hip)
+//  d_q: queries [nq_total, ldq] of q_dtype; qsel: [nsel] int32 query numbers or NULL (identity)
+//  outputs for query number j go to out_*[j*k ...]
+int scan_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, const int *d_qsel,
+                int64_t nsel, int k, const int64_t *d_row_limit, int64_t *d_out_idx,
+                double *d_out_sim, int32_t *d_out_cnt, hipStream_t st);
+
+// fp32-MFMA candidate search + fp64 rescoring (sim_topk_mfma.hip)
+int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_t nq, int k,
+                const int64_t *d_row_limit, int64_t *d_out_idx, double *d_out_sim,
+                int32_t *d_out_cnt, hipStream_t st);

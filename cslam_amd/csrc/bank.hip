@@ -1,0 +1,537 @@
+// bank.hip -- descriptor bank in HBM + the exact float64 scan search (gfx950).
+//
+// Replaces cslam/nns_matching.py:10-76 (NearestNeighborsMatching):
+//   storage   : growable float32 [cap, ld] array in HBM (amortised doubling like
+//               nns_matching.py:31-37), + per-row float64 sum of squares.
+//   scan_exact: one wave per bank row, lanes stride the columns with 16-byte loads
+//               (coalesced 1 KiB per wave instruction), float64 accumulate, butterfly
+//               reduce, wave-resident sorted top-k list.  HBM-bound: reads n*ld*4
+//               bytes per pass over up to QT queries.  This is the online (nq small)
+//               path and the fallback of the MFMA batch path.
+#include <stdarg.h>
+#include <new>
+#include "bank.h"
+
+// ------------------------------------------------------------------ errors ----
+static thread_local char g_err[512] = "";
+void cslam_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+CSLAM_API const char *cslam_last_error(void) { return g_err; }
+CSLAM_API int cslam_version(void) { return 100; }
+
+CSLAM_API int cslam_device_count(int *count) {
+    ARG_CHECK(count, "count is NULL");
+    HIP_TRY(hipGetDeviceCount(count));
+    return CSLAM_OK;
+}
+
+CSLAM_API int cslam_device_info(int device, char *name, int name_len, int64_t *hbm_bytes, int *cu_count) {
+    hipDeviceProp_t p;
+    HIP_TRY(hipGetDeviceProperties(&p, device));
+    if (name && name_len > 0) { strncpy(name, p.gcnArchName, name_len - 1); name[name_len - 1] = 0; }
+    if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+    if (cu_count) *cu_count = p.multiProcessorCount;
+    return CSLAM_OK;
+}
+
+// ------------------------------------------------------------------ storage ----
+int bank_ws_reserve(cslam_bank *b, int slot, size_t bytes) {
+    if (bytes <= b->ws_bytes[slot]) return CSLAM_OK;
+    if (b->ws[slot]) HIP_TRY(hipFree(b->ws[slot]));   // hipFree synchronises the device
+    b->ws[slot] = nullptr; b->ws_bytes[slot] = 0;
+    size_t want = bytes + bytes / 4;
+    HIP_TRY(hipMalloc((void **)&b->ws[slot], want));
+    b->ws_bytes[slot] = want;
+    return CSLAM_OK;
+}
+
+static int bank_grow(cslam_bank *b, int64_t need) {
+    if (need <= b->cap) return CSLAM_OK;
+    int64_t ncap = b->cap > 0 ? b->cap : 1000;   // reference starts at 1000 rows (nns_matching.py:21)
+    while (ncap < need) ncap *= 2;               // and doubles (nns_matching.py:36)
+    float *rows = nullptr; double *vv = nullptr; float *invn = nullptr;
+    HIP_TRY(hipMalloc((void **)&rows, (size_t)ncap * b->ld * sizeof(float)));
+    HIP_TRY(hipMalloc((void **)&vv, (size_t)ncap * sizeof(double)));
+    HIP_TRY(hipMalloc((void **)&invn, (size_t)ncap * sizeof(float)));
+    if (b->n > 0) {
+        HIP_TRY(hipMemcpy(rows, b->rows, (size_t)b->n * b->ld * sizeof(float), hipMemcpyDeviceToDevice));
+        HIP_TRY(hipMemcpy(vv, b->vv, (size_t)b->n * sizeof(double), hipMemcpyDeviceToDevice));
+        HIP_TRY(hipMemcpy(invn, b->invn, (size_t)b->n * sizeof(float), hipMemcpyDeviceToDevice));
+    }
+    if (b->rows) HIP_TRY(hipFree(b->rows));
+    if (b->vv) HIP_TRY(hipFree(b->vv));
+    if (b->invn) HIP_TRY(hipFree(b->invn));
+    b->rows = rows; b->vv = vv; b->invn = invn; b->cap = ncap;
+    return CSLAM_OK;
+}
+
+CSLAM_API int cslam_bank_create(int device, int dim, int64_t capacity_hint, cslam_bank_t **out) {
+    ARG_CHECK(out, "out is NULL");
+    ARG_CHECK(dim > 0, "dim must be > 0");
+    HIP_TRY(hipSetDevice(device));
+    cslam_bank *b = new (std::nothrow) cslam_bank();
+    if (!b) { cslam_set_error("out of host memory"); return CSLAM_E_NOMEM; }
+    memset(b, 0, sizeof(*b));
+    b->device = device; b->dim = dim; b->ld = (int)round_up64(dim, 32);
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, device) == hipSuccess) b->num_cu = p.multiProcessorCount;
+    if (b->num_cu <= 0) b->num_cu = 256;
+    int rc = bank_grow(b, capacity_hint > 0 ? capacity_hint : 1000);
+    if (rc != CSLAM_OK) { delete b; return rc; }
+    if (hipEventCreate(&b->ev0) == hipSuccess && hipEventCreate(&b->ev1) == hipSuccess) b->ev_valid = true;
+    *out = b;
+    return CSLAM_OK;
+}
+
+CSLAM_API int cslam_bank_destroy(cslam_bank_t *b) {
+    if (!b) return CSLAM_OK;
+    (void)hipSetDevice(b->device);
+    (void)hipDeviceSynchronize();
+    if (b->rows) (void)hipFree(b->rows);
+    if (b->vv) (void)hipFree(b->vv);
+    if (b->invn) (void)hipFree(b->invn);
+    for (int s = 0; s < 2; ++s) if (b->ws[s]) (void)hipFree(b->ws[s]);
+    if (b->stage) (void)hipFree(b->stage);
+    if (b->ev_valid) { (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1); }
+    delete b;
+    return CSLAM_OK;
+}
+
+CSLAM_API int cslam_bank_size(const cslam_bank_t *b, int64_t *n, int *dim) {
+    ARG_CHECK(b, "bank is NULL");
+    if (n) *n = b->n;
+    if (dim) *dim = b->dim;
+    return CSLAM_OK;
+}
+
+CSLAM_API int cslam_bank_clear(cslam_bank_t *b) {
+    ARG_CHECK(b, "bank is NULL");
+    b->n = 0;
+    return CSLAM_OK;
+}
+
+// one wave per appended row: copy (with float64->float32 cast when SRC is double, the
+// numpy assignment cast of nns_matching.py:39), zero the padding, float64 sum of squares.
+template <typename SRC>
+__global__ __launch_bounds__(256) void bank_append_kernel(const SRC *__restrict__ src, int64_t ld_src,
+                                                          int64_t nrows, int dim, int ld,
+                                                          float *__restrict__ rows, double *__restrict__ vv,
+                                                          float *__restrict__ invn, int64_t row0) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= nrows) return;
+    const SRC *s = src + r * ld_src;
+    float *d = rows + (row0 + r) * (int64_t)ld;
+    double acc = 0.0;
+    for (int c = lane; c < ld; c += 64) {
+        float v = c < dim ? (float)s[c] : 0.0f;
+        d[c] = v;
+        acc += (double)v * (double)v;
+    }
+    acc = wave_allreduce_sum(acc);
+    if (lane == 0) {
+        vv[row0 + r] = acc;
+        invn[row0 + r] = (float)(1.0 / sqrt(acc));   // zero row -> +inf (NaN score, like the reference)
+    }
+}
+
+template <typename SRC>
+static int bank_append_launch(cslam_bank *b, const SRC *d_src, int64_t ld_src, int64_t n, hipStream_t st) {
+    if (n == 0) return CSLAM_OK;
+    dim3 grid((unsigned)ceil_div64(n, 4));
+    hipLaunchKernelGGL(bank_append_kernel<SRC>, grid, dim3(256), 0, st, d_src, ld_src, n, b->dim, b->ld,
+                       b->rows, b->vv, b->invn, b->n);
+    HIP_TRY(hipGetLastError());
+    b->n += n;
+    b->last_stream = st;
+    return CSLAM_OK;
+}
+
+CSLAM_API int cslam_bank_add_host(cslam_bank_t *b, const void *vecs, int dtype, int64_t n) {
+    ARG_CHECK(b && (vecs || n == 0), "NULL argument");
+    ARG_CHECK(dtype == CSLAM_F32 || dtype == CSLAM_F64, "dtype must be CSLAM_F32 or CSLAM_F64");
+    ARG_CHECK(n >= 0, "n < 0");
+    if (n == 0) return CSLAM_OK;
+    HIP_TRY(hipSetDevice(b->device));
+    int rc = bank_grow(b, b->n + n);
+    if (rc) return rc;
+    size_t esz = dtype == CSLAM_F32 ? 4 : 8;
+    const int64_t chunk_rows = 16384;
+    for (int64_t r0 = 0; r0 < n; r0 += chunk_rows) {
+        int64_t m = n - r0 < chunk_rows ? n - r0 : chunk_rows;
+        size_t bytes = (size_t)m * b->dim * esz;
+        if (bytes > b->stage_bytes) {
+            if (b->stage) HIP_TRY(hipFree(b->stage));
+            b->stage = nullptr; b->stage_bytes = 0;
+            HIP_TRY(hipMalloc((void **)&b->stage, bytes));
+            b->stage_bytes = bytes;
+        }
+        HIP_TRY(hipMemcpy(b->stage, (const char *)vecs + (size_t)r0 * b->dim * esz, bytes, hipMemcpyHostToDevice));
+        if (dtype == CSLAM_F32) rc = bank_append_launch<float>(b, (const float *)b->stage, b->dim, m, 0);
+        else rc = bank_append_launch<double>(b, (const double *)b->stage, b->dim, m, 0);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(0));
+    }
+    return CSLAM_OK;
+}
+
+CSLAM_API int cslam_bank_add_dev(cslam_bank_t *b, const float *d_vecs, int64_t ld, int64_t n, void *stream) {
+    ARG_CHECK(b && (d_vecs || n == 0), "NULL argument");
+    ARG_CHECK(n >= 0 && ld >= b->dim, "bad n / ld");
+    HIP_TRY(hipSetDevice(b->device));
+    int rc = bank_grow(b, b->n + n);
+    if (rc) return rc;
+    return bank_append_launch<float>(b, d_vecs, ld, n, (hipStream_t)stream);
+}
+
+CSLAM_API int cslam_bank_read_host(const cslam_bank_t *b, int64_t row0, int64_t nrows, float *out) {
+    ARG_CHECK(b && (out || nrows == 0), "NULL argument");
+    ARG_CHECK(row0 >= 0 && nrows >= 0 && row0 + nrows <= b->cap, "row range outside the bank");
+    if (nrows == 0) return CSLAM_OK;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy2D(out, (size_t)b->dim * 4, b->rows + row0 * b->ld, (size_t)b->ld * 4,
+                        (size_t)b->dim * 4, (size_t)nrows, hipMemcpyDeviceToHost));
+    return CSLAM_OK;
+}
+
+CSLAM_API int cslam_bank_device_ptr(const cslam_bank_t *b, const float **d_rows, int64_t *ld) {
+    ARG_CHECK(b, "bank is NULL");
+    if (d_rows) *d_rows = b->rows;
+    if (ld) *ld = b->ld;
+    return CSLAM_OK;
+}
+
+// ---------------------------------------------------------------- exact scan ----
+#define SCAN_THREADS 512
+#define SCAN_WAVES 8
+#define LIST_MAX 64
+
+// Query tile in LDS as QS (float or double), [QT][ld]; list merge area after it.
+template <typename QS, int QT, bool Q_IN_LDS>
+__global__ __launch_bounds__(SCAN_THREADS) void scan_exact_kernel(
+    const float *__restrict__ rows, int ld, const double *__restrict__ vv, int64_t n_rows,
+    const QS *__restrict__ q, int64_t ldq, int dim,
+    const int *__restrict__ qsel, int nsel, int sel0,
+    int kk, const int64_t *__restrict__ row_limit,
+    const double *__restrict__ bound_key, const int *__restrict__ bound_idx,
+    double *__restrict__ part_key, int *__restrict__ part_idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    QS *qlds = (QS *)smem;
+    const size_t q_bytes = Q_IN_LDS ? (size_t)QT * ld * sizeof(QS) : 0;
+    double *mkey = (double *)(smem + q_bytes);                                    // [8][QT][64]
+    int *midx = (int *)(smem + q_bytes + (size_t)SCAN_WAVES * QT * LIST_MAX * 8); // [8][QT][64]
+
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int G = gridDim.x;
+    const int tile = blockIdx.y;
+    const int s_base = sel0 + tile * QT;   // first selected-query slot of this tile
+
+    int qn[QT];           // query number (row of q / outputs)
+    bool qvalid[QT];
+    int64_t lim[QT];
+    double bk[QT]; int bi[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        int s = s_base + t;
+        qvalid[t] = s < nsel;
+        qn[t] = qvalid[t] ? (qsel ? qsel[s] : s) : 0;
+        lim[t] = (qvalid[t] && row_limit) ? row_limit[qn[t]] : n_rows;
+        if (lim[t] > n_rows) lim[t] = n_rows;
+        bk[t] = (bound_key && qvalid[t]) ? bound_key[s] : INFINITY;
+        bi[t] = (bound_key && qvalid[t]) ? bound_idx[s] : 0x7fffffff;
+    }
+    if (Q_IN_LDS) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+            for (int c = threadIdx.x; c < ld; c += SCAN_THREADS)
+                qlds[(size_t)t * ld + c] = (qvalid[t] && c < dim) ? q[(size_t)qn[t] * ldq + c] : (QS)0;
+        __syncthreads();
+    }
+    const QS *qp[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) qp[t] = Q_IN_LDS ? (qlds + (size_t)t * ld) : (q + (size_t)qn[t] * ldq);
+
+    // uu = q.q in float64 (per wave, redundantly)
+    double uu[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        double a = 0.0;
+        for (int c = lane; c < dim; c += 64) { double x = (double)qp[t][c]; a += x * x; }
+        uu[t] = wave_allreduce_sum(a);
+    }
+
+    WaveList list[QT];
+    double thr_k[QT]; int thr_i[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) { list[t].init(); thr_k[t] = -INFINITY; thr_i[t] = -1; }
+
+    const int nchunk = ld >> 2;   // float4 chunks per row
+    for (int64_t row = (int64_t)blockIdx.x * SCAN_WAVES + wave; row < n_rows; row += (int64_t)G * SCAN_WAVES) {
+        const float4 *rp = (const float4 *)(rows + row * (int64_t)ld);
+        double acc[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) acc[t] = 0.0;
+#pragma unroll 4
+        for (int c = lane; c < nchunk; c += 64) {
+            float4 b = rp[c];
+            // columns >= dim are zero in the bank, so the (possibly unpadded, global) query
+            // values there are never multiplied by anything but 0 -- but avoid reading them
+            const int col = c * 4;
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                double q0, q1, q2, q3;
+                if (Q_IN_LDS || col + 3 < dim) {
+                    q0 = (double)qp[t][col]; q1 = (double)qp[t][col + 1];
+                    q2 = (double)qp[t][col + 2]; q3 = (double)qp[t][col + 3];
+                } else {
+                    q0 = col < dim ? (double)qp[t][col] : 0.0;
+                    q1 = col + 1 < dim ? (double)qp[t][col + 1] : 0.0;
+                    q2 = col + 2 < dim ? (double)qp[t][col + 2] : 0.0;
+                    q3 = 0.0;
+                }
+                acc[t] += (double)b.x * q0;
+                acc[t] += (double)b.y * q1;
+                acc[t] += (double)b.z * q2;
+                acc[t] += (double)b.w * q3;
+            }
+        }
+        const double vvr = vv[row];
+        const int irow = (int)row;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            double uv = wave_allreduce_sum(acc[t]);
+            if (!qvalid[t] || row >= lim[t]) continue;
+            double key = rank_key(sim_from_dots(uv, uu[t], vvr));
+            if (!ranks_before(bk[t], bi[t], key, irow)) continue;        // already reported in an earlier pass
+            if (!ranks_before(key, irow, thr_k[t], thr_i[t])) continue;  // not in the current top-kk
+            list[t].insert(key, irow, lane);
+            thr_k[t] = list[t].key_at(kk - 1);
+            thr_i[t] = list[t].idx_at(kk - 1);
+        }
+    }
+
+    // block merge: 8 wave lists -> one list per query, written to part_*[slot][block][kk]
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        mkey[(wave * QT + t) * LIST_MAX + lane] = list[t].key;
+        midx[(wave * QT + t) * LIST_MAX + lane] = list[t].idx;
+    }
+    __syncthreads();
+    if (wave < QT && (s_base + wave) < nsel) {
+        const int t = wave;
+        WaveList m; m.init();
+        double tk = -INFINITY; int ti = -1;
+        for (int w = 0; w < SCAN_WAVES; ++w) {
+            for (int pos = 0; pos < kk; ++pos) {
+                double ck = mkey[(w * QT + t) * LIST_MAX + pos];
+                int ci = midx[(w * QT + t) * LIST_MAX + pos];
+                if (ci < 0 || !ranks_before(ck, ci, tk, ti)) break;   // lists are sorted
+                m.insert(ck, ci, lane);
+                tk = m.key_at(kk - 1); ti = m.idx_at(kk - 1);
+            }
+        }
+        if (lane < kk) {
+            size_t o = ((size_t)(tile * QT + t) * G + blockIdx.x) * kk + lane;
+            part_key[o] = m.key;
+            part_idx[o] = m.idx;
+        }
+    }
+}
+
+// One wave per selected query: merge the G per-block lists, write the results.
+__global__ __launch_bounds__(64) void scan_merge_kernel(
+    const double *__restrict__ part_key, const int *__restrict__ part_idx, int G, int kk,
+    const int *__restrict__ qsel, int sel0, int k_total, int k_off,
+    int64_t *__restrict__ out_idx, double *__restrict__ out_sim, int32_t *__restrict__ out_cnt,
+    double *__restrict__ bound_key, int *__restrict__ bound_idx) {
+    const int lane = threadIdx.x;
+    const int slot = blockIdx.x;            // slot within this launch's chunk
+    const int s = sel0 + slot;
+    const int qn = qsel ? qsel[s] : s;
+    const double *pk = part_key + (size_t)slot * G * kk;
+    const int *pi = part_idx + (size_t)slot * G * kk;
+    WaveList m; m.init();
+    double tk = -INFINITY; int ti = -1;
+    const int total = G * kk;
+    for (int base = 0; base < total; base += 64) {
+        int e = base + lane;
+        double ck = e < total ? pk[e] : -INFINITY;
+        int ci = e < total ? pi[e] : -1;
+        unsigned long long mask = __ballot(ci >= 0 && ranks_before(ck, ci, tk, ti));
+        while (mask) {
+            int src = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            double k2 = __shfl(ck, src, 64);
+            int i2 = __shfl(ci, src, 64);
+            if (ranks_before(k2, i2, tk, ti)) {
+                m.insert(k2, i2, lane);
+                tk = m.key_at(kk - 1); ti = m.idx_at(kk - 1);
+            }
+        }
+    }
+    unsigned long long vmask = __ballot(lane < kk && m.idx >= 0);
+    const int cnt = __popcll(vmask);
+    const double lastk = m.key_at(cnt > 0 ? cnt - 1 : 0);
+    const int lasti = m.idx_at(cnt > 0 ? cnt - 1 : 0);
+    if (lane < kk) {
+        size_t o = (size_t)qn * k_total + k_off + lane;
+        out_idx[o] = m.idx >= 0 ? (int64_t)m.idx : -1;
+        out_sim[o] = (m.idx >= 0 && m.key != INFINITY) ? m.key : NAN;
+    }
+    if (lane == 0) {
+        out_cnt[qn] = (k_off == 0 ? 0 : out_cnt[qn]) + cnt;
+        // the next pass (k > 64) reports entries ranking strictly after the last one written here
+        if (bound_key && cnt > 0) { bound_key[s] = lastk; bound_idx[s] = lasti; }
+    }
+}
+
+__global__ void fill_bounds_kernel(double *bk, int *bi, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { bk[i] = INFINITY; bi[i] = 0x7fffffff; }
+}
+
+template <typename QS>
+static int scan_launch(cslam_bank *b, const QS *d_q, int64_t ldq, const int *d_qsel, int nsel, int sel0,
+                       int nchunk, int kk, const int64_t *d_row_limit, const double *bkey, const int *bidx,
+                       double *part_key, int *part_idx, int G, hipStream_t st) {
+    const size_t merge_bytes = (size_t)SCAN_WAVES * LIST_MAX * 12;
+    const size_t lds_budget = 150 * 1024;
+    int qt = 4;
+    if ((size_t)4 * b->ld * sizeof(QS) + 4 * merge_bytes > lds_budget || nchunk == 1) qt = 1;
+    bool in_lds = (size_t)qt * b->ld * sizeof(QS) + qt * merge_bytes <= lds_budget;
+    size_t lds = (in_lds ? (size_t)qt * b->ld * sizeof(QS) : 0) + qt * merge_bytes;
+    dim3 grid((unsigned)G, (unsigned)ceil_div64(nchunk, qt));
+#define SCAN_GO(QT, INL)                                                                              \
+    do {                                                                                              \
+        auto kern = scan_exact_kernel<QS, QT, INL>;                                                   \
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,   \
+                                    (int)lds));                                                       \
+        hipLaunchKernelGGL(kern, grid, dim3(SCAN_THREADS), lds, st, b->rows, b->ld, b->vv, b->n, d_q, \
+                           ldq, b->dim, d_qsel, nsel, sel0, kk, d_row_limit, bkey, bidx, part_key,    \
+                           part_idx);                                                                 \
+    } while (0)
+    if (qt == 4) SCAN_GO(4, true);
+    else if (in_lds) SCAN_GO(1, true);
+    else SCAN_GO(1, false);
+#undef SCAN_GO
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
+int scan_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, const int *d_qsel,
+                int64_t nsel, int k, const int64_t *d_row_limit, int64_t *d_out_idx,
+                double *d_out_sim, int32_t *d_out_cnt, hipStream_t st) {
+    if (nsel == 0) return CSLAM_OK;
+    // grid: enough waves to cover the HBM latency, never more blocks than 8-row groups
+    int G = b->num_cu * 2;
+    int64_t need = ceil_div64(b->n > 0 ? b->n : 1, SCAN_WAVES);
+    if (G > need) G = (int)need;
+    if (G < 1) G = 1;
+    const int CH = 1024;   // selected queries per launch (bounds the partial-list workspace)
+    const int passes = (int)ceil_div64(k, LIST_MAX);
+    size_t part_elems = (size_t)CH * G * LIST_MAX;
+    size_t off_pk = 0, off_pi = off_pk + part_elems * 8, off_bk = off_pi + part_elems * 4;
+    size_t off_bi = off_bk + (size_t)nsel * 8, total = off_bi + (size_t)nsel * 4;
+    int rc = bank_ws_reserve(b, 1, total);
+    if (rc) return rc;
+    double *part_key = (double *)(b->ws[1] + off_pk);
+    int *part_idx = (int *)(b->ws[1] + off_pi);
+    double *bkey = passes > 1 ? (double *)(b->ws[1] + off_bk) : nullptr;
+    int *bidx = passes > 1 ? (int *)(b->ws[1] + off_bi) : nullptr;
+    if (passes > 1) {
+        hipLaunchKernelGGL(fill_bounds_kernel, dim3((unsigned)ceil_div64(nsel, 256)), dim3(256), 0, st, bkey,
+                           bidx, (int)nsel);
+        HIP_TRY(hipGetLastError());
+    }
+    for (int p = 0; p < passes; ++p) {
+        int kk = k - p * LIST_MAX < LIST_MAX ? k - p * LIST_MAX : LIST_MAX;
+        for (int64_t s0 = 0; s0 < nsel; s0 += CH) {
+            int nchunk = (int)(nsel - s0 < CH ? nsel - s0 : CH);
+            if (q_dtype == CSLAM_F32)
+                rc = scan_launch<float>(b, (const float *)d_q, ldq, d_qsel, (int)nsel, (int)s0, nchunk, kk,
+                                        d_row_limit, bkey, bidx, part_key, part_idx, G, st);
+            else
+                rc = scan_launch<double>(b, (const double *)d_q, ldq, d_qsel, (int)nsel, (int)s0, nchunk, kk,
+                                         d_row_limit, bkey, bidx, part_key, part_idx, G, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL(scan_merge_kernel, dim3((unsigned)nchunk), dim3(64), 0, st, part_key, part_idx, G,
+                               kk, d_qsel, (int)s0, k, p * LIST_MAX, d_out_idx, d_out_sim, d_out_cnt, bkey, bidx);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    return CSLAM_OK;
+}
+
+// ------------------------------------------------------------ search entry ----
+CSLAM_API int cslam_bank_search_dev(cslam_bank_t *b, const void *d_queries, int q_dtype, int64_t ldq,
+                                    int64_t nq, int k, const int64_t *d_row_limit, int mode,
+                                    int64_t *d_out_idx, double *d_out_sim, int32_t *d_out_cnt,
+                                    void *stream) {
+    ARG_CHECK(b && (d_queries || nq == 0) && d_out_idx && d_out_sim && d_out_cnt, "NULL argument");
+    ARG_CHECK(q_dtype == CSLAM_F32 || q_dtype == CSLAM_F64, "q_dtype must be CSLAM_F32 or CSLAM_F64");
+    ARG_CHECK(nq >= 0 && k >= 1, "nq must be >= 0 and k >= 1");
+    ARG_CHECK(ldq >= b->dim, "ldq < dim");
+    ARG_CHECK(nq < (1LL << 31) && b->n < (1LL << 31), "nq / bank rows must be < 2^31");
+    HIP_TRY(hipSetDevice(b->device));
+    hipStream_t st = (hipStream_t)stream;
+    b->last_stream = st;
+    b->stats[0] = 0; b->stats[2] = 0; b->stats[3] = 0;
+    if (nq == 0) return CSLAM_OK;
+    int use = mode;
+    if (use == CSLAM_MODE_AUTO) use = (nq <= 8 || k > 8 || b->n < 256) ? CSLAM_MODE_SCAN : CSLAM_MODE_MFMA;
+    if (use == CSLAM_MODE_MFMA && k > 8) use = CSLAM_MODE_SCAN;   // candidate lists hold 16 entries
+    b->stats[1] = use;
+    if (use == CSLAM_MODE_SCAN)
+        return scan_search(b, d_queries, q_dtype, ldq, nullptr, nq, k, d_row_limit, d_out_idx, d_out_sim,
+                           d_out_cnt, st);
+    return mfma_search(b, d_queries, q_dtype, ldq, nq, k, d_row_limit, d_out_idx, d_out_sim, d_out_cnt, st);
+}
+
+CSLAM_API int cslam_bank_search_host(cslam_bank_t *b, const void *queries, int q_dtype, int64_t nq,
+                                     int k, const int64_t *row_limit, int mode,
+                                     int64_t *out_idx, double *out_sim, int32_t *out_cnt) {
+    ARG_CHECK(b && (queries || nq == 0) && out_idx && out_sim && out_cnt, "NULL argument");
+    ARG_CHECK(q_dtype == CSLAM_F32 || q_dtype == CSLAM_F64, "q_dtype must be CSLAM_F32 or CSLAM_F64");
+    ARG_CHECK(nq >= 0 && k >= 1, "nq must be >= 0 and k >= 1");
+    if (nq == 0) return CSLAM_OK;
+    HIP_TRY(hipSetDevice(b->device));
+    const size_t esz = q_dtype == CSLAM_F32 ? 4 : 8;
+    const size_t qb = (size_t)nq * b->dim * esz;
+    const size_t lb = row_limit ? (size_t)nq * 8 : 0;
+    const size_t ib = (size_t)nq * k * 8, sb = (size_t)nq * k * 8, cb = (size_t)nq * 4;
+    char *buf = nullptr;
+    size_t off_q = 0, off_l = round_up64(off_q + qb, 256), off_i = round_up64(off_l + lb, 256);
+    size_t off_s = round_up64(off_i + ib, 256), off_c = round_up64(off_s + sb, 256);
+    size_t total = off_c + cb;
+    HIP_TRY(hipMalloc((void **)&buf, total));
+    int rc = CSLAM_OK;
+    do {
+        if (hipMemcpy(buf + off_q, queries, qb, hipMemcpyHostToDevice) != hipSuccess) { rc = CSLAM_E_HIP; break; }
+        if (row_limit && hipMemcpy(buf + off_l, row_limit, lb, hipMemcpyHostToDevice) != hipSuccess) { rc = CSLAM_E_HIP; break; }
+        rc = cslam_bank_search_dev(b, buf + off_q, q_dtype, b->dim, nq, k,
+                                   row_limit ? (const int64_t *)(buf + off_l) : nullptr, mode,
+                                   (int64_t *)(buf + off_i), (double *)(buf + off_s), (int32_t *)(buf + off_c), 0);
+        if (rc) break;
+        if (hipStreamSynchronize(0) != hipSuccess) { rc = CSLAM_E_HIP; break; }
+        if (hipMemcpy(out_idx, buf + off_i, ib, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(out_sim, buf + off_s, sb, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(out_cnt, buf + off_c, cb, hipMemcpyDeviceToHost) != hipSuccess) { rc = CSLAM_E_HIP; break; }
+    } while (0);
+    if (rc == CSLAM_E_HIP && g_err[0] == 0) cslam_set_error("HIP copy failed: %s", hipGetErrorString(hipGetLastError()));
+    (void)hipFree(buf);
+    return rc;
+}
+
+CSLAM_API int cslam_bank_last_stats(cslam_bank_t *b, int64_t stats[4]) {
+    ARG_CHECK(b && stats, "NULL argument");
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->last_stream));
+    for (int i = 0; i < 4; ++i) stats[i] = b->stats[i];
+    return CSLAM_OK;
+}

@@ -1,0 +1,76 @@
+// Internal helpers shared by the .hip translation units of libcslam_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+#include "../../include/cslam_hip.h"
+
+#define CSLAM_API extern "C" __attribute__((visibility("default")))
+
+void cslam_set_error(const char *fmt, ...);
+
+#define HIP_TRY(expr)                                                              \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess) {                                                    \
+            cslam_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), \
+                            __FILE__, __LINE__);                                   \
+            return CSLAM_E_HIP;                                                    \
+        }                                                                          \
+    } while (0)
+
+#define ARG_CHECK(cond, msg)                  \
+    do {                                      \
+        if (!(cond)) {                        \
+            cslam_set_error("invalid argument: %s", msg); \
+            return CSLAM_E_INVALID;           \
+        }                                     \
+    } while (0)
+
+static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+static inline int64_t ceil_div64(int64_t x, int64_t m) { return (x + m - 1) / m; }
+
+// ---- ranking order shared by every kernel -------------------------------------------
+// rank key of a float64 similarity: NaN ranks first (reference: argsort()[::-1] puts NaN
+// first, cslam/nns_matching.py:60), an empty slot is -inf with index -1.
+__device__ __forceinline__ double rank_key(double sim) { return (sim != sim) ? INFINITY : sim; }
+// "a ranks before b": larger key, ties -> larger row index
+__device__ __forceinline__ bool ranks_before(double ka, int ia, double kb, int ib) {
+    return ka > kb || (ka == kb && ia > ib);
+}
+
+// reference similarity from the three dots (scipy correlation(centered=False) + clip)
+__device__ __forceinline__ double sim_from_dots(double uv, double uu, double vv) {
+    double dist = 1.0 - uv / sqrt(uu * vv);
+    dist = dist < 0.0 ? 0.0 : dist;   // NaN compares false -> propagates
+    dist = dist > 2.0 ? 2.0 : dist;
+    return 1.0 - dist;
+}
+
+// butterfly all-reduce of a double over the 64 lanes; every lane ends with identical bits
+__device__ __forceinline__ double wave_allreduce_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// A sorted list of up to 64 (key, idx) entries held one-per-lane across a wave
+// (lane 0 = best).  Empty entries: key = -inf, idx = -1.
+struct WaveList {
+    double key;
+    int idx;
+    __device__ __forceinline__ void init() { key = -INFINITY; idx = -1; }
+    // wave-uniform candidate (ck, ci); returns nothing, list stays sorted; entry 63 falls out
+    __device__ __forceinline__ void insert(double ck, int ci, int lane) {
+        double pk = __shfl_up(key, 1, 64);
+        int pi = __shfl_up(idx, 1, 64);
+        bool before_me = ranks_before(ck, ci, key, idx);
+        bool before_prev = (lane > 0) && ranks_before(ck, ci, pk, pi);
+        if (before_prev) { key = pk; idx = pi; }
+        else if (before_me) { key = ck; idx = ci; }
+    }
+    __device__ __forceinline__ double key_at(int pos) const { return __shfl(key, pos, 64); }
+    __device__ __forceinline__ int idx_at(int pos) const { return __shfl(idx, pos, 64); }
+};

@@ -1,0 +1,497 @@
+// sim_topk_mfma.hip -- batched all-pairs cosine similarity + top-k on gfx950 matrix cores.
+//
+// Replaces, for a batch of queries, the loop of cslam/nns_matching.py:55-61
+//   for i in range(n): sim[i] = 1 - cosine(query, data[i]);  argsort(sim)[::-1][:k]
+// (and its callers lcsm.py:45-47, 66, 75-76) without ever materialising the
+// nq x n similarity matrix.
+//
+// Stage 1  sim_topk_mfma_kernel   S^T tile = Bank_tile (128 rows) x Query_tile^T (128 queries)
+//          in exact-f32 MFMA (v_mfma_f32_32x32x2_f32), K streamed in 32-float steps through
+//          double-buffered LDS filled by global_load_lds (16 B/lane, XOR-swizzled source so
+//          ds_read_b128 fragment reads are bank-conflict free).  Queries are the MFMA "B"
+//          operand, so a lane's 16 accumulator registers all belong to ONE query: the
+//          running top-16 candidate list of that query lives in that lane's registers and
+//          the epilogue is lane-local (no cross-lane traffic, no score matrix in memory).
+//          One workgroup = one (query tile, bank segment) work item.
+// Stage 2  rescore_kernel         one wave per query: merge the per-segment candidate lists,
+//          re-score the contenders in float64 with the reference formula, order them
+//          exactly, and certify with a rigorous f32 error bound that no row outside the
+//          candidate set can reach the k-th place.  Uncertified queries (never seen on
+//          random data) are re-done by the exact scan kernel (bank.hip).
+#include "bank.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define TM 128          // bank rows per tile
+#define TN 128          // queries per tile
+#define TK 32           // floats per K step
+#define KP 16           // candidate list length per (query, segment)
+#define MF_THREADS 256
+#define STAGE_BYTES (2 * TM * TK * 4)   // A + B tile of one stage = 32 KiB
+
+__device__ __forceinline__ void glds16(const float *g, char *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+struct MfmaArgs {
+    const float *bank; int64_t ldb;      // bank rows, stride in floats
+    const float *invn; int n_rows;
+    const float *q; int64_t ldq; int nq; // f32 queries (rows clamped to nq-1 by the loader)
+    const int *lim;                      // [nqt*TN] visible-row limit per query (0 for padding)
+    const int *qt_maxlim;                // [nqt]
+    int nkt;                             // K steps = ld / 32
+    int nqt, nseg, tps, n_btiles;
+    float *part_key; int *part_idx;      // [nqt*TN][nseg][KP]
+};
+
+__global__ __launch_bounds__(MF_THREADS, 2) void sim_topk_mfma_kernel(MfmaArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    // XCD-aware work-item mapping: the hardware places block b on XCD b % 8; give each XCD a
+    // contiguous run of items so that co-resident blocks share bank segments / query tiles in
+    // that XCD's L2 (speed only; any mapping is correct).
+    const int T = p.nqt * p.nseg;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, j8 = bid >> 3, q8 = T >> 3, r8 = T & 7;
+    const int item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j8;
+    const int qt = item / p.nseg, seg = item - qt * p.nseg;
+
+    int t_beg = seg * p.tps;
+    int t_end = t_beg + p.tps;
+    if (t_end > p.n_btiles) t_end = p.n_btiles;
+    {
+        int ml = p.qt_maxlim[qt];
+        int te = (ml + TM - 1) / TM;
+        if (t_end > te) t_end = te;
+    }
+
+    // per-lane candidate lists for the two query columns this lane owns
+    float lk[2][KP]; int li[2][KP];
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int j = 0; j < KP; ++j) { lk[n][j] = -INFINITY; li[n][j] = -1; }
+    int lim[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) lim[n] = p.lim[qt * TN + wn * 64 + n * 32 + l31];
+
+    const int ntiles = t_end - t_beg;
+    if (ntiles > 0) {
+        // ---- loader addressing: thread handles LDS chunks pch = i*256 + tid, i = 0..3
+        // chunk pch -> tile row pch>>3, physical 16-B slot pch&7 holding logical chunk slot ^ ((row>>1)&7)
+        const float *gB[4];          // query pointers (fixed rows, advance along K)
+        int rowA[4], colc[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int pch = i * 256 + tid;
+            int r = pch >> 3, slot = pch & 7;
+            int c = slot ^ ((r >> 1) & 7);
+            rowA[i] = r; colc[i] = c * 4;
+            int64_t qrow = (int64_t)qt * TN + r;
+            if (qrow > p.nq - 1) qrow = p.nq - 1;
+            gB[i] = p.q + qrow * p.ldq + c * 4;
+        }
+        const int wave_chunk = wave * 64 * 16;   // this wave's 1 KiB slice of each 4 KiB group
+
+        auto stage_load = [&](int stage, int tile, int kt) {
+            char *sA = smem + stage * STAGE_BYTES;
+            char *sB = sA + TM * TK * 4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int64_t brow = (int64_t)tile * TM + rowA[i];
+                if (brow > p.n_rows - 1) brow = p.n_rows - 1;
+                const float *ga = p.bank + brow * p.ldb + (kt * TK + colc[i]);
+                glds16(ga, sA + i * 4096 + wave_chunk);
+                glds16(gB[i] + kt * TK, sB + i * 4096 + wave_chunk);
+            }
+        };
+
+        // ---- fragment read offsets (bytes) within a tile: row*128 + ((2j+h) ^ swz)*16
+        const int swz = (lane >> 1) & 7;
+        int foff[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) foff[j] = (((2 * j + h) ^ swz) << 4);
+        const int arow0 = (wm * 64 + l31) * 128;
+        const int brow0 = (wn * 64 + l31) * 128;
+
+        f32x16 acc[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+        const int total = ntiles * p.nkt;
+        stage_load(0, t_beg, 0);
+        __builtin_amdgcn_s_waitcnt(0);   // vmcnt(0)
+        __syncthreads();
+
+        int tile = t_beg, kt = 0, cur = 0;
+        for (int it = 0; it < total; ++it) {
+            // prefetch the next K step (possibly of the next bank tile) into the other stage
+            int nkt_ = kt + 1, ntile = tile;
+            if (nkt_ == p.nkt) { nkt_ = 0; ntile = tile + 1; }
+            if (it + 1 < total) stage_load(cur ^ 1, ntile, nkt_);
+
+            const char *sA = smem + cur * STAGE_BYTES;
+            const char *sB = sA + TM * TK * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 a0 = *(const f32x4 *)(sA + arow0 + foff[j]);
+                f32x4 a1 = *(const f32x4 *)(sA + arow0 + 32 * 128 + foff[j]);
+                f32x4 b0 = *(const f32x4 *)(sB + brow0 + foff[j]);
+                f32x4 b1 = *(const f32x4 *)(sB + brow0 + 32 * 128 + foff[j]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b1[t], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b0[t], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc[1][1], 0, 0, 0);
+                }
+            }
+
+            if (kt == p.nkt - 1) {
+                // ---- tile epilogue: lane-local candidate update, then clear the accumulators
+                const int row_base = tile * TM + wm * 64 + 4 * h;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    float inv[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        int row = row_base + m * 32 + (r & 3) + 8 * (r >> 2);
+                        inv[r] = p.invn[row < p.n_rows ? row : p.n_rows - 1];
+                    }
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        f32x16 keys;
+                        bool any = false;
+                        const float thr = lk[n][KP - 1];
+                        const int rel_lim = lim[n] - (row_base + m * 32);   // row < lim  <=>  rowoff < rel_lim
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            float kx = acc[m][n][r] * inv[r];
+                            keys[r] = kx;
+                            bool ok = ((r & 3) + 8 * (r >> 2)) < rel_lim;
+                            any |= ok && !(kx <= thr);     // NaN passes (ranks first)
+                            acc[m][n][r] = 0.0f;
+                        }
+                        if (__any(any)) {
+#pragma unroll 1
+                            for (int r = 0; r < 16; ++r) {
+                                float ck = keys[r];        // uniform dynamic index -> s_set_gpr_idx
+                                int roff = (r & 3) + 8 * (r >> 2);
+                                ck = (ck != ck) ? INFINITY : ck;
+                                bool ins = (roff < rel_lim) && (ck > lk[n][KP - 1]);
+                                if (__any(ins)) {
+                                    ck = ins ? ck : -INFINITY;
+                                    int ci = row_base + m * 32 + roff;
+#pragma unroll
+                                    for (int j = 0; j < KP; ++j) {
+                                        bool sw = ck > lk[n][j];
+                                        float tk = sw ? lk[n][j] : ck;
+                                        int ti = sw ? li[n][j] : ci;
+                                        lk[n][j] = sw ? ck : lk[n][j];
+                                        li[n][j] = sw ? ci : li[n][j];
+                                        ck = tk; ci = ti;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+
+            __builtin_amdgcn_s_waitcnt(0);   // next stage landed (vmcnt(0))
+            __syncthreads();
+            cur ^= 1;
+            kt = nkt_; tile = ntile;
+        }
+    }
+
+    // ---- block merge: 4 lists per query (2 row-halves of the wave x 2 waves along M) -> 1
+    __syncthreads();
+    float *mk = (float *)smem;                       // [TN][4][KP]
+    int *mi = (int *)(smem + TN * 4 * KP * 4);       // [TN][4][KP]
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        int qcol = wn * 64 + n * 32 + l31;
+        int src = wm * 2 + h;
+#pragma unroll
+        for (int j = 0; j < KP; ++j) {
+            mk[(qcol * 4 + src) * KP + j] = lk[n][j];
+            mi[(qcol * 4 + src) * KP + j] = li[n][j];
+        }
+    }
+    __syncthreads();
+    if (tid < TN) {
+        const float *k0 = mk + (tid * 4) * KP;
+        const int *i0 = mi + (tid * 4) * KP;
+        int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+        size_t o = ((size_t)(qt * TN + tid) * p.nseg + seg) * KP;
+        for (int j = 0; j < KP; ++j) {
+            float c0 = p0 < KP ? k0[p0] : -INFINITY;
+            float c1 = p1 < KP ? k0[KP + p1] : -INFINITY;
+            float c2 = p2 < KP ? k0[2 * KP + p2] : -INFINITY;
+            float c3 = p3 < KP ? k0[3 * KP + p3] : -INFINITY;
+            int best = 0; float bk = c0;
+            if (c1 > bk) { bk = c1; best = 1; }
+            if (c2 > bk) { bk = c2; best = 2; }
+            if (c3 > bk) { bk = c3; best = 3; }
+            int bi;
+            if (best == 0) { bi = p0 < KP ? i0[p0] : -1; ++p0; }
+            else if (best == 1) { bi = i0[KP + p1]; ++p1; }
+            else if (best == 2) { bi = i0[2 * KP + p2]; ++p2; }
+            else { bi = i0[3 * KP + p3]; ++p3; }
+            p.part_key[o + j] = bk;
+            p.part_idx[o + j] = (bk == -INFINITY) ? -1 : bi;
+        }
+    }
+}
+
+// ---- query preparation: float32 padded copy, per-query row limits, per-tile max limit ----
+template <typename QS>
+__global__ void mfma_prep_kernel(const QS *__restrict__ q, int64_t ldq, int nq, int dim, int ld,
+                                 float *__restrict__ q32, const int64_t *__restrict__ row_limit,
+                                 int n_rows, int *__restrict__ lim, int *__restrict__ qt_maxlim, int nq_pad) {
+    const int row = blockIdx.x;
+    if (row >= nq_pad) return;
+    if (q32) {
+        for (int c = threadIdx.x; c < ld; c += blockDim.x)
+            q32[(size_t)row * ld + c] = (row < nq && c < dim) ? (float)q[(size_t)row * ldq + c] : 0.0f;
+    }
+    if (threadIdx.x == 0) {
+        int l = 0;
+        if (row < nq) {
+            int64_t v = row_limit ? row_limit[row] : n_rows;
+            if (v > n_rows) v = n_rows;
+            if (v < 0) v = 0;
+            l = (int)v;
+        }
+        lim[row] = l;
+        atomicMax(&qt_maxlim[row / TN], l);
+    }
+}
+
+// ---- stage 2: merge, float64 re-score, exact order, certificate ---------------------------
+template <typename QS>
+__global__ __launch_bounds__(256) void rescore_kernel(
+    const float *__restrict__ bank, int ld, const double *__restrict__ vv,
+    const QS *__restrict__ q, int64_t ldq, int dim, int nq,
+    const float *__restrict__ part_key, const int *__restrict__ part_idx, int nseg,
+    int k, double err_bound,
+    int64_t *__restrict__ out_idx, double *__restrict__ out_sim, int32_t *__restrict__ out_cnt,
+    int *__restrict__ flag_list, int *__restrict__ flag_count) {
+    const int lane = threadIdx.x & 63;
+    const int qn = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (qn >= nq) return;
+    const QS *qp = q + (size_t)qn * ldq;
+
+    // uu = q.q (float64)
+    double uu = 0.0;
+    for (int c = lane; c < dim; c += 64) { double x = (double)qp[c]; uu += x * x; }
+    uu = wave_allreduce_sum(uu);
+    const double qnorm = sqrt(uu);
+
+    // 1. merge the per-segment lists by f32 key; track the bound t32 on every row NOT kept
+    WaveList cand; cand.init();
+    double t32 = -INFINITY;
+    const float *pk = part_key + (size_t)qn * nseg * KP;
+    const int *pi = part_idx + (size_t)qn * nseg * KP;
+    const int total = nseg * KP;
+    for (int base = 0; base < total; base += 64) {
+        int e = base + lane;
+        double ck = e < total ? (double)pk[e] : -INFINITY;
+        int ci = e < total ? pi[e] : -1;
+        // a full segment list may have dropped rows no better than its last entry
+        bool seg_last_full = (e < total) && ((e % KP) == KP - 1) && ci >= 0;
+        double tl = seg_last_full ? ck : -INFINITY;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { double o = __shfl_xor(tl, off, 64); tl = o > tl ? o : tl; }
+        t32 = tl > t32 ? tl : t32;
+        unsigned long long mask = __ballot(ci >= 0);
+        while (mask) {
+            int src = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            double k2 = __shfl(ck, src, 64);
+            int i2 = __shfl(ci, src, 64);
+            // entries falling off the 64-entry list are bounded by its last key (tracked below)
+            double lastk = cand.key_at(63);
+            int lasti = cand.idx_at(63);
+            if (lasti >= 0 && ranks_before(k2, i2, lastk, lasti)) t32 = lastk > t32 ? lastk : t32;
+            else if (lasti >= 0) { t32 = k2 > t32 ? k2 : t32; continue; }
+            cand.insert(k2, i2, lane);
+        }
+    }
+    unsigned long long cmask = __ballot(cand.idx >= 0);
+    const int ncand = __popcll(cmask);
+    // contenders: the first KP candidates whose f32 key is within 2e of the k-th f32 key
+    const double e_abs = err_bound * qnorm;                 // error bound in key units (dot / ||b||)
+    const int kth = (k - 1 < ncand - 1) ? k - 1 : ncand - 1;
+    const double ck_k = ncand > 0 ? cand.key_at(kth > 0 ? kth : 0) : -INFINITY;
+    int nres = 0;
+    {
+        bool want = cand.idx >= 0 && lane < KP && (cand.key >= ck_k - 2.0 * e_abs || !(e_abs == e_abs));
+        unsigned long long wm_ = __ballot(want);
+        nres = __popcll(wm_);            // candidates are sorted, so `want` lanes are a prefix
+        if (nres < ncand) {              // everything after the prefix is treated as "not kept"
+            double nk = cand.key_at(nres);
+            t32 = nk > t32 ? nk : t32;
+        }
+    }
+
+    // 2. exact float64 scores of the contenders, exact order
+    WaveList ex; ex.init();
+    const int nchunk = ld >> 2;
+    for (int c0 = 0; c0 < nres; ++c0) {
+        const int row = cand.idx_at(c0);
+        const float4 *rp = (const float4 *)(bank + (size_t)row * ld);
+        double acc = 0.0;
+#pragma unroll 4
+        for (int c = lane; c < nchunk; c += 64) {
+            float4 b = rp[c];
+            const int col = c * 4;
+            double q0 = col < dim ? (double)qp[col] : 0.0;
+            double q1 = col + 1 < dim ? (double)qp[col + 1] : 0.0;
+            double q2 = col + 2 < dim ? (double)qp[col + 2] : 0.0;
+            double q3 = col + 3 < dim ? (double)qp[col + 3] : 0.0;
+            acc += (double)b.x * q0;
+            acc += (double)b.y * q1;
+            acc += (double)b.z * q2;
+            acc += (double)b.w * q3;
+        }
+        double uv = wave_allreduce_sum(acc);
+        double key = rank_key(sim_from_dots(uv, uu, vv[row]));
+        ex.insert(key, row, lane);
+    }
+
+    // 3. certificate: every row outside the contenders has f32 key <= t32, hence exact
+    //    normalised score <= t32/||q|| + err_bound; the k-th exact score must beat that.
+    const int nout = k < nres ? k : nres;
+    bool certified;
+    if (t32 == -INFINITY) certified = true;                       // nothing was left out
+    else if (nres < k) certified = false;
+    else {
+        // sim = clamp(ratio, -1, 1) is monotone in ratio; rows left out have ratio <= bound
+        double xk = ex.key_at(k - 1);
+        double bound = t32 / qnorm + err_bound;
+        if (bound < -1.0) bound = -1.0;
+        certified = xk > bound;                                   // false when anything is NaN
+    }
+
+    if (lane < k) {
+        size_t o = (size_t)qn * k + lane;
+        bool v = lane < nout && ex.idx >= 0;
+        out_idx[o] = v ? (int64_t)ex.idx : -1;
+        out_sim[o] = (v && ex.key != INFINITY) ? ex.key : NAN;
+    }
+    if (lane == 0) {
+        out_cnt[qn] = nout;
+        if (!certified) { int s = atomicAdd(flag_count, 1); flag_list[s] = qn; }
+    }
+}
+
+int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_t nq, int k,
+                const int64_t *d_row_limit, int64_t *d_out_idx, double *d_out_sim,
+                int32_t *d_out_cnt, hipStream_t st) {
+    const int ld = b->ld;
+    const int nqt = (int)ceil_div64(nq, TN);
+    const int nq_pad = nqt * TN;
+    const int n_btiles = (int)ceil_div64(b->n, TM);
+    int nseg = (int)ceil_div64(8 * 2 * b->num_cu, nqt);
+    int max_seg = n_btiles / 4; if (max_seg < 1) max_seg = 1;
+    if (nseg > max_seg) nseg = max_seg;
+    if (nseg < 1) nseg = 1;
+    const int tps = (int)ceil_div64(n_btiles, nseg);
+    nseg = (int)ceil_div64(n_btiles, tps);
+
+    const bool direct = q_dtype == CSLAM_F32 && b->dim == ld && (ldq % 4 == 0) && (((uintptr_t)d_q) % 16 == 0);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = (size_t)round_up64((int64_t)(off + bytes), 256); return o; };
+    size_t o_q32 = carve(direct ? 0 : (size_t)nq_pad * ld * 4);
+    size_t o_lim = carve((size_t)nq_pad * 4);
+    size_t o_qtm = carve((size_t)nqt * 4);
+    size_t o_pk = carve((size_t)nq_pad * nseg * KP * 4);
+    size_t o_pi = carve((size_t)nq_pad * nseg * KP * 4);
+    size_t o_fl = carve((size_t)nq * 4);
+    size_t o_fc = carve(256);
+    int rc = bank_ws_reserve(b, 0, off);
+    if (rc) return rc;
+    char *ws = b->ws[0];
+    float *q32 = direct ? nullptr : (float *)(ws + o_q32);
+    int *lim = (int *)(ws + o_lim);
+    int *qtm = (int *)(ws + o_qtm);
+    float *part_key = (float *)(ws + o_pk);
+    int *part_idx = (int *)(ws + o_pi);
+    int *flag_list = (int *)(ws + o_fl);
+    int *flag_count = (int *)(ws + o_fc);
+
+    HIP_TRY(hipMemsetAsync(qtm, 0, (size_t)nqt * 4, st));
+    HIP_TRY(hipMemsetAsync(flag_count, 0, 4, st));
+    if (q_dtype == CSLAM_F32)
+        hipLaunchKernelGGL(mfma_prep_kernel<float>, dim3(nq_pad), dim3(256), 0, st, (const float *)d_q, ldq,
+                           (int)nq, b->dim, ld, q32, d_row_limit, (int)b->n, lim, qtm, nq_pad);
+    else
+        hipLaunchKernelGGL(mfma_prep_kernel<double>, dim3(nq_pad), dim3(256), 0, st, (const double *)d_q, ldq,
+                           (int)nq, b->dim, ld, q32, d_row_limit, (int)b->n, lim, qtm, nq_pad);
+    HIP_TRY(hipGetLastError());
+
+    MfmaArgs a;
+    a.bank = b->rows; a.ldb = ld; a.invn = b->invn; a.n_rows = (int)b->n;
+    a.q = direct ? (const float *)d_q : q32; a.ldq = direct ? ldq : ld; a.nq = direct ? (int)nq : nq_pad;
+    a.lim = lim; a.qt_maxlim = qtm; a.nkt = ld / TK;
+    a.nqt = nqt; a.nseg = nseg; a.tps = tps; a.n_btiles = n_btiles;
+    a.part_key = part_key; a.part_idx = part_idx;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
+        attr_set = true;
+    }
+    if (b->ev_valid) HIP_TRY(hipEventRecord(b->ev0, st));
+    hipLaunchKernelGGL(sim_topk_mfma_kernel, dim3(nqt * nseg), dim3(MF_THREADS), 2 * STAGE_BYTES, st, a);
+    HIP_TRY(hipGetLastError());
+    if (b->ev_valid) HIP_TRY(hipEventRecord(b->ev1, st));
+
+    // rigorous bound on |f32 key - exact| / ||q||: ld-term fma chain (gamma_ld), inv-norm
+    // rounding, key multiply rounding, query f64->f32 rounding; 2^-24 unit roundoff.
+    const double u = 5.9604644775390625e-08;
+    const double err_bound = 1.0625 * ((double)ld + 8.0) * u;
+    const unsigned rgrid = (unsigned)ceil_div64(nq, 4);
+    if (q_dtype == CSLAM_F32)
+        hipLaunchKernelGGL(rescore_kernel<float>, dim3(rgrid), dim3(256), 0, st, b->rows, ld, b->vv,
+                           (const float *)d_q, ldq, b->dim, (int)nq, part_key, part_idx, nseg, k, err_bound,
+                           d_out_idx, d_out_sim, d_out_cnt, flag_list, flag_count);
+    else
+        hipLaunchKernelGGL(rescore_kernel<double>, dim3(rgrid), dim3(256), 0, st, b->rows, ld, b->vv,
+                           (const double *)d_q, ldq, b->dim, (int)nq, part_key, part_idx, nseg, k, err_bound,
+                           d_out_idx, d_out_sim, d_out_cnt, flag_list, flag_count);
+    HIP_TRY(hipGetLastError());
+
+    // uncertified queries -> exact scan (needs the count on the host: one 4-byte readback)
+    int nflag = 0;
+    HIP_TRY(hipMemcpyAsync(&nflag, flag_count, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    b->stats[0] = nflag; b->stats[2] = nseg; b->stats[3] = nqt;
+    if (nflag > 0)
+        return scan_search(b, d_q, q_dtype, ldq, flag_list, nflag, k, d_row_limit, d_out_idx, d_out_sim,
+                           d_out_cnt, st);
+    return CSLAM_OK;
+}
+
+CSLAM_API int cslam_bank_last_kernel_ms(cslam_bank_t *b, float *ms) {
+    ARG_CHECK(b && ms, "NULL argument");
+    *ms = -1.0f;
+    if (!b->ev_valid || b->stats[1] != CSLAM_MODE_MFMA) return CSLAM_OK;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipEventSynchronize(b->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, b->ev0, b->ev1));
+    return CSLAM_OK;
+}

@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""Nearest-neighbour matching of global descriptors on an MI355X.
+
+Drop-in for the reference class of the same name (cslam/nns_matching.py:7-76):
+same constructor, `add_item`, `search`, `search_best`, and the public attributes
+`n`, `dim`, `items`, `data` the reference's callers and tests touch.  The bank
+lives in HBM behind libcslam_hip.so; scores are computed by hand-written HIP
+kernels (exact float64 scan for single queries, fp32-MFMA candidates + float64
+re-score for batches).  There is no CPU path: without the library or a GPU every
+call raises `CslamHipError`.
+
+Batch / device-resident extensions (not in the reference; used by the batched
+callers in this package and by bench.py): `add_items`, `search_batch`,
+`add_items_device`, `search_device`.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import CslamHipError, MODE_AUTO, MODE_MFMA, MODE_SCAN  # noqa: F401
+
+
+def _as_query_array(q):
+    q = np.asarray(q)
+    if q.dtype == np.float32:
+        return np.ascontiguousarray(q), _lib.F32
+    return np.ascontiguousarray(q, dtype=np.float64), _lib.F64
+
+
+class NearestNeighborsMatching(object):
+    """Nearest Neighbor matching of description vectors (HBM-resident bank)."""
+
+    def __init__(self, dim=None, device=0):
+        """Initialization
+
+        Args:
+            dim (int, optional): Global descriptor size. Defaults to None
+                (inferred from the first vector, cslam/nns_matching.py:32-34).
+            device (int): HIP device ordinal holding the bank.
+        """
+        self.n = 0
+        self.dim = dim
+        self.items = dict()
+        self.device = device
+        self._bank = None
+        self._lib = None
+        if dim is not None:
+            self._create(dim)
+
+    # ------------------------------------------------------------- plumbing ----
+    def _create(self, dim):
+        _lib.require_gpu()
+        self._lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self._lib.cslam_bank_create(self.device, int(dim), 1000, C.byref(h)))
+        self._bank = h
+        self.dim = int(dim)
+
+    def __del__(self):
+        try:
+            if self._bank is not None and self._lib is not None:
+                self._lib.cslam_bank_destroy(self._bank)
+                self._bank = None
+        except Exception:
+            pass
+
+    @property
+    def data(self):
+        """Host copy of the bank storage, shape (capacity, dim) float32, zeros past `n`
+        (the reference's public array, cslam/nns_matching.py:21; [] before the first add)."""
+        if self._bank is None:
+            return []
+        cap = 1000
+        while cap < self.n:
+            cap *= 2
+        out = np.zeros((cap, self.dim), dtype=np.float32)
+        if self.n:
+            _lib.check(self._lib.cslam_bank_read_host(self._bank, 0, self.n, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    # ------------------------------------------------------- reference API ----
+    def add_item(self, vector, item):
+        """Add item to the matching list (cslam/nns_matching.py:23-40)
+
+        Args:
+            vector (np.array): descriptor
+            item: identification info (e.g., int)
+        """
+        vector = np.asarray(vector)
+        assert vector.ndim == 1
+        if self._bank is None:
+            self._create(len(vector))
+        if len(vector) != self.dim:
+            raise ValueError(f"could not broadcast input array from shape ({len(vector)},) "
+                             f"into shape ({self.dim},)")
+        v, dt = _as_query_array(vector)
+        _lib.check(self._lib.cslam_bank_add_host(self._bank, v.ctypes.data_as(C.c_void_p), dt, 1))
+        self.items[self.n] = item
+        self.n += 1
+
+    def search(self, query, k):
+        """Search for nearest neighbors (cslam/nns_matching.py:42-61)
+
+        Args:
+            query (np.array): descriptor to match
+            k (int): number of best matches to return
+
+        Returns:
+            list(int, np.array): best matches
+        """
+        if self._bank is None:
+            return [], []
+        query = np.asarray(query)
+        if query.ndim != 1 or len(query) != self.dim:
+            raise ValueError(f"shapes ({query.shape}) and ({self.dim},) not aligned")
+        if self.n == 0 or k <= 0:
+            return [], np.zeros(0)
+        idx, sims, cnt = self.search_batch(query[None, :], k)
+        c = int(cnt[0])
+        return [self.items[int(r)] for r in idx[0, :c]], sims[0, :c].copy()
+
+    def search_best(self, query):
+        """Search for the nearest neighbor (cslam/nns_matching.py:63-76)
+
+        Returns:
+            int, np.array: best match
+        """
+        if self._bank is None:
+            return None, None
+        items, similarities = self.search(query, 1)
+        return items[0], similarities[0]
+
+    # ---------------------------------------------------------- extensions ----
+    def add_items(self, vectors, items):
+        """Append many descriptors at once: vectors [m, dim], items iterable of m ids."""
+        vectors = np.asarray(vectors)
+        assert vectors.ndim == 2
+        items = list(items)
+        assert len(items) == vectors.shape[0]
+        if vectors.shape[0] == 0:
+            return
+        if self._bank is None:
+            self._create(vectors.shape[1])
+        if vectors.shape[1] != self.dim:
+            raise ValueError("descriptor dimension mismatch")
+        v, dt = _as_query_array(vectors)
+        _lib.check(self._lib.cslam_bank_add_host(self._bank, v.ctypes.data_as(C.c_void_p), dt, v.shape[0]))
+        for it in items:
+            self.items[self.n] = it
+            self.n += 1
+
+    def search_batch(self, queries, k, row_limit=None, mode=MODE_AUTO):
+        """Top-k of every query row against the bank.
+
+        row_limit: optional int64 [nq]; query j only sees bank rows < row_limit[j]
+        (the causal order of global_descriptor_loop_closure_detection.py:157-160).
+        Returns (rows [nq,k] int64 (-1 padded), sims [nq,k] float64 (NaN padded), cnt [nq] int32).
+        """
+        if self._bank is None:
+            raise CslamHipError("search_batch on a bank that was never populated")
+        q, dt = _as_query_array(queries)
+        assert q.ndim == 2 and q.shape[1] == self.dim
+        nq = q.shape[0]
+        k = int(k)
+        idx = np.full((nq, k), -1, dtype=np.int64)
+        sims = np.full((nq, k), np.nan, dtype=np.float64)
+        cnt = np.zeros(nq, dtype=np.int32)
+        lim_p = None
+        if row_limit is not None:
+            lim = np.ascontiguousarray(row_limit, dtype=np.int64)
+            assert lim.shape == (nq,)
+            lim_p = lim.ctypes.data_as(C.c_void_p)
+        _lib.check(self._lib.cslam_bank_search_host(
+            self._bank, q.ctypes.data_as(C.c_void_p), dt, nq, k, lim_p, int(mode),
+            idx.ctypes.data_as(C.c_void_p), sims.ctypes.data_as(C.c_void_p),
+            cnt.ctypes.data_as(C.c_void_p)))
+        return idx, sims, cnt
+
+    def add_items_device(self, vectors, items=None):
+        """Append float32 descriptors that already live in HBM (torch tensor [m, >=dim])."""
+        import torch
+        assert vectors.is_cuda and vectors.dtype == torch.float32 and vectors.dim() == 2
+        assert vectors.stride(1) == 1
+        m = vectors.shape[0]
+        if self._bank is None:
+            self.device = vectors.device.index or 0
+            self._create(vectors.shape[1])
+        st = torch.cuda.current_stream(vectors.device).cuda_stream
+        _lib.check(self._lib.cslam_bank_add_dev(self._bank, C.c_void_p(vectors.data_ptr()),
+                                                vectors.stride(0), m, C.c_void_p(st)))
+        items = range(self.n, self.n + m) if items is None else list(items)
+        for it in items:
+            self.items[self.n] = it
+            self.n += 1
+
+    def search_device(self, queries, k, row_limit=None, mode=MODE_AUTO, out=None):
+        """Device-resident search: queries torch [nq, dim] float32/float64 on the bank's GPU.
+        Returns torch tensors (rows int64 [nq,k], sims float64 [nq,k], cnt int32 [nq])."""
+        import torch
+        assert queries.is_cuda and queries.dim() == 2 and queries.stride(1) == 1
+        dt = _lib.F32 if queries.dtype == torch.float32 else _lib.F64
+        assert queries.dtype in (torch.float32, torch.float64)
+        nq = queries.shape[0]
+        if out is None:
+            out = (torch.empty((nq, k), dtype=torch.int64, device=queries.device),
+                   torch.empty((nq, k), dtype=torch.float64, device=queries.device),
+                   torch.empty((nq,), dtype=torch.int32, device=queries.device))
+        lim_p = None
+        if row_limit is not None:
+            assert row_limit.is_cuda and row_limit.dtype == torch.int64 and row_limit.is_contiguous()
+            lim_p = C.c_void_p(row_limit.data_ptr())
+        st = torch.cuda.current_stream(queries.device).cuda_stream
+        _lib.check(self._lib.cslam_bank_search_dev(
+            self._bank, C.c_void_p(queries.data_ptr()), dt, queries.stride(0), nq, int(k), lim_p,
+            int(mode), C.c_void_p(out[0].data_ptr()), C.c_void_p(out[1].data_ptr()),
+            C.c_void_p(out[2].data_ptr()), C.c_void_p(st)))
+        return out
+
+    def last_stats(self):
+        """(uncertified queries re-done by the scan, mode used, bank segments, query tiles)."""
+        s = (C.c_int64 * 4)()
+        _lib.check(self._lib.cslam_bank_last_stats(self._bank, C.byref(s)))
+        return tuple(int(x) for x in s)
+
+    def last_kernel_ms(self):
+        ms = C.c_float(-1.0)
+        _lib.check(self._lib.cslam_bank_last_kernel_ms(self._bank, C.byref(ms)))
+        return float(ms.value)

@@ -1,0 +1,142 @@
+/*
+ * cslam_hip.h -- C ABI of libcslam_hip.so, the MI355X (gfx950) implementation of
+ * cslam's global-descriptor loop-closure hot path.
+ *
+ * The reference (lajoiepy/cslam) has no FFI for this path: it is duck-typed Python
+ * (SURVEY.md section 8b).  Each entry point below therefore names the reference
+ * Python function whose arithmetic it replaces; the Python classes in cslam_amd/
+ * keep the reference signatures and call these through ctypes.
+ *
+ * Conventions
+ *   - every function returns 0 (CSLAM_OK) or a negative CSLAM_E_* code;
+ *     cslam_last_error() returns a thread-local message for the last failure;
+ *   - plain pointers and sizes only; no torch / numpy types;
+ *   - "_host" entry points take host pointers and synchronise before returning;
+ *     "_dev" entry points take device pointers, enqueue on `stream`
+ *     (a hipStream_t passed as void*, NULL = default stream) and do not synchronise;
+ *   - bank rows are float32 (reference storage dtype, cslam/nns_matching.py:21,39);
+ *     queries are float32 (CSLAM_F32) or float64 (CSLAM_F64);
+ *   - row indices are int64 in the API (bank row number = order of insertion,
+ *     the key of the reference's `items` dict, cslam/nns_matching.py:38).
+ */
+#ifndef CSLAM_HIP_H
+#define CSLAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSLAM_OK 0
+#define CSLAM_E_INVALID (-1)  /* bad argument */
+#define CSLAM_E_HIP (-2)      /* HIP runtime error (message in cslam_last_error) */
+#define CSLAM_E_NOMEM (-3)
+#define CSLAM_E_DIM (-4)      /* descriptor dimension mismatch */
+
+#define CSLAM_F32 0
+#define CSLAM_F64 1
+
+/* search strategy (cslam_bank_search_*: `mode`) */
+#define CSLAM_MODE_AUTO 0  /* scan for small nq, MFMA for batches */
+#define CSLAM_MODE_SCAN 1  /* HBM-bound exact fp64 scan kernel */
+#define CSLAM_MODE_MFMA 2  /* fp32-MFMA candidates + fp64 re-score + certificate (+ scan fallback) */
+
+typedef struct cslam_bank cslam_bank_t;
+
+const char *cslam_last_error(void);
+int cslam_version(void);
+int cslam_device_count(int *count);
+int cslam_device_info(int device, char *name, int name_len, int64_t *hbm_bytes, int *cu_count);
+
+/* ---- descriptor bank: NearestNeighborsMatching.__init__/add_item ----------
+ * replaces cslam/nns_matching.py:10-40 (growable float32 bank, amortised doubling).
+ * The bank lives in HBM on `device`; rows are padded to a multiple of 32 floats.   */
+int cslam_bank_create(int device, int dim, int64_t capacity_hint, cslam_bank_t **out);
+int cslam_bank_destroy(cslam_bank_t *bank);
+int cslam_bank_size(const cslam_bank_t *bank, int64_t *n, int *dim);
+int cslam_bank_clear(cslam_bank_t *bank);
+/* append n rows given on the host; dtype CSLAM_F32 or CSLAM_F64 (values are cast to
+ * float32 on store exactly like `self.data[self.n] = vector`, nns_matching.py:39). */
+int cslam_bank_add_host(cslam_bank_t *bank, const void *vecs, int dtype, int64_t n);
+/* append n float32 rows already in device memory, row stride `ld` floats */
+int cslam_bank_add_dev(cslam_bank_t *bank, const float *d_vecs, int64_t ld, int64_t n, void *stream);
+/* copy rows [row0, row0+nrows) back to the host, dense [nrows, dim] float32
+ * (backs the reference's public `.data` attribute, tests/test_sparse_matching.py:36) */
+int cslam_bank_read_host(const cslam_bank_t *bank, int64_t row0, int64_t nrows, float *out);
+/* raw device views (row stride in floats); valid until the next add that grows the bank */
+int cslam_bank_device_ptr(const cslam_bank_t *bank, const float **d_rows, int64_t *ld);
+
+/* ---- search: NearestNeighborsMatching.search / search_best -----------------
+ * replaces cslam/nns_matching.py:42-76:
+ *     sim[i] = 1 - clip(1 - q.b_i / sqrt((q.q)(b_i.b_i)), 0, 2)   for i < limit
+ *     order  = descending sim (NaN first), ties -> larger row index
+ * row_limit: NULL, or [nq] int64: query j only sees rows < row_limit[j] (the causal
+ *     order of global_descriptor_loop_closure_detection.py:157-160).
+ * out_idx [nq,k] int64 (-1 padded), out_sim [nq,k] float64 (NaN padded),
+ * out_cnt [nq] int32 = min(k, rows visible).
+ * Scores are computed in float64 from the float32 bank / given-dtype query; the
+ * returned order is the exact order of those float64 scores in every mode.       */
+int cslam_bank_search_host(cslam_bank_t *bank, const void *queries, int q_dtype, int64_t nq,
+                           int k, const int64_t *row_limit, int mode,
+                           int64_t *out_idx, double *out_sim, int32_t *out_cnt);
+/* device-pointer variant: d_queries [nq, ldq] (ldq in elements), outputs device arrays */
+int cslam_bank_search_dev(cslam_bank_t *bank, const void *d_queries, int q_dtype, int64_t ldq,
+                          int64_t nq, int k, const int64_t *d_row_limit, int mode,
+                          int64_t *d_out_idx, double *d_out_sim, int32_t *d_out_cnt,
+                          void *stream);
+/* statistics of the last search on this bank (for tests / bench):
+ * stats[0] = queries that failed the fp32 certificate and were re-done by the scan,
+ * stats[1] = mode actually used (CSLAM_MODE_*), stats[2] = bank segments,
+ * stats[3] = query tiles.  Synchronises the bank's last stream.                    */
+int cslam_bank_last_stats(cslam_bank_t *bank, int64_t stats[4]);
+/* time (ms, HIP events on the launch stream) of the dominant kernel of the last
+ * MFMA-mode search: sim_topk_mfma.  -1 if the last search did not use it.        */
+int cslam_bank_last_kernel_ms(cslam_bank_t *bank, float *ms);
+
+/* ---- descriptor heads (device pointers; all float32) -------------------------- */
+/* rows of x [n, d] (stride ld) scaled to unit L2 norm, x / max(||x||, eps);
+ * F.normalize(p=2) of cslam/vpr/cosplace_utils/layers.py:32-36, netvlad.py:105-106,126-128;
+ * eps = 1e-12 (torch default).  zero_norm_to_one != 0 gives sklearn.preprocessing.normalize
+ * semantics instead (zero rows stay zero; netvlad.py:235-236). */
+int cslam_l2_normalize_dev(float *d_x, int64_t n, int d, int64_t ld, float eps,
+                           int zero_norm_to_one, void *stream);
+/* NetVLADLayer.forward, cslam/vpr/netvlad.py:94-130.
+ * feat [B, C, P] (NCHW flattened), assign_w [K, C] (1x1 conv, no bias: vladv1),
+ * assign_b [K] or NULL, centroids [K, C]; out [B, K*C]. */
+int cslam_vlad_aggregate_dev(const float *d_feat, const float *d_assign_w, const float *d_assign_b,
+                             const float *d_centroids, int B, int C, int P, int K,
+                             float *d_out, void *stream);
+/* CosPlace aggregation head, cslam/vpr/cosplace_utils/network.py:23-29 + layers.py:8-36:
+ * L2Norm(C) -> GeM(p, eps) -> Flatten -> Linear(W [Dout, C], b [Dout]) -> L2Norm.
+ * feat [B, C, P]; out [B, Dout]. */
+int cslam_gem_fc_head_dev(const float *d_feat, float p, float eps, const float *d_W,
+                          const float *d_b, int B, int C, int P, int Dout,
+                          float *d_out, void *stream);
+/* PCA projection + row L2, cslam/vpr/netvlad.py:234-236 (sklearn PCA.transform + normalize):
+ * out = normalize(((x - mean) @ comp^T) * scale) with comp [Dout, Din], mean [Din] or NULL,
+ * scale [Dout] or NULL (1/sqrt(explained_variance) when whitening). x [B, Din], out [B, Dout]. */
+int cslam_pca_project_dev(const float *d_x, const float *d_comp, const float *d_mean,
+                          const float *d_scale, int B, int Din, int Dout, float *d_out,
+                          void *stream);
+/* image transform, cslam/vpr/netvlad.py:202-208 / cosplace.py:73-79:
+ * CenterCrop(crop) -> Resize(out_hw, PIL bicubic, antialiased, 8-bit intermediate) ->
+ * ToTensor (/255, HWC->CHW) -> Normalize(mean, std).
+ * img [B, H, W, 3] uint8 RGB; out [B, 3, out_hw, out_hw] float32. */
+int cslam_preprocess_dev(const uint8_t *d_img, int B, int H, int W, int crop, int out_hw,
+                         const float mean[3], const float std_[3], float *d_out, void *stream);
+
+/* ---- candidate sparsifier pieces (cslam/mac/mac.py) --------------------------- */
+/* grad_from_fiedler, mac.py:112-130: g[k] = w[k] * (v[i_k] - v[j_k])^2, float64 */
+int cslam_mac_grad_dev(const double *d_fiedler, const int32_t *d_edge_i, const int32_t *d_edge_j,
+                       const double *d_weights, int64_t m, double *d_grad, void *stream);
+/* y = L x for the weighted graph Laplacian given as an edge list (i, j, w), nvec columns
+ * (column-major x, y [n, nvec]); the SpMM inside _tracemin_fiedler (networkx) */
+int cslam_laplacian_spmm_dev(const int32_t *d_edge_i, const int32_t *d_edge_j, const double *d_w,
+                             int64_t m, const double *d_x, int64_t n, int nvec, double *d_y,
+                             void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSLAM_HIP_H */

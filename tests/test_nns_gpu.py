@@ -1,0 +1,193 @@
+"""GPU parity tests of the descriptor-matching hot path (run with -m gpu on an MI355X).
+
+Every test goes Python class -> ctypes -> libcslam_hip.so (C ABI) -> HIP kernels and compares
+with (a) the reference-generated golden vectors and (b) the CPU oracle on identical inputs.
+Bar: top-k indices bit-identical; scores within 1e-5 of the reference (north_star gate) and
+within 1e-12 of the float64 oracle.
+"""
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, assert_topk_equal, nns_case_inputs, nns_case_names, unit_rows
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def nnm():
+    from cslam_amd import nns_matching
+    return nns_matching
+
+
+def make_bank(nnm, bank):
+    nn = nnm.NearestNeighborsMatching()
+    nn.add_items(bank, range(bank.shape[0]))
+    return nn
+
+
+@pytest.mark.parametrize("mode", ["scan", "mfma"])
+def test_golden_reference_vectors(nnm, mode):
+    g = np.load(GOLDEN + "/nns_g1.npz")
+    m = nnm.MODE_SCAN if mode == "scan" else nnm.MODE_MFMA
+    for name in nns_case_names(g):
+        bank, q = nns_case_inputs(g, name)
+        k = int(g[name + "/k"])
+        nn = make_bank(nnm, bank)
+        idx, sims, cnt = nn.search_batch(q, k, mode=m)
+        assert_topk_equal(idx, sims, cnt, g[name + "/idx"], g[name + "/sims"], g[name + "/cnt"], 1e-5)
+        oi, os_, oc = pyoracle.nns_search(bank, q, k)
+        assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
+        if mode == "mfma" and k <= 8:
+            assert nn.last_stats()[1] == nnm.MODE_MFMA
+
+
+def test_reference_single_query_api(nnm):
+    """add_item / search / search_best exactly as the reference's callers use them."""
+    g = np.load(GOLDEN + "/nns_g1.npz")
+    name = "r_n257_d512_k10_f32"
+    bank, q = nns_case_inputs(g, name)
+    nn = nnm.NearestNeighborsMatching()
+    assert nn.search(q[0], 3) == ([], []) and nn.search_best(q[0]) == (None, None)
+    for i in range(bank.shape[0]):
+        nn.add_item(bank[i], 1000 + i)          # items are arbitrary ids
+    assert nn.n == 257 and nn.dim == 512
+    assert np.array_equal(nn.data[:nn.n], bank) and nn.data.shape == (1000, 512)
+    for j in range(4):
+        items, sims = nn.search(q[j], 10)
+        assert items == [1000 + int(r) for r in g[name + "/idx"][j]]
+        assert np.max(np.abs(sims - g[name + "/sims"][j])) < 1e-5
+        best, s = nn.search_best(q[j])
+        assert best == items[0] and s == sims[0]
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(5000, 4096, 300, 5), (1537, 512, 130, 8), (777, 100, 257, 3),
+                                      (300, 10, 129, 1), (129, 64, 1000, 5)])
+def test_mfma_vs_oracle_seeded(nnm, n, d, nq, k):
+    bank = unit_rows(np.random.default_rng(n + d), n, d)
+    q = unit_rows(np.random.default_rng(n + d + 1), nq, d)
+    nn = make_bank(nnm, bank)
+    oi, os_, oc = pyoracle.nns_search(bank, q, k)
+    for mode in (nnm.MODE_MFMA, nnm.MODE_SCAN, nnm.MODE_AUTO):
+        idx, sims, cnt = nn.search_batch(q, k, mode=mode)
+        assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
+    # float64 queries (the inter-robot path: lcsm.py:63 np.asarray(msg.descriptor))
+    qd = np.random.default_rng(9).standard_normal((64, d))
+    oi, os_, oc = pyoracle.nns_search(bank, qd, k)
+    for mode in (nnm.MODE_MFMA, nnm.MODE_SCAN):
+        idx, sims, cnt = nn.search_batch(qd, k, mode=mode)
+        assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
+
+
+def test_non_unit_norm_and_scaling(nnm):
+    rng = np.random.default_rng(3)
+    bank = (rng.standard_normal((900, 96)) * rng.uniform(1e-3, 1e3, size=(900, 1))).astype(np.float32)
+    q = (rng.standard_normal((200, 96)) * 7.0).astype(np.float32)
+    nn = make_bank(nnm, bank)
+    oi, os_, oc = pyoracle.nns_search(bank, q, 5)
+    for mode in (nnm.MODE_MFMA, nnm.MODE_SCAN):
+        idx, sims, cnt = nn.search_batch(q, 5, mode=mode)
+        assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
+
+
+@pytest.mark.parametrize("mode", ["scan", "mfma"])
+def test_causal_row_limit(nnm, mode):
+    """Row j sees rows < j: the intra-robot order of gdlcd.py:157-160 done as one batch."""
+    m = nnm.MODE_SCAN if mode == "scan" else nnm.MODE_MFMA
+    bank = unit_rows(np.random.default_rng(21), 700, 256)
+    nn = make_bank(nnm, bank)
+    lim = np.arange(700, dtype=np.int64)
+    idx, sims, cnt = nn.search_batch(bank, 5, row_limit=lim, mode=m)
+    oi, os_, oc = pyoracle.nns_search(bank, bank, 5, row_limit=lim)
+    assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
+    assert cnt[0] == 0 and cnt[3] == 3 and np.all(idx[0] == -1)
+
+
+def test_duplicates_zero_rows_and_ties(nnm):
+    rng = np.random.default_rng(4)
+    bank = rng.standard_normal((400, 128)).astype(np.float32)
+    bank[100] = bank[7]; bank[250] = bank[7]; bank[399] = bank[7]      # exact ties -> larger row first
+    bank[33] = 0.0; bank[301] = 0.0                                     # NaN scores rank first
+    q = np.concatenate([bank[7:8], rng.standard_normal((140, 128)).astype(np.float32)])
+    nn = make_bank(nnm, bank)
+    oi, os_, oc = pyoracle.nns_search(bank, q, 8)
+    assert list(oi[0, :6]) == [301, 33, 399, 250, 100, 7]
+    for mode in (nnm.MODE_MFMA, nnm.MODE_SCAN):
+        idx, sims, cnt = nn.search_batch(q, 8, mode=mode)
+        assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
+
+
+def test_certificate_fallback_on_unresolvable_near_ties(nnm):
+    """Rows that differ by less than float32 roundoff of the dot product: the fp32-MFMA stage
+    cannot rank them, the certificate must fail, and the float64 scan must still give the
+    oracle's exact order."""
+    rng = np.random.default_rng(6)
+    base = unit_rows(rng, 1, 1024)[0]
+    bank = np.tile(base, (600, 1)).astype(np.float32)
+    # perturb one coordinate per row by a few float32 ulps -> cosine differences ~1e-9
+    for i in range(600):
+        bank[i, i % 1024] = np.nextafter(bank[i, i % 1024], np.float32(1.0)) if i % 3 else bank[i, i % 1024]
+        bank[i, (7 * i) % 1024] *= np.float32(1.0 + (i % 5) * 1.2e-7)
+    q = unit_rows(rng, 130, 1024)
+    q[0] = base
+    nn = make_bank(nnm, bank)
+    idx, sims, cnt = nn.search_batch(q, 5, mode=nnm.MODE_MFMA)
+    assert nn.last_stats()[0] > 0, "certificate should have rejected these queries"
+    oi, os_, oc = pyoracle.nns_search(bank, q, 5)
+    assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
+
+
+def test_large_k_multi_pass(nnm):
+    """k >= n and k > 64 (the reference test uses k = n = 100: test_sparse_matching.py:62)."""
+    bank = unit_rows(np.random.default_rng(8), 100, 100)
+    q = unit_rows(np.random.default_rng(9), 5, 100)
+    nn = make_bank(nnm, bank)
+    for k in (100, 103, 65, 64):
+        idx, sims, cnt = nn.search_batch(q, k)
+        oi, os_, oc = pyoracle.nns_search(bank, q, k)
+        assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
+    bank = unit_rows(np.random.default_rng(10), 3000, 64)
+    nn = make_bank(nnm, bank)
+    idx, sims, cnt = nn.search_batch(q[:, :64].copy(), 200)
+    oi, os_, oc = pyoracle.nns_search(bank, q[:, :64].copy(), 200)
+    assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
+
+
+def test_growth_keeps_contents(nnm):
+    """Amortised doubling (nns_matching.py:31-37): contents survive reallocation."""
+    bank = unit_rows(np.random.default_rng(12), 2500, 48)
+    nn = nnm.NearestNeighborsMatching()
+    for s in range(0, 2500, 500):
+        nn.add_items(bank[s:s + 500], range(s, s + 500))
+    assert nn.n == 2500 and nn.data.shape == (4000, 48)
+    assert np.array_equal(nn.data[:2500], bank)
+    idx, sims, cnt = nn.search_batch(bank[:64], 1, mode=nnm.MODE_MFMA)
+    assert np.array_equal(idx[:, 0], np.arange(64))
+
+
+def test_full_size_bank_properties(nnm):
+    """BASELINE config 3 size (100k x 4096 bank): size-independent properties.
+    (1) a bank row queried against the bank finds itself first with similarity clipped to <= 1;
+    (2) MFMA batch path == independent float64 scan path on the same queries;
+    (3) a few queries against the CPU oracle (bit-identical indices)."""
+    import torch
+    n, d = 100_000, 4096
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    bank = torch.randn((n, d), generator=gen, device="cuda", dtype=torch.float32)
+    bank /= bank.norm(dim=1, keepdim=True)
+    nn = nnm.NearestNeighborsMatching()
+    nn.add_items_device(bank)
+    sel = torch.arange(0, n, 97, device="cuda")[:1024]
+    q = bank[sel].contiguous()
+    rows, sims, cnt = nn.search_device(q, 5, mode=nnm.MODE_MFMA)
+    assert nn.last_stats()[1] == nnm.MODE_MFMA
+    assert torch.equal(rows[:, 0], sel)
+    assert float(sims[:, 0].min()) > 1 - 1e-6 and float(sims[:, 0].max()) <= 1.0
+    assert torch.all(sims[:, :-1] >= sims[:, 1:])
+    r2, s2, c2 = nn.search_device(q[:64].contiguous(), 5, mode=nnm.MODE_SCAN)
+    assert torch.equal(rows[:64], r2) and torch.equal(cnt[:64], c2)
+    assert float((sims[:64] - s2).abs().max()) < 1e-12
+    hb = bank.cpu().numpy()
+    oi, os_, oc = pyoracle.nns_search(hb, q[:6].cpu().numpy(), 5)
+    assert np.array_equal(rows[:6].cpu().numpy(), oi)
+    assert np.max(np.abs(sims[:6].cpu().numpy() - os_)) < 1e-12

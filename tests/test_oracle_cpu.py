@@ -1,0 +1,71 @@
+"""CPU suite: the oracle (oracle/nns_oracle.c) against the reference-generated golden vectors.
+
+tests/golden/nns_g1.npz was produced by oracle/gen_golden.py importing the REAL reference
+(cslam/nns_matching.py) in the build container.  Indices must be identical; scores within
+3e-7 (the reference accumulates float32 dots for float32 queries -- see nns_oracle.c header).
+"""
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, assert_topk_equal, nns_case_inputs, nns_case_names
+from oracle import pyoracle
+
+
+@pytest.fixture(scope="module")
+def g1():
+    return np.load(GOLDEN + "/nns_g1.npz")
+
+
+def test_oracle_matches_reference_golden(g1):
+    names = nns_case_names(g1)
+    assert len(names) >= 17
+    for name in names:
+        bank, q = nns_case_inputs(g1, name)
+        k = int(g1[name + "/k"])
+        idx, sims, cnt = pyoracle.nns_search(bank, q, k)
+        assert_topk_equal(idx, sims, cnt, g1[name + "/idx"], g1[name + "/sims"], g1[name + "/cnt"], 3e-7)
+
+
+def test_oracle_tie_rule_and_nan():
+    # duplicates tie exactly -> larger row first; zero row -> NaN ranks first (argsort()[::-1])
+    rng = np.random.default_rng(0)
+    bank = rng.standard_normal((6, 16)).astype(np.float32)
+    bank[4] = bank[1]
+    bank[2] = 0.0
+    q = bank[1:2].copy()
+    idx, sims, cnt = pyoracle.nns_search(bank, q, 4)
+    assert idx[0, 0] == 2 and np.isnan(sims[0, 0])
+    assert list(idx[0, 1:3]) == [4, 1]
+    assert sims[0, 1] == sims[0, 2]
+
+
+def test_oracle_row_limit_is_causal_mask():
+    rng = np.random.default_rng(1)
+    bank = rng.standard_normal((50, 32)).astype(np.float32)
+    q = bank[:10].copy()
+    lim = np.arange(10, dtype=np.int64)
+    idx, sims, cnt = pyoracle.nns_search(bank, q, 3, row_limit=lim)
+    assert list(cnt) == [min(3, i) for i in range(10)]
+    for j in range(10):
+        assert np.all(idx[j, :cnt[j]] < j)
+        ref = pyoracle.nns_search(bank[:j], q[j:j + 1], 3)[0][0] if j else np.full(3, -1)
+        assert np.array_equal(idx[j], ref)
+
+
+def test_oracle_cosine_equals_euclidean_order():
+    """The reference's own numerical pin (tests/test_sparse_matching.py:51-81): on unit vectors
+    cosine order == Euclidean order (ties within 1e-6 tolerated)."""
+    rng = np.random.default_rng(5)
+    bank = rng.random((100, 100))
+    bank /= np.linalg.norm(bank, axis=1, keepdims=True)
+    bank32 = bank.astype(np.float32)
+    for _ in range(20):
+        q = rng.random(100)
+        q /= np.linalg.norm(q)
+        ds = np.linalg.norm(q[None, :] - bank32, axis=1)
+        order = np.argsort(ds)
+        idx, sims, _ = pyoracle.nns_search(bank32, q[None, :], 100)
+        assert np.all(sims[0, :-1] >= sims[0, 1:])
+        for j in range(100):
+            if order[j] != idx[0, j]:
+                assert abs(ds[order[j]] - ds[idx[0, j]]) < 1e-6
