@@ -46,7 +46,7 @@ _SIGNATURES = {
     "cslam_pca_project_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "cslam_preprocess_dev": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(_f * 3), C.POINTER(_f * 3), _vp, _vp]),
     "cslam_mac_grad_dev": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
-    "cslam_laplacian_spmm_dev": (_i, [_vp, _vp, _vp, _i64, _vp, _i64, _i, _vp, _vp]),
+    "cslam_csr_spmm_dev": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _vp, _vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

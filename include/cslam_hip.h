@@ -114,10 +114,12 @@ int cslam_gem_fc_head_dev(const float *d_feat, float p, float eps, const float *
                           const float *d_b, int B, int C, int P, int Dout,
                           float *d_out, void *stream);
 /* PCA projection + row L2, cslam/vpr/netvlad.py:234-236 (sklearn PCA.transform + normalize):
- * out = normalize(((x - mean) @ comp^T) * scale) with comp [Dout, Din], mean [Din] or NULL,
- * scale [Dout] or NULL (1/sqrt(explained_variance) when whitening). x [B, Din], out [B, Dout]. */
-int cslam_pca_project_dev(const float *d_x, const float *d_comp, const float *d_mean,
-                          const float *d_scale, int B, int Din, int Dout, float *d_out,
+ *   y = x @ comp^T - mean_proj ;  y *= inv_scale (whitening) ;  y /= ||y|| (zero rows stay zero)
+ * comp [Dout, Din]; mean_proj [Dout] = mean @ comp^T (precomputed once by the caller) or NULL;
+ * inv_scale [Dout] = 1/sqrt(explained_variance) or NULL.  x [B, Din], out [B, Dout].
+ * Din must be a multiple of 32.  fp32 MFMA GEMM with split-K (deterministic reduction). */
+int cslam_pca_project_dev(const float *d_x, const float *d_comp, const float *d_mean_proj,
+                          const float *d_inv_scale, int B, int Din, int Dout, float *d_out,
                           void *stream);
 /* image transform, cslam/vpr/netvlad.py:202-208 / cosplace.py:73-79:
  * CenterCrop(crop) -> Resize(out_hw, PIL bicubic, antialiased, 8-bit intermediate) ->
@@ -130,11 +132,11 @@ int cslam_preprocess_dev(const uint8_t *d_img, int B, int H, int W, int crop, in
 /* grad_from_fiedler, mac.py:112-130: g[k] = w[k] * (v[i_k] - v[j_k])^2, float64 */
 int cslam_mac_grad_dev(const double *d_fiedler, const int32_t *d_edge_i, const int32_t *d_edge_j,
                        const double *d_weights, int64_t m, double *d_grad, void *stream);
-/* y = L x for the weighted graph Laplacian given as an edge list (i, j, w), nvec columns
- * (column-major x, y [n, nvec]); the SpMM inside _tracemin_fiedler (networkx) */
-int cslam_laplacian_spmm_dev(const int32_t *d_edge_i, const int32_t *d_edge_j, const double *d_w,
-                             int64_t m, const double *d_x, int64_t n, int nvec, double *d_y,
-                             void *stream);
+/* y = A x for a float64 CSR matrix (the Laplacian L(w) of mac.py:61-77), nvec dense columns,
+ * x and y column-major [n, nvec]: the L @ X product inside networkx _tracemin_fiedler
+ * (third-party).  One thread per (row, column): deterministic. */
+int cslam_csr_spmm_dev(const int64_t *d_indptr, const int32_t *d_indices, const double *d_data,
+                       int64_t n, const double *d_x, int nvec, double *d_y, void *stream);
 
 #ifdef __cplusplus
 }

@@ -129,7 +129,6 @@ def test_certificate_fallback_on_unresolvable_near_ties(nnm):
         bank[i, i % 1024] = np.nextafter(bank[i, i % 1024], np.float32(1.0)) if i % 3 else bank[i, i % 1024]
         bank[i, (7 * i) % 1024] *= np.float32(1.0 + (i % 5) * 1.2e-7)
     q = unit_rows(rng, 130, 1024)
-    q[0] = base
     nn = make_bank(nnm, bank)
     idx, sims, cnt = nn.search_batch(q, 5, mode=nnm.MODE_MFMA)
     assert nn.last_stats()[0] > 0, "certificate should have rejected these queries"
