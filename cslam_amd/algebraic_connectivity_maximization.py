@@ -1,0 +1,327 @@
+"""Inter-robot loop-closure candidate selection by algebraic-connectivity maximisation.
+
+Drop-in for the reference module of the same name
+(cslam/algebraic_connectivity_maximization.py): `EdgeInterRobot` and
+`AlgebraicConnectivityMaximization` keep the reference's constructor, methods, public
+attributes and -- deliberately -- its observable quirks (they are what Swarm-SLAM runs on):
+  * `EdgeInterRobot.__eq__` ignores the weight and the direction (reference :18-31);
+  * `add_match` looks the edge up under its UN-normalised key while storage uses the
+    normalised `edge_key` (reference :565-572 vs :174), so the keep-the-larger-weight rule
+    only fires when robot0_id < robot1_id;
+  * `fill_odometry` adds chain edges for every robot, excluded ones at offset 0 (:348-362);
+  * `remove_candidate_edges` compares with the direction/weight-blind `==` (:184-187).
+The bookkeeping is control-plane Python like the reference's; the numerical core
+(Laplacian, Fiedler pair, Frank-Wolfe) is cslam_amd/mac/.
+"""
+from typing import NamedTuple
+
+import numpy as np
+
+from cslam_amd.mac.mac import MAC
+from cslam_amd.mac.utils import Edge
+
+
+class EdgeInterRobot(NamedTuple):
+    """ Inter-robot loop closure edge
+    """
+    robot0_id: int
+    robot0_keyframe_id: int
+    robot1_id: int
+    robot1_keyframe_id: int
+    weight: float
+
+    def __eq__(self, other):
+        """Equality ignores the weight and the orientation of the edge."""
+        a = (self.robot0_id, self.robot0_keyframe_id)
+        b = (self.robot1_id, self.robot1_keyframe_id)
+        c = (other.robot0_id, other.robot0_keyframe_id)
+        d = (other.robot1_id, other.robot1_keyframe_id)
+        return (a == c and b == d) or (a == d and b == c)
+
+
+_DEFAULT_PARAMS = {
+    "frontend.enable_sparsification": True,
+    "evaluation.enable_sparsification_comparison": False,
+}
+
+
+class AlgebraicConnectivityMaximization(object):
+
+    def __init__(self, robot_id=0, max_nb_robots=1, max_iters=20, fixed_weight=1.0,
+                 extra_params=_DEFAULT_PARAMS):
+        """Initialization
+
+        Args:
+            robot_id (int, optional): ID of the robot
+            max_nb_robots (int, optional): number of robots. Defaults to 1.
+            max_iters (int, optional): maximum number of iterations. Defaults to 20.
+            fixed_weight (float, optional): weight of fixed measurements. Defaults to 1.0.
+        """
+        self.fixed_weight = fixed_weight
+        self.params = extra_params
+        self.fixed_edges = []
+        self.candidate_edges = {}
+        self.already_considered_matches = set()
+        self.max_iters = max_iters
+        self.max_nb_robots = max_nb_robots
+        self.robot_id = robot_id
+        self.total_nb_poses = 0
+        self.nb_poses = {r: 0 for r in range(max_nb_robots)}
+        self.initial_fixed_edge_exists = {r: False for r in range(max_nb_robots)}
+        self.offsets = {}
+        self.log_greedy_edges = []
+        self.log_mac_edges = []
+
+    # ---------------------------------------------------------------- bookkeeping ----
+    def edge_key(self, edge):
+        """Direction-normalised (robot, keyframe, robot, keyframe) key (reference :76-90)."""
+        if edge.robot0_id < edge.robot1_id:
+            return (edge.robot0_id, edge.robot0_keyframe_id, edge.robot1_id, edge.robot1_keyframe_id)
+        return (edge.robot1_id, edge.robot1_keyframe_id, edge.robot0_id, edge.robot0_keyframe_id)
+
+    def replace_weight(self, edge, weight):
+        """Copy of `edge` with a new weight; EdgeInterRobot or mac Edge (reference :92-109)."""
+        if type(edge) is EdgeInterRobot:
+            return edge._replace(weight=weight)
+        if type(edge) is Edge:
+            return Edge(edge.i, edge.j, weight)
+
+    def update_nb_poses(self, edge):
+        """nb_poses[r] = largest keyframe id seen for r, plus one (reference :111-120)."""
+        for rid, kf in ((edge.robot0_id, edge.robot0_keyframe_id), (edge.robot1_id, edge.robot1_keyframe_id)):
+            if kf + 1 > self.nb_poses[rid]:
+                self.nb_poses[rid] = kf + 1
+
+    def update_initial_fixed_edge_exists(self, fixed_edge):
+        """Remember which robots already have a fixed INTER-robot link (reference :122-132)."""
+        if fixed_edge.robot0_id != fixed_edge.robot1_id:
+            self.initial_fixed_edge_exists[fixed_edge.robot0_id] = True
+            self.initial_fixed_edge_exists[fixed_edge.robot1_id] = True
+
+    def set_graph(self, fixed_edges, candidate_edges):
+        """Fill graph struct (reference :134-153)."""
+        self.fixed_edges = fixed_edges
+        for e in self.fixed_edges:
+            self.update_nb_poses(e)
+            self.update_initial_fixed_edge_exists(e)
+        for e in candidate_edges:
+            self.update_nb_poses(e)
+        for e in candidate_edges:
+            self.candidate_edges[self.edge_key(e)] = e
+
+    def add_fixed_edge(self, edge):
+        """Add an already computed edge to the graph (reference :155-164)."""
+        self.fixed_edges.append(edge)
+        self.update_nb_poses(edge)
+        self.update_initial_fixed_edge_exists(edge)
+
+    def add_candidate_edge(self, edge):
+        """Add a candidate edge unless it was already selected / failed (reference :166-178)."""
+        key = self.edge_key(edge)
+        if key in self.already_considered_matches:
+            return
+        self.candidate_edges[key] = edge
+        self.update_nb_poses(edge)
+
+    def remove_candidate_edges(self, edges, failed=False):
+        """Drop candidates equal (weight/direction-blind) to any of `edges`, and never
+        consider them again (reference :180-191)."""
+        for k in list(self.candidate_edges.keys()):
+            if self.candidate_edges[k] in edges:
+                del self.candidate_edges[k]
+        for edge in edges:
+            self.already_considered_matches.add(self.edge_key(edge))
+
+    def candidate_edges_to_fixed(self, edges):
+        """Candidates that became measurements: fixed weight, moved to the fixed set
+        (reference :193-203; mutates `edges` in place like the reference)."""
+        for i in range(len(edges)):
+            edges[i] = self.replace_weight(edges[i], weight=self.fixed_weight)
+            self.update_initial_fixed_edge_exists(edges[i])
+        self.fixed_edges.extend(edges)
+        self.remove_candidate_edges(edges)
+
+    def add_match(self, match):
+        """Add a potential match, keeping the larger weight when the (un-normalised) key is
+        already a candidate (reference :559-572)."""
+        key = (match.robot0_id, match.robot0_keyframe_id, match.robot1_id, match.robot1_keyframe_id)
+        if key in self.candidate_edges and not (match.weight > self.candidate_edges[key].weight):
+            return
+        self.add_candidate_edge(match)
+
+    # ------------------------------------------------------------- initial guesses ----
+    def greedy_initialization(self, nb_candidates_to_choose, edges):
+        """One-hot vector of the nb_candidates_to_choose largest weights (reference :205-218)."""
+        weights = [e.weight for e in edges]
+        w_init = np.zeros(len(weights))
+        chosen = np.argpartition(weights, -nb_candidates_to_choose)[-nb_candidates_to_choose:]
+        w_init[chosen] = 1.0
+        return w_init
+
+    def pseudo_greedy_initialization(self, nb_candidates_to_choose, nb_random, edges):
+        """Greedy for the first nb_candidates_to_choose - nb_random picks, uniformly random for
+        the rest; falls back to plain greedy after 2*nb_random failed draws (reference :220-246)."""
+        w_init = self.greedy_initialization(nb_candidates_to_choose - nb_random, edges)
+        nb_edges = len(edges)
+        picked, trial, max_trials = 0, 0, 2 * nb_random
+        while picked < nb_random and trial < max_trials:
+            j = int(np.random.rand() * nb_edges)
+            if w_init[j] < 0.5:
+                w_init[j] = 1.0
+                picked += 1
+            trial += 1
+        if trial >= max_trials:
+            w_init = self.greedy_initialization(nb_candidates_to_choose, edges)
+        return w_init
+
+    def random_initialization(self, nb_candidates_to_choose, edges):
+        """Random weights then greedy (reference :248-256; overwrites `edges` weights in place)."""
+        for e in range(len(edges)):
+            edges[e] = self.replace_weight(edges[e], np.random.rand())
+        return self.greedy_initialization(nb_candidates_to_choose, edges)
+
+    def connection_biased_greedy_selection(self, nb_candidates_to_choose, edges, is_robot_included):
+        """Greedy selection that first takes, for every included robot without a fixed
+        inter-robot link, its heaviest candidate (reference :258-289)."""
+        pool = edges.copy()
+        forced = []
+        for rid in [r for r in is_robot_included.keys() if is_robot_included[r]]:
+            if self.initial_fixed_edge_exists[rid]:
+                continue
+            best, best_w = None, -1
+            for i, e in enumerate(pool):
+                if (e.robot0_id == rid or e.robot1_id == rid) and e.weight > best_w:
+                    best, best_w = i, e.weight
+            if best is not None:
+                forced.append(best)
+                pool[best] = self.replace_weight(pool[best], weight=0.0)
+        w_init = np.zeros(len(edges))
+        remaining = nb_candidates_to_choose - len(forced)
+        if remaining > 0:
+            w_init = self.greedy_initialization(remaining, self.rekey_edges(pool, is_robot_included))
+        for i in forced:
+            w_init[i] = 1.0
+        return w_init
+
+    # -------------------------------------------------------------------- re-keying ----
+    def compute_offsets(self, is_robot_included):
+        """Node-id offset of every included robot so that all poses live in one graph;
+        excluded robots keep offset 0 (reference :291-310)."""
+        self.offsets = {r: 0 for r in range(self.max_nb_robots)}
+        running = 0
+        for r in range(self.max_nb_robots):
+            if is_robot_included[r]:
+                self.offsets[r] = running
+                running += self.nb_poses[r]
+
+    def rekey_edges(self, edges, is_robot_included):
+        """(robot, keyframe) pairs -> single-graph node ids, dropping edges that touch an
+        excluded robot (reference :312-335)."""
+        return [Edge(self.offsets[e.robot0_id] + e.robot0_keyframe_id,
+                     self.offsets[e.robot1_id] + e.robot1_keyframe_id, e.weight)
+                for e in edges if is_robot_included[e.robot0_id] and is_robot_included[e.robot1_id]]
+
+    def get_included_edges(self, edges, is_robot_included):
+        """Edges whose two robots are included (reference :337-346)."""
+        return [e for e in edges if is_robot_included[e.robot0_id] and is_robot_included[e.robot1_id]]
+
+    def fill_odometry(self):
+        """Odometry chain edges inferred from the pose counts (reference :348-362)."""
+        odom_edges = []
+        for r in range(len(self.nb_poses)):
+            base = self.offsets[r]
+            odom_edges.extend(Edge(base + k, base + k + 1, self.fixed_weight)
+                              for k in range(self.nb_poses[r] - 1))
+        return odom_edges
+
+    def recover_inter_robot_edges(self, edges, is_robot_included):
+        """Inverse of rekey_edges: node ids back to (robot, keyframe) (reference :364-389)."""
+        recovered = []
+        for e in edges:
+            r0 = r1 = 0
+            for o in self.offsets:
+                if o != 0 and is_robot_included[o]:
+                    if e.i >= self.offsets[o]:
+                        r0 = o
+                    if e.j >= self.offsets[o]:
+                        r1 = o
+            recovered.append(EdgeInterRobot(r0, e.i - self.offsets[r0], r1, e.j - self.offsets[r1], e.weight))
+        return recovered
+
+    def check_graph_disconnections(self, is_other_robot_considered):
+        """A robot is included if it is this robot, or is considered and touches at least one
+        fixed or candidate edge (reference :391-417)."""
+        connected = {r: (r == self.robot_id) for r in range(self.max_nb_robots)}
+        for edge in list(self.fixed_edges) + list(self.candidate_edges.values()):
+            for rid in (edge.robot0_id, edge.robot1_id):
+                if is_other_robot_considered[rid]:
+                    connected[rid] = True
+        return connected
+
+    def check_initial_fixed_measurements_exists(self, is_robot_included):
+        """True iff every included robot already has a fixed inter-robot link (reference :419-434)."""
+        return all(self.initial_fixed_edge_exists[r] for r in is_robot_included if is_robot_included[r])
+
+    # ----------------------------------------------------------------------- solve ----
+    def run_mac_solver(self, fixed_edges, candidate_edges, w_init, nb_candidates_to_choose):
+        """Frank-Wolfe MAC with the reference's retry policy: any failure of the Fiedler
+        solve (singular Laplacian of a disconnected selection) re-draws the initial guess with
+        one more random pick, at most nb_candidates_to_choose times (reference :436-466)."""
+        mac = MAC(fixed_edges, candidate_edges, self.total_nb_poses)
+        result = w_init.copy()
+        trial = 0
+        while trial < nb_candidates_to_choose:
+            try:
+                result, _, _ = mac.fw_subset(w_init, nb_candidates_to_choose, max_iters=self.max_iters)
+                break
+            except Exception:
+                trial += 1
+                w_init = self.pseudo_greedy_initialization(nb_candidates_to_choose, trial, candidate_edges)
+        return result
+
+    def select_candidates(self, nb_candidates_to_choose, is_other_robot_considered,
+                          greedy_initialization=True):
+        """Select `nb_candidates_to_choose` candidate edges (reference :468-543).
+
+        Returns:
+            list(EdgeInterRobot): selected edges (also removed from the candidates)
+        """
+        is_robot_included = self.check_graph_disconnections(is_other_robot_considered)
+        self.compute_offsets(is_robot_included)
+        rekeyed_fixed = self.rekey_edges(self.fixed_edges, is_robot_included)
+        rekeyed_fixed.extend(self.fill_odometry())
+        rekeyed_cand = self.rekey_edges(self.candidate_edges.values(), is_robot_included)
+        if nb_candidates_to_choose > len(rekeyed_cand):
+            nb_candidates_to_choose = len(rekeyed_cand)
+        if len(rekeyed_cand) == 0:
+            return []
+
+        self.total_nb_poses = sum(self.nb_poses[n] for n in range(len(self.nb_poses)))
+        if greedy_initialization:
+            w_init = self.greedy_initialization(nb_candidates_to_choose, rekeyed_cand)
+        else:
+            w_init = self.random_initialization(nb_candidates_to_choose, rekeyed_cand)
+
+        if self.params["frontend.enable_sparsification"] and \
+                self.check_initial_fixed_measurements_exists(is_robot_included):
+            result = self.run_mac_solver(rekeyed_fixed, rekeyed_cand, w_init, nb_candidates_to_choose)
+        else:
+            result = self.connection_biased_greedy_selection(
+                nb_candidates_to_choose,
+                self.get_included_edges(self.candidate_edges.values(), is_robot_included),
+                is_robot_included)
+
+        if self.params["evaluation.enable_sparsification_comparison"]:
+            self.sparsification_comparison_logs(rekeyed_cand, is_robot_included, w_init, result)
+
+        selected = [rekeyed_cand[i] for i in np.nonzero(result.astype(int))[0]]
+        inter_robot_edges = self.recover_inter_robot_edges(selected, is_robot_included)
+        self.remove_candidate_edges(inter_robot_edges)
+        return inter_robot_edges
+
+    def sparsification_comparison_logs(self, rekeyed_candidate_edges, is_robot_included,
+                                       greedy_result, mac_result):
+        """Keep both selections for the evaluation log (reference :545-557)."""
+        pick = lambda r: [rekeyed_candidate_edges[i] for i in np.nonzero(r.astype(int))[0]]
+        self.log_greedy_edges = self.recover_inter_robot_edges(pick(greedy_result), is_robot_included)
+        self.log_mac_edges = self.recover_inter_robot_edges(pick(mac_result), is_robot_included)

@@ -1,0 +1,180 @@
+"""Sparse matching for loop closure detection on an MI355X.
+
+Drop-in for cslam/loop_closure_sparse_matching.py: same constructor (ROS parameter dict),
+same five methods, same public attributes (`local_nnsm`, `other_robots_nnsm`,
+`candidate_selector`).  Descriptor banks are HBM-resident `NearestNeighborsMatching`
+objects; the candidate bookkeeping is `AlgebraicConnectivityMaximization`.
+
+Batched extensions (`process_local_keyframes`, `process_remote_descriptors`) give the same
+matches as calling the per-keyframe reference methods in order, with one GPU launch per
+batch instead of one per keyframe (the causal order of
+global_descriptor_loop_closure_detection.py:157-160 is kept with a per-row visibility limit).
+"""
+import numpy as np
+
+from cslam_amd.nns_matching import NearestNeighborsMatching
+from cslam_amd.algebraic_connectivity_maximization import AlgebraicConnectivityMaximization, EdgeInterRobot
+
+
+def _scan_context_matching():
+    # Lidar place recognition (cslam/lidar_pr/) is outside the accelerated path; use the
+    # reference's own class when the cslam package is installed next to this one.
+    try:
+        from cslam.lidar_pr.scancontext_matching import ScanContextMatching
+    except ImportError as e:  # pragma: no cover
+        raise ImportError("frontend.sensor_type == 'lidar' needs cslam.lidar_pr "
+                          "(ScanContext is not part of cslam_amd)") from e
+    return ScanContextMatching()
+
+
+class LoopClosureSparseMatching(object):
+    """Sparse matching for loop closure detection
+        Matches global descriptors to generate loop closure candidates
+        Then candidates are selected such that we respect the communication budget
+    """
+
+    def __init__(self, params, device=0):
+        """ Initialization of loop closure matching
+
+        Args:
+            params (dict): ROS 2 parameters
+            device (int): HIP device holding this robot's descriptor banks
+        """
+        self.params = params
+        lidar = self.params["frontend.sensor_type"] == "lidar"
+        new_bank = _scan_context_matching if lidar else (lambda: NearestNeighborsMatching(device=device))
+        self.local_nnsm = new_bank()
+        self.other_robots_nnsm = {}
+        for i in range(self.params['max_nb_robots']):
+            if i != self.params['robot_id']:
+                self.other_robots_nnsm[i] = new_bank()
+        self.candidate_selector = AlgebraicConnectivityMaximization(
+            self.params['robot_id'], self.params['max_nb_robots'], extra_params=self.params)
+
+    # ------------------------------------------------------------ reference API ----
+    def add_local_global_descriptor(self, embedding, keyframe_id):
+        """ Add a local keyframe for matching (reference lcsm.py:36-54)
+
+        Args:
+            embedding (np.array): global descriptor
+            id (int): keyframe id
+        """
+        matches = []
+        self.local_nnsm.add_item(embedding, keyframe_id)
+        me = self.params['robot_id']
+        for i in range(self.params['max_nb_robots']):
+            if i == me:
+                continue
+            kf, similarity = self.other_robots_nnsm[i].search_best(embedding)
+            if kf is not None and similarity >= self.params['frontend.similarity_threshold']:
+                match = EdgeInterRobot(me, keyframe_id, i, kf, similarity)
+                self.candidate_selector.add_match(match)
+                matches.append(match)
+        return matches
+
+    def add_other_robot_global_descriptor(self, msg):
+        """ Add keyframe global descriptor info from other robot (reference lcsm.py:56-72)
+
+        Args:
+            msg (cslam_common_interfaces.msg.GlobalDescriptor): global descriptor info
+        """
+        descriptor = np.asarray(msg.descriptor)          # float64, as in the reference
+        self.other_robots_nnsm[msg.robot_id].add_item(descriptor, msg.keyframe_id)
+        kf, similarity = self.local_nnsm.search_best(descriptor)
+        if kf is None or not similarity >= self.params['frontend.similarity_threshold']:
+            return None
+        match = EdgeInterRobot(self.params['robot_id'], kf, msg.robot_id, msg.keyframe_id, similarity)
+        self.candidate_selector.add_match(match)
+        return match
+
+    @staticmethod
+    def _first_valid(kfs, similarities, kf_id, min_gap, threshold):
+        for kf, similarity in zip(kfs, similarities):
+            if abs(kf - kf_id) < min_gap or similarity < threshold:
+                continue
+            return kf
+        return None
+
+    def match_local_loop_closures(self, descriptor, kf_id):
+        """Intra-robot loop closure: best of the top `nb_best_matches` that is far enough in
+        time and similar enough (reference lcsm.py:74-92)."""
+        kfs, similarities = self.local_nnsm.search(descriptor, k=self.params['frontend.nb_best_matches'])
+        if len(kfs) > 0 and kfs[0] == kf_id:
+            kfs, similarities = kfs[1:], similarities[1:]
+        if len(kfs) == 0 or kfs[0] is None:
+            return None, None
+        kf = self._first_valid(kfs, similarities, kf_id,
+                               self.params['frontend.intra_loop_min_inbetween_keyframes'],
+                               self.params['frontend.similarity_threshold'])
+        return (kf, kfs) if kf is not None else (None, None)
+
+    def select_candidates(self, number_of_candidates, is_neighbor_in_range, greedy_initialization=True):
+        """Select inter-robot loop closure candidates according to budget (reference lcsm.py:94-110)
+
+        Returns:
+            list(EdgeInterRobot): selected edges
+        """
+        return self.candidate_selector.select_candidates(number_of_candidates, is_neighbor_in_range,
+                                                         greedy_initialization)
+
+    # ------------------------------------------------------- batched extensions ----
+    def process_local_keyframes(self, embeddings, keyframe_ids, intra=True):
+        """Batch equivalent of, for each keyframe in order (gdlcd.py:148-174):
+               match_local_loop_closures(e, id); add_local_global_descriptor(e, id)
+        Returns (intra_matches list of (kf_id, matched_kf or None), inter_matches list of
+        EdgeInterRobot in the order the sequential calls would produce them)."""
+        emb = np.asarray(embeddings)
+        ids = [int(i) for i in keyframe_ids]
+        m = emb.shape[0]
+        assert emb.ndim == 2 and len(ids) == m
+        intra_out = []
+        n0 = self.local_nnsm.n
+        self.local_nnsm.add_items(emb, ids)
+        if intra:
+            k = int(self.params['frontend.nb_best_matches'])
+            lim = n0 + np.arange(m, dtype=np.int64)           # keyframe j sees rows added before it
+            rows, sims, cnt = self.local_nnsm.search_batch(emb, k, row_limit=lim)
+            for j in range(m):
+                kfs = [self.local_nnsm.items[int(r)] for r in rows[j, :cnt[j]]]
+                s = sims[j, :cnt[j]]
+                if len(kfs) > 0 and kfs[0] == ids[j]:
+                    kfs, s = kfs[1:], s[1:]
+                kf = None
+                if len(kfs) > 0 and kfs[0] is not None:
+                    kf = self._first_valid(kfs, s, ids[j],
+                                           self.params['frontend.intra_loop_min_inbetween_keyframes'],
+                                           self.params['frontend.similarity_threshold'])
+                intra_out.append((ids[j], kf))
+        me = self.params['robot_id']
+        best = {}
+        for i in range(self.params['max_nb_robots']):
+            if i != me and self.other_robots_nnsm[i].n > 0:
+                best[i] = self.other_robots_nnsm[i].search_batch(emb, 1)
+        inter_out = []
+        for j in range(m):
+            for i in sorted(best):
+                rows, sims, cnt = best[i]
+                if cnt[j] > 0 and sims[j, 0] >= self.params['frontend.similarity_threshold']:
+                    match = EdgeInterRobot(me, ids[j], i, self.other_robots_nnsm[i].items[int(rows[j, 0])],
+                                           sims[j, 0])
+                    self.candidate_selector.add_match(match)
+                    inter_out.append(match)
+        return intra_out, inter_out
+
+    def process_remote_descriptors(self, robot_id, descriptors, keyframe_ids):
+        """Batch equivalent of add_other_robot_global_descriptor for consecutive messages of
+        one robot (descriptors as float64 [m, d], like np.asarray(msg.descriptor))."""
+        desc = np.asarray(descriptors, dtype=np.float64)
+        ids = [int(i) for i in keyframe_ids]
+        self.other_robots_nnsm[robot_id].add_items(desc, ids)
+        out = []
+        if self.local_nnsm.n == 0:
+            return out
+        rows, sims, cnt = self.local_nnsm.search_batch(desc, 1)
+        for j in range(desc.shape[0]):
+            if cnt[j] > 0 and sims[j, 0] >= self.params['frontend.similarity_threshold']:
+                match = EdgeInterRobot(self.params['robot_id'], self.local_nnsm.items[int(rows[j, 0])],
+                                       robot_id, ids[j], sims[j, 0])
+                self.candidate_selector.add_match(match)
+                out.append(match)
+        return out

@@ -1,0 +1,102 @@
+"""Frank-Wolfe maximisation of the algebraic connectivity (reference: cslam/mac/mac.py).
+
+Same iterates as the reference's MAC class: L(w) = L_fixed + sum_k w_k weight_k L_k,
+gradient g_k = weight_k (v_i - v_j)^2 from the Fiedler vector, linear maximisation oracle =
+top-k of the gradient, step 2/(it+2), dual bound / gap test, final rounding with weight
+tie-break.  The per-edge Python loops of the reference (mac.py:123-129, 178-180) are
+vectorised with the same operation order, so results are bit-identical.
+"""
+from collections import namedtuple
+
+import numpy as np
+
+from .fiedler import fiedler_tracemin_lu
+from .utils import weight_graph_lap_from_edge_list, weight_graph_lap_from_edges
+
+MACResult = namedtuple('MACResult', ['w', 'F_unrounded', 'objective_values', 'duality_gaps'])
+
+
+class MAC:
+
+    def __init__(self, fixed_measurements, candidate_measurements, num_poses):
+        self.L_odom = weight_graph_lap_from_edge_list(fixed_measurements, num_poses)
+        self.num_poses = num_poses
+        self.weights = np.array([m.weight for m in candidate_measurements])
+        self.edge_list = np.array([(m.i, m.j) for m in candidate_measurements])
+        self.verbose = False
+
+    def find_fiedler_pair(self, L, method='tracemin_lu', tol=1e-8):
+        """(lambda_2(L), v_2(L)); reference mac.py:35-59."""
+        assert method == 'tracemin_lu'
+        return fiedler_tracemin_lu(L, tol=tol, seed=np.random.RandomState(7))
+
+    def combined_laplacian(self, w, tol=1e-10):
+        """L(w): fixed edges plus candidates weighted by w (reference mac.py:61-77)."""
+        idx = np.where(w > tol)
+        prod = w[idx] * self.weights[idx]
+        C1 = weight_graph_lap_from_edges(self.edge_list[idx], prod, self.num_poses)
+        return self.L_odom + C1
+
+    def evaluate_fiedler_pair(self, w, method='tracemin_lu', tol=1e-8):
+        return self.find_fiedler_pair(self.combined_laplacian(w), method, tol)
+
+    def evaluate_objective(self, w):
+        return self.find_fiedler_pair(self.combined_laplacian(w))[0]
+
+    def grad_from_fiedler(self, fiedler_vec):
+        """Supergradient of lambda_2 w.r.t. w (reference mac.py:112-130):
+        kdelta = weight_k (v_i - v_j);  grad_k = kdelta (v_i - v_j)."""
+        if len(self.weights) == 0:
+            return np.zeros(0)
+        d = fiedler_vec[self.edge_list[:, 0]] - fiedler_vec[self.edge_list[:, 1]]
+        return (self.weights * d) * d
+
+    def round_solution(self, w, k):
+        """Top-k indicator, ties broken arbitrarily (reference mac.py:132-147)."""
+        idx = np.argpartition(w, -k)[-k:]
+        rounded = np.zeros(len(w))
+        if k > 0:
+            rounded[idx] = 1.0
+        return rounded
+
+    def simple_random_round(self, w, k):
+        """Independent Bernoulli rounding (reference mac.py:149-166)."""
+        x = np.zeros(len(w))
+        for i in range(len(w)):
+            if w[i] > np.random.rand():
+                x[i] = 1.0
+        return x
+
+    def round_solution_tiebreaker(self, w, k, decimal_tol=10):
+        """Top-k of w rounded to `decimal_tol` decimals, ties towards larger edge weight
+        (reference mac.py:168-189)."""
+        zipped = np.empty(len(w), dtype=[('w', 'float'), ('weight', 'float')])
+        zipped['w'] = w.round(decimals=decimal_tol)
+        zipped['weight'] = self.weights
+        idx = np.argpartition(zipped, -k, order=['w', 'weight'])[-k:]
+        rounded = np.zeros(len(w))
+        if k > 0:
+            rounded[idx] = 1.0
+        return rounded
+
+    def fw_subset(self, w_init, k, max_iters=5, duality_gap_tol=1e-8, trace=None):
+        """Frank-Wolfe on the relaxed subset selection (reference mac.py:191-233).
+        Returns (rounded solution, unrounded iterate, dual upper bound)."""
+        u_i = float("inf")
+        w_i = w_init
+        for it in range(max_iters):
+            f_i, vec_i = self.evaluate_fiedler_pair(w_i)
+            grad_i = self.grad_from_fiedler(vec_i)
+            if trace is not None:
+                trace.append((float(f_i), float(np.linalg.norm(grad_i))))
+            s_i = self.round_solution(grad_i, k)
+            u_i = min(u_i, f_i + grad_i @ (s_i - w_i))
+            if u_i - f_i < duality_gap_tol:
+                if self.verbose:
+                    print("Duality gap tolerance reached, found optimal solution")
+                return self.round_solution_tiebreaker(w_i, k), w_i, u_i
+            alpha = 2.0 / (it + 2.0)
+            w_i = w_i + alpha * (s_i - w_i)
+        if self.verbose:
+            print("Reached maximum iterations")
+        return self.round_solution_tiebreaker(w_i, k), w_i, u_i

@@ -1,0 +1,114 @@
+"""CosPlace global descriptor on an MI355X (reference: cslam/vpr/cosplace.py and
+cslam/vpr/cosplace_utils/{network,layers}.py).
+
+Drop-in class `CosPlace(params, node)` with `compute_embedding(keyframe) -> np.ndarray`.
+Backbone (ResNet-18/50/101/152 or VGG-16 trunk) runs on PyTorch-ROCm; the transform and the
+aggregation head L2Norm -> GeM -> Flatten -> Linear -> L2Norm are HIP kernels.
+"""
+from os.path import isfile, join
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import _lib
+from . import heads
+from .backbones import get_backbone
+from .netvlad import _share_dir
+
+IMAGENET_DEFAULT_MEAN = heads.IMAGENET_DEFAULT_MEAN
+IMAGENET_DEFAULT_STD = heads.IMAGENET_DEFAULT_STD
+
+
+class GeoLocalizationNet(object):
+    """Backbone + aggregation head (reference cosplace_utils/network.py:19-35).  Parameter
+    names of the reference checkpoint: 'backbone.*', 'aggregation.1.p' (GeM),
+    'aggregation.3.weight|bias' (Linear)."""
+
+    def __init__(self, backbone, fc_output_dim, device):
+        self.backbone, self.features_dim = get_backbone(backbone)
+        self.backbone = self.backbone.to(device).eval()
+        for p in self.backbone.parameters():
+            p.requires_grad_(False)
+        self.gem_p, self.gem_eps = 3.0, 1e-6
+        lin = nn.Linear(self.features_dim, fc_output_dim)
+        self.fc_weight = lin.weight.detach().to(device).contiguous()
+        self.fc_bias = lin.bias.detach().to(device).contiguous()
+        self.device = device
+
+    def load_state_dict(self, state):
+        bb = {k[len("backbone."):]: v for k, v in state.items() if k.startswith("backbone.")}
+        self.backbone.load_state_dict(bb)
+        self.gem_p = float(state["aggregation.1.p"].reshape(-1)[0])
+        self.fc_weight = state["aggregation.3.weight"].float().to(self.device).contiguous()
+        self.fc_bias = state["aggregation.3.bias"].float().to(self.device).contiguous()
+
+    @torch.no_grad()
+    def forward(self, x, backbone_dtype=None):
+        if backbone_dtype is not None and backbone_dtype != torch.float32:
+            with torch.autocast("cuda", dtype=backbone_dtype):
+                f = self.backbone(x)
+            f = f.float()
+        else:
+            f = self.backbone(x)
+        return heads.gem_fc_head(f.contiguous(), self.gem_p, self.gem_eps, self.fc_weight, self.fc_bias)
+
+
+class CosPlace(object):
+    """CosPlace matcher"""
+
+    def __init__(self, params, node):
+        self.params = params
+        self.node = node
+        self.enable = self.params['frontend.nn_checkpoint'].lower() != 'disable'
+        self.descriptor_dim = self.params.get('frontend.cosplace.descriptor_dim', 64)
+        if not self.enable:
+            return
+        _lib.require_gpu()
+        if not torch.cuda.is_available():
+            raise _lib.CslamHipError("CosPlace needs PyTorch-ROCm with a visible MI355X")
+        self.device = torch.device("cuda")
+        self.crop = int(self.params["frontend.image_crop_size"])
+        self.model = GeoLocalizationNet(self.params['frontend.cosplace.backbone'], self.descriptor_dim,
+                                        self.device)
+        ckpt = self.params['frontend.nn_checkpoint']
+        if ckpt == 'random':               # benchmark / test mode: seeded random weights, no files
+            self.random_init(int(self.params.get('frontend.random_seed', 0)))
+            return
+        resume_ckpt = join(_share_dir(), ckpt)
+        if isfile(resume_ckpt):
+            self._log("info", "loading checkpoint '{}'".format(resume_ckpt))
+            self.model.load_state_dict(torch.load(resume_ckpt, map_location="cpu"))
+        else:
+            self._log("error", "Error: Checkpoint path is incorrect {}".format(resume_ckpt))
+            raise SystemExit()             # the reference calls exit() here (cosplace.py:68-70)
+
+    def _log(self, level, msg):
+        if self.node is not None:
+            getattr(self.node.get_logger(), level)(msg)
+
+    def random_init(self, seed=0):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        with torch.no_grad():
+            for m in self.model.backbone.modules():
+                if isinstance(m, nn.Conv2d):
+                    fan_in = m.in_channels * m.kernel_size[0] * m.kernel_size[1]
+                    m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (2.0 / fan_in) ** 0.5)
+                    if m.bias is not None:
+                        m.bias.zero_()
+            w = torch.randn((self.descriptor_dim, self.model.features_dim), generator=g) / self.model.features_dim ** 0.5
+            self.model.fc_weight = w.to(self.device).contiguous()
+            self.model.fc_bias = torch.zeros(self.descriptor_dim, device=self.device)
+
+    @torch.no_grad()
+    def compute_embeddings_device(self, frames_u8, backbone_dtype=None):
+        """frames [B,H,W,3] uint8 (device) -> descriptors [B, d] float32 (device)."""
+        x = heads.preprocess(frames_u8.contiguous(), self.crop)
+        return self.model.forward(x, backbone_dtype)
+
+    def compute_embedding(self, keyframe):
+        """Global image descriptor of one RGB keyframe (reference cosplace.py:81-105)."""
+        if not self.enable:
+            return np.random.rand(self.descriptor_dim)
+        frame = torch.from_numpy(np.ascontiguousarray(keyframe)).to(self.device).unsqueeze(0)
+        return self.compute_embeddings_device(frame)[0].cpu().numpy()

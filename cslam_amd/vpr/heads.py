@@ -1,0 +1,80 @@
+"""torch-tensor front ends of the HIP descriptor heads (C ABI: include/cslam_hip.h).
+
+PyTorch is plumbing here (device memory + the current stream); the arithmetic is in
+cslam_amd/csrc/heads.hip and gemm_nt.hip.  Every function requires CUDA(ROCm) tensors.
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+
+IMAGENET_DEFAULT_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_DEFAULT_STD = (0.229, 0.224, 0.225)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _chk(t, dtype=torch.float32):
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise _lib.CslamHipError("HIP heads need contiguous device tensors of dtype %s" % dtype)
+
+
+def preprocess(frames_u8, crop, out_hw=224, mean=IMAGENET_DEFAULT_MEAN, std=IMAGENET_DEFAULT_STD):
+    """[B,H,W,3] uint8 RGB -> [B,3,out_hw,out_hw] float32 (netvlad.py:202-208)."""
+    _chk(frames_u8, torch.uint8)
+    B, H, W, _ = frames_u8.shape
+    out = torch.empty((B, 3, out_hw, out_hw), dtype=torch.float32, device=frames_u8.device)
+    m, s = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    _lib.check(_lib.load().cslam_preprocess_dev(_p(frames_u8), B, H, W, int(crop), int(out_hw), C.byref(m),
+                                                C.byref(s), _p(out), _stream(out)))
+    return out
+
+
+def vlad_aggregate(feat, assign_w, assign_b, centroids):
+    """[B,C,h,w] -> [B, 64*C]  NetVLADLayer.forward (netvlad.py:94-130)."""
+    _chk(feat); _chk(assign_w); _chk(centroids)
+    B, Cc = feat.shape[:2]
+    P = feat.shape[2] * feat.shape[3]
+    K = centroids.shape[0]
+    out = torch.empty((B, K * Cc), dtype=torch.float32, device=feat.device)
+    _lib.check(_lib.load().cslam_vlad_aggregate_dev(_p(feat), _p(assign_w), _p(assign_b) if assign_b is not None else None,
+                                                    _p(centroids), B, Cc, P, K, _p(out), _stream(out)))
+    return out
+
+
+def gem_fc_head(feat, p, eps, W, b):
+    """[B,C,h,w] -> [B,Dout]  L2Norm->GeM->Flatten->Linear->L2Norm (network.py:23-29)."""
+    _chk(feat); _chk(W)
+    B, Cc = feat.shape[:2]
+    P = feat.shape[2] * feat.shape[3]
+    out = torch.empty((B, W.shape[0]), dtype=torch.float32, device=feat.device)
+    _lib.check(_lib.load().cslam_gem_fc_head_dev(_p(feat), float(p), float(eps), _p(W),
+                                                 _p(b) if b is not None else None, B, Cc, P, W.shape[0],
+                                                 _p(out), _stream(out)))
+    return out
+
+
+def pca_project(x, components, mean_proj, inv_scale):
+    """[B,Din] -> normalised [B,Dout] (netvlad.py:234-236)."""
+    _chk(x); _chk(components)
+    out = torch.empty((x.shape[0], components.shape[0]), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().cslam_pca_project_dev(_p(x), _p(components),
+                                                 _p(mean_proj) if mean_proj is not None else None,
+                                                 _p(inv_scale) if inv_scale is not None else None,
+                                                 x.shape[0], x.shape[1], components.shape[0], _p(out), _stream(out)))
+    return out
+
+
+def l2_normalize_(x, eps=1e-12, zero_norm_to_one=False):
+    """In-place row normalisation of a [n,d] tensor."""
+    _chk(x)
+    _lib.check(_lib.load().cslam_l2_normalize_dev(_p(x), x.shape[0], x.shape[1], x.stride(0), float(eps),
+                                                  int(zero_norm_to_one), _stream(x)))
+    return x

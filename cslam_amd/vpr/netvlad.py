@@ -1,0 +1,160 @@
+"""NetVLAD global descriptor on an MI355X (reference: cslam/vpr/netvlad.py).
+
+Drop-in class `NetVLAD(params, node)` with `compute_embedding(keyframe) -> np.ndarray`.
+Pipeline per frame (reference :212-241): CenterCrop -> bicubic Resize(224) -> ToTensor ->
+Normalize [HIP: cslam_preprocess_dev] -> VGG-16 conv5_3 encoder [PyTorch-ROCm] ->
+NetVLAD soft-assignment + residual aggregation + intra-norm + L2 [HIP: cslam_vlad_aggregate_dev]
+-> PCA projection + L2 [HIP fp32-MFMA GEMM: cslam_pca_project_dev].
+`compute_embeddings_device` is the batched, device-resident form used by bench.py and the
+batched matcher: frames and descriptors never leave HBM.
+"""
+import os
+import pickle
+from os.path import isfile, join
+
+import numpy as np
+import torch
+from torch import nn
+
+from .. import _lib
+from . import heads
+from .backbones import vgg16_features_trunk
+
+IMAGENET_DEFAULT_MEAN = heads.IMAGENET_DEFAULT_MEAN
+IMAGENET_DEFAULT_STD = heads.IMAGENET_DEFAULT_STD
+
+
+def _share_dir():
+    try:
+        from ament_index_python.packages import get_package_share_directory
+        return get_package_share_directory("cslam")
+    except Exception:
+        return ""
+
+
+def _strip_module(state):
+    return {k.replace(".module.", "."): v for k, v in state.items()}
+
+
+class NetVLADLayer(object):
+    """Parameters of the reference's NetVLADLayer (netvlad.py:28-61): 1x1 soft-assignment conv
+    (no bias in vladv1) and cluster centroids; forward runs in HIP."""
+
+    def __init__(self, num_clusters=64, dim=512, device="cuda"):
+        self.num_clusters, self.dim = num_clusters, dim
+        self.conv_weight = torch.zeros((num_clusters, dim), dtype=torch.float32, device=device)
+        self.conv_bias = None
+        self.centroids = torch.rand((num_clusters, dim), dtype=torch.float32, device=device)
+
+    def load(self, conv_weight, centroids, conv_bias=None):
+        dev = self.centroids.device
+        self.conv_weight = torch.as_tensor(conv_weight, dtype=torch.float32).reshape(self.num_clusters, self.dim).contiguous().to(dev)
+        self.centroids = torch.as_tensor(centroids, dtype=torch.float32).contiguous().to(dev)
+        self.conv_bias = None if conv_bias is None else torch.as_tensor(conv_bias, dtype=torch.float32).contiguous().to(dev)
+
+    def forward(self, x):
+        return heads.vlad_aggregate(x.contiguous(), self.conv_weight, self.conv_bias, self.centroids)
+
+    __call__ = forward
+
+
+class NetVLAD(object):
+    """NetVLAD matcher"""
+
+    def __init__(self, params, node):
+        self.params = params
+        self.node = node
+        self.enable = self.params['frontend.nn_checkpoint'].lower() != 'disable'
+        if not self.enable:
+            return
+        _lib.require_gpu()
+        if not torch.cuda.is_available():
+            raise _lib.CslamHipError("NetVLAD needs PyTorch-ROCm with a visible MI355X")
+        self.device = torch.device("cuda")
+        self.crop = int(self.params["frontend.image_crop_size"])
+        self.encoder = vgg16_features_trunk().to(self.device).eval()
+        self.pool = NetVLADLayer(num_clusters=64, dim=512, device=self.device)
+        self.pca_components = None     # [Dout, Din] device
+        self.pca_mean_proj = None      # [Dout] = mean @ components.T
+        self.pca_inv_scale = None
+        for p in self.encoder.parameters():
+            p.requires_grad_(False)
+
+        ckpt = self.params['frontend.nn_checkpoint']
+        if ckpt == 'random':               # benchmark / test mode: seeded random weights, no files
+            self.random_init(int(self.params.get('frontend.random_seed', 0)),
+                             int(self.params.get('frontend.netvlad.pca_dim', 4096)))
+            return
+        pkg_folder = _share_dir()
+        resume_ckpt = join(pkg_folder, ckpt)
+        pca_name = self.params.get('frontend.netvlad.pca_checkpoint')
+        if pca_name is None and node is not None:
+            pca_name = node.get_parameter('frontend.netvlad.pca_checkpoint').value
+        if isfile(resume_ckpt):
+            checkpoint = torch.load(resume_ckpt, map_location="cpu")
+            self.load_state_dict(checkpoint['state_dict'])
+        else:
+            print("Error: Checkpoint path is incorrect")     # reference prints and continues (:198-199)
+        pca = pickle.load(open(join(pkg_folder, pca_name), 'rb'))
+        self.set_pca(pca.components_, pca.mean_, getattr(pca, "explained_variance_", None),
+                     bool(getattr(pca, "whiten", False)))
+
+    # ------------------------------------------------------------------ weights ----
+    def load_state_dict(self, state):
+        """Reference checkpoint layout: 'encoder.<idx>.weight|bias', 'pool.conv.weight',
+        'pool.centroids' (optionally with DataParallel's '.module.')."""
+        state = _strip_module(state)
+        enc = {k[len("encoder."):]: v for k, v in state.items() if k.startswith("encoder.")}
+        self.encoder.load_state_dict(enc)
+        self.pool.load(state["pool.conv.weight"], state["pool.centroids"], state.get("pool.conv.bias"))
+
+    def set_pca(self, components, mean, explained_variance=None, whiten=False):
+        comp = np.ascontiguousarray(components, dtype=np.float32)
+        mean = np.asarray(mean, dtype=np.float32)
+        self.pca_components = torch.from_numpy(comp).to(self.device)
+        self.pca_mean_proj = torch.from_numpy((mean.reshape(1, -1) @ comp.T).reshape(-1).astype(np.float32)).to(self.device)
+        self.pca_inv_scale = None
+        if whiten:
+            scale = np.sqrt(np.asarray(explained_variance, dtype=np.float32))
+            scale[scale < np.finfo(np.float32).eps] = np.finfo(np.float32).eps
+            self.pca_inv_scale = torch.from_numpy((1.0 / scale).astype(np.float32)).to(self.device)
+
+    def random_init(self, seed=0, pca_dim=4096):
+        """Seeded random weights of the reference architecture (no checkpoint ships with cslam:
+        models/.gitignore); used for throughput runs and structural tests."""
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        with torch.no_grad():
+            for m in self.encoder.modules():
+                if isinstance(m, nn.Conv2d):
+                    fan_in = m.in_channels * 9
+                    m.weight.copy_(torch.randn(m.weight.shape, generator=g) * (2.0 / fan_in) ** 0.5)
+                    m.bias.zero_()
+        cent = torch.rand((64, 512), generator=g)
+        w = torch.randn((64, 512), generator=g) * 0.5
+        self.pool.load(w, cent)
+        din = 64 * 512
+        comp = torch.randn((pca_dim, din), generator=g, dtype=torch.float32) / din ** 0.5
+        self.pca_components = comp.to(self.device)
+        self.pca_mean_proj = torch.zeros(pca_dim, dtype=torch.float32, device=self.device)
+        self.pca_inv_scale = None
+
+    # ------------------------------------------------------------------ forward ----
+    @torch.no_grad()
+    def compute_embeddings_device(self, frames_u8, backbone_dtype=None):
+        """frames [B,H,W,3] uint8 (device) -> descriptors [B, d] float32 (device)."""
+        x = heads.preprocess(frames_u8.contiguous(), self.crop)
+        if backbone_dtype is not None and backbone_dtype != torch.float32:
+            with torch.autocast("cuda", dtype=backbone_dtype):
+                f = self.encoder(x)
+            f = f.float()
+        else:
+            f = self.encoder(x)
+        v = self.pool(f)
+        return heads.pca_project(v, self.pca_components, self.pca_mean_proj, self.pca_inv_scale)
+
+    def compute_embedding(self, keyframe):
+        """Global image descriptor of one RGB keyframe (reference :212-245)."""
+        if not self.enable:
+            return np.random.rand(128)
+        frame = torch.from_numpy(np.ascontiguousarray(keyframe)).to(self.device).unsqueeze(0)
+        return self.compute_embeddings_device(frame)[0].cpu().numpy()

@@ -1,0 +1,159 @@
+"""GPU parity tests of the descriptor heads and the image transform (-m gpu).
+
+Golden vectors come from the REFERENCE's own torch modules (NetVLADLayer, GeM/L2Norm/Flatten),
+sklearn's PCA and Pillow (oracle/gen_golden_heads.py); the numpy oracle is checked alongside.
+Tolerance: float32 kernels vs float32 reference modules, 1e-5 absolute on unit-norm outputs
+(north_star's fp32 gate); the integer resize is bit-exact.
+"""
+import numpy as np
+import pytest
+
+from helpers import GOLDEN
+from oracle import heads_oracle as ho
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def g():
+    return np.load(GOLDEN + "/heads_g.npz")
+
+
+@pytest.fixture(scope="module")
+def T():
+    import torch
+    from cslam_amd.vpr import heads
+    return torch, heads
+
+
+def dev(T, a):
+    torch, _ = T
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_vlad_matches_reference_layer(g, T):
+    torch, heads = T
+    for name in ("a", "b"):
+        x = g[f"vlad_{name}/x"]
+        y = heads.vlad_aggregate(dev(T, x), dev(T, g["vlad/conv_w"]), None, dev(T, g["vlad/centroids"])).cpu().numpy()
+        assert y.shape == g[f"vlad_{name}/y"].shape
+        assert np.max(np.abs(y - g[f"vlad_{name}/y"])) < 2e-7          # outputs are ~1e-2: tight absolute
+        o = ho.vlad_forward(x, g["vlad/conv_w"], None, g["vlad/centroids"])
+        assert np.max(np.abs(y - o)) < 2e-7
+        assert np.allclose(np.linalg.norm(y, axis=1), 1.0, atol=1e-5)
+
+
+def test_vlad_with_bias_and_odd_shapes(T):
+    torch, heads = T
+    rng = np.random.default_rng(0)
+    for (B, C, H, W) in [(3, 512, 5, 3), (1, 96, 20, 13), (2, 64, 1, 1)]:
+        x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+        w = rng.standard_normal((64, C)).astype(np.float32)
+        b = rng.standard_normal(64).astype(np.float32)
+        c = rng.random((64, C)).astype(np.float32)
+        y = heads.vlad_aggregate(dev(T, x), dev(T, w), dev(T, b), dev(T, c)).cpu().numpy()
+        o = ho.vlad_forward(x, w, b, c)
+        assert np.max(np.abs(y - o)) < 1e-6
+
+
+def test_cosplace_head_matches_reference_modules(g, T):
+    torch, heads = T
+    for tag in ("p3", "p237"):
+        x, W, b, p = g[f"gem_{tag}/x"], g[f"gem_{tag}/W"], g[f"gem_{tag}/b"], float(g[f"gem_{tag}/p"])
+        y = heads.gem_fc_head(dev(T, x), p, 1e-6, dev(T, W), dev(T, b)).cpu().numpy()
+        assert np.max(np.abs(y - g[f"gem_{tag}/y"])) < 1e-5
+        assert np.max(np.abs(y - ho.cosplace_head(x, p, 1e-6, W, b))) < 1e-5
+        assert np.allclose(np.linalg.norm(y, axis=1), 1.0, atol=1e-5)
+
+
+def test_pca_project_matches_sklearn(g, T):
+    torch, heads = T
+    for t in ("n", "w"):
+        comp, mean, var, x = g[f"pca_{t}/components"], g[f"pca_{t}/mean"], g[f"pca_{t}/var"], g[f"pca_{t}/x"]
+        mean_proj = (mean.reshape(1, -1) @ comp.T).reshape(-1).astype(np.float32)
+        inv = None
+        if t == "w":
+            inv = dev(T, (1.0 / np.sqrt(var)).astype(np.float32))
+        y = heads.pca_project(dev(T, x), dev(T, comp), dev(T, mean_proj), inv).cpu().numpy()
+        assert np.max(np.abs(y - g[f"pca_{t}/y"])) < 1e-5
+        assert np.max(np.abs(y - ho.pca_transform_normalize(x, comp, mean, var, t == "w"))) < 1e-5
+
+
+def test_pca_gemm_full_shape_split_k(T):
+    """NetVLAD's real projection shape (32768 -> 4096), batch 130 (ragged tile), vs float64 numpy."""
+    torch, heads = T
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn((130, 32768), generator=gen, device="cuda")
+    comp = torch.randn((4096, 32768), generator=gen, device="cuda") / 181.0
+    y = heads.pca_project(x, comp, None, None)
+    ref = (x[:8].double() @ comp.double().T)
+    ref = ref / ref.norm(dim=1, keepdim=True)
+    assert float((y[:8].double() - ref).abs().max()) < 1e-5
+    yb = heads.pca_project(x[122:].contiguous(), comp, None, None)        # batch-size independence
+    assert float((yb - y[122:]).abs().max()) < 1e-6
+
+
+def test_l2_normalize_variants(T):
+    torch, heads = T
+    x = torch.randn((37, 1000), device="cuda") * 3
+    x[5] = 0
+    a = heads.l2_normalize_(x.clone())
+    assert torch.allclose(a, torch.nn.functional.normalize(x, dim=1), atol=1e-6)
+    b = heads.l2_normalize_(x.clone(), zero_norm_to_one=True)
+    assert float(b[5].abs().max()) == 0.0 and torch.allclose(b[6], x[6] / x[6].norm(), atol=1e-6)
+
+
+def test_preprocess_bit_exact_vs_pillow(g, T):
+    torch, heads = T
+    for i in range(2):
+        img = np.random.default_rng(7 + i).integers(0, 256, size=(480, 640, 3), dtype=np.uint8)
+        if i == 1:
+            yy, xx = np.mgrid[0:480, 0:640]
+            img = np.stack([(xx * 255 // 639), (yy * 255 // 479), ((xx // 40 + yy // 40) % 2) * 255],
+                           axis=2).astype(np.uint8)
+        out = heads.preprocess(dev(T, img[None]), 376).cpu().numpy()[0]
+        gold = g[f"prep_{i}/out"]
+        # recover the uint8 resize result: must be identical to Pillow's
+        mean = np.array(heads.IMAGENET_DEFAULT_MEAN, dtype=np.float32)[:, None, None]
+        std = np.array(heads.IMAGENET_DEFAULT_STD, dtype=np.float32)[:, None, None]
+        u8 = np.rint((out * std + mean) * 255.0).astype(np.int64).transpose(1, 2, 0)
+        assert np.array_equal(u8, g[f"prep_{i}/resized_u8"].astype(np.int64))
+        assert np.max(np.abs(out - gold)) <= 2.4e-7           # <= 1 float32 ulp at |x| <= 2.7
+    # batch of frames, other crop size
+    imgs = np.random.default_rng(3).integers(0, 256, size=(3, 300, 400, 3), dtype=np.uint8)
+    out = heads.preprocess(dev(T, imgs), 256, 112).cpu().numpy()
+    for b in range(3):
+        o = ho.preprocess(imgs[b], 256, 112, heads.IMAGENET_DEFAULT_MEAN, heads.IMAGENET_DEFAULT_STD)
+        assert np.max(np.abs(out[b] - o)) <= 2.4e-7
+
+
+def test_extractors_end_to_end_structure(T):
+    """NetVLAD / CosPlace drop-in classes with seeded random weights (no checkpoints ship with
+    the reference): HIP pipeline == the same pipeline restated with torch + the numpy oracle."""
+    torch, heads = T
+    from cslam_amd.vpr.netvlad import NetVLAD
+    from cslam_amd.vpr.cosplace import CosPlace
+    frames = np.random.default_rng(1).integers(0, 256, size=(2, 480, 640, 3), dtype=np.uint8)
+    nv = NetVLAD({"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376,
+                  "frontend.netvlad.pca_dim": 128}, None)
+    e = nv.compute_embedding(frames[0])
+    assert e.shape == (128,) and e.dtype == np.float32 and abs(np.linalg.norm(e) - 1) < 1e-5
+    x = torch.from_numpy(ho.preprocess(frames[0], 376, 224, heads.IMAGENET_DEFAULT_MEAN,
+                                       heads.IMAGENET_DEFAULT_STD))[None].cuda()
+    with torch.no_grad():
+        f = nv.encoder(x)
+    v = ho.vlad_forward(f.cpu().numpy(), nv.pool.conv_weight.cpu().numpy(), None, nv.pool.centroids.cpu().numpy())
+    ref = ho.sk_normalize(v @ nv.pca_components.cpu().numpy().T)
+    assert np.max(np.abs(e - ref[0])) < 1e-5
+    cp = CosPlace({"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376,
+                   "frontend.cosplace.descriptor_dim": 512, "frontend.cosplace.backbone": "resnet18"}, None)
+    e = cp.compute_embeddings_device(torch.from_numpy(frames).cuda()).cpu().numpy()
+    assert e.shape == (2, 512) and np.allclose(np.linalg.norm(e, axis=1), 1, atol=1e-5)
+    xs = np.stack([ho.preprocess(fr, 376, 224, heads.IMAGENET_DEFAULT_MEAN, heads.IMAGENET_DEFAULT_STD)
+                   for fr in frames])
+    with torch.no_grad():
+        f = cp.model.backbone(torch.from_numpy(xs).cuda())
+    ref = ho.cosplace_head(f.cpu().numpy(), 3.0, 1e-6, cp.model.fc_weight.cpu().numpy(),
+                           cp.model.fc_bias.cpu().numpy())
+    assert np.max(np.abs(e - ref)) < 1e-5
+    assert NetVLAD({"frontend.nn_checkpoint": "disable"}, None).compute_embedding(frames[0]).shape == (128,)

@@ -1,0 +1,220 @@
+"""CPU suite: candidate sparsifier host logic (cslam_amd.algebraic_connectivity_maximization,
+cslam_amd.mac) against golden vectors recorded from the REFERENCE classes
+(tests/golden/mac_g7.npz, made by oracle/gen_golden_mac.py), plus the reference's own
+property tests (tests/test_algebraic_connectivity.py) re-expressed for this package.
+"""
+import random
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN
+from cslam_amd.algebraic_connectivity_maximization import AlgebraicConnectivityMaximization, EdgeInterRobot
+from cslam_amd.mac.mac import MAC
+from cslam_amd.mac.utils import Edge, weight_graph_lap_from_edge_list
+
+
+@pytest.fixture(scope="module")
+def g7():
+    return np.load(GOLDEN + "/mac_g7.npz")
+
+
+def _edges(arr):
+    return [EdgeInterRobot(int(a), int(b), int(c), int(d), float(w)) for a, b, c, d, w in arr]
+
+
+@pytest.mark.parametrize("tag,R,K", [("mac_R1_P100_C50_K10", 1, 10), ("mac_R3_P100_C100_K10", 3, 10),
+                                     ("mac_R5_P100_C200_K100", 5, 100), ("mac_R8_P400_C600_K60", 8, 60)])
+def test_selection_identical_to_reference(g7, tag, R, K):
+    trace = []
+    orig = MAC.fw_subset
+
+    def traced(self, w_init, k, max_iters=5, duality_gap_tol=1e-8, trace=None):
+        return orig(self, w_init, k, max_iters=max_iters, duality_gap_tol=duality_gap_tol, trace=trace_sink)
+
+    trace_sink = trace
+    MAC.fw_subset = traced
+    try:
+        ac = AlgebraicConnectivityMaximization(robot_id=0, max_nb_robots=R)
+        ac.set_graph(_edges(g7[tag + "/fixed"]), _edges(g7[tag + "/cand"]))
+        sel = ac.select_candidates(K, {r: True for r in range(R)}, greedy_initialization=True)
+    finally:
+        MAC.fw_subset = orig
+    got = np.array([tuple(e) for e in sel], dtype=np.float64).reshape(-1, 5)
+    assert np.array_equal(got, g7[tag + "/selected"])                       # same edges, same order
+    ref_trace = g7[tag + "/trace"]
+    assert len(trace) == len(ref_trace)
+    if len(trace):
+        t = np.array(trace)
+        assert np.allclose(t[:, 0], ref_trace[:, 0], rtol=1e-9, atol=1e-13)  # lambda_2 per FW iteration
+        assert np.allclose(t[:, 1], ref_trace[:, 1], rtol=1e-7, atol=1e-13)  # ||grad||
+    assert np.array_equal(np.array(sorted(ac.candidate_edges.keys()), dtype=np.int64).reshape(-1, 4),
+                          g7[tag + "/remaining"])
+
+
+def test_bookkeeping_script_identical_to_reference(g7):
+    R = 3
+    ac = AlgebraicConnectivityMaximization(robot_id=1, max_nb_robots=R)
+    matches = [tuple(m) for m in g7["acm/matches"]]
+    for m in matches:
+        ac.add_match(EdgeInterRobot(int(m[0]), int(m[1]), int(m[2]), int(m[3]), float(m[4])))
+    for m in matches[:10]:
+        ac.add_match(EdgeInterRobot(int(m[2]), int(m[3]), int(m[0]), int(m[1]), float(m[4]) + 0.5))
+        ac.add_match(EdgeInterRobot(int(m[0]), int(m[1]), int(m[2]), int(m[3]), float(m[4]) - 0.5))
+
+    def check(step):
+        keys = sorted(ac.candidate_edges.keys())
+        assert np.array_equal(np.array(keys, dtype=np.int64).reshape(-1, 4), g7[f"acm/s{step}_keys"])
+        assert np.array_equal(np.array([ac.candidate_edges[k].weight for k in keys]), g7[f"acm/s{step}_w"])
+        assert [ac.nb_poses[r] for r in range(R)] == list(g7[f"acm/s{step}_nb_poses"])
+        assert [ac.initial_fixed_edge_exists[r] for r in range(R)] == list(g7[f"acm/s{step}_ife"])
+        assert len(ac.fixed_edges) == int(g7[f"acm/s{step}_nfixed"])
+        assert np.array_equal(np.array(sorted(ac.already_considered_matches), dtype=np.int64).reshape(-1, 4),
+                              g7[f"acm/s{step}_considered"])
+
+    def same(sel, name):
+        assert np.array_equal(np.array([tuple(e) for e in sel], dtype=np.float64).reshape(-1, 5), g7[name])
+
+    check(0)
+    inr = {0: True, 1: True, 2: True}
+    sel0 = ac.select_candidates(5, inr); same(sel0, "acm/sel0"); check(1)
+    ac.candidate_edges_to_fixed(list(sel0[:3]))
+    ac.remove_candidate_edges(list(sel0[3:]), failed=True); check(2)
+    sel1 = ac.select_candidates(4, inr); same(sel1, "acm/sel1"); check(3)
+    sel2 = ac.select_candidates(4, {0: True, 1: True, 2: False}); same(sel2, "acm/sel2"); check(4)
+    ac.compute_offsets(ac.check_graph_disconnections({0: True, 1: True, 2: False}))
+    assert [ac.offsets[r] for r in range(R)] == list(g7["acm/final_offsets"])
+
+
+# ---- the reference's property tests, re-expressed (tests/test_algebraic_connectivity.py) ----
+def build_multi_robot_graph(nb_poses, nb_candidate_edges, max_nb_robots, rnd):
+    fixed = [EdgeInterRobot(i, nb_poses - 1, i + 1, nb_poses - 1, 1) for i in range(max_nb_robots - 1)]
+    cand = {}
+    while len(cand) < nb_candidate_edges:
+        r0 = rnd.randrange(max_nb_robots)
+        r1 = rnd.choice([r for r in range(max_nb_robots) if r != r0])
+        e = EdgeInterRobot(r0, rnd.randrange(nb_poses), r1, rnd.randrange(nb_poses), 1)
+        key = (e.robot0_id, e.robot0_keyframe_id, e.robot1_id, e.robot1_keyframe_id) if r0 < r1 else \
+              (e.robot1_id, e.robot1_keyframe_id, e.robot0_id, e.robot0_keyframe_id)
+        cand[key] = e
+    return fixed, list(cand.values())
+
+
+def build_simple_graph(nb_poses, nb_candidate_edges, rnd):
+    cand = {}
+    while len(cand) < nb_candidate_edges:
+        e = EdgeInterRobot(0, rnd.randrange(nb_poses), 0, rnd.randrange(nb_poses), 1)
+        cand[(e.robot0_keyframe_id, e.robot1_keyframe_id)] = e
+    return [], list(cand.values())
+
+
+def test_edge_equality_ignores_weight_and_direction():
+    a = EdgeInterRobot(0, 1, 2, 3, 0.5)
+    assert a == EdgeInterRobot(0, 1, 2, 3, 0.9) and a == EdgeInterRobot(2, 3, 0, 1, 0.1)
+    assert not (a == EdgeInterRobot(0, 1, 2, 4, 0.5))
+    assert a in [EdgeInterRobot(2, 3, 0, 1, 7.0)]
+
+
+def test_selection_sizes_and_no_reselection():
+    rnd = random.Random(0)
+    np.random.seed(0)
+    fixed, cand = build_simple_graph(100, 50, rnd)
+    ac = AlgebraicConnectivityMaximization()
+    ac.set_graph(fixed, cand)
+    before = list(ac.candidate_edges.values())
+    sel0 = ac.select_candidates(10, {0: True}, greedy_initialization=False)
+    assert len(sel0) == 10 and len(set(sel0)) == 10
+    assert all(e in before for e in sel0)
+    ac.candidate_edges_to_fixed(sel0)
+    assert all(e not in list(ac.candidate_edges.values()) for e in sel0)
+    sel1 = ac.select_candidates(10, {0: True}, greedy_initialization=False)
+    for e0 in sel0:
+        for e1 in sel1:
+            assert not (e0.robot0_keyframe_id == e1.robot0_keyframe_id and
+                        e0.robot1_keyframe_id == e1.robot1_keyframe_id)
+    for i in range(10):
+        ac.add_candidate_edge(EdgeInterRobot(0, rnd.randrange(100), 0, rnd.randrange(100), 1.0))
+    assert len(ac.select_candidates(12, {0: True}, greedy_initialization=False)) == 12
+
+
+def test_greedy_initialization_is_topk_weight_sum():
+    rnd = random.Random(1)
+    fixed, cand = build_simple_graph(100, 50, rnd)
+    weights = np.random.default_rng(1).random(50)
+    ac = AlgebraicConnectivityMaximization()
+    cand = [ac.replace_weight(e, weight=w) for e, w in zip(cand, weights)]
+    ac.set_graph(fixed, cand)
+    inc = ac.check_graph_disconnections({0: True})
+    ac.compute_offsets(inc)
+    edges = ac.rekey_edges(ac.candidate_edges.values(), inc)
+    w_init = ac.greedy_initialization(10, edges)
+    assert abs(np.sum(weights[w_init.astype(bool)]) - np.sum(np.sort(weights)[-10:])) < 1e-12
+
+
+def test_offsets_rekey_roundtrip_and_exclusion():
+    rnd = random.Random(2)
+    fixed, cand = build_multi_robot_graph(10, 10, 5, rnd)
+    ac = AlgebraicConnectivityMaximization(robot_id=1, max_nb_robots=5)
+    ac.set_graph(fixed, cand)
+    considered = {i: True for i in range(5)}
+    inc = ac.check_graph_disconnections(considered)
+    assert all(inc.values())
+    ac.compute_offsets(inc)
+    for r in range(1, 5):
+        assert ac.offsets[r] == ac.offsets[r - 1] + ac.nb_poses[r - 1]
+    rek = ac.rekey_edges(ac.candidate_edges.values(), inc)
+    back = ac.recover_inter_robot_edges(rek, inc)
+    assert back == list(ac.candidate_edges.values())
+    for e in rek:
+        assert 0 <= e.i < sum(ac.nb_poses.values()) and 0 <= e.j < sum(ac.nb_poses.values())
+    considered[2] = False
+    inc = ac.check_graph_disconnections(considered)
+    assert not inc[2] and inc[0] and inc[1] and inc[3] and inc[4]
+    ac.compute_offsets(inc)
+    assert ac.offsets[2] == 0 and ac.offsets[3] == ac.offsets[1] + ac.nb_poses[1]
+    assert all(e.robot0_id != 2 and e.robot1_id != 2 for e in
+               ac.get_included_edges(ac.candidate_edges.values(), inc))
+
+
+def test_add_match_keeps_max_weight_only_for_ordered_key():
+    """The reference quirk (acm.py:559-572): the lookup key is not direction-normalised."""
+    ac = AlgebraicConnectivityMaximization(robot_id=0, max_nb_robots=2)
+    ac.add_match(EdgeInterRobot(0, 1, 1, 2, 0.5))
+    ac.add_match(EdgeInterRobot(0, 1, 1, 2, 0.3))
+    assert ac.candidate_edges[(0, 1, 1, 2)].weight == 0.5
+    ac.add_match(EdgeInterRobot(0, 1, 1, 2, 0.8))
+    assert ac.candidate_edges[(0, 1, 1, 2)].weight == 0.8
+    ac.add_match(EdgeInterRobot(1, 2, 0, 1, 0.1))      # reversed direction: overwrites (quirk)
+    assert ac.candidate_edges[(0, 1, 1, 2)].weight == 0.1
+
+
+def test_remove_candidates_and_never_reconsider():
+    rnd = random.Random(3)
+    fixed, cand = build_multi_robot_graph(10, 10, 3, rnd)
+    ac = AlgebraicConnectivityMaximization(robot_id=0, max_nb_robots=3)
+    ac.set_graph(fixed, cand)
+    n0 = len(ac.candidate_edges)
+    first = list(ac.candidate_edges.values())[0]
+    ac.remove_candidate_edges([first])
+    assert len(ac.candidate_edges) == n0 - 1
+    ac.remove_candidate_edges([EdgeInterRobot(0, 1, 4, 1, 1.0)])
+    assert len(ac.candidate_edges) == n0 - 1
+    ac.add_candidate_edge(first)                       # already considered -> ignored
+    assert len(ac.candidate_edges) == n0 - 1
+
+
+def test_laplacian_assembly_and_gradient():
+    edges = [Edge(0, 1, 1.0), Edge(1, 2, 2.0), Edge(0, 2, 0.5), Edge(1, 2, 0.25)]
+    L = weight_graph_lap_from_edge_list(edges, 4).toarray()
+    ref = np.zeros((4, 4))
+    for e in edges:
+        ref[e.i, e.i] += e.weight; ref[e.j, e.j] += e.weight
+        ref[e.i, e.j] -= e.weight; ref[e.j, e.i] -= e.weight
+    assert np.array_equal(L, ref)
+    mac = MAC([Edge(k, k + 1, 1.0) for k in range(9)], [Edge(0, 9, 0.7), Edge(2, 6, 0.4)], 10)
+    lam, v = mac.evaluate_fiedler_pair(np.array([1.0, 0.0]))
+    Ld = mac.combined_laplacian(np.array([1.0, 0.0])).toarray()
+    w = np.linalg.eigvalsh(Ld)
+    assert abs(lam - w[1]) < 1e-8 and np.linalg.norm(Ld @ v - lam * v) < 1e-6
+    g = mac.grad_from_fiedler(v)
+    assert np.allclose(g, [0.7 * (v[0] - v[9]) ** 2, 0.4 * (v[2] - v[6]) ** 2])
