@@ -68,6 +68,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch wheels bundle their own ROCm runtime (torch/lib/libamdhip64.so ...).  Import torch
+    # first so that this library and torch share ONE HIP/HSA runtime in the process; loading
+    # /opt/rocm's copy first and torch's afterwards leaves the process without a visible GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise CslamHipError(
             f"{LIB_PATH} not found: the HIP extension is not built "
