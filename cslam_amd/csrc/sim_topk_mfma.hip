@@ -258,13 +258,13 @@ __global__ __launch_bounds__(MF_THREADS, 2) void sim_topk_mfma_kernel(MfmaArgs p
 
 // ---- query preparation: float32 padded copy, per-query row limits, per-tile max limit ----
 template <typename QS>
-__global__ void mfma_prep_kernel(const QS *__restrict__ q, int64_t ldq, int nq, int dim, int ld,
+__global__ void mfma_prep_kernel(const QS *__restrict__ q, int64_t ldq, int nq, int dim, int kd, int ld,
                                  float *__restrict__ q32, const int64_t *__restrict__ row_limit,
                                  int n_rows, int *__restrict__ lim, int *__restrict__ qt_maxlim, int nq_pad) {
     const int row = blockIdx.x;
     if (row >= nq_pad) return;
     if (q32) {
-        for (int c = threadIdx.x; c < ld; c += blockDim.x)
+        for (int c = threadIdx.x; c < kd; c += blockDim.x)
             q32[(size_t)row * ld + c] = (row < nq && c < dim) ? (float)q[(size_t)row * ldq + c] : 0.0f;
     }
     if (threadIdx.x == 0) {
@@ -283,7 +283,7 @@ __global__ void mfma_prep_kernel(const QS *__restrict__ q, int64_t ldq, int nq, 
 // ---- stage 2: merge, float64 re-score, exact order, certificate ---------------------------
 template <typename QS>
 __global__ __launch_bounds__(256) void rescore_kernel(
-    const float *__restrict__ bank, int ld, const double *__restrict__ vv,
+    const float *__restrict__ bank, int64_t pitch, int ld, const double *__restrict__ vv,
     const QS *__restrict__ q, int64_t ldq, int dim, int nq,
     const float *__restrict__ part_key, const int *__restrict__ part_idx, int nseg,
     int k, double err_bound,
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void rescore_kernel(
     const int nchunk = ld >> 2;
     for (int c0 = 0; c0 < nres; ++c0) {
         const int row = cand.idx_at(c0);
-        const float4 *rp = (const float4 *)(bank + (size_t)row * ld);
+        const float4 *rp = (const float4 *)(bank + (size_t)row * pitch);
         double acc = 0.0;
 #pragma unroll 4
         for (int c = lane; c < nchunk; c += 64) {
@@ -401,18 +401,36 @@ __global__ __launch_bounds__(256) void rescore_kernel(
 int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_t nq, int k,
                 const int64_t *d_row_limit, int64_t *d_out_idx, double *d_out_sim,
                 int32_t *d_out_cnt, hipStream_t st) {
-    const int ld = b->ld;
+    const int ld = b->ld, kd = b->kd;
     const int nqt = (int)ceil_div64(nq, TN);
     const int nq_pad = nqt * TN;
     const int n_btiles = (int)ceil_div64(b->n, TM);
-    int nseg = (int)ceil_div64(8 * 2 * b->num_cu, nqt);
-    int max_seg = n_btiles / 4; if (max_seg < 1) max_seg = 1;
-    if (nseg > max_seg) nseg = max_seg;
-    if (nseg < 1) nseg = 1;
-    const int tps = (int)ceil_div64(n_btiles, nseg);
-    nseg = (int)ceil_div64(n_btiles, tps);
+    // Segment count: all work items take the same time and the chip holds S = 2 workgroups per CU,
+    // so the grid runs in ceil(T/S) rounds; pick the split whose last round is fullest
+    // (C3: 782 query tiles x 17 segments = 13294 items = 25.96 rounds instead of 9.16 with 6),
+    // discounting the fixed per-item cost (prologue, list merge ~ 0.3 tile-times) and preferring
+    // fewer segments (shorter candidate merge in rescore_kernel).
+    const int slots = 2 * b->num_cu;
+    int nseg = 1, tps = n_btiles;
+    {
+        double best = -1.0;
+        int max_seg = (int)ceil_div64(slots, nqt);      // few query tiles: split finer to fill the chip
+        if (max_seg < 64) max_seg = 64;
+        if (max_seg > n_btiles) max_seg = n_btiles;
+        for (int s = 1; s <= max_seg; ++s) {
+            int t = (int)ceil_div64(n_btiles, s);
+            int se = (int)ceil_div64(n_btiles, t);
+            if (se != s) continue;
+            double T = (double)nqt * se;
+            double rounds = ceil(T / slots);
+            double eff = T / (rounds * slots) * ((double)t / (t + 0.3)) - 0.0005 * se;
+            if (eff > best) { best = eff; nseg = se; tps = t; }
+        }
+    }
 
-    const bool direct = q_dtype == CSLAM_F32 && b->dim == ld && (ldq % 4 == 0) && (((uintptr_t)d_q) % 16 == 0);
+    // queries are used in place only when their pitch is not L2-set-aliasing (see bank.hip)
+    const bool direct = q_dtype == CSLAM_F32 && b->dim == kd && (ldq % 4 == 0) && (ldq % 256 != 0) &&
+                        (((uintptr_t)d_q) % 16 == 0);
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = (size_t)round_up64((int64_t)(off + bytes), 256); return o; };
     size_t o_q32 = carve(direct ? 0 : (size_t)nq_pad * ld * 4);
@@ -437,16 +455,16 @@ int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_
     HIP_TRY(hipMemsetAsync(flag_count, 0, 4, st));
     if (q_dtype == CSLAM_F32)
         hipLaunchKernelGGL(mfma_prep_kernel<float>, dim3(nq_pad), dim3(256), 0, st, (const float *)d_q, ldq,
-                           (int)nq, b->dim, ld, q32, d_row_limit, (int)b->n, lim, qtm, nq_pad);
+                           (int)nq, b->dim, kd, ld, q32, d_row_limit, (int)b->n, lim, qtm, nq_pad);
     else
         hipLaunchKernelGGL(mfma_prep_kernel<double>, dim3(nq_pad), dim3(256), 0, st, (const double *)d_q, ldq,
-                           (int)nq, b->dim, ld, q32, d_row_limit, (int)b->n, lim, qtm, nq_pad);
+                           (int)nq, b->dim, kd, ld, q32, d_row_limit, (int)b->n, lim, qtm, nq_pad);
     HIP_TRY(hipGetLastError());
 
     MfmaArgs a;
     a.bank = b->rows; a.ldb = ld; a.invn = b->invn; a.n_rows = (int)b->n;
     a.q = direct ? (const float *)d_q : q32; a.ldq = direct ? ldq : ld; a.nq = direct ? (int)nq : nq_pad;
-    a.lim = lim; a.qt_maxlim = qtm; a.nkt = ld / TK;
+    a.lim = lim; a.qt_maxlim = qtm; a.nkt = kd / TK;
     a.nqt = nqt; a.nseg = nseg; a.tps = tps; a.n_btiles = n_btiles;
     a.part_key = part_key; a.part_idx = part_idx;
     static bool attr_set = false;
@@ -463,14 +481,14 @@ int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_
     // rigorous bound on |f32 key - exact| / ||q||: ld-term fma chain (gamma_ld), inv-norm
     // rounding, key multiply rounding, query f64->f32 rounding; 2^-24 unit roundoff.
     const double u = 5.9604644775390625e-08;
-    const double err_bound = 1.0625 * ((double)ld + 8.0) * u;
+    const double err_bound = 1.0625 * ((double)kd + 8.0) * u;
     const unsigned rgrid = (unsigned)ceil_div64(nq, 4);
     if (q_dtype == CSLAM_F32)
-        hipLaunchKernelGGL(rescore_kernel<float>, dim3(rgrid), dim3(256), 0, st, b->rows, ld, b->vv,
+        hipLaunchKernelGGL(rescore_kernel<float>, dim3(rgrid), dim3(256), 0, st, b->rows, (int64_t)ld, kd, b->vv,
                            (const float *)d_q, ldq, b->dim, (int)nq, part_key, part_idx, nseg, k, err_bound,
                            d_out_idx, d_out_sim, d_out_cnt, flag_list, flag_count);
     else
-        hipLaunchKernelGGL(rescore_kernel<double>, dim3(rgrid), dim3(256), 0, st, b->rows, ld, b->vv,
+        hipLaunchKernelGGL(rescore_kernel<double>, dim3(rgrid), dim3(256), 0, st, b->rows, (int64_t)ld, kd, b->vv,
                            (const double *)d_q, ldq, b->dim, (int)nq, part_key, part_idx, nseg, k, err_bound,
                            d_out_idx, d_out_sim, d_out_cnt, flag_list, flag_count);
     HIP_TRY(hipGetLastError());

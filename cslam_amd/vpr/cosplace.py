@@ -27,7 +27,7 @@ class GeoLocalizationNet(object):
 
     def __init__(self, backbone, fc_output_dim, device):
         self.backbone, self.features_dim = get_backbone(backbone)
-        self.backbone = self.backbone.to(device).eval()
+        self.backbone = self.backbone.to(device).eval().to(memory_format=torch.channels_last)
         for p in self.backbone.parameters():
             p.requires_grad_(False)
         self.gem_p, self.gem_eps = 3.0, 1e-6
@@ -103,7 +103,7 @@ class CosPlace(object):
     @torch.no_grad()
     def compute_embeddings_device(self, frames_u8, backbone_dtype=None):
         """frames [B,H,W,3] uint8 (device) -> descriptors [B, d] float32 (device)."""
-        x = heads.preprocess(frames_u8.contiguous(), self.crop)
+        x = heads.preprocess(frames_u8.contiguous(), self.crop).contiguous(memory_format=torch.channels_last)
         return self.model.forward(x, backbone_dtype)
 
     def compute_embedding(self, keyframe):
