@@ -149,16 +149,30 @@ def main():
     # roofline of the dominant hand-written kernel, from the launches inside the timed steps
     # (algorithmic work: 2*D flop per (query, bank row) pair)
     nq_step = world * a.batch if world > 1 else a.batch
+    # primary: the full C3 batch launch (100k queries) of the timed match leg; the smaller
+    # launches inside the extract+match steps are reported alongside
+    ach = 2.0 * nqm * a.bank_rows * a.dim / (match_kernel_ms * 1e-3) / 1e12
+    src = "match-leg launches (%d queries), HIP events on the launch stream" % nqm
+    in_step = None
     if step_kernel_ms and world == 1:
-        ach = 2.0 * nq_step * a.bank_rows * a.dim / (np.mean(step_kernel_ms) * 1e-3) / 1e12
-        src = "in-step launches"
-    else:
-        ach = 2.0 * nqm * a.bank_rows * a.dim / (match_kernel_ms * 1e-3) / 1e12
-        src = "match-only leg launches"
+        in_step = round(2.0 * nq_step * a.bank_rows * a.dim / (np.mean(step_kernel_ms) * 1e-3) / 1e12, 2)
+    # HBM-side traffic per launch comes from the committed rocprofv3 PMC passes of this same
+    # match leg (tools/gpu_pmc.sh + tools/pmc_summary.py; FETCH_SIZE x2 correction per the
+    # MI355X guide); it cannot be collected inside an unprofiled run.
+    traffic, traffic_src = None, None
+    try:
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+        if cands and a.bank_rows == 100_000 and a.dim == 4096:
+            pm = json.load(open(cands[-1]))
+            traffic = pm.get("traffic_bytes")
+            traffic_src = os.path.basename(cands[-1]) + " (100k-query launch; L2 hit rate %.2f)" % pm.get("l2_hit_rate", float("nan"))
+    except Exception:
+        pass
     roofline = {"bound": "mfma", "kernel": "sim_topk_mfma_kernel", "achieved": round(ach, 2),
                 "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": None, "source": src,
-                "match_leg_achieved": round(2.0 * nqm * a.bank_rows * a.dim / (match_kernel_ms * 1e-3) / 1e12, 2)}
+                "traffic": traffic, "traffic_source": traffic_src, "source": src,
+                "kernel_ms": round(match_kernel_ms, 3), "in_step_achieved": in_step}
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -5,30 +5,28 @@
 // (and its callers lcsm.py:45-47, 66, 75-76) without ever materialising the
 // nq x n similarity matrix.
 //
-// Stage 1  sim_topk_mfma_kernel   S^T tile = Bank_tile (128 rows) x Query_tile^T (128 queries)
-//          in exact-f32 MFMA (v_mfma_f32_32x32x2_f32), K streamed in 32-float steps through
-//          double-buffered LDS filled by global_load_lds (16 B/lane, XOR-swizzled source so
-//          ds_read_b128 fragment reads are bank-conflict free).  Queries are the MFMA "B"
-//          operand, so a lane's 16 accumulator registers all belong to ONE query: the
-//          running top-16 candidate list of that query lives in that lane's registers and
-//          the epilogue is lane-local (no cross-lane traffic, no score matrix in memory).
-//          One workgroup = one (query tile, bank segment) work item.
+// Stage 1  sim_topk_mfma_kernel   S^T tile = Bank_tile x Query_tile^T in exact-f32 MFMA
+//          (v_mfma_f32_32x32x2_f32), K streamed in 32-float steps through double-buffered LDS
+//          filled by global_load_lds (16 B/lane, XOR-swizzled source so ds_read_b128 fragment
+//          reads are bank-conflict free).  Queries are the MFMA "B" operand, so a lane's 16
+//          accumulator registers all belong to ONE query: the running candidate list of that
+//          query lives in that lane's registers and the epilogue is lane-local (no cross-lane
+//          traffic, no score matrix in memory).  One workgroup = one (query tile, bank segment).
+//          Two tile shapes (template): 128x128 (4 waves, 2 workgroups/CU) and 256x256 (8 waves,
+//          1 workgroup/CU: half the L2->LDS traffic per flop, twice the prefetch distance).
 // Stage 2  rescore_kernel         one wave per query: merge the per-segment candidate lists,
 //          re-score the contenders in float64 with the reference formula, order them
 //          exactly, and certify with a rigorous f32 error bound that no row outside the
 //          candidate set can reach the k-th place.  Uncertified queries (never seen on
 //          random data) are re-done by the exact scan kernel (bank.hip).
+#include <stdlib.h>
 #include "bank.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define TM 128          // bank rows per tile
-#define TN 128          // queries per tile
 #define TK 32           // floats per K step
-#define KP 16           // candidate list length per (query, segment)
-#define MF_THREADS 256
-#define STAGE_BYTES (2 * TM * TK * 4)   // A + B tile of one stage = 32 KiB
+#define KP 16           // merged candidate list length per (query, segment)
 
 __device__ __forceinline__ void glds16(const float *g, char *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
@@ -36,22 +34,36 @@ __device__ __forceinline__ void glds16(const float *g, char *lds_wave_base) {
 }
 
 struct MfmaArgs {
-    const float *bank; int64_t ldb;      // bank rows, stride in floats
+    const float *bank; int64_t ldb;      // bank rows, pitch in floats
     const float *invn; int n_rows;
     const float *q; int64_t ldq; int nq; // f32 queries (rows clamped to nq-1 by the loader)
     const int *lim;                      // [nqt*TN] visible-row limit per query (0 for padding)
     const int *qt_maxlim;                // [nqt]
-    int nkt;                             // K steps = ld / 32
+    int nkt;                             // K steps = kd / 32
     int nqt, nseg, tps, n_btiles;
-    float *part_key; int *part_idx;      // [nqt*TN][nseg][KP]
+    float *part_key; int *part_idx;      // [nqt*TN][nseg][KP] merged candidates, sorted
+    float *part_bound;                   // [nqt*TN][nseg] upper bound of the key of every row of the
+                                         // segment that is NOT in the merged list (-inf: none dropped)
 };
 
-__global__ __launch_bounds__(MF_THREADS, 2) void sim_topk_mfma_kernel(MfmaArgs p) {
+// T_ = tile edge (bank rows = queries per tile), MT = 32-row MFMA tiles per wave along the bank
+// axis (wave tile = 32*MT x 64), KPL = per-lane candidate list length.
+// Waves: 2 along the bank axis x (T_/64) along the query axis.
+// DBG != 0 are TIMING-ONLY ablations (wrong results): 1 = no global loads after the first K step,
+// 2 = no per-step wait/barrier.  Selected with CSLAM_MFMA_DBG; never used by the product path.
+template <int T_, int MT, int KPL, int DBG>
+__global__ __launch_bounds__(T_ * 2, 2) void sim_topk_mfma_kernel(MfmaArgs p) {
+    constexpr int NTHR = T_ * 2;                 // 256 or 512 threads
+    constexpr int NWN = T_ / 64;                 // waves along the query axis
+    constexpr int OPB = T_ * TK * 4;             // bytes of one operand tile in LDS
+    constexpr int STAGE = 2 * OPB;
+    constexpr int NLD = T_ * 8 / NTHR;           // 16-byte chunks per thread per operand (= 4)
+    static_assert(T_ == 64 * MT, "wave tile must cover half the bank tile");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / NWN, wn = wave % NWN;
     const int h = lane >> 5, l31 = lane & 31;
 
     // XCD-aware work-item mapping: the hardware places block b on XCD b % 8; give each XCD a
@@ -68,48 +80,48 @@ __global__ __launch_bounds__(MF_THREADS, 2) void sim_topk_mfma_kernel(MfmaArgs p
     if (t_end > p.n_btiles) t_end = p.n_btiles;
     {
         int ml = p.qt_maxlim[qt];
-        int te = (ml + TM - 1) / TM;
+        int te = (ml + T_ - 1) / T_;
         if (t_end > te) t_end = te;
     }
 
     // per-lane candidate lists for the two query columns this lane owns
-    float lk[2][KP]; int li[2][KP];
+    float lk[2][KPL]; int li[2][KPL];
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int j = 0; j < KP; ++j) { lk[n][j] = -INFINITY; li[n][j] = -1; }
+        for (int j = 0; j < KPL; ++j) { lk[n][j] = -INFINITY; li[n][j] = -1; }
     int lim[2];
 #pragma unroll
-    for (int n = 0; n < 2; ++n) lim[n] = p.lim[qt * TN + wn * 64 + n * 32 + l31];
+    for (int n = 0; n < 2; ++n) lim[n] = p.lim[qt * T_ + wn * 64 + n * 32 + l31];
 
     const int ntiles = t_end - t_beg;
     if (ntiles > 0) {
-        // ---- loader addressing: thread handles LDS chunks pch = i*256 + tid, i = 0..3
-        // chunk pch -> tile row pch>>3, physical 16-B slot pch&7 holding logical chunk slot ^ ((row>>1)&7)
-        const float *gB[4];          // query pointers (fixed rows, advance along K)
-        int rowA[4], colc[4];
+        // ---- loader: thread handles LDS chunks pch = i*NTHR + tid; chunk pch -> tile row pch>>3,
+        // physical 16-B slot pch&7 holding logical chunk slot ^ ((row>>1)&7)
+        const float *gB[NLD];
+        int rowA[NLD], colc[NLD];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int pch = i * 256 + tid;
+        for (int i = 0; i < NLD; ++i) {
+            int pch = i * NTHR + tid;
             int r = pch >> 3, slot = pch & 7;
             int c = slot ^ ((r >> 1) & 7);
             rowA[i] = r; colc[i] = c * 4;
-            int64_t qrow = (int64_t)qt * TN + r;
+            int64_t qrow = (int64_t)qt * T_ + r;
             if (qrow > p.nq - 1) qrow = p.nq - 1;
             gB[i] = p.q + qrow * p.ldq + c * 4;
         }
-        const int wave_chunk = wave * 64 * 16;   // this wave's 1 KiB slice of each 4 KiB group
+        const int wave_chunk = wave * 1024;          // this wave's 1 KiB slice of each NTHR*16-byte group
 
         auto stage_load = [&](int stage, int tile, int kt) {
-            char *sA = smem + stage * STAGE_BYTES;
-            char *sB = sA + TM * TK * 4;
+            char *sA = smem + stage * STAGE;
+            char *sB = sA + OPB;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int64_t brow = (int64_t)tile * TM + rowA[i];
+            for (int i = 0; i < NLD; ++i) {
+                int64_t brow = (int64_t)tile * T_ + rowA[i];
                 if (brow > p.n_rows - 1) brow = p.n_rows - 1;
                 const float *ga = p.bank + brow * p.ldb + (kt * TK + colc[i]);
-                glds16(ga, sA + i * 4096 + wave_chunk);
-                glds16(gB[i] + kt * TK, sB + i * 4096 + wave_chunk);
+                glds16(ga, sA + i * (NTHR * 16) + wave_chunk);
+                glds16(gB[i] + kt * TK, sB + i * (NTHR * 16) + wave_chunk);
             }
         };
 
@@ -118,12 +130,12 @@ __global__ __launch_bounds__(MF_THREADS, 2) void sim_topk_mfma_kernel(MfmaArgs p
         int foff[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) foff[j] = (((2 * j + h) ^ swz) << 4);
-        const int arow0 = (wm * 64 + l31) * 128;
+        const int arow0 = (wm * 32 * MT + l31) * 128;
         const int brow0 = (wn * 64 + l31) * 128;
 
-        f32x16 acc[2][2];
+        f32x16 acc[MT][2];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -139,30 +151,31 @@ __global__ __launch_bounds__(MF_THREADS, 2) void sim_topk_mfma_kernel(MfmaArgs p
             // prefetch the next K step (possibly of the next bank tile) into the other stage
             int nkt_ = kt + 1, ntile = tile;
             if (nkt_ == p.nkt) { nkt_ = 0; ntile = tile + 1; }
-            if (it + 1 < total) stage_load(cur ^ 1, ntile, nkt_);
+            if (DBG != 1 && it + 1 < total) stage_load(cur ^ 1, ntile, nkt_);
 
-            const char *sA = smem + cur * STAGE_BYTES;
-            const char *sB = sA + TM * TK * 4;
+            const char *sA = smem + cur * STAGE;
+            const char *sB = sA + OPB;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                f32x4 a0 = *(const f32x4 *)(sA + arow0 + foff[j]);
-                f32x4 a1 = *(const f32x4 *)(sA + arow0 + 32 * 128 + foff[j]);
-                f32x4 b0 = *(const f32x4 *)(sB + brow0 + foff[j]);
-                f32x4 b1 = *(const f32x4 *)(sB + brow0 + 32 * 128 + foff[j]);
+                f32x4 a[MT], b[2];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b0[t], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[t], b1[t], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b0[t], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc[1][1], 0, 0, 0);
-                }
+                for (int m = 0; m < MT; ++m) a[m] = *(const f32x4 *)(sA + arow0 + m * 32 * 128 + foff[j]);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) b[n] = *(const f32x4 *)(sB + brow0 + n * 32 * 128 + foff[j]);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][t], b[n][t], acc[m][n], 0, 0, 0);
             }
 
             if (kt == p.nkt - 1) {
                 // ---- tile epilogue: lane-local candidate update, then clear the accumulators
-                const int row_base = tile * TM + wm * 64 + 4 * h;
+                const int row_base = tile * T_ + wm * 32 * MT + 4 * h;
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
+                for (int m = 0; m < MT; ++m) {
                     float inv[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -173,7 +186,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void sim_topk_mfma_kernel(MfmaArgs p
                     for (int n = 0; n < 2; ++n) {
                         f32x16 keys;
                         bool any = false;
-                        const float thr = lk[n][KP - 1];
+                        const float thr = lk[n][KPL - 1];
                         const int rel_lim = lim[n] - (row_base + m * 32);   // row < lim  <=>  rowoff < rel_lim
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
@@ -189,12 +202,12 @@ __global__ __launch_bounds__(MF_THREADS, 2) void sim_topk_mfma_kernel(MfmaArgs p
                                 float ck = keys[r];        // uniform dynamic index -> s_set_gpr_idx
                                 int roff = (r & 3) + 8 * (r >> 2);
                                 ck = (ck != ck) ? INFINITY : ck;
-                                bool ins = (roff < rel_lim) && (ck > lk[n][KP - 1]);
+                                bool ins = (roff < rel_lim) && (ck > lk[n][KPL - 1]);
                                 if (__any(ins)) {
                                     ck = ins ? ck : -INFINITY;
                                     int ci = row_base + m * 32 + roff;
 #pragma unroll
-                                    for (int j = 0; j < KP; ++j) {
+                                    for (int j = 0; j < KPL; ++j) {
                                         bool sw = ck > lk[n][j];
                                         float tk = sw ? lk[n][j] : ck;
                                         int ti = sw ? li[n][j] : ci;
@@ -209,50 +222,63 @@ __global__ __launch_bounds__(MF_THREADS, 2) void sim_topk_mfma_kernel(MfmaArgs p
                 }
             }
 
-            __builtin_amdgcn_s_waitcnt(0);   // next stage landed (vmcnt(0))
-            __syncthreads();
+            if (DBG != 2) {
+                __builtin_amdgcn_s_waitcnt(0);   // next stage landed (vmcnt(0))
+                __syncthreads();
+            }
             cur ^= 1;
             kt = nkt_; tile = ntile;
         }
     }
 
-    // ---- block merge: 4 lists per query (2 row-halves of the wave x 2 waves along M) -> 1
+    // ---- block merge: 4 lists per query (2 row-halves of the wave x 2 waves along the bank axis)
+    // -> the best KP of them, plus the bound on everything dropped: a full lane list may have
+    // dropped rows no better than its last key; the merge drops entries no better than its last.
     __syncthreads();
-    float *mk = (float *)smem;                       // [TN][4][KP]
-    int *mi = (int *)(smem + TN * 4 * KP * 4);       // [TN][4][KP]
+    float *mk = (float *)smem;                       // [T_][4][KPL]
+    int *mi = (int *)(smem + T_ * 4 * KPL * 4);      // [T_][4][KPL]
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         int qcol = wn * 64 + n * 32 + l31;
         int src = wm * 2 + h;
 #pragma unroll
-        for (int j = 0; j < KP; ++j) {
-            mk[(qcol * 4 + src) * KP + j] = lk[n][j];
-            mi[(qcol * 4 + src) * KP + j] = li[n][j];
+        for (int j = 0; j < KPL; ++j) {
+            mk[(qcol * 4 + src) * KPL + j] = lk[n][j];
+            mi[(qcol * 4 + src) * KPL + j] = li[n][j];
         }
     }
     __syncthreads();
-    if (tid < TN) {
-        const float *k0 = mk + (tid * 4) * KP;
-        const int *i0 = mi + (tid * 4) * KP;
+    if (tid < T_) {
+        const float *k0 = mk + (tid * 4) * KPL;
+        const int *i0 = mi + (tid * 4) * KPL;
         int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-        size_t o = ((size_t)(qt * TN + tid) * p.nseg + seg) * KP;
+        size_t o = ((size_t)(qt * T_ + tid) * p.nseg + seg) * KP;
+        float bound = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (i0[s * KPL + KPL - 1] >= 0) bound = fmaxf(bound, k0[s * KPL + KPL - 1]);   // full lane list
         for (int j = 0; j < KP; ++j) {
-            float c0 = p0 < KP ? k0[p0] : -INFINITY;
-            float c1 = p1 < KP ? k0[KP + p1] : -INFINITY;
-            float c2 = p2 < KP ? k0[2 * KP + p2] : -INFINITY;
-            float c3 = p3 < KP ? k0[3 * KP + p3] : -INFINITY;
+            float c0 = p0 < KPL ? k0[p0] : -INFINITY;
+            float c1 = p1 < KPL ? k0[KPL + p1] : -INFINITY;
+            float c2 = p2 < KPL ? k0[2 * KPL + p2] : -INFINITY;
+            float c3 = p3 < KPL ? k0[3 * KPL + p3] : -INFINITY;
             int best = 0; float bk = c0;
             if (c1 > bk) { bk = c1; best = 1; }
             if (c2 > bk) { bk = c2; best = 2; }
             if (c3 > bk) { bk = c3; best = 3; }
             int bi;
-            if (best == 0) { bi = p0 < KP ? i0[p0] : -1; ++p0; }
-            else if (best == 1) { bi = i0[KP + p1]; ++p1; }
-            else if (best == 2) { bi = i0[2 * KP + p2]; ++p2; }
-            else { bi = i0[3 * KP + p3]; ++p3; }
+            if (best == 0) { bi = p0 < KPL ? i0[p0] : -1; ++p0; }
+            else if (best == 1) { bi = i0[KPL + p1]; ++p1; }
+            else if (best == 2) { bi = i0[2 * KPL + p2]; ++p2; }
+            else { bi = i0[3 * KPL + p3]; ++p3; }
             p.part_key[o + j] = bk;
             p.part_idx[o + j] = (bk == -INFINITY) ? -1 : bi;
         }
+        // heads left after taking KP entries are the best entries the merge dropped
+        float c0 = p0 < KPL ? k0[p0] : -INFINITY, c1 = p1 < KPL ? k0[KPL + p1] : -INFINITY;
+        float c2 = p2 < KPL ? k0[2 * KPL + p2] : -INFINITY, c3 = p3 < KPL ? k0[3 * KPL + p3] : -INFINITY;
+        bound = fmaxf(fmaxf(bound, fmaxf(c0, c1)), fmaxf(c2, c3));
+        p.part_bound[(size_t)(qt * T_ + tid) * p.nseg + seg] = bound;
     }
 }
 
@@ -260,7 +286,8 @@ __global__ __launch_bounds__(MF_THREADS, 2) void sim_topk_mfma_kernel(MfmaArgs p
 template <typename QS>
 __global__ void mfma_prep_kernel(const QS *__restrict__ q, int64_t ldq, int nq, int dim, int kd, int ld,
                                  float *__restrict__ q32, const int64_t *__restrict__ row_limit,
-                                 int n_rows, int *__restrict__ lim, int *__restrict__ qt_maxlim, int nq_pad) {
+                                 int n_rows, int *__restrict__ lim, int *__restrict__ qt_maxlim, int nq_pad,
+                                 int tile) {
     const int row = blockIdx.x;
     if (row >= nq_pad) return;
     if (q32) {
@@ -276,7 +303,7 @@ __global__ void mfma_prep_kernel(const QS *__restrict__ q, int64_t ldq, int nq, 
             l = (int)v;
         }
         lim[row] = l;
-        atomicMax(&qt_maxlim[row / TN], l);
+        atomicMax(&qt_maxlim[row / tile], l);
     }
 }
 
@@ -285,7 +312,8 @@ template <typename QS>
 __global__ __launch_bounds__(256) void rescore_kernel(
     const float *__restrict__ bank, int64_t pitch, int ld, const double *__restrict__ vv,
     const QS *__restrict__ q, int64_t ldq, int dim, int nq,
-    const float *__restrict__ part_key, const int *__restrict__ part_idx, int nseg,
+    const float *__restrict__ part_key, const int *__restrict__ part_idx,
+    const float *__restrict__ part_bound, int nseg,
     int k, double err_bound,
     int64_t *__restrict__ out_idx, double *__restrict__ out_sim, int32_t *__restrict__ out_cnt,
     int *__restrict__ flag_list, int *__restrict__ flag_count) {
@@ -300,9 +328,16 @@ __global__ __launch_bounds__(256) void rescore_kernel(
     uu = wave_allreduce_sum(uu);
     const double qnorm = sqrt(uu);
 
-    // 1. merge the per-segment lists by f32 key; track the bound t32 on every row NOT kept
-    WaveList cand; cand.init();
+    // 1. t32 = upper bound on the f32 key of every row NOT kept: the per-segment bounds of stage 1 ...
     double t32 = -INFINITY;
+    for (int s = lane; s < nseg; s += 64) {
+        double bnd = (double)part_bound[(size_t)qn * nseg + s];
+        t32 = bnd > t32 ? bnd : t32;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { double o = __shfl_xor(t32, off, 64); t32 = o > t32 ? o : t32; }
+    //    ... and whatever the merge of the per-segment lists below drops.
+    WaveList cand; cand.init();
     const float *pk = part_key + (size_t)qn * nseg * KP;
     const int *pi = part_idx + (size_t)qn * nseg * KP;
     const int total = nseg * KP;
@@ -310,23 +345,26 @@ __global__ __launch_bounds__(256) void rescore_kernel(
         int e = base + lane;
         double ck = e < total ? (double)pk[e] : -INFINITY;
         int ci = e < total ? pi[e] : -1;
-        // a full segment list may have dropped rows no better than its last entry
-        bool seg_last_full = (e < total) && ((e % KP) == KP - 1) && ci >= 0;
-        double tl = seg_last_full ? ck : -INFINITY;
+        // only entries that can enter the current 64-entry list need the serial insert
+        double lastk = cand.key_at(63);
+        int lasti = cand.idx_at(63);
+        bool enters = ci >= 0 && (lasti < 0 || ranks_before(ck, ci, lastk, lasti));
+        double dropk = (ci >= 0 && !enters) ? ck : -INFINITY;
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) { double o = __shfl_xor(tl, off, 64); tl = o > tl ? o : tl; }
-        t32 = tl > t32 ? tl : t32;
-        unsigned long long mask = __ballot(ci >= 0);
+        for (int off = 32; off >= 1; off >>= 1) { double o = __shfl_xor(dropk, off, 64); dropk = o > dropk ? o : dropk; }
+        t32 = dropk > t32 ? dropk : t32;
+        unsigned long long mask = __ballot(enters);
         while (mask) {
             int src = __ffsll((long long)mask) - 1;
             mask &= mask - 1;
             double k2 = __shfl(ck, src, 64);
             int i2 = __shfl(ci, src, 64);
-            // entries falling off the 64-entry list are bounded by its last key (tracked below)
-            double lastk = cand.key_at(63);
-            int lasti = cand.idx_at(63);
-            if (lasti >= 0 && ranks_before(k2, i2, lastk, lasti)) t32 = lastk > t32 ? lastk : t32;
-            else if (lasti >= 0) { t32 = k2 > t32 ? k2 : t32; continue; }
+            lastk = cand.key_at(63);
+            lasti = cand.idx_at(63);
+            if (lasti >= 0) {       // list full: something falls off
+                if (ranks_before(k2, i2, lastk, lasti)) t32 = lastk > t32 ? lastk : t32;
+                else { t32 = k2 > t32 ? k2 : t32; continue; }
+            }
             cand.insert(k2, i2, lane);
         }
     }
@@ -398,19 +436,51 @@ __global__ __launch_bounds__(256) void rescore_kernel(
     }
 }
 
+template <int T_, int MT, int KPL>
+static int launch_stage1(const MfmaArgs &a, int dbg, hipStream_t st) {
+    constexpr int lds = 2 * 2 * T_ * TK * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 0>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 1>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 2>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr_set = true;
+    }
+    const dim3 grid(a.nqt * a.nseg), blk(T_ * 2);
+    if (dbg == 1) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 1>), grid, blk, lds, st, a);
+    else if (dbg == 2) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 2>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 0>), grid, blk, lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
 int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_t nq, int k,
                 const int64_t *d_row_limit, int64_t *d_out_idx, double *d_out_sim,
                 int32_t *d_out_cnt, hipStream_t st) {
+    static int dbg = -1, tile_env = -1;
+    if (dbg < 0) {
+        const char *v = getenv("CSLAM_MFMA_DBG");       // timing-only ablations, see the kernel
+        dbg = v ? atoi(v) : 0;
+        if (dbg < 0 || dbg > 2) dbg = 0;
+        const char *t = getenv("CSLAM_MFMA_TILE");      // 128 | 256 (default chosen below)
+        tile_env = t ? atoi(t) : 0;
+    }
     const int ld = b->ld, kd = b->kd;
-    const int nqt = (int)ceil_div64(nq, TN);
-    const int nq_pad = nqt * TN;
-    const int n_btiles = (int)ceil_div64(b->n, TM);
-    // Segment count: all work items take the same time and the chip holds S = 2 workgroups per CU,
-    // so the grid runs in ceil(T/S) rounds; pick the split whose last round is fullest
-    // (C3: 782 query tiles x 17 segments = 13294 items = 25.96 rounds instead of 9.16 with 6),
-    // discounting the fixed per-item cost (prologue, list merge ~ 0.3 tile-times) and preferring
-    // fewer segments (shorter candidate merge in rescore_kernel).
-    const int slots = 2 * b->num_cu;
+    // tile shape: 256x256 halves the operand traffic per flop; it needs enough work to fill the
+    // chip with one workgroup per CU, so small batches stay on 128x128
+    int tile = (nq >= 8192 && b->n >= 8192) ? 256 : 128;
+    if (tile_env == 128 || tile_env == 256) tile = tile_env;
+    const int nqt = (int)ceil_div64(nq, tile);
+    const int nq_pad = nqt * tile;
+    const int n_btiles = (int)ceil_div64(b->n, tile);
+    // Segment count: all work items take the same time and the chip holds S workgroups, so the
+    // grid runs in ceil(T/S) rounds; pick the split whose last round is fullest, discounting the
+    // fixed per-item cost (prologue, list merge ~ 0.3 tile-times) and preferring fewer segments
+    // (shorter candidate merge in rescore_kernel).
+    const int slots = (tile == 256 ? 1 : 2) * b->num_cu;
     int nseg = 1, tps = n_btiles;
     {
         double best = -1.0;
@@ -438,6 +508,7 @@ int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_
     size_t o_qtm = carve((size_t)nqt * 4);
     size_t o_pk = carve((size_t)nq_pad * nseg * KP * 4);
     size_t o_pi = carve((size_t)nq_pad * nseg * KP * 4);
+    size_t o_pb = carve((size_t)nq_pad * nseg * 4);
     size_t o_fl = carve((size_t)nq * 4);
     size_t o_fc = carve(256);
     int rc = bank_ws_reserve(b, 0, off);
@@ -448,6 +519,7 @@ int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_
     int *qtm = (int *)(ws + o_qtm);
     float *part_key = (float *)(ws + o_pk);
     int *part_idx = (int *)(ws + o_pi);
+    float *part_bound = (float *)(ws + o_pb);
     int *flag_list = (int *)(ws + o_fl);
     int *flag_count = (int *)(ws + o_fc);
 
@@ -455,10 +527,10 @@ int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_
     HIP_TRY(hipMemsetAsync(flag_count, 0, 4, st));
     if (q_dtype == CSLAM_F32)
         hipLaunchKernelGGL(mfma_prep_kernel<float>, dim3(nq_pad), dim3(256), 0, st, (const float *)d_q, ldq,
-                           (int)nq, b->dim, kd, ld, q32, d_row_limit, (int)b->n, lim, qtm, nq_pad);
+                           (int)nq, b->dim, kd, ld, q32, d_row_limit, (int)b->n, lim, qtm, nq_pad, tile);
     else
         hipLaunchKernelGGL(mfma_prep_kernel<double>, dim3(nq_pad), dim3(256), 0, st, (const double *)d_q, ldq,
-                           (int)nq, b->dim, kd, ld, q32, d_row_limit, (int)b->n, lim, qtm, nq_pad);
+                           (int)nq, b->dim, kd, ld, q32, d_row_limit, (int)b->n, lim, qtm, nq_pad, tile);
     HIP_TRY(hipGetLastError());
 
     MfmaArgs a;
@@ -466,31 +538,25 @@ int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_
     a.q = direct ? (const float *)d_q : q32; a.ldq = direct ? ldq : ld; a.nq = direct ? (int)nq : nq_pad;
     a.lim = lim; a.qt_maxlim = qtm; a.nkt = kd / TK;
     a.nqt = nqt; a.nseg = nseg; a.tps = tps; a.n_btiles = n_btiles;
-    a.part_key = part_key; a.part_idx = part_idx;
-    static bool attr_set = false;
-    if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES));
-        attr_set = true;
-    }
+    a.part_key = part_key; a.part_idx = part_idx; a.part_bound = part_bound;
     if (b->ev_valid) HIP_TRY(hipEventRecord(b->ev0, st));
-    hipLaunchKernelGGL(sim_topk_mfma_kernel, dim3(nqt * nseg), dim3(MF_THREADS), 2 * STAGE_BYTES, st, a);
-    HIP_TRY(hipGetLastError());
+    rc = tile == 256 ? launch_stage1<256, 4, 8>(a, dbg, st) : launch_stage1<128, 2, 16>(a, dbg, st);
+    if (rc) return rc;
     if (b->ev_valid) HIP_TRY(hipEventRecord(b->ev1, st));
 
-    // rigorous bound on |f32 key - exact| / ||q||: ld-term fma chain (gamma_ld), inv-norm
+    // rigorous bound on |f32 key - exact| / ||q||: kd-term fma chain (gamma_kd), inv-norm
     // rounding, key multiply rounding, query f64->f32 rounding; 2^-24 unit roundoff.
     const double u = 5.9604644775390625e-08;
     const double err_bound = 1.0625 * ((double)kd + 8.0) * u;
     const unsigned rgrid = (unsigned)ceil_div64(nq, 4);
     if (q_dtype == CSLAM_F32)
         hipLaunchKernelGGL(rescore_kernel<float>, dim3(rgrid), dim3(256), 0, st, b->rows, (int64_t)ld, kd, b->vv,
-                           (const float *)d_q, ldq, b->dim, (int)nq, part_key, part_idx, nseg, k, err_bound,
-                           d_out_idx, d_out_sim, d_out_cnt, flag_list, flag_count);
+                           (const float *)d_q, ldq, b->dim, (int)nq, part_key, part_idx, part_bound, nseg, k,
+                           err_bound, d_out_idx, d_out_sim, d_out_cnt, flag_list, flag_count);
     else
         hipLaunchKernelGGL(rescore_kernel<double>, dim3(rgrid), dim3(256), 0, st, b->rows, (int64_t)ld, kd, b->vv,
-                           (const double *)d_q, ldq, b->dim, (int)nq, part_key, part_idx, nseg, k, err_bound,
-                           d_out_idx, d_out_sim, d_out_cnt, flag_list, flag_count);
+                           (const double *)d_q, ldq, b->dim, (int)nq, part_key, part_idx, part_bound, nseg, k,
+                           err_bound, d_out_idx, d_out_sim, d_out_cnt, flag_list, flag_count);
     HIP_TRY(hipGetLastError());
 
     // uncertified queries -> exact scan (needs the count on the host: one 4-byte readback)
@@ -498,7 +564,7 @@ int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_
     HIP_TRY(hipMemcpyAsync(&nflag, flag_count, 4, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     b->stats[0] = nflag; b->stats[2] = nseg; b->stats[3] = nqt;
-    if (nflag > 0)
+    if (nflag > 0 && dbg == 0)
         return scan_search(b, d_q, q_dtype, ldq, flag_list, nflag, k, d_row_limit, d_out_idx, d_out_sim,
                            d_out_cnt, st);
     return CSLAM_OK;
