@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--match-queries", type=int, default=100_000, help="queries of the match-only leg")
     ap.add_argument("--backbone-dtype", default="fp32", choices=["fp32", "bf16"])
-    ap.add_argument("--extract-chunk", type=int, default=64, help="frames per backbone forward")
+    ap.add_argument("--extract-chunk", type=int, default=128, help="frames per backbone forward")
     ap.add_argument("--cpu-queries", type=int, default=12, help="cpu_baseline sample size (queries)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extract", action="store_true", help="debug: time the match leg only")

@@ -13,8 +13,8 @@ struct cslam_bank {
     double *vv;     // [cap]      sum of squares of each row, float64
     float *invn;    // [cap]      (float)(1/sqrt(vv)); used by the fp32 candidate stage only
     // grow-on-demand workspace
-    char *ws[2];          // [0] MFMA path, [1] scan path (the scan is also the MFMA fallback)
-    size_t ws_bytes[2];
+    char *ws[3];          // [0] MFMA path, [1] scan path (also the MFMA fallback), [2] host-API staging
+    size_t ws_bytes[3];
     char *stage;    // device staging for host->device adds
     size_t stage_bytes;
     hipStream_t last_stream;

@@ -98,7 +98,7 @@ CSLAM_API int cslam_bank_destroy(cslam_bank_t *b) {
     if (b->rows) (void)hipFree(b->rows);
     if (b->vv) (void)hipFree(b->vv);
     if (b->invn) (void)hipFree(b->invn);
-    for (int s = 0; s < 2; ++s) if (b->ws[s]) (void)hipFree(b->ws[s]);
+    for (int s = 0; s < 3; ++s) if (b->ws[s]) (void)hipFree(b->ws[s]);
     if (b->stage) (void)hipFree(b->stage);
     if (b->ev_valid) { (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1); }
     delete b;
@@ -211,13 +211,14 @@ CSLAM_API int cslam_bank_device_ptr(const cslam_bank_t *b, const float **d_rows,
 }
 
 // ---------------------------------------------------------------- exact scan ----
-#define SCAN_THREADS 512
-#define SCAN_WAVES 8
+// workgroup size: 8 waves for single-query tiles (4 workgroups/CU fit), 16 waves for 4-query tiles
+// (their 64-128 KiB of LDS allows one workgroup per CU, so the waves must come from inside it)
+#define SCAN_MAX_WAVES 16
 #define LIST_MAX 64
 
 // Query tile in LDS as QS (float or double), [QT][ld]; list merge area after it.
 template <typename QS, int QT, bool Q_IN_LDS>
-__global__ __launch_bounds__(SCAN_THREADS) void scan_exact_kernel(
+__global__ __launch_bounds__(QT == 1 ? 512 : 1024) void scan_exact_kernel(
     const float *__restrict__ rows, int64_t pitch, int ld, const double *__restrict__ vv, int64_t n_rows,
     const QS *__restrict__ q, int64_t ldq, int dim,
     const int *__restrict__ qsel, int nsel, int sel0,
@@ -228,7 +229,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void scan_exact_kernel(
     QS *qlds = (QS *)smem;
     const size_t q_bytes = Q_IN_LDS ? (size_t)QT * ld * sizeof(QS) : 0;
     double *mkey = (double *)(smem + q_bytes);                                    // [8][QT][64]
-    int *midx = (int *)(smem + q_bytes + (size_t)SCAN_WAVES * QT * LIST_MAX * 8); // [8][QT][64]
+    const int SCAN_WAVES = blockDim.x >> 6, SCAN_THREADS = blockDim.x;
+    int *midx = (int *)(smem + q_bytes + (size_t)SCAN_WAVES * QT * LIST_MAX * 8); // [waves][QT][64]
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -406,10 +408,13 @@ template <typename QS>
 static int scan_launch(cslam_bank *b, const QS *d_q, int64_t ldq, const int *d_qsel, int nsel, int sel0,
                        int nchunk, int kk, const int64_t *d_row_limit, const double *bkey, const int *bidx,
                        double *part_key, int *part_idx, int G, hipStream_t st) {
-    const size_t merge_bytes = (size_t)SCAN_WAVES * LIST_MAX * 12;
+    const int wide = 16, narrow = 8;       // waves per workgroup for QT = 4 / QT = 1
+    size_t merge_bytes = (size_t)wide * LIST_MAX * 12;
     const size_t lds_budget = 150 * 1024;
     int qt = 4;
     if ((size_t)4 * b->kd * sizeof(QS) + 4 * merge_bytes > lds_budget || nchunk == 1) qt = 1;
+    const int waves = qt == 4 ? wide : narrow;
+    merge_bytes = (size_t)waves * LIST_MAX * 12;
     bool in_lds = (size_t)qt * b->kd * sizeof(QS) + qt * merge_bytes <= lds_budget;
     size_t lds = (in_lds ? (size_t)qt * b->kd * sizeof(QS) : 0) + qt * merge_bytes;
     dim3 grid((unsigned)G, (unsigned)ceil_div64(nchunk, qt));
@@ -418,7 +423,7 @@ static int scan_launch(cslam_bank *b, const QS *d_q, int64_t ldq, const int *d_q
         auto kern = scan_exact_kernel<QS, QT, INL>;                                                   \
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize,   \
                                     (int)lds));                                                       \
-        hipLaunchKernelGGL(kern, grid, dim3(SCAN_THREADS), lds, st, b->rows, (int64_t)b->ld, b->kd, b->vv, b->n, d_q, \
+        hipLaunchKernelGGL(kern, grid, dim3(waves * 64), lds, st, b->rows, (int64_t)b->ld, b->kd, b->vv, b->n, d_q, \
                            ldq, b->dim, d_qsel, nsel, sel0, kk, d_row_limit, bkey, bidx, part_key,    \
                            part_idx);                                                                 \
     } while (0)
@@ -436,7 +441,7 @@ int scan_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, const 
     if (nsel == 0) return CSLAM_OK;
     // grid: enough waves to cover the HBM latency, never more blocks than 8-row groups
     int G = b->num_cu * 2;
-    int64_t need = ceil_div64(b->n > 0 ? b->n : 1, SCAN_WAVES);
+    int64_t need = ceil_div64(b->n > 0 ? b->n : 1, 8);
     if (G > need) G = (int)need;
     if (G < 1) G = 1;
     const int CH = 1024;   // selected queries per launch (bounds the partial-list workspace)
@@ -511,12 +516,13 @@ CSLAM_API int cslam_bank_search_host(cslam_bank_t *b, const void *queries, int q
     const size_t qb = (size_t)nq * b->dim * esz;
     const size_t lb = row_limit ? (size_t)nq * 8 : 0;
     const size_t ib = (size_t)nq * k * 8, sb = (size_t)nq * k * 8, cb = (size_t)nq * 4;
-    char *buf = nullptr;
     size_t off_q = 0, off_l = round_up64(off_q + qb, 256), off_i = round_up64(off_l + lb, 256);
     size_t off_s = round_up64(off_i + ib, 256), off_c = round_up64(off_s + sb, 256);
     size_t total = off_c + cb;
-    HIP_TRY(hipMalloc((void **)&buf, total));
-    int rc = CSLAM_OK;
+    // persistent per-bank staging (no hipMalloc/hipFree on the per-keyframe path)
+    int rc = bank_ws_reserve(b, 2, total);
+    if (rc) return rc;
+    char *buf = b->ws[2];
     do {
         if (hipMemcpy(buf + off_q, queries, qb, hipMemcpyHostToDevice) != hipSuccess) { rc = CSLAM_E_HIP; break; }
         if (row_limit && hipMemcpy(buf + off_l, row_limit, lb, hipMemcpyHostToDevice) != hipSuccess) { rc = CSLAM_E_HIP; break; }
@@ -530,7 +536,6 @@ CSLAM_API int cslam_bank_search_host(cslam_bank_t *b, const void *queries, int q
             hipMemcpy(out_cnt, buf + off_c, cb, hipMemcpyDeviceToHost) != hipSuccess) { rc = CSLAM_E_HIP; break; }
     } while (0);
     if (rc == CSLAM_E_HIP && g_err[0] == 0) cslam_set_error("HIP copy failed: %s", hipGetErrorString(hipGetLastError()));
-    (void)hipFree(buf);
     return rc;
 }
 

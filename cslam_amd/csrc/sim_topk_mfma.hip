@@ -493,7 +493,11 @@ int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_
             if (se != s) continue;
             double T = (double)nqt * se;
             double rounds = ceil(T / slots);
-            double eff = T / (rounds * slots) * ((double)t / (t + 0.3)) - 0.0005 * se;
+            // uneven segments (last one shorter) let workgroups that share a bank stream or a
+            // query tile drift apart in time and lose their L2/MALL sharing: measured 82.8 % of
+            // peak with 15 x 27-tile segments over 391 tiles vs 87.5 % with even splits
+            double balance = (double)n_btiles / ((double)se * t);
+            double eff = T / (rounds * slots) * balance * balance * ((double)t / (t + 0.3)) - 0.0005 * se;
             if (eff > best) { best = eff; nseg = se; tps = t; }
         }
     }
