@@ -190,3 +190,36 @@ def test_full_size_bank_properties(nnm):
     oi, os_, oc = pyoracle.nns_search(hb, q[:6].cpu().numpy(), 5)
     assert np.array_equal(rows[:6].cpu().numpy(), oi)
     assert np.max(np.abs(sims[:6].cpu().numpy() - os_)) < 1e-12
+
+
+@pytest.mark.parametrize("n,d,nq,k,f64", [(9000, 64, 8300, 5, False), (8200, 96, 8192, 8, True)])
+def test_large_tile_path_vs_oracle(nnm, n, d, nq, k, f64):
+    """nq >= 8192 and n >= 8192 select the 256x256 MFMA tile (8 waves, per-lane lists of 8 with
+    explicit drop bounds): ragged tile edges, causal limits, float64 queries."""
+    bank = unit_rows(np.random.default_rng(n), n, d)
+    q = unit_rows(np.random.default_rng(n + 1), nq, d)
+    if f64:
+        q = q.astype(np.float64) * 3.0
+    nn = make_bank(nnm, bank)
+    idx, sims, cnt = nn.search_batch(q, k, mode=nnm.MODE_MFMA)
+    assert nn.last_stats()[1] == nnm.MODE_MFMA and nn.last_stats()[3] == -(-nq // 256)
+    oi, os_, oc = pyoracle.nns_search(bank, q, k)
+    assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
+    lim = np.minimum(np.arange(nq, dtype=np.int64) * 2, n)
+    idx, sims, cnt = nn.search_batch(q, k, row_limit=lim, mode=nnm.MODE_MFMA)
+    oi, os_, oc = pyoracle.nns_search(bank, q, k, row_limit=lim)
+    assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
+
+
+def test_large_tile_clustered_rows_force_bounds(nnm):
+    """Near-duplicate clusters overflow the 8-entry per-lane lists of the 256 tile: the drop
+    bound must flag those queries (or keep them certified correctly) -- results stay exact."""
+    rng = np.random.default_rng(5)
+    centers = unit_rows(rng, 40, 128)
+    bank = np.repeat(centers, 210, axis=0) + 0.01 * rng.standard_normal((8400, 128)).astype(np.float32)
+    bank = bank.astype(np.float32)
+    q = np.repeat(centers, 208, axis=0)[:8200] + 0.01 * rng.standard_normal((8200, 128)).astype(np.float32)
+    nn = make_bank(nnm, bank)
+    idx, sims, cnt = nn.search_batch(q.astype(np.float32), 5, mode=nnm.MODE_MFMA)
+    oi, os_, oc = pyoracle.nns_search(bank, q.astype(np.float32), 5)
+    assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)

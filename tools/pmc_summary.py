@@ -54,7 +54,9 @@ for name in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ
     if v is not None:
         out[name] = v
 if "SQ_VALU_MFMA_BUSY_CYCLES" in out and "GRBM_GUI_ACTIVE" in out:
-    out["mfma_util_est"] = out["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * out["GRBM_GUI_ACTIVE"])
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs; MFMA busy cycles over 256 CUs x 4 SIMDs
+    out["gpu_clock_cycles"] = out["GRBM_GUI_ACTIVE"] / 8.0
+    out["mfma_util_est"] = out["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / out["gpu_clock_cycles"]
 out["algorithmic_flop"] = 2.0 * 1e5 * 1e5 * 4096
 out["algorithmic_min_bytes"] = 2 * 1e5 * 4096 * 4
 os.makedirs("profiles", exist_ok=True)
