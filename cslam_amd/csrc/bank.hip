@@ -446,7 +446,9 @@ int scan_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, const 
     if (G < 1) G = 1;
     const int CH = 1024;   // selected queries per launch (bounds the partial-list workspace)
     const int passes = (int)ceil_div64(k, LIST_MAX);
-    size_t part_elems = (size_t)CH * G * LIST_MAX;
+    // partial lists: (queries per launch, rounded up to whole 4-query tiles) x G x entries per list
+    const size_t ch_eff = (size_t)round_up64(nsel < CH ? nsel : CH, 4);
+    size_t part_elems = ch_eff * G * (size_t)(k < LIST_MAX ? k : LIST_MAX);
     size_t off_pk = 0, off_pi = off_pk + part_elems * 8, off_bk = off_pi + part_elems * 4;
     size_t off_bi = off_bk + (size_t)nsel * 8, total = off_bi + (size_t)nsel * 4;
     int rc = bank_ws_reserve(b, 1, total);

@@ -25,8 +25,8 @@ __device__ __forceinline__ void glds16(const float *g, char *lds_wave_base) {
 }
 
 // A [M, K] (rows = output features), B [N, K] (rows = batch); part [S][N][M]
-__global__ __launch_bounds__(256, 2) void gemm_nt_splitk_kernel(const float *__restrict__ A, int M,
-                                                                const float *__restrict__ B, int N, int K,
+__global__ __launch_bounds__(256, 2) void gemm_nt_splitk_kernel(const float *__restrict__ A, int64_t lda, int M,
+                                                                const float *__restrict__ B, int64_t ldb, int N, int K,
                                                                 int mt, int nt, int kt_per_split,
                                                                 float *__restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -48,8 +48,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_splitk_kernel(const float *__r
         int pch = i * 256 + tid, r = pch >> 3, slot = pch & 7, c = slot ^ ((r >> 1) & 7);
         int64_t ra = (int64_t)tm * TM + r; if (ra > M - 1) ra = M - 1;
         int64_t rb = (int64_t)tn * TN + r; if (rb > N - 1) rb = N - 1;
-        gA[i] = A + ra * K + c * 4;
-        gB[i] = B + rb * K + c * 4;
+        gA[i] = A + ra * lda + c * 4;
+        gB[i] = B + rb * ldb + c * 4;
     }
     const int wave_chunk = wave * 1024;
     auto stage_load = [&](int stage, int kt) {
@@ -156,12 +156,13 @@ static float *g_part = nullptr;
 static size_t g_part_bytes = 0;
 static int g_part_dev = -1;
 
-CSLAM_API int cslam_pca_project_dev(const float *d_x, const float *d_comp, const float *d_mean_proj,
-                                    const float *d_inv_scale, int B, int Din, int Dout, float *d_out,
-                                    void *stream) {
+CSLAM_API int cslam_pca_project_dev(const float *d_x, int64_t ldx, const float *d_comp, int64_t ldc,
+                                    const float *d_mean_proj, const float *d_inv_scale, int B, int Din, int Dout,
+                                    float *d_out, void *stream) {
     ARG_CHECK(d_x && d_comp && d_out, "NULL argument");
     ARG_CHECK(B >= 0 && Din >= TK && Dout >= 1 && Din % TK == 0, "Din must be a positive multiple of 32");
     ARG_CHECK(((uintptr_t)d_x % 16 == 0) && ((uintptr_t)d_comp % 16 == 0), "x / comp must be 16-byte aligned");
+    ARG_CHECK(ldx >= Din && ldc >= Din && ldx % 4 == 0 && ldc % 4 == 0, "row pitches must be >= Din and multiples of 4 floats");
     if (B == 0) return CSLAM_OK;
     hipStream_t st = (hipStream_t)stream;
     int dev = 0; HIP_TRY(hipGetDevice(&dev));
@@ -185,8 +186,8 @@ CSLAM_API int cslam_pca_project_dev(const float *d_x, const float *d_comp, const
                                     2 * STAGE_BYTES));
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_nt_splitk_kernel, dim3(mt * nt * S), dim3(256), 2 * STAGE_BYTES, st, d_comp, Dout, d_x,
-                       B, Din, mt, nt, kps, g_part);
+    hipLaunchKernelGGL(gemm_nt_splitk_kernel, dim3(mt * nt * S), dim3(256), 2 * STAGE_BYTES, st, d_comp, ldc, Dout, d_x,
+                       ldx, B, Din, mt, nt, kps, g_part);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(pca_epilogue_kernel, dim3(B), dim3(256), 0, st, g_part, S, B, Dout, d_mean_proj, d_inv_scale,
                        d_out);

@@ -64,9 +64,9 @@ CSLAM_API int cslam_l2_normalize_dev(float *d_x, int64_t n, int d, int64_t ld, f
 #define VK 64
 #define VPCH 128
 #define VWCH 32
-__global__ __launch_bounds__(512) void vlad_kernel(const float *__restrict__ feat, const float *__restrict__ W,
+__global__ __launch_bounds__(512) void vlad_generic_kernel(const float *__restrict__ feat, const float *__restrict__ W,
                                                    const float *__restrict__ bias, const float *__restrict__ cent,
-                                                   int C, int P, float *__restrict__ out) {
+                                                   int C, int P, float *__restrict__ out, int64_t ldo) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *a_lds = (float *)smem;                    // [VPCH][VK]
     float *w_lds = a_lds + VPCH * VK;                // [VWCH][VK]  (transposed weight chunk)
@@ -165,24 +165,212 @@ __global__ __launch_bounds__(512) void vlad_kernel(const float *__restrict__ fea
     }
     float gs = 1.0f / fmaxf(sqrtf(gsum), 1e-12f);
     if (c_own < C) {
-        float *o = out + (size_t)blockIdx.x * VK * C;
+        float *o = out + (size_t)blockIdx.x * ldo;
 #pragma unroll
         for (int k = 0; k < VK; ++k) o[(size_t)k * C + c_own] = acc[k] * gs;
     }
 }
 
+// Fast path (P <= 256 pixels, e.g. NetVLAD's 14x14): the image's feature map is streamed twice
+// through LDS in 32-channel slabs (contiguous 32*P floats in NCHW, coalesced, next slab prefetched
+// into registers while the current one is consumed), so no thread ever waits on a dependent
+// global load.  Sweep 1: thread = pixel, accumulates ||x_p||^2 and the 64 logits; softmax -> a[p][k]
+// (pre-scaled by 1/||x_p||) in LDS.  Sweep 2: thread = (channel in slab, group of 4 clusters),
+// V[k,c] = sum_p a'[p][k] x[c,p] with x read conflict-free (slab row stride P_PAD = 257) and a' as one
+// broadcast ds_read_b128; the 16x4 results per thread stay in registers until the two normalisations.
+#define VL_CC 32
+#define VL_PMAX 256
+#define VL_PPAD 257
+__global__ __launch_bounds__(512) void vlad_fast_kernel(const float *__restrict__ feat, const float *__restrict__ W,
+                                                        const float *__restrict__ bias, const float *__restrict__ cent,
+                                                        int C, int P, float *__restrict__ out, int64_t ldo) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *a_lds = (float *)smem;                     // [VL_PMAX][VK]   a'[p][k] = softmax * inv_norm
+    float *xs = a_lds + VL_PMAX * VK;                 // [VL_CC][VL_PPAD]
+    float *ws = xs + VL_CC * VL_PPAD;                 // [VL_CC][VK]
+    float *invn = ws + VL_CC * VK;                    // [VL_PMAX]
+    float *asum = invn + VL_PMAX;                     // [VK]
+    float *red = asum + VK;                           // [VK] + 16
+    const int tid = threadIdx.x;
+    const float *x = feat + (size_t)blockIdx.x * C * P;
+    const int nslab = (C + VL_CC - 1) / VL_CC;
+    const int slab_elems = VL_CC * P;                 // <= 8192
+    constexpr int NPF = (VL_CC * VL_PMAX + 511) / 512;   // 16 prefetch registers per thread
+
+    float pf[NPF];
+    auto prefetch = [&](int sl) {
+        const int base = sl * slab_elems, limit = C * P;
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            int e = i * 512 + tid;
+            pf[i] = (e < slab_elems && base + e < limit) ? x[base + e] : 0.0f;
+        }
+    };
+    // slab element e = i*512 + tid lives at (channel e / P, pixel e % P): walk it incrementally
+    const int cc_start = tid / P, pp_start = tid - cc_start * P, dq = 512 / P, dr = 512 - dq * P;
+    auto commit = [&]() {
+        int cc = cc_start, pp = pp_start;
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            if (i * 512 + tid < slab_elems) xs[cc * VL_PPAD + pp] = pf[i];
+            cc += dq; pp += dr;
+            if (pp >= P) { pp -= P; ++cc; }
+        }
+    };
+
+    // ---------------- sweep 1: norms + logits (thread = pixel)
+    // the two halves of the workgroup split each slab's channels: thread (half, pixel)
+    const int half = tid >> 8, px = tid & 255;
+    float lg[VK];
+#pragma unroll
+    for (int k = 0; k < VK; ++k) lg[k] = 0.0f;
+    float ss = 0.0f;
+    prefetch(0);
+    for (int sl = 0; sl < nslab; ++sl) {
+        __syncthreads();                               // previous slab fully consumed
+        commit();
+        const int c0 = sl * VL_CC;
+        for (int e = tid; e < VL_CC * VK; e += 512) {  // ws[cc][k] = W[k][c0+cc]; lanes along k: conflict-free
+            int cc = e >> 6, k = e & 63;
+            ws[cc * VK + k] = (c0 + cc < C) ? W[(size_t)k * C + c0 + cc] : 0.0f;
+        }
+        if (sl + 1 < nslab) prefetch(sl + 1);
+        __syncthreads();
+        if (px < P) {
+#pragma unroll 4
+            for (int ci = 0; ci < VL_CC / 2; ++ci) {
+                const int cc = half * (VL_CC / 2) + ci;
+                float xv = xs[cc * VL_PPAD + px];
+                ss += xv * xv;
+                const float4 *wr = (const float4 *)(ws + cc * VK);
+#pragma unroll
+                for (int k4 = 0; k4 < VK / 4; ++k4) {
+                    float4 w4 = wr[k4];
+                    lg[4 * k4 + 0] += w4.x * xv; lg[4 * k4 + 1] += w4.y * xv;
+                    lg[4 * k4 + 2] += w4.z * xv; lg[4 * k4 + 3] += w4.w * xv;
+                }
+            }
+        }
+    }
+    // combine the two halves through a_lds, then softmax in the lower half
+    if (half == 1 && px < P) {
+#pragma unroll
+        for (int k = 0; k < VK; ++k) a_lds[px * VK + k] = lg[k];
+        invn[px] = ss;
+    }
+    __syncthreads();
+    if (half == 0 && px < P) {
+        ss += invn[px];
+        float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);            // F.normalize(dim=1), netvlad.py:105-106
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < VK; ++k) {
+            lg[k] = (lg[k] + a_lds[px * VK + k]) * inv + (bias ? bias[k] : 0.0f);
+            mx = fmaxf(mx, lg[k]);
+        }
+        float se = 0.0f;
+#pragma unroll
+        for (int k = 0; k < VK; ++k) { lg[k] = expf(lg[k] - mx); se += lg[k]; }
+        float rs = 1.0f / se;
+#pragma unroll
+        for (int k = 0; k < VK; ++k) a_lds[px * VK + k] = lg[k] * rs;      // softmax, netvlad.py:109-110
+        invn[px] = inv;
+    }
+    prefetch(0);                                       // sweep 2 starts from the first slab again
+    __syncthreads();
+    if (tid < VK) {                                    // asum[k] = sum_p a[p][k]  (unscaled)
+        float s = 0.0f;
+        for (int pp = 0; pp < P; ++pp) s += a_lds[pp * VK + tid];
+        asum[tid] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < P * VK; e += 512) a_lds[e] *= invn[e / VK];       // a' = a / ||x_p||
+
+    // ---------------- sweep 2: V[k,c] (thread = channel-in-slab x 4 clusters)
+    const int cl = tid & 31, k0 = (tid >> 5) * 4;
+    float vout[16][4];
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) vout[sl][j] = 0.0f;
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) {
+        if (sl < nslab) {
+            __syncthreads();
+            commit();
+            if (sl + 1 < nslab) prefetch(sl + 1);
+            __syncthreads();
+            float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+            const float *xr = xs + cl * VL_PPAD;
+#pragma unroll 4
+            for (int pp = 0; pp < P; ++pp) {
+                float xv = xr[pp];
+                float4 a4 = *(const float4 *)(a_lds + pp * VK + k0);
+                a0 += a4.x * xv; a1 += a4.y * xv; a2 += a4.z * xv; a3 += a4.w * xv;
+            }
+            const int c = sl * VL_CC + cl;
+            if (c < C) {
+                // V[k,c] = sum_p a[k,p] (x[c,p]/||x_p|| - cent[k,c])   (netvlad.py:115-124)
+                vout[sl][0] = a0 - asum[k0 + 0] * cent[(size_t)(k0 + 0) * C + c];
+                vout[sl][1] = a1 - asum[k0 + 1] * cent[(size_t)(k0 + 1) * C + c];
+                vout[sl][2] = a2 - asum[k0 + 2] * cent[(size_t)(k0 + 2) * C + c];
+                vout[sl][3] = a3 - asum[k0 + 3] * cent[(size_t)(k0 + 3) * C + c];
+            }
+        }
+    }
+    // intra-normalisation over c for every k (netvlad.py:126): the 32 lanes sharing k0 hold all c
+    float sc[4], gpart = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float s = 0.0f;
+#pragma unroll
+        for (int sl = 0; sl < 16; ++sl) s += vout[sl][j] * vout[sl][j];
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        float nk = sqrtf(s);
+        sc[j] = 1.0f / fmaxf(nk, 1e-12f);
+        float nn = nk * sc[j];
+        gpart += nn * nn;
+    }
+    // global L2 over all K*C (netvlad.py:127-128): sum the 16 cluster groups
+    __syncthreads();
+    if (cl == 0) red[tid >> 5] = gpart;
+    __syncthreads();
+    float gsum = 0.0f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) gsum += red[g];
+    const float gs = 1.0f / fmaxf(sqrtf(gsum), 1e-12f);
+    float *o = out + (size_t)blockIdx.x * ldo;
+#pragma unroll
+    for (int sl = 0; sl < 16; ++sl) {
+        const int c = sl * VL_CC + cl;
+        if (sl < nslab && c < C) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[(size_t)(k0 + j) * C + c] = vout[sl][j] * sc[j] * gs;
+        }
+    }
+}
+
 CSLAM_API int cslam_vlad_aggregate_dev(const float *d_feat, const float *d_assign_w, const float *d_assign_b,
                                        const float *d_centroids, int B, int C, int P, int K,
-                                       float *d_out, void *stream) {
+                                       float *d_out, int64_t ldo, void *stream) {
     ARG_CHECK(d_feat && d_assign_w && d_centroids && d_out, "NULL argument");
     ARG_CHECK(K == VK, "K must be 64 (reference: num_clusters=64, netvlad.py:176)");
     ARG_CHECK(C >= 1 && C <= 512 && P >= 1 && B >= 0, "need 1 <= C <= 512 (reference encoder_dim = 512, netvlad.py:162)");
+    ARG_CHECK(ldo >= (int64_t)K * C, "output pitch smaller than K*C");
     if (B == 0) return CSLAM_OK;
-    int threads = (int)round_up64(C > VPCH ? C : VPCH, 64);
-    size_t lds = (size_t)(VPCH * VK + VWCH * VK + VPCH + 16 * VK + 16) * 4;
-    HIP_TRY(hipFuncSetAttribute((const void *)vlad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(vlad_kernel, dim3(B), dim3(threads), lds, (hipStream_t)stream, d_feat, d_assign_w,
-                       d_assign_b, d_centroids, C, P, d_out);
+    if (P <= VL_PMAX) {
+        size_t lds = (size_t)(VL_PMAX * VK + VL_CC * VL_PPAD + VL_CC * VK + VL_PMAX + VK + VK + 16) * 4;
+        HIP_TRY(hipFuncSetAttribute((const void *)vlad_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(vlad_fast_kernel, dim3(B), dim3(512), lds, (hipStream_t)stream, d_feat, d_assign_w,
+                           d_assign_b, d_centroids, C, P, d_out, ldo);
+    } else {
+        int threads = (int)round_up64(C > VPCH ? C : VPCH, 64);
+        size_t lds = (size_t)(VPCH * VK + VWCH * VK + VPCH + 16 * VK + 16) * 4;
+        HIP_TRY(hipFuncSetAttribute((const void *)vlad_generic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(vlad_generic_kernel, dim3(B), dim3(threads), lds, (hipStream_t)stream, d_feat, d_assign_w,
+                           d_assign_b, d_centroids, C, P, d_out, ldo);
+    }
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }
@@ -298,47 +486,101 @@ __device__ __forceinline__ int clip8(int v) {
     return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
 
-// horizontal pass: tmp[b][y][xo][ch] for the cropped rows y in [0, crop)
-__global__ __launch_bounds__(256) void resize_h_kernel(const uint8_t *__restrict__ img, int H, int W, int crop,
-                                                       int top, int left, int out_w, int ksize,
-                                                       const int *__restrict__ bounds, const int *__restrict__ kk,
-                                                       uint8_t *__restrict__ tmp) {
-    const int b = blockIdx.y, y = blockIdx.x;
-    const uint8_t *row = img + ((size_t)b * H + top + y) * W * 3 + (size_t)left * 3;
-    for (int e = threadIdx.x; e < out_w * 3; e += blockDim.x) {
-        int xo = e / 3, ch = e - xo * 3;
-        int xmin = bounds[xo * 2], xn = bounds[xo * 2 + 1];
-        const int *k = kk + (size_t)xo * ksize;
-        int ss = 1 << (PREC_BITS - 1);
-        for (int x = 0; x < xn; ++x) ss += (int)row[(xmin + x) * 3 + ch] * k[x];
-        tmp[(((size_t)b * crop + y) * out_w + xo) * 3 + ch] = (uint8_t)clip8(ss);
+// Fused crop + horizontal pass + vertical pass + ToTensor + Normalize.  One workgroup = one image x
+// PP_TY output rows: the input rows those outputs need (about 1.7*PP_TY + 8 at 376 -> 224) are
+// read from HBM once with 4-byte loads into LDS, resized horizontally to uint8 in LDS (Pillow
+// rounds and clips to 8 bits between the passes), then vertically, and stored as float32 CHW with
+// consecutive lanes on consecutive x.  HBM traffic per frame ~ crop*crop*3 (x1.3 row overlap between
+// tiles, absorbed by L2) + 3*out*out*4 bytes; the old two-kernel version moved the uint8
+// intermediate through memory and read single bytes.
+#define PP_TY 16
+__global__ __launch_bounds__(256) void preprocess_fused_kernel(
+    const uint8_t *__restrict__ img, int H, int W, int crop, int top, int left, int out_hw, int ksize,
+    int max_rows, const int *__restrict__ bounds, const int *__restrict__ kk,
+    float m0, float m1, float m2, float s0, float s1, float s2, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int in_row_bytes = (crop * 3 + 3) & ~3;        // padded to dwords
+    const int tmp_row_bytes = out_hw * 3;
+    int *s_bounds = (int *)smem;                                     // [out_hw][2]
+    int *s_kk = s_bounds + out_hw * 2;                               // [out_hw][ksize]
+    uint8_t *s_in = (uint8_t *)(s_kk + out_hw * ksize);              // [max_rows][in_row_bytes]
+    uint8_t *s_tmp = s_in + (size_t)max_rows * in_row_bytes;         // [max_rows][tmp_row_bytes]
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int b = blockIdx.y, y0 = blockIdx.x * PP_TY;
+    const int ny = out_hw - y0 < PP_TY ? out_hw - y0 : PP_TY;
+    for (int e = tid; e < out_hw * 2; e += nt) s_bounds[e] = bounds[e];
+    for (int e = tid; e < out_hw * ksize; e += nt) s_kk[e] = kk[e];
+    const int rlo = bounds[y0 * 2];
+    const int ylast = y0 + ny - 1;
+    const int rhi = bounds[ylast * 2] + bounds[ylast * 2 + 1];
+    const int nrows = rhi - rlo;
+    // ---- load the input rows (crop window) into LDS
+    const size_t row0 = ((size_t)b * H + top + rlo) * W * 3 + (size_t)left * 3;
+    const int row_bytes = crop * 3;
+    const bool aligned = ((((size_t)img + row0) & 3) == 0) && (((size_t)W * 3) % 4 == 0) && (row_bytes % 4 == 0);
+    // all loops below: one wave per row (or per (channel, output row) pair), lanes along the row --
+    // no runtime integer divisions on the per-element path
+    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    if (aligned) {
+        const int ndw = row_bytes >> 2;
+        for (int r = wave; r < nrows; r += nw) {
+            const uint32_t *g = (const uint32_t *)(img + row0 + (size_t)r * W * 3);
+            uint32_t *d = (uint32_t *)(s_in + (size_t)r * in_row_bytes);
+            for (int c = lane; c < ndw; c += 64) d[c] = g[c];
+        }
+    } else {
+        for (int r = wave; r < nrows; r += nw)
+            for (int c = lane; c < row_bytes; c += 64)
+                s_in[(size_t)r * in_row_bytes + c] = img[row0 + (size_t)r * W * 3 + c];
     }
-}
-
-// vertical pass + ToTensor + Normalize: out[b][ch][yo][xo]
-__global__ __launch_bounds__(256) void resize_v_kernel(const uint8_t *__restrict__ tmp, int crop, int out_hw,
-                                                       int ksize, const int *__restrict__ bounds,
-                                                       const int *__restrict__ kk, float m0, float m1, float m2,
-                                                       float s0, float s1, float s2, float *__restrict__ out) {
-    const int b = blockIdx.y, yo = blockIdx.x;
-    const int ymin = bounds[yo * 2], yn = bounds[yo * 2 + 1];
-    const int *k = kk + (size_t)yo * ksize;
-    for (int e = threadIdx.x; e < out_hw * 3; e += blockDim.x) {
-        int xo = e / 3, ch = e - xo * 3;
-        int ss = 1 << (PREC_BITS - 1);
-        for (int y = 0; y < yn; ++y) ss += (int)tmp[(((size_t)b * crop + ymin + y) * out_hw + xo) * 3 + ch] * k[y];
-        float v = (float)clip8(ss) / 255.0f;                       // ToTensor
-        float mean = ch == 0 ? m0 : (ch == 1 ? m1 : m2), sd = ch == 0 ? s0 : (ch == 1 ? s1 : s2);
-        out[(((size_t)b * 3 + ch) * out_hw + yo) * out_hw + xo] = (v - mean) / sd;   // Normalize
+    __syncthreads();
+    // ---- horizontal pass (uint8 result, rounded + clipped like ImagingResampleHorizontal_8bpc);
+    //      a lane owns one output x and produces its three channels with one read of the taps
+    for (int r = wave; r < nrows; r += nw) {
+        const uint8_t *rowp = s_in + (size_t)r * in_row_bytes;
+        uint8_t *dst = s_tmp + (size_t)r * tmp_row_bytes;
+        for (int xo = lane; xo < out_hw; xo += 64) {
+            const int xmin = s_bounds[xo * 2], xn = s_bounds[xo * 2 + 1];
+            const int *k = s_kk + xo * ksize;
+            const uint8_t *src = rowp + xmin * 3;
+            int a0 = 1 << (PREC_BITS - 1), a1 = a0, a2 = a0;
+            for (int x = 0; x < xn; ++x) {
+                const int kx = k[x];
+                a0 += (int)src[x * 3] * kx; a1 += (int)src[x * 3 + 1] * kx; a2 += (int)src[x * 3 + 2] * kx;
+            }
+            dst[xo * 3] = (uint8_t)clip8(a0); dst[xo * 3 + 1] = (uint8_t)clip8(a1); dst[xo * 3 + 2] = (uint8_t)clip8(a2);
+        }
+    }
+    __syncthreads();
+    // ---- vertical pass + ToTensor + Normalize: one wave per output row, lanes along x, the three
+    //      channel planes written as three coalesced rows
+    for (int yo = wave; yo < ny; yo += nw) {
+        const int y = y0 + yo;
+        const int ymin = s_bounds[y * 2], yn = s_bounds[y * 2 + 1];
+        const int *k = s_kk + y * ksize;
+        const uint8_t *base = s_tmp + (size_t)(ymin - rlo) * tmp_row_bytes;
+        float *o0 = out + (((size_t)b * 3 + 0) * out_hw + y) * out_hw;
+        float *o1 = o0 + (size_t)out_hw * out_hw, *o2 = o1 + (size_t)out_hw * out_hw;
+        for (int xo = lane; xo < out_hw; xo += 64) {
+            const uint8_t *src = base + xo * 3;
+            int a0 = 1 << (PREC_BITS - 1), a1 = a0, a2 = a0;
+            for (int j = 0; j < yn; ++j) {
+                const int kj = k[j];
+                const uint8_t *q = src + (size_t)j * tmp_row_bytes;
+                a0 += (int)q[0] * kj; a1 += (int)q[1] * kj; a2 += (int)q[2] * kj;
+            }
+            o0[xo] = ((float)clip8(a0) / 255.0f - m0) / s0;        // ToTensor, Normalize
+            o1[xo] = ((float)clip8(a1) / 255.0f - m1) / s1;
+            o2[xo] = ((float)clip8(a2) / 255.0f - m2) / s2;
+        }
     }
 }
 
 struct PreprocCache {
-    int device, crop, out_hw, ksize;
+    int device, crop, out_hw, ksize, max_rows;
     int *d_bounds, *d_kk;
-    uint8_t *d_tmp; size_t tmp_bytes;
 };
-static PreprocCache g_pp = {-1, 0, 0, 0, nullptr, nullptr, nullptr, 0};
+static PreprocCache g_pp = {-1, 0, 0, 0, 0, nullptr, nullptr};
 
 CSLAM_API int cslam_preprocess_dev(const uint8_t *d_img, int B, int H, int W, int crop, int out_hw,
                                    const float mean[3], const float std_[3], float *d_out, void *stream) {
@@ -352,27 +594,30 @@ CSLAM_API int cslam_preprocess_dev(const uint8_t *d_img, int B, int H, int W, in
     if (g_pp.device != dev || g_pp.crop != crop || g_pp.out_hw != out_hw) {
         std::vector<int> bounds, kk;
         int ksize = precompute_coeffs(crop, 0.0, (double)crop, out_hw, bounds, kk);
+        int max_rows = 0;
+        for (int y0 = 0; y0 < out_hw; y0 += PP_TY) {
+            int yl = y0 + PP_TY - 1 < out_hw - 1 ? y0 + PP_TY - 1 : out_hw - 1;
+            int span = bounds[yl * 2] + bounds[yl * 2 + 1] - bounds[y0 * 2];
+            if (span > max_rows) max_rows = span;
+        }
         if (g_pp.d_bounds) { (void)hipFree(g_pp.d_bounds); (void)hipFree(g_pp.d_kk); }
         HIP_TRY(hipMalloc((void **)&g_pp.d_bounds, bounds.size() * 4));
         HIP_TRY(hipMalloc((void **)&g_pp.d_kk, kk.size() * 4));
         HIP_TRY(hipMemcpy(g_pp.d_bounds, bounds.data(), bounds.size() * 4, hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(g_pp.d_kk, kk.data(), kk.size() * 4, hipMemcpyHostToDevice));
-        g_pp.device = dev; g_pp.crop = crop; g_pp.out_hw = out_hw; g_pp.ksize = ksize;
+        g_pp.device = dev; g_pp.crop = crop; g_pp.out_hw = out_hw; g_pp.ksize = ksize; g_pp.max_rows = max_rows;
     }
-    size_t need = (size_t)B * crop * out_hw * 3;
-    if (need > g_pp.tmp_bytes) {
-        if (g_pp.d_tmp) HIP_TRY(hipFree(g_pp.d_tmp));
-        g_pp.d_tmp = nullptr; g_pp.tmp_bytes = 0;
-        HIP_TRY(hipMalloc((void **)&g_pp.d_tmp, need));
-        g_pp.tmp_bytes = need;
-    }
+    const size_t in_row_bytes = ((size_t)crop * 3 + 3) & ~(size_t)3;
+    const size_t lds = (size_t)out_hw * 2 * 4 + (size_t)out_hw * g_pp.ksize * 4 +
+                       (size_t)g_pp.max_rows * (in_row_bytes + (size_t)out_hw * 3);
+    ARG_CHECK(lds <= 160 * 1024, "crop / output size too large for the fused transform's LDS tile");
+    HIP_TRY(hipFuncSetAttribute((const void *)preprocess_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
     // torchvision CenterCrop: top = round((H - crop) / 2), left = round((W - crop) / 2)
     const int top = (int)lrint((H - crop) / 2.0), left = (int)lrint((W - crop) / 2.0);
-    hipLaunchKernelGGL(resize_h_kernel, dim3(crop, B), dim3(256), 0, st, d_img, H, W, crop, top, left, out_hw,
-                       g_pp.ksize, g_pp.d_bounds, g_pp.d_kk, g_pp.d_tmp);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(resize_v_kernel, dim3(out_hw, B), dim3(256), 0, st, g_pp.d_tmp, crop, out_hw, g_pp.ksize,
-                       g_pp.d_bounds, g_pp.d_kk, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], d_out);
+    hipLaunchKernelGGL(preprocess_fused_kernel, dim3((out_hw + PP_TY - 1) / PP_TY, B), dim3(256), lds, st, d_img, H,
+                       W, crop, top, left, out_hw, g_pp.ksize, g_pp.max_rows, g_pp.d_bounds, g_pp.d_kk, mean[0],
+                       mean[1], mean[2], std_[0], std_[1], std_[2], d_out);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }

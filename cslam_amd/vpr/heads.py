@@ -37,15 +37,24 @@ def preprocess(frames_u8, crop, out_hw=224, mean=IMAGENET_DEFAULT_MEAN, std=IMAG
     return out
 
 
-def vlad_aggregate(feat, assign_w, assign_b, centroids):
+def padded_rows(n, d, device, dtype=torch.float32):
+    """[n, d] view whose row pitch avoids multiples of 256 floats (power-of-two pitches put the same
+    column of every row into the same L2 set; see csrc/bank.hip)."""
+    pitch = d + 32 if d % 256 == 0 else d
+    return torch.empty((n, pitch), dtype=dtype, device=device)[:, :d]
+
+
+def vlad_aggregate(feat, assign_w, assign_b, centroids, out=None):
     """[B,C,h,w] -> [B, 64*C]  NetVLADLayer.forward (netvlad.py:94-130)."""
     _chk(feat); _chk(assign_w); _chk(centroids)
     B, Cc = feat.shape[:2]
     P = feat.shape[2] * feat.shape[3]
     K = centroids.shape[0]
-    out = torch.empty((B, K * Cc), dtype=torch.float32, device=feat.device)
+    if out is None:
+        out = padded_rows(B, K * Cc, feat.device)
+    assert out.shape == (B, K * Cc) and out.stride(1) == 1
     _lib.check(_lib.load().cslam_vlad_aggregate_dev(_p(feat), _p(assign_w), _p(assign_b) if assign_b is not None else None,
-                                                    _p(centroids), B, Cc, P, K, _p(out), _stream(out)))
+                                                    _p(centroids), B, Cc, P, K, _p(out), out.stride(0), _stream(out)))
     return out
 
 
@@ -62,10 +71,12 @@ def gem_fc_head(feat, p, eps, W, b):
 
 
 def pca_project(x, components, mean_proj, inv_scale):
-    """[B,Din] -> normalised [B,Dout] (netvlad.py:234-236)."""
-    _chk(x); _chk(components)
+    """[B,Din] -> normalised [B,Dout] (netvlad.py:234-236); x / components may be pitched views."""
+    for t in (x, components):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.stride(1) == 1):
+            raise _lib.CslamHipError("pca_project needs float32 device tensors with unit column stride")
     out = torch.empty((x.shape[0], components.shape[0]), dtype=torch.float32, device=x.device)
-    _lib.check(_lib.load().cslam_pca_project_dev(_p(x), _p(components),
+    _lib.check(_lib.load().cslam_pca_project_dev(_p(x), x.stride(0), _p(components), components.stride(0),
                                                  _p(mean_proj) if mean_proj is not None else None,
                                                  _p(inv_scale) if inv_scale is not None else None,
                                                  x.shape[0], x.shape[1], components.shape[0], _p(out), _stream(out)))

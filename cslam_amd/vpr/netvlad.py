@@ -112,7 +112,8 @@ class NetVLAD(object):
     def set_pca(self, components, mean, explained_variance=None, whiten=False):
         comp = np.ascontiguousarray(components, dtype=np.float32)
         mean = np.asarray(mean, dtype=np.float32)
-        self.pca_components = torch.from_numpy(comp).to(self.device)
+        self.pca_components = heads.padded_rows(comp.shape[0], comp.shape[1], self.device)
+        self.pca_components.copy_(torch.from_numpy(comp))
         self.pca_mean_proj = torch.from_numpy((mean.reshape(1, -1) @ comp.T).reshape(-1).astype(np.float32)).to(self.device)
         self.pca_inv_scale = None
         if whiten:
@@ -135,7 +136,8 @@ class NetVLAD(object):
         self.pool.load(w, cent)
         din = 64 * 512
         comp = torch.randn((pca_dim, din), generator=g, dtype=torch.float32) / din ** 0.5
-        self.pca_components = comp.to(self.device)
+        self.pca_components = heads.padded_rows(pca_dim, din, self.device)
+        self.pca_components.copy_(comp)
         self.pca_mean_proj = torch.zeros(pca_dim, dtype=torch.float32, device=self.device)
         self.pca_inv_scale = None
 

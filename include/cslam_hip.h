@@ -103,10 +103,10 @@ int cslam_l2_normalize_dev(float *d_x, int64_t n, int d, int64_t ld, float eps,
                            int zero_norm_to_one, void *stream);
 /* NetVLADLayer.forward, cslam/vpr/netvlad.py:94-130.
  * feat [B, C, P] (NCHW flattened), assign_w [K, C] (1x1 conv, no bias: vladv1),
- * assign_b [K] or NULL, centroids [K, C]; out [B, K*C]. */
+ * assign_b [K] or NULL, centroids [K, C]; out [B, K*C] with row pitch ldo floats. */
 int cslam_vlad_aggregate_dev(const float *d_feat, const float *d_assign_w, const float *d_assign_b,
                              const float *d_centroids, int B, int C, int P, int K,
-                             float *d_out, void *stream);
+                             float *d_out, int64_t ldo, void *stream);
 /* CosPlace aggregation head, cslam/vpr/cosplace_utils/network.py:23-29 + layers.py:8-36:
  * L2Norm(C) -> GeM(p, eps) -> Flatten -> Linear(W [Dout, C], b [Dout]) -> L2Norm.
  * feat [B, C, P]; out [B, Dout]. */
@@ -117,10 +117,11 @@ int cslam_gem_fc_head_dev(const float *d_feat, float p, float eps, const float *
  *   y = x @ comp^T - mean_proj ;  y *= inv_scale (whitening) ;  y /= ||y|| (zero rows stay zero)
  * comp [Dout, Din]; mean_proj [Dout] = mean @ comp^T (precomputed once by the caller) or NULL;
  * inv_scale [Dout] = 1/sqrt(explained_variance) or NULL.  x [B, Din], out [B, Dout].
- * Din must be a multiple of 32.  fp32 MFMA GEMM with split-K (deterministic reduction). */
-int cslam_pca_project_dev(const float *d_x, const float *d_comp, const float *d_mean_proj,
-                          const float *d_inv_scale, int B, int Din, int Dout, float *d_out,
-                          void *stream);
+ * Din must be a multiple of 32; ldx / ldc are the row pitches of x / comp in floats (pad them off
+ * multiples of 256 floats: power-of-two pitches alias in L2).  fp32 MFMA GEMM, deterministic split-K. */
+int cslam_pca_project_dev(const float *d_x, int64_t ldx, const float *d_comp, int64_t ldc,
+                          const float *d_mean_proj, const float *d_inv_scale, int B, int Din, int Dout,
+                          float *d_out, void *stream);
 /* image transform, cslam/vpr/netvlad.py:202-208 / cosplace.py:73-79:
  * CenterCrop(crop) -> Resize(out_hw, PIL bicubic, antialiased, 8-bit intermediate) ->
  * ToTensor (/255, HWC->CHW) -> Normalize(mean, std).
