@@ -1,6 +1,7 @@
 // Descriptor bank object shared by bank.hip (storage + exact scan) and sim_topk_mfma.hip.
 #pragma once
 #include "common.h"
+#include <vector>
 
 struct cslam_bank {
     int device;
@@ -22,6 +23,8 @@ struct cslam_bank {
     bool ev_valid;
     int64_t stats[4];
     int num_cu;
+    std::vector<int> item_map_host;   // cached work-item order of the MFMA path (see sim_topk_mfma.hip)
+    int item_map_key[4];
 };
 
 int bank_ws_reserve(cslam_bank *b, int slot, size_t bytes);

@@ -75,7 +75,12 @@ CSLAM_API int cslam_bank_create(int device, int dim, int64_t capacity_hint, csla
     HIP_TRY(hipSetDevice(device));
     cslam_bank *b = new (std::nothrow) cslam_bank();
     if (!b) { cslam_set_error("out of host memory"); return CSLAM_E_NOMEM; }
-    memset(b, 0, sizeof(*b));
+    b->device = 0; b->dim = 0; b->kd = 0; b->ld = 0; b->n = 0; b->cap = 0;
+    b->rows = nullptr; b->vv = nullptr; b->invn = nullptr;
+    for (int s = 0; s < 3; ++s) { b->ws[s] = nullptr; b->ws_bytes[s] = 0; }
+    b->stage = nullptr; b->stage_bytes = 0; b->last_stream = nullptr; b->ev_valid = false;
+    for (int s = 0; s < 4; ++s) { b->stats[s] = 0; b->item_map_key[s] = -1; }
+    b->num_cu = 0;
     b->device = device; b->dim = dim; b->kd = (int)round_up64(dim, 32);
     // Row pitch: a power-of-two pitch (4096 floats = 16 KiB) maps the same K offset of every row to
     // the same L2 set -- measured 17 % L2 hit rate, 2.1 TB fetched per 100k-query pass; one extra

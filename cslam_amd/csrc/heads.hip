@@ -522,11 +522,23 @@ __global__ __launch_bounds__(256) void preprocess_fused_kernel(
     // no runtime integer divisions on the per-element path
     const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
     if (aligned) {
-        const int ndw = row_bytes >> 2;
-        for (int r = wave; r < nrows; r += nw) {
-            const uint32_t *g = (const uint32_t *)(img + row0 + (size_t)r * W * 3);
-            uint32_t *d = (uint32_t *)(s_in + (size_t)r * in_row_bytes);
-            for (int c = lane; c < ndw; c += 64) d[c] = g[c];
+        // dword e = i*nt + tid of the tile lives at (row e / ndw, dword e % ndw): walk it incrementally,
+        // 8 independent global loads in flight per thread before the LDS stores
+        const int ndw = row_bytes >> 2, total = nrows * ndw;
+        const int dq = nt / ndw, dr = nt - dq * ndw;
+        int r = tid / ndw, c = tid - r * ndw;
+        for (int base = 0; base < total; base += nt * 8) {
+            uint32_t v[8]; int rr[8], cc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                rr[j] = r; cc[j] = c;
+                v[j] = (base + j * nt + tid < total) ? *(const uint32_t *)(img + row0 + (size_t)r * W * 3 + (size_t)c * 4) : 0u;
+                r += dq; c += dr;
+                if (c >= ndw) { c -= ndw; ++r; }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (base + j * nt + tid < total) ((uint32_t *)(s_in + (size_t)rr[j] * in_row_bytes))[cc[j]] = v[j];
         }
     } else {
         for (int r = wave; r < nrows; r += nw)

@@ -42,6 +42,7 @@ struct MfmaArgs {
     int nkt;                             // K steps = kd / 32
     int nqt, nseg, tps, n_btiles;
     float *part_key; int *part_idx;      // [nqt*TN][nseg][KP] merged candidates, sorted
+    const int *item_map;                 // [nqt*nseg] (query tile << 16 | segment) in patch-major order
     float *part_bound;                   // [nqt*TN][nseg] upper bound of the key of every row of the
                                          // segment that is NOT in the merged list (-inf: none dropped)
 };
@@ -67,13 +68,16 @@ __global__ __launch_bounds__(T_ * 2, 2) void sim_topk_mfma_kernel(MfmaArgs p) {
     const int h = lane >> 5, l31 = lane & 31;
 
     // XCD-aware work-item mapping: the hardware places block b on XCD b % 8; give each XCD a
-    // contiguous run of items so that co-resident blocks share bank segments / query tiles in
-    // that XCD's L2 (speed only; any mapping is correct).
+    // contiguous run of the item list.  The list is patch-major over the (query tile, segment)
+    // grid (host-built table), so the ~32/64 workgroups resident on an XCD form a roughly square
+    // patch: ~sqrt as many distinct bank/query streams per L2 as a row of the grid would give
+    // (speed only; any mapping is correct).
     const int T = p.nqt * p.nseg;
     const int bid = blockIdx.x;
     const int xcd = bid & 7, j8 = bid >> 3, q8 = T >> 3, r8 = T & 7;
     const int item = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + j8;
-    const int qt = item / p.nseg, seg = item - qt * p.nseg;
+    const int packed = p.item_map[item];
+    const int qt = packed >> 16, seg = packed & 0xffff;
 
     int t_beg = seg * p.tps;
     int t_end = t_beg + p.tps;
@@ -515,6 +519,7 @@ int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_
     size_t o_pb = carve((size_t)nq_pad * nseg * 4);
     size_t o_fl = carve((size_t)nq * 4);
     size_t o_fc = carve(256);
+    size_t o_im = carve((size_t)nqt * nseg * 4);
     int rc = bank_ws_reserve(b, 0, off);
     if (rc) return rc;
     char *ws = b->ws[0];
@@ -526,6 +531,29 @@ int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_
     float *part_bound = (float *)(ws + o_pb);
     int *flag_list = (int *)(ws + o_fl);
     int *flag_count = (int *)(ws + o_fc);
+    int *item_map = (int *)(ws + o_im);
+    {
+        // patch-major order of the (query tile, segment) grid; patches of a x bseg items ~ the number
+        // of workgroups resident per XCD
+        const int per_xcd = slots / 8 > 0 ? slots / 8 : 1;
+        int bseg = (int)floor(sqrt((double)per_xcd) + 0.5);
+        if (bseg > nseg) bseg = nseg;
+        if (bseg < 1) bseg = 1;
+        int aq = (int)ceil_div64(per_xcd, bseg);
+        if (aq < 1) aq = 1;
+        if (b->item_map_host.size() != (size_t)nqt * nseg || b->item_map_key[0] != nqt || b->item_map_key[1] != nseg ||
+            b->item_map_key[2] != aq || b->item_map_key[3] != bseg) {
+            b->item_map_host.clear();
+            b->item_map_host.reserve((size_t)nqt * nseg);
+            for (int q0 = 0; q0 < nqt; q0 += aq)
+                for (int s0 = 0; s0 < nseg; s0 += bseg)
+                    for (int qq = q0; qq < q0 + aq && qq < nqt; ++qq)
+                        for (int sg = s0; sg < s0 + bseg && sg < nseg; ++sg)
+                            b->item_map_host.push_back((qq << 16) | sg);
+            b->item_map_key[0] = nqt; b->item_map_key[1] = nseg; b->item_map_key[2] = aq; b->item_map_key[3] = bseg;
+        }
+        HIP_TRY(hipMemcpyAsync(item_map, b->item_map_host.data(), (size_t)nqt * nseg * 4, hipMemcpyHostToDevice, st));
+    }
 
     HIP_TRY(hipMemsetAsync(qtm, 0, (size_t)nqt * 4, st));
     HIP_TRY(hipMemsetAsync(flag_count, 0, 4, st));
@@ -542,7 +570,7 @@ int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_
     a.q = direct ? (const float *)d_q : q32; a.ldq = direct ? ldq : ld; a.nq = direct ? (int)nq : nq_pad;
     a.lim = lim; a.qt_maxlim = qtm; a.nkt = kd / TK;
     a.nqt = nqt; a.nseg = nseg; a.tps = tps; a.n_btiles = n_btiles;
-    a.part_key = part_key; a.part_idx = part_idx; a.part_bound = part_bound;
+    a.part_key = part_key; a.part_idx = part_idx; a.part_bound = part_bound; a.item_map = item_map;
     if (b->ev_valid) HIP_TRY(hipEventRecord(b->ev0, st));
     rc = tile == 256 ? launch_stage1<256, 4, 8>(a, dbg, st) : launch_stage1<128, 2, 16>(a, dbg, st);
     if (rc) return rc;
