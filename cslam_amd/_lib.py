@@ -47,6 +47,9 @@ _SIGNATURES = {
     "cslam_preprocess_dev": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(_f * 3), C.POINTER(_f * 3), _vp, _vp]),
     "cslam_mac_grad_dev": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "cslam_csr_spmm_dev": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _vp, _vp]),
+    "cslam_csr_spmm4_dev": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "cslam_chain_forward_dev": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cslam_chain_backward_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

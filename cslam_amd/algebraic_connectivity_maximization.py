@@ -263,11 +263,28 @@ class AlgebraicConnectivityMaximization(object):
         return all(self.initial_fixed_edge_exists[r] for r in is_robot_included if is_robot_included[r])
 
     # ----------------------------------------------------------------------- solve ----
+    def _fiedler_solver(self):
+        """Inner solver of the Fiedler computation: 'frontend.mac_fiedler_solver' in the params
+        ('tracemin_lu' | 'chain' | 'chain_gpu' | 'auto').  'auto' keeps the reference's sparse-LU path for
+        small graphs (bit-compatible selections) and moves graphs of >= 20000 poses to the chain-reduced
+        HIP solver when a GPU is visible."""
+        choice = self.params.get('frontend.mac_fiedler_solver', 'auto') if hasattr(self.params, 'get') else 'auto'
+        if choice != 'auto':
+            return choice
+        if self.total_nb_poses >= 20000:
+            try:
+                import torch
+                if torch.cuda.is_available():
+                    return 'chain_gpu'
+            except ImportError:
+                pass
+        return 'tracemin_lu'
+
     def run_mac_solver(self, fixed_edges, candidate_edges, w_init, nb_candidates_to_choose):
         """Frank-Wolfe MAC with the reference's retry policy: any failure of the Fiedler
         solve (singular Laplacian of a disconnected selection) re-draws the initial guess with
         one more random pick, at most nb_candidates_to_choose times (reference :436-466)."""
-        mac = MAC(fixed_edges, candidate_edges, self.total_nb_poses)
+        mac = MAC(fixed_edges, candidate_edges, self.total_nb_poses, fiedler_solver=self._fiedler_solver())
         result = w_init.copy()
         trial = 0
         while trial < nb_candidates_to_choose:

@@ -1,0 +1,136 @@
+"""Device version of the chain-reduced Fiedler solver (see chain_solver.py for the algorithm).
+
+Per Laplacian: the host builds the chain/junction structure (O(n) numpy), the reduced junction
+Laplacian is factorised densely on the GPU (float64 Cholesky), and every TraceMIN iteration runs
+    W = L X                      cslam_csr_spmm4_dev      (HIP, one lane per row)
+    W = A^-1 X                   cslam_chain_forward_dev  (two segmented scans + junction gather, HIP)
+                                 dense triangular solves on the junction system
+                                 cslam_chain_backward_dev (closed-form interior potentials, HIP)
+plus 4x4 dense algebra.  Vectors are [n][4] float64 and never leave HBM.
+"""
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+
+from .. import _lib
+from .chain_solver import ChainReducedSolver
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+class ChainReducedSolverGPU(object):
+    MAX_DENSE = 24000          # junctions; above this the reduced system is solved on the host (sparse LU)
+
+    def __init__(self, L, ground, device="cuda"):
+        import torch
+        self.torch = torch
+        self.lib = _lib.load()
+        host = ChainReducedSolver.__new__(ChainReducedSolver)
+        ChainReducedSolver.__init__(host, L, ground, factorize=False)
+        self.host = host
+        n, nJ = host.n, host.nJ
+        self.n, self.nJ = n, nJ
+        dev = torch.device(device)
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+        self.is_j = t(host.is_j, np.uint8)
+        self.r = t(host.r if n > 1 else np.zeros(1), np.float64)
+        self.J = t(host.J, np.int64)
+        nseg = len(host.sa)
+        seg_start_of = np.full(nJ, -1, dtype=np.int32); seg_end_of = np.full(nJ, -1, dtype=np.int32)
+        seg_start_of[host.jid[host.sa]] = np.arange(nseg, dtype=np.int32)
+        seg_end_of[host.jid[host.sb]] = np.arange(nseg, dtype=np.int32)
+        self.seg_start_of, self.seg_end_of = t(seg_start_of, np.int32), t(seg_end_of, np.int32)
+        self.sa, self.sb = t(host.sa if nseg else np.zeros(1), np.int64), t(host.sb if nseg else np.zeros(1), np.int64)
+        self.Rl = t(host.Rl if nseg else np.ones(1), np.float64)
+        self.Rn = t(host.R, np.float64)
+        self.jid = t(host.jid, np.int32)
+        self.seg_of = t(host.seg_of_start[host.start], np.int32)
+        nch = (n + 2047) // 2048
+        f64 = lambda *shape: torch.empty(shape, dtype=torch.float64, device=dev)
+        self.Bn, self.Qn, self.tmp = f64(n, 4), f64(n, 4), f64(n, 4)
+        self.scratch = f64(9 * nch + 64)
+        self.bt = f64(nJ, 4)
+        self.free = t(host.free, np.int64)
+        self.dense = nJ - 1 <= self.MAX_DENSE
+        if self.dense:
+            Sf = torch.from_numpy(host.Sf.toarray()).to(dev)
+            self.chol = torch.linalg.cholesky(Sf)
+        else:
+            host.factorize()
+
+    def solve(self, X):
+        """X [n,4] float64 device tensor -> A^-1 X (row `ground` = 0)."""
+        torch = self.torch
+        assert X.shape == (self.n, 4) and X.dtype == torch.float64 and X.is_contiguous()
+        st = C.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
+        _lib.check(self.lib.cslam_chain_forward_dev(
+            _p(X), _p(self.is_j), _p(self.r), self.n, _p(self.J), self.nJ, _p(self.seg_start_of),
+            _p(self.seg_end_of), _p(self.sa), _p(self.sb), _p(self.Rl), _p(self.Bn), _p(self.Qn), _p(self.tmp),
+            _p(self.scratch), _p(self.bt), st))
+        xJ = torch.zeros((self.nJ, 4), dtype=torch.float64, device=X.device)
+        if self.nJ > 1:
+            rhs = self.bt[self.free]
+            if self.dense:
+                xJ[self.free] = torch.cholesky_solve(rhs, self.chol)
+            else:
+                xJ[self.free] = torch.from_numpy(self.host.lu.solve(rhs.cpu().numpy())).to(X.device)
+        out = torch.empty_like(X)
+        _lib.check(self.lib.cslam_chain_backward_dev(
+            _p(xJ), _p(self.Bn), _p(self.Qn), _p(self.r), _p(self.Rn), _p(self.jid), _p(self.seg_of), _p(self.sa),
+            _p(self.sb), _p(self.Rl), self.n, _p(out), st))
+        return out
+
+
+def fiedler_tracemin_chain_gpu(L, tol=1e-8, seed=None, device="cuda", stats=None):
+    """TraceMIN-Fiedler (same start block, projection and stopping rule as the reference's
+    networkx call, see fiedler.py) with every O(n) step on the GPU.  Returns (lambda_2, v numpy)."""
+    import torch
+    if seed is None:
+        seed = np.random.RandomState(7)
+    L = sp.csr_matrix(L, dtype=np.float64)
+    L.sort_indices()
+    n = L.shape[0]
+    assert n > 4, "use the host solver for tiny graphs"
+    dev = torch.device(device)
+    lib = _lib.load()
+    X = torch.from_numpy(np.ascontiguousarray(np.asarray(seed.normal(size=(4, n))).T)).to(dev)
+    ground = int((L.indptr[1:] - L.indptr[:-1]).argmax())
+    solver = ChainReducedSolverGPU(L, ground, device)
+    indptr = torch.from_numpy(L.indptr.astype(np.int64)).to(dev)
+    indices = torch.from_numpy(L.indices.astype(np.int32)).to(dev)
+    data = torch.from_numpy(L.data).to(dev)
+    Lnorm = float(abs(L).sum(axis=1).max())
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    W = torch.empty_like(X)
+
+    def orthonormalise(X):
+        for _ in range(2):                                   # CholQR2
+            R = torch.linalg.cholesky(X.T @ X).T             # X = Q R, R upper triangular
+            X = torch.linalg.solve_triangular(R, X, upper=True, left=False)
+        return X
+
+    import time
+    if stats is not None:
+        torch.cuda.synchronize(); stats['setup_s'] = time.perf_counter() - stats.get('t0', time.perf_counter()); stats['iters'] = 0
+        stats['nJ'] = solver.nJ; t_loop = time.perf_counter()
+    X = X - X.mean(dim=0, keepdim=True)
+    while True:
+        if stats is not None:
+            stats['iters'] += 1
+        X = orthonormalise(X).contiguous()
+        _lib.check(lib.cslam_csr_spmm4_dev(_p(indptr), _p(indices), _p(data), n, _p(X), _p(W), st))
+        H = X.T @ W
+        sigma, Y = torch.linalg.eigh(H)
+        X = (X @ Y).contiguous()
+        res = float((W @ Y[:, 0] - sigma[0] * X[:, 0]).abs().sum()) / Lnorm
+        if res < tol:
+            break
+        Wi = solver.solve(X)
+        X = Wi @ torch.linalg.inv(Wi.T @ X).T
+        X = X - X.mean(dim=0, keepdim=True)
+    if stats is not None:
+        torch.cuda.synchronize(); stats['loop_s'] = time.perf_counter() - t_loop
+    return float(sigma[0]), X[:, 0].cpu().numpy()

@@ -11,6 +11,7 @@ from collections import namedtuple
 import numpy as np
 
 from .fiedler import fiedler_tracemin_lu
+from .chain_solver import fiedler_tracemin_chain
 from .utils import weight_graph_lap_from_edge_list, weight_graph_lap_from_edges
 
 MACResult = namedtuple('MACResult', ['w', 'F_unrounded', 'objective_values', 'duality_gaps'])
@@ -18,7 +19,11 @@ MACResult = namedtuple('MACResult', ['w', 'F_unrounded', 'objective_values', 'du
 
 class MAC:
 
-    def __init__(self, fixed_measurements, candidate_measurements, num_poses):
+    def __init__(self, fixed_measurements, candidate_measurements, num_poses, fiedler_solver='tracemin_lu'):
+        # 'tracemin_lu'  sparse LU inner solves, the reference's path (networkx + SuperLU)
+        # 'chain'        chain-reduced inner solves, host numpy (same iterates to ~1e-15)
+        # 'chain_gpu'    chain-reduced inner solves and every O(n) step in HIP (large graphs)
+        self.fiedler_solver = fiedler_solver
         self.L_odom = weight_graph_lap_from_edge_list(fixed_measurements, num_poses)
         self.num_poses = num_poses
         self.weights = np.array([m.weight for m in candidate_measurements])
@@ -28,6 +33,11 @@ class MAC:
     def find_fiedler_pair(self, L, method='tracemin_lu', tol=1e-8):
         """(lambda_2(L), v_2(L)); reference mac.py:35-59."""
         assert method == 'tracemin_lu'
+        if self.fiedler_solver == 'chain_gpu':
+            from .chain_solver_gpu import fiedler_tracemin_chain_gpu
+            return fiedler_tracemin_chain_gpu(L, tol=tol, seed=np.random.RandomState(7))
+        if self.fiedler_solver == 'chain':
+            return fiedler_tracemin_chain(L, tol=tol, seed=np.random.RandomState(7))
         return fiedler_tracemin_lu(L, tol=tol, seed=np.random.RandomState(7))
 
     def combined_laplacian(self, w, tol=1e-10):

@@ -139,6 +139,27 @@ int cslam_mac_grad_dev(const double *d_fiedler, const int32_t *d_edge_i, const i
 int cslam_csr_spmm_dev(const int64_t *d_indptr, const int32_t *d_indices, const double *d_data,
                        int64_t n, const double *d_x, int nvec, double *d_y, void *stream);
 
+/* same product with x, y stored [n][4] row-major (the layout of the chain-reduced solver below) */
+int cslam_csr_spmm4_dev(const int64_t *d_indptr, const int32_t *d_indices, const double *d_data,
+                        int64_t n, const double *d_x, double *d_y, void *stream);
+
+/* Chain-reduced Laplacian solve (cslam_amd/mac/chain_solver.py): replaces the sparse-LU solves inside
+ * networkx `_tracemin_fiedler` that cslam/mac/mac.py:52-58 calls (85 % of MAC's time).  Vectors are
+ * [n][4] float64 row-major.  forward: segmented prefix sums of the right-hand side along the odometry
+ * chains (Bn, Qn) and the reduced right-hand side bt [nJ][4] on the junction nodes; backward: closed-form
+ * interior potentials from the junction solution xJ [nJ][4].  Structure arrays (is_junction [n] u8,
+ * r [n-1] chain resistances, J [nJ], per-junction segment ids, per-segment end nodes sa/sb and total
+ * resistance Rl, per-node Rn / jid / seg_of) are built once per Laplacian by the host.
+ * d_tmp: [n][4]; d_scratch: >= 9 * ceil(n / 2048) doubles + slack (see mac_kernels.hip). */
+int cslam_chain_forward_dev(const double *d_b, const uint8_t *d_is_junction, const double *d_r, int64_t n,
+                            const int64_t *d_J, int nJ, const int *d_seg_start_of, const int *d_seg_end_of,
+                            const int64_t *d_sa, const int64_t *d_sb, const double *d_Rl,
+                            double *d_Bn, double *d_Qn, double *d_tmp, double *d_scratch, double *d_bt,
+                            void *stream);
+int cslam_chain_backward_dev(const double *d_xJ, const double *d_Bn, const double *d_Qn, const double *d_r,
+                             const double *d_Rn, const int *d_jid, const int *d_seg_of, const int64_t *d_sa,
+                             const int64_t *d_sb, const double *d_Rl, int64_t n, double *d_x, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -218,3 +218,67 @@ def test_laplacian_assembly_and_gradient():
     assert abs(lam - w[1]) < 1e-8 and np.linalg.norm(Ld @ v - lam * v) < 1e-6
     g = mac.grad_from_fiedler(v)
     assert np.allclose(g, [0.7 * (v[0] - v[9]) ** 2, 0.4 * (v[2] - v[6]) ** 2])
+
+
+# ---- chain-reduced solver (cslam_amd/mac/chain_solver.py): exact elimination of the odometry chains ----
+def _random_pose_graph(R, P, m, seed, overlap=False):
+    rng = np.random.default_rng(seed)
+    edges = [Edge(r * P + k, r * P + k + 1, 1.0) for r in range(R) for k in range(P - 1)]
+    edges += [Edge(r * P + P - 1, (r + 1) * P + P - 1, 1.0) for r in range(R - 1)]
+    if overlap:                      # the reference chains excluded robots at offset 0: doubled chain edges
+        edges += [Edge(k, k + 1, 1.0) for k in range(P // 2)]
+    for _ in range(m):
+        a, b = rng.integers(0, R * P, 2)
+        if a != b:
+            edges.append(Edge(int(a), int(b), float(rng.random() * 0.9 + 0.1)))
+    return weight_graph_lap_from_edge_list(edges, R * P)
+
+
+@pytest.mark.parametrize("R,P,m,overlap", [(1, 60, 5, False), (3, 50, 12, False), (4, 300, 80, True), (8, 400, 600, False)])
+def test_chain_reduced_solver_is_exact(R, P, m, overlap):
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    from cslam_amd.mac.chain_solver import ChainReducedSolver, fiedler_tracemin_chain
+    from cslam_amd.mac.fiedler import fiedler_tracemin_lu
+    L = _random_pose_graph(R, P, m, R + P, overlap)
+    n = L.shape[0]
+    g = int((L.indptr[1:] - L.indptr[:-1]).argmax())
+    keep = np.array([i for i in range(n) if i != g])
+    B = np.random.default_rng(1).standard_normal((n, 4))
+    xr = np.zeros((n, 4))
+    xr[keep] = spla.splu(sp.csc_matrix(L)[keep][:, keep].tocsc()).solve(B[keep])
+    x = ChainReducedSolver(L, g).solve(B)
+    assert np.max(np.abs(x - xr)) < 1e-9 * max(1.0, np.max(np.abs(xr)))
+    assert np.all(x[g] == 0)
+    l1, v1 = fiedler_tracemin_lu(L)
+    l2, v2 = fiedler_tracemin_chain(L)
+    assert abs(l1 - l2) < 1e-12 * max(1.0, abs(l1)) + 1e-14
+    assert min(np.max(np.abs(v1 - v2)), np.max(np.abs(v1 + v2))) < 1e-9
+
+
+def test_chain_solver_handles_missing_chain_edges_and_ragged_ids():
+    """Nodes that are not consecutive on any chain (gaps between robots) are junctions."""
+    from cslam_amd.mac.chain_solver import ChainReducedSolver
+    edges = [Edge(k, k + 1, 2.0) for k in range(0, 19)] + [Edge(k, k + 1, 0.5) for k in range(20, 44)]
+    edges += [Edge(5, 30, 1.0), Edge(19, 20 + 7, 0.3), Edge(0, 44, 0.7), Edge(2, 4, 0.9)]
+    L = weight_graph_lap_from_edge_list(edges, 45)
+    Ld = L.toarray()
+    g = 30
+    keep = [i for i in range(45) if i != g]
+    b = np.random.default_rng(2).standard_normal(45)
+    xr = np.zeros(45); xr[keep] = np.linalg.solve(Ld[np.ix_(keep, keep)], b[keep])
+    x = ChainReducedSolver(L, g).solve(b)
+    assert np.max(np.abs(x - xr)) < 1e-11
+
+
+@pytest.mark.parametrize("tag,R,K", [("mac_R3_P100_C100_K10", 3, 10), ("mac_R5_P100_C200_K100", 5, 100),
+                                     ("mac_R8_P400_C600_K60", 8, 60)])
+def test_selection_with_chain_solver_equals_reference(g7, tag, R, K):
+    """MAC driven by the chain-reduced (host) solver selects exactly the reference's edges."""
+    params = {"frontend.enable_sparsification": True, "evaluation.enable_sparsification_comparison": False,
+              "frontend.mac_fiedler_solver": "chain"}
+    ac = AlgebraicConnectivityMaximization(robot_id=0, max_nb_robots=R, extra_params=params)
+    ac.set_graph(_edges(g7[tag + "/fixed"]), _edges(g7[tag + "/cand"]))
+    sel = ac.select_candidates(K, {r: True for r in range(R)}, greedy_initialization=True)
+    got = np.array([tuple(e) for e in sel], dtype=np.float64).reshape(-1, 5)
+    assert np.array_equal(got, g7[tag + "/selected"])

@@ -52,3 +52,64 @@ def test_mac_grad_and_csr_spmm_match_numpy():
                                       C.c_void_p(data.data_ptr()), n, C.c_void_p(ones.data_ptr()), 1,
                                       C.c_void_p(y1.data_ptr()), None))
     assert float(y1.abs().max()) < 1e-9
+
+
+def _pose_graph(R, P, m, seed):
+    import scipy.sparse as sp
+    rng = np.random.default_rng(seed)
+    n = R * P
+    i = np.concatenate([np.arange(r * P, r * P + P - 1) for r in range(R)])
+    fi = np.array([r * P + P - 1 for r in range(R - 1)], dtype=np.int64)
+    a, b = rng.integers(0, n, m), rng.integers(0, n, m)
+    ok = a != b
+    ii = np.concatenate([i, fi, a[ok]]); jj = np.concatenate([i + 1, fi + P, b[ok]])
+    ww = np.concatenate([np.ones(len(i)), np.ones(len(fi)), rng.random(ok.sum()) * 0.9 + 0.1])
+    rows = np.stack([ii, jj, ii, jj], 1).ravel(); cols = np.stack([ii, jj, jj, ii], 1).ravel()
+    data = np.stack([ww, ww, -ww, -ww], 1).ravel()
+    return sp.csr_matrix(sp.coo_matrix((data, (rows, cols)), shape=(n, n)))
+
+
+@pytest.mark.parametrize("R,P,m", [(1, 50, 4), (3, 700, 40), (8, 2600, 900), (2, 4097, 3)])
+def test_chain_solver_gpu_matches_host(R, P, m):
+    """Segmented-scan kernels + junction solve + back-substitution == the numpy statement
+    (chunk boundaries of the 2048-element scan are crossed by segments of every length)."""
+    import torch
+    from cslam_amd.mac.chain_solver import ChainReducedSolver
+    from cslam_amd.mac.chain_solver_gpu import ChainReducedSolverGPU
+    L = _pose_graph(R, P, m, R * P + m)
+    n = L.shape[0]
+    g = int((L.indptr[1:] - L.indptr[:-1]).argmax())
+    B = np.random.default_rng(0).standard_normal((n, 4))
+    xh = ChainReducedSolver(L, g).solve(B)
+    xd = ChainReducedSolverGPU(L, g).solve(torch.from_numpy(B).cuda()).cpu().numpy()
+    assert np.max(np.abs(xd - xh)) < 1e-9 * max(1.0, np.max(np.abs(xh)))
+    r = L @ xd - B
+    r[g] = 0
+    assert np.max(np.abs(r)) < 1e-8 * max(1.0, np.max(np.abs(B)))
+
+
+def test_fiedler_gpu_matches_reference_algorithm():
+    from cslam_amd.mac.chain_solver_gpu import fiedler_tracemin_chain_gpu
+    from cslam_amd.mac.fiedler import fiedler_tracemin_lu
+    for (R, P, m) in [(3, 100, 30), (8, 400, 600), (8, 2000, 2000)]:
+        L = _pose_graph(R, P, m, 7)
+        l1, v1 = fiedler_tracemin_lu(L)
+        l2, v2 = fiedler_tracemin_chain_gpu(L)
+        assert abs(l1 - l2) < 1e-9 * abs(l1) + 1e-13
+        assert min(np.max(np.abs(v1 - v2)), np.max(np.abs(v1 + v2))) < 1e-6
+        assert np.linalg.norm(L @ v2 - l2 * v2, 1) / abs(L).sum(axis=1).max() < 1e-8
+
+
+@pytest.mark.parametrize("tag,R,K", [("mac_R3_P100_C100_K10", 3, 10), ("mac_R8_P400_C600_K60", 8, 60)])
+def test_selection_with_gpu_solver_equals_reference(tag, R, K):
+    from helpers import GOLDEN
+    from cslam_amd.algebraic_connectivity_maximization import AlgebraicConnectivityMaximization, EdgeInterRobot
+    g7 = np.load(GOLDEN + "/mac_g7.npz")
+    ed = lambda arr: [EdgeInterRobot(int(a), int(b), int(c), int(d), float(w)) for a, b, c, d, w in arr]
+    params = {"frontend.enable_sparsification": True, "evaluation.enable_sparsification_comparison": False,
+              "frontend.mac_fiedler_solver": "chain_gpu"}
+    ac = AlgebraicConnectivityMaximization(robot_id=0, max_nb_robots=R, extra_params=params)
+    ac.set_graph(ed(g7[tag + "/fixed"]), ed(g7[tag + "/cand"]))
+    sel = ac.select_candidates(K, {r: True for r in range(R)}, greedy_initialization=True)
+    got = np.array([tuple(e) for e in sel], dtype=np.float64).reshape(-1, 5)
+    assert np.array_equal(got, g7[tag + "/selected"])
