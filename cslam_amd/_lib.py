@@ -48,6 +48,9 @@ _SIGNATURES = {
     "cslam_mac_grad_dev": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "cslam_csr_spmm_dev": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _vp, _vp]),
     "cslam_csr_spmm4_dev": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),
+    "cslam_block4_gram_dev": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "cslam_block4_affine_dev": (_i, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "cslam_block4_residual_dev": (_i, [_vp, _vp, _i64, _vp, C.c_double, _vp, _vp, _vp]),
     "cslam_chain_forward_dev": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cslam_chain_backward_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
 }

@@ -317,3 +317,123 @@ CSLAM_API int cslam_csr_spmm4_dev(const int64_t *d_indptr, const int32_t *d_indi
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }
+
+// ---- 4-column block operations of the TraceMIN outer loop ([n][4] float64 row-major) ----
+// (tall-skinny products through a BLAS dgemm take ~10-30 ms each at n = 1e6; these are one
+// streaming pass each)
+#define B4_BLOCK 256
+// partial[block][16] = sum over the block's rows of a_i^T b_i ; partial[block][16..19] = column sums of b
+__global__ __launch_bounds__(B4_BLOCK) void block4_gram_kernel(const double *__restrict__ A, const double *__restrict__ Bm,
+                                                               int64_t n, double *__restrict__ partial) {
+    __shared__ double red[4][20];
+    double acc[20];
+#pragma unroll
+    for (int i = 0; i < 20; ++i) acc[i] = 0.0;
+    for (int64_t k = (int64_t)blockIdx.x * B4_BLOCK + threadIdx.x; k < n; k += (int64_t)gridDim.x * B4_BLOCK) {
+        double a[CQ], b[CQ];
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) { a[c] = A[k * CQ + c]; b[c] = Bm[k * CQ + c]; }
+#pragma unroll
+        for (int i = 0; i < CQ; ++i)
+#pragma unroll
+            for (int j = 0; j < CQ; ++j) acc[i * CQ + j] += a[i] * b[j];
+#pragma unroll
+        for (int j = 0; j < CQ; ++j) acc[16 + j] += b[j];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < 20; ++i) {
+        double v = acc[i];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 20)
+        partial[(size_t)blockIdx.x * 20 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+__global__ void block4_gram_finish_kernel(const double *__restrict__ partial, int nblocks, double *__restrict__ out20) {
+    const int i = threadIdx.x;
+    if (i >= 20) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * 20 + i];   // fixed order: deterministic
+    out20[i] = s;
+}
+
+// out[k][:] = A[k][:] * M (4x4, row-major) - shift[:]
+__global__ __launch_bounds__(256) void block4_affine_kernel(const double *__restrict__ A, int64_t n,
+                                                            const double *__restrict__ M16, const double *__restrict__ shift4,
+                                                            double *__restrict__ out) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double a[CQ], o[CQ];
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) a[c] = A[k * CQ + c];
+#pragma unroll
+    for (int j = 0; j < CQ; ++j) {
+        double s = shift4 ? -shift4[j] : 0.0;
+#pragma unroll
+        for (int i = 0; i < CQ; ++i) s += a[i] * M16[i * CQ + j];
+        o[j] = s;
+    }
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) out[k * CQ + c] = o[c];
+}
+
+// partial[block] = sum_k | sum_c W[k][c] y[c]  -  sigma * X[k][0] |   (1-norm of the Ritz residual)
+__global__ __launch_bounds__(B4_BLOCK) void block4_residual_kernel(const double *__restrict__ W, const double *__restrict__ X,
+                                                                   int64_t n, const double *__restrict__ y4, double sigma,
+                                                                   double *__restrict__ partial) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    const double y0 = y4[0], y1 = y4[1], y2 = y4[2], y3 = y4[3];
+    for (int64_t k = (int64_t)blockIdx.x * B4_BLOCK + threadIdx.x; k < n; k += (int64_t)gridDim.x * B4_BLOCK) {
+        double w = W[k * CQ] * y0 + W[k * CQ + 1] * y1 + W[k * CQ + 2] * y2 + W[k * CQ + 3] * y3;
+        acc += fabs(w - sigma * X[k * CQ]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void block4_sum_finish_kernel(const double *__restrict__ partial, int nblocks, double *__restrict__ out1) {
+    if (threadIdx.x != 0) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[b];
+    out1[0] = s;
+}
+
+#define B4_GRID 1024
+CSLAM_API int cslam_block4_gram_dev(const double *d_A, const double *d_B, int64_t n, double *d_partial,
+                                    double *d_out20, void *stream) {
+    ARG_CHECK(d_A && d_B && d_partial && d_out20 && n >= 1, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    int grid = (int)ceil_div64(n, B4_BLOCK); if (grid > B4_GRID) grid = B4_GRID;
+    hipLaunchKernelGGL(block4_gram_kernel, dim3(grid), dim3(B4_BLOCK), 0, st, d_A, d_B, n, d_partial);
+    hipLaunchKernelGGL(block4_gram_finish_kernel, dim3(1), dim3(64), 0, st, d_partial, grid, d_out20);
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
+CSLAM_API int cslam_block4_affine_dev(const double *d_A, int64_t n, const double *d_M16, const double *d_shift4,
+                                      double *d_out, void *stream) {
+    ARG_CHECK(d_A && d_M16 && d_out && n >= 1, "bad argument");
+    hipLaunchKernelGGL(block4_affine_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                       d_A, n, d_M16, d_shift4, d_out);
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
+CSLAM_API int cslam_block4_residual_dev(const double *d_W, const double *d_X, int64_t n, const double *d_y4,
+                                        double sigma, double *d_partial, double *d_out1, void *stream) {
+    ARG_CHECK(d_W && d_X && d_y4 && d_partial && d_out1 && n >= 1, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    int grid = (int)ceil_div64(n, B4_BLOCK); if (grid > B4_GRID) grid = B4_GRID;
+    hipLaunchKernelGGL(block4_residual_kernel, dim3(grid), dim3(B4_BLOCK), 0, st, d_W, d_X, n, d_y4, sigma, d_partial);
+    hipLaunchKernelGGL(block4_sum_finish_kernel, dim3(1), dim3(64), 0, st, d_partial, grid, d_out1);
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}

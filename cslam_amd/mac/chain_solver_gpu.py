@@ -105,32 +105,59 @@ def fiedler_tracemin_chain_gpu(L, tol=1e-8, seed=None, device="cuda", stats=None
     Lnorm = float(abs(L).sum(axis=1).max())
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     W = torch.empty_like(X)
+    partial = torch.empty(20 * 1024, dtype=torch.float64, device=dev)
+    out20 = torch.empty(20, dtype=torch.float64, device=dev)
+    small = torch.empty(16 + 4, dtype=torch.float64, device=dev)       # 4x4 matrix + 4-vector staging
+
+    def gram(A, B):
+        """(A^T B as numpy 4x4, column sums of B)"""
+        _lib.check(lib.cslam_block4_gram_dev(_p(A), _p(B), n, _p(partial), _p(out20), st))
+        h = out20.cpu().numpy()
+        return h[:16].reshape(4, 4).copy(), h[16:].copy()
+
+    def affine(A, M, shift=None):
+        """A @ M - shift, one streaming pass"""
+        small[:16] = torch.from_numpy(np.ascontiguousarray(M, dtype=np.float64).reshape(-1)).to(dev)
+        sp_ = None
+        if shift is not None:
+            small[16:] = torch.from_numpy(np.ascontiguousarray(shift, dtype=np.float64)).to(dev)
+            sp_ = C.c_void_p(small.data_ptr() + 16 * 8)
+        out = torch.empty_like(A)
+        _lib.check(lib.cslam_block4_affine_dev(_p(A), n, _p(small), sp_, _p(out), st))
+        return out
 
     def orthonormalise(X):
-        for _ in range(2):                                   # CholQR2
-            R = torch.linalg.cholesky(X.T @ X).T             # X = Q R, R upper triangular
-            X = torch.linalg.solve_triangular(R, X, upper=True, left=False)
+        for _ in range(2):                                   # CholQR2: X = Q R
+            G, _ = gram(X, X)
+            R = np.linalg.cholesky(G).T
+            X = affine(X, np.linalg.inv(R))
         return X
 
     import time
+    import scipy.linalg
     if stats is not None:
         torch.cuda.synchronize(); stats['setup_s'] = time.perf_counter() - stats.get('t0', time.perf_counter()); stats['iters'] = 0
         stats['nJ'] = solver.nJ; t_loop = time.perf_counter()
-    X = X - X.mean(dim=0, keepdim=True)
+    _, cs = gram(X, X)
+    X = affine(X, np.eye(4), cs / n)                         # project out the constant vector
     while True:
         if stats is not None:
             stats['iters'] += 1
-        X = orthonormalise(X).contiguous()
+        X = orthonormalise(X)
         _lib.check(lib.cslam_csr_spmm4_dev(_p(indptr), _p(indices), _p(data), n, _p(X), _p(W), st))
-        H = X.T @ W
-        sigma, Y = torch.linalg.eigh(H)
-        X = (X @ Y).contiguous()
-        res = float((W @ Y[:, 0] - sigma[0] * X[:, 0]).abs().sum()) / Lnorm
+        H, _ = gram(X, W)
+        sigma, Y = scipy.linalg.eigh(0.5 * (H + H.T))
+        X = affine(X, Y)
+        small[:4] = torch.from_numpy(np.ascontiguousarray(Y[:, 0])).to(dev)
+        _lib.check(lib.cslam_block4_residual_dev(_p(W), _p(X), n, _p(small), float(sigma[0]), _p(partial), _p(out20), st))
+        res = float(out20[0].item()) / Lnorm
         if res < tol:
             break
         Wi = solver.solve(X)
-        X = Wi @ torch.linalg.inv(Wi.T @ X).T
-        X = X - X.mean(dim=0, keepdim=True)
+        M, _ = gram(Wi, X)                                   # W^T X
+        X = affine(Wi, np.linalg.inv(M).T)
+        _, cs = gram(X, X)
+        X = affine(X, np.eye(4), cs / n)
     if stats is not None:
         torch.cuda.synchronize(); stats['loop_s'] = time.perf_counter() - t_loop
     return float(sigma[0]), X[:, 0].cpu().numpy()

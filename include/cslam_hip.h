@@ -143,6 +143,19 @@ int cslam_csr_spmm_dev(const int64_t *d_indptr, const int32_t *d_indices, const 
 int cslam_csr_spmm4_dev(const int64_t *d_indptr, const int32_t *d_indices, const double *d_data,
                         int64_t n, const double *d_x, double *d_y, void *stream);
 
+/* 4-column block operations of the TraceMIN outer loop on [n][4] float64 row-major vectors
+ * (the X'X, X'LX, X Y, projection and residual steps of networkx `_tracemin_fiedler`):
+ *   gram:     out20[0..15] = A^T B (4x4 row-major), out20[16..19] = column sums of B
+ *   affine:   out = A * M16 - shift4 (shift4 may be NULL)
+ *   residual: out1 = sum_k | (W y4)[k] - sigma * X[k][0] |
+ * d_partial: scratch of >= 20 * 1024 doubles.  Deterministic (fixed reduction order). */
+int cslam_block4_gram_dev(const double *d_A, const double *d_B, int64_t n, double *d_partial,
+                          double *d_out20, void *stream);
+int cslam_block4_affine_dev(const double *d_A, int64_t n, const double *d_M16, const double *d_shift4,
+                            double *d_out, void *stream);
+int cslam_block4_residual_dev(const double *d_W, const double *d_X, int64_t n, const double *d_y4,
+                              double sigma, double *d_partial, double *d_out1, void *stream);
+
 /* Chain-reduced Laplacian solve (cslam_amd/mac/chain_solver.py): replaces the sparse-LU solves inside
  * networkx `_tracemin_fiedler` that cslam/mac/mac.py:52-58 calls (85 % of MAC's time).  Vectors are
  * [n][4] float64 row-major.  forward: segmented prefix sums of the right-hand side along the odometry
