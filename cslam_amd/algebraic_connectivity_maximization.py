@@ -18,7 +18,7 @@ from typing import NamedTuple
 import numpy as np
 
 from cslam_amd.mac.mac import MAC
-from cslam_amd.mac.utils import Edge
+from cslam_amd.mac.utils import Edge, EdgeArrays
 
 
 class EdgeInterRobot(NamedTuple):
@@ -234,6 +234,13 @@ class AlgebraicConnectivityMaximization(object):
                               for k in range(self.nb_poses[r] - 1))
         return odom_edges
 
+    def fill_odometry_arrays(self):
+        """fill_odometry() in column form (no per-edge objects)."""
+        i = [np.arange(self.offsets[r], self.offsets[r] + self.nb_poses[r] - 1, dtype=np.int64)
+             for r in range(len(self.nb_poses)) if self.nb_poses[r] > 1]
+        i = np.concatenate(i) if i else np.zeros(0, dtype=np.int64)
+        return EdgeArrays(i, i + 1, np.full(len(i), float(self.fixed_weight)))
+
     def recover_inter_robot_edges(self, edges, is_robot_included):
         """Inverse of rekey_edges: node ids back to (robot, keyframe) (reference :364-389)."""
         recovered = []
@@ -306,7 +313,11 @@ class AlgebraicConnectivityMaximization(object):
         is_robot_included = self.check_graph_disconnections(is_other_robot_considered)
         self.compute_offsets(is_robot_included)
         rekeyed_fixed = self.rekey_edges(self.fixed_edges, is_robot_included)
-        rekeyed_fixed.extend(self.fill_odometry())
+        if sum(self.nb_poses.values()) >= 20000:
+            # large graphs: the odometry chains as arrays (same edges, same order as fill_odometry())
+            rekeyed_fixed = EdgeArrays.from_edges(rekeyed_fixed).concat(self.fill_odometry_arrays())
+        else:
+            rekeyed_fixed.extend(self.fill_odometry())
         rekeyed_cand = self.rekey_edges(self.candidate_edges.values(), is_robot_included)
         if nb_candidates_to_choose > len(rekeyed_cand):
             nb_candidates_to_choose = len(rekeyed_cand)

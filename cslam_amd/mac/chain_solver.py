@@ -68,6 +68,7 @@ class ChainReducedSolver:
         ri = np.concatenate([jid[self.sa], jid[li]])
         rj = np.concatenate([jid[self.sb], jid[lj]])
         rw = np.concatenate([1.0 / self.Rl, lw])
+        self.red_i, self.red_j, self.red_w = ri, rj, rw        # reduced graph as an edge list (junction ids)
         S = sp.coo_matrix((np.concatenate([rw, rw, -rw, -rw]),
                            (np.concatenate([ri, rj, ri, rj]), np.concatenate([ri, rj, rj, ri]))),
                           shape=(self.nJ, self.nJ)).tocsc()

@@ -22,7 +22,10 @@ def _p(t):
 
 
 class ChainReducedSolverGPU(object):
-    MAX_DENSE = 24000          # junctions; above this the reduced system is solved on the host (sparse LU)
+    # junctions; above this the reduced system is solved on the host (sparse LU).  A dense float64
+    # factor of 64k junctions is 33 GB -- small next to 288 GB of HBM -- while a sparse LU of a
+    # loop-closure graph with random long-range edges fills in almost completely.
+    MAX_DENSE = 64000
 
     def __init__(self, L, ground, device="cuda"):
         import torch
@@ -56,8 +59,22 @@ class ChainReducedSolverGPU(object):
         self.free = t(host.free, np.int64)
         self.dense = nJ - 1 <= self.MAX_DENSE
         if self.dense:
-            Sf = torch.from_numpy(host.Sf.toarray()).to(dev)
+            # assemble the grounded junction Laplacian directly in HBM from the reduced edge list
+            # (a 40k-junction matrix is 12.8 GB: never materialised on the host)
+            g = int(host.jid[host.ground])
+            m = nJ - 1
+            Sf = torch.zeros((m, m), dtype=torch.float64, device=dev)
+            ri, rj, rw = t(host.red_i, np.int64), t(host.red_j, np.int64), t(host.red_w, np.float64)
+            fi = ri - (ri > g).to(torch.int64)
+            fj = rj - (rj > g).to(torch.int64)
+            ki, kj = ri != g, rj != g
+            both = ki & kj
+            Sf.index_put_((fi[ki], fi[ki]), rw[ki], accumulate=True)
+            Sf.index_put_((fj[kj], fj[kj]), rw[kj], accumulate=True)
+            Sf.index_put_((fi[both], fj[both]), -rw[both], accumulate=True)
+            Sf.index_put_((fj[both], fi[both]), -rw[both], accumulate=True)
             self.chol = torch.linalg.cholesky(Sf)
+            del Sf
         else:
             host.factorize()
 

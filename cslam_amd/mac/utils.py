@@ -23,8 +23,40 @@ def _laplacian_from_arrays(i, j, w, n):
     return csr_matrix(coo_matrix((data, (rows, cols)), shape=[n, n]))
 
 
+class EdgeArrays(object):
+    """Column form of a list of Edge (i, j, weight arrays), in the same order.  Lets the million
+    odometry edges of a large pose graph skip the per-edge Python objects; the Laplacian built from
+    it is bit-identical to the one built from the equivalent list."""
+
+    def __init__(self, i, j, weight):
+        self.i = np.asarray(i, dtype=np.int64)
+        self.j = np.asarray(j, dtype=np.int64)
+        self.weight = np.asarray(weight, dtype=np.float64)
+
+    def __len__(self):
+        return len(self.i)
+
+    @staticmethod
+    def from_edges(edges):
+        if isinstance(edges, EdgeArrays):
+            return edges
+        if len(edges) == 0:
+            return EdgeArrays(np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0))
+        arr = np.array([(e.i, e.j, e.weight) for e in edges], dtype=np.float64)
+        return EdgeArrays(arr[:, 0].astype(np.int64), arr[:, 1].astype(np.int64), arr[:, 2])
+
+    def concat(self, other):
+        o = EdgeArrays.from_edges(other)
+        return EdgeArrays(np.concatenate([self.i, o.i]), np.concatenate([self.j, o.j]),
+                          np.concatenate([self.weight, o.weight]))
+
+
 def weight_graph_lap_from_edge_list(edges, num_vars):
     """Sparse weighted graph Laplacian from a list of Edge (reference utils.py:47-84)."""
+    if isinstance(edges, EdgeArrays):
+        if len(edges) == 0:
+            return csr_matrix((num_vars, num_vars), dtype=np.float64)
+        return _laplacian_from_arrays(edges.i, edges.j, edges.weight, num_vars)
     if len(edges) == 0:
         return csr_matrix((num_vars, num_vars), dtype=np.float64)
     arr = np.array([(e.i, e.j, e.weight) for e in edges], dtype=np.float64)

@@ -1,0 +1,23 @@
+"""GPU test: a plain-C program drives the hot path through include/cslam_hip.h only (-m gpu)."""
+import os
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_plain_c_client(tmp_path):
+    exe = str(tmp_path / "abi_smoke")
+    libdir = os.path.join(ROOT, "cslam_amd")
+    r = subprocess.run(["gcc", "-std=c11", "-O1", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "c_abi", "abi_smoke.c"), "-L" + libdir, "-lcslam_hip", "-lm",
+                        "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = libdir + ":/opt/rocm/lib:" + env.get("LD_LIBRARY_PATH", "")
+    r = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "C ABI smoke ok" in r.stdout
