@@ -21,6 +21,54 @@ def _p(t):
     return C.c_void_p(t.data_ptr())
 
 
+def blocked_cholesky_(A, bs=2048):
+    """In-place lower Cholesky factor of a symmetric positive definite float64 device matrix, right-
+    looking by blocks: small diagonal factorisations + one triangular solve + one plain GEMM
+    (hipBLASLt fp64) per block column.  The library potrf ran at ~4 TFLOP/s on 32k junctions; the
+    trailing GEMMs run an order of magnitude faster.  Only the lower triangle of the result is valid."""
+    import torch
+    m = A.shape[0]
+    for k in range(0, m, bs):
+        e = min(k + bs, m)
+        A[k:e, k:e] = torch.linalg.cholesky(A[k:e, k:e])
+        if e < m:
+            L11 = A[k:e, k:e]
+            A[e:, k:e] = torch.linalg.solve_triangular(L11, A[e:, k:e].T, upper=False).T     # L21 = A21 L11^-T
+            L21 = A[e:, k:e]
+            A[e:, e:] -= L21 @ L21.T
+    return A
+
+
+class BlockedCholeskySolve(object):
+    """x = (L L^T)^-1 b for a dense lower factor L and a thin right-hand side (4 columns): the
+    diagonal blocks are inverted once, after which forward and backward substitution are plain
+    GEMMs that stream L twice per solve (the library potrs/trsm path took ~0.1 s per call on 32k
+    junctions with 4 columns)."""
+
+    def __init__(self, L, bs=2048):
+        import torch
+        self.L, self.bs, self.m = L, bs, L.shape[0]
+        self.starts = list(range(0, self.m, bs))
+        eye = lambda k: torch.eye(k, dtype=L.dtype, device=L.device)
+        self.dinv = [torch.linalg.solve_triangular(L[k:min(k + bs, self.m), k:min(k + bs, self.m)],
+                                                  eye(min(k + bs, self.m) - k), upper=False) for k in self.starts]
+
+    def solve(self, b):
+        x = b.clone()
+        L, m, bs = self.L, self.m, self.bs
+        for t, k in enumerate(self.starts):                       # forward: L y = b
+            e = min(k + bs, m)
+            x[k:e] = self.dinv[t] @ x[k:e]
+            if e < m:
+                x[e:] -= L[e:, k:e] @ x[k:e]
+        for t in range(len(self.starts) - 1, -1, -1):              # backward: L^T x = y
+            k = self.starts[t]; e = min(k + bs, m)
+            x[k:e] = self.dinv[t].T @ x[k:e]
+            if k > 0:
+                x[:k] -= L[k:e, :k].T @ x[k:e]
+        return x
+
+
 class ChainReducedSolverGPU(object):
     # junctions; above this the reduced system is solved on the host (sparse LU).  A dense float64
     # factor of 64k junctions is 33 GB -- small next to 288 GB of HBM -- while a sparse LU of a
@@ -28,11 +76,16 @@ class ChainReducedSolverGPU(object):
     MAX_DENSE = 64000
 
     def __init__(self, L, ground, device="cuda"):
-        import torch
+        import os, time, torch
         self.torch = torch
+        _t = [time.perf_counter()]
+        def _lap(tag):
+            if os.environ.get('CSLAM_MAC_TIMING'):
+                torch.cuda.synchronize(); _t.append(time.perf_counter()); print(f'      [{tag} {(_t[-1]-_t[-2])*1e3:.0f} ms]', end='', flush=True)
         self.lib = _lib.load()
         host = ChainReducedSolver.__new__(ChainReducedSolver)
         ChainReducedSolver.__init__(host, L, ground, factorize=False)
+        _lap('host structure')
         self.host = host
         n, nJ = host.n, host.nJ
         self.n, self.nJ = n, nJ
@@ -57,6 +110,7 @@ class ChainReducedSolverGPU(object):
         self.scratch = f64(9 * nch + 64)
         self.bt = f64(nJ, 4)
         self.free = t(host.free, np.int64)
+        _lap('upload')
         self.dense = nJ - 1 <= self.MAX_DENSE
         if self.dense:
             # assemble the grounded junction Laplacian directly in HBM from the reduced edge list
@@ -73,10 +127,16 @@ class ChainReducedSolverGPU(object):
             Sf.index_put_((fj[kj], fj[kj]), rw[kj], accumulate=True)
             Sf.index_put_((fi[both], fj[both]), -rw[both], accumulate=True)
             Sf.index_put_((fj[both], fi[both]), -rw[both], accumulate=True)
+            _lap('assemble nJ=%d' % nJ)
             self.chol = torch.linalg.cholesky(Sf)
             del Sf
+            _lap('cholesky')
+            self.tri = BlockedCholeskySolve(self.chol) if m > 4096 else None
         else:
             host.factorize()
+        _lap('block inverses')
+        if os.environ.get('CSLAM_MAC_TIMING'):
+            print(flush=True)
 
     def solve(self, X):
         """X [n,4] float64 device tensor -> A^-1 X (row `ground` = 0)."""
@@ -91,7 +151,7 @@ class ChainReducedSolverGPU(object):
         if self.nJ > 1:
             rhs = self.bt[self.free]
             if self.dense:
-                xJ[self.free] = torch.cholesky_solve(rhs, self.chol)
+                xJ[self.free] = self.tri.solve(rhs) if self.tri is not None else torch.cholesky_solve(rhs, self.chol)
             else:
                 xJ[self.free] = torch.from_numpy(self.host.lu.solve(rhs.cpu().numpy())).to(X.device)
         out = torch.empty_like(X)

@@ -20,6 +20,15 @@ while len(cand) < C:
           e.robot1_keyframe_id if a < b else e.robot0_keyframe_id)] = e
 cand = list(cand.values())
 sels = {}
+from cslam_amd.mac.mac import MAC
+_orig = MAC.evaluate_fiedler_pair
+_times = []
+def _timed(self, w, method='tracemin_lu', tol=1e-8):
+    t0 = time.perf_counter(); L = self.combined_laplacian(w); t1 = time.perf_counter()
+    out = self.find_fiedler_pair(L, method, tol); t2 = time.perf_counter()
+    _times.append((t1 - t0, t2 - t1, int((w > 1e-10).sum())))
+    return out
+MAC.evaluate_fiedler_pair = _timed
 for s in solvers:
     params = {"frontend.enable_sparsification": True, "evaluation.enable_sparsification_comparison": False,
               "frontend.mac_fiedler_solver": s}
@@ -29,6 +38,9 @@ for s in solvers:
     sel = ac.select_candidates(K, {r: True for r in range(R)})
     dt = time.perf_counter() - t0
     sels[s] = sorted(tuple(e)[:4] for e in sel)
+    if _times:
+        print('   per FW iteration (laplacian s, fiedler s, active edges):', [(round(a, 2), round(b, 2), c) for a, b, c in _times[:3]], '...', [(round(a, 2), round(b, 2), c) for a, b, c in _times[-2:]], 'sum fiedler %.1fs' % sum(b for _, b, _ in _times))
+        _times.clear()
     print(f"{s}: n={R*P} candidates={C} K={K}: select_candidates {dt:.1f}s, selected {len(sel)}", flush=True)
 if len(sels) > 1:
     base = sels[solvers[0]]
