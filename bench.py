@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--cpu-queries", type=int, default=12, help="cpu_baseline sample size (queries)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extract", action="store_true", help="debug: time the match leg only")
+    ap.add_argument("--debug-shared-gpu", action="store_true",
+                    help="debug only: all ranks share cuda:0 and exchange descriptors through gloo/CPU, to "
+                         "exercise the N>1 control flow on a 1-GPU box (numbers are meaningless)")
     return ap.parse_args()
 
 
@@ -60,7 +63,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 and a.debug_shared_gpu:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local_rank = 0
+        dist.init_process_group("gloo")
+    elif world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
@@ -92,7 +99,14 @@ def main():
         kernel_ms.append(nn.last_kernel_ms())
         return out
 
-    matcher = ShardedInterRobotMatcher(rank, world, search, k_intra=a.k)
+    gather_fn = None
+    if a.debug_shared_gpu and world > 1:
+        def gather_fn(local, world_size, group=None):          # gloo has no device all-gather: stage through the host
+            out = torch.empty((world_size * local.shape[0], local.shape[1]), dtype=local.dtype)
+            dist.all_gather_into_tensor(out, local.cpu().contiguous())
+            return out.to(local.device)
+    matcher = (ShardedInterRobotMatcher(rank, world, search, k_intra=a.k, gather_fn=gather_fn) if gather_fn
+               else ShardedInterRobotMatcher(rank, world, search, k_intra=a.k))
 
     def extract():
         if extractor is None:
@@ -118,7 +132,7 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
-            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            t = torch.tensor([dt], device="cpu" if a.debug_shared_gpu else dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt

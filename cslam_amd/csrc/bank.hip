@@ -502,8 +502,10 @@ CSLAM_API int cslam_bank_search_dev(cslam_bank_t *b, const void *d_queries, int 
     b->stats[0] = 0; b->stats[2] = 0; b->stats[3] = 0;
     if (nq == 0) return CSLAM_OK;
     int use = mode;
-    if (use == CSLAM_MODE_AUTO) use = (nq <= 8 || k > 8 || b->n < 256) ? CSLAM_MODE_SCAN : CSLAM_MODE_MFMA;
-    if (use == CSLAM_MODE_MFMA && k > 8) use = CSLAM_MODE_SCAN;   // candidate lists hold 16 entries
+    // the MFMA path keeps 16 merged candidates per (query, segment): k <= 16 (the reference's default
+    // nb_best_matches is 10); larger k, tiny banks and single queries use the exact scan
+    if (use == CSLAM_MODE_AUTO) use = (nq <= 8 || k > 16 || b->n < 256) ? CSLAM_MODE_SCAN : CSLAM_MODE_MFMA;
+    if (use == CSLAM_MODE_MFMA && k > 16) use = CSLAM_MODE_SCAN;
     b->stats[1] = use;
     if (use == CSLAM_MODE_SCAN)
         return scan_search(b, d_queries, q_dtype, ldq, nullptr, nq, k, d_row_limit, d_out_idx, d_out_sim,

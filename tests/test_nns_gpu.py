@@ -223,3 +223,19 @@ def test_large_tile_clustered_rows_force_bounds(nnm):
     idx, sims, cnt = nn.search_batch(q.astype(np.float32), 5, mode=nnm.MODE_MFMA)
     oi, os_, oc = pyoracle.nns_search(bank, q.astype(np.float32), 5)
     assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
+
+
+@pytest.mark.parametrize("n,d,nq,k", [(3000, 256, 500, 10), (9000, 128, 8300, 16), (4000, 512, 300, 12)])
+def test_mfma_path_serves_default_nb_best_matches(nnm, n, d, nq, k):
+    """k up to 16 (the reference's default frontend.nb_best_matches is 10) stays on the MFMA path."""
+    bank = unit_rows(np.random.default_rng(n + k), n, d)
+    q = unit_rows(np.random.default_rng(n + k + 1), nq, d)
+    nn = make_bank(nnm, bank)
+    idx, sims, cnt = nn.search_batch(q, k, mode=nnm.MODE_AUTO)
+    assert nn.last_stats()[1] == nnm.MODE_MFMA
+    oi, os_, oc = pyoracle.nns_search(bank, q, k)
+    assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
+    idx, sims, cnt = nn.search_batch(q[:40], 17, mode=nnm.MODE_AUTO)       # beyond the lists -> scan
+    assert nn.last_stats()[1] == nnm.MODE_SCAN
+    oi, os_, oc = pyoracle.nns_search(bank, q[:40], 17)
+    assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
