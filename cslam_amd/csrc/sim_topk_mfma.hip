@@ -52,7 +52,7 @@ struct MfmaArgs {
 // Waves: 2 along the bank axis x (T_/64) along the query axis.
 // DBG != 0 are TIMING-ONLY ablations (wrong results): 1 = no global loads after the first K step,
 // 2 = no per-step wait/barrier.  Selected with CSLAM_MFMA_DBG; never used by the product path.
-template <int T_, int MT, int KPL, int DBG>
+template <int T_, int MT, int KPL, int DBG, bool ILV>
 __global__ __launch_bounds__(T_ * 2, 2) void sim_topk_mfma_kernel(MfmaArgs p) {
     constexpr int NTHR = T_ * 2;                 // 256 or 512 threads
     constexpr int NWN = T_ / 64;                 // waves along the query axis
@@ -116,17 +116,18 @@ __global__ __launch_bounds__(T_ * 2, 2) void sim_topk_mfma_kernel(MfmaArgs p) {
         }
         const int wave_chunk = wave * 1024;          // this wave's 1 KiB slice of each NTHR*16-byte group
 
-        auto stage_load = [&](int stage, int tile, int kt) {
+        auto stage_load_part = [&](int stage, int tile, int kt, int i) {   // 2 LDS-DMA instructions
             char *sA = smem + stage * STAGE;
             char *sB = sA + OPB;
+            int64_t brow = (int64_t)tile * T_ + rowA[i];
+            if (brow > p.n_rows - 1) brow = p.n_rows - 1;
+            const float *ga = p.bank + brow * p.ldb + (kt * TK + colc[i]);
+            glds16(ga, sA + i * (NTHR * 16) + wave_chunk);
+            glds16(gB[i] + kt * TK, sB + i * (NTHR * 16) + wave_chunk);
+        };
+        auto stage_load = [&](int stage, int tile, int kt) {
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                int64_t brow = (int64_t)tile * T_ + rowA[i];
-                if (brow > p.n_rows - 1) brow = p.n_rows - 1;
-                const float *ga = p.bank + brow * p.ldb + (kt * TK + colc[i]);
-                glds16(ga, sA + i * (NTHR * 16) + wave_chunk);
-                glds16(gB[i] + kt * TK, sB + i * (NTHR * 16) + wave_chunk);
-            }
+            for (int i = 0; i < NLD; ++i) stage_load_part(stage, tile, kt, i);
         };
 
         // ---- fragment read offsets (bytes) within a tile: row*128 + ((2j+h) ^ swz)*16
@@ -155,7 +156,11 @@ __global__ __launch_bounds__(T_ * 2, 2) void sim_topk_mfma_kernel(MfmaArgs p) {
             // prefetch the next K step (possibly of the next bank tile) into the other stage
             int nkt_ = kt + 1, ntile = tile;
             if (nkt_ == p.nkt) { nkt_ = 0; ntile = tile + 1; }
-            if (DBG != 1 && it + 1 < total) stage_load(cur ^ 1, ntile, nkt_);
+            const bool pf = (DBG != 1) && (it + 1 < total);
+            if (!ILV && pf) stage_load(cur ^ 1, ntile, nkt_);
+            // interleaved form: branch-free (a branch would split the scheduling region); the very last
+            // step re-fetches its own tile into the idle stage, which nobody reads
+            const int ltile = (it + 1 < total) ? ntile : tile, lkt = (it + 1 < total) ? nkt_ : kt;
 
             const char *sA = smem + cur * STAGE;
             const char *sB = sA + OPB;
@@ -173,6 +178,19 @@ __global__ __launch_bounds__(T_ * 2, 2) void sim_topk_mfma_kernel(MfmaArgs p) {
 #pragma unroll
                         for (int n = 0; n < 2; ++n)
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][t], b[n][t], acc[m][n], 0, 0, 0);
+                if (ILV) {
+                    // one quarter of the next stage's LDS-DMA per K group, issued BETWEEN this group's MFMAs:
+                    // a global_load_lds costs ~60-180 issue cycles; eight of them back to back at the top of
+                    // the step (both waves of a SIMD do that right after the barrier) leave the matrix pipe
+                    // idle ~1.3k cycles per step.  Behind an MFMA the issue hides in its 64-cycle shadow.
+                    if (DBG != 1) stage_load_part(cur ^ 1, ltile, lkt, j);
+                    constexpr int G = MT * 2 * 4;                 // MFMAs per K group (16 or 32)
+                    __builtin_amdgcn_sched_group_barrier(0x008, G / 4, 0);      // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);          // VMEM read (LDS-DMA)
+                    __builtin_amdgcn_sched_group_barrier(0x008, G / 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, G / 2, 0);
+                }
             }
 
             if (kt == p.nkt - 1) {
@@ -441,22 +459,25 @@ __global__ __launch_bounds__(256) void rescore_kernel(
 }
 
 template <int T_, int MT, int KPL>
-static int launch_stage1(const MfmaArgs &a, int dbg, hipStream_t st) {
+static int launch_stage1(const MfmaArgs &a, int dbg, int ilv, hipStream_t st) {
     constexpr int lds = 2 * 2 * T_ * TK * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 0>,
+        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 0, false>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 1>,
+        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 0, true>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 2>,
+        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 1, false>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 2, false>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     const dim3 grid(a.nqt * a.nseg), blk(T_ * 2);
-    if (dbg == 1) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 1>), grid, blk, lds, st, a);
-    else if (dbg == 2) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 2>), grid, blk, lds, st, a);
-    else hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 0>), grid, blk, lds, st, a);
+    if (dbg == 1) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 1, false>), grid, blk, lds, st, a);
+    else if (dbg == 2) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 2, false>), grid, blk, lds, st, a);
+    else if (ilv) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 0, true>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 0, false>), grid, blk, lds, st, a);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }
@@ -464,13 +485,15 @@ static int launch_stage1(const MfmaArgs &a, int dbg, hipStream_t st) {
 int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_t nq, int k,
                 const int64_t *d_row_limit, int64_t *d_out_idx, double *d_out_sim,
                 int32_t *d_out_cnt, hipStream_t st) {
-    static int dbg = -1, tile_env = -1;
+    static int dbg = -1, tile_env = -1, ilv_env = -1;
     if (dbg < 0) {
         const char *v = getenv("CSLAM_MFMA_DBG");       // timing-only ablations, see the kernel
         dbg = v ? atoi(v) : 0;
         if (dbg < 0 || dbg > 2) dbg = 0;
         const char *t = getenv("CSLAM_MFMA_TILE");      // 128 | 256 (default chosen below)
         tile_env = t ? atoi(t) : 0;
+        const char *iv = getenv("CSLAM_MFMA_ILV");     // 0: all LDS-DMA at the top of the K step (A/B switch)
+        if (iv) ilv_env = atoi(iv) != 0;
     }
     const int ld = b->ld, kd = b->kd;
     // tile shape: 256x256 halves the operand traffic per flop; it needs enough work to fill the
@@ -572,7 +595,11 @@ int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_
     a.nqt = nqt; a.nseg = nseg; a.tps = tps; a.n_btiles = n_btiles;
     a.part_key = part_key; a.part_idx = part_idx; a.part_bound = part_bound; a.item_map = item_map;
     if (b->ev_valid) HIP_TRY(hipEventRecord(b->ev0, st));
-    rc = tile == 256 ? launch_stage1<256, 4, 8>(a, dbg, st) : launch_stage1<128, 2, 16>(a, dbg, st);
+    // interleaved LDS-DMA issue: +3.4 points of peak on the 256 tile (one workgroup per CU: both waves of
+    // a SIMD used to issue their 8 loads together right after the barrier); -0.5 on the 128 tile, whose
+    // two independent workgroups per CU already overlap each other's issue slots
+    const int ilv = ilv_env >= 0 ? ilv_env : (tile == 256 ? 1 : 0);
+    rc = tile == 256 ? launch_stage1<256, 4, 8>(a, dbg, ilv, st) : launch_stage1<128, 2, 16>(a, dbg, ilv, st);
     if (rc) return rc;
     if (b->ev_valid) HIP_TRY(hipEventRecord(b->ev1, st));
 
