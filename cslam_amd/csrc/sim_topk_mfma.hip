@@ -52,7 +52,7 @@ struct MfmaArgs {
 // Waves: 2 along the bank axis x (T_/64) along the query axis.
 // DBG != 0 are TIMING-ONLY ablations (wrong results): 1 = no global loads after the first K step,
 // 2 = no per-step wait/barrier.  Selected with CSLAM_MFMA_DBG; never used by the product path.
-template <int T_, int MT, int KPL, int DBG, bool ILV>
+template <int T_, int MT, int KPL, int DBG, int ILV>
 __global__ __launch_bounds__(T_ * 2, 2) void sim_topk_mfma_kernel(MfmaArgs p) {
     constexpr int NTHR = T_ * 2;                 // 256 or 512 threads
     constexpr int NWN = T_ / 64;                 // waves along the query axis
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(T_ * 2, 2) void sim_topk_mfma_kernel(MfmaArgs p) {
             int nkt_ = kt + 1, ntile = tile;
             if (nkt_ == p.nkt) { nkt_ = 0; ntile = tile + 1; }
             const bool pf = (DBG != 1) && (it + 1 < total);
-            if (!ILV && pf) stage_load(cur ^ 1, ntile, nkt_);
+            if (ILV == 0 && pf) stage_load(cur ^ 1, ntile, nkt_);
             // interleaved form: branch-free (a branch would split the scheduling region); the very last
             // step re-fetches its own tile into the idle stage, which nobody reads
             const int ltile = (it + 1 < total) ? ntile : tile, lkt = (it + 1 < total) ? nkt_ : kt;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(T_ * 2, 2) void sim_topk_mfma_kernel(MfmaArgs p) {
 #pragma unroll
                         for (int n = 0; n < 2; ++n)
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m][t], b[n][t], acc[m][n], 0, 0, 0);
-                if (ILV) {
+                if (ILV == 1) {
                     // one quarter of the next stage's LDS-DMA per K group, issued BETWEEN this group's MFMAs:
                     // a global_load_lds costs ~60-180 issue cycles; eight of them back to back at the top of
                     // the step (both waves of a SIMD do that right after the barrier) leave the matrix pipe
@@ -190,6 +190,22 @@ __global__ __launch_bounds__(T_ * 2, 2) void sim_topk_mfma_kernel(MfmaArgs p) {
                     __builtin_amdgcn_sched_group_barrier(0x008, G / 4, 0);
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, G / 2, 0);
+                } else if (ILV == 2) {
+                    // same, but everything is issued during the first two K groups so that the last loads
+                    // have two groups of MFMAs (not a quarter of one) to land before the end-of-step wait
+                    constexpr int G = MT * 2 * 4;
+                    if (j < 2) {
+                        if (DBG != 1) { stage_load_part(cur ^ 1, ltile, lkt, 2 * j); stage_load_part(cur ^ 1, ltile, lkt, 2 * j + 1); }
+                        __builtin_amdgcn_sched_group_barrier(0x008, G / 8, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, G / 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, G / 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, G / 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, G / 8, 0);
+                    }
                 }
             }
 
@@ -463,21 +479,24 @@ static int launch_stage1(const MfmaArgs &a, int dbg, int ilv, hipStream_t st) {
     constexpr int lds = 2 * 2 * T_ * TK * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 0, false>,
+        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 0, 0>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 0, true>,
+        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 0, 1>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 1, false>,
+        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 0, 2>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 2, false>,
+        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 1, 0>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 2, 0>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         attr_set = true;
     }
     const dim3 grid(a.nqt * a.nseg), blk(T_ * 2);
-    if (dbg == 1) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 1, false>), grid, blk, lds, st, a);
-    else if (dbg == 2) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 2, false>), grid, blk, lds, st, a);
-    else if (ilv) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 0, true>), grid, blk, lds, st, a);
-    else hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 0, false>), grid, blk, lds, st, a);
+    if (dbg == 1) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 1, 0>), grid, blk, lds, st, a);
+    else if (dbg == 2) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 2, 0>), grid, blk, lds, st, a);
+    else if (ilv == 2) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 0, 2>), grid, blk, lds, st, a);
+    else if (ilv) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 0, 1>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 0, 0>), grid, blk, lds, st, a);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }
@@ -493,7 +512,7 @@ int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_
         const char *t = getenv("CSLAM_MFMA_TILE");      // 128 | 256 (default chosen below)
         tile_env = t ? atoi(t) : 0;
         const char *iv = getenv("CSLAM_MFMA_ILV");     // 0: all LDS-DMA at the top of the K step (A/B switch)
-        if (iv) ilv_env = atoi(iv) != 0;
+        if (iv) ilv_env = atoi(iv);
     }
     const int ld = b->ld, kd = b->kd;
     // tile shape: 256x256 halves the operand traffic per flop; it needs enough work to fill the

@@ -161,6 +161,9 @@ class ChainReducedSolverGPU(object):
         return out
 
 
+_START_CACHE = {}
+
+
 def fiedler_tracemin_chain_gpu(L, tol=1e-8, seed=None, device="cuda", stats=None):
     """TraceMIN-Fiedler (same start block, projection and stopping rule as the reference's
     networkx call, see fiedler.py) with every O(n) step on the GPU.  Returns (lambda_2, v numpy)."""
@@ -173,7 +176,12 @@ def fiedler_tracemin_chain_gpu(L, tol=1e-8, seed=None, device="cuda", stats=None
     assert n > 4, "use the host solver for tiny graphs"
     dev = torch.device(device)
     lib = _lib.load()
-    X = torch.from_numpy(np.ascontiguousarray(np.asarray(seed.normal(size=(4, n))).T)).to(dev)
+    # the reference re-seeds RandomState(7) for every call (mac.py:56-58): the start block only depends on n
+    key = (n, str(dev), seed.get_state()[1].tobytes())
+    if _START_CACHE.get('key') != key:
+        _START_CACHE['key'] = key
+        _START_CACHE['X0'] = torch.from_numpy(np.ascontiguousarray(np.asarray(seed.normal(size=(4, n))).T)).to(dev)
+    X = _START_CACHE['X0'].clone()
     ground = int((L.indptr[1:] - L.indptr[:-1]).argmax())
     solver = ChainReducedSolverGPU(L, ground, device)
     indptr = torch.from_numpy(L.indptr.astype(np.int64)).to(dev)
