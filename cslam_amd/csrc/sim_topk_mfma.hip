@@ -515,9 +515,10 @@ int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_
         if (iv) ilv_env = atoi(iv);
     }
     const int ld = b->ld, kd = b->kd;
-    // tile shape: 256x256 halves the operand traffic per flop; it needs enough work to fill the
-    // chip with one workgroup per CU, so small batches stay on 128x128
-    int tile = (nq >= 8192 && b->n >= 8192) ? 256 : 128;
+    // tile shape: 256x256 halves the operand traffic per flop and is faster from nq = 512 upwards
+    // (measured at 100k rows: 76.6 vs 73.9 % of peak at nq = 1024, 87.1 vs 80.5 % at 4096); below that
+    // the 128x128 tile wastes less query padding
+    int tile = (nq > 256 && b->n >= 1024) ? 256 : 128;
     if (tile_env == 128 || tile_env == 256) tile = tile_env;
     const int nqt = (int)ceil_div64(nq, tile);
     const int nq_pad = nqt * tile;

@@ -5,6 +5,8 @@ with (a) the reference-generated golden vectors and (b) the CPU oracle on identi
 Bar: top-k indices bit-identical; scores within 1e-5 of the reference (north_star gate) and
 within 1e-12 of the float64 oracle.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -194,7 +196,7 @@ def test_full_size_bank_properties(nnm):
 
 @pytest.mark.parametrize("n,d,nq,k,f64", [(9000, 64, 8300, 5, False), (8200, 96, 8192, 8, True)])
 def test_large_tile_path_vs_oracle(nnm, n, d, nq, k, f64):
-    """nq >= 8192 and n >= 8192 select the 256x256 MFMA tile (8 waves, per-lane lists of 8 with
+    """Large batches on the 256x256 MFMA tile (8 waves, per-lane lists of 8 with
     explicit drop bounds): ragged tile edges, causal limits, float64 queries."""
     bank = unit_rows(np.random.default_rng(n), n, d)
     q = unit_rows(np.random.default_rng(n + 1), nq, d)
@@ -202,7 +204,9 @@ def test_large_tile_path_vs_oracle(nnm, n, d, nq, k, f64):
         q = q.astype(np.float64) * 3.0
     nn = make_bank(nnm, bank)
     idx, sims, cnt = nn.search_batch(q, k, mode=nnm.MODE_MFMA)
-    assert nn.last_stats()[1] == nnm.MODE_MFMA and nn.last_stats()[3] == -(-nq // 256)
+    assert nn.last_stats()[1] == nnm.MODE_MFMA
+    if not os.environ.get("CSLAM_MFMA_TILE"):
+        assert nn.last_stats()[3] == -(-nq // 256)          # 256-row query tiles
     oi, os_, oc = pyoracle.nns_search(bank, q, k)
     assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
     lim = np.minimum(np.arange(nq, dtype=np.int64) * 2, n)
