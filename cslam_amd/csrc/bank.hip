@@ -505,7 +505,7 @@ CSLAM_API int cslam_bank_search_dev(cslam_bank_t *b, const void *d_queries, int 
     // the MFMA path keeps 16 merged candidates per (query, segment): k <= 16 (the reference's default
     // nb_best_matches is 10); larger k, tiny banks and single queries use the exact scan
     if (use == CSLAM_MODE_AUTO) use = (nq <= 8 || k > 16 || b->n < 256) ? CSLAM_MODE_SCAN : CSLAM_MODE_MFMA;
-    if (use == CSLAM_MODE_MFMA && k > 16) use = CSLAM_MODE_SCAN;
+    if (use == CSLAM_MODE_MFMA && (k > 16 || b->n < 1)) use = CSLAM_MODE_SCAN;   // empty bank: the scan writes cnt = 0
     b->stats[1] = use;
     if (use == CSLAM_MODE_SCAN)
         return scan_search(b, d_queries, q_dtype, ldq, nullptr, nq, k, d_row_limit, d_out_idx, d_out_sim,

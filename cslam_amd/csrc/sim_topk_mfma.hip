@@ -522,6 +522,7 @@ int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_
     if (tile_env == 128 || tile_env == 256) tile = tile_env;
     const int nqt = (int)ceil_div64(nq, tile);
     const int nq_pad = nqt * tile;
+    ARG_CHECK(nqt < 32768, "too many queries for one call (item map packs the query tile in 15 bits): split the batch");
     const int n_btiles = (int)ceil_div64(b->n, tile);
     // Segment count: all work items take the same time and the chip holds S workgroups, so the
     // grid runs in ceil(T/S) rounds; pick the split whose last round is fullest, discounting the

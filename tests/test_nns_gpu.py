@@ -243,3 +243,15 @@ def test_mfma_path_serves_default_nb_best_matches(nnm, n, d, nq, k):
     assert nn.last_stats()[1] == nnm.MODE_SCAN
     oi, os_, oc = pyoracle.nns_search(bank, q[:40], 17)
     assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
+
+
+def test_empty_bank_with_known_dim(nnm):
+    """A bank constructed with dim but no rows: every mode reports zero matches (the reference returns
+    empty arrays from search, nns_matching.py:55-61 with n = 0)."""
+    nn = nnm.NearestNeighborsMatching(dim=64)
+    q = unit_rows(np.random.default_rng(0), 20, 64)
+    for mode in (nnm.MODE_AUTO, nnm.MODE_SCAN, nnm.MODE_MFMA):
+        idx, sims, cnt = nn.search_batch(q, 3, mode=mode)
+        assert np.all(cnt == 0) and np.all(idx == -1) and np.all(np.isnan(sims))
+    items, sims = nn.search(q[0], 5)
+    assert items == [] and len(sims) == 0
