@@ -1,0 +1,33 @@
+"""BASELINE config 2 on one GPU: CosPlace ResNet-18 512-D extract of 10k synthetic 640x480 keyframes +
+causal intra-robot NNS (top-5 of every keyframe among the EARLIER keyframes) over the growing bank.
+python tools/perf_c2.py [frames] [chunk]"""
+import sys, time
+import torch
+sys.path.insert(0, ".")
+from cslam_amd import nns_matching as nnm
+from cslam_amd.vpr.cosplace import CosPlace
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000
+CH = int(sys.argv[2]) if len(sys.argv) > 2 else 250
+torch.backends.cudnn.benchmark = True
+cp = CosPlace({"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376,
+               "frontend.cosplace.descriptor_dim": 512, "frontend.cosplace.backbone": "resnet18"}, None)
+g = torch.Generator(device="cuda").manual_seed(7)
+frames = torch.randint(0, 256, (CH, 480, 640, 3), generator=g, device="cuda", dtype=torch.uint8)
+cp.compute_embeddings_device(frames); torch.cuda.synchronize()          # warm-up (MIOpen find)
+nn = nnm.NearestNeighborsMatching()
+t0 = time.perf_counter(); te = 0.0; tm = 0.0
+done = 0
+while done < N:
+    m = min(CH, N - done)
+    a = time.perf_counter()
+    d = cp.compute_embeddings_device(frames[:m]); torch.cuda.synchronize()
+    b = time.perf_counter()
+    nn.add_items_device(d)                                               # descriptors never leave HBM
+    lim = torch.arange(done, done + m, device="cuda", dtype=torch.int64) # keyframe i sees rows < i
+    rows, sims, cnt = nn.search_device(d, 5, row_limit=lim, mode=nnm.MODE_AUTO); torch.cuda.synchronize()
+    c = time.perf_counter()
+    te += b - a; tm += c - b; done += m
+dt = time.perf_counter() - t0
+print(f"C2: {N} keyframes, chunk {CH}: extract+match {N/dt:.0f} keyframes/s (extract {N/te:.0f}/s, causal match {N/tm:.0f}/s), "
+      f"bank rows {nn.n}, last chunk cnt min {int(cnt.min())}")
