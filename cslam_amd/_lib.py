@@ -53,6 +53,15 @@ _SIGNATURES = {
     "cslam_block4_residual_dev": (_i, [_vp, _vp, _i64, _vp, C.c_double, _vp, _vp, _vp]),
     "cslam_chain_forward_dev": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cslam_chain_backward_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
+    "cslam_scbank_create": (_i, [_i, _i, _i, _i64, _vp]),
+    "cslam_scbank_destroy": (_i, [_vp]),
+    "cslam_scbank_size": (_i, [_vp, _vp, _vp, _vp]),
+    "cslam_scbank_clear": (_i, [_vp]),
+    "cslam_scbank_add_host": (_i, [_vp, _vp, _i64]),
+    "cslam_scbank_add_dev": (_i, [_vp, _vp, _i64, _vp]),
+    "cslam_scbank_read_host": (_i, [_vp, _i64, _i64, _vp, _vp]),
+    "cslam_scbank_search_host": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cslam_scbank_search_dev": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -3,7 +3,7 @@
 Drop-in for cslam/loop_closure_sparse_matching.py: same constructor (ROS parameter dict),
 same five methods, same public attributes (`local_nnsm`, `other_robots_nnsm`,
 `candidate_selector`).  Descriptor banks are HBM-resident `NearestNeighborsMatching`
-objects; the candidate bookkeeping is `AlgebraicConnectivityMaximization`.
+objects (`ScanContextMatching` for `frontend.sensor_type: lidar`); the candidate bookkeeping is `AlgebraicConnectivityMaximization`.
 
 Batched extensions (`process_local_keyframes`, `process_remote_descriptors`) give the same
 matches as calling the per-keyframe reference methods in order, with one GPU launch per
@@ -16,15 +16,10 @@ from cslam_amd.nns_matching import NearestNeighborsMatching
 from cslam_amd.algebraic_connectivity_maximization import AlgebraicConnectivityMaximization, EdgeInterRobot
 
 
-def _scan_context_matching():
-    # Lidar place recognition (cslam/lidar_pr/) is outside the accelerated path; use the
-    # reference's own class when the cslam package is installed next to this one.
-    try:
-        from cslam.lidar_pr.scancontext_matching import ScanContextMatching
-    except ImportError as e:  # pragma: no cover
-        raise ImportError("frontend.sensor_type == 'lidar' needs cslam.lidar_pr "
-                          "(ScanContext is not part of cslam_amd)") from e
-    return ScanContextMatching()
+def _scan_context_matching(device):
+    # lidar twin of the descriptor bank (reference lcsm.py:3,21-22,28-29)
+    from cslam_amd.lidar_pr.scancontext_matching import ScanContextMatching
+    return ScanContextMatching(device=device)
 
 
 class LoopClosureSparseMatching(object):
@@ -42,7 +37,8 @@ class LoopClosureSparseMatching(object):
         """
         self.params = params
         lidar = self.params["frontend.sensor_type"] == "lidar"
-        new_bank = _scan_context_matching if lidar else (lambda: NearestNeighborsMatching(device=device))
+        new_bank = (lambda: _scan_context_matching(device)) if lidar else \
+            (lambda: NearestNeighborsMatching(device=device))
         self.local_nnsm = new_bank()
         self.other_robots_nnsm = {}
         for i in range(self.params['max_nb_robots']):

@@ -173,6 +173,41 @@ int cslam_chain_backward_dev(const double *d_xJ, const double *d_Bn, const doubl
                              const double *d_Rn, const int *d_jid, const int *d_seg_of, const int64_t *d_sa,
                              const int64_t *d_sb, const double *d_Rl, int64_t n, double *d_x, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Lidar place recognition: ScanContext bank.
+ * Replaces cslam/lidar_pr/scancontext_matching.py:5-104 (ScanContextMatching) with its helpers
+ * scancontext_utils.py:78-79 (sc2rk) and :81-113 (distance_sc).  Scan contexts are float64
+ * [rings, sectors] row-major (the reference's np.zeros default dtype), ring keys are the row means
+ * in numpy's summation order, all arithmetic float64.
+ *   add_*    : scancontext_matching.py:23-42 (copies; ring keys and column norms computed on device)
+ *   read_host: the reference's public `scancontexts` / `ringkeys` arrays
+ *   search_* : scancontext_matching.py:44-87 for a batch of queries.  Stage 1 = num_candidates
+ *              nearest ring keys (brute force instead of the per-query KD-tree, same set, ascending
+ *              distance, ties -> smaller row); stage 2 = distance_sc(candidate, query) for each;
+ *              best = first strict minimum below 1.0.  best_idx[j] = -1 when no candidate is below 1.0
+ *              (the reference then answers items[0] with similarity 0.0 -- the Python class does that),
+ *              best_sim[j] = 1 - best distance, best_yaw[j] = yaw_diff in sectors (1..sectors).
+ *              row_limit[j] (optional) hides bank rows >= row_limit[j] from query j.
+ *              cand / cdist / cyaw [nq, num_candidates] are optional (NULL) diagnostics: candidate
+ *              rows (-1 = bank smaller than num_candidates), their distances and yaw shifts.
+ */
+typedef struct cslam_scbank cslam_scbank_t;
+int cslam_scbank_create(int device, int rings, int sectors, int64_t capacity_hint, cslam_scbank_t **out);
+int cslam_scbank_destroy(cslam_scbank_t *bank);
+int cslam_scbank_size(const cslam_scbank_t *bank, int64_t *n, int *rings, int *sectors);
+int cslam_scbank_clear(cslam_scbank_t *bank);
+int cslam_scbank_add_host(cslam_scbank_t *bank, const double *sc, int64_t n);
+int cslam_scbank_add_dev(cslam_scbank_t *bank, const double *d_sc, int64_t n, void *stream);
+int cslam_scbank_read_host(const cslam_scbank_t *bank, int64_t first, int64_t count, double *sc_out,
+                           double *ringkeys_out);
+int cslam_scbank_search_host(cslam_scbank_t *bank, const double *queries, int64_t nq, int num_candidates,
+                             const int64_t *row_limit, int64_t *best_idx, double *best_sim,
+                             int32_t *best_yaw, int64_t *cand, double *cdist, int32_t *cyaw);
+int cslam_scbank_search_dev(cslam_scbank_t *bank, const double *d_queries, int64_t nq, int num_candidates,
+                            const int64_t *d_row_limit, int64_t *d_best_idx, double *d_best_sim,
+                            int32_t *d_best_yaw, int64_t *d_cand, double *d_cdist, int32_t *d_cyaw,
+                            void *stream);
+
 #ifdef __cplusplus
 }
 #endif

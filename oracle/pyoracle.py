@@ -52,3 +52,50 @@ def nns_search(bank, queries, k, row_limit=None):
                                cnt.ctypes.data_as(C.c_void_p))
     assert rc == 0
     return idx, sims, cnt
+
+
+# ---- lidar ScanContext (sc_oracle.c) -----------------------------------------------------
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def sc_ringkey(sc):
+    """Oracle for sc2rk (cslam/lidar_pr/scancontext_utils.py:78-79). sc [R,S] float64."""
+    lib = load()
+    sc = np.ascontiguousarray(sc, dtype=np.float64)
+    rk = np.empty(sc.shape[0], dtype=np.float64)
+    assert lib.oracle_sc_ringkey(_p(sc), sc.shape[0], sc.shape[1], _p(rk)) == 0
+    return rk
+
+
+def sc_distance(sc1, sc2):
+    """Oracle for distance_sc (scancontext_utils.py:81-113) -> (dist, yaw_diff)."""
+    lib = load()
+    sc1 = np.ascontiguousarray(sc1, dtype=np.float64)
+    sc2 = np.ascontiguousarray(sc2, dtype=np.float64)
+    d = C.c_double()
+    y = C.c_int()
+    assert lib.oracle_sc_distance(_p(sc1), _p(sc2), sc1.shape[0], sc1.shape[1], C.byref(d), C.byref(y)) == 0
+    return d.value, y.value
+
+
+def sc_search(bank, queries, num_candidates=10, row_limit=None):
+    """Oracle for ScanContextMatching.search over a batch (scancontext_matching.py:44-87).
+    bank [n,R,S], queries [nq,R,S] float64.  Returns dict(best_idx [nq] (-1 = the reference's
+    'no candidate under distance 1' branch), best_sim, best_yaw, cand [nq,C], cdist, cyaw)."""
+    lib = load()
+    bank = np.ascontiguousarray(bank, dtype=np.float64)
+    q = np.ascontiguousarray(queries, dtype=np.float64)
+    R, S = q.shape[1], q.shape[2]
+    n, nq = bank.shape[0], q.shape[0]
+    lim = np.ascontiguousarray(row_limit, dtype=np.int64) if row_limit is not None else None
+    out = dict(best_idx=np.empty(nq, np.int64), best_sim=np.empty(nq, np.float64),
+               best_yaw=np.empty(nq, np.int32), cand=np.empty((nq, num_candidates), np.int64),
+               cdist=np.empty((nq, num_candidates), np.float64), cyaw=np.empty((nq, num_candidates), np.int32))
+    lib.oracle_sc_search.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_int,
+                                     C.c_void_p] + [C.c_void_p] * 6
+    rc = lib.oracle_sc_search(_p(bank), n, R, S, _p(q), nq, num_candidates, _p(lim), _p(out["best_idx"]),
+                              _p(out["best_sim"]), _p(out["best_yaw"]), _p(out["cand"]), _p(out["cdist"]),
+                              _p(out["cyaw"]))
+    assert rc == 0
+    return out

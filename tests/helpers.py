@@ -56,3 +56,27 @@ def assert_topk_equal(idx, sims, cnt, ridx, rsims, rcnt, score_tol):
         a, b = sims[m], rsims[m]
         both_nan = np.isnan(a) & np.isnan(b)
         assert np.all(both_nan | (np.abs(a - b) <= score_tol)), float(np.nanmax(np.abs(a - b)))
+
+
+# ---- lidar ScanContext synthetic recipe (heights quantised to 1/256 so fixtures store u16) ----
+def synth_scancontexts(rng, n, rings=20, sectors=60):
+    """n random scan contexts [n, rings, sectors] float64: heights in [0, 6), ~30 % empty bins,
+    ~10 % empty sectors (columns), quantised to multiples of 1/256."""
+    h = rng.random((n, rings, sectors)) * 6.0
+    h[rng.random((n, rings, sectors)) < 0.3] = 0.0
+    h *= (rng.random((n, 1, sectors)) >= 0.1)
+    return np.floor(h * 256.0) / 256.0
+
+
+def synth_sc_revisits(rng, bank, m, noise=0.15):
+    """m revisit queries: a bank place rotated by a random sector shift, jittered on its non-empty
+    bins.  Returns (queries [m, rings, sectors], place [m], shift [m])."""
+    n, _, sectors = bank.shape
+    place = rng.integers(0, n, size=m)
+    shift = rng.integers(0, sectors, size=m)
+    q = np.empty((m,) + bank.shape[1:])
+    for j in range(m):
+        s = np.roll(bank[place[j]], int(shift[j]), axis=1)
+        s = np.where(s > 0, np.maximum(s + noise * rng.standard_normal(s.shape), 0.0), 0.0)
+        q[j] = np.floor(s * 256.0) / 256.0
+    return q, place, shift

@@ -1,0 +1,66 @@
+"""CPU: the ScanContext oracle (oracle/sc_oracle.c) against the golden vectors recorded from the
+reference (oracle/gen_golden_sc.py -> tests/golden/sc_g9.npz)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, synth_scancontexts, synth_sc_revisits
+from oracle import pyoracle
+
+
+@pytest.fixture(scope="module")
+def g9():
+    return np.load(os.path.join(GOLDEN, "sc_g9.npz"))
+
+
+def case(g, name):
+    bank = g[name + "/bank_u16"].astype(np.float64) / 256.0
+    q = g[name + "/q_u16"].astype(np.float64) / 256.0
+    return bank, q, int(g[name + "/ncand"])
+
+
+def test_golden_has_all_cases(g9):
+    assert list(g9["names"]) == ["n3", "n12", "n150", "n150c4"]
+
+
+@pytest.mark.parametrize("name", ["n3", "n12", "n150", "n150c4"])
+def test_oracle_matches_reference(g9, name):
+    bank, q, ncand = case(g9, name)
+    n = len(bank)
+    rk = np.stack([pyoracle.sc_ringkey(b) for b in bank])
+    assert np.array_equal(rk, g9[name + "/ringkeys"])                 # numpy's summation order
+    o = pyoracle.sc_search(bank, q, ncand)
+    ref_c = g9[name + "/cands"].copy()
+    ref_c[ref_c >= n] = -1                                            # KD-tree "missing neighbour" marker
+    assert np.array_equal(o["cand"], ref_c)
+    m = ref_c >= 0
+    assert np.abs(o["cdist"] - g9[name + "/dists"])[m].max() <= 1e-12
+    assert np.array_equal(o["cyaw"][m], g9[name + "/yaws"][m])
+    items = np.where(o["best_idx"] >= 0, 1000 + 7 * o["best_idx"], 1000)
+    assert np.array_equal(items, g9[name + "/items"])
+    assert np.abs(o["best_sim"] - g9[name + "/sims"]).max() <= 1e-12
+
+
+def test_oracle_distance_function_properties():
+    rng = np.random.default_rng(5)
+    bank = synth_scancontexts(rng, 4)
+    for s in (1, 17, 59):
+        d, yaw = pyoracle.sc_distance(bank[0], np.roll(bank[0], s, axis=1))
+        assert abs(d) < 1e-15 and yaw == s
+    d, yaw = pyoracle.sc_distance(bank[0], bank[0])                   # zero shift is found last (roll by 60)
+    assert abs(d) < 1e-15 and yaw == 60
+    d, yaw = pyoracle.sc_distance(bank[0], np.zeros_like(bank[0]))    # nothing engaged
+    assert d == 1.0 and yaw == 1
+
+
+def test_oracle_row_limit_and_revisits():
+    rng = np.random.default_rng(6)
+    bank = synth_scancontexts(rng, 60)
+    q, place, shift = synth_sc_revisits(rng, bank, 6)
+    o = pyoracle.sc_search(bank, q, 10)
+    assert np.array_equal(o["best_idx"], place)
+    assert np.array_equal(o["best_yaw"], np.where(shift == 0, 60, shift))
+    lim = np.minimum(place, 5)                                        # hide the true place
+    o2 = pyoracle.sc_search(bank, q, 10, row_limit=lim)
+    assert np.all(o2["best_idx"] < np.maximum(lim, 1)) and np.all(o2["cand"] < lim[:, None])
