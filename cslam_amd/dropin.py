@@ -7,8 +7,10 @@ After install(), `from cslam.nns_matching import NearestNeighborsMatching`,
 `from cslam.algebraic_connectivity_maximization import ...`, `from cslam.vpr.netvlad import NetVLAD`
 and `from cslam.vpr.cosplace import CosPlace` -- the imports made by
 cslam/global_descriptor_loop_closure_detection.py:39-60 and
-cslam/loop_closure_sparse_matching.py:2-4 -- resolve to the MI355X implementations.  Every
-other cslam module (ROS glue, broker, lidar, ...) keeps coming from the installed reference.
+cslam/loop_closure_sparse_matching.py:2-4 -- resolve to the MI355X implementations, and so do
+`cslam.lidar_pr.scancontext_matching` (lcsm.py:3) and `cslam.broker` (gdlcd.py:9,329).  Every other
+cslam module (ROS glue, neighbour manager, lidar handler, ...) keeps coming from the installed
+reference.
 """
 import importlib
 import sys
@@ -21,6 +23,8 @@ _MAP = {
     "cslam.mac.utils": "cslam_amd.mac.utils",
     "cslam.vpr.netvlad": "cslam_amd.vpr.netvlad",
     "cslam.vpr.cosplace": "cslam_amd.vpr.cosplace",
+    "cslam.lidar_pr.scancontext_matching": "cslam_amd.lidar_pr.scancontext_matching",
+    "cslam.broker": "cslam_amd.broker",
 }
 
 

@@ -174,3 +174,16 @@ class LoopClosureSparseMatching(object):
                 self.candidate_selector.add_match(match)
                 out.append(match)
         return out
+
+    def process_remote_chunk(self, chunk, last_keyframe_received=-1):
+        """One received GlobalDescriptors message in packed form (cslam_amd.wire.DescriptorChunk):
+        the body of gdlcd.py:407-422 -- keep the rows newer than the last keyframe received from
+        that robot (neighbors_manager.py:147-169), add them, match them.  Returns (matches, updated
+        last-received keyframe id)."""
+        from cslam_amd.wire import unknown_rows
+        rows, last = unknown_rows(chunk, last_keyframe_received)
+        if len(rows) == 0:
+            return [], last
+        matches = self.process_remote_descriptors(chunk.robot_id, chunk.as_float64()[rows],
+                                                  np.asarray(chunk.keyframe_ids)[rows])
+        return matches, last

@@ -148,3 +148,39 @@ def test_reference_unit_tests_reexpressed():
                 lcsm.add_other_robot_global_descriptor(GlobalDescriptor(i, r, v.tolist()))
         sel = lcsm.select_candidates(budget, {r: True for r in range(R)})
         assert len(sel) == budget
+
+
+def test_packed_wire_path_equals_per_message_callbacks():
+    """Robot 1 publishes through PackedDescriptorBuffer -> bytes -> DescriptorChunk; robot 0 ingests the
+    chunks with process_remote_chunk.  Same matches as feeding robot 0 one GlobalDescriptor message per
+    keyframe (gdlcd.py:407-422), including the re-sent rows that get_unknown_range drops."""
+    from cslam_amd.loop_closure_sparse_matching import LoopClosureSparseMatching
+    from cslam_amd.wire import DescriptorChunk, PackedDescriptorBuffer
+    g = np.load(GOLDEN + "/seq_g2.npz")
+    desc = g["thr0.1/desc"]
+    R, T, D = desc.shape
+    a = LoopClosureSparseMatching(make_params(0, R, 0.1))
+    b = LoopClosureSparseMatching(make_params(0, R, 0.1))
+    for x in (a, b):
+        x.process_local_keyframes(desc[0], list(range(T)), intra=False)
+    buf = PackedDescriptorBuffer(robot_id=1)
+    seq, bat, last = [], [], -1
+    sent = 0
+    for upto in (25, 60, T):
+        for t in range(sent, upto):
+            buf.append(t, desc[1, t])
+        sent = upto
+        for ch in buf.chunks(max(0, upto - 45), 10):          # overlaps what was sent before
+            wire = DescriptorChunk.from_bytes(ch.to_bytes())
+            assert len(wire) <= 10
+            m, new_last = b.process_remote_chunk(wire, last)
+            bat += m
+            for msg in wire.messages():                         # reference: one callback row at a time
+                if msg.keyframe_id > last:
+                    r = a.add_other_robot_global_descriptor(msg)
+                    if r is not None:
+                        seq.append(r)
+            last = new_last
+    assert last == T - 1 and a.other_robots_nnsm[1].n == T and b.other_robots_nnsm[1].n == T
+    assert [tuple(m) for m in seq] == [tuple(m) for m in bat] and len(seq) > 0
+    assert np.array_equal(a.other_robots_nnsm[1].data, b.other_robots_nnsm[1].data)
