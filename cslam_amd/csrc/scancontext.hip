@@ -479,3 +479,126 @@ CSLAM_API int cslam_scbank_search_host(cslam_scbank_t *b, const double *queries,
     }
     return CSLAM_OK;
 }
+
+// ------------------------------------------------------------ descriptor ----
+// cslam/lidar_pr/scancontext_utils.py:10-75 (xy2theta, pt2rs, ptcloud2sc): polar binning of a float64
+// point cloud, each bin keeping max(point height + 2) over the FIRST 500 points that fall in it in cloud
+// order (the reference's `enough_large` storage; later points are dropped) and 0.0 for unused slots.
+// One workgroup of 16 waves per frame; bin counters and running maxima live in LDS.  The order-dependent
+// cap is honoured without serialising the points: per 1024-point chunk every wave ranks its lanes within
+// equal-bin groups (ballot), per-wave bin totals are prefix-summed across the 16 waves per bin, and a
+// point takes part iff (points of its bin before it) < 500.
+#define SCD_WAVES 16
+#define SCD_CAP 500
+#define SCD_MAX_BINS 2048
+
+__device__ __forceinline__ double np_floordiv_pos(double a, double b) {   // numpy npy_divmod, a >= 0, b > 0
+    double mod = fmod(a, b);
+    double div = __ddiv_rn(__dsub_rn(a, mod), b);
+    if (div != 0.0) {
+        double fl = floor(div);
+        if (__dsub_rn(div, fl) > 0.5) fl += 1.0;
+        return fl;
+    }
+    return 0.0;
+}
+
+__device__ __forceinline__ unsigned long long f64_ordered(double v) {
+    unsigned long long u = (unsigned long long)__double_as_longlong(v);
+    return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double f64_unordered(unsigned long long u) {
+    u = (u >> 63) ? (u & 0x7fffffffffffffffull) : ~u;
+    return __longlong_as_double((long long)u);
+}
+
+__global__ __launch_bounds__(SCD_WAVES * 64) void sc_from_cloud_kernel(
+    const double *__restrict__ pts, const int64_t *__restrict__ offsets, int R, int S, double gap_ring,
+    double gap_sector, double *__restrict__ out, int *__restrict__ bad_sector) {
+    __shared__ int s_cnt[SCD_MAX_BINS];
+    __shared__ unsigned long long s_max[SCD_MAX_BINS];
+    __shared__ unsigned short s_hist[SCD_WAVES][SCD_MAX_BINS];
+    const int f = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int nb = R * S;
+    const int64_t p0 = offsets[f], p1 = offsets[f + 1];
+    for (int b = t; b < nb; b += blockDim.x) { s_cnt[b] = 0; s_max[b] = 0ull; }
+    const double k = 180.0 / 3.141592653589793;
+    for (int64_t base = p0; base < p1; base += SCD_WAVES * 64) {
+        for (int e = t; e < SCD_WAVES * nb; e += blockDim.x) s_hist[e / nb][e % nb] = 0;
+        __syncthreads();
+        const int64_t i = base + t;
+        int bin = -1;
+        double h = 0.0;
+        if (i < p1) {
+            double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+            if (!(x != x || y != y || z != z)) {
+                h = __dadd_rn(z, 2.0);
+                if (x == 0.0) x = 0.001;
+                if (y == 0.0) y = 0.001;
+                double theta;
+                if (x >= 0 && y >= 0) theta = __dmul_rn(k, atan(__ddiv_rn(y, x)));
+                else if (x < 0 && y >= 0) theta = __dsub_rn(180.0, __dmul_rn(k, atan(__ddiv_rn(y, -x))));
+                else if (x < 0 && y < 0) theta = __dadd_rn(180.0, __dmul_rn(k, atan(__ddiv_rn(y, x))));
+                else theta = __dsub_rn(360.0, __dmul_rn(k, atan(__ddiv_rn(-y, x))));
+                const double far = sqrt(__dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y)));
+                double ring = np_floordiv_pos(far, gap_ring);
+                const double sector = np_floordiv_pos(theta, gap_sector);
+                if (ring >= (double)R) ring = (double)(R - 1);
+                const int is = (int)sector;
+                if (is < 0 || is >= S) atomicOr(bad_sector, 1);      // the reference raises IndexError
+                else bin = (int)ring * S + is;
+            }
+        }
+        // rank among the equal-bin lanes of this wave, and the wave's total per bin
+        int rank = 0;
+        unsigned long long remaining = __ballot(bin >= 0);
+        while (remaining) {
+            const int leader = __ffsll((long long)remaining) - 1;
+            const int b = __shfl(bin, leader, 64);
+            const unsigned long long m = __ballot(bin == b);
+            if (bin == b) {
+                rank = __popcll(m & ((1ull << lane) - 1ull));
+                if (lane == leader) s_hist[w][b] = (unsigned short)__popcll(m);
+            }
+            remaining &= ~m;
+        }
+        __syncthreads();
+        for (int b = t; b < nb; b += blockDim.x) {          // exclusive prefix over the waves, per bin
+            int running = s_cnt[b];
+            for (int ww = 0; ww < SCD_WAVES; ++ww) {
+                const int c = s_hist[ww][b];
+                s_hist[ww][b] = (unsigned short)(running < SCD_CAP ? running : SCD_CAP);
+                running += c;
+            }
+            s_cnt[b] = running;
+        }
+        __syncthreads();
+        if (bin >= 0 && (int)s_hist[w][bin] + rank < SCD_CAP) atomicMax(&s_max[bin], f64_ordered(h));
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int b = t; b < nb; b += blockDim.x) {
+        double v = 0.0;
+        if (s_cnt[b] > 0) {
+            v = f64_unordered(s_max[b]);
+            if (s_cnt[b] < SCD_CAP && v < 0.0) v = 0.0;     // an unused storage slot holds 0.0
+        }
+        out[(int64_t)f * nb + b] = v;
+    }
+}
+
+CSLAM_API int cslam_scancontext_from_cloud_dev(const double *d_points, const int64_t *d_offsets, int n_frames,
+                                               int rings, int sectors, double max_length, double *d_out,
+                                               int32_t *d_status, void *stream) {
+    ARG_CHECK(d_offsets && d_out && d_status, "NULL argument");   // d_points may be NULL when every frame is empty
+    ARG_CHECK(n_frames >= 0, "n_frames must be >= 0");
+    ARG_CHECK(rings >= 1 && sectors >= 1 && rings * sectors <= SCD_MAX_BINS, "rings * sectors must be in [1, 2048]");
+    ARG_CHECK(max_length > 0.0, "max_length must be > 0");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(d_status, 0, sizeof(int32_t), st));
+    if (n_frames == 0) return CSLAM_OK;
+    hipLaunchKernelGGL(sc_from_cloud_kernel, dim3((unsigned)n_frames), dim3(SCD_WAVES * 64), 0, st, d_points,
+                       d_offsets, rings, sectors, max_length / rings, 360.0 / sectors, d_out, d_status);
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}

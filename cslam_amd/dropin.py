@@ -8,7 +8,7 @@ After install(), `from cslam.nns_matching import NearestNeighborsMatching`,
 and `from cslam.vpr.cosplace import CosPlace` -- the imports made by
 cslam/global_descriptor_loop_closure_detection.py:39-60 and
 cslam/loop_closure_sparse_matching.py:2-4 -- resolve to the MI355X implementations, and so do
-`cslam.lidar_pr.scancontext_matching` (lcsm.py:3) and `cslam.broker` (gdlcd.py:9,329).  Every other
+`cslam.lidar_pr.scancontext_matching` (lcsm.py:3), `cslam.lidar_pr.scancontext` (gdlcd.py:50) and `cslam.broker` (gdlcd.py:9,329).  Every other
 cslam module (ROS glue, neighbour manager, lidar handler, ...) keeps coming from the installed
 reference.
 """
@@ -24,6 +24,7 @@ _MAP = {
     "cslam.vpr.netvlad": "cslam_amd.vpr.netvlad",
     "cslam.vpr.cosplace": "cslam_amd.vpr.cosplace",
     "cslam.lidar_pr.scancontext_matching": "cslam_amd.lidar_pr.scancontext_matching",
+    "cslam.lidar_pr.scancontext": "cslam_amd.lidar_pr.scancontext",
     "cslam.broker": "cslam_amd.broker",
 }
 

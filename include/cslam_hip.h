@@ -208,6 +208,17 @@ int cslam_scbank_search_dev(cslam_scbank_t *bank, const double *d_queries, int64
                             int32_t *d_best_yaw, int64_t *d_cand, double *d_cdist, int32_t *d_cyaw,
                             void *stream);
 
+/* Scan-context descriptor of float64 point clouds (cslam/lidar_pr/scancontext_utils.py:10-75 ptcloud2sc,
+ * called by lidar_pr/scancontext.py:14-16 with rings x sectors = 20 x 60, max_length 80).
+ * d_points: all frames concatenated, [total_points, 3]; frame f owns rows d_offsets[f] .. d_offsets[f+1]-1.
+ * d_out [n_frames, rings*sectors] float64.  NaN points are skipped; a bin keeps the maximum of z + 2 over
+ * its first 500 points in cloud order (the reference's storage cap), 0.0 when its storage has unused slots.
+ * *d_status (device int32) is set non-zero when a point has theta == 360 exactly, where the reference
+ * raises IndexError (the point is skipped here). */
+int cslam_scancontext_from_cloud_dev(const double *d_points, const int64_t *d_offsets, int n_frames,
+                                     int rings, int sectors, double max_length, double *d_out,
+                                     int32_t *d_status, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,5 +74,32 @@ def main():
     print("wrote", path, os.path.getsize(path), "bytes")
 
 
+def main_cloud():
+    """ptcloud2sc (scancontext_utils.py:46-75) on float64 point clouds -> tests/golden/sc_cloud_g11.npz."""
+    import cslam.lidar_pr.scancontext_utils as sc_utils
+    from helpers import synth_lidar_cloud
+    out = {}
+    for name, seed, n, dense in (("wall40k", 31, 40000, True), ("sparse6k", 32, 6000, False), ("tiny", 33, 40, False)):
+        pts32 = synth_lidar_cloud(np.random.default_rng(seed), n, dense)
+        pts = pts32.astype(np.float64)
+        sc = sc_utils.ptcloud2sc(pts, [20, 60], 80)
+        out[name + "/pts"] = pts32
+        out[name + "/sc"] = sc
+        cnt = np.zeros((20, 60), int)
+        for p in pts:
+            if not np.isnan(p).any():
+                r, c = sc_utils.pt2rs(p, 4.0, 6.0, 20, 60)
+                cnt[r, c] += 1
+        print(name, "points", n, "bins over the 500 cap:", int((cnt > 500).sum()), "max", cnt.max(),
+              "nonzero bins", int((sc != 0).sum()))
+    out["names"] = np.array(["wall40k", "sparse6k", "tiny"])
+    path = os.path.join(HERE, "..", "tests", "golden", "sc_cloud_g11.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
 if __name__ == "__main__":
-    main()
+    if "cloud" in sys.argv[1:]:
+        main_cloud()
+    else:
+        main()

@@ -99,3 +99,16 @@ def sc_search(bank, queries, num_candidates=10, row_limit=None):
                               _p(out["cyaw"]))
     assert rc == 0
     return out
+
+
+def ptcloud2sc(points, shape=(20, 60), max_length=80.0):
+    """Oracle for ptcloud2sc (cslam/lidar_pr/scancontext_utils.py:46-75). points [n,3] -> [R,S] float64."""
+    lib = load()
+    pts = np.ascontiguousarray(points, dtype=np.float64)
+    sc = np.empty(shape, dtype=np.float64)
+    lib.oracle_ptcloud2sc.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_double, C.c_void_p]
+    rc = lib.oracle_ptcloud2sc(_p(pts), pts.shape[0], shape[0], shape[1], float(max_length), _p(sc))
+    if rc == -2:
+        raise IndexError("sector index out of range (theta == 360), as in the reference")
+    assert rc == 0
+    return sc

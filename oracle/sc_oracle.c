@@ -133,3 +133,52 @@ API int oracle_sc_search(const double *bank, int64_t n, int R, int S, const doub
     free(rk); free(qrk); free(d2);
     return 0;
 }
+
+/* ---- descriptor: oracle_ptcloud2sc <- cslam/lidar_pr/scancontext_utils.py:10-75 (xy2theta, pt2rs,
+ * ptcloud2sc) for float64 clouds [n,3].  Every bin keeps the maximum of point[2] + 2.0 over the first
+ * 500 points that fall in it (in cloud order; the reference's `enough_large` storage) and 0.0 for the
+ * unused storage slots.  np.divmod is restated from numpy's npy_divmod. */
+static double np_floordiv(double a, double b) {
+    double mod = fmod(a, b);
+    double div = (a - mod) / b;
+    if (mod != 0.0 && ((b < 0) != (mod < 0))) div -= 1.0;
+    if (div != 0.0) {
+        double fl = floor(div);
+        if (div - fl > 0.5) fl += 1.0;
+        return fl;
+    }
+    return copysign(0.0, a / b);
+}
+
+API int oracle_ptcloud2sc(const double *pts, int64_t n, int R, int S, double max_length, double *sc) {
+    const int cap = 500;
+    const double gap_ring = max_length / R, gap_sector = 360.0 / S;
+    const double k = 180.0 / 3.141592653589793;
+    int *cnt = calloc((size_t)R * S, sizeof(int));
+    for (int i = 0; i < R * S; i++) sc[i] = 0.0;
+    for (int64_t i = 0; i < n; i++) {
+        double x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+        if (isnan(x) || isnan(y) || isnan(z)) continue;
+        double h = z + 2.0;
+        if (x == 0.0) x = 0.001;
+        if (y == 0.0) y = 0.001;
+        double theta;
+        if (x >= 0 && y >= 0) theta = k * atan(y / x);
+        else if (x < 0 && y >= 0) theta = 180.0 - (k * atan(y / (-x)));
+        else if (x < 0 && y < 0) theta = 180.0 + (k * atan(y / x));
+        else theta = 360.0 - (k * atan((-y) / x));
+        double far = sqrt(x * x + y * y);
+        double ring = np_floordiv(far, gap_ring), sector = np_floordiv(theta, gap_sector);
+        if (ring >= R) ring = R - 1;
+        int ir = (int)ring, is = (int)sector;
+        if (is < 0 || is >= S) { free(cnt); return -2; }     /* the reference raises IndexError */
+        int b = ir * S + is;
+        if (cnt[b] >= cap) continue;
+        if (cnt[b] == 0 || h > sc[b]) sc[b] = (cnt[b] == 0) ? h : (h > sc[b] ? h : sc[b]);
+        cnt[b]++;
+    }
+    for (int b = 0; b < R * S; b++)
+        if (cnt[b] < cap && sc[b] < 0.0) sc[b] = 0.0;       /* an unused storage slot holds 0.0 */
+    free(cnt);
+    return 0;
+}

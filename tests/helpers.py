@@ -80,3 +80,21 @@ def synth_sc_revisits(rng, bank, m, noise=0.15):
         s = np.where(s > 0, np.maximum(s + noise * rng.standard_normal(s.shape), 0.0), 0.0)
         q[j] = np.floor(s * 256.0) / 256.0
     return q, place, shift
+
+
+def synth_lidar_cloud(rng, n, dense_core=True):
+    """n lidar-like points [n, 3] float32 (exactly representable in float64): ranges skewed to the near
+    field so that some polar bins collect far more than 500 returns (the cap in the reference's
+    ptcloud2sc), heights around the -2 m ground plane, a few NaN returns and exact zeros."""
+    r = rng.gamma(2.0, 6.0 if dense_core else 15.0, size=n)
+    a = rng.random(n) * 2 * np.pi
+    if dense_core:
+        a[: n // 4] = rng.normal(0.3, 0.02, size=n // 4)       # a wall: many returns in few sectors
+        r[: n // 4] = rng.normal(5.0, 0.3, size=n // 4)
+    z = -2.0 + np.abs(rng.normal(0.0, 1.2, size=n)) * (rng.random(n) < 0.7) - 0.3 * (rng.random(n) < 0.1)
+    pts = np.stack([r * np.cos(a), r * np.sin(a), z], axis=1).astype(np.float32)
+    k = max(n // 200, 3)
+    pts[rng.integers(0, n, size=k), rng.integers(0, 3, size=k)] = np.nan
+    pts[rng.integers(0, n, size=3), 0] = 0.0
+    pts[rng.integers(0, n, size=3), 1] = 0.0
+    return pts[rng.permutation(n)]

@@ -169,8 +169,8 @@ def test_packed_wire_path_equals_per_message_callbacks():
     for upto in (25, 60, T):
         for t in range(sent, upto):
             buf.append(t, desc[1, t])
-        sent = upto
-        for ch in buf.chunks(max(0, upto - 45), 10):          # overlaps what was sent before
+        resend_from, sent = max(0, sent - 15), upto
+        for ch in buf.chunks(resend_from, 10):                 # overlaps what was sent before
             wire = DescriptorChunk.from_bytes(ch.to_bytes())
             assert len(wire) <= 10
             m, new_last = b.process_remote_chunk(wire, last)

@@ -64,3 +64,14 @@ def test_oracle_row_limit_and_revisits():
     lim = np.minimum(place, 5)                                        # hide the true place
     o2 = pyoracle.sc_search(bank, q, 10, row_limit=lim)
     assert np.all(o2["best_idx"] < np.maximum(lim, 1)) and np.all(o2["cand"] < lim[:, None])
+
+
+def test_ptcloud2sc_oracle_matches_reference():
+    g = np.load(os.path.join(GOLDEN, "sc_cloud_g11.npz"))
+    assert list(g["names"]) == ["wall40k", "sparse6k", "tiny"]
+    for name in g["names"]:
+        sc = pyoracle.ptcloud2sc(g[name + "/pts"].astype(np.float64))
+        assert np.array_equal(sc, g[name + "/sc"]), name
+    # the 500-point storage cap is order dependent: the fixture has bins far above it
+    pts = g["wall40k/pts"].astype(np.float64)
+    assert not np.array_equal(pyoracle.ptcloud2sc(pts[::-1].copy()), g["wall40k/sc"])

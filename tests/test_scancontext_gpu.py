@@ -142,3 +142,47 @@ def test_lidar_sparse_matching_batched_equals_sequential():
     assert [tuple(e) for e in bat_inter] == [tuple(e) for e in seq_inter]
     assert len(seq_inter) > 10 and sum(k is not None for _, k in seq_intra) > 5
     assert a.candidate_selector.candidate_edges.keys() == b.candidate_selector.candidate_edges.keys()
+
+
+# ---- descriptor (ptcloud2sc) --------------------------------------------------------------
+def test_ptcloud2sc_golden_reference_frames():
+    from cslam_amd.lidar_pr.scancontext import ScanContext
+    g = np.load(os.path.join(GOLDEN, "sc_cloud_g11.npz"))
+    ex = ScanContext({}, None)
+    for name in g["names"]:
+        pts = g[name + "/pts"]
+        d = ex.compute_embedding(pts)                           # float32 cloud, widened exactly
+        assert d.shape == (1200,) and d.dtype == np.float64
+        assert np.array_equal(d.reshape(20, 60), g[name + "/sc"]), name
+    batch = ex.compute_embeddings([g[n + "/pts"].astype(np.float64) for n in g["names"]])
+    for i, name in enumerate(g["names"]):
+        assert np.array_equal(batch[i].reshape(20, 60), g[name + "/sc"])
+
+
+@pytest.mark.parametrize("n,dense,seed", [(150000, True, 41), (1023, False, 42), (1025, False, 43), (0, False, 44)])
+def test_ptcloud2sc_bit_exact_vs_oracle(n, dense, seed):
+    from cslam_amd.lidar_pr.scancontext import ScanContext
+    from helpers import synth_lidar_cloud
+    from oracle import pyoracle
+    pts = synth_lidar_cloud(np.random.default_rng(seed), n, dense).astype(np.float64) if n else np.zeros((0, 3))
+    if n:
+        pts += np.random.default_rng(seed).random(pts.shape) * 1e-7      # genuine float64 coordinates
+    d = ScanContext({}, None).compute_embedding(pts).reshape(20, 60)
+    assert np.array_equal(d, pyoracle.ptcloud2sc(pts))
+
+
+def test_lidar_extract_then_match_round_trip():
+    """A place seen twice, the second time with the sensor yawed by 90 degrees: the descriptors match with
+    the yaw recovered (15 sectors of 6 degrees), through the two drop-in classes."""
+    from cslam_amd.lidar_pr.scancontext import ScanContext
+    from helpers import synth_lidar_cloud
+    ex = ScanContext({}, None)
+    m = new_matcher()
+    clouds = [synth_lidar_cloud(np.random.default_rng(50 + i), 20000, False).astype(np.float64) for i in range(12)]
+    for i, d in enumerate(ex.compute_embeddings(clouds)):
+        m.add_item(d, i)
+    c = clouds[7][~np.isnan(clouds[7]).any(axis=1)]
+    rot = np.stack([-c[:, 1], c[:, 0], c[:, 2]], axis=1)               # +90 degrees about z
+    items, sims = m.search(ex.compute_embedding(rot), 1)
+    assert items == [7] and sims[0] > 0.9
+    assert m.last_yaw_diff_deg in (45 * 6.0, 15 * 6.0)
