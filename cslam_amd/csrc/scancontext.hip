@@ -294,6 +294,76 @@ __global__ __launch_bounds__(256) void sc_knn_kernel(const double *__restrict__ 
     }
 }
 
+// Batch form of stage 1 for the default 20 rings: QT queries share every bank row read (the row sits in
+// registers, the query ring keys in LDS), so the ring-key array is streamed once per QT queries instead of
+// once per query.  grid (G, ceil(nq / QT)), 256 threads.  Same distances, same order, same lists.
+template <int RR, int QT>
+__global__ __launch_bounds__(256) void sc_knn_tile_kernel(const double *__restrict__ rk, int64_t n,
+                                                          const double *__restrict__ qrk,
+                                                          const int64_t *__restrict__ row_limit, int nq, int C,
+                                                          double *__restrict__ part_key, int *__restrict__ part_idx) {
+    __shared__ double s_q[QT][RR];
+    __shared__ int64_t s_lim[QT];
+    __shared__ double s_key[4][SC_MAX_CAND];
+    __shared__ int s_idx[4][SC_MAX_CAND];
+    const int q0 = blockIdx.y * QT, g = blockIdx.x, G = gridDim.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int e = threadIdx.x; e < QT * RR; e += 256) {
+        const int t = e / RR, r = e - t * RR;
+        s_q[t][r] = q0 + t < nq ? qrk[(int64_t)(q0 + t) * RR + r] : 0.0;
+    }
+    if (threadIdx.x < QT) {
+        const int q = q0 + threadIdx.x;
+        int64_t lim = (q < nq) ? (row_limit ? row_limit[q] : n) : 0;
+        lim = lim < n ? lim : n;
+        s_lim[threadIdx.x] = lim < 0 ? 0 : lim;
+    }
+    __syncthreads();
+    const int64_t per = (n + G - 1) / G;
+    const int64_t r0 = (int64_t)g * per;
+    int64_t r1 = r0 + per;
+    r1 = r1 < n ? r1 : n;
+    WaveList wl[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) wl[t].init();
+    for (int64_t base = r0 + wave * 64; base < r1; base += 256) {
+        const int64_t row = base + lane;
+        const bool in = row < r1;
+        double v[RR];
+        const double *p = rk + (in ? row : r0) * RR;
+#pragma unroll
+        for (int r = 0; r < RR; ++r) v[r] = p[r];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            double d2 = 0.0;
+#pragma unroll
+            for (int r = 0; r < RR; ++r) {
+                const double d = __dsub_rn(v[r], s_q[t][r]);
+                d2 = fma(d, d, d2);
+            }
+            wavelist_offer(wl[t], -d2, SC_ENC((int)row), in && row < s_lim[t], C, lane);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        __syncthreads();
+        if (lane < C) { s_key[wave][lane] = wl[t].key; s_idx[wave][lane] = wl[t].idx; }
+        __syncthreads();
+        if (wave == 0 && q0 + t < nq) {
+            for (int w = 1; w < 4; ++w) {
+                double k = lane < C ? s_key[w][lane] : -INFINITY;
+                int i = lane < C ? s_idx[w][lane] : -1;
+                wavelist_offer(wl[t], k, i, i >= 0, C, lane);
+            }
+            if (lane < C) {
+                size_t o = ((size_t)(q0 + t) * G + g) * C + lane;
+                part_key[o] = wl[t].key;
+                part_idx[o] = wl[t].idx;
+            }
+        }
+    }
+}
+
 // one wave per query: merge the G partial lists; cand[q][c] = bank row or -1
 __global__ __launch_bounds__(64) void sc_knn_merge_kernel(const double *__restrict__ part_key,
                                                           const int *__restrict__ part_idx, int G, int C,
@@ -411,9 +481,14 @@ CSLAM_API int cslam_scbank_search_dev(cslam_scbank_t *b, const double *d_q, int6
     HIP_TRY(hipSetDevice(b->device));
     hipStream_t st = (hipStream_t)stream;
     const int C = num_candidates, R = b->R, S = b->S;
-    int G = (int)ceil_div64(b->n > 0 ? b->n : 1, 2048);
-    const int gmax = b->num_cu * 4;
-    if (G > gmax) G = gmax;
+    // row chunks per query (tile): enough workgroups to fill the chip, no more -- every chunk pays the
+    // warm-up of its candidate lists (~C ln(rows) insertions), so long chunks are cheaper than many
+    const bool tiled = (R == 20 && nq >= 8);
+    const int64_t qgroups = tiled ? ceil_div64(nq, 8) : nq;
+    int G = (int)ceil_div64((int64_t)b->num_cu * 4, qgroups);
+    const int64_t gcap = ceil_div64(b->n > 0 ? b->n : 1, 2048);
+    if (G > gcap) G = (int)gcap;
+    if (G < 1) G = 1;
     size_t o_qrk = 0, o_qcn = o_qrk + al256((size_t)nq * R * 8), o_pk = o_qcn + al256((size_t)nq * S * 8);
     size_t o_pi = o_pk + al256((size_t)nq * G * C * 8), o_cand = o_pi + al256((size_t)nq * G * C * 4);
     size_t o_cd = o_cand + al256((size_t)nq * C * 8), o_cy = o_cd + al256((size_t)nq * C * 8);
@@ -428,8 +503,14 @@ CSLAM_API int cslam_scbank_search_dev(cslam_scbank_t *b, const double *d_q, int6
     int *cy = d_cyaw ? d_cyaw : (int *)(b->ws + o_cy);
     rc = sc_prep_launch(d_q, nq, R, S, qrk, qcn, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(sc_knn_kernel, dim3((unsigned)G, (unsigned)nq), dim3(256), 0, st, b->rk, b->n, R, qrk,
-                       d_row_limit, C, pk, pi);
+    if (tiled) {
+        constexpr int QT = 8;
+        hipLaunchKernelGGL((sc_knn_tile_kernel<20, QT>), dim3((unsigned)G, (unsigned)ceil_div64(nq, QT)), dim3(256),
+                           0, st, b->rk, b->n, qrk, d_row_limit, (int)nq, C, pk, pi);
+    } else {
+        hipLaunchKernelGGL(sc_knn_kernel, dim3((unsigned)G, (unsigned)nq), dim3(256), 0, st, b->rk, b->n, R, qrk,
+                           d_row_limit, C, pk, pi);
+    }
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(sc_knn_merge_kernel, dim3((unsigned)nq), dim3(64), 0, st, pk, pi, G, C, cand);
     HIP_TRY(hipGetLastError());

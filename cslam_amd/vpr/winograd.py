@@ -1,0 +1,115 @@
+"""Winograd F(2x2, 3x3) execution of the wide 3x3 convolutions of the extractor backbone.
+
+The backbone stays a PyTorch module (same layer list, same parameter names, checkpoints load unchanged:
+vpr/backbones.py); `WinogradTrunk` only changes HOW its 3x3 / stride 1 / pad 1 convolutions with many
+input channels are executed: hand-written HIP input / output transforms (csrc/winograd.hip through
+`cslam_wino_input_dev` / `cslam_wino_output_dev`, bias + ReLU + the following MaxPool fused into the
+output transform) around 16 plain fp32 GEMMs (`torch.bmm` = rocBLAS).  2.25x fewer multiplications than
+the direct convolution MIOpen runs for the same layer; fp32 throughout, results equal to the direct
+form to ~1e-6 relative (tests/test_heads_gpu.py).  Every other layer (the 3- and 64/128-channel
+convolutions, whose transforms would cost more HBM traffic than they save in FLOPs) runs through torch.
+"""
+import ctypes as C
+
+import torch
+from torch import nn
+
+from .. import _lib
+from .heads import _p, _stream
+
+_G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+
+
+def wino_weights(weight):
+    """[Cout, Cin, 3, 3] -> U [16, Cin, Cout] float32, U[4i+j] = (G g G^T)[i][j] (computed in float64)."""
+    g = weight.detach().to(torch.float64).cpu()
+    u = torch.einsum("ik,ockl,jl->ijco", _G, g, _G)            # [4,4,Cin,Cout]
+    return u.reshape(16, g.shape[1], g.shape[0]).to(torch.float32).contiguous()
+
+
+class _Step(object):
+    __slots__ = ("kind", "module", "conv", "relu", "pool", "U", "bias")
+
+    def __init__(self):
+        self.kind, self.module, self.conv, self.relu, self.pool, self.U, self.bias = "torch", None, None, False, False, None, None
+
+
+class WinogradTrunk(object):
+    """Runs an nn.Sequential of Conv2d / ReLU / MaxPool2d like `encoder(x)`, with the eligible
+    convolutions (+ their ReLU, + their MaxPool2d(2,2)) replaced by the Winograd pipeline."""
+
+    def __init__(self, encoder, min_in_channels=256):
+        self.encoder = encoder
+        self.min_in_channels = int(min_in_channels)
+        self._ws = {}
+        self.refresh()
+
+    def refresh(self):
+        """(Re)build the plan and the transformed weights from the encoder's current parameters."""
+        mods = list(self.encoder)
+        self.steps = []
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            st = _Step()
+            ok = (isinstance(m, nn.Conv2d) and m.kernel_size == (3, 3) and m.stride == (1, 1) and m.padding == (1, 1)
+                  and m.dilation == (1, 1) and m.groups == 1 and m.in_channels >= self.min_in_channels
+                  and m.in_channels % 4 == 0 and m.out_channels % 4 == 0 and m.weight.is_cuda)
+            if ok:
+                st.kind, st.conv, st.relu, st.pool = "wino", m, False, False
+                st.U = wino_weights(m.weight).to(m.weight.device)
+                st.bias = None if m.bias is None else m.bias.detach().to(torch.float32).contiguous()
+                i += 1
+                if i < len(mods) and isinstance(mods[i], nn.ReLU):
+                    st.relu = True
+                    i += 1
+                    p = mods[i] if i < len(mods) else None
+                    if isinstance(p, nn.MaxPool2d) and p.kernel_size in (2, (2, 2)) and p.stride in (2, (2, 2)) \
+                            and p.padding in (0, (0, 0)) and not p.ceil_mode:
+                        st.pool = True
+                        i += 1
+            else:
+                st.kind, st.module = "torch", m
+                i += 1
+            self.steps.append(st)
+        return self
+
+    def _buf(self, name, numel, device):
+        b = self._ws.get(name)
+        if b is None or b.numel() < numel or b.device != device:
+            b = torch.empty(numel, dtype=torch.float32, device=device)
+            self._ws[name] = b
+        return b[:numel]
+
+    @torch.no_grad()
+    def __call__(self, x):
+        """x [B,C,H,W] float32 (any memory format) -> [B,C',H',W'] float32, channels_last memory."""
+        lib = _lib.load()
+        x = x.contiguous(memory_format=torch.channels_last)
+        for st in self.steps:
+            if st.kind == "torch":
+                x = st.module(x)
+                continue
+            B, Cin, H, W = x.shape
+            if H % 2 or W % 2 or H < 2 or W < 2:                # odd maps: the direct form
+                x = st.conv(x)
+                if st.relu:
+                    x = torch.relu_(x)
+                if st.pool:
+                    x = torch.nn.functional.max_pool2d(x, 2, 2)
+                continue
+            x = x.contiguous(memory_format=torch.channels_last)
+            Cout = st.conv.out_channels
+            T = B * (H // 2) * (W // 2)
+            V = self._buf("V", 16 * T * Cin, x.device).view(16, T, Cin)
+            M = self._buf("M", 16 * T * Cout, x.device).view(16, T, Cout)
+            s = _stream(x)
+            _lib.check(lib.cslam_wino_input_dev(_p(x), B, H, W, Cin, _p(V), s))     # x's storage is NHWC
+            torch.bmm(V, st.U, out=M)
+            Ho, Wo = (H // 2, W // 2) if st.pool else (H, W)
+            y = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device,
+                            memory_format=torch.channels_last)
+            _lib.check(lib.cslam_wino_output_dev(_p(M), _p(st.bias) if st.bias is not None else None, B, H, W, Cout,
+                                                 int(st.relu), int(st.pool), _p(y), s))
+            x = y
+        return x

@@ -219,6 +219,17 @@ int cslam_scancontext_from_cloud_dev(const double *d_points, const int64_t *d_of
                                      int rings, int sectors, double max_length, double *d_out,
                                      int32_t *d_status, void *stream);
 
+/* Winograd F(2x2, 3x3) transforms for the 3x3 / stride 1 / pad 1 convolutions of the extractor backbone
+ * (the VGG-16 trunk built at cslam/vpr/netvlad.py:163-171; the reference runs it through torch's direct
+ * convolution).  Activations are NHWC float32.  conv(x, g) + bias = output(bmm(input(x), U)) with
+ * U[xi][ci][co] = (G g G^T)[xi]; the 16 GEMMs V[xi] (T x C) . U[xi] (C x Cout) are plain library GEMMs.
+ *   input : x [B,H,W,C] -> V [16, T, C], T = B*(H/2)*(W/2); H, W even, C % 4 == 0
+ *   output: M [16, T, C] -> y [B,H,W,C], or [B,H/2,W/2,C] when pool != 0 (the MaxPool2d(2,2) that follows
+ *           the layer fused in); bias [C] or NULL; relu != 0 applies max(., 0) before the pooling. */
+int cslam_wino_input_dev(const float *d_x, int B, int H, int W, int C, float *d_V, void *stream);
+int cslam_wino_output_dev(const float *d_M, const float *d_bias, int B, int H, int W, int C, int relu,
+                          int pool, float *d_y, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

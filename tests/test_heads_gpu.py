@@ -157,3 +157,60 @@ def test_extractors_end_to_end_structure(T):
                            cp.model.fc_bias.cpu().numpy())
     assert np.max(np.abs(e - ref)) < 1e-5
     assert NetVLAD({"frontend.nn_checkpoint": "disable"}, None).compute_embedding(frames[0]).shape == (128,)
+
+
+# ---- Winograd F(2x2,3x3) execution of the wide backbone convolutions (vpr/winograd.py) ----
+@pytest.mark.parametrize("B,cin,cout,H,W,relu,pool,bias", [(2, 128, 256, 28, 28, True, False, True),
+                                                          (3, 256, 64, 14, 6, True, True, True),
+                                                          (1, 512, 512, 14, 14, False, False, True),
+                                                          (2, 64, 128, 8, 10, False, True, False)])
+def test_winograd_conv_equals_direct_float64(T, B, cin, cout, H, W, relu, pool, bias):
+    """The two HIP transforms around 16 GEMMs == conv2d (+bias, ReLU, MaxPool) evaluated in float64."""
+    torch, _ = T
+    from torch import nn
+    from cslam_amd.vpr.winograd import WinogradTrunk
+    torch.manual_seed(B * 1000 + cin)
+    mods = [nn.Conv2d(cin, cout, 3, padding=1, bias=bias)]
+    if relu:
+        mods.append(nn.ReLU())
+        if pool:
+            mods.append(nn.MaxPool2d(2, 2))
+    seq = nn.Sequential(*mods).cuda().eval()
+    x = torch.randn((B, cin, H, W), device="cuda")
+    wt = WinogradTrunk(seq, min_in_channels=64)
+    assert [s.kind for s in wt.steps][0] == "wino" and wt.steps[0].relu == relu and wt.steps[0].pool == (relu and pool)
+    y = wt(x)
+    with torch.no_grad():
+        ref = nn.Sequential(*[m for m in seq]).double()(x.double())
+    seq.float()
+    assert y.shape == ref.shape
+    scale = ref.abs().max().item()
+    assert (y.double() - ref).abs().max().item() <= 5e-6 * scale
+
+
+def test_winograd_trunk_equals_direct_trunk_and_falls_back_on_odd_maps(T):
+    torch, _ = T
+    from cslam_amd.vpr.backbones import vgg16_features_trunk
+    from cslam_amd.vpr.winograd import WinogradTrunk
+    torch.manual_seed(3)
+    enc = vgg16_features_trunk().cuda().eval()
+    wt = WinogradTrunk(enc, min_in_channels=128)
+    assert sum(s.kind == "wino" for s in wt.steps) == 10 and sum(s.pool for s in wt.steps) == 3
+    for hw in (224, 112, 72):                       # 72 -> 36 -> 18 -> 9: odd maps in the last block
+        x = torch.randn((2, 3, hw, hw), device="cuda")
+        with torch.no_grad():
+            a = enc(x)
+        b = wt(x)
+        assert a.shape == b.shape
+        assert (a - b).abs().max().item() <= 1e-5 * a.abs().max().item()
+
+
+def test_netvlad_descriptors_winograd_vs_direct(T):
+    torch, _ = T
+    from cslam_amd.vpr.netvlad import NetVLAD
+    frames = torch.from_numpy(np.random.default_rng(5).integers(0, 256, size=(4, 480, 640, 3), dtype=np.uint8)).cuda()
+    base = {"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376, "frontend.netvlad.pca_dim": 512}
+    a = NetVLAD(dict(base, **{"frontend.backbone_conv": "winograd"}), None).compute_embeddings_device(frames)
+    b = NetVLAD(dict(base, **{"frontend.backbone_conv": "direct"}), None).compute_embeddings_device(frames)
+    assert (a - b).abs().max().item() <= 1e-5                  # unit-norm descriptors, north_star's fp32 gate
+    assert torch.all((a * b).sum(1) > 1 - 1e-6)
