@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--match-queries", type=int, default=100_000, help="queries of the match-only leg")
     ap.add_argument("--backbone-dtype", default="fp32", choices=["fp32", "bf16"])
     ap.add_argument("--extract-chunk", type=int, default=256, help="frames per backbone forward")
-    ap.add_argument("--backbone-conv", default="winograd", choices=["winograd", "direct"],
+    ap.add_argument("--backbone-conv", default="winograd", choices=["winograd", "winograd2", "direct"],
                     help="execution of the wide 3x3 backbone convolutions (vpr/winograd.py)")
     ap.add_argument("--cpu-queries", type=int, default=48, help="cpu_baseline sample size (queries)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -112,6 +112,55 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restric
     }
 }
 
+// Epilogue of the layers that stay on the direct convolution (3 / 64 input channels): bias + ReLU
+// (+ MaxPool2d(2,2)) in ONE pass over the NHWC activation instead of torch's three (add, relu, pool).
+// x [B][H][W][C]; y = x in place when POOL is false, else [B][H/2][W/2][C].
+template <bool RELU, bool POOL>
+__global__ __launch_bounds__(256) void bias_act_pool_kernel(const float *__restrict__ x, const float *__restrict__ bias,
+                                                            int64_t n_out, int H, int W, int C, float *__restrict__ y) {
+    const int c4n = C >> 2;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= n_out) return;
+    const int c4 = (int)(gid % c4n);
+    const f4 bv = bias ? *((const f4 *)bias + c4) : (f4)(0.0f);
+    if (!POOL) {
+        f4 v = *((const f4 *)x + gid) + bv;
+        if (RELU) v = __builtin_elementwise_max(v, (f4)(0.0f));
+        *((f4 *)y + gid) = v;
+        return;
+    }
+    const int Wo = W >> 1, Ho = H >> 1;
+    const int64_t pix = gid / c4n;
+    const int wo = (int)(pix % Wo);
+    const int ho = (int)((pix / Wo) % Ho);
+    const int64_t b = pix / ((int64_t)Wo * Ho);
+    const f4 *p = (const f4 *)(x + ((b * H + 2 * ho) * W + 2 * wo) * C) + c4;
+    const int64_t rowstride = (int64_t)W * c4n;
+    f4 v = __builtin_elementwise_max(__builtin_elementwise_max(p[0], p[c4n]),
+                                     __builtin_elementwise_max(p[rowstride], p[rowstride + c4n])) + bv;
+    if (RELU) v = __builtin_elementwise_max(v, (f4)(0.0f));      // max commutes with + bias and with ReLU
+    *((f4 *)y + gid) = v;
+}
+
+CSLAM_API int cslam_bias_act_pool_dev(const float *d_x, const float *d_bias, int B, int H, int W, int C, int relu,
+                                      int pool, float *d_y, void *stream) {
+    ARG_CHECK(d_x && d_y, "NULL argument");
+    ARG_CHECK(B >= 1 && H >= 1 && W >= 1 && C >= 4 && (C % 4) == 0, "C must be a multiple of 4");
+    ARG_CHECK(!pool || ((H % 2) == 0 && (W % 2) == 0), "pooling needs even H and W");
+    ARG_CHECK(pool || d_x == d_y || d_y + (int64_t)B * H * W * C <= d_x || d_x + (int64_t)B * H * W * C <= d_y,
+              "y must be x itself or not overlap it");
+    const int64_t n = pool ? (int64_t)B * (H / 2) * (W / 2) * (C / 4) : (int64_t)B * H * W * (C / 4);
+    ARG_CHECK(ceil_div64(n, 256) < (1LL << 31), "too many elements for one launch");
+    dim3 grid((unsigned)ceil_div64(n, 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (relu && pool) hipLaunchKernelGGL((bias_act_pool_kernel<true, true>), grid, block, 0, st, d_x, d_bias, n, H, W, C, d_y);
+    else if (relu) hipLaunchKernelGGL((bias_act_pool_kernel<true, false>), grid, block, 0, st, d_x, d_bias, n, H, W, C, d_y);
+    else if (pool) hipLaunchKernelGGL((bias_act_pool_kernel<false, true>), grid, block, 0, st, d_x, d_bias, n, H, W, C, d_y);
+    else hipLaunchKernelGGL((bias_act_pool_kernel<false, false>), grid, block, 0, st, d_x, d_bias, n, H, W, C, d_y);
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
 CSLAM_API int cslam_wino_input_dev(const float *d_x, int B, int H, int W, int C, float *d_V, void *stream) {
     ARG_CHECK(d_x && d_V, "NULL argument");
     ARG_CHECK(B >= 1 && H >= 2 && W >= 2 && (H % 2) == 0 && (W % 2) == 0, "H and W must be even and >= 2");
@@ -137,6 +186,152 @@ CSLAM_API int cslam_wino_output_dev(const float *d_M, const float *d_bias, int B
     else if (relu) hipLaunchKernelGGL((wino_output_kernel<true, false>), grid, block, 0, st, d_M, d_bias, B, H, W, C, d_y);
     else if (pool) hipLaunchKernelGGL((wino_output_kernel<false, true>), grid, block, 0, st, d_M, d_bias, B, H, W, C, d_y);
     else hipLaunchKernelGGL((wino_output_kernel<false, false>), grid, block, 0, st, d_M, d_bias, B, H, W, C, d_y);
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
+// ---------------------------------------------------------------- F(4x4, 3x3) ----
+// Same scheme with 6x6 input tiles and 4x4 output tiles: 36 GEMMs, 4x fewer multiplications than the direct
+// form (F(2x2,3x3): 2.25x) and V / M only 2.25x the activation size (F(2x2,3x3): 4x).  The transform
+// constants (up to 8) cost about one decimal digit: ~1e-5 relative on a layer output against ~1.5e-6
+// for F(2x2,3x3) (measured, tests/test_heads_gpu.py) -- opt-in through `frontend.backbone_conv`.
+// One thread owns 2 consecutive channels of one tile (72 live values).
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void wino4_bt(f2 &d0, f2 &d1, f2 &d2, f2 &d3, f2 &d4, f2 &d5) {
+    const f2 r0 = 4.0f * d0 - 5.0f * d2 + d4;
+    const f2 r1 = -4.0f * (d1 + d2) + d3 + d4;
+    const f2 r2 = 4.0f * (d1 - d2) - d3 + d4;
+    const f2 r3 = 2.0f * (d3 - d1) - d2 + d4;
+    const f2 r4 = 2.0f * (d1 - d3) - d2 + d4;
+    const f2 r5 = 4.0f * d1 - 5.0f * d3 + d5;
+    d0 = r0; d1 = r1; d2 = r2; d3 = r3; d4 = r4; d5 = r5;
+}
+
+__global__ __launch_bounds__(256) void wino4_input_kernel(const float *__restrict__ x, int B, int H, int W, int C,
+                                                          float *__restrict__ V) {
+    const int c2n = C >> 1;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int TH = H >> 2, TW = W >> 2;
+    const int64_t T = (int64_t)B * TH * TW;
+    if (gid >= T * c2n) return;
+    const int c2 = (int)(gid % c2n);
+    const int64_t t = gid / c2n;
+    const int tj = (int)(t % TW);
+    const int ti = (int)((t / TW) % TH);
+    const int b = (int)(t / ((int64_t)TW * TH));
+    const int h0 = 4 * ti - 1, w0 = 4 * tj - 1;
+    f2 d[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int h = h0 + i;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int w = w0 + j;
+            const bool in = (h >= 0) & (h < H) & (w >= 0) & (w < W);
+            const f2 v = *((const f2 *)(x + (((int64_t)b * H + (in ? h : 0)) * W + (in ? w : 0)) * C) + c2);
+            d[i][j] = in ? v : (f2)(0.0f);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) wino4_bt(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wino4_bt(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);
+    const int64_t plane = T * C;
+    float *o = V + t * C + 2 * c2;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) __builtin_nontemporal_store(d[i][j], (f2 *)(o + (int64_t)(6 * i + j) * plane));
+}
+
+__device__ __forceinline__ void wino4_at(const f2 m0, const f2 m1, const f2 m2, const f2 m3, const f2 m4, const f2 m5,
+                                         f2 &s0, f2 &s1, f2 &s2, f2 &s3) {
+    const f2 a = m1 + m2, bq = m1 - m2, c = m3 + m4, e = m3 - m4;
+    s0 = m0 + a + c;
+    s1 = bq + 2.0f * e;
+    s2 = a + 4.0f * c;
+    s3 = bq + 8.0f * e + m5;
+}
+
+template <bool RELU, bool POOL>
+__global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restrict__ M, const float *__restrict__ bias,
+                                                           int B, int H, int W, int C, float *__restrict__ y) {
+    const int c2n = C >> 1;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int TH = H >> 2, TW = W >> 2;
+    const int64_t T = (int64_t)B * TH * TW;
+    if (gid >= T * c2n) return;
+    const int c2 = (int)(gid % c2n);
+    const int64_t t = gid / c2n;
+    const int64_t plane = T * C;
+    const float *p = M + t * C + 2 * c2;
+    f2 s[4][6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        f2 m[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) m[i] = __builtin_nontemporal_load((const f2 *)(p + (int64_t)(6 * i + j) * plane));
+        wino4_at(m[0], m[1], m[2], m[3], m[4], m[5], s[0][j], s[1][j], s[2][j], s[3][j]);
+    }
+    const f2 bv = bias ? *((const f2 *)bias + c2) : (f2)(0.0f);
+    f2 o[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        wino4_at(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o[i][0], o[i][1], o[i][2], o[i][3]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[i][j] += bv;
+            if (RELU) o[i][j] = __builtin_elementwise_max(o[i][j], (f2)(0.0f));
+        }
+    }
+    const int tj = (int)(t % TW);
+    const int ti = (int)((t / TW) % TH);
+    const int b = (int)(t / ((int64_t)TW * TH));
+    if (POOL) {
+        const int Ho = H >> 1, Wo = W >> 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f2 v = __builtin_elementwise_max(__builtin_elementwise_max(o[2 * i][2 * j], o[2 * i][2 * j + 1]),
+                                                 __builtin_elementwise_max(o[2 * i + 1][2 * j], o[2 * i + 1][2 * j + 1]));
+                *((f2 *)(y + (((int64_t)b * Ho + 2 * ti + i) * Wo + 2 * tj + j) * C) + c2) = v;
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                *((f2 *)(y + (((int64_t)b * H + 4 * ti + i) * W + 4 * tj + j) * C) + c2) = o[i][j];
+    }
+}
+
+CSLAM_API int cslam_wino4_input_dev(const float *d_x, int B, int H, int W, int C, float *d_V, void *stream) {
+    ARG_CHECK(d_x && d_V, "NULL argument");
+    ARG_CHECK(B >= 1 && H >= 4 && W >= 4 && (H % 4) == 0 && (W % 4) == 0, "H and W must be multiples of 4");
+    ARG_CHECK(C >= 2 && (C % 2) == 0, "C must be even");
+    const int64_t n = (int64_t)B * (H / 4) * (W / 4) * (C / 2);
+    ARG_CHECK(ceil_div64(n, 256) < (1LL << 31), "too many tiles for one launch");
+    hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream, d_x, B,
+                       H, W, C, d_V);
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
+CSLAM_API int cslam_wino4_output_dev(const float *d_M, const float *d_bias, int B, int H, int W, int C, int relu,
+                                     int pool, float *d_y, void *stream) {
+    ARG_CHECK(d_M && d_y, "NULL argument");
+    ARG_CHECK(B >= 1 && H >= 4 && W >= 4 && (H % 4) == 0 && (W % 4) == 0, "H and W must be multiples of 4");
+    ARG_CHECK(C >= 2 && (C % 2) == 0, "C must be even");
+    const int64_t n = (int64_t)B * (H / 4) * (W / 4) * (C / 2);
+    ARG_CHECK(ceil_div64(n, 256) < (1LL << 31), "too many tiles for one launch");
+    dim3 grid((unsigned)ceil_div64(n, 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (relu && pool) hipLaunchKernelGGL((wino4_output_kernel<true, true>), grid, block, 0, st, d_M, d_bias, B, H, W, C, d_y);
+    else if (relu) hipLaunchKernelGGL((wino4_output_kernel<true, false>), grid, block, 0, st, d_M, d_bias, B, H, W, C, d_y);
+    else if (pool) hipLaunchKernelGGL((wino4_output_kernel<false, true>), grid, block, 0, st, d_M, d_bias, B, H, W, C, d_y);
+    else hipLaunchKernelGGL((wino4_output_kernel<false, false>), grid, block, 0, st, d_M, d_bias, B, H, W, C, d_y);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }

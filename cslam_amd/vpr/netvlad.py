@@ -75,10 +75,14 @@ class NetVLAD(object):
         self.crop = int(self.params["frontend.image_crop_size"])
         # channels_last: MIOpen's NHWC fp32 igemm kernels are ~6 % faster than NCHW on gfx950 (measured)
         self.encoder = vgg16_features_trunk().to(self.device).eval().to(memory_format=torch.channels_last)
-        # 'winograd' (default): the 3x3 convolutions with >= 128 input channels run as Winograd F(2x2,3x3)
-        # (HIP transforms + rocBLAS GEMMs, vpr/winograd.py; +39 % frames/s, 1.6e-6 from the direct form);
-        # 'direct': every layer through torch / MIOpen
+        # How the 3x3 convolutions with >= 64 input channels are executed (vpr/winograd.py):
+        #   'winograd'  (default) F(4x4,3x3) on maps whose sides are multiples of 4, F(2x2,3x3) on the others
+        #   'winograd2' F(2x2,3x3) only;  'direct' every layer through torch / MIOpen.
+        # Measured on VGG-16 at B = 256: 7.9k / 5.4k / 3.6k frames/s; max error against a float64 trunk
+        # 3.7e-6 / 1.3e-6 / 1.4e-6 of the largest activation.
         self.backbone_conv = str(self.params.get('frontend.backbone_conv', 'winograd')).lower()
+        if self.backbone_conv not in ('winograd', 'winograd2', 'direct'):
+            raise ValueError("frontend.backbone_conv must be 'winograd', 'winograd2' or 'direct'")
         self.trunk = None
         self.pool = NetVLADLayer(num_clusters=64, dim=512, device=self.device)
         self.pca_components = None     # [Dout, Din] device
@@ -158,9 +162,9 @@ class NetVLAD(object):
             with torch.autocast("cuda", dtype=backbone_dtype):
                 f = self.encoder(x)
             f = f.float()
-        elif self.backbone_conv == 'winograd':
+        elif self.backbone_conv in ('winograd', 'winograd2'):
             if self.trunk is None:
-                self.trunk = WinogradTrunk(self.encoder, min_in_channels=128)
+                self.trunk = WinogradTrunk(self.encoder, min_in_channels=64, tile=4 if self.backbone_conv == 'winograd' else 2)
             f = self.trunk(x)
         else:
             f = self.encoder(x)

@@ -163,6 +163,7 @@ def test_extractors_end_to_end_structure(T):
 @pytest.mark.parametrize("B,cin,cout,H,W,relu,pool,bias", [(2, 128, 256, 28, 28, True, False, True),
                                                           (3, 256, 64, 14, 6, True, True, True),
                                                           (1, 512, 512, 14, 14, False, False, True),
+                                                          (40, 64, 128, 16, 24, True, True, True),
                                                           (2, 64, 128, 8, 10, False, True, False)])
 def test_winograd_conv_equals_direct_float64(T, B, cin, cout, H, W, relu, pool, bias):
     """The two HIP transforms around 16 GEMMs == conv2d (+bias, ReLU, MaxPool) evaluated in float64."""
@@ -177,15 +178,16 @@ def test_winograd_conv_equals_direct_float64(T, B, cin, cout, H, W, relu, pool, 
             mods.append(nn.MaxPool2d(2, 2))
     seq = nn.Sequential(*mods).cuda().eval()
     x = torch.randn((B, cin, H, W), device="cuda")
-    wt = WinogradTrunk(seq, min_in_channels=64)
-    assert [s.kind for s in wt.steps][0] == "wino" and wt.steps[0].relu == relu and wt.steps[0].pool == (relu and pool)
-    y = wt(x)
     with torch.no_grad():
-        ref = nn.Sequential(*[m for m in seq]).double()(x.double())
+        ref = seq.double()(x.double())
     seq.float()
-    assert y.shape == ref.shape
     scale = ref.abs().max().item()
-    assert (y.double() - ref).abs().max().item() <= 5e-6 * scale
+    for tile, tol in ((2, 5e-6), (4, 2e-5)):
+        wt = WinogradTrunk(seq, min_in_channels=64, tile=tile)
+        assert [s.kind for s in wt.steps][0] == "wino" and wt.steps[0].relu == relu and wt.steps[0].pool == (relu and pool)
+        y = wt(x)
+        assert y.shape == ref.shape
+        assert (y.double() - ref).abs().max().item() <= tol * scale, tile
 
 
 def test_winograd_trunk_equals_direct_trunk_and_falls_back_on_odd_maps(T):
@@ -194,15 +196,23 @@ def test_winograd_trunk_equals_direct_trunk_and_falls_back_on_odd_maps(T):
     from cslam_amd.vpr.winograd import WinogradTrunk
     torch.manual_seed(3)
     enc = vgg16_features_trunk().cuda().eval()
-    wt = WinogradTrunk(enc, min_in_channels=128)
-    assert sum(s.kind == "wino" for s in wt.steps) == 10 and sum(s.pool for s in wt.steps) == 3
-    for hw in (224, 112, 72):                       # 72 -> 36 -> 18 -> 9: odd maps in the last block
-        x = torch.randn((2, 3, hw, hw), device="cuda")
-        with torch.no_grad():
-            a = enc(x)
-        b = wt(x)
-        assert a.shape == b.shape
-        assert (a - b).abs().max().item() <= 1e-5 * a.abs().max().item()
+    for tile, minc, nw in ((2, 128, 10), (4, 64, 12)):
+        wt = WinogradTrunk(enc, min_in_channels=minc, tile=tile)
+        kinds = [s.kind for s in wt.steps]
+        assert kinds.count("wino") == nw and kinds.count("direct") == 13 - nw and kinds.count("torch") == 0
+        assert sum(s.pool for s in wt.steps) == 4
+        for B, hw in ((2, 224), (24, 112), (2, 72)):   # 72 -> 36 -> 18 -> 9: odd maps in the last block
+            x = torch.randn((B, 3, hw, hw), device="cuda")
+            with torch.no_grad():
+                r = enc.double()(x.double())
+                enc.float()
+                a = enc(x)
+            b = wt(x)
+            assert a.shape == b.shape
+            scale = r.abs().max().item()
+            e_direct = (a.double() - r).abs().max().item() / scale
+            e_wino = (b.double() - r).abs().max().item() / scale
+            assert e_wino <= 1e-5 and e_wino <= 5 * e_direct + 1e-6, (tile, hw, e_wino, e_direct)
 
 
 def test_netvlad_descriptors_winograd_vs_direct(T):
@@ -210,7 +220,10 @@ def test_netvlad_descriptors_winograd_vs_direct(T):
     from cslam_amd.vpr.netvlad import NetVLAD
     frames = torch.from_numpy(np.random.default_rng(5).integers(0, 256, size=(4, 480, 640, 3), dtype=np.uint8)).cuda()
     base = {"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376, "frontend.netvlad.pca_dim": 512}
-    a = NetVLAD(dict(base, **{"frontend.backbone_conv": "winograd"}), None).compute_embeddings_device(frames)
+    frames = frames.repeat(16, 1, 1, 1)                        # 64 frames: enough tiles for the F(4x4) path
     b = NetVLAD(dict(base, **{"frontend.backbone_conv": "direct"}), None).compute_embeddings_device(frames)
-    assert (a - b).abs().max().item() <= 1e-5                  # unit-norm descriptors, north_star's fp32 gate
-    assert torch.all((a * b).sum(1) > 1 - 1e-6)
+    for mode in ("winograd", "winograd2"):
+        a = NetVLAD(dict(base, **{"frontend.backbone_conv": mode}), None).compute_embeddings_device(frames)
+        assert (a - b).abs().max().item() <= 1e-5              # unit-norm descriptors, north_star's fp32 gate
+        assert torch.all((a * b).sum(1) > 1 - 1e-6)
+        assert torch.equal(a[:4], a[4:8])                      # batch position does not change a descriptor

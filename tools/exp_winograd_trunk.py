@@ -14,14 +14,18 @@ def t(fn, n=3):
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n
 g = torch.Generator(device="cuda").manual_seed(0)
-for minc in (256, 128, 64):
-    wt = WinogradTrunk(nv.encoder, min_in_channels=minc)
+for minc, tile in ((128, 2), (128, 4), (64, 4)):
+    wt = WinogradTrunk(nv.encoder, min_in_channels=minc, tile=tile)
     x = torch.randn((8, 3, 224, 224), generator=g, device="cuda").contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
         a = nv.encoder(x); b = wt(x)
+        r = nv.encoder.double()(x.double()); nv.encoder.float()
     err = (a - b).abs().max().item() / a.abs().max().item()
+    e64w = (b.double() - r).abs().max().item() / r.abs().max().item()
+    e64d = (a.double() - r).abs().max().item() / r.abs().max().item()
+    print(f"tile {tile}: vs float64 trunk: winograd {e64w:.2e}, direct fp32 {e64d:.2e}")
     print(f"min_in_channels {minc}: wino steps {sum(s.kind == 'wino' for s in wt.steps)}, max |diff| / max |ref| = {err:.2e}")
-    for B in (1, 16, 128):
+    for B in (1, 128, 256):
         x = torch.randn((B, 3, 224, 224), generator=g, device="cuda").contiguous(memory_format=torch.channels_last)
         with torch.no_grad():
             td = t(lambda: nv.encoder(x)); tw = t(lambda: wt(x))
