@@ -29,6 +29,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
+HBM_PEAK_GBS = 8000.0              # same guide: HBM3E ~8 TB/s
 
 
 def parse():
@@ -191,6 +192,38 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_src, "source": src,
                 "kernel_ms": round(match_kernel_ms, 3), "in_step_achieved": in_step}
 
+    # the hand-written kernels of the extract leg are the Winograd transforms (HBM-bound streaming): time the
+    # largest one on its real shape with HIP events on the launch stream.  Algorithmic bytes per launch:
+    # the activation once + V once (2.25x the activation for 6x6 tiles), DESIGN.md section 3.6.
+    extract_roofline = None
+    if extractor is not None and rank == 0 and extractor.backbone_conv == "winograd":
+        import ctypes as C
+        from cslam_amd import _lib
+        lib = _lib.load()
+        eb, eh, ec = a.extract_chunk, 112, 128                      # conv2_2's input at the bench chunk size
+        xt = torch.randn((eb, eh, eh, ec), device=dev)
+        vt = torch.empty((36, eb * (eh // 4) * (eh // 4), ec), device=dev)
+        st = torch.cuda.current_stream().cuda_stream
+
+        def wino_in():
+            _lib.check(lib.cslam_wino4_input_dev(xt.data_ptr(), eb, eh, eh, ec, vt.data_ptr(), st))
+        wino_in()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            wino_in()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 5
+        nbytes = (xt.numel() + vt.numel()) * 4
+        extract_roofline = {"bound": "hbm", "kernel": "wino4_input_kernel", "achieved": round(nbytes / ms / 1e6, 1),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                            "traffic": None, "kernel_ms": round(ms, 3),
+                            "shape": f"x [{eb},{eh},{eh},{ec}] -> V [36,{vt.shape[1]},{ec}]",
+                            "note": "largest hand-written kernel of the extract leg; the 36 GEMMs between the "
+                                    "transforms are rocBLAS"}
+        del xt, vt
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         from oracle import pyoracle
@@ -241,6 +274,7 @@ def main():
             "match_only_queries": nqm,
             "uncertified_queries": int(uncertified),
             "roofline": roofline,
+            "roofline_extract": extract_roofline,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))

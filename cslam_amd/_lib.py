@@ -63,6 +63,7 @@ _SIGNATURES = {
     "cslam_scbank_search_host": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cslam_scbank_search_dev": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cslam_bias_act_pool_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "cslam_conv3x3_c3_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "cslam_wino_input_dev": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "cslam_wino_output_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "cslam_wino4_input_dev": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),

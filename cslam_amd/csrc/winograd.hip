@@ -161,6 +161,85 @@ CSLAM_API int cslam_bias_act_pool_dev(const float *d_x, const float *d_bias, int
     return CSLAM_OK;
 }
 
+// First layer (3 input channels, e.g. VGG-16 conv1_1): direct 3x3 convolution + bias + ReLU written once,
+// NCHW planar input (what the preprocessing kernel produces) -> NHWC output.  A workgroup owns 64
+// consecutive pixels; lane = pixel (the 27 tap loads of a wave are contiguous runs served by L1), wave w
+// computes output channels [16w, 16w+16) (+64, ...) with wave-uniform weights read through the scalar cache
+// (v_fmac with an SGPR operand).  The 64 x Cout tile is transposed through LDS so that every store
+// instruction writes whole consecutive NHWC pixels (1 KiB runs).  HBM-bound on the output write
+// (Cout*4 B per pixel); 2*27*Cout flop per pixel on the VALU.
+#define C3_CG 16
+__global__ __launch_bounds__(256) void conv3x3_c3_kernel(const float *__restrict__ x, const float *__restrict__ wt,
+                                                         const float *__restrict__ bias, int B, int H, int W, int Cout,
+                                                         int relu, float *__restrict__ y) {
+    extern __shared__ float s_t[];                      // [64][Cout + 4]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t npix = (int64_t)B * H * W;
+    const int64_t pix0 = (int64_t)blockIdx.x * 64;
+    const int64_t pix = pix0 + lane;
+    const bool live = pix < npix;
+    const int64_t pc = live ? pix : npix - 1;
+    const int w = (int)(pc % W);
+    const int h = (int)((pc / W) % H);
+    const int64_t b = pc / ((int64_t)W * H);
+    const float *xb = x + b * 3 * (int64_t)H * W;
+    float v[27];
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int hh = h + kh - 1;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ww = w + kw - 1;
+                const bool in = (hh >= 0) & (hh < H) & (ww >= 0) & (ww < W);
+                v[ci * 9 + kh * 3 + kw] = in ? xb[((int64_t)ci * H + hh) * W + ww] : 0.0f;
+            }
+        }
+    const int P = Cout + 4;
+    for (int co0 = wave * C3_CG; co0 < Cout; co0 += 4 * C3_CG) {
+        float acc[C3_CG];
+#pragma unroll
+        for (int j = 0; j < C3_CG; ++j) acc[j] = bias ? bias[co0 + j] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 27; ++k) {
+            const float *wk = wt + k * Cout + co0;      // wave-uniform address
+#pragma unroll
+            for (int j = 0; j < C3_CG; ++j) acc[j] = fmaf(wk[j], v[k], acc[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < C3_CG; j += 4) {
+            f4 o = {acc[j], acc[j + 1], acc[j + 2], acc[j + 3]};
+            if (relu) o = __builtin_elementwise_max(o, (f4)(0.0f));
+            *((f4 *)(s_t + lane * P + co0 + j)) = o;
+        }
+    }
+    __syncthreads();
+    const int c4n = Cout >> 2;
+    for (int e = threadIdx.x; e < 64 * c4n; e += 256) {
+        const int p = e / c4n, c4 = e - p * c4n;
+        if (pix0 + p < npix) *((f4 *)(y + (pix0 + p) * Cout) + c4) = *((const f4 *)(s_t + p * P) + c4);
+    }
+}
+
+CSLAM_API int cslam_conv3x3_c3_dev(const float *d_x, const float *d_wt, const float *d_bias, int B, int H, int W,
+                                   int Cout, int relu, float *d_y, void *stream) {
+    ARG_CHECK(d_x && d_wt && d_y, "NULL argument");
+    ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty input");
+    ARG_CHECK(Cout >= 16 && (Cout % 16) == 0 && Cout <= 512, "Cout must be a multiple of 16, at most 512");
+    const int64_t n = (int64_t)B * H * W;
+    ARG_CHECK(ceil_div64(n, 256) < (1LL << 31), "too many pixels for one launch");
+    ARG_CHECK(ceil_div64(n, 64) < (1LL << 31), "too many pixels for one launch");
+    const size_t lds = (size_t)64 * (Cout + 4) * 4;
+    ARG_CHECK(lds <= 160 * 1024, "Cout too large for the LDS tile");
+    HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_c3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(conv3x3_c3_kernel, dim3((unsigned)ceil_div64(n, 64)), dim3(256), lds, (hipStream_t)stream, d_x,
+                       d_wt, d_bias, B, H, W, Cout, relu, d_y);
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
 CSLAM_API int cslam_wino_input_dev(const float *d_x, int B, int H, int W, int C, float *d_V, void *stream) {
     ARG_CHECK(d_x && d_V, "NULL argument");
     ARG_CHECK(B >= 1 && H >= 2 && W >= 2 && (H % 2) == 0 && (W % 2) == 0, "H and W must be even and >= 2");

@@ -157,7 +157,9 @@ class NetVLAD(object):
     @torch.no_grad()
     def compute_embeddings_device(self, frames_u8, backbone_dtype=None):
         """frames [B,H,W,3] uint8 (device) -> descriptors [B, d] float32 (device)."""
-        x = heads.preprocess(frames_u8.contiguous(), self.crop).contiguous(memory_format=torch.channels_last)
+        x = heads.preprocess(frames_u8.contiguous(), self.crop)
+        if self.backbone_conv == 'direct' or (backbone_dtype is not None and backbone_dtype != torch.float32):
+            x = x.contiguous(memory_format=torch.channels_last)
         if backbone_dtype is not None and backbone_dtype != torch.float32:
             with torch.autocast("cuda", dtype=backbone_dtype):
                 f = self.encoder(x)

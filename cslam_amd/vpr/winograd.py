@@ -79,6 +79,18 @@ class WinogradTrunk(object):
                             and p.padding in (0, (0, 0)) and not p.ceil_mode:
                         st.pool = True
                         i += 1
+            elif (isinstance(m, nn.Conv2d) and m.in_channels == 3 and m.kernel_size == (3, 3) and m.stride == (1, 1)
+                  and m.padding == (1, 1) and m.dilation == (1, 1) and m.groups == 1 and m.out_channels % 16 == 0
+                  and m.out_channels <= 512 and m.weight.is_cuda and not (i + 2 < len(mods) and isinstance(
+                      mods[i + 1], nn.ReLU) and isinstance(mods[i + 2], nn.MaxPool2d))):
+                # first layer: hand-written direct convolution, bias + ReLU fused, planar input -> NHWC
+                st.kind, st.conv = "c3", m
+                st.U = m.weight.detach().to(torch.float32).permute(1, 2, 3, 0).reshape(27, m.out_channels).contiguous()
+                st.bias = None if m.bias is None else m.bias.detach().to(torch.float32).contiguous()
+                i += 1
+                if i < len(mods) and isinstance(mods[i], nn.ReLU):
+                    st.relu = True
+                    i += 1
             elif (isinstance(m, nn.Conv2d) and m.groups == 1 and m.out_channels % 4 == 0 and m.bias is not None
                   and m.weight.is_cuda and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU)):
                 # direct convolution without its bias, then bias + ReLU (+ MaxPool) in one HIP pass
@@ -107,8 +119,17 @@ class WinogradTrunk(object):
     def __call__(self, x):
         """x [B,C,H,W] float32 (any memory format) -> [B,C',H',W'] float32, channels_last memory."""
         lib = _lib.load()
-        x = x.contiguous(memory_format=torch.channels_last)
         for st in self.steps:
+            if st.kind == "c3":
+                x = x.contiguous()                                   # planar [B,3,H,W]
+                B, _, H, W = x.shape
+                Cout = st.conv.out_channels
+                y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+                _lib.check(lib.cslam_conv3x3_c3_dev(_p(x), _p(st.U), _p(st.bias) if st.bias is not None else None,
+                                                    B, H, W, Cout, int(st.relu), _p(y), _stream(x)))
+                x = y
+                continue
+            x = x.contiguous(memory_format=torch.channels_last)
             if st.kind == "torch":
                 x = st.module(x)
                 continue

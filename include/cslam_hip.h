@@ -231,6 +231,11 @@ int cslam_scancontext_from_cloud_dev(const double *d_points, const int64_t *d_of
  * [B,H/2,W/2,C]. */
 int cslam_bias_act_pool_dev(const float *d_x, const float *d_bias, int B, int H, int W, int C, int relu,
                             int pool, float *d_y, void *stream);
+/* First backbone layer (3 input channels): y = relu(conv3x3(x, w) + bias), stride 1, zero padding 1.
+ * x [B,3,H,W] planar (the output of cslam_preprocess_dev), wt [27, Cout] = weight[co][ci][kh][kw] transposed
+ * to [(ci*3+kh)*3+kw][co], y [B,H,W,Cout] NHWC. */
+int cslam_conv3x3_c3_dev(const float *d_x, const float *d_wt, const float *d_bias, int B, int H, int W,
+                         int Cout, int relu, float *d_y, void *stream);
 int cslam_wino_input_dev(const float *d_x, int B, int H, int W, int C, float *d_V, void *stream);
 int cslam_wino_output_dev(const float *d_M, const float *d_bias, int B, int H, int W, int C, int relu,
                           int pool, float *d_y, void *stream);

@@ -199,7 +199,8 @@ def test_winograd_trunk_equals_direct_trunk_and_falls_back_on_odd_maps(T):
     for tile, minc, nw in ((2, 128, 10), (4, 64, 12)):
         wt = WinogradTrunk(enc, min_in_channels=minc, tile=tile)
         kinds = [s.kind for s in wt.steps]
-        assert kinds.count("wino") == nw and kinds.count("direct") == 13 - nw and kinds.count("torch") == 0
+        assert kinds.count("wino") == nw and kinds.count("c3") == 1 and kinds.count("direct") == 12 - nw \
+            and kinds.count("torch") == 0
         assert sum(s.pool for s in wt.steps) == 4
         for B, hw in ((2, 224), (24, 112), (2, 72)):   # 72 -> 36 -> 18 -> 9: odd maps in the last block
             x = torch.randn((B, 3, hw, hw), device="cuda")
@@ -227,3 +228,22 @@ def test_netvlad_descriptors_winograd_vs_direct(T):
         assert (a - b).abs().max().item() <= 1e-5              # unit-norm descriptors, north_star's fp32 gate
         assert torch.all((a * b).sum(1) > 1 - 1e-6)
         assert torch.equal(a[:4], a[4:8])                      # batch position does not change a descriptor
+
+
+def test_first_layer_conv_c3_matches_float64(T):
+    """conv1_1 in hand-written HIP (planar input -> NHWC, bias + ReLU fused) against float64 conv2d."""
+    torch, _ = T
+    from torch import nn
+    from cslam_amd.vpr.winograd import WinogradTrunk
+    torch.manual_seed(11)
+    for cout, relu, hw in ((64, True, (37, 50)), (16, False, (8, 8))):
+        mods = [nn.Conv2d(3, cout, 3, padding=1)] + ([nn.ReLU()] if relu else [])
+        seq = nn.Sequential(*mods).cuda().eval()
+        x = torch.randn((3, 3) + hw, device="cuda")
+        wt = WinogradTrunk(seq)
+        assert [s.kind for s in wt.steps] == ["c3"]
+        y = wt(x)
+        with torch.no_grad():
+            ref = seq.double()(x.double())
+        seq.float()
+        assert y.shape == ref.shape and (y.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
