@@ -12,6 +12,7 @@ The first convolution (3 input channels) stays on torch's direct form, with bias
 in one HIP pass (`cslam_bias_act_pool_dev`).
 """
 import ctypes as C
+import os
 
 import torch
 from torch import nn
@@ -33,6 +34,31 @@ def wino_weights(weight, tile=2):
     return u.reshape(G.shape[0] ** 2, g.shape[1], g.shape[0]).to(torch.float32).contiguous()
 
 
+_TUNED = {"done": False}
+
+
+def use_tuned_gemms():
+    """Pick the fastest library solution for the strided-batched fp32 GEMM shapes of the VGG-16 trunk at the
+    256-frame chunk bench.py and the batched callers use: torch's TunableOp replays the selections recorded on an
+    MI355X in `tunableop_gfx950.csv` (tuning itself stays off, unknown shapes keep the library default, and a
+    library / architecture mismatch makes torch ignore the file).  +8 % frames/s over the default heuristic.
+    Regenerate with `PYTORCH_TUNABLEOP_ENABLED=1 python tools/extract_leg.py`.  CSLAM_TUNED_GEMM=0 disables."""
+    if _TUNED["done"] or os.environ.get("CSLAM_TUNED_GEMM", "1") == "0":
+        return
+    _TUNED["done"] = True
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")
+    try:
+        import torch.cuda.tunable as tunable
+        if tunable.is_enabled() or not os.path.exists(path):
+            return                                   # the user drives TunableOp themselves
+        tunable.enable(True)
+        tunable.tuning_enable(False)
+        tunable.read_file(path)
+    except Exception as e:                            # never fatal: the default solutions are still correct
+        import warnings
+        warnings.warn("cslam_amd: tuned GEMM table not loaded (%s)" % e)
+
+
 class _Step(object):
     __slots__ = ("kind", "module", "conv", "relu", "pool", "U", "U4", "bias")
 
@@ -51,6 +77,7 @@ class WinogradTrunk(object):
         self.encoder = encoder
         self.min_in_channels = int(min_in_channels)
         self.tile = int(tile)
+        use_tuned_gemms()
         self._ws = {}
         self.refresh()
 
