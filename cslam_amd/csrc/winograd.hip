@@ -13,6 +13,12 @@
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+// Block order: plain (workgroup b = tiles b*256/(C/2)...).  Two XCD-aware orders were measured and rejected:
+// giving each XCD (b % 8) a contiguous eighth of the tile range, or runs of 64 workgroups, brings FETCH_SIZE down
+// from 1.65x to 1.03-1.08x the activation (halo re-reads hit the local L2), but scatters the 36-plane V write
+// stream over 8 windows and the kernel gets 5-8 % slower: the extra fetches come from the Infinity Cache, the
+// writes are what the kernel is bound by.
+
 // x [B][H][W][C] (NHWC), V [16][T][C] with T = B * (H/2) * (W/2), tile t = (b * H/2 + ti) * W/2 + tj.
 __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict__ x, int B, int H, int W, int C,
                                                          float *__restrict__ V) {
