@@ -65,9 +65,9 @@ _SIGNATURES = {
     "cslam_bias_act_pool_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "cslam_conv3x3_c3_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "cslam_wino_input_dev": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
-    "cslam_wino_output_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "cslam_wino_output_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "cslam_wino4_input_dev": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
-    "cslam_wino4_output_dev": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "cslam_wino4_output_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "cslam_scancontext_from_cloud_dev": (_i, [_vp, _vp, _i, _i, _i, C.c_double, _vp, _vp, _vp]),
 }
 

@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
 // exactly one window of the MaxPool2d(2, 2) that follows the layer).
 template <bool RELU, bool POOL>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restrict__ M, const float *__restrict__ bias,
-                                                          int B, int H, int W, int C, float *__restrict__ y) {
+                                                          const float *__restrict__ res, int B, int H, int W, int C,
+                                                          float *__restrict__ y) {
     const int c4n = C >> 2;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int TH = H >> 1, TW = W >> 1;
@@ -92,19 +93,23 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restric
         s[1][j] = m[1][j] - m[2][j] - m[3][j];
     }
     const f4 bv = bias ? *((const f4 *)bias + c4) : (f4)(0.0f);
+    const int tj = (int)(t % TW);
+    const int ti = (int)((t / TW) % TH);
+    const int b = (int)(t / ((int64_t)TW * TH));
     f4 o[2][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {          // (.) A, + bias, activation
+    for (int i = 0; i < 2; ++i) {          // (.) A, + bias (+ residual), activation
         o[i][0] = s[i][0] + s[i][1] + s[i][2] + bv;
         o[i][1] = s[i][1] - s[i][2] - s[i][3] + bv;
+        if (res) {                         // ResNet shortcut, same NHWC shape as y (never with POOL)
+            o[i][0] += *((const f4 *)(res + (((int64_t)b * H + 2 * ti + i) * W + 2 * tj) * C) + c4);
+            o[i][1] += *((const f4 *)(res + (((int64_t)b * H + 2 * ti + i) * W + 2 * tj + 1) * C) + c4);
+        }
         if (RELU) {
             o[i][0] = __builtin_elementwise_max(o[i][0], (f4)(0.0f));
             o[i][1] = __builtin_elementwise_max(o[i][1], (f4)(0.0f));
         }
     }
-    const int tj = (int)(t % TW);
-    const int ti = (int)((t / TW) % TH);
-    const int b = (int)(t / ((int64_t)TW * TH));
     if (POOL) {
         f4 v = __builtin_elementwise_max(__builtin_elementwise_max(o[0][0], o[0][1]),
                                          __builtin_elementwise_max(o[1][0], o[1][1]));
@@ -258,19 +263,20 @@ CSLAM_API int cslam_wino_input_dev(const float *d_x, int B, int H, int W, int C,
     return CSLAM_OK;
 }
 
-CSLAM_API int cslam_wino_output_dev(const float *d_M, const float *d_bias, int B, int H, int W, int C, int relu,
-                                    int pool, float *d_y, void *stream) {
+CSLAM_API int cslam_wino_output_dev(const float *d_M, const float *d_bias, const float *d_res, int B, int H, int W,
+                                    int C, int relu, int pool, float *d_y, void *stream) {
     ARG_CHECK(d_M && d_y, "NULL argument");
+    ARG_CHECK(!(d_res && pool), "a residual input cannot be combined with pooling");
     ARG_CHECK(B >= 1 && H >= 2 && W >= 2 && (H % 2) == 0 && (W % 2) == 0, "H and W must be even and >= 2");
     ARG_CHECK(C >= 4 && (C % 4) == 0, "C must be a multiple of 4");
     const int64_t n = (int64_t)B * (H / 2) * (W / 2) * (C / 4);
     ARG_CHECK(ceil_div64(n, 256) < (1LL << 31), "too many tiles for one launch");
     dim3 grid((unsigned)ceil_div64(n, 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (relu && pool) hipLaunchKernelGGL((wino_output_kernel<true, true>), grid, block, 0, st, d_M, d_bias, B, H, W, C, d_y);
-    else if (relu) hipLaunchKernelGGL((wino_output_kernel<true, false>), grid, block, 0, st, d_M, d_bias, B, H, W, C, d_y);
-    else if (pool) hipLaunchKernelGGL((wino_output_kernel<false, true>), grid, block, 0, st, d_M, d_bias, B, H, W, C, d_y);
-    else hipLaunchKernelGGL((wino_output_kernel<false, false>), grid, block, 0, st, d_M, d_bias, B, H, W, C, d_y);
+    if (relu && pool) hipLaunchKernelGGL((wino_output_kernel<true, true>), grid, block, 0, st, d_M, d_bias, d_res, B, H, W, C, d_y);
+    else if (relu) hipLaunchKernelGGL((wino_output_kernel<true, false>), grid, block, 0, st, d_M, d_bias, d_res, B, H, W, C, d_y);
+    else if (pool) hipLaunchKernelGGL((wino_output_kernel<false, true>), grid, block, 0, st, d_M, d_bias, d_res, B, H, W, C, d_y);
+    else hipLaunchKernelGGL((wino_output_kernel<false, false>), grid, block, 0, st, d_M, d_bias, d_res, B, H, W, C, d_y);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }
@@ -341,7 +347,8 @@ __device__ __forceinline__ void wino4_at(const f2 m0, const f2 m1, const f2 m2, 
 
 template <bool RELU, bool POOL>
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restrict__ M, const float *__restrict__ bias,
-                                                           int B, int H, int W, int C, float *__restrict__ y) {
+                                                           const float *__restrict__ res, int B, int H, int W, int C,
+                                                           float *__restrict__ y) {
     const int c2n = C >> 1;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int TH = H >> 2, TW = W >> 2;
@@ -360,6 +367,9 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restri
         wino4_at(m[0], m[1], m[2], m[3], m[4], m[5], s[0][j], s[1][j], s[2][j], s[3][j]);
     }
     const f2 bv = bias ? *((const f2 *)bias + c2) : (f2)(0.0f);
+    const int tj = (int)(t % TW);
+    const int ti = (int)((t / TW) % TH);
+    const int b = (int)(t / ((int64_t)TW * TH));
     f2 o[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -367,12 +377,10 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             o[i][j] += bv;
+            if (res) o[i][j] += *((const f2 *)(res + (((int64_t)b * H + 4 * ti + i) * W + 4 * tj + j) * C) + c2);
             if (RELU) o[i][j] = __builtin_elementwise_max(o[i][j], (f2)(0.0f));
         }
     }
-    const int tj = (int)(t % TW);
-    const int ti = (int)((t / TW) % TH);
-    const int b = (int)(t / ((int64_t)TW * TH));
     if (POOL) {
         const int Ho = H >> 1, Wo = W >> 1;
 #pragma unroll
@@ -404,19 +412,20 @@ CSLAM_API int cslam_wino4_input_dev(const float *d_x, int B, int H, int W, int C
     return CSLAM_OK;
 }
 
-CSLAM_API int cslam_wino4_output_dev(const float *d_M, const float *d_bias, int B, int H, int W, int C, int relu,
-                                     int pool, float *d_y, void *stream) {
+CSLAM_API int cslam_wino4_output_dev(const float *d_M, const float *d_bias, const float *d_res, int B, int H, int W,
+                                     int C, int relu, int pool, float *d_y, void *stream) {
     ARG_CHECK(d_M && d_y, "NULL argument");
+    ARG_CHECK(!(d_res && pool), "a residual input cannot be combined with pooling");
     ARG_CHECK(B >= 1 && H >= 4 && W >= 4 && (H % 4) == 0 && (W % 4) == 0, "H and W must be multiples of 4");
     ARG_CHECK(C >= 2 && (C % 2) == 0, "C must be even");
     const int64_t n = (int64_t)B * (H / 4) * (W / 4) * (C / 2);
     ARG_CHECK(ceil_div64(n, 256) < (1LL << 31), "too many tiles for one launch");
     dim3 grid((unsigned)ceil_div64(n, 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (relu && pool) hipLaunchKernelGGL((wino4_output_kernel<true, true>), grid, block, 0, st, d_M, d_bias, B, H, W, C, d_y);
-    else if (relu) hipLaunchKernelGGL((wino4_output_kernel<true, false>), grid, block, 0, st, d_M, d_bias, B, H, W, C, d_y);
-    else if (pool) hipLaunchKernelGGL((wino4_output_kernel<false, true>), grid, block, 0, st, d_M, d_bias, B, H, W, C, d_y);
-    else hipLaunchKernelGGL((wino4_output_kernel<false, false>), grid, block, 0, st, d_M, d_bias, B, H, W, C, d_y);
+    if (relu && pool) hipLaunchKernelGGL((wino4_output_kernel<true, true>), grid, block, 0, st, d_M, d_bias, d_res, B, H, W, C, d_y);
+    else if (relu) hipLaunchKernelGGL((wino4_output_kernel<true, false>), grid, block, 0, st, d_M, d_bias, d_res, B, H, W, C, d_y);
+    else if (pool) hipLaunchKernelGGL((wino4_output_kernel<false, true>), grid, block, 0, st, d_M, d_bias, d_res, B, H, W, C, d_y);
+    else hipLaunchKernelGGL((wino4_output_kernel<false, false>), grid, block, 0, st, d_M, d_bias, d_res, B, H, W, C, d_y);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }

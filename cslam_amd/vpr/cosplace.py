@@ -14,6 +14,7 @@ from torch import nn
 from .. import _lib
 from . import heads
 from .backbones import get_backbone
+from .winograd import WinogradResNet, WinogradTrunk
 from .netvlad import _share_dir
 
 IMAGENET_DEFAULT_MEAN = heads.IMAGENET_DEFAULT_MEAN
@@ -25,7 +26,12 @@ class GeoLocalizationNet(object):
     names of the reference checkpoint: 'backbone.*', 'aggregation.1.p' (GeM),
     'aggregation.3.weight|bias' (Linear)."""
 
-    def __init__(self, backbone, fc_output_dim, device):
+    def __init__(self, backbone, fc_output_dim, device, backbone_conv="winograd"):
+        self.backbone_name = backbone
+        # 'winograd' | 'winograd2' | 'direct': how the 3x3 / stride 1 convolutions run (vpr/winograd.py); the
+        # Winograd modes also fold every eval-mode BatchNorm into its convolution
+        self.backbone_conv = backbone_conv
+        self.runner = None
         self.backbone, self.features_dim = get_backbone(backbone)
         self.backbone = self.backbone.to(device).eval().to(memory_format=torch.channels_last)
         for p in self.backbone.parameters():
@@ -39,6 +45,7 @@ class GeoLocalizationNet(object):
     def load_state_dict(self, state):
         bb = {k[len("backbone."):]: v for k, v in state.items() if k.startswith("backbone.")}
         self.backbone.load_state_dict(bb)
+        self.runner = None                     # folded / transformed weights are rebuilt on the next forward
         self.gem_p = float(state["aggregation.1.p"].reshape(-1)[0])
         self.fc_weight = state["aggregation.3.weight"].float().to(self.device).contiguous()
         self.fc_bias = state["aggregation.3.bias"].float().to(self.device).contiguous()
@@ -49,6 +56,12 @@ class GeoLocalizationNet(object):
             with torch.autocast("cuda", dtype=backbone_dtype):
                 f = self.backbone(x)
             f = f.float()
+        elif self.backbone_conv in ("winograd", "winograd2"):
+            if self.runner is None:
+                tile = 4 if self.backbone_conv == "winograd" else 2
+                self.runner = (WinogradTrunk(self.backbone, 64, tile) if self.backbone_name == "vgg16"
+                               else WinogradResNet(self.backbone, 64, tile))
+            f = self.runner(x)
         else:
             f = self.backbone(x)
         return heads.gem_fc_head(f.contiguous(), self.gem_p, self.gem_eps, self.fc_weight, self.fc_bias)
@@ -69,8 +82,11 @@ class CosPlace(object):
             raise _lib.CslamHipError("CosPlace needs PyTorch-ROCm with a visible MI355X")
         self.device = torch.device("cuda")
         self.crop = int(self.params["frontend.image_crop_size"])
+        self.backbone_conv = str(self.params.get('frontend.backbone_conv', 'winograd')).lower()
+        if self.backbone_conv not in ('winograd', 'winograd2', 'direct'):
+            raise ValueError("frontend.backbone_conv must be 'winograd', 'winograd2' or 'direct'")
         self.model = GeoLocalizationNet(self.params['frontend.cosplace.backbone'], self.descriptor_dim,
-                                        self.device)
+                                        self.device, self.backbone_conv)
         ckpt = self.params['frontend.nn_checkpoint']
         if ckpt == 'random':               # benchmark / test mode: seeded random weights, no files
             self.random_init(int(self.params.get('frontend.random_seed', 0)))
@@ -99,6 +115,7 @@ class CosPlace(object):
             w = torch.randn((self.descriptor_dim, self.model.features_dim), generator=g) / self.model.features_dim ** 0.5
             self.model.fc_weight = w.to(self.device).contiguous()
             self.model.fc_bias = torch.zeros(self.descriptor_dim, device=self.device)
+        self.model.runner = None
 
     @torch.no_grad()
     def compute_embeddings_device(self, frames_u8, backbone_dtype=None):

@@ -43,7 +43,7 @@ def use_tuned_gemms():
     MI355X in `tunableop_gfx950.csv` (tuning itself stays off, unknown shapes keep the library default, and a
     library / architecture mismatch makes torch ignore the file).  +8 % frames/s over the default heuristic.
     Regenerate with `PYTORCH_TUNABLEOP_ENABLED=1 python tools/extract_leg.py`.  CSLAM_TUNED_GEMM=0 disables."""
-    if _TUNED["done"] or os.environ.get("CSLAM_TUNED_GEMM", "1") == "0":
+    if _TUNED["done"] or os.environ.get("CSLAM_TUNED_GEMM", "1") == "0" or not torch.cuda.is_available():
         return
     _TUNED["done"] = True
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tunableop_gfx950.csv")
@@ -59,6 +59,122 @@ def use_tuned_gemms():
         warnings.warn("cslam_amd: tuned GEMM table not loaded (%s)" % e)
 
 
+def wino_conv3x3(ws, x, U, U4, bias, relu, pool=False, residual=None):
+    """3x3 / stride 1 / pad 1 convolution of x [B,Cin,H,W] (channels_last storage, even H and W) through the
+    Winograd pipeline; U / U4 from `wino_weights` (U4 None = F(2x2,3x3) only).  bias [Cout] or None, residual
+    (channels_last, shaped like the output) is added before the ReLU.  `ws` owns the V / M workspaces."""
+    lib = _lib.load()
+    B, Cin, H, W = x.shape
+    Cout = U.shape[2]
+    # F(4x4) needs enough tiles to keep its 36 GEMMs efficient; single frames stay on F(2x2)
+    four = U4 is not None and H % 4 == 0 and W % 4 == 0 and B * (H // 4) * (W // 4) >= 512
+    n2, Uu = (36, U4) if four else (16, U)
+    T = B * (H // 4) * (W // 4) if four else B * (H // 2) * (W // 2)
+    V = ws._buf("V", n2 * T * Cin, x.device).view(n2, T, Cin)
+    M = ws._buf("M", n2 * T * Cout, x.device).view(n2, T, Cout)
+    s = _stream(x)
+    fin, fout = (lib.cslam_wino4_input_dev, lib.cslam_wino4_output_dev) if four else \
+        (lib.cslam_wino_input_dev, lib.cslam_wino_output_dev)
+    _lib.check(fin(_p(x), B, H, W, Cin, _p(V), s))                           # x's storage is NHWC
+    torch.bmm(V, Uu, out=M)
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    y = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if residual is not None:
+        residual = residual.contiguous(memory_format=torch.channels_last)
+        assert residual.shape == y.shape and not pool
+    _lib.check(fout(_p(M), _p(bias) if bias is not None else None, _p(residual) if residual is not None else None,
+                    B, H, W, Cout, int(relu), int(pool), _p(y), s))
+    return y
+
+
+class _Workspace(object):
+    def __init__(self):
+        self._ws = {}
+
+    def _buf(self, name, numel, device):
+        b = self._ws.get(name)
+        if b is None or b.numel() < numel or b.device != device:
+            b = torch.empty(numel, dtype=torch.float32, device=device)
+            self._ws[name] = b
+        return b[:numel]
+
+
+def fold_bn(conv, bn):
+    """Eval-mode BatchNorm folded into the preceding convolution: (weight * s[co], beta - mean * s (+ bias * s)),
+    s = gamma / sqrt(var + eps).  Exact in real arithmetic; computed in float64."""
+    s = (bn.weight.double() / torch.sqrt(bn.running_var.double() + bn.eps))
+    w = (conv.weight.double() * s[:, None, None, None]).float().contiguous(memory_format=torch.channels_last)
+    b = bn.bias.double() - bn.running_mean.double() * s
+    if conv.bias is not None:
+        b = b + conv.bias.double() * s
+    return w, b.float().contiguous()
+
+
+class _FoldedConv(object):
+    """conv + eval BatchNorm as one convolution; 3x3 / stride 1 / pad 1 ones also carry Winograd weights."""
+
+    def __init__(self, conv, bn, tile, min_in_channels):
+        self.weight, self.bias = fold_bn(conv, bn)
+        self.stride, self.padding = conv.stride, conv.padding
+        self.U = self.U4 = None
+        if (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+                and conv.groups == 1 and conv.in_channels >= min_in_channels and conv.in_channels % 4 == 0
+                and conv.out_channels % 4 == 0 and conv.weight.is_cuda):
+            self.U = wino_weights(self.weight).to(self.weight.device)
+            self.U4 = wino_weights(self.weight, 4).to(self.weight.device) if tile == 4 else None
+
+    def __call__(self, ws, x, relu, residual=None):
+        H, W = x.shape[2], x.shape[3]
+        if self.U is not None and H % 2 == 0 and W % 2 == 0 and H >= 2 and W >= 2:
+            return wino_conv3x3(ws, x.contiguous(memory_format=torch.channels_last), self.U, self.U4, self.bias, relu,
+                                False, residual)
+        y = torch.nn.functional.conv2d(x, self.weight, self.bias, self.stride, self.padding)
+        if residual is not None:
+            y += residual
+        return torch.relu_(y) if relu else y
+
+
+class WinogradResNet(_Workspace):
+    """Runs the ResNet trunks of vpr/backbones.py (`resnet_trunk`: conv1, bn1, relu, maxpool, layer1..4 of
+    BasicBlock / Bottleneck) like `trunk(x)` in eval mode, with every BatchNorm folded into its convolution and
+    the 3x3 / stride 1 convolutions on even maps executed through the Winograd pipeline (bias, shortcut add and
+    ReLU fused into the output transform).  Strided / 1x1 / 7x7 convolutions and odd maps go through torch."""
+
+    def __init__(self, trunk, min_in_channels=64, tile=4):
+        super().__init__()
+        self.trunk, self.min_in_channels, self.tile = trunk, int(min_in_channels), int(tile)
+        use_tuned_gemms()
+        self.refresh()
+
+    def refresh(self):
+        mods = list(self.trunk)
+        mk = lambda c, b: _FoldedConv(c, b, self.tile, self.min_in_channels)      # noqa: E731
+        self.stem = mk(mods[0], mods[1])
+        self.stem_pool = mods[3]
+        self.blocks = []
+        for layer in mods[4:]:
+            for blk in layer:
+                d = {"down": None if blk.downsample is None else mk(blk.downsample[0], blk.downsample[1]),
+                     "c1": mk(blk.conv1, blk.bn1), "c2": mk(blk.conv2, blk.bn2),
+                     "c3": mk(blk.conv3, blk.bn3) if hasattr(blk, "conv3") else None}
+                self.blocks.append(d)
+        return self
+
+    @torch.no_grad()
+    def __call__(self, x):
+        x = x.contiguous(memory_format=torch.channels_last)
+        x = self.stem_pool(self.stem(self, x, True))
+        for b in self.blocks:
+            idt = x if b["down"] is None else b["down"](self, x, False)
+            o = b["c1"](self, x, True)
+            if b["c3"] is None:                       # BasicBlock
+                x = b["c2"](self, o, True, idt)
+            else:                                     # Bottleneck
+                o = b["c2"](self, o, True)
+                x = b["c3"](self, o, True, idt)
+        return x
+
+
 class _Step(object):
     __slots__ = ("kind", "module", "conv", "relu", "pool", "U", "U4", "bias")
 
@@ -67,18 +183,18 @@ class _Step(object):
         self.U, self.U4, self.bias = None, None, None
 
 
-class WinogradTrunk(object):
+class WinogradTrunk(_Workspace):
     """Runs an nn.Sequential of Conv2d / ReLU / MaxPool2d like `encoder(x)`, with the eligible
     convolutions (+ their ReLU, + their MaxPool2d(2,2)) replaced by the Winograd pipeline."""
 
     def __init__(self, encoder, min_in_channels=256, tile=2):
         """tile = 2: F(2x2,3x3) everywhere; tile = 4: F(4x4,3x3) on the maps whose sides are multiples of 4
         (F(2x2,3x3) on the others)."""
+        super().__init__()
         self.encoder = encoder
         self.min_in_channels = int(min_in_channels)
         self.tile = int(tile)
         use_tuned_gemms()
-        self._ws = {}
         self.refresh()
 
     def refresh(self):
@@ -135,13 +251,6 @@ class WinogradTrunk(object):
             self.steps.append(st)
         return self
 
-    def _buf(self, name, numel, device):
-        b = self._ws.get(name)
-        if b is None or b.numel() < numel or b.device != device:
-            b = torch.empty(numel, dtype=torch.float32, device=device)
-            self._ws[name] = b
-        return b[:numel]
-
     @torch.no_grad()
     def __call__(self, x):
         """x [B,C,H,W] float32 (any memory format) -> [B,C',H',W'] float32, channels_last memory."""
@@ -180,22 +289,6 @@ class WinogradTrunk(object):
                     x = torch.nn.functional.max_pool2d(x, 2, 2)
                 continue
             x = x.contiguous(memory_format=torch.channels_last)
-            Cout = st.conv.out_channels
-            # F(4x4) needs enough tiles to keep its 36 GEMMs efficient; single frames stay on F(2x2)
-            four = st.U4 is not None and H % 4 == 0 and W % 4 == 0 and B * (H // 4) * (W // 4) >= 512
-            n2, U = (36, st.U4) if four else (16, st.U)
-            T = B * (H // 4) * (W // 4) if four else B * (H // 2) * (W // 2)
-            V = self._buf("V", n2 * T * Cin, x.device).view(n2, T, Cin)
-            M = self._buf("M", n2 * T * Cout, x.device).view(n2, T, Cout)
-            s = _stream(x)
-            fin, fout = (lib.cslam_wino4_input_dev, lib.cslam_wino4_output_dev) if four else \
-                (lib.cslam_wino_input_dev, lib.cslam_wino_output_dev)
-            _lib.check(fin(_p(x), B, H, W, Cin, _p(V), s))                           # x's storage is NHWC
-            torch.bmm(V, U, out=M)
-            Ho, Wo = (H // 2, W // 2) if st.pool else (H, W)
-            y = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device,
-                            memory_format=torch.channels_last)
-            _lib.check(fout(_p(M), _p(st.bias) if st.bias is not None else None, B, H, W, Cout,
-                            int(st.relu), int(st.pool), _p(y), s))
+            y = wino_conv3x3(self, x, st.U, st.U4, st.bias, st.relu, st.pool)
             x = y
         return x

@@ -225,7 +225,9 @@ int cslam_scancontext_from_cloud_dev(const double *d_points, const int64_t *d_of
  * U[xi][ci][co] = (G g G^T)[xi]; the 16 GEMMs V[xi] (T x C) . U[xi] (C x Cout) are plain library GEMMs.
  *   input : x [B,H,W,C] -> V [16, T, C], T = B*(H/2)*(W/2); H, W even, C % 4 == 0
  *   output: M [16, T, C] -> y [B,H,W,C], or [B,H/2,W/2,C] when pool != 0 (the MaxPool2d(2,2) that follows
- *           the layer fused in); bias [C] or NULL; relu != 0 applies max(., 0) before the pooling. */
+ *           the layer fused in); bias [C] or NULL; residual (NULL, or an NHWC tensor shaped like y, pool == 0:
+ *           the shortcut of a ResNet block, cosplace_utils/network.py:39-56) is added before the activation;
+ *           relu != 0 applies max(., 0) before the pooling. */
 /* bias + ReLU (+ MaxPool2d(2,2)) in one pass over an NHWC activation, for the layers left on the direct
  * convolution: y = pool(relu(x + bias)).  Without pooling y may be x (in place); with pooling y is
  * [B,H/2,W/2,C]. */
@@ -237,13 +239,13 @@ int cslam_bias_act_pool_dev(const float *d_x, const float *d_bias, int B, int H,
 int cslam_conv3x3_c3_dev(const float *d_x, const float *d_wt, const float *d_bias, int B, int H, int W,
                          int Cout, int relu, float *d_y, void *stream);
 int cslam_wino_input_dev(const float *d_x, int B, int H, int W, int C, float *d_V, void *stream);
-int cslam_wino_output_dev(const float *d_M, const float *d_bias, int B, int H, int W, int C, int relu,
-                          int pool, float *d_y, void *stream);
+int cslam_wino_output_dev(const float *d_M, const float *d_bias, const float *d_residual, int B, int H, int W,
+                          int C, int relu, int pool, float *d_y, void *stream);
 /* F(4x4, 3x3) variant: 6x6 input tiles, V / M [36, T, C] with T = B*(H/4)*(W/4); H, W multiples of 4, C even.
  * 4x fewer multiplications than the direct form, about one decimal digit less accurate than F(2x2, 3x3). */
 int cslam_wino4_input_dev(const float *d_x, int B, int H, int W, int C, float *d_V, void *stream);
-int cslam_wino4_output_dev(const float *d_M, const float *d_bias, int B, int H, int W, int C, int relu,
-                           int pool, float *d_y, void *stream);
+int cslam_wino4_output_dev(const float *d_M, const float *d_bias, const float *d_residual, int B, int H, int W,
+                           int C, int relu, int pool, float *d_y, void *stream);
 
 #ifdef __cplusplus
 }

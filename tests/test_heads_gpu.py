@@ -247,3 +247,49 @@ def test_first_layer_conv_c3_matches_float64(T):
             ref = seq.double()(x.double())
         seq.float()
         assert y.shape == ref.shape and (y.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("name,B,hw", [("resnet18", 24, 224), ("resnet18", 2, 96), ("resnet50", 8, 224)])
+def test_winograd_resnet_equals_torch_trunk(T, name, B, hw):
+    """BatchNorm folding + Winograd 3x3 + fused shortcut/ReLU == the torch eval trunk, both judged against float64."""
+    torch, _ = T
+    from torch import nn
+    from cslam_amd.vpr.backbones import resnet_trunk
+    from cslam_amd.vpr.winograd import WinogradResNet
+    torch.manual_seed(17)
+    trunk = resnet_trunk(name).cuda().eval()
+    with torch.no_grad():
+        for m in trunk.modules():
+            if isinstance(m, nn.BatchNorm2d):                      # non-trivial statistics to fold
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.6, 1.2)
+                m.bias.normal_(0, 0.1)
+    x = torch.randn((B, 3, hw, hw), device="cuda")
+    with torch.no_grad():
+        r = trunk.double()(x.double())
+        trunk.float()
+        a = trunk(x.contiguous(memory_format=torch.channels_last))
+    for tile in (4, 2):
+        run = WinogradResNet(trunk, 64, tile)
+        assert any(b["c1"].U is not None or b["c2"].U is not None for b in run.blocks)
+        b = run(x)
+        assert b.shape == r.shape
+        scale = r.abs().max().item()
+        e_direct = (a.double() - r).abs().max().item() / scale
+        e_wino = (b.double() - r).abs().max().item() / scale
+        assert e_wino <= 2e-5 and e_wino <= 6 * e_direct + 1e-6, (tile, e_wino, e_direct)
+
+
+def test_cosplace_descriptors_winograd_vs_direct(T):
+    torch, _ = T
+    from cslam_amd.vpr.cosplace import CosPlace
+    frames = torch.from_numpy(np.random.default_rng(6).integers(0, 256, size=(4, 480, 640, 3), dtype=np.uint8)).cuda()
+    frames = frames.repeat(8, 1, 1, 1)
+    base = {"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376, "frontend.cosplace.descriptor_dim": 512}
+    for bb in ("resnet18", "vgg16"):
+        p = dict(base, **{"frontend.cosplace.backbone": bb})
+        d = CosPlace(dict(p, **{"frontend.backbone_conv": "direct"}), None).compute_embeddings_device(frames)
+        for mode in ("winograd", "winograd2"):
+            w = CosPlace(dict(p, **{"frontend.backbone_conv": mode}), None).compute_embeddings_device(frames)
+            assert (w - d).abs().max().item() <= 1e-5, (bb, mode)

@@ -1,6 +1,6 @@
 """BASELINE config 2 on one GPU: CosPlace ResNet-18 512-D extract of 10k synthetic 640x480 keyframes +
 causal intra-robot NNS (top-5 of every keyframe among the EARLIER keyframes) over the growing bank.
-python tools/perf_c2.py [frames] [chunk]"""
+python tools/perf_c2.py [frames] [chunk] [winograd|winograd2|direct]"""
 import sys, time
 import torch
 sys.path.insert(0, ".")
@@ -9,9 +9,11 @@ from cslam_amd.vpr.cosplace import CosPlace
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000
 CH = int(sys.argv[2]) if len(sys.argv) > 2 else 250
+MODE = sys.argv[3] if len(sys.argv) > 3 else "winograd"
 torch.backends.cudnn.benchmark = True
 cp = CosPlace({"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376,
-               "frontend.cosplace.descriptor_dim": 512, "frontend.cosplace.backbone": "resnet18"}, None)
+               "frontend.cosplace.descriptor_dim": 512, "frontend.cosplace.backbone": "resnet18",
+               "frontend.backbone_conv": MODE}, None)
 g = torch.Generator(device="cuda").manual_seed(7)
 frames = torch.randint(0, 256, (CH, 480, 640, 3), generator=g, device="cuda", dtype=torch.uint8)
 cp.compute_embeddings_device(frames); torch.cuda.synchronize()          # warm-up (MIOpen find)
@@ -29,5 +31,5 @@ while done < N:
     c = time.perf_counter()
     te += b - a; tm += c - b; done += m
 dt = time.perf_counter() - t0
-print(f"C2: {N} keyframes, chunk {CH}: extract+match {N/dt:.0f} keyframes/s (extract {N/te:.0f}/s, causal match {N/tm:.0f}/s), "
+print(f"C2 [{MODE}]: {N} keyframes, chunk {CH}: extract+match {N/dt:.0f} keyframes/s (extract {N/te:.0f}/s, causal match {N/tm:.0f}/s), "
       f"bank rows {nn.n}, last chunk cnt min {int(cnt.min())}")
