@@ -592,7 +592,10 @@ struct PreprocCache {
     int device, crop, out_hw, ksize, max_rows;
     int *d_bounds, *d_kk;
 };
-static PreprocCache g_pp = {-1, 0, 0, 0, 0, nullptr, nullptr};
+// Coefficient tables per (device, crop, output size).  Entries are never freed or moved once built: the online
+// path captures this launch in a hipGraph, and a table pointer baked into a graph must stay valid when another
+// extractor with a different crop is used in between.
+static std::vector<PreprocCache *> g_pp_all;
 
 CSLAM_API int cslam_preprocess_dev(const uint8_t *d_img, int B, int H, int W, int crop, int out_hw,
                                    const float mean[3], const float std_[3], float *d_out, void *stream) {
@@ -603,7 +606,10 @@ CSLAM_API int cslam_preprocess_dev(const uint8_t *d_img, int B, int H, int W, in
     hipStream_t st = (hipStream_t)stream;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    if (g_pp.device != dev || g_pp.crop != crop || g_pp.out_hw != out_hw) {
+    PreprocCache *pp = nullptr;
+    for (PreprocCache *c : g_pp_all)
+        if (c->device == dev && c->crop == crop && c->out_hw == out_hw) pp = c;
+    if (!pp) {
         std::vector<int> bounds, kk;
         int ksize = precompute_coeffs(crop, 0.0, (double)crop, out_hw, bounds, kk);
         int max_rows = 0;
@@ -612,13 +618,14 @@ CSLAM_API int cslam_preprocess_dev(const uint8_t *d_img, int B, int H, int W, in
             int span = bounds[yl * 2] + bounds[yl * 2 + 1] - bounds[y0 * 2];
             if (span > max_rows) max_rows = span;
         }
-        if (g_pp.d_bounds) { (void)hipFree(g_pp.d_bounds); (void)hipFree(g_pp.d_kk); }
-        HIP_TRY(hipMalloc((void **)&g_pp.d_bounds, bounds.size() * 4));
-        HIP_TRY(hipMalloc((void **)&g_pp.d_kk, kk.size() * 4));
-        HIP_TRY(hipMemcpy(g_pp.d_bounds, bounds.data(), bounds.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(g_pp.d_kk, kk.data(), kk.size() * 4, hipMemcpyHostToDevice));
-        g_pp.device = dev; g_pp.crop = crop; g_pp.out_hw = out_hw; g_pp.ksize = ksize; g_pp.max_rows = max_rows;
+        pp = new PreprocCache{dev, crop, out_hw, ksize, max_rows, nullptr, nullptr};
+        HIP_TRY(hipMalloc((void **)&pp->d_bounds, bounds.size() * 4));
+        HIP_TRY(hipMalloc((void **)&pp->d_kk, kk.size() * 4));
+        HIP_TRY(hipMemcpy(pp->d_bounds, bounds.data(), bounds.size() * 4, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(pp->d_kk, kk.data(), kk.size() * 4, hipMemcpyHostToDevice));
+        g_pp_all.push_back(pp);
     }
+    const PreprocCache &g_pp = *pp;
     const size_t in_row_bytes = ((size_t)crop * 3 + 3) & ~(size_t)3;
     const size_t lds = (size_t)out_hw * 2 * 4 + (size_t)out_hw * g_pp.ksize * 4 +
                        (size_t)g_pp.max_rows * (in_row_bytes + (size_t)out_hw * 3);

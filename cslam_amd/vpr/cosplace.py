@@ -32,6 +32,7 @@ class GeoLocalizationNet(object):
         # Winograd modes also fold every eval-mode BatchNorm into its convolution
         self.backbone_conv = backbone_conv
         self.runner = None
+        self._epoch = object()
         self.backbone, self.features_dim = get_backbone(backbone)
         self.backbone = self.backbone.to(device).eval().to(memory_format=torch.channels_last)
         for p in self.backbone.parameters():
@@ -46,22 +47,32 @@ class GeoLocalizationNet(object):
         bb = {k[len("backbone."):]: v for k, v in state.items() if k.startswith("backbone.")}
         self.backbone.load_state_dict(bb)
         self.runner = None                     # folded / transformed weights are rebuilt on the next forward
+        self._epoch = object()
         self.gem_p = float(state["aggregation.1.p"].reshape(-1)[0])
         self.fc_weight = state["aggregation.3.weight"].float().to(self.device).contiguous()
         self.fc_bias = state["aggregation.3.bias"].float().to(self.device).contiguous()
 
+    def runner_epoch(self):
+        """Changes whenever the weights were reloaded (a captured graph of the old weights is then stale)."""
+        return self._epoch
+
+    def make_runner(self):
+        tile = 4 if self.backbone_conv == "winograd" else 2
+        return (WinogradTrunk(self.backbone, 64, tile) if self.backbone_name == "vgg16"
+                else WinogradResNet(self.backbone, 64, tile))
+
     @torch.no_grad()
-    def forward(self, x, backbone_dtype=None):
+    def forward(self, x, backbone_dtype=None, runner=None):
         if backbone_dtype is not None and backbone_dtype != torch.float32:
             with torch.autocast("cuda", dtype=backbone_dtype):
                 f = self.backbone(x)
             f = f.float()
         elif self.backbone_conv in ("winograd", "winograd2"):
-            if self.runner is None:
-                tile = 4 if self.backbone_conv == "winograd" else 2
-                self.runner = (WinogradTrunk(self.backbone, 64, tile) if self.backbone_name == "vgg16"
-                               else WinogradResNet(self.backbone, 64, tile))
-            f = self.runner(x)
+            if runner is None:
+                if self.runner is None:
+                    self.runner = self.make_runner()
+                runner = self.runner
+            f = runner(x)
         else:
             f = self.backbone(x)
         return heads.gem_fc_head(f.contiguous(), self.gem_p, self.gem_eps, self.fc_weight, self.fc_bias)
@@ -87,6 +98,13 @@ class CosPlace(object):
             raise ValueError("frontend.backbone_conv must be 'winograd', 'winograd2' or 'direct'")
         self.model = GeoLocalizationNet(self.params['frontend.cosplace.backbone'], self.descriptor_dim,
                                         self.device, self.backbone_conv)
+        # frontend.hip_graph: true replays one-keyframe calls from a captured HIP graph of the whole pipeline.
+        # Off by default: on ROCm 7.2 replaying the ~45-node graph takes 6.2 ms against 1.2 ms for launching the
+        # same kernels one by one (tools/perf_online.py), so plain launches are the faster online path today.
+        self.use_graph = bool(self.params.get('frontend.hip_graph', False))
+        self._online = None
+        self._online_runner = None
+        self._online_model = None
         ckpt = self.params['frontend.nn_checkpoint']
         if ckpt == 'random':               # benchmark / test mode: seeded random weights, no files
             self.random_init(int(self.params.get('frontend.random_seed', 0)))
@@ -116,16 +134,28 @@ class CosPlace(object):
             self.model.fc_weight = w.to(self.device).contiguous()
             self.model.fc_bias = torch.zeros(self.descriptor_dim, device=self.device)
         self.model.runner = None
+        self.model._epoch = object()
 
     @torch.no_grad()
-    def compute_embeddings_device(self, frames_u8, backbone_dtype=None):
+    def compute_embeddings_device(self, frames_u8, backbone_dtype=None, _runner=None):
         """frames [B,H,W,3] uint8 (device) -> descriptors [B, d] float32 (device)."""
         x = heads.preprocess(frames_u8.contiguous(), self.crop).contiguous(memory_format=torch.channels_last)
-        return self.model.forward(x, backbone_dtype)
+        return self.model.forward(x, backbone_dtype, _runner)
 
     def compute_embedding(self, keyframe):
         """Global image descriptor of one RGB keyframe (reference cosplace.py:81-105)."""
         if not self.enable:
             return np.random.rand(self.descriptor_dim)
-        frame = torch.from_numpy(np.ascontiguousarray(keyframe)).to(self.device).unsqueeze(0)
+        keyframe = np.ascontiguousarray(keyframe)
+        if self.use_graph and keyframe.dtype == np.uint8 and keyframe.ndim == 3:
+            if self._online is None or self._online_model is not self.model.runner_epoch():
+                # the graph owns its trunk runner: its workspaces must never move under a captured pointer
+                self._online_runner = self.model.make_runner() if self.backbone_conv != 'direct' else None
+                self._online = heads.OnlineGraph(
+                    lambda fr: self.compute_embeddings_device(fr, _runner=self._online_runner), self.device)
+                self._online_model = self.model.runner_epoch()
+            e = self._online(keyframe)
+            if e is not None:
+                return e
+        frame = torch.from_numpy(keyframe).to(self.device).unsqueeze(0)
         return self.compute_embeddings_device(frame)[0].cpu().numpy()

@@ -89,3 +89,56 @@ def l2_normalize_(x, eps=1e-12, zero_norm_to_one=False):
     _lib.check(_lib.load().cslam_l2_normalize_dev(_p(x), x.shape[0], x.shape[1], x.stride(0), float(eps),
                                                   int(zero_norm_to_one), _stream(x)))
     return x
+
+
+class OnlineGraph(object):
+    """The one-keyframe pipeline (H2D of the frame excluded) captured once per frame shape in a HIP graph and
+    replayed: the online path is ~45 small launches per keyframe, launch-bound when issued one by one.
+    `fn(frames_u8 [1,H,W,3] device) -> [1,d] device` must only launch on the current stream and keep every
+    buffer it touches alive and in place (dedicated workspaces; the C side never frees what a graph may hold).
+    Any capture failure disables the graph for good and the caller falls back to plain launches of the same
+    kernels."""
+
+    def __init__(self, fn, device):
+        self.fn, self.device = fn, device
+        self.entries = {}
+        self.failed = False
+
+    def _capture(self, shape):
+        inp = torch.empty((1,) + tuple(shape), dtype=torch.uint8, device=self.device)
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            for _ in range(2):                       # lazy initialisation, workspace growth, library handles
+                self.fn(inp)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = self.fn(inp)
+        pin_in = torch.empty(tuple(shape), dtype=torch.uint8).pin_memory()
+        pin_out = torch.empty(tuple(out.shape), dtype=out.dtype).pin_memory()
+        return graph, inp, out, pin_in, pin_out
+
+    def __call__(self, frame):
+        """frame: numpy uint8 [H,W,3] -> numpy [d], or None when graphs are unavailable."""
+        if self.failed:
+            return None
+        key = tuple(frame.shape)
+        try:
+            ent = self.entries.get(key)
+            if ent is None:
+                ent = self.entries[key] = self._capture(key)
+            graph, inp, out, pin_in, pin_out = ent
+            pin_in.copy_(torch.from_numpy(frame))
+            inp[0].copy_(pin_in, non_blocking=True)
+            graph.replay()
+            pin_out.copy_(out, non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()
+            return pin_out[0].numpy().copy()
+        except Exception as e:                        # noqa: BLE001 - capture support varies; same kernels either way
+            import warnings
+            warnings.warn("cslam_amd: HIP graph capture of the online path failed (%s); using plain launches" % e)
+            self.failed = True
+            self.entries.clear()
+            return None

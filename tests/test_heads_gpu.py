@@ -91,6 +91,16 @@ def test_pca_gemm_full_shape_split_k(T):
     assert float((y[:8].double() - ref).abs().max()) < 1e-5
     yb = heads.pca_project(x[122:].contiguous(), comp, None, None)        # batch-size independence
     assert float((yb - y[122:]).abs().max()) < 1e-6
+    for b in (1, 2, 3, 4):                                                # small batches: the GEMV kernel
+        ys = heads.pca_project(x[:b].contiguous(), comp, None, None)
+        assert float((ys.double() - ref[:b]).abs().max()) < 1e-5
+        assert float((ys - y[:b]).abs().max()) < 1e-6
+    xs = torch.randn((3, 288), generator=gen, device="cuda")              # Din not a multiple of the 256-float stride
+    cs = torch.randn((50, 288), generator=gen, device="cuda")
+    mp = torch.randn(50, generator=gen, device="cuda")
+    rs = xs.double() @ cs.double().T - mp.double()
+    rs = rs / rs.norm(dim=1, keepdim=True)
+    assert float((heads.pca_project(xs, cs, mp, None).double() - rs).abs().max()) < 1e-5
 
 
 def test_l2_normalize_variants(T):
@@ -293,3 +303,28 @@ def test_cosplace_descriptors_winograd_vs_direct(T):
         for mode in ("winograd", "winograd2"):
             w = CosPlace(dict(p, **{"frontend.backbone_conv": mode}), None).compute_embeddings_device(frames)
             assert (w - d).abs().max().item() <= 1e-5, (bb, mode)
+
+
+def test_online_hip_graph_replay_equals_plain_launches(T):
+    """With frontend.hip_graph compute_embedding (one keyframe) replays a captured HIP graph; it must return what the
+    same kernels give when launched one by one (the library GEMMs may pick another solution under capture, hence
+    1e-6 rather than bit equality), also after batched calls grew the shared workspaces in between."""
+    torch, _ = T
+    from cslam_amd.vpr.netvlad import NetVLAD
+    from cslam_amd.vpr.cosplace import CosPlace
+    rng = np.random.default_rng(8)
+    frames = rng.integers(0, 256, size=(3, 480, 640, 3), dtype=np.uint8)
+    small = rng.integers(0, 256, size=(400, 500, 3), dtype=np.uint8)         # a second frame shape -> second graph
+    base = {"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376, "frontend.netvlad.pca_dim": 256,
+            "frontend.cosplace.descriptor_dim": 128, "frontend.cosplace.backbone": "resnet18"}
+    for cls in (NetVLAD, CosPlace):
+        g = cls(dict(base, **{"frontend.hip_graph": True}), None)
+        p = cls(dict(base), None)
+        assert g.use_graph and not p.use_graph
+        for rnd in range(2):
+            for f in (frames[0], frames[1], small, frames[2]):
+                a, b = g.compute_embedding(f), p.compute_embedding(f)
+                assert a.dtype == np.float32 and a.shape == b.shape and np.abs(a - b).max() <= 1e-6, (cls.__name__, rnd)
+            big = torch.from_numpy(np.repeat(frames, 11, axis=0)).cuda()     # 33 frames: grows V / M / split-K buffers
+            g.compute_embeddings_device(big)
+        assert g._online is not None and not g._online.failed and len(g._online.entries) == 2, cls.__name__

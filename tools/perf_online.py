@@ -43,19 +43,24 @@ def main():
               "frontend.cosplace.descriptor_dim": 512, "frontend.cosplace.backbone": "resnet18"}
     nv = NetVLAD(params, None)
     t_all = timeit(lambda: nv.compute_embedding(frame), a.iters, sync)
+    nvg = NetVLAD(dict(params, **{"frontend.hip_graph": True}), None)
+    t_graph = timeit(lambda: nvg.compute_embedding(frame), a.iters, sync)
     dframe = torch.from_numpy(frame).cuda().unsqueeze(0)
     t_h2d = timeit(lambda: torch.from_numpy(frame).cuda(), a.iters, sync)
     t_pre = timeit(lambda: heads.preprocess(dframe, 376), a.iters, sync)
-    x = heads.preprocess(dframe, 376).contiguous(memory_format=torch.channels_last)
+    x = heads.preprocess(dframe, 376)
     with torch.no_grad():
-        t_enc = timeit(lambda: nv.encoder(x), a.iters, sync)
+        from cslam_amd.vpr.winograd import WinogradTrunk
+        wt = WinogradTrunk(nv.encoder, 64, 2)
+        t_enc = timeit(lambda: wt(x), a.iters, sync)
         f = nv.encoder(x)
         t_vlad = timeit(lambda: nv.pool(f), a.iters, sync)
         v = nv.pool(f)
         t_pca = timeit(lambda: heads.pca_project(v, nv.pca_components, nv.pca_mean_proj, nv.pca_inv_scale), a.iters, sync)
     print(f"NetVLAD compute_embedding B=1: {t_all * 1e3:.3f} ms/keyframe  "
           f"[H2D {t_h2d * 1e6:.0f} us | preprocess {t_pre * 1e6:.0f} us | VGG-16 {t_enc * 1e6:.0f} us | "
-          f"VLAD {t_vlad * 1e6:.0f} us | PCA {t_pca * 1e6:.0f} us]")
+          f"VLAD {t_vlad * 1e6:.0f} us | PCA {t_pca * 1e6:.0f} us]; same pipeline replayed from a captured HIP graph "
+          f"(frontend.hip_graph): {t_graph * 1e3:.3f} ms")
     cp = CosPlace(params, None)
     t_cp = timeit(lambda: cp.compute_embedding(frame), a.iters, sync)
     print(f"CosPlace (ResNet-18, 512-D) compute_embedding B=1: {t_cp * 1e3:.3f} ms/keyframe")
