@@ -351,6 +351,160 @@ __global__ __launch_bounds__(512) void vlad_fast_kernel(const float *__restrict_
     }
 }
 
+// ---- small batches (the online path: one keyframe per call) ----------------------------------------------
+// vlad_fast_kernel keeps one image in one workgroup, which is the right shape for a batch (256 images fill the chip)
+// but leaves 255 CUs idle for a single keyframe (272 us, latency of 32 dependent slab steps).  For B <= 8 the same
+// arithmetic is split three ways: (1) soft-assignment per 16-pixel tile, (2) residual aggregation per 32-channel
+// slab, (3) the two normalisations per cluster.  Partial sums cross kernels through a small scratch buffer and
+// are always added in a fixed order (deterministic).  netvlad.py:94-130.
+#define VS_PT 16
+__global__ __launch_bounds__(256) void vlad_wt_kernel(const float *__restrict__ W, int C, float *__restrict__ Wt) {
+    const int e = blockIdx.x * 256 + threadIdx.x;          // Wt[c][k] = W[k][c]
+    if (e < C * VK) Wt[e] = W[(size_t)(e & (VK - 1)) * C + (e >> 6)];
+}
+
+__global__ __launch_bounds__(256) void vlad_assign_kernel(const float *__restrict__ feat, const float *__restrict__ Wt,
+                                                          const float *__restrict__ bias, int C, int P, int ntile,
+                                                          float *__restrict__ a_out, float *__restrict__ asum_part) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *xs = sm;                          // [C][VS_PT]
+    float *part = xs + (size_t)C * VS_PT;    // [16][VS_PT] partial sums of squares
+    float *lg = part + 16 * VS_PT;           // [VS_PT][VK]
+    float *invn = lg + VS_PT * VK;           // [VS_PT]
+    const int b = blockIdx.y, tile = blockIdx.x, p0 = tile * VS_PT, tid = threadIdx.x;
+    const float *x = feat + (size_t)b * C * P;
+    for (int e = tid; e < C * VS_PT; e += 256) {
+        const int c = e >> 4, pp = e & 15;
+        xs[e] = (p0 + pp < P) ? x[(size_t)c * P + p0 + pp] : 0.0f;
+    }
+    __syncthreads();
+    {
+        const int pp = tid & 15, cp = tid >> 4;
+        float s = 0.0f;
+        for (int c = cp; c < C; c += 16) { float v = xs[c * VS_PT + pp]; s += v * v; }
+        part[cp * VS_PT + pp] = s;
+    }
+    const int k = tid & 63, pg = tid >> 6;   // wave pg owns pixels 4pg..4pg+3: xs reads are wave broadcasts
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll 8
+    for (int c = 0; c < C; ++c) {
+        const float w = Wt[(size_t)c * VK + k];
+        const float4 xv = *(const float4 *)(xs + c * VS_PT + pg * 4);
+        a0 += w * xv.x; a1 += w * xv.y; a2 += w * xv.z; a3 += w * xv.w;
+    }
+    lg[(pg * 4 + 0) * VK + k] = a0; lg[(pg * 4 + 1) * VK + k] = a1;
+    lg[(pg * 4 + 2) * VK + k] = a2; lg[(pg * 4 + 3) * VK + k] = a3;
+    __syncthreads();
+    if (tid < VS_PT) {
+        float ss = 0.0f;
+        for (int cp = 0; cp < 16; ++cp) ss += part[cp * VS_PT + tid];
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);            // F.normalize(dim=1), netvlad.py:105-106
+        float mx = -INFINITY;
+        for (int kk = 0; kk < VK; ++kk) {
+            float v = lg[tid * VK + kk] * inv + (bias ? bias[kk] : 0.0f);
+            lg[tid * VK + kk] = v;
+            mx = fmaxf(mx, v);
+        }
+        float se = 0.0f;
+        for (int kk = 0; kk < VK; ++kk) { float v = expf(lg[tid * VK + kk] - mx); lg[tid * VK + kk] = v; se += v; }
+        const float rs = 1.0f / se;
+        for (int kk = 0; kk < VK; ++kk) lg[tid * VK + kk] *= rs;      // softmax, netvlad.py:109-110
+        invn[tid] = inv;
+    }
+    __syncthreads();
+    if (tid < VK) {
+        float s = 0.0f;
+        for (int pp = 0; pp < VS_PT; ++pp)
+            if (p0 + pp < P) s += lg[pp * VK + tid];
+        asum_part[((size_t)b * ntile + tile) * VK + tid] = s;
+    }
+    for (int e = tid; e < VS_PT * VK; e += 256) {
+        const int pp = e >> 6;
+        if (p0 + pp < P) a_out[((size_t)b * P + p0 + pp) * VK + (e & 63)] = lg[e] * invn[pp];   // a' = a / ||x_p||
+    }
+}
+
+// grid (nslab, B), 512 threads: thread = (channel in slab, group of 4 clusters), as in sweep 2 of vlad_fast_kernel
+__global__ __launch_bounds__(512) void vlad_slab_kernel(const float *__restrict__ feat, const float *__restrict__ a_in,
+                                                        const float *__restrict__ asum_part, int ntile,
+                                                        const float *__restrict__ cent, int C, int P, int nslab,
+                                                        float *__restrict__ out, int64_t ldo, float *__restrict__ ss_part) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *a_lds = sm;                              // [P][VK]
+    float *xs = a_lds + (size_t)VL_PMAX * VK;       // [VL_CC][VL_PPAD]
+    float *asum = xs + VL_CC * VL_PPAD;             // [VK]
+    const int sl = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const float *x = feat + ((size_t)b * C + (size_t)sl * VL_CC) * P;
+    for (int e = tid; e < P * VK; e += 512) a_lds[e] = a_in[(size_t)b * P * VK + e];
+    const int nch = (C - sl * VL_CC) < VL_CC ? (C - sl * VL_CC) : VL_CC;
+    for (int e = tid; e < VL_CC * P; e += 512) {
+        const int cc = e / P, pp = e - cc * P;
+        xs[cc * VL_PPAD + pp] = cc < nch ? x[e] : 0.0f;
+    }
+    if (tid < VK) {
+        float s = 0.0f;
+        for (int t = 0; t < ntile; ++t) s += asum_part[((size_t)b * ntile + t) * VK + tid];
+        asum[tid] = s;
+    }
+    __syncthreads();
+    const int cl = tid & 31, k0 = (tid >> 5) * 4;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    const float *xr = xs + cl * VL_PPAD;
+#pragma unroll 4
+    for (int pp = 0; pp < P; ++pp) {
+        const float xv = xr[pp];
+        const float4 a4 = *(const float4 *)(a_lds + pp * VK + k0);
+        a0 += a4.x * xv; a1 += a4.y * xv; a2 += a4.z * xv; a3 += a4.w * xv;
+    }
+    const int c = sl * VL_CC + cl;
+    float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (c < C) {
+        // V[k,c] = sum_p a[k,p] (x[c,p]/||x_p|| - cent[k,c])   (netvlad.py:115-124)
+        v[0] = a0 - asum[k0 + 0] * cent[(size_t)(k0 + 0) * C + c];
+        v[1] = a1 - asum[k0 + 1] * cent[(size_t)(k0 + 1) * C + c];
+        v[2] = a2 - asum[k0 + 2] * cent[(size_t)(k0 + 2) * C + c];
+        v[3] = a3 - asum[k0 + 3] * cent[(size_t)(k0 + 3) * C + c];
+        float *o = out + (size_t)b * ldo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[(size_t)(k0 + j) * C + c] = v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float s = v[j] * v[j];
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (cl == 0) ss_part[((size_t)b * VK + k0 + j) * nslab + sl] = s;
+    }
+}
+
+// grid (VK, B), 256 threads: intra-normalisation of cluster k (netvlad.py:126) and the global L2 (:127-128)
+__global__ __launch_bounds__(256) void vlad_norm_kernel(float *__restrict__ out, int64_t ldo,
+                                                        const float *__restrict__ ss_part, int nslab, int C) {
+    __shared__ float nn2[VK];
+    __shared__ float scs[VK];
+    const int k = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    if (tid < VK) {
+        float s = 0.0f;
+        for (int sl = 0; sl < nslab; ++sl) s += ss_part[((size_t)b * VK + tid) * nslab + sl];
+        const float nk = sqrtf(s);
+        const float sc = 1.0f / fmaxf(nk, 1e-12f);
+        const float nn = nk * sc;
+        scs[tid] = sc;
+        nn2[tid] = nn * nn;
+    }
+    __syncthreads();
+    float gsum = 0.0f;
+    for (int kk = 0; kk < VK; ++kk) gsum += nn2[kk];
+    const float f = scs[k] * (1.0f / fmaxf(sqrtf(gsum), 1e-12f));
+    float *o = out + (size_t)b * ldo + (size_t)k * C;
+    for (int c = tid; c < C; c += 256) o[c] *= f;
+}
+
+// scratch of the small-batch path; grows only, superseded buffers stay allocated (hipGraph-safe, like g_part)
+static float *g_vs = nullptr;
+static size_t g_vs_floats = 0;
+static int g_vs_dev = -1;
+
 CSLAM_API int cslam_vlad_aggregate_dev(const float *d_feat, const float *d_assign_w, const float *d_assign_b,
                                        const float *d_centroids, int B, int C, int P, int K,
                                        float *d_out, int64_t ldo, void *stream) {
@@ -359,6 +513,33 @@ CSLAM_API int cslam_vlad_aggregate_dev(const float *d_feat, const float *d_assig
     ARG_CHECK(C >= 1 && C <= 512 && P >= 1 && B >= 0, "need 1 <= C <= 512 (reference encoder_dim = 512, netvlad.py:162)");
     ARG_CHECK(ldo >= (int64_t)K * C, "output pitch smaller than K*C");
     if (B == 0) return CSLAM_OK;
+    if (B <= 8 && P <= VL_PMAX) {
+        hipStream_t st = (hipStream_t)stream;
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        const int ntile = (P + VS_PT - 1) / VS_PT, nslab = (C + VL_CC - 1) / VL_CC;
+        const size_t n_wt = (size_t)C * VK, n_a = (size_t)B * P * VK, n_as = (size_t)B * ntile * VK;
+        const size_t n_ss = (size_t)B * VK * nslab, need = n_wt + n_a + n_as + n_ss;
+        if (need > g_vs_floats || g_vs_dev != dev) {
+            size_t want = need > 2 * g_vs_floats ? need : 2 * g_vs_floats;
+            if (want < ((size_t)1 << 20)) want = (size_t)1 << 20;
+            float *fresh = nullptr;
+            HIP_TRY(hipMalloc((void **)&fresh, want * 4));
+            g_vs = fresh; g_vs_floats = want; g_vs_dev = dev;
+        }
+        float *wt = g_vs, *a = wt + n_wt, *as = a + n_a, *ss = as + n_as;
+        hipLaunchKernelGGL(vlad_wt_kernel, dim3((unsigned)((C * VK + 255) / 256)), dim3(256), 0, st, d_assign_w, C, wt);
+        const size_t lds1 = ((size_t)C * VS_PT + 16 * VS_PT + VS_PT * VK + VS_PT) * 4;
+        HIP_TRY(hipFuncSetAttribute((const void *)vlad_assign_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+        hipLaunchKernelGGL(vlad_assign_kernel, dim3(ntile, B), dim3(256), lds1, st, d_feat, wt, d_assign_b, C, P, ntile, a, as);
+        const size_t lds2 = ((size_t)VL_PMAX * VK + VL_CC * VL_PPAD + VK) * 4;
+        HIP_TRY(hipFuncSetAttribute((const void *)vlad_slab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        hipLaunchKernelGGL(vlad_slab_kernel, dim3(nslab, B), dim3(512), lds2, st, d_feat, a, as, ntile, d_centroids, C, P,
+                           nslab, d_out, ldo, ss);
+        hipLaunchKernelGGL(vlad_norm_kernel, dim3(VK, B), dim3(256), 0, st, d_out, ldo, ss, nslab, C);
+        HIP_TRY(hipGetLastError());
+        return CSLAM_OK;
+    }
     if (P <= VL_PMAX) {
         size_t lds = (size_t)(VL_PMAX * VK + VL_CC * VL_PPAD + VL_CC * VK + VL_PMAX + VK + VK + 16) * 4;
         HIP_TRY(hipFuncSetAttribute((const void *)vlad_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

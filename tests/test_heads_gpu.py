@@ -56,6 +56,22 @@ def test_vlad_with_bias_and_odd_shapes(T):
         assert np.max(np.abs(y - o)) < 1e-6
 
 
+def test_vlad_small_batch_path_equals_batch_kernel(T):
+    """B <= 8 runs the three-kernel split (online path), larger batches the one-workgroup-per-image kernel."""
+    torch, heads = T
+    rng = np.random.default_rng(4)
+    for (C, H, W) in [(512, 14, 14), (96, 7, 9), (512, 16, 16)]:
+        x = rng.standard_normal((12, C, H, W)).astype(np.float32)
+        w = rng.standard_normal((64, C)).astype(np.float32) * 0.3
+        c = rng.random((64, C)).astype(np.float32)
+        big = heads.vlad_aggregate(dev(T, x), dev(T, w), None, dev(T, c)).cpu().numpy()
+        o = ho.vlad_forward(x, w, None, c)
+        assert np.max(np.abs(big - o)) < 1e-6
+        for b in (1, 3, 8):
+            small = heads.vlad_aggregate(dev(T, x[:b]), dev(T, w), None, dev(T, c)).cpu().numpy()
+            assert np.max(np.abs(small - o[:b])) < 1e-6 and np.max(np.abs(small - big[:b])) < 1e-6
+
+
 def test_cosplace_head_matches_reference_modules(g, T):
     torch, heads = T
     for tag in ("p3", "p237"):
