@@ -114,22 +114,65 @@ class LoopClosureSparseMatching(object):
                                                          greedy_initialization)
 
     # ------------------------------------------------------- batched extensions ----
+    # Descriptor banks (NearestNeighborsMatching) take the chunk through HBM: it is uploaded once -- or not at all
+    # when the extractor hands over its device tensor -- and every add / search of the chunk reads that copy
+    # (one chunk feeds 1 add + 1 intra search + one inter search per other robot).  The lidar matcher keeps its
+    # host-array interface.
+    def _stage(self, embeddings):
+        """-> (host array or None, device tensor or None, m).  Query dtype follows the input like the reference
+        (float32 stays float32, anything else is float64: nns_matching.py:55-58 through np.dot)."""
+        dev_ok = hasattr(self.local_nnsm, "search_device")
+        try:
+            import torch
+        except ImportError:                                     # pragma: no cover
+            torch = None
+        if torch is not None and isinstance(embeddings, torch.Tensor):
+            t = embeddings if embeddings.dtype in (torch.float32, torch.float64) else embeddings.double()
+            if dev_ok:
+                return None, t.to("cuda:%d" % self.local_nnsm.device).contiguous(), t.shape[0]
+            return t.cpu().numpy(), None, t.shape[0]
+        emb = np.asarray(embeddings)
+        assert emb.ndim == 2
+        if dev_ok and emb.shape[0] > 0:
+            h = np.ascontiguousarray(emb if emb.dtype == np.float32 else emb.astype(np.float64))
+            return emb, torch.from_numpy(h).to("cuda:%d" % self.local_nnsm.device), emb.shape[0]
+        return emb, None, emb.shape[0]
+
+    @staticmethod
+    def _add(bank, host, dev, ids):
+        if dev is not None:
+            import torch
+            bank.add_items_device(dev if dev.dtype == torch.float32 else dev.float(), ids)   # stored as float32
+        else:
+            bank.add_items(host, ids)
+
+    @staticmethod
+    def _search(bank, host, dev, k, row_limit=None):
+        if dev is not None:
+            lim = None
+            if row_limit is not None:
+                import torch
+                lim = torch.from_numpy(np.ascontiguousarray(row_limit, dtype=np.int64)).to(dev.device)
+            rows, sims, cnt = bank.search_device(dev, int(k), row_limit=lim)
+            return rows.cpu().numpy(), sims.cpu().numpy(), cnt.cpu().numpy()
+        return bank.search_batch(host, k, row_limit=row_limit)
+
     def process_local_keyframes(self, embeddings, keyframe_ids, intra=True):
         """Batch equivalent of, for each keyframe in order (gdlcd.py:148-174):
                match_local_loop_closures(e, id); add_local_global_descriptor(e, id)
+        `embeddings`: [m, d] numpy array or torch tensor (a CUDA tensor is used in place).
         Returns (intra_matches list of (kf_id, matched_kf or None), inter_matches list of
         EdgeInterRobot in the order the sequential calls would produce them)."""
-        emb = np.asarray(embeddings)
+        host, dev, m = self._stage(embeddings)
         ids = [int(i) for i in keyframe_ids]
-        m = emb.shape[0]
-        assert emb.ndim == 2 and len(ids) == m
+        assert len(ids) == m
         intra_out = []
         n0 = self.local_nnsm.n
-        self.local_nnsm.add_items(emb, ids)
+        self._add(self.local_nnsm, host, dev, ids)
         if intra:
             k = int(self.params['frontend.nb_best_matches'])
             lim = n0 + np.arange(m, dtype=np.int64)           # keyframe j sees rows added before it
-            rows, sims, cnt = self.local_nnsm.search_batch(emb, k, row_limit=lim)
+            rows, sims, cnt = self._search(self.local_nnsm, host, dev, k, lim)
             for j in range(m):
                 kfs = [self.local_nnsm.items[int(r)] for r in rows[j, :cnt[j]]]
                 s = sims[j, :cnt[j]]
@@ -145,7 +188,7 @@ class LoopClosureSparseMatching(object):
         best = {}
         for i in range(self.params['max_nb_robots']):
             if i != me and self.other_robots_nnsm[i].n > 0:
-                best[i] = self.other_robots_nnsm[i].search_batch(emb, 1)
+                best[i] = self._search(self.other_robots_nnsm[i], host, dev, 1)
         inter_out = []
         for j in range(m):
             for i in sorted(best):
@@ -160,14 +203,18 @@ class LoopClosureSparseMatching(object):
     def process_remote_descriptors(self, robot_id, descriptors, keyframe_ids):
         """Batch equivalent of add_other_robot_global_descriptor for consecutive messages of
         one robot (descriptors as float64 [m, d], like np.asarray(msg.descriptor))."""
-        desc = np.asarray(descriptors, dtype=np.float64)
+        if not hasattr(descriptors, "is_cuda"):
+            descriptors = np.asarray(descriptors, dtype=np.float64)
+        host, dev, m = self._stage(descriptors)
+        if dev is not None and str(dev.dtype) != "torch.float64":
+            dev = dev.double()                                   # received descriptors are float64 (lcsm.py:63)
         ids = [int(i) for i in keyframe_ids]
-        self.other_robots_nnsm[robot_id].add_items(desc, ids)
+        self._add(self.other_robots_nnsm[robot_id], host, dev, ids)
         out = []
         if self.local_nnsm.n == 0:
             return out
-        rows, sims, cnt = self.local_nnsm.search_batch(desc, 1)
-        for j in range(desc.shape[0]):
+        rows, sims, cnt = self._search(self.local_nnsm, host, dev, 1)
+        for j in range(m):
             if cnt[j] > 0 and sims[j, 0] >= self.params['frontend.similarity_threshold']:
                 match = EdgeInterRobot(self.params['robot_id'], self.local_nnsm.items[int(rows[j, 0])],
                                        robot_id, ids[j], sims[j, 0])

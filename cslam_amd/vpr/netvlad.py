@@ -151,8 +151,13 @@ class NetVLAD(object):
                     m.bias.zero_()
         self.trunk = None
         self._online = self._online_trunk = None
-        cent = torch.rand((64, 512), generator=g)
-        w = torch.randn((64, 512), generator=g) * 0.5
+        # centroids on the scale of the L2-normalised local descriptors they cluster and an assignment tied to them
+        # (the relation of the reference's init_params, netvlad.py:63-92: conv weight = 2 * alpha * centroid), so
+        # that the random-weight descriptors actually depend on the image (uniform centroids of norm ~13 swamp the
+        # unit-norm features: every residual is ~ -centroid and all descriptors coincide)
+        cent = torch.randn((64, 512), generator=g)
+        cent = cent / cent.norm(dim=1, keepdim=True) * 0.5
+        w = 2.0 * 10.0 * cent
         self.pool.load(w, cent)
         din = 64 * 512
         comp = torch.randn((pca_dim, din), generator=g, dtype=torch.float32) / din ** 0.5

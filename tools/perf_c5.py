@@ -1,0 +1,112 @@
+#!/usr/bin/env python
+"""BASELINE config 5 rehearsed on ONE GPU: the full loop for R robots x P keyframes each -- NetVLAD extract
+(VGG-16 fp32, 4096-D) of synthetic place-revisiting 640x480 frames, per-keyframe intra + inter-robot matching in
+the reference's causal order through the batched LoopClosureSparseMatching calls, the packed descriptor exchange
+between the robots, and the budgeted candidate selection (algebraic connectivity maximisation) on the broker.
+In the 8-GPU configuration every robot owns a GPU; here the eight robots take turns on one.
+
+    python tools/perf_c5.py [keyframes_per_robot=12500] [robots=8] [budget=1000] [chunk=250]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    P = int(sys.argv[1]) if len(sys.argv) > 1 else 12500
+    R = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    K = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
+    CH = int(sys.argv[4]) if len(sys.argv) > 4 else 250
+    import torch
+    from cslam_amd.loop_closure_sparse_matching import LoopClosureSparseMatching
+    from cslam_amd.vpr.netvlad import NetVLAD
+    from cslam_amd.wire import PackedDescriptorBuffer
+
+    dev = torch.device("cuda")
+    nv = NetVLAD({"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376, "frontend.netvlad.pca_dim": 4096}, None)
+    g = torch.Generator(device=dev).manual_seed(5)
+    n_places = 2000
+    # a "place" is a smooth random colour field (a 12x16 grid blown up to 480x640) so that places differ at every
+    # scale the network sees; a visit adds +-6 grey levels of pixel noise
+    coarse = torch.rand((n_places, 3, 12, 16), generator=g, device=dev)
+    places = (torch.nn.functional.interpolate(coarse, size=(480, 640), mode="bilinear", align_corners=False) * 255.0)
+    places = places.permute(0, 2, 3, 1).contiguous().to(torch.uint8)
+    del coarse
+    params = lambda r: {"robot_id": r, "max_nb_robots": R, "frontend.sensor_type": "stereo",   # noqa: E731
+                        "frontend.similarity_threshold": 0.6, "frontend.nb_best_matches": 10,
+                        "frontend.intra_loop_min_inbetween_keyframes": 20, "frontend.enable_sparsification": True,
+                        "evaluation.enable_sparsification_comparison": False}
+    # similarity threshold between "same place, new noise" and "different place" for these seeded random weights
+    def views(idx):
+        noise = torch.randint(-6, 7, (len(idx), 480, 640, 3), generator=g, device=dev, dtype=torch.int16)
+        return (places[idx].to(torch.int16) + noise).clamp_(0, 255).to(torch.uint8)
+    cal = torch.arange(64, device=dev)
+    d1, d2 = nv.compute_embeddings_device(views(cal)), nv.compute_embeddings_device(views(cal))
+    sims = (d1 @ d2.T).cpu().numpy()
+    same, diff = np.diag(sims), sims[~np.eye(64, dtype=bool)]
+    # a query is compared with thousands of rows, the calibration with 4032 pairs: stay close to the same-place side
+    thr = float(1.0 - 4.0 * (1.0 - same.min()))
+    print(f"calibration: 1 - similarity: same place {1 - same.max():.2e}..{1 - same.min():.2e}, different places "
+          f"{1 - diff.max():.2e}..{1 - diff.min():.2e} -> frontend.similarity_threshold 1 - {1 - thr:.2e}")
+    base = params
+    params = lambda r: dict(base(r), **{"frontend.similarity_threshold": thr})    # noqa: E731
+    lc = [LoopClosureSparseMatching(params(r)) for r in range(R)]
+    bufs = [PackedDescriptorBuffer(r) for r in range(R)]
+    rng = np.random.default_rng(5)
+    # each robot walks its own stretch of places and visits 3 % of its keyframes somewhere random (loop closures)
+    walk = [(rng.integers(0, n_places) + np.arange(P) // 8) % n_places for _ in range(R)]
+    for r in range(R):
+        jump = rng.random(P) < 0.03
+        walk[r] = np.where(jump, rng.integers(0, n_places, size=P), walk[r])
+    t_ext = t_loc = t_rem = 0.0
+    n_intra = n_inter = 0
+    nv.compute_embeddings_device(places[:CH])                     # warm-up
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for s in range(0, P, CH):
+        m = min(CH, P - s)
+        ids = list(range(s, s + m))
+        for r in range(R):
+            t0 = time.perf_counter()
+            frames = views(torch.from_numpy(walk[r][s:s + m]).to(dev))
+            ddev = nv.compute_embeddings_device(frames)
+            desc = ddev.cpu().numpy()                              # the copy that goes on the wire
+            t1 = time.perf_counter()
+            intra, inter = lc[r].process_local_keyframes(ddev, ids)    # matching reads the device tensor in place
+            n_intra += sum(k is not None for _, k in intra)
+            n_inter += len(inter)
+            t2 = time.perf_counter()
+            bufs[r].extend(ids, desc)
+            for chunk in bufs[r].chunks(s, 10 ** 9):              # one packed message per chunk of new keyframes
+                for o in range(R):
+                    if o != r:
+                        n_inter += len(lc[o].process_remote_descriptors(r, chunk.as_float64(), chunk.keyframe_ids))
+            bufs[r].delete_below(s + m)
+            t3 = time.perf_counter()
+            t_ext += t1 - t0; t_loc += t2 - t1; t_rem += t3 - t2
+    t_front = time.perf_counter() - t_start
+    sel = lc[0].candidate_selector
+    n_cand = len(sel.candidate_edges)
+    t0 = time.perf_counter()
+    chosen = lc[0].select_candidates(K, {r: True for r in range(R)})
+    t_sel1 = time.perf_counter() - t0
+    sel.candidate_edges_to_fixed(list(chosen))
+    t0 = time.perf_counter()
+    chosen2 = lc[0].select_candidates(K, {r: True for r in range(R)})     # now with fixed inter-robot links: MAC
+    t_sel2 = time.perf_counter() - t0
+    n = R * P
+    print(f"C5 rehearsal on one GPU: {R} robots x {P} keyframes = {n} keyframes, chunk {CH}")
+    print(f"  front end {t_front:.1f} s = {n / t_front:.0f} keyframes/s  [frames+extract {t_ext:.1f} s | local add + intra + inter "
+          f"{t_loc:.1f} s | exchange to {R - 1} peers {t_rem:.1f} s]; intra closures {n_intra}, inter-robot matches {n_inter}")
+    print(f"  broker: {n_cand} candidate edges on robot 0; select_candidates(K={K}) first call {t_sel1:.2f} s "
+          f"({len(chosen)} edges, biased greedy until every robot has a fixed link), second call {t_sel2:.2f} s "
+          f"({len(chosen2)} edges, MAC over {n} poses, solver {sel._fiedler_solver() if hasattr(sel, '_fiedler_solver') else '?'})")
+    print(f"  whole loop {t_front + t_sel1 + t_sel2:.1f} s -> {n / (t_front + t_sel1 + t_sel2):.0f} keyframes/s")
+
+
+if __name__ == "__main__":
+    main()
