@@ -56,14 +56,10 @@ class AlgebraicConnectivityMaximization(object):
 
     def __init__(self, robot_id=0, max_nb_robots=1, max_iters=20, fixed_weight=1.0,
                  extra_params=_DEFAULT_PARAMS):
-        """Initialization
-
-        Args:
-            robot_id (int, optional): ID of the robot
-            max_nb_robots (int, optional): number of robots. Defaults to 1.
-            max_iters (int, optional): maximum number of iterations. Defaults to 20.
-            fixed_weight (float, optional): weight of fixed measurements. Defaults to 1.0.
-        """
+        """Same signature as the reference (:36-45): this robot's id, how many robots the team can have, the
+        Frank-Wolfe iteration cap handed to MAC, the weight given to edges once they are measurements, and the
+        ROS parameter dict (read: frontend.enable_sparsification, evaluation.enable_sparsification_comparison,
+        frontend.mac_fiedler_solver)."""
         self.fixed_weight = fixed_weight
         self.params = extra_params
         self.fixed_edges = []

@@ -344,3 +344,19 @@ def test_online_hip_graph_replay_equals_plain_launches(T):
             big = torch.from_numpy(np.repeat(frames, 11, axis=0)).cuda()     # 33 frames: grows V / M / split-K buffers
             g.compute_embeddings_device(big)
         assert g._online is not None and not g._online.failed and len(g._online.entries) == 2, cls.__name__
+
+
+def test_tuned_gemm_table_is_loaded_and_harmless(T):
+    """The TunableOp selections shipped for the VGG-16 trunk load on this box (same library build) and a GEMM whose
+    shape is not in the table still runs; tuning itself stays off."""
+    torch, _ = T
+    import torch.cuda.tunable as tunable
+    from cslam_amd.vpr import winograd
+    winograd.use_tuned_gemms()
+    if not tunable.is_enabled():
+        pytest.skip("TunableOp was disabled by the environment (CSLAM_TUNED_GEMM=0)")
+    assert not tunable.tuning_is_enabled()
+    a, b = torch.randn((16, 300, 72), device="cuda"), torch.randn((16, 72, 40), device="cuda")
+    assert torch.allclose(torch.bmm(a, b), torch.einsum("bij,bjk->bik", a.double(), b.double()).float(), atol=1e-3)
+    names = [r[1] for r in tunable.get_results()]
+    assert any(n.startswith("nn_512_12544_512_B_36") for n in names), names[:5]

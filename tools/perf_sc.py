@@ -81,6 +81,25 @@ def main():
     t_cpu = (time.perf_counter() - t0) / ns
     same = np.array_equal(o["best_idx"], bi.cpu().numpy()[:ns]) and np.array_equal(o["best_sim"], bs.cpu().numpy()[:ns])
     print(f"CPU oracle (C, 1 core): {t_cpu * 1e3:.1f} ms/query (ring keys recomputed per call); identical to GPU: {same}")
+    # descriptor: ptcloud2sc of lidar-sized clouds, one frame and a batch of 32
+    from cslam_amd.lidar_pr.scancontext import ScanContext
+    from helpers import synth_lidar_cloud
+    ex = ScanContext({}, None)
+    clouds = [synth_lidar_cloud(np.random.default_rng(100 + i), 130000, True).astype(np.float64) for i in range(32)]
+    ex.compute_embedding(clouds[0])
+    t0 = time.perf_counter()
+    for c in clouds[:8]:
+        ex.compute_embedding(c)
+    t_one = (time.perf_counter() - t0) / 8
+    t0 = time.perf_counter()
+    ex.compute_embeddings(clouds)
+    t_b = (time.perf_counter() - t0) / 32
+    t0 = time.perf_counter()
+    ref = pyoracle.ptcloud2sc(clouds[0])
+    t_c = time.perf_counter() - t0
+    same = np.array_equal(ref.reshape(-1), ex.compute_embedding(clouds[0]))
+    print(f"ptcloud2sc, 130k-point clouds (host arrays in, 3.1 MB each): {t_one * 1e3:.2f} ms/frame one at a time, "
+          f"{t_b * 1e3:.2f} ms/frame in a batch of 32; C oracle {t_c * 1e3:.1f} ms/frame; identical: {same}")
 
 
 if __name__ == "__main__":
