@@ -95,6 +95,10 @@ def main():
     fgen = torch.Generator(device=dev).manual_seed(7 + rank)
     frames = torch.randint(0, 256, (a.batch, 480, 640, 3), generator=fgen, device=dev, dtype=torch.uint8)
     qgen = torch.Generator(device=dev).manual_seed(4321 + rank)
+    if extractor is not None:
+        # model set-up, not a step: builds the transformed weights, the V / M workspaces and loads the GEMM table
+        extractor.compute_embeddings_device(frames[:a.extract_chunk], bdt)
+        torch.cuda.synchronize()
 
     kernel_ms = []
 

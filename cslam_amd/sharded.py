@@ -5,6 +5,7 @@ Per step every rank contributes its new descriptors Q_g; ONE all-gather (RCCL ov
 torch.distributed backend "nccl") gives every rank all queries; rank g then scores
     its own rows      -> top-k   against B_g   (intra-robot, lcsm.py:74-92)
     every other robot -> best-1  against B_g   (lcsm.py:56-72: remote descriptor vs local bank)
+in one launch over all N*m queries (the best-1 is the head of the top-k list).
 The reference needs best-1 per (query, bank) pair only, so results stay on the rank that
 owns the bank: no second collective, no reduction (the reference exchanges descriptors over
 ROS 2 topics, gdlcd.py:198-227,407-422; this replaces that transport inside one node).
@@ -36,12 +37,14 @@ class ShardedInterRobotMatcher(object):
          inter (rows, sims, cnt, robot_of_query [nq_remote]) for all other robots' queries)."""
         m = local_desc.shape[0]
         allq = self.gather_fn(local_desc, self.world)
-        intra = self.search_fn(allq[self.rank * m:(self.rank + 1) * m], self.k_intra)
         if self.world == 1:
-            return intra, None
-        keep = torch.ones(self.world * m, dtype=torch.bool, device=allq.device)
-        keep[self.rank * m:(self.rank + 1) * m] = False
-        remote = allq[keep]
-        robot = torch.arange(self.world, device=allq.device).repeat_interleave(m)[keep]
-        rows, sims, cnt = self.search_fn(remote, 1)
-        return intra, (rows, sims, cnt, robot)
+            return self.search_fn(allq, self.k_intra), None
+        # ONE launch over every robot's new descriptors: the best-1 the remote rows need is the head of the
+        # same top-k list the local rows need in full (same scores, same order), so nothing is computed twice
+        rows, sims, cnt = self.search_fn(allq, self.k_intra)
+        lo, hi = self.rank * m, (self.rank + 1) * m
+        intra = (rows[lo:hi], sims[lo:hi], cnt[lo:hi])
+        robot = torch.arange(self.world, device=allq.device).repeat_interleave(m)
+        cut = lambda t: torch.cat((t[:lo], t[hi:]))             # noqa: E731 -- everyone's rows except this robot's
+        inter = (cut(rows)[:, :1], cut(sims)[:, :1], cut(cnt).clamp(max=1), cut(robot))
+        return intra, inter
