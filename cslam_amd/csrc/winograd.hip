@@ -400,6 +400,11 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restri
     }
 }
 
+// Measured and rejected: evaluating the first layer (3 -> 64 + ReLU) inside this layer's input transform for
+// conv1_2, so that the 12.8 MB-per-frame activation between them never touches HBM.  The fused kernel (6x6 window
+// of first-layer outputs recomputed per tile from an 8x8x3 LDS patch, 972 packed FMAs per thread, 256 VGPRs) ran
+// 3.9 ms per 256 frames against 1.2 ms (conv3x3_c3_kernel) + 2.0 ms (this kernel's conv1_2 launch) separately.
+
 CSLAM_API int cslam_wino4_input_dev(const float *d_x, int B, int H, int W, int C, float *d_V, void *stream) {
     ARG_CHECK(d_x && d_V, "NULL argument");
     ARG_CHECK(B >= 1 && H >= 4 && W >= 4 && (H % 4) == 0 && (W % 4) == 0, "H and W must be multiples of 4");
