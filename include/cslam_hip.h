@@ -17,7 +17,12 @@
  *   - bank rows are float32 (reference storage dtype, cslam/nns_matching.py:21,39);
  *     queries are float32 (CSLAM_F32) or float64 (CSLAM_F64);
  *   - row indices are int64 in the API (bank row number = order of insertion,
- *     the key of the reference's `items` dict, cslam/nns_matching.py:38).
+ *     the key of the reference's `items` dict, cslam/nns_matching.py:38);
+ *   - threading: like the reference classes (one rclpy single-threaded executor per robot,
+ *     loop_closure_detection_node.py:109) objects are not thread-safe, and the descriptor-head entry points
+ *     share per-process scratch buffers: call them from one thread (or one stream at a time) per process;
+ *   - scratch buffers and coefficient tables owned by the library only grow and are released at process exit,
+ *     so device pointers captured in a hipGraph stay valid.
  */
 #ifndef CSLAM_HIP_H
 #define CSLAM_HIP_H
