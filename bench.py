@@ -18,6 +18,7 @@ separately), `roofline` of the dominant hand-written kernel (sim_topk_mfma, HIP-
 its launch stream inside the timed steps) and `cpu_baseline` (the C oracle on a bounded sample).
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -183,7 +184,6 @@ def main():
     # MI355X guide); it cannot be collected inside an unprofiled run.
     traffic, traffic_src = None, None
     try:
-        import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
         if cands and a.bank_rows == 100_000 and a.dim == 4096:
             pm = json.load(open(cands[-1]))
@@ -220,9 +220,20 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
         nbytes = (xt.numel() + vt.numel()) * 4
+        # HBM-side bytes of this very launch shape from the committed FETCH_SIZE / WRITE_SIZE passes
+        # (tools/gpu_round4.sh + tools/pmc_extract_summary.py), like roofline.traffic above
+        etraffic, esrc = None, None
+        try:
+            ec = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_extract_pmc_summary.json")))
+            if ec and eb == 256:
+                ej = json.load(open(ec[-1]))
+                etraffic, esrc = ej.get("traffic_bytes"), os.path.basename(ec[-1])
+        except Exception:
+            pass
         extract_roofline = {"bound": "hbm", "kernel": "wino4_input_kernel", "achieved": round(nbytes / ms / 1e6, 1),
                             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
-                            "traffic": None, "kernel_ms": round(ms, 3),
+                            "traffic": etraffic, "traffic_source": esrc, "algorithmic_bytes": nbytes,
+                            "kernel_ms": round(ms, 3),
                             "shape": f"x [{eb},{eh},{eh},{ec}] -> V [36,{vt.shape[1]},{ec}]",
                             "note": "largest hand-written kernel of the extract leg; the 36 GEMMs between the "
                                     "transforms are rocBLAS"}

@@ -27,4 +27,5 @@ python tools/kernel_trace_summary.py $(find $O/ext_trace -name "*kernel_trace.cs
 for c in FETCH_SIZE WRITE_SIZE; do d=ext_fetch; [ $c = WRITE_SIZE ] && d=ext_write
   python tools/kernel_trace_summary.py $(find $O/$d -name "*counter_collection.csv" | head -1) --pmc $c >> $O/extract_pmc.txt 2>&1; done
 cat $O/extract_pmc.txt
+# afterwards, in the build container: python tools/pmc_summary.py gpurun_out <tag>; python tools/pmc_extract_summary.py gpurun_out <tag>
 echo all done
