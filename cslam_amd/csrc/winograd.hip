@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
                                                          float *__restrict__ V) {
     const int c4n = C >> 2;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int TH = H >> 1, TW = W >> 1;
+    const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;      // ragged maps: the last tile row / column is partly outside
     const int64_t T = (int64_t)B * TH * TW;
     if (gid >= T * c4n) return;
     const int c4 = (int)(gid % c4n);
@@ -67,14 +67,14 @@ __global__ __launch_bounds__(256) void wino_input_kernel(const float *__restrict
 }
 
 // M [16][T][C]; y [B][H][W][C] (POOL = false) or [B][H/2][W/2][C] (POOL = true: the 2x2 outputs of a tile are
-// exactly one window of the MaxPool2d(2, 2) that follows the layer).
+// exactly one window of the MaxPool2d(2, 2) that follows the layer).  Tiles may hang over the map (odd H / W).
 template <bool RELU, bool POOL>
 __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restrict__ M, const float *__restrict__ bias,
                                                           const float *__restrict__ res, int B, int H, int W, int C,
                                                           float *__restrict__ y) {
     const int c4n = C >> 2;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int TH = H >> 1, TW = W >> 1;
+    const int TH = (H + 1) >> 1, TW = (W + 1) >> 1;      // ragged maps: the last tile row / column is partly outside
     const int64_t T = (int64_t)B * TH * TW;
     if (gid >= T * c4n) return;
     const int c4 = (int)(gid % c4n);
@@ -101,25 +101,27 @@ __global__ __launch_bounds__(256) void wino_output_kernel(const float *__restric
     for (int i = 0; i < 2; ++i) {          // (.) A, + bias (+ residual), activation
         o[i][0] = s[i][0] + s[i][1] + s[i][2] + bv;
         o[i][1] = s[i][1] - s[i][2] - s[i][3] + bv;
-        if (res) {                         // ResNet shortcut, same NHWC shape as y (never with POOL)
+        if (res && 2 * ti + i < H) {       // ResNet shortcut, same NHWC shape as y (never with POOL)
             o[i][0] += *((const f4 *)(res + (((int64_t)b * H + 2 * ti + i) * W + 2 * tj) * C) + c4);
-            o[i][1] += *((const f4 *)(res + (((int64_t)b * H + 2 * ti + i) * W + 2 * tj + 1) * C) + c4);
+            if (2 * tj + 1 < W) o[i][1] += *((const f4 *)(res + (((int64_t)b * H + 2 * ti + i) * W + 2 * tj + 1) * C) + c4);
         }
         if (RELU) {
             o[i][0] = __builtin_elementwise_max(o[i][0], (f4)(0.0f));
             o[i][1] = __builtin_elementwise_max(o[i][1], (f4)(0.0f));
         }
     }
-    if (POOL) {
+    if (POOL) {                                // MaxPool2d(2,2) floors: a window partly outside the map has no output
+        const int Ho = H >> 1, Wo = W >> 1;
         f4 v = __builtin_elementwise_max(__builtin_elementwise_max(o[0][0], o[0][1]),
                                          __builtin_elementwise_max(o[1][0], o[1][1]));
-        *((f4 *)(y + (((int64_t)b * TH + ti) * TW + tj) * C) + c4) = v;
+        if (ti < Ho && tj < Wo) *((f4 *)(y + (((int64_t)b * Ho + ti) * Wo + tj) * C) + c4) = v;
     } else {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                *((f4 *)(y + (((int64_t)b * H + 2 * ti + i) * W + 2 * tj + j) * C) + c4) = o[i][j];
+                if (2 * ti + i < H && 2 * tj + j < W)
+                    *((f4 *)(y + (((int64_t)b * H + 2 * ti + i) * W + 2 * tj + j) * C) + c4) = o[i][j];
     }
 }
 
@@ -253,9 +255,9 @@ CSLAM_API int cslam_conv3x3_c3_dev(const float *d_x, const float *d_wt, const fl
 
 CSLAM_API int cslam_wino_input_dev(const float *d_x, int B, int H, int W, int C, float *d_V, void *stream) {
     ARG_CHECK(d_x && d_V, "NULL argument");
-    ARG_CHECK(B >= 1 && H >= 2 && W >= 2 && (H % 2) == 0 && (W % 2) == 0, "H and W must be even and >= 2");
+    ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
     ARG_CHECK(C >= 4 && (C % 4) == 0, "C must be a multiple of 4");
-    const int64_t n = (int64_t)B * (H / 2) * (W / 2) * (C / 4);
+    const int64_t n = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
     ARG_CHECK(ceil_div64(n, 256) < (1LL << 31), "too many tiles for one launch");
     hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream, d_x, B,
                        H, W, C, d_V);
@@ -267,9 +269,9 @@ CSLAM_API int cslam_wino_output_dev(const float *d_M, const float *d_bias, const
                                     int C, int relu, int pool, float *d_y, void *stream) {
     ARG_CHECK(d_M && d_y, "NULL argument");
     ARG_CHECK(!(d_res && pool), "a residual input cannot be combined with pooling");
-    ARG_CHECK(B >= 1 && H >= 2 && W >= 2 && (H % 2) == 0 && (W % 2) == 0, "H and W must be even and >= 2");
+    ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
     ARG_CHECK(C >= 4 && (C % 4) == 0, "C must be a multiple of 4");
-    const int64_t n = (int64_t)B * (H / 2) * (W / 2) * (C / 4);
+    const int64_t n = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
     ARG_CHECK(ceil_div64(n, 256) < (1LL << 31), "too many tiles for one launch");
     dim3 grid((unsigned)ceil_div64(n, 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
@@ -303,7 +305,7 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float *__restric
                                                           float *__restrict__ V) {
     const int c2n = C >> 1;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int TH = H >> 2, TW = W >> 2;
+    const int TH = (H + 3) >> 2, TW = (W + 3) >> 2;      // ragged maps: the last tile row / column is partly outside
     const int64_t T = (int64_t)B * TH * TW;
     if (gid >= T * c2n) return;
     const int c2 = (int)(gid % c2n);
@@ -351,7 +353,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restri
                                                            float *__restrict__ y) {
     const int c2n = C >> 1;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int TH = H >> 2, TW = W >> 2;
+    const int TH = (H + 3) >> 2, TW = (W + 3) >> 2;      // ragged maps: the last tile row / column is partly outside
     const int64_t T = (int64_t)B * TH * TW;
     if (gid >= T * c2n) return;
     const int c2 = (int)(gid % c2n);
@@ -377,7 +379,8 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             o[i][j] += bv;
-            if (res) o[i][j] += *((const f2 *)(res + (((int64_t)b * H + 4 * ti + i) * W + 4 * tj + j) * C) + c2);
+            if (res && 4 * ti + i < H && 4 * tj + j < W)
+                o[i][j] += *((const f2 *)(res + (((int64_t)b * H + 4 * ti + i) * W + 4 * tj + j) * C) + c2);
             if (RELU) o[i][j] = __builtin_elementwise_max(o[i][j], (f2)(0.0f));
         }
     }
@@ -389,14 +392,16 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restri
             for (int j = 0; j < 2; ++j) {
                 f2 v = __builtin_elementwise_max(__builtin_elementwise_max(o[2 * i][2 * j], o[2 * i][2 * j + 1]),
                                                  __builtin_elementwise_max(o[2 * i + 1][2 * j], o[2 * i + 1][2 * j + 1]));
-                *((f2 *)(y + (((int64_t)b * Ho + 2 * ti + i) * Wo + 2 * tj + j) * C) + c2) = v;
+                if (2 * ti + i < Ho && 2 * tj + j < Wo)
+                    *((f2 *)(y + (((int64_t)b * Ho + 2 * ti + i) * Wo + 2 * tj + j) * C) + c2) = v;
             }
     } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                *((f2 *)(y + (((int64_t)b * H + 4 * ti + i) * W + 4 * tj + j) * C) + c2) = o[i][j];
+                if (4 * ti + i < H && 4 * tj + j < W)
+                    *((f2 *)(y + (((int64_t)b * H + 4 * ti + i) * W + 4 * tj + j) * C) + c2) = o[i][j];
     }
 }
 
@@ -407,9 +412,9 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restri
 
 CSLAM_API int cslam_wino4_input_dev(const float *d_x, int B, int H, int W, int C, float *d_V, void *stream) {
     ARG_CHECK(d_x && d_V, "NULL argument");
-    ARG_CHECK(B >= 1 && H >= 4 && W >= 4 && (H % 4) == 0 && (W % 4) == 0, "H and W must be multiples of 4");
+    ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
     ARG_CHECK(C >= 2 && (C % 2) == 0, "C must be even");
-    const int64_t n = (int64_t)B * (H / 4) * (W / 4) * (C / 2);
+    const int64_t n = (int64_t)B * ((H + 3) / 4) * ((W + 3) / 4) * (C / 2);
     ARG_CHECK(ceil_div64(n, 256) < (1LL << 31), "too many tiles for one launch");
     hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream, d_x, B,
                        H, W, C, d_V);
@@ -421,9 +426,9 @@ CSLAM_API int cslam_wino4_output_dev(const float *d_M, const float *d_bias, cons
                                      int C, int relu, int pool, float *d_y, void *stream) {
     ARG_CHECK(d_M && d_y, "NULL argument");
     ARG_CHECK(!(d_res && pool), "a residual input cannot be combined with pooling");
-    ARG_CHECK(B >= 1 && H >= 4 && W >= 4 && (H % 4) == 0 && (W % 4) == 0, "H and W must be multiples of 4");
+    ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
     ARG_CHECK(C >= 2 && (C % 2) == 0, "C must be even");
-    const int64_t n = (int64_t)B * (H / 4) * (W / 4) * (C / 2);
+    const int64_t n = (int64_t)B * ((H + 3) / 4) * ((W + 3) / 4) * (C / 2);
     ARG_CHECK(ceil_div64(n, 256) < (1LL << 31), "too many tiles for one launch");
     dim3 grid((unsigned)ceil_div64(n, 256)), block(256);
     hipStream_t st = (hipStream_t)stream;

@@ -60,16 +60,18 @@ def use_tuned_gemms():
 
 
 def wino_conv3x3(ws, x, U, U4, bias, relu, pool=False, residual=None):
-    """3x3 / stride 1 / pad 1 convolution of x [B,Cin,H,W] (channels_last storage, even H and W) through the
+    """3x3 / stride 1 / pad 1 convolution of x [B,Cin,H,W] (channels_last storage, any H and W) through the
     Winograd pipeline; U / U4 from `wino_weights` (U4 None = F(2x2,3x3) only).  bias [Cout] or None, residual
     (channels_last, shaped like the output) is added before the ReLU.  `ws` owns the V / M workspaces."""
     lib = _lib.load()
     B, Cin, H, W = x.shape
     Cout = U.shape[2]
-    # F(4x4) needs enough tiles to keep its 36 GEMMs efficient; single frames stay on F(2x2)
-    four = U4 is not None and H % 4 == 0 and W % 4 == 0 and B * (H // 4) * (W // 4) >= 512
+    # F(4x4) needs enough tiles to keep its 36 GEMMs efficient (single frames stay on F(2x2)) and maps whose
+    # sides waste at most ~1/3 of the padded tile area (14 -> 16, 7 -> 8); tiles may hang over the map
+    t4h, t4w, t2h, t2w = -(-H // 4), -(-W // 4), -(-H // 2), -(-W // 2)
+    four = U4 is not None and B * t4h * t4w >= 512 and 16 * t4h * t4w <= 1.35 * H * W
     n2, Uu = (36, U4) if four else (16, U)
-    T = B * (H // 4) * (W // 4) if four else B * (H // 2) * (W // 2)
+    T = B * t4h * t4w if four else B * t2h * t2w
     V = ws._buf("V", n2 * T * Cin, x.device).view(n2, T, Cin)
     M = ws._buf("M", n2 * T * Cout, x.device).view(n2, T, Cout)
     s = _stream(x)
@@ -124,8 +126,7 @@ class _FoldedConv(object):
             self.U4 = wino_weights(self.weight, 4).to(self.weight.device) if tile == 4 else None
 
     def __call__(self, ws, x, relu, residual=None):
-        H, W = x.shape[2], x.shape[3]
-        if self.U is not None and H % 2 == 0 and W % 2 == 0 and H >= 2 and W >= 2:
+        if self.U is not None:
             return wino_conv3x3(ws, x.contiguous(memory_format=torch.channels_last), self.U, self.U4, self.bias, relu,
                                 False, residual)
         y = torch.nn.functional.conv2d(x, self.weight, self.bias, self.stride, self.padding)
@@ -137,8 +138,9 @@ class _FoldedConv(object):
 class WinogradResNet(_Workspace):
     """Runs the ResNet trunks of vpr/backbones.py (`resnet_trunk`: conv1, bn1, relu, maxpool, layer1..4 of
     BasicBlock / Bottleneck) like `trunk(x)` in eval mode, with every BatchNorm folded into its convolution and
-    the 3x3 / stride 1 convolutions on even maps executed through the Winograd pipeline (bias, shortcut add and
-    ReLU fused into the output transform).  Strided / 1x1 / 7x7 convolutions and odd maps go through torch."""
+    the 3x3 / stride 1 convolutions executed through the Winograd pipeline (bias, shortcut add and ReLU fused into
+    the output transform; tiles hang over odd maps such as layer4's 7x7).  Strided / 1x1 / 7x7 convolutions go
+    through torch."""
 
     def __init__(self, trunk, min_in_channels=64, tile=4):
         super().__init__()
@@ -279,14 +281,6 @@ class WinogradTrunk(_Workspace):
                                                    memory_format=torch.channels_last)
                 _lib.check(lib.cslam_bias_act_pool_dev(_p(x), _p(st.bias), B, H, W, Cout, 1, int(pool), _p(y), _stream(x)))
                 x = y if not (st.pool and not pool) else torch.nn.functional.max_pool2d(y, 2, 2)
-                continue
-            B, Cin, H, W = x.shape
-            if H % 2 or W % 2 or H < 2 or W < 2:                # odd maps: the direct form
-                x = st.conv(x)
-                if st.relu:
-                    x = torch.relu_(x)
-                if st.pool:
-                    x = torch.nn.functional.max_pool2d(x, 2, 2)
                 continue
             x = x.contiguous(memory_format=torch.channels_last)
             y = wino_conv3x3(self, x, st.U, st.U4, st.bias, st.relu, st.pool)

@@ -228,8 +228,8 @@ int cslam_scancontext_from_cloud_dev(const double *d_points, const int64_t *d_of
  * (the VGG-16 trunk built at cslam/vpr/netvlad.py:163-171; the reference runs it through torch's direct
  * convolution).  Activations are NHWC float32.  conv(x, g) + bias = output(bmm(input(x), U)) with
  * U[xi][ci][co] = (G g G^T)[xi]; the 16 GEMMs V[xi] (T x C) . U[xi] (C x Cout) are plain library GEMMs.
- *   input : x [B,H,W,C] -> V [16, T, C], T = B*(H/2)*(W/2); H, W even, C % 4 == 0
- *   output: M [16, T, C] -> y [B,H,W,C], or [B,H/2,W/2,C] when pool != 0 (the MaxPool2d(2,2) that follows
+ *   input : x [B,H,W,C] -> V [16, T, C], T = B*ceil(H/2)*ceil(W/2) (tiles may hang over an odd map), C % 4 == 0
+ *   output: M [16, T, C] -> y [B,H,W,C], or [B,floor(H/2),floor(W/2),C] when pool != 0 (the MaxPool2d(2,2) that follows
  *           the layer fused in); bias [C] or NULL; residual (NULL, or an NHWC tensor shaped like y, pool == 0:
  *           the shortcut of a ResNet block, cosplace_utils/network.py:39-56) is added before the activation;
  *           relu != 0 applies max(., 0) before the pooling. */
@@ -246,7 +246,7 @@ int cslam_conv3x3_c3_dev(const float *d_x, const float *d_wt, const float *d_bia
 int cslam_wino_input_dev(const float *d_x, int B, int H, int W, int C, float *d_V, void *stream);
 int cslam_wino_output_dev(const float *d_M, const float *d_bias, const float *d_residual, int B, int H, int W,
                           int C, int relu, int pool, float *d_y, void *stream);
-/* F(4x4, 3x3) variant: 6x6 input tiles, V / M [36, T, C] with T = B*(H/4)*(W/4); H, W multiples of 4, C even.
+/* F(4x4, 3x3) variant: 6x6 input tiles, V / M [36, T, C] with T = B*ceil(H/4)*ceil(W/4) (ragged maps allowed), C even.
  * 4x fewer multiplications than the direct form, about one decimal digit less accurate than F(2x2, 3x3). */
 int cslam_wino4_input_dev(const float *d_x, int B, int H, int W, int C, float *d_V, void *stream);
 int cslam_wino4_output_dev(const float *d_M, const float *d_bias, const float *d_residual, int B, int H, int W,

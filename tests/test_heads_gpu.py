@@ -190,6 +190,10 @@ def test_extractors_end_to_end_structure(T):
                                                           (3, 256, 64, 14, 6, True, True, True),
                                                           (1, 512, 512, 14, 14, False, False, True),
                                                           (40, 64, 128, 16, 24, True, True, True),
+                                                          (40, 64, 96, 14, 14, True, False, True),     # ragged F(4x4) tiles
+                                                          (40, 128, 64, 14, 18, True, True, True),
+                                                          (2, 128, 64, 7, 9, True, True, True),        # odd maps, floor pooling
+                                                          (3, 64, 64, 5, 1, False, False, True),
                                                           (2, 64, 128, 8, 10, False, True, False)])
 def test_winograd_conv_equals_direct_float64(T, B, cin, cout, H, W, relu, pool, bias):
     """The two HIP transforms around 16 GEMMs == conv2d (+bias, ReLU, MaxPool) evaluated in float64."""
@@ -216,7 +220,7 @@ def test_winograd_conv_equals_direct_float64(T, B, cin, cout, H, W, relu, pool, 
         assert (y.double() - ref).abs().max().item() <= tol * scale, tile
 
 
-def test_winograd_trunk_equals_direct_trunk_and_falls_back_on_odd_maps(T):
+def test_winograd_trunk_equals_direct_trunk_including_odd_maps(T):
     torch, _ = T
     from cslam_amd.vpr.backbones import vgg16_features_trunk
     from cslam_amd.vpr.winograd import WinogradTrunk
@@ -228,7 +232,7 @@ def test_winograd_trunk_equals_direct_trunk_and_falls_back_on_odd_maps(T):
         assert kinds.count("wino") == nw and kinds.count("c3") == 1 and kinds.count("direct") == 12 - nw \
             and kinds.count("torch") == 0
         assert sum(s.pool for s in wt.steps) == 4
-        for B, hw in ((2, 224), (24, 112), (2, 72)):   # 72 -> 36 -> 18 -> 9: odd maps in the last block
+        for B, hw in ((2, 224), (24, 112), (2, 72), (40, 200)):   # 72 -> ... -> 9 and 200 -> ... -> 25 -> 12: odd maps
             x = torch.randn((B, 3, hw, hw), device="cuda")
             with torch.no_grad():
                 r = enc.double()(x.double())
@@ -275,7 +279,8 @@ def test_first_layer_conv_c3_matches_float64(T):
         assert y.shape == ref.shape and (y.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("name,B,hw", [("resnet18", 24, 224), ("resnet18", 2, 96), ("resnet50", 8, 224)])
+@pytest.mark.parametrize("name,B,hw", [("resnet18", 24, 224), ("resnet18", 2, 96), ("resnet50", 8, 224),
+                                       ("resnet18", 130, 224)])          # 130 frames: layer4's 7x7 maps on ragged F(4x4)
 def test_winograd_resnet_equals_torch_trunk(T, name, B, hw):
     """BatchNorm folding + Winograd 3x3 + fused shortcut/ReLU == the torch eval trunk, both judged against float64."""
     torch, _ = T
