@@ -224,10 +224,10 @@ def main():
         # (tools/gpu_round4.sh + tools/pmc_extract_summary.py), like roofline.traffic above
         etraffic, esrc = None, None
         try:
-            ec = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_extract_pmc_summary.json")))
-            if ec and eb == 256:
-                ej = json.load(open(ec[-1]))
-                etraffic, esrc = ej.get("traffic_bytes"), os.path.basename(ec[-1])
+            efiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_extract_pmc_summary.json")))
+            if efiles and eb == 256:
+                ej = json.load(open(efiles[-1]))
+                etraffic, esrc = ej.get("traffic_bytes"), os.path.basename(efiles[-1])
         except Exception:
             pass
         extract_roofline = {"bound": "hbm", "kernel": "wino4_input_kernel", "achieved": round(nbytes / ms / 1e6, 1),

@@ -231,6 +231,12 @@ class LoopClosureSparseMatching(object):
         rows, last = unknown_rows(chunk, last_keyframe_received)
         if len(rows) == 0:
             return [], last
-        matches = self.process_remote_descriptors(chunk.robot_id, chunk.as_float64()[rows],
-                                                  np.asarray(chunk.keyframe_ids)[rows])
+        desc = chunk.descriptors[rows]
+        if hasattr(self.local_nnsm, "search_device"):
+            # float32 on the wire -> upload the 4 bytes per value, widen to the receiver's float64 in HBM (exact)
+            import torch
+            desc = torch.from_numpy(np.ascontiguousarray(desc)).to("cuda:%d" % self.local_nnsm.device).double()
+        else:
+            desc = desc.astype(np.float64)
+        matches = self.process_remote_descriptors(chunk.robot_id, desc, np.asarray(chunk.keyframe_ids)[rows])
         return matches, last

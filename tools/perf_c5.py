@@ -84,7 +84,7 @@ def main():
             for chunk in bufs[r].chunks(s, 10 ** 9):              # one packed message per chunk of new keyframes
                 for o in range(R):
                     if o != r:
-                        n_inter += len(lc[o].process_remote_descriptors(r, chunk.as_float64(), chunk.keyframe_ids))
+                        n_inter += len(lc[o].process_remote_chunk(chunk, s - 1)[0])
             bufs[r].delete_below(s + m)
             t3 = time.perf_counter()
             t_ext += t1 - t0; t_loc += t2 - t1; t_rem += t3 - t2
