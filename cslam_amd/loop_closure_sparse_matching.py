@@ -169,35 +169,50 @@ class LoopClosureSparseMatching(object):
         intra_out = []
         n0 = self.local_nnsm.n
         self._add(self.local_nnsm, host, dev, ids)
+        thr = self.params['frontend.similarity_threshold']
         if intra:
             k = int(self.params['frontend.nb_best_matches'])
             lim = n0 + np.arange(m, dtype=np.int64)           # keyframe j sees rows added before it
             rows, sims, cnt = self._search(self.local_nnsm, host, dev, k, lim)
+            rows_l, sims_l, cnt_l = rows.tolist(), sims.tolist(), cnt.tolist()   # plain lists: no numpy scalars below
+            items = self.local_nnsm.items
+            gap = self.params['frontend.intra_loop_min_inbetween_keyframes']
             for j in range(m):
-                kfs = [self.local_nnsm.items[int(r)] for r in rows[j, :cnt[j]]]
-                s = sims[j, :cnt[j]]
-                if len(kfs) > 0 and kfs[0] == ids[j]:
+                c = cnt_l[j]
+                kfs = [items[r] for r in rows_l[j][:c]]
+                s = sims_l[j][:c]
+                if c > 0 and kfs[0] == ids[j]:
                     kfs, s = kfs[1:], s[1:]
                 kf = None
                 if len(kfs) > 0 and kfs[0] is not None:
-                    kf = self._first_valid(kfs, s, ids[j],
-                                           self.params['frontend.intra_loop_min_inbetween_keyframes'],
-                                           self.params['frontend.similarity_threshold'])
+                    kf = self._first_valid(kfs, s, ids[j], gap, thr)
                 intra_out.append((ids[j], kf))
         me = self.params['robot_id']
-        best = {}
-        for i in range(self.params['max_nb_robots']):
-            if i != me and self.other_robots_nnsm[i].n > 0:
-                best[i] = self._search(self.other_robots_nnsm[i], host, dev, 1)
+        others = [i for i in range(self.params['max_nb_robots']) if i != me and self.other_robots_nnsm[i].n > 0]
         inter_out = []
-        for j in range(m):
-            for i in sorted(best):
-                rows, sims, cnt = best[i]
-                if cnt[j] > 0 and sims[j, 0] >= self.params['frontend.similarity_threshold']:
-                    match = EdgeInterRobot(me, ids[j], i, self.other_robots_nnsm[i].items[int(rows[j, 0])],
-                                           sims[j, 0])
-                    self.candidate_selector.add_match(match)
-                    inter_out.append(match)
+        if others:
+            # best-1 per other robot, thresholded with array operations; Python only touches the actual matches,
+            # in the order the sequential calls produce them (keyframe-major, robot id ascending)
+            best_rows = np.empty((m, len(others)), dtype=np.int64)
+            best_sims = np.empty((m, len(others)), dtype=np.float64)
+            hit = np.zeros((m, len(others)), dtype=bool)
+            # device banks: enqueue every search first, read the results back afterwards (no stall between launches)
+            pending = [self.other_robots_nnsm[i].search_device(dev, 1) for i in others] if dev is not None else None
+            for c, i in enumerate(others):
+                if pending is not None:
+                    rows, sims, cnt = (t.cpu().numpy() for t in pending[c])
+                else:
+                    rows, sims, cnt = self._search(self.other_robots_nnsm[i], host, dev, 1)
+                best_rows[:, c], best_sims[:, c] = rows[:, 0], sims[:, 0]
+                with np.errstate(invalid="ignore"):
+                    hit[:, c] = (cnt > 0) & (sims[:, 0] >= thr)
+            jj, cc = np.nonzero(hit)                           # row-major: j ascending, then robot ascending
+            add_match = self.candidate_selector.add_match
+            for j, c, r, sv in zip(jj.tolist(), cc.tolist(), best_rows[jj, cc].tolist(), best_sims[jj, cc].tolist()):
+                i = others[c]
+                match = EdgeInterRobot(me, ids[j], i, self.other_robots_nnsm[i].items[r], np.float64(sv))
+                add_match(match)
+                inter_out.append(match)
         return intra_out, inter_out
 
     def process_remote_descriptors(self, robot_id, descriptors, keyframe_ids):
@@ -214,12 +229,13 @@ class LoopClosureSparseMatching(object):
         if self.local_nnsm.n == 0:
             return out
         rows, sims, cnt = self._search(self.local_nnsm, host, dev, 1)
-        for j in range(m):
-            if cnt[j] > 0 and sims[j, 0] >= self.params['frontend.similarity_threshold']:
-                match = EdgeInterRobot(self.params['robot_id'], self.local_nnsm.items[int(rows[j, 0])],
-                                       robot_id, ids[j], sims[j, 0])
-                self.candidate_selector.add_match(match)
-                out.append(match)
+        with np.errstate(invalid="ignore"):
+            jj = np.nonzero((cnt > 0) & (sims[:, 0] >= self.params['frontend.similarity_threshold']))[0]
+        items, me = self.local_nnsm.items, self.params['robot_id']
+        for j, r, sv in zip(jj.tolist(), rows[jj, 0].tolist(), sims[jj, 0].tolist()):
+            match = EdgeInterRobot(me, items[r], robot_id, ids[j], np.float64(sv))
+            self.candidate_selector.add_match(match)
+            out.append(match)
         return out
 
     def process_remote_chunk(self, chunk, last_keyframe_received=-1):

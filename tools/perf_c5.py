@@ -24,6 +24,7 @@ def main():
     import torch
     from cslam_amd.loop_closure_sparse_matching import LoopClosureSparseMatching
     from cslam_amd.vpr.netvlad import NetVLAD
+    from cslam_amd.vpr import heads
     from cslam_amd.wire import PackedDescriptorBuffer
 
     dev = torch.device("cuda")
@@ -44,12 +45,20 @@ def main():
     def views(idx):
         noise = torch.randint(-6, 7, (len(idx), 480, 640, 3), generator=g, device=dev, dtype=torch.int16)
         return (places[idx].to(torch.int16) + noise).clamp_(0, 255).to(torch.uint8)
+    # Centre the projection like the reference's fitted PCA does (`pca.mean_`): random VLAD weights put a large
+    # common component into every descriptor (all cosines > 0.99), which is not what trained, whitened descriptors
+    # look like and sends most queries down the exact-scan fallback of the certificate.
+    with torch.no_grad():
+        nv.compute_embeddings_device(views(torch.arange(4, device=dev)))          # builds the trunk runner
+        xcal = nv.trunk(heads.preprocess(views(torch.arange(256, 512, device=dev)), 376))
+        vcal = nv.pool(xcal.contiguous())
+        nv.pca_mean_proj = (vcal @ nv.pca_components.T).mean(dim=0).contiguous()
     cal = torch.arange(64, device=dev)
     d1, d2 = nv.compute_embeddings_device(views(cal)), nv.compute_embeddings_device(views(cal))
     sims = (d1 @ d2.T).cpu().numpy()
     same, diff = np.diag(sims), sims[~np.eye(64, dtype=bool)]
     # a query is compared with thousands of rows, the calibration with 4032 pairs: stay close to the same-place side
-    thr = float(1.0 - 4.0 * (1.0 - same.min()))
+    thr = float(max(1.0 - 4.0 * (1.0 - same.min()), (same.min() + diff.max()) / 2))
     print(f"calibration: 1 - similarity: same place {1 - same.max():.2e}..{1 - same.min():.2e}, different places "
           f"{1 - diff.max():.2e}..{1 - diff.min():.2e} -> frontend.similarity_threshold 1 - {1 - thr:.2e}")
     base = params
