@@ -357,6 +357,159 @@ __global__ __launch_bounds__(QT == 1 ? 512 : 1024) void scan_exact_kernel(
     }
 }
 
+// ---------------------------------------------------------------- exact search, many queries ----
+// scan_exact_kernel streams the bank once per 4 queries: the right shape for the online case and for a handful of
+// uncertified queries, a cliff for hundreds of them (k > 16 batches, or degenerate data -- near-duplicate descriptors
+// -- that defeats the fp32 certificate: 100k queries would re-read a 1.64 GB bank 25 000 times).  This kernel
+// computes the same float64 scores for a 64-row x 32-query tile per workgroup: row and query chunks of 64 columns
+// transposed into LDS, each thread accumulating a 2 x 4 block of float64 dots in column order, then the wave-resident
+// top-k lists (one lane per row of the tile).  The bank is read once per 32 queries and the work is bound by the
+// float64 FMA rate.  Same partial-list format as scan_exact_kernel, merged by scan_merge_kernel.
+#define XT_TR 64
+#define XT_TQ 32
+#define XT_KC 64
+template <typename QS>
+__global__ __launch_bounds__(256) void exact_tile_kernel(
+    const float *__restrict__ rows, int64_t pitch, int kd, const double *__restrict__ vv, int64_t n_rows,
+    const QS *__restrict__ q, int64_t ldq, int dim,
+    const int *__restrict__ qsel, int nsel, int sel0,
+    int kk, const int64_t *__restrict__ row_limit,
+    const double *__restrict__ bound_key, const int *__restrict__ bound_idx,
+    double *__restrict__ part_key, int *__restrict__ part_idx) {
+    __shared__ float s_r[XT_KC][XT_TR];          // row chunk, transposed: [column][row]
+    __shared__ QS s_q[XT_KC][XT_TQ];             // query chunk, transposed: [column][query]
+    __shared__ double s_key[XT_TQ][XT_TR];
+    __shared__ double s_uu[XT_TQ];
+    __shared__ int s_qn[XT_TQ];
+    __shared__ int64_t s_lim[XT_TQ];
+    __shared__ double s_bk[XT_TQ];
+    __shared__ int s_bi[XT_TQ];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = gridDim.x, tile = blockIdx.y;
+    const int s_base = sel0 + tile * XT_TQ;
+    if (tid < XT_TQ) {
+        const int s = s_base + tid;
+        const bool ok = s < nsel;
+        const int qn = ok ? (qsel ? qsel[s] : s) : -1;
+        s_qn[tid] = qn;
+        int64_t lim = (ok && row_limit) ? row_limit[qn] : n_rows;
+        s_lim[tid] = ok ? (lim > n_rows ? n_rows : lim) : 0;
+        s_bk[tid] = (bound_key && ok) ? bound_key[s] : INFINITY;
+        s_bi[tid] = (bound_key && ok) ? bound_idx[s] : 0x7fffffff;
+    }
+    __syncthreads();
+    // uu = q.q in float64: wave w owns queries 8w .. 8w+7
+    for (int t = wave * 8; t < wave * 8 + 8; ++t) {
+        const int qn = s_qn[t];
+        double a = 0.0;
+        if (qn >= 0)
+            for (int c = lane; c < dim; c += 64) { double x = (double)q[(size_t)qn * ldq + c]; a += x * x; }
+        a = wave_allreduce_sum(a);
+        if (lane == 0) s_uu[t] = a;
+    }
+    WaveList list[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) list[t].init();
+    const int ri = tid & 31, qi = tid >> 5;                     // thread: rows 2ri, 2ri+1 x queries 4qi .. 4qi+3
+    const int lrow = tid & 63, lk = (tid >> 6) * 16;            // loader: row of the tile, 16 columns of the chunk
+    const int lq = tid & 31, lqk = (tid >> 5) * 8;              // loader: query of the tile, 8 columns of the chunk
+    const int ntiles = (int)((n_rows + XT_TR - 1) / XT_TR);
+    for (int rt = blockIdx.x; rt < ntiles; rt += G) {
+        const int64_t row0 = (int64_t)rt * XT_TR;
+        double acc[2][4];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
+        for (int kc = 0; kc < kd; kc += XT_KC) {
+            __syncthreads();
+            {
+                const int64_t r = row0 + lrow < n_rows ? row0 + lrow : n_rows - 1;
+                const float *src = rows + r * pitch + kc + lk;
+#pragma unroll
+                for (int j = 0; j < 16; j += 4) {
+                    float4 v = (kc + lk + j < kd) ? *(const float4 *)(src + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    s_r[lk + j][lrow] = v.x; s_r[lk + j + 1][lrow] = v.y;
+                    s_r[lk + j + 2][lrow] = v.z; s_r[lk + j + 3][lrow] = v.w;
+                }
+                const int qn = s_qn[lq];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c = kc + lqk + j;
+                    s_q[lqk + j][lq] = (qn >= 0 && c < dim) ? q[(size_t)qn * ldq + c] : (QS)0;
+                }
+            }
+            __syncthreads();
+#pragma unroll 8
+            for (int k = 0; k < XT_KC; ++k) {
+                const float2 rv = *(const float2 *)&s_r[k][2 * ri];
+                const double r0 = (double)rv.x, r1 = (double)rv.y;
+                const double q0 = (double)s_q[k][4 * qi], q1 = (double)s_q[k][4 * qi + 1];
+                const double q2 = (double)s_q[k][4 * qi + 2], q3 = (double)s_q[k][4 * qi + 3];
+                acc[0][0] += r0 * q0; acc[0][1] += r0 * q1; acc[0][2] += r0 * q2; acc[0][3] += r0 * q3;
+                acc[1][0] += r1 * q0; acc[1][1] += r1 * q1; acc[1][2] += r1 * q2; acc[1][3] += r1 * q3;
+            }
+        }
+        __syncthreads();                                         // s_key of the previous row tile fully consumed
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int64_t row = row0 + 2 * ri + a;
+            const double vvr = row < n_rows ? vv[row] : 1.0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int t = 4 * qi + b;
+                double key = -INFINITY;                          // masked out
+                if (row < s_lim[t]) {
+                    key = rank_key(sim_from_dots(acc[a][b], s_uu[t], vvr));
+                    if (!ranks_before(s_bk[t], s_bi[t], key, (int)row)) key = -INFINITY;   // reported by an earlier pass
+                    else if (key == -INFINITY) key = -1.79769313486231570e308;            // keep a real -inf score rankable
+                }
+                s_key[t][2 * ri + a] = key;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const double key = s_key[wave * 8 + t][lane];
+            const int idx = (int)(row0 + lane);
+            double tk = list[t].key_at(kk - 1);
+            int ti = list[t].idx_at(kk - 1);
+            unsigned long long m = __ballot(key != -INFINITY && ranks_before(key, idx, tk, ti));
+            while (m) {
+                const int src = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const double ck = __shfl(key, src, 64);
+                const int ci = __shfl(idx, src, 64);
+                if (ranks_before(ck, ci, tk, ti)) {
+                    list[t].insert(ck, ci, lane);
+                    tk = list[t].key_at(kk - 1);
+                    ti = list[t].idx_at(kk - 1);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int slot = tile * XT_TQ + wave * 8 + t;
+        if (s_base + wave * 8 + t < nsel && lane < kk) {
+            const size_t o = ((size_t)slot * G + blockIdx.x) * kk + lane;
+            part_key[o] = list[t].key;
+            part_idx[o] = list[t].idx;
+        }
+    }
+}
+
+template <typename QS>
+static int exact_tile_launch(cslam_bank *b, const QS *d_q, int64_t ldq, const int *d_qsel, int nsel, int sel0,
+                             int nchunk, int kk, const int64_t *d_row_limit, const double *bkey, const int *bidx,
+                             double *part_key, int *part_idx, int G, hipStream_t st) {
+    dim3 grid((unsigned)G, (unsigned)ceil_div64(nchunk, XT_TQ));
+    hipLaunchKernelGGL(exact_tile_kernel<QS>, grid, dim3(256), 0, st, b->rows, (int64_t)b->ld, b->kd, b->vv, b->n, d_q,
+                       ldq, b->dim, d_qsel, nsel, sel0, kk, d_row_limit, bkey, bidx, part_key, part_idx);
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
 // One wave per selected query: merge the G per-block lists, write the results.
 __global__ __launch_bounds__(64) void scan_merge_kernel(
     const double *__restrict__ part_key, const int *__restrict__ part_idx, int G, int kk,
@@ -451,8 +604,16 @@ int scan_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, const 
     if (G < 1) G = 1;
     const int CH = 1024;   // selected queries per launch (bounds the partial-list workspace)
     const int passes = (int)ceil_div64(k, LIST_MAX);
-    // partial lists: (queries per launch, rounded up to whole 4-query tiles) x G x entries per list
-    const size_t ch_eff = (size_t)round_up64(nsel < CH ? nsel : CH, 4);
+    // many queries: 64-row x 32-query float64 tiles (exact_tile_kernel) instead of one bank pass per 4 queries
+    const bool tiled = nsel >= 16;
+    if (tiled) {
+        const int64_t qtiles = ceil_div64(nsel < CH ? nsel : CH, XT_TQ), rtiles = ceil_div64(b->n > 0 ? b->n : 1, XT_TR);
+        G = (int)ceil_div64((int64_t)b->num_cu * 2, qtiles);
+        if (G > rtiles) G = (int)rtiles;
+        if (G < 1) G = 1;
+    }
+    // partial lists: (queries per launch, rounded up to whole query tiles) x G x entries per list
+    const size_t ch_eff = (size_t)round_up64(nsel < CH ? nsel : CH, tiled ? XT_TQ : 4);
     size_t part_elems = ch_eff * G * (size_t)(k < LIST_MAX ? k : LIST_MAX);
     size_t off_pk = 0, off_pi = off_pk + part_elems * 8, off_bk = off_pi + part_elems * 4;
     size_t off_bi = off_bk + (size_t)nsel * 8, total = off_bi + (size_t)nsel * 4;
@@ -471,7 +632,13 @@ int scan_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, const 
         int kk = k - p * LIST_MAX < LIST_MAX ? k - p * LIST_MAX : LIST_MAX;
         for (int64_t s0 = 0; s0 < nsel; s0 += CH) {
             int nchunk = (int)(nsel - s0 < CH ? nsel - s0 : CH);
-            if (q_dtype == CSLAM_F32)
+            if (tiled && q_dtype == CSLAM_F32)
+                rc = exact_tile_launch<float>(b, (const float *)d_q, ldq, d_qsel, (int)nsel, (int)s0, nchunk, kk,
+                                              d_row_limit, bkey, bidx, part_key, part_idx, G, st);
+            else if (tiled)
+                rc = exact_tile_launch<double>(b, (const double *)d_q, ldq, d_qsel, (int)nsel, (int)s0, nchunk, kk,
+                                               d_row_limit, bkey, bidx, part_key, part_idx, G, st);
+            else if (q_dtype == CSLAM_F32)
                 rc = scan_launch<float>(b, (const float *)d_q, ldq, d_qsel, (int)nsel, (int)s0, nchunk, kk,
                                         d_row_limit, bkey, bidx, part_key, part_idx, G, st);
             else

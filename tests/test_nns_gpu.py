@@ -255,3 +255,37 @@ def test_empty_bank_with_known_dim(nnm):
         assert np.all(cnt == 0) and np.all(idx == -1) and np.all(np.isnan(sims))
     items, sims = nn.search(q[0], 5)
     assert items == [] and len(sims) == 0
+
+
+@pytest.mark.parametrize("n,d,nq,k,f64", [(3000, 4096, 700, 5, False), (1111, 100, 333, 20, True),
+                                         (130, 64, 70, 70, False), (5000, 512, 1500, 3, True)])
+def test_exact_tile_kernel_many_queries_vs_oracle(nnm, n, d, nq, k, f64):
+    """MODE_SCAN with >= 16 queries runs the 64-row x 32-query float64 tile kernel (also the certificate's fallback for
+    many uncertified queries): ragged tiles, dims that are no multiple of the 64-column chunk, k > 64 lists, row limits."""
+    rng = np.random.default_rng(n + nq)
+    bank = unit_rows(rng, n, d)
+    bank[n // 2] = bank[n // 3]                                   # an exact duplicate: tie broken by the larger row
+    q = unit_rows(rng, nq, d)
+    q[: nq // 4] = bank[rng.integers(0, n, nq // 4)] * np.float32(1.5)
+    if f64:
+        q = q.astype(np.float64)
+    lim = rng.integers(0, n + 1, size=nq)
+    nn = make_bank(nnm, bank)
+    for row_limit in (None, lim):
+        idx, sims, cnt = nn.search_batch(q, k, row_limit=row_limit, mode=nnm.MODE_SCAN)
+        oi, os_, oc = pyoracle.nns_search(bank, q, k, row_limit=row_limit)
+        assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
+
+
+def test_degenerate_descriptors_fall_back_without_a_cliff(nnm):
+    """Near-duplicate descriptors (every cosine within 1e-6 of 1) defeat the fp32 certificate for most queries; the
+    float64 tile kernel answers them exactly."""
+    rng = np.random.default_rng(77)
+    base = unit_rows(rng, 1, 1024)
+    bank = (base + 2e-4 * rng.standard_normal((4000, 1024)).astype(np.float32)).astype(np.float32)
+    q = (base + 2e-4 * rng.standard_normal((600, 1024)).astype(np.float32)).astype(np.float32)
+    nn = make_bank(nnm, bank)
+    idx, sims, cnt = nn.search_batch(q, 5, mode=nnm.MODE_MFMA)
+    oi, os_, oc = pyoracle.nns_search(bank, q, 5)
+    assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
+    assert nn.last_stats()[0] > 0                                 # the fallback really ran

@@ -4,7 +4,7 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cslam_amd import nns_matching as nnm
-for n in (2500, 12500, 125000):
+for n in (2500, 12500, 125000):   # scan mode with >= 16 queries = the float64 tile kernel
     bank = torch.randn((n, 4096), device="cuda"); bank /= bank.norm(dim=1, keepdim=True)
     m = nnm.NearestNeighborsMatching(); m.add_items_device(bank)
     for dt in (torch.float32, torch.float64):
