@@ -361,12 +361,12 @@ __global__ __launch_bounds__(QT == 1 ? 512 : 1024) void scan_exact_kernel(
 // scan_exact_kernel streams the bank once per 4 queries: the right shape for the online case and for a handful of
 // uncertified queries, a cliff for hundreds of them (k > 16 batches, or degenerate data -- near-duplicate descriptors
 // -- that defeats the fp32 certificate: 100k queries would re-read a 1.64 GB bank 25 000 times).  This kernel
-// computes the same float64 scores for a 64-row x 32-query tile per workgroup: row and query chunks of 64 columns
-// transposed into LDS, each thread accumulating a 2 x 4 block of float64 dots in column order, then the wave-resident
-// top-k lists (one lane per row of the tile).  The bank is read once per 32 queries and the work is bound by the
+// computes the same float64 scores for a 64-row x 64-query tile per workgroup: row and query chunks of 64 columns
+// transposed into LDS, each thread accumulating a 4 x 4 block of float64 dots in column order, then the wave-resident
+// top-k lists (one lane per row of the tile).  The bank is read once per 64 queries and the work is bound by the
 // float64 FMA rate.  Same partial-list format as scan_exact_kernel, merged by scan_merge_kernel.
 #define XT_TR 64
-#define XT_TQ 32
+#define XT_TQ 64
 #define XT_KC 64
 template <typename QS>
 __global__ __launch_bounds__(256) void exact_tile_kernel(
@@ -376,9 +376,12 @@ __global__ __launch_bounds__(256) void exact_tile_kernel(
     int kk, const int64_t *__restrict__ row_limit,
     const double *__restrict__ bound_key, const int *__restrict__ bound_idx,
     double *__restrict__ part_key, int *__restrict__ part_idx) {
-    __shared__ float s_r[XT_KC][XT_TR];          // row chunk, transposed: [column][row]
-    __shared__ QS s_q[XT_KC][XT_TQ];             // query chunk, transposed: [column][query]
-    __shared__ double s_key[XT_TQ][XT_TR];
+    // operand chunks and the tile's keys share one buffer (the keys are written after the last chunk was consumed)
+    __shared__ __attribute__((aligned(16))) char s_buf[XT_KC * XT_TR * 4 + XT_KC * XT_TQ * sizeof(QS) > XT_TQ * XT_TR * 8
+                                                        ? XT_KC * XT_TR * 4 + XT_KC * XT_TQ * sizeof(QS) : XT_TQ * XT_TR * 8];
+    float (*s_r)[XT_TR] = (float (*)[XT_TR])s_buf;                               // [column][row]
+    QS (*s_q)[XT_TQ] = (QS (*)[XT_TQ])(s_buf + XT_KC * XT_TR * 4);                // [column][query]
+    double (*s_key)[XT_TR] = (double (*)[XT_TR])s_buf;                           // [query][row]
     __shared__ double s_uu[XT_TQ];
     __shared__ int s_qn[XT_TQ];
     __shared__ int64_t s_lim[XT_TQ];
@@ -398,8 +401,8 @@ __global__ __launch_bounds__(256) void exact_tile_kernel(
         s_bi[tid] = (bound_key && ok) ? bound_idx[s] : 0x7fffffff;
     }
     __syncthreads();
-    // uu = q.q in float64: wave w owns queries 8w .. 8w+7
-    for (int t = wave * 8; t < wave * 8 + 8; ++t) {
+    constexpr int QW = XT_TQ / 4;                                // queries (and lists) per wave
+    for (int t = wave * QW; t < wave * QW + QW; ++t) {           // uu = q.q in float64
         const int qn = s_qn[t];
         double a = 0.0;
         if (qn >= 0)
@@ -407,18 +410,17 @@ __global__ __launch_bounds__(256) void exact_tile_kernel(
         a = wave_allreduce_sum(a);
         if (lane == 0) s_uu[t] = a;
     }
-    WaveList list[8];
+    WaveList list[QW];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) list[t].init();
-    const int ri = tid & 31, qi = tid >> 5;                     // thread: rows 2ri, 2ri+1 x queries 4qi .. 4qi+3
-    const int lrow = tid & 63, lk = (tid >> 6) * 16;            // loader: row of the tile, 16 columns of the chunk
-    const int lq = tid & 31, lqk = (tid >> 5) * 8;              // loader: query of the tile, 8 columns of the chunk
+    for (int t = 0; t < QW; ++t) list[t].init();
+    const int ri = tid & 15, qi = tid >> 4;                      // thread: rows 4ri .. 4ri+3 x queries 4qi .. 4qi+3
+    const int lrow = tid & 63, lk = (tid >> 6) * 16;             // loader: row / query of the tile, 16 columns of the chunk
     const int ntiles = (int)((n_rows + XT_TR - 1) / XT_TR);
     for (int rt = blockIdx.x; rt < ntiles; rt += G) {
         const int64_t row0 = (int64_t)rt * XT_TR;
-        double acc[2][4];
+        double acc[4][4];
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 4; ++a)
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[a][b] = 0.0;
         for (int kc = 0; kc < kd; kc += XT_KC) {
@@ -426,34 +428,36 @@ __global__ __launch_bounds__(256) void exact_tile_kernel(
             {
                 const int64_t r = row0 + lrow < n_rows ? row0 + lrow : n_rows - 1;
                 const float *src = rows + r * pitch + kc + lk;
+                const int qn = s_qn[lrow];
 #pragma unroll
                 for (int j = 0; j < 16; j += 4) {
                     float4 v = (kc + lk + j < kd) ? *(const float4 *)(src + j) : make_float4(0.f, 0.f, 0.f, 0.f);
                     s_r[lk + j][lrow] = v.x; s_r[lk + j + 1][lrow] = v.y;
                     s_r[lk + j + 2][lrow] = v.z; s_r[lk + j + 3][lrow] = v.w;
                 }
-                const int qn = s_qn[lq];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int c = kc + lqk + j;
-                    s_q[lqk + j][lq] = (qn >= 0 && c < dim) ? q[(size_t)qn * ldq + c] : (QS)0;
+                for (int j = 0; j < 16; ++j) {
+                    const int c = kc + lk + j;
+                    s_q[lk + j][lrow] = (qn >= 0 && c < dim) ? q[(size_t)qn * ldq + c] : (QS)0;
                 }
             }
             __syncthreads();
-#pragma unroll 8
+#pragma unroll 4
             for (int k = 0; k < XT_KC; ++k) {
-                const float2 rv = *(const float2 *)&s_r[k][2 * ri];
-                const double r0 = (double)rv.x, r1 = (double)rv.y;
-                const double q0 = (double)s_q[k][4 * qi], q1 = (double)s_q[k][4 * qi + 1];
-                const double q2 = (double)s_q[k][4 * qi + 2], q3 = (double)s_q[k][4 * qi + 3];
-                acc[0][0] += r0 * q0; acc[0][1] += r0 * q1; acc[0][2] += r0 * q2; acc[0][3] += r0 * q3;
-                acc[1][0] += r1 * q0; acc[1][1] += r1 * q1; acc[1][2] += r1 * q2; acc[1][3] += r1 * q3;
+                const float4 rv = *(const float4 *)&s_r[k][4 * ri];
+                const double r[4] = {(double)rv.x, (double)rv.y, (double)rv.z, (double)rv.w};
+                const double qv[4] = {(double)s_q[k][4 * qi], (double)s_q[k][4 * qi + 1], (double)s_q[k][4 * qi + 2],
+                                      (double)s_q[k][4 * qi + 3]};
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) acc[a][b] += r[a] * qv[b];
             }
         }
-        __syncthreads();                                         // s_key of the previous row tile fully consumed
+        __syncthreads();                                         // last chunk consumed: the buffer becomes s_key
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            const int64_t row = row0 + 2 * ri + a;
+        for (int a = 0; a < 4; ++a) {
+            const int64_t row = row0 + 4 * ri + a;
             const double vvr = row < n_rows ? vv[row] : 1.0;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
@@ -462,15 +466,14 @@ __global__ __launch_bounds__(256) void exact_tile_kernel(
                 if (row < s_lim[t]) {
                     key = rank_key(sim_from_dots(acc[a][b], s_uu[t], vvr));
                     if (!ranks_before(s_bk[t], s_bi[t], key, (int)row)) key = -INFINITY;   // reported by an earlier pass
-                    else if (key == -INFINITY) key = -1.79769313486231570e308;            // keep a real -inf score rankable
                 }
-                s_key[t][2 * ri + a] = key;
+                s_key[t][4 * ri + a] = key;
             }
         }
         __syncthreads();
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const double key = s_key[wave * 8 + t][lane];
+        for (int t = 0; t < QW; ++t) {
+            const double key = s_key[wave * QW + t][lane];
             const int idx = (int)(row0 + lane);
             double tk = list[t].key_at(kk - 1);
             int ti = list[t].idx_at(kk - 1);
@@ -489,9 +492,9 @@ __global__ __launch_bounds__(256) void exact_tile_kernel(
         }
     }
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const int slot = tile * XT_TQ + wave * 8 + t;
-        if (s_base + wave * 8 + t < nsel && lane < kk) {
+    for (int t = 0; t < QW; ++t) {
+        const int slot = tile * XT_TQ + wave * QW + t;
+        if (s_base + wave * QW + t < nsel && lane < kk) {
             const size_t o = ((size_t)slot * G + blockIdx.x) * kk + lane;
             part_key[o] = list[t].key;
             part_idx[o] = list[t].idx;

@@ -260,7 +260,7 @@ def test_empty_bank_with_known_dim(nnm):
 @pytest.mark.parametrize("n,d,nq,k,f64", [(3000, 4096, 700, 5, False), (1111, 100, 333, 20, True),
                                          (130, 64, 70, 70, False), (5000, 512, 1500, 3, True)])
 def test_exact_tile_kernel_many_queries_vs_oracle(nnm, n, d, nq, k, f64):
-    """MODE_SCAN with >= 16 queries runs the 64-row x 32-query float64 tile kernel (also the certificate's fallback for
+    """MODE_SCAN with >= 16 queries runs the 64-row x 64-query float64 tile kernel (also the certificate's fallback for
     many uncertified queries): ragged tiles, dims that are no multiple of the 64-column chunk, k > 64 lists, row limits."""
     rng = np.random.default_rng(n + nq)
     bank = unit_rows(rng, n, d)
