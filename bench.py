@@ -9,9 +9,13 @@ One step (BASELINE config 3, per rank = per robot):
     B synthetic 640x480 RGB keyframes already in HBM (uint8, seeded on device)
       -> NetVLAD extract: crop/bicubic-resize/normalise [HIP] -> VGG-16 conv5_3 [PyTorch-ROCm, fp32]
          -> VLAD aggregation [HIP] -> PCA 32768->4096 + L2 [HIP fp32 MFMA]
-      -> (N > 1) RCCL all-gather of the new descriptors: every robot sees every query
-      -> top-5 against the rank's resident 100k x 4096 bank for its own keyframes and best-1 for
-         the other robots' keyframes [HIP: sim_topk_mfma + float64 re-score]
+      -> (N > 1) RCCL all-gather of the new descriptors: every rank sees every query
+      -> top-5 against the resident 100k x 4096 bank [HIP: sim_topk_mfma + float64 re-score].
+         N > 1, --shard-mode rows (default): the bank of the metric is split by rows over the ranks, every
+         rank scores all N*B new descriptors against its 100k/N rows, one all-to-all returns the lists to the
+         keyframes' owners and cslam_topk_merge_dev picks the exact whole-bank top-5 (SURVEY 8e);
+         --shard-mode robots: BASELINE config 4's shape, one full bank per rank (= per robot), top-5 for
+         its own keyframes and best-1 for the other robots' keyframes
 value = keyframes processed by all ranks / max-over-ranks time of exactly K steps.
 The JSON line also carries: match_only / extract_only throughputs (the two legs timed
 separately), `roofline` of the dominant hand-written kernel (sim_topk_mfma, HIP-event timed on
@@ -50,6 +54,12 @@ def parse():
     ap.add_argument("--cpu-queries", type=int, default=48, help="cpu_baseline sample size (queries)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extract", action="store_true", help="debug: time the match leg only")
+    ap.add_argument("--shard-mode", default="rows", choices=["rows", "robots"],
+                    help="N > 1 only.  rows (default): the ONE --bank-rows bank of the metric is split by rows over "
+                         "the ranks, every keyframe gets its top-k over the whole bank (all-gather of descriptors, "
+                         "local top-k, all-to-all of the lists, HIP merge; SURVEY 8e).  robots: BASELINE config 4's "
+                         "shape, every rank owns a full --bank-rows bank of its own robot and scores everybody's "
+                         "keyframes against it (pair work per rank grows with N)")
     ap.add_argument("--debug-shared-gpu", action="store_true",
                     help="debug only: all ranks share cuda:0 and exchange descriptors through gloo/CPU, to "
                          "exercise the N>1 control flow on a 1-GPU box (numbers are meaningless)")
@@ -61,7 +71,7 @@ def main():
     import torch
     import torch.distributed as dist
     from cslam_amd import nns_matching as nnm
-    from cslam_amd.sharded import ShardedInterRobotMatcher
+    from cslam_amd.sharded import RowShardedBankMatcher, ShardedInterRobotMatcher
     from cslam_amd.vpr.netvlad import NetVLAD
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,8 +92,11 @@ def main():
     torch.backends.cudnn.benchmark = True
 
     # ---- resident state: this robot's bank (BASELINE.md recipe: unit-norm Gaussian rows) ----
+    rows_mode = world > 1 and a.shard_mode == "rows"
+    offs = [g * a.bank_rows // world for g in range(world + 1)] if rows_mode else [0, a.bank_rows]
+    local_rows = offs[rank + 1] - offs[rank] if rows_mode else a.bank_rows     # rows resident on this GPU
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    bank = torch.randn((a.bank_rows, a.dim), generator=gen, device=dev, dtype=torch.float32)
+    bank = torch.randn((local_rows, a.dim), generator=gen, device=dev, dtype=torch.float32)
     bank /= bank.norm(dim=1, keepdim=True)
     nn = nnm.NearestNeighborsMatching(device=local_rank)
     nn.add_items_device(bank)
@@ -108,14 +121,22 @@ def main():
         kernel_ms.append(nn.last_kernel_ms())
         return out
 
-    gather_fn = None
+    hooks = {}
     if a.debug_shared_gpu and world > 1:
-        def gather_fn(local, world_size, group=None):          # gloo has no device all-gather: stage through the host
+        def gather_fn(local, world_size, group=None):          # gloo has no device collectives: stage through the host
             out = torch.empty((world_size * local.shape[0], local.shape[1]), dtype=local.dtype)
             dist.all_gather_into_tensor(out, local.cpu().contiguous())
             return out.to(local.device)
-    matcher = (ShardedInterRobotMatcher(rank, world, search, k_intra=a.k, gather_fn=gather_fn) if gather_fn
-               else ShardedInterRobotMatcher(rank, world, search, k_intra=a.k))
+
+        def exchange_fn(packed, world_size, group=None):
+            out = torch.empty(packed.shape, dtype=packed.dtype)
+            dist.all_to_all_single(out, packed.cpu().contiguous())
+            return out.to(packed.device)
+        hooks = {"gather_fn": gather_fn}
+        if rows_mode:
+            hooks["exchange_fn"] = exchange_fn
+    matcher = (RowShardedBankMatcher(rank, world, search, offs, k=a.k, **hooks) if rows_mode
+               else ShardedInterRobotMatcher(rank, world, search, k_intra=a.k, **hooks))
 
     def extract():
         if extractor is None:
@@ -165,7 +186,9 @@ def main():
     kernel_ms.clear()
     dm = timed(lambda: search(mq, a.k), max(1, min(a.steps, 2)))
     nm = max(1, min(a.steps, 2))
-    match_only = world * nqm * nm / dm
+    # rows mode: the ranks together hold ONE bank, so nqm queries per rank against every shard = nqm whole-bank
+    # searches (merge not included in this leg); otherwise every rank searches its own full bank
+    match_only = (1 if rows_mode else world) * nqm * nm / dm
     match_kernel_ms = float(np.mean(kernel_ms))
     uncertified = nn.last_stats()[0]
 
@@ -174,18 +197,18 @@ def main():
     nq_step = world * a.batch if world > 1 else a.batch
     # primary: the full C3 batch launch (100k queries) of the timed match leg; the smaller
     # launches inside the extract+match steps are reported alongside
-    ach = 2.0 * nqm * a.bank_rows * a.dim / (match_kernel_ms * 1e-3) / 1e12
+    ach = 2.0 * nqm * local_rows * a.dim / (match_kernel_ms * 1e-3) / 1e12
     src = "match-leg launches (%d queries), HIP events on the launch stream" % nqm
     in_step = None
     if step_kernel_ms and world == 1:
-        in_step = round(2.0 * nq_step * a.bank_rows * a.dim / (np.mean(step_kernel_ms) * 1e-3) / 1e12, 2)
+        in_step = round(2.0 * nq_step * local_rows * a.dim / (np.mean(step_kernel_ms) * 1e-3) / 1e12, 2)
     # HBM-side traffic per launch comes from the committed rocprofv3 PMC passes of this same
     # match leg (tools/gpu_pmc.sh + tools/pmc_summary.py; FETCH_SIZE x2 correction per the
     # MI355X guide); it cannot be collected inside an unprofiled run.
     traffic, traffic_src = None, None
     try:
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
-        if cands and a.bank_rows == 100_000 and a.dim == 4096:
+        if cands and local_rows == 100_000 and a.dim == 4096:
             pm = json.load(open(cands[-1]))
             traffic = pm.get("traffic_bytes")
             traffic_src = os.path.basename(cands[-1]) + " (100k-query launch; L2 hit rate %.2f)" % pm.get("l2_hit_rate", float("nan"))
@@ -279,10 +302,14 @@ def main():
             "data": "synthetic (seeded on-device uint8 640x480 frames, unit-norm Gaussian bank, random-init "
                     "VGG-16/VLAD/PCA weights: the reference ships no checkpoints)",
             "config": {"workload": "C3: NetVLAD VGG-16 4096-D extract + D.D^T MFMA similarity + top-5, "
-                                   f"{a.bank_rows}-row bank per GPU" + ("" if extractor else " [match leg only]"),
+                                   f"{a.bank_rows}-row bank" + (" per GPU" if not rows_mode else "") + ("" if extractor else " [match leg only]"),
                        "bank_rows": a.bank_rows, "dim": a.dim, "keyframes_per_rank_per_step": a.batch, "k": a.k,
                        "queries_per_rank_per_step": nq_step,
-                       "parallelism": "1 robot bank per GPU, RCCL all-gather of new descriptors" if world > 1 else "single GPU"},
+                       "bank_rows_per_gpu": local_rows,
+                       "parallelism": ("single GPU" if world == 1 else
+                                       "one %d-row bank split by rows over %d GPUs: RCCL all-gather of the new descriptors, "
+                                       "local top-k, all-to-all of the lists, HIP merge" % (a.bank_rows, world) if rows_mode
+                                       else "1 robot bank per GPU, RCCL all-gather of new descriptors")},
             "extract_only": None if extract_only is None else round(extract_only, 2),
             "backbone_conv": None if extractor is None else extractor.backbone_conv,
             "match_only": round(match_only, 2),

@@ -40,6 +40,7 @@ _SIGNATURES = {
     "cslam_bank_search_dev": (_i, [_vp, _vp, _i, _i64, _i64, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "cslam_bank_last_stats": (_i, [_vp, C.POINTER(_i64 * 4)]),
     "cslam_bank_last_kernel_ms": (_i, [_vp, C.POINTER(_f)]),
+    "cslam_topk_merge_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp]),
     "cslam_l2_normalize_dev": (_i, [_vp, _i64, _i, _i64, _f, _i, _vp]),
     "cslam_vlad_aggregate_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp]),
     "cslam_gem_fc_head_dev": (_i, [_vp, _f, _f, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -725,3 +725,64 @@ CSLAM_API int cslam_bank_last_stats(cslam_bank_t *b, int64_t stats[4]) {
     for (int i = 0; i < 4; ++i) stats[i] = b->stats[i];
     return CSLAM_OK;
 }
+
+// ---- merge of per-shard top-k lists (one bank row-sharded over several GPUs) ----------------
+// The global top-k of a query is contained in the union of its per-shard top-k lists; shard s holds the
+// global rows [row_offset[s], row_offset[s] + n_s).  One thread per query picks the k best of the <= S*k
+// entries in the shared ranking order (larger key, NaN first, ties -> larger GLOBAL row): k rounds of
+// "best entry ranking after the previous pick".  Rows are unique across shards, so the order is strict.
+struct MergeOffsets { int64_t off[64]; };
+
+__global__ __launch_bounds__(64) void topk_merge_kernel(const int64_t *__restrict__ idx, const double *__restrict__ sim,
+                                                        const int32_t *__restrict__ cnt, MergeOffsets offs, int S,
+                                                        int64_t nq, int k, int64_t *__restrict__ out_idx,
+                                                        double *__restrict__ out_sim, int32_t *__restrict__ out_cnt) {
+    int64_t q = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (q >= nq) return;
+    double last_key = 0.0;
+    int64_t last_row = 0;
+    int produced = 0;
+    for (int j = 0; j < k; ++j) {
+        bool have = false;
+        double bkey = 0.0, bsim = 0.0;
+        int64_t brow = -1;
+        for (int s = 0; s < S; ++s) {
+            int c = cnt[(int64_t)s * nq + q];
+            c = c < 0 ? 0 : (c > k ? k : c);
+            const int64_t *li = idx + ((int64_t)s * nq + q) * k;
+            const double *ls = sim + ((int64_t)s * nq + q) * k;
+            for (int e = 0; e < c; ++e) {
+                double v = ls[e];
+                double key = rank_key(v);
+                int64_t row = li[e] + offs.off[s];
+                // entry must rank strictly after the previous pick ...
+                if (j > 0 && !(last_key > key || (last_key == key && last_row > row))) continue;
+                // ... and before the best seen so far in this round
+                if (!have || key > bkey || (key == bkey && row > brow)) { have = true; bkey = key; bsim = v; brow = row; }
+                else break;   // the list is sorted: nothing further down can beat this shard's first eligible entry
+            }
+        }
+        if (!have) break;
+        out_idx[q * k + j] = brow;
+        out_sim[q * k + j] = bsim;
+        last_key = bkey; last_row = brow;
+        ++produced;
+    }
+    for (int j = produced; j < k; ++j) { out_idx[q * k + j] = -1; out_sim[q * k + j] = NAN; }
+    out_cnt[q] = produced;
+}
+
+CSLAM_API int cslam_topk_merge_dev(const int64_t *d_idx, const double *d_sim, const int32_t *d_cnt,
+                                   const int64_t *row_offset, int shards, int64_t nq, int k,
+                                   int64_t *d_out_idx, double *d_out_sim, int32_t *d_out_cnt, void *stream) {
+    ARG_CHECK(d_idx && d_sim && d_cnt && row_offset && d_out_idx && d_out_sim && d_out_cnt, "NULL argument");
+    ARG_CHECK(shards >= 1 && shards <= 64, "shards must be in [1, 64]");
+    ARG_CHECK(nq >= 0 && k >= 1, "nq >= 0 and k >= 1 required");
+    if (nq == 0) return CSLAM_OK;
+    MergeOffsets offs;
+    for (int s = 0; s < 64; ++s) offs.off[s] = s < shards ? row_offset[s] : 0;
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)ceil_div64(nq, 64)), dim3(64), 0, (hipStream_t)stream,
+                       d_idx, d_sim, d_cnt, offs, shards, nq, k, d_out_idx, d_out_sim, d_out_cnt);
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}

@@ -41,8 +41,8 @@ class NetVLADLayer(object):
     """Parameters of the reference's NetVLADLayer (netvlad.py:28-61): 1x1 soft-assignment conv
     (no bias in vladv1) and cluster centroids; forward runs in HIP."""
 
-    def __init__(self, num_clusters=64, dim=512, device="cuda"):
-        self.num_clusters, self.dim = num_clusters, dim
+    def __init__(self, num_clusters=64, dim=512, device="cuda", vladv2=False):
+        self.num_clusters, self.dim, self.vladv2, self.alpha = num_clusters, dim, bool(vladv2), 0
         self.conv_weight = torch.zeros((num_clusters, dim), dtype=torch.float32, device=device)
         self.conv_bias = None
         self.centroids = torch.rand((num_clusters, dim), dtype=torch.float32, device=device)
@@ -52,6 +52,34 @@ class NetVLADLayer(object):
         self.conv_weight = torch.as_tensor(conv_weight, dtype=torch.float32).reshape(self.num_clusters, self.dim).contiguous().to(dev)
         self.centroids = torch.as_tensor(centroids, dtype=torch.float32).contiguous().to(dev)
         self.conv_bias = None if conv_bias is None else torch.as_tensor(conv_bias, dtype=torch.float32).contiguous().to(dev)
+
+    def init_params(self, clsts, traindescs):
+        """Training-time initialisation from k-means clusters `clsts` [K, C] and sampled training descriptors
+        `traindescs` [n, C] (reference netvlad.py:63-92; host arithmetic, as there -- it runs once before training
+        and is not on the extract path).  vladv1: alpha = -ln(0.01) / mean gap between the two largest
+        unit-cluster dots of every descriptor, assignment weight = alpha * clsts/|clsts|, no bias.  vladv2: alpha
+        from the two nearest training descriptors of every cluster -- the reference squares what
+        `kneighbors(clsts, 2)[1]` returns, i.e. the neighbour INDICES, and that is reproduced --, weight =
+        2 alpha * centroids, bias = -alpha * |centroids|."""
+        clsts = np.asarray(clsts)
+        traindescs = np.asarray(traindescs)
+        assert clsts.shape == (self.num_clusters, self.dim) and traindescs.ndim == 2 and traindescs.shape[1] == self.dim
+        if not self.vladv2:
+            assign = clsts / np.linalg.norm(clsts, axis=1, keepdims=True)
+            dots = np.dot(assign, traindescs.T)
+            dots.sort(0)
+            dots = dots[::-1, :]
+            self.alpha = (-np.log(0.01) / np.mean(dots[0, :] - dots[1, :])).item()
+            self.load(self.alpha * assign, clsts, None)
+        else:
+            c64, t64 = clsts.astype(np.float64), traindescs.astype(np.float64)
+            d2 = (c64 * c64).sum(1)[:, None] - 2.0 * c64 @ t64.T + (t64 * t64).sum(1)[None, :]
+            two = np.argsort(d2, axis=1, kind="stable")[:, :2]                 # 2 nearest descriptors, nearest first
+            ds_sq = np.square(two)
+            self.alpha = (-np.log(0.01) / np.mean(ds_sq[:, 1] - ds_sq[:, 0])).item()
+            cent = torch.as_tensor(clsts, dtype=torch.float32)
+            self.load((2.0 * self.alpha * cent).numpy(), clsts, (-self.alpha * cent.norm(dim=1)).numpy())
+        return self
 
     def forward(self, x):
         return heads.vlad_aggregate(x.contiguous(), self.conv_weight, self.conv_bias, self.centroids)

@@ -98,6 +98,17 @@ int cslam_bank_last_stats(cslam_bank_t *bank, int64_t stats[4]);
 /* time (ms, HIP events on the launch stream) of the dominant kernel of the last
  * MFMA-mode search: sim_topk_mfma.  -1 if the last search did not use it.        */
 int cslam_bank_last_kernel_ms(cslam_bank_t *bank, float *ms);
+/* One bank row-sharded over several GPUs (the single-bank metric at > 1 GPU): merge of the
+ * per-shard results of cslam_bank_search_dev into the top-k of the whole bank -- what
+ * `argsort(sim)[::-1][:k]` (cslam/nns_matching.py:60-61) returns over all rows, because the global top-k
+ * is contained in the union of the per-shard top-k lists.  Shard s holds the global rows
+ * [row_offset[s], row_offset[s] + n_s); row_offset is a HOST array of `shards` (<= 64) entries.
+ * d_idx / d_sim [shards, nq, k] and d_cnt [shards, nq] are the shards' outputs (each list in search order,
+ * shard-local rows); outputs as cslam_bank_search_dev with GLOBAL rows; same order: descending similarity,
+ * NaN first, ties -> larger global row.  Similarities are passed through bit for bit.            */
+int cslam_topk_merge_dev(const int64_t *d_idx, const double *d_sim, const int32_t *d_cnt,
+                         const int64_t *row_offset, int shards, int64_t nq, int k,
+                         int64_t *d_out_idx, double *d_out_sim, int32_t *d_out_cnt, void *stream);
 
 /* ---- descriptor heads (device pointers; all float32) -------------------------- */
 /* rows of x [n, d] (stride ld) scaled to unit L2 norm, x / max(||x||, eps);

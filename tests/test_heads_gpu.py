@@ -365,3 +365,21 @@ def test_tuned_gemm_table_is_loaded_and_harmless(T):
     assert torch.allclose(torch.bmm(a, b), torch.einsum("bij,bjk->bik", a.double(), b.double()).float(), atol=1e-3)
     names = [r[1] for r in tunable.get_results()]
     assert any(n.startswith("nn_512_12544_512_B_36") for n in names), names[:5]
+
+
+def test_vlad_init_params_matches_reference(T):
+    """NetVLADLayer.init_params (netvlad.py:63-92) on the reference's own outputs (G12): alpha,
+    assignment weights / bias, centroids, and a forward pass of the initialised layer through the HIP kernel --
+    vladv1 (no bias) and vladv2 (bias; the reference squares the neighbour indices, reproduced)."""
+    from cslam_amd.vpr.netvlad import NetVLADLayer
+    g = np.load(GOLDEN + "/vlad_init_g12.npz")
+    for tag, v2 in (("v1", False), ("v2", True)):
+        layer = NetVLADLayer(64, 32, device="cuda", vladv2=v2).init_params(g["clsts"], g["train"])
+        assert abs(layer.alpha - float(g[tag + "/alpha"])) <= 1e-6 * abs(float(g[tag + "/alpha"]))
+        assert np.allclose(layer.conv_weight.cpu().numpy(), g[tag + "/conv_w"], rtol=1e-6, atol=0)
+        assert np.array_equal(layer.centroids.cpu().numpy(), g[tag + "/centroids"])
+        assert (layer.conv_bias is None) == (not v2)
+        if v2:
+            assert np.allclose(layer.conv_bias.cpu().numpy(), g[tag + "/conv_b"], rtol=1e-6, atol=0)
+        y = layer(dev(T, g["x"])).cpu().numpy()
+        assert y.shape == g[tag + "/y"].shape and np.max(np.abs(y - g[tag + "/y"])) < 1e-6

@@ -289,3 +289,68 @@ def test_degenerate_descriptors_fall_back_without_a_cliff(nnm):
     oi, os_, oc = pyoracle.nns_search(bank, q, 5)
     assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
     assert nn.last_stats()[0] > 0                                 # the fallback really ran
+
+
+@pytest.mark.parametrize("cuts,k", [((0, 150, 400), 8), ((0, 398, 400), 5), ((0, 100, 200, 300, 400), 1),
+                                    ((0, 34, 35, 400), 16)])
+def test_row_sharded_bank_merge_equals_whole_bank(nnm, cuts, k):
+    """one bank split by rows over several GPUs.  Per-shard searches (here: several banks on one GPU)
+    merged by cslam_topk_merge_dev give the whole-bank result bit for bit -- rows, float64 scores, counts --
+    including exact ties across shards (larger global row first), NaN scores (first) and shards shorter than k.
+    Every search runs the exact float64 kernel (MODE_SCAN) so that duplicate rows living in different shards get
+    bit-identical scores: the scoring kernels agree to ~1e-16, not to the bit, and the order of EXACT duplicates
+    across shards is only defined when one kernel scored them all (tie-free data: next test, MFMA mode)."""
+    import torch
+    from cslam_amd.sharded import merge_topk_device
+    rng = np.random.default_rng(4)
+    bank = rng.standard_normal((400, 128)).astype(np.float32)
+    bank[100] = bank[7]; bank[250] = bank[7]; bank[399] = bank[7]      # exact ties in different shards
+    bank[33] = 0.0; bank[301] = 0.0                                     # NaN scores in different shards
+    q = np.concatenate([bank[7:8], rng.standard_normal((140, 128)).astype(np.float32)])
+    oi, os_, oc = pyoracle.nns_search(bank, q, k)
+    whole = make_bank(nnm, bank)
+    dq = torch.from_numpy(q).cuda()
+    wi, ws, wc = whole.search_device(dq, k, mode=nnm.MODE_SCAN)
+    parts = []
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        parts.append(make_bank(nnm, bank[lo:hi]).search_device(dq, k, mode=nnm.MODE_SCAN))
+    mi, ms, mc = merge_topk_device(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]),
+                                   torch.stack([p[2] for p in parts]), cuts[:-1])
+    torch.cuda.synchronize()
+    assert_topk_equal(mi.cpu().numpy(), ms.cpu().numpy(), mc.cpu().numpy(), oi, os_, oc, 1e-12)
+    assert torch.equal(mi, wi) and torch.equal(mc, wc)
+    assert np.array_equal(ms.cpu().numpy().view(np.int64), ws.cpu().numpy().view(np.int64))   # scores bit for bit
+
+
+def test_row_sharded_matcher_single_process(nnm):
+    """RowShardedBankMatcher.step end to end on the GPU with the exchange replaced by an in-process transpose
+    (2 simulated ranks on one device): each rank's keyframes get the oracle's top-k over the whole bank."""
+    import torch
+    from cslam_amd.sharded import RowShardedBankMatcher
+    bank = unit_rows(np.random.default_rng(11), 3000, 256)
+    offs = [0, 1700, 3000]
+    shards = [make_bank(nnm, bank[offs[g]:offs[g + 1]]) for g in range(2)]
+    qs = [torch.from_numpy(unit_rows(np.random.default_rng(20 + g), 64, 256)).cuda() for g in range(2)]
+    allq = torch.cat(qs)
+    packed = {}
+
+    def run(g, sink):
+        m = RowShardedBankMatcher(g, 2, lambda q, k: shards[g].search_device(q, k, mode=nnm.MODE_MFMA), offs, k=5,
+                                  gather_fn=lambda local, w: allq, exchange_fn=sink)
+        return m.step(qs[g])
+
+    class _Stop(Exception):
+        pass
+
+    def capture(g):
+        def sink(p, w):
+            packed[g] = p.clone()
+            raise _Stop()
+        return sink
+    for g in range(2):                                  # pass 1: record what every rank would send
+        with pytest.raises(_Stop):
+            run(g, capture(g))
+    for g in range(2):                                  # pass 2: deliver slice g of every rank's buffer
+        rows, sims, cnt = run(g, lambda p, w: torch.stack([packed[s][g] for s in range(2)]))
+        oi, os_, oc = pyoracle.nns_search(bank, qs[g].cpu().numpy(), 5)
+        assert_topk_equal(rows.cpu().numpy(), sims.cpu().numpy(), cnt.cpu().numpy(), oi, os_, oc, 1e-12)

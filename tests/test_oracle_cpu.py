@@ -69,3 +69,20 @@ def test_oracle_cosine_equals_euclidean_order():
         for j in range(100):
             if order[j] != idx[0, j]:
                 assert abs(ds[order[j]] - ds[idx[0, j]]) < 1e-6
+
+
+def test_vlad_init_params_host_logic_matches_reference():
+    """SURVEY 8 row a5 (host arithmetic, no GPU): NetVLADLayer.init_params against the reference's own outputs
+    (G12, oracle/gen_golden_vlad_init.py), and the numpy oracle's forward pass of the initialised layers."""
+    from cslam_amd.vpr.netvlad import NetVLADLayer
+    from oracle import heads_oracle as ho
+    g = np.load(GOLDEN + "/vlad_init_g12.npz")
+    for tag, v2 in (("v1", False), ("v2", True)):
+        layer = NetVLADLayer(64, 32, device="cpu", vladv2=v2).init_params(g["clsts"], g["train"])
+        assert abs(layer.alpha - float(g[tag + "/alpha"])) <= 1e-6 * abs(float(g[tag + "/alpha"]))
+        assert np.allclose(layer.conv_weight.numpy(), g[tag + "/conv_w"], rtol=1e-6, atol=0)
+        assert np.array_equal(layer.centroids.numpy(), g[tag + "/centroids"])
+        b = None if not v2 else layer.conv_bias.numpy()
+        assert (b is None) == (tag + "/conv_b" not in g.files)
+        y = ho.vlad_forward(g["x"], layer.conv_weight.numpy(), b, layer.centroids.numpy())
+        assert np.max(np.abs(y - g[tag + "/y"])) < 1e-6

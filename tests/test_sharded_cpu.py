@@ -4,6 +4,7 @@ import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -63,3 +64,71 @@ def test_single_rank_is_passthrough():
     m = ShardedInterRobotMatcher(0, 1, search, k_intra=7)
     intra, inter = m.step(torch.zeros(3, 8))
     assert inter is None and calls == [((3, 8), 7)]
+
+
+# ---- one bank row-sharded over the ranks (the single-bank metric at > 1 GPU) ----------------
+def _host_merge(rows, sims, cnt, row_offsets):
+    """Test stand-in for cslam_topk_merge_dev (the product merge is the HIP kernel; tests/test_nns_gpu.py checks
+    that one): k best of the shards' lists, descending similarity, NaN first, ties -> larger global row."""
+    S, m, k = rows.shape
+    out_r = np.full((m, k), -1, np.int64)
+    out_s = np.full((m, k), np.nan)
+    out_c = np.zeros(m, np.int32)
+    for q in range(m):
+        ent = [(np.inf if np.isnan(sims[s, q, e]) else sims[s, q, e], int(rows[s, q, e]) + int(row_offsets[s]),
+                sims[s, q, e]) for s in range(S) for e in range(int(cnt[s, q]))]
+        ent.sort(key=lambda t: (t[0], t[1]), reverse=True)
+        for j, (_, r, v) in enumerate(ent[:k]):
+            out_r[q, j], out_s[q, j] = r, v
+        out_c[q] = min(k, len(ent))
+    return torch.from_numpy(out_r), torch.from_numpy(out_s), torch.from_numpy(out_c)
+
+
+def _row_worker(rank, world, port, outdir, shard_rows):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cslam_amd.sharded import RowShardedBankMatcher
+    from oracle import pyoracle
+    from helpers import unit_rows
+    offs = np.concatenate(([0], np.cumsum(shard_rows)))
+    whole = unit_rows(np.random.default_rng(99), int(offs[-1]), 64)
+    shard = whole[offs[rank]:offs[rank + 1]]
+
+    def search(q, k):
+        i, s, c = pyoracle.nns_search(shard, q.numpy(), k)
+        return torch.from_numpy(i), torch.from_numpy(s), torch.from_numpy(c)
+
+    merge = lambda r, s, c, o: _host_merge(r.numpy(), s.numpy(), c.numpy(), o)      # noqa: E731
+    m = RowShardedBankMatcher(rank, world, search, offs[:world], k=5, merge_fn=merge)
+    local = torch.from_numpy(unit_rows(np.random.default_rng(4321 + rank), 40, 64))
+    rows, sims, cnt = m.step(local)
+    np.savez(os.path.join(outdir, f"s{rank}.npz"), rows=rows.numpy(), sims=sims.numpy(), cnt=cnt.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shard_rows", [(300, 300), (597, 3)])
+def test_two_rank_gloo_row_sharded_bank(tmp_path, shard_rows):
+    """Each rank's keyframes get the top-k of the WHOLE bank: indices and float64 scores identical to the
+    oracle on the unsharded bank (the 3-row shard returns fewer than k entries to the merge)."""
+    from helpers import unit_rows
+    from oracle import pyoracle
+    world, port = 2, 30500 + (os.getpid() % 1000)
+    mp.spawn(_row_worker, args=(world, port, str(tmp_path), shard_rows), nprocs=world, join=True)
+    whole = unit_rows(np.random.default_rng(99), sum(shard_rows), 64)
+    for r in range(world):
+        q = unit_rows(np.random.default_rng(4321 + r), 40, 64)
+        i, s, c = pyoracle.nns_search(whole, q, 5)
+        got = np.load(tmp_path / f"s{r}.npz")
+        assert np.array_equal(got["rows"], i) and np.array_equal(got["sims"], s) and np.array_equal(got["cnt"], c)
+
+
+def test_host_merge_stand_in_order():
+    rows = np.array([[[2, 0, -1]], [[1, 0, -1]]])                      # shard 0: rows 2,0 ; shard 1: rows 1,0
+    sims = np.array([[[0.5, 0.25, np.nan]], [[np.nan, 0.5, np.nan]]])   # shard 1 starts with a NaN score
+    r, s, c = _host_merge(rows, sims, np.array([[2], [2]]), [0, 10])
+    assert r.tolist() == [[11, 10, 2]] and c.tolist() == [3]            # NaN first, tie 0.5 -> larger global row
+    assert np.isnan(s[0, 0]) and s[0, 1:].tolist() == [0.5, 0.5]
