@@ -236,6 +236,69 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(const float *__restrict
     }
 }
 
+// Cout = 64 form of the same layer (VGG-16 conv1_1).  The generic kernel above spends most of its issue slots on
+// per-pixel index arithmetic (64-bit div / mod, 27 predicated tap loads repeated by all four waves: ~590 of its 808
+// VALU instructions per wave) rather than on its 216 packed FMAs.  Here a workgroup owns a 32-wide x 2-high pixel
+// tile addressed by a 3-D grid (no division), the 3 x 4 x 34 input patch with its zero border is staged ONCE in
+// LDS, every lane reads its 27 taps from there, wave w computes channels [16w, 16w+16), and the 64 x 64 tile goes
+// out through LDS as whole NHWC pixels (8 KiB contiguous per tile row).
+#define C3T_W 32
+#define C3T_H 2
+#define C3T_PW (C3T_W + 2)
+__global__ __launch_bounds__(256) void conv3x3_c3_tile64_kernel(const float *__restrict__ x, const float *__restrict__ wt,
+                                                                const float *__restrict__ bias, int H, int W, int relu,
+                                                                float *__restrict__ y) {
+    constexpr int COUT = 64, P = COUT + 4;
+    __shared__ float s_in[3 * (C3T_H + 2) * C3T_PW];            // [ci][row][col], zero border included
+    __shared__ __attribute__((aligned(16))) float s_t[C3T_W * C3T_H * P];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w0 = blockIdx.x * C3T_W, h0 = blockIdx.y * C3T_H;
+    const int64_t b = blockIdx.z;
+    const float *xb = x + b * 3 * (int64_t)H * W;
+    for (int e = threadIdx.x; e < 3 * (C3T_H + 2) * C3T_PW; e += 256) {
+        const int ci = e / ((C3T_H + 2) * C3T_PW), r = (e / C3T_PW) % (C3T_H + 2), c = e % C3T_PW;   // constant divisors
+        const int hh = h0 + r - 1, ww = w0 + c - 1;
+        const bool in = (hh >= 0) & (hh < H) & (ww >= 0) & (ww < W);
+        s_in[e] = in ? xb[((int64_t)ci * H + hh) * W + ww] : 0.0f;
+    }
+    __syncthreads();
+    const int pr = lane >> 5, pc = lane & 31;                   // this lane's pixel inside the tile
+    float v[27];
+#pragma unroll
+    for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+                v[ci * 9 + kh * 3 + kw] = s_in[(ci * (C3T_H + 2) + pr + kh) * C3T_PW + pc + kw];
+    const int co0 = wave * C3_CG;
+    float acc[C3_CG];
+#pragma unroll
+    for (int j = 0; j < C3_CG; ++j) acc[j] = bias ? bias[co0 + j] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+        const float *wk = wt + k * COUT + co0;                  // wave-uniform address: scalar loads
+#pragma unroll
+        for (int j = 0; j < C3_CG; ++j) acc[j] = fmaf(wk[j], v[k], acc[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < C3_CG; j += 4) {
+        f4 o = {acc[j], acc[j + 1], acc[j + 2], acc[j + 3]};
+        if (relu) o = __builtin_elementwise_max(o, (f4)(0.0f));
+        *((f4 *)(s_t + lane * P + co0 + j)) = o;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < (C3T_W * C3T_H * (COUT / 4)) / 256; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        const int p = e >> 4, c4 = e & 15;                      // COUT / 4 = 16 float4 per pixel
+        const int hh = h0 + (p >> 5), ww = w0 + (p & 31);
+        if (hh < H && ww < W)
+            *((f4 *)(y + ((b * H + hh) * (int64_t)W + ww) * COUT) + c4) = *((const f4 *)(s_t + p * P) + c4);
+    }
+}
+
 CSLAM_API int cslam_conv3x3_c3_dev(const float *d_x, const float *d_wt, const float *d_bias, int B, int H, int W,
                                    int Cout, int relu, float *d_y, void *stream) {
     ARG_CHECK(d_x && d_wt && d_y, "NULL argument");
@@ -244,6 +307,12 @@ CSLAM_API int cslam_conv3x3_c3_dev(const float *d_x, const float *d_wt, const fl
     const int64_t n = (int64_t)B * H * W;
     ARG_CHECK(ceil_div64(n, 256) < (1LL << 31), "too many pixels for one launch");
     ARG_CHECK(ceil_div64(n, 64) < (1LL << 31), "too many pixels for one launch");
+    if (Cout == 64 && B <= 65535 && ceil_div64(H, C3T_H) <= 65535) {
+        hipLaunchKernelGGL(conv3x3_c3_tile64_kernel, dim3((unsigned)ceil_div64(W, C3T_W), (unsigned)ceil_div64(H, C3T_H), (unsigned)B),
+                           dim3(256), 0, (hipStream_t)stream, d_x, d_wt, d_bias, H, W, relu, d_y);
+        HIP_TRY(hipGetLastError());
+        return CSLAM_OK;
+    }
     const size_t lds = (size_t)64 * (Cout + 4) * 4;
     ARG_CHECK(lds <= 160 * 1024, "Cout too large for the LDS tile");
     HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_c3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

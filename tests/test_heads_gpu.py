@@ -266,7 +266,8 @@ def test_first_layer_conv_c3_matches_float64(T):
     from torch import nn
     from cslam_amd.vpr.winograd import WinogradTrunk
     torch.manual_seed(11)
-    for cout, relu, hw in ((64, True, (37, 50)), (16, False, (8, 8))):
+    for cout, relu, hw in ((64, True, (37, 50)), (64, False, (224, 224)), (64, True, (1, 1)), (16, False, (8, 8)),
+                           (32, True, (33, 65))):     # Cout = 64: tiled kernel (ragged tiles in both directions)
         mods = [nn.Conv2d(3, cout, 3, padding=1)] + ([nn.ReLU()] if relu else [])
         seq = nn.Sequential(*mods).cuda().eval()
         x = torch.randn((3, 3) + hw, device="cuda")
