@@ -1,0 +1,194 @@
+// wino_fused.hip -- a 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels as ONE kernel:
+// Winograd F(2x2, 3x3) input transform, the 16 per-frequency products on the fp32 MFMA pipe and the output
+// transform + bias + ReLU (+ the 2x2 max-pool that follows) without V or M ever leaving the compute unit (gfx950).
+//
+// Why: at 64 -> 64 channels (VGG-16 conv1_2 on 224 x 224 maps, cslam/vpr/netvlad.py:163-171) the three-kernel form
+// (transform, batched GEMM, transform: winograd.hip) is HBM-bound in every phase -- V and M are 2.25x (F(4x4)) or 4x
+// (F(2x2)) the activation and are written and read once each: 33.7 GB per 256 frames, 6.2 ms.  With K = 64 the whole
+// contraction of a tile block fits in registers, so here HBM sees the activation once (x1.4 halo, mostly L2) and the
+// pooled output once (4.1 GB per 256 frames); the work is then bound by the MFMA pipe: 16 * 64 * 64 * 2 flop per
+// 2x2-pixel tile = 4.2e11 flop per 256 frames = 2.7 ms at the 157 TFLOP/s fp32-MFMA peak.
+//
+// One workgroup (4 waves) owns 8 x 4 tiles (16 x 8 output pixels).  K is walked in four 16-channel quarters:
+//   P1  the 18 x 10 pixel patch of the quarter -> LDS (zero border = the convolution's padding)
+//   P2  every thread transforms one tile x channel pair: V = B^T d B -> LDS [16 xi][32 tiles][16 ch (+4 pad)]
+//   P3  wave w multiplies the 32 tiles by U_xi[:, 16w..16w+15]: v_mfma_f32_16x16x4_f32, A from LDS as one
+//       ds_read_b128 per (xi, 16-tile block) (row pitch 20 floats: conflict-free), B straight from a pre-permuted
+//       copy of U in global memory (262 KB, L2-resident; one float4 per lane per xi), 16 xi x 2 tile blocks x 4
+//       accumulator registers = 128 VGPRs.  The next quarter's patch is fetched under the MFMAs.
+// Epilogue: every lane holds all 16 frequencies of its 8 (tile, channel) pairs: A^T M A, bias, ReLU, max of the 2x2
+// block, 64-byte runs of NHWC output.  Same arithmetic as wino_input_kernel / rocBLAS / wino_output_kernel up to the
+// order of the K summation (MFMA fma chain in 4 groups of 16 channels).
+#include "common.h"
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+#define WF_TBW 8
+#define WF_TBH 4
+#define WF_NT (WF_TBW * WF_TBH)
+#define WF_PW (2 * WF_TBW + 2)
+#define WF_PH (2 * WF_TBH + 2)
+#define WF_NPIX (WF_PW * WF_PH)
+#define WF_PS 20
+#define WF_VS 20
+
+template <bool RELU, bool POOL>
+__global__ __launch_bounds__(256, 2) void wino2_fused64_kernel(const float *__restrict__ x, const float *__restrict__ Up,
+                                                               const float *__restrict__ bias, int H, int W,
+                                                               float *__restrict__ y) {
+    __shared__ __attribute__((aligned(16))) float s_d[WF_NPIX * WF_PS];
+    __shared__ __attribute__((aligned(16))) float s_v[16 * WF_NT * WF_VS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int bx = blockIdx.x, by = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int gx0 = bx * (2 * WF_TBW) - 1, gy0 = by * (2 * WF_TBH) - 1;
+    const float *xb = x + b * (int64_t)H * W * 64;
+
+    // patch loader geometry: element e = (pixel, float4 f of the 16-channel quarter), 720 elements, <= 3 per thread
+    int p_off[3];          // LDS offset (floats), -1 = no element
+    int64_t p_src[3];      // global offset (floats) without the quarter, -1 = zero border
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int e = tid + 256 * i;
+        const int pix = e >> 2, f = e & 3;
+        const int pr = pix / WF_PW, pc = pix - pr * WF_PW;
+        const int gy = gy0 + pr, gx = gx0 + pc;
+        const bool in = (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W);
+        p_off[i] = e < 4 * WF_NPIX ? pix * WF_PS + 4 * f : -1;
+        p_src[i] = (e < 4 * WF_NPIX && in) ? ((int64_t)gy * W + gx) * 64 + 4 * f : -1;
+    }
+    f4 pre[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) pre[i] = p_src[i] >= 0 ? *(const f4 *)(xb + p_src[i]) : (f4)(0.0f);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        if (p_off[i] >= 0) *(f4 *)(s_d + p_off[i]) = pre[i];
+
+    f4 acc[16][2];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) { acc[xi][0] = (f4)(0.0f); acc[xi][1] = (f4)(0.0f); }
+
+    // transform geometry: this thread's tile and channel pair
+    const int t_tile = tid >> 3, t_cp = tid & 7;
+    const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
+    const float *t_src = s_d + ((2 * t_ty) * WF_PW + 2 * t_tx) * WF_PS + 2 * t_cp;
+    float *t_dst = s_v + t_tile * WF_VS + 2 * t_cp;
+    const float *a_src = s_v + r16 * WF_VS + 4 * g;
+    const f4 *up = (const f4 *)Up + wave * 64 + lane;          // + ((kq * 16 + xi) * 4) * 64
+
+    __syncthreads();
+    for (int kq = 0; kq < 4; ++kq) {
+        // B fragments of the first half of the frequencies: in flight during the transform
+        f4 bq[16];
+#pragma unroll
+        for (int xi = 0; xi < 8; ++xi) bq[xi] = up[(int64_t)((kq * 16 + xi) * 4) * 64];
+        {   // P2: V = B^T d B for (tile, channel pair)
+            f2 d[4][4], r[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[i][j] = *(const f2 *)(t_src + (i * WF_PW + j) * WF_PS);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                r[0][j] = d[0][j] - d[2][j];
+                r[1][j] = d[1][j] + d[2][j];
+                r[2][j] = d[2][j] - d[1][j];
+                r[3][j] = d[1][j] - d[3][j];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                *(f2 *)(t_dst + (4 * i + 0) * WF_NT * WF_VS) = r[i][0] - r[i][2];
+                *(f2 *)(t_dst + (4 * i + 1) * WF_NT * WF_VS) = r[i][1] + r[i][2];
+                *(f2 *)(t_dst + (4 * i + 2) * WF_NT * WF_VS) = r[i][2] - r[i][1];
+                *(f2 *)(t_dst + (4 * i + 3) * WF_NT * WF_VS) = r[i][1] - r[i][3];
+            }
+        }
+        __syncthreads();                                        // V complete; the patch buffer is free
+        if (kq < 3) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                pre[i] = p_src[i] >= 0 ? *(const f4 *)(xb + p_src[i] + (kq + 1) * 16) : (f4)(0.0f);
+        }
+#pragma unroll
+        for (int xi = 8; xi < 16; ++xi) bq[xi] = up[(int64_t)((kq * 16 + xi) * 4) * 64];
+        // P3: 16 frequencies x 2 blocks of 16 tiles x 4 K-steps
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) {
+            // the two tile blocks alternate so that no MFMA waits on the one issued just before it
+            // (32-cycle issue, 40-cycle dependent latency)
+            const f4 a0 = *(const f4 *)(a_src + (xi * WF_NT) * WF_VS);
+            const f4 a1 = *(const f4 *)(a_src + (xi * WF_NT + 16) * WF_VS);
+            acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bq[xi].x, acc[xi][0], 0, 0, 0);
+            acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bq[xi].x, acc[xi][1], 0, 0, 0);
+            acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bq[xi].y, acc[xi][0], 0, 0, 0);
+            acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bq[xi].y, acc[xi][1], 0, 0, 0);
+            acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bq[xi].z, acc[xi][0], 0, 0, 0);
+            acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bq[xi].z, acc[xi][1], 0, 0, 0);
+            acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bq[xi].w, acc[xi][0], 0, 0, 0);
+            acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bq[xi].w, acc[xi][1], 0, 0, 0);
+        }
+        if (kq < 3) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                if (p_off[i] >= 0) *(f4 *)(s_d + p_off[i]) = pre[i];
+        }
+        __syncthreads();                                        // next patch visible; V free
+    }
+
+    // epilogue: lane (r16, g) holds M_xi[tile = 16 mb + 4 g + v][channel 16 wave + r16] in acc[xi][mb][v]
+    const int co = 16 * wave + r16;
+    const float bv = bias ? bias[co] : 0.0f;
+    const int Ho = POOL ? H >> 1 : H, Wo = POOL ? W >> 1 : W;
+    float *yb = y + b * (int64_t)Ho * Wo * 64 + co;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int tile = 16 * mb + 4 * g + v;
+            const int ty = tile >> 3, tx = tile & 7;
+            float m[16];
+#pragma unroll
+            for (int xi = 0; xi < 16; ++xi) m[xi] = acc[xi][mb][v];
+            float t0[4], t1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t0[j] = m[0 + j] + m[4 + j] + m[8 + j];
+                t1[j] = m[4 + j] - m[8 + j] - m[12 + j];
+            }
+            float y00 = t0[0] + t0[1] + t0[2] + bv, y01 = t0[1] - t0[2] - t0[3] + bv;
+            float y10 = t1[0] + t1[1] + t1[2] + bv, y11 = t1[1] - t1[2] - t1[3] + bv;
+            if (RELU) { y00 = fmaxf(y00, 0.0f); y01 = fmaxf(y01, 0.0f); y10 = fmaxf(y10, 0.0f); y11 = fmaxf(y11, 0.0f); }
+            if (POOL) {
+                const int py = by * WF_TBH + ty, px = bx * WF_TBW + tx;
+                if (py < Ho && px < Wo) yb[((int64_t)py * Wo + px) * 64] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));
+            } else {
+                const int oy = (by * WF_TBH + ty) * 2, ox = (bx * WF_TBW + tx) * 2;
+                if (oy < H && ox < W) yb[((int64_t)oy * W + ox) * 64] = y00;
+                if (oy < H && ox + 1 < W) yb[((int64_t)oy * W + ox + 1) * 64] = y01;
+                if (oy + 1 < H && ox < W) yb[((int64_t)(oy + 1) * W + ox) * 64] = y10;
+                if (oy + 1 < H && ox + 1 < W) yb[((int64_t)(oy + 1) * W + ox + 1) * 64] = y11;
+            }
+        }
+    }
+}
+
+CSLAM_API int cslam_wino2_fused64_dev(const float *d_x, const float *d_Up, const float *d_bias, int B, int H, int W,
+                                      int relu, int pool, float *d_y, void *stream) {
+    ARG_CHECK(d_x && d_Up && d_y, "NULL argument");
+    ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
+    ARG_CHECK(!pool || ((H % 2) == 0 && (W % 2) == 0), "pooling needs even H and W");
+    const int64_t gx = ceil_div64(W, 2 * WF_TBW), gy = ceil_div64(H, 2 * WF_TBH);
+    ARG_CHECK(gy <= 65535 && B <= 65535, "map too tall / batch too large for one launch");
+    dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)B), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (relu && pool) hipLaunchKernelGGL((wino2_fused64_kernel<true, true>), grid, block, 0, st, d_x, d_Up, d_bias, H, W, d_y);
+    else if (relu) hipLaunchKernelGGL((wino2_fused64_kernel<true, false>), grid, block, 0, st, d_x, d_Up, d_bias, H, W, d_y);
+    else if (pool) hipLaunchKernelGGL((wino2_fused64_kernel<false, true>), grid, block, 0, st, d_x, d_Up, d_bias, H, W, d_y);
+    else hipLaunchKernelGGL((wino2_fused64_kernel<false, false>), grid, block, 0, st, d_x, d_Up, d_bias, H, W, d_y);
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}

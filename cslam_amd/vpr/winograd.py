@@ -34,6 +34,24 @@ def wino_weights(weight, tile=2):
     return u.reshape(G.shape[0] ** 2, g.shape[1], g.shape[0]).to(torch.float32).contiguous()
 
 
+def fused64_weights(U):
+    """U [16, 64, 64] (F(2x2,3x3), `wino_weights(w, 2)`) -> the operand order of `cslam_wino2_fused64_dev`:
+    Up[kq][xi][w][g][c][s] = U[xi][16 kq + 4 g + s][16 w + c] (one float4 per MFMA lane and frequency)."""
+    assert tuple(U.shape) == (16, 64, 64)
+    return U.view(16, 4, 4, 4, 4, 16).permute(1, 0, 4, 2, 5, 3).contiguous()
+
+
+def wino_fused64(x, Up, bias, relu, pool):
+    """64 -> 64 channel 3x3 convolution of x [B,64,H,W] (channels_last storage) as one kernel (csrc/wino_fused.hip)."""
+    lib = _lib.load()
+    B, _, H, W = x.shape
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    y = torch.empty((B, 64, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    _lib.check(lib.cslam_wino2_fused64_dev(_p(x), _p(Up), _p(bias) if bias is not None else None, B, H, W, int(relu),
+                                           int(pool), _p(y), _stream(x)))
+    return y
+
+
 _TUNED = {"done": False}
 
 
@@ -178,24 +196,26 @@ class WinogradResNet(_Workspace):
 
 
 class _Step(object):
-    __slots__ = ("kind", "module", "conv", "relu", "pool", "U", "U4", "bias")
+    __slots__ = ("kind", "module", "conv", "relu", "pool", "U", "U4", "Up", "bias")
 
     def __init__(self):
         self.kind, self.module, self.conv, self.relu, self.pool = "torch", None, None, False, False
-        self.U, self.U4, self.bias = None, None, None
+        self.U, self.U4, self.Up, self.bias = None, None, None, None
 
 
 class WinogradTrunk(_Workspace):
     """Runs an nn.Sequential of Conv2d / ReLU / MaxPool2d like `encoder(x)`, with the eligible
     convolutions (+ their ReLU, + their MaxPool2d(2,2)) replaced by the Winograd pipeline."""
 
-    def __init__(self, encoder, min_in_channels=256, tile=2):
+    def __init__(self, encoder, min_in_channels=256, tile=2, fused64=None):
         """tile = 2: F(2x2,3x3) everywhere; tile = 4: F(4x4,3x3) on the maps whose sides are multiples of 4
-        (F(2x2,3x3) on the others)."""
+        (F(2x2,3x3) on the others).  fused64: run the 64 -> 64 channel layers (VGG-16 conv1_2) through the single
+        fused F(2x2,3x3) kernel instead of transform / GEMM / transform (default on; CSLAM_WINO_FUSED64=0 disables)."""
         super().__init__()
         self.encoder = encoder
         self.min_in_channels = int(min_in_channels)
         self.tile = int(tile)
+        self.fused64 = (os.environ.get("CSLAM_WINO_FUSED64", "1") != "0") if fused64 is None else bool(fused64)
         use_tuned_gemms()
         self.refresh()
 
@@ -214,6 +234,8 @@ class WinogradTrunk(_Workspace):
                 st.kind, st.conv, st.relu, st.pool = "wino", m, False, False
                 st.U = wino_weights(m.weight).to(m.weight.device)
                 st.U4 = wino_weights(m.weight, 4).to(m.weight.device) if self.tile == 4 else None
+                if self.fused64 and m.in_channels == 64 and m.out_channels == 64:
+                    st.Up = fused64_weights(st.U)
                 st.bias = None if m.bias is None else m.bias.detach().to(torch.float32).contiguous()
                 i += 1
                 if i < len(mods) and isinstance(mods[i], nn.ReLU):
@@ -283,6 +305,9 @@ class WinogradTrunk(_Workspace):
                 x = y if not (st.pool and not pool) else torch.nn.functional.max_pool2d(y, 2, 2)
                 continue
             x = x.contiguous(memory_format=torch.channels_last)
+            if st.Up is not None and not (st.pool and (x.shape[2] % 2 or x.shape[3] % 2)):
+                x = wino_fused64(x, st.Up, st.bias, st.relu, st.pool)
+                continue
             y = wino_conv3x3(self, x, st.U, st.U4, st.bias, st.relu, st.pool)
             x = y
         return x

@@ -262,6 +262,13 @@ int cslam_wino_output_dev(const float *d_M, const float *d_bias, const float *d_
 int cslam_wino4_input_dev(const float *d_x, int B, int H, int W, int C, float *d_V, void *stream);
 int cslam_wino4_output_dev(const float *d_M, const float *d_bias, const float *d_residual, int B, int H, int W,
                            int C, int relu, int pool, float *d_y, void *stream);
+/* The same 3x3 / stride 1 / pad 1 convolution for 64 -> 64 channels (VGG-16 conv1_2, netvlad.py:163-171 +
+ * the call at :227) as ONE kernel: F(2x2,3x3) input transform, the 16 per-frequency products on the fp32 MFMA pipe
+ * and output transform + bias + ReLU (+ MaxPool2d(2,2)) with V and M kept on the compute unit (csrc/wino_fused.hip).
+ * x [B,H,W,64] NHWC; Up = U [16,64,64] of the F(2x2) form permuted to [kq 4][xi 16][w 4][g 4][c 16][s 4] with
+ * Up[kq][xi][w][g][c][s] = U[xi][16 kq + 4 g + s][16 w + c]; y [B,H,W,64] or [B,H/2,W/2,64] (pool). */
+int cslam_wino2_fused64_dev(const float *d_x, const float *d_Up, const float *d_bias, int B, int H, int W,
+                            int relu, int pool, float *d_y, void *stream);
 
 #ifdef __cplusplus
 }

@@ -384,3 +384,32 @@ def test_vlad_init_params_matches_reference(T):
             assert np.allclose(layer.conv_bias.cpu().numpy(), g[tag + "/conv_b"], rtol=1e-6, atol=0)
         y = layer(dev(T, g["x"])).cpu().numpy()
         assert y.shape == g[tag + "/y"].shape and np.max(np.abs(y - g[tag + "/y"])) < 1e-6
+
+
+@pytest.mark.parametrize("B,H,W,relu,pool,bias", [(2, 224, 224, True, True, True), (3, 37, 50, True, False, True),
+                                                  (1, 8, 16, False, True, False), (5, 16, 8, True, True, True),
+                                                  (2, 1, 1, False, False, True), (1, 40, 70, True, True, True)])
+def test_fused_winograd_64_to_64_equals_float64_and_unfused(T, B, H, W, relu, pool, bias):
+    """The single-kernel F(2x2,3x3) form of a 64 -> 64 channel layer (VGG-16 conv1_2: csrc/wino_fused.hip) against a
+    float64 conv2d (+ ReLU + MaxPool2d) and against the transform / rocBLAS / transform pipeline it replaces; ragged
+    tile blocks in both directions, with and without bias / ReLU / pooling."""
+    torch, _ = T
+    from torch import nn
+    from cslam_amd.vpr.winograd import WinogradTrunk
+    torch.manual_seed(23)
+    mods = [nn.Conv2d(64, 64, 3, padding=1, bias=bias)] + ([nn.ReLU()] if relu else []) + \
+        ([nn.MaxPool2d(2, 2)] if pool and relu else [])
+    seq = nn.Sequential(*mods).cuda().eval()
+    x = torch.randn((B, 64, H, W), device="cuda")
+    fused = WinogradTrunk(seq, 64, 2, fused64=True)
+    plain = WinogradTrunk(seq, 64, 2, fused64=False)
+    assert fused.steps[0].Up is not None and plain.steps[0].Up is None
+    yf, yp = fused(x), plain(x)
+    with torch.no_grad():
+        ref = seq.double()(x.double())
+    seq.float()
+    scale = ref.abs().max().item()
+    assert yf.shape == ref.shape == yp.shape
+    ef = (yf.double() - ref).abs().max().item() / scale
+    ep = (yp.double() - ref).abs().max().item() / scale
+    assert ef <= 3e-6 and ef <= 3 * ep + 1e-7, (ef, ep)

@@ -1,0 +1,26 @@
+"""conv1_2 of VGG-16 (64 -> 64 channels, 224 x 224, + ReLU + MaxPool) at 256 frames: fused F(2x2) kernel vs the
+F(4x4) transform / rocBLAS / transform pipeline; and the whole trunk either way."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from torch import nn
+from cslam_amd.vpr.netvlad import NetVLAD
+from cslam_amd.vpr.winograd import WinogradTrunk
+nv = NetVLAD({"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376, "frontend.netvlad.pca_dim": 4096}, None)
+mods = list(nv.encoder)
+def best(fn, n=5):
+    fn(); torch.cuda.synchronize(); ts = []
+    for _ in range(n):
+        t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+    return min(ts)
+x1 = torch.randn((256, 64, 224, 224), device="cuda").contiguous(memory_format=torch.channels_last)
+sub = nn.Sequential(*mods[2:5])
+print([type(m).__name__ for m in sub])
+for f in (False, True):
+    tr = WinogradTrunk(sub, 64, 4, fused64=f)
+    print(f"conv1_2+relu+pool fused64={f}: {best(lambda: tr(x1))*1e3:.3f} ms per 256 frames")
+del x1
+x = torch.randn((256, 3, 224, 224), device="cuda")
+for f in (False, True):
+    tr = WinogradTrunk(nv.encoder, 64, 4, fused64=f)
+    print(f"whole trunk fused64={f}: {best(lambda: tr(x))*1e3:.3f} ms per 256 frames")
