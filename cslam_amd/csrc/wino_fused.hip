@@ -32,28 +32,39 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define WF_NPIX (WF_PW * WF_PH)
 #define WF_PS 20
 #define WF_VS 20
+#ifndef WF_ABL
+#define WF_ABL 0      // timing experiments only (tools/exp_fused_ablation.sh): bit mask of phases to leave out
+#endif
 
-template <bool RELU, bool POOL>
-__global__ __launch_bounds__(256, 2) void wino2_fused64_kernel(const float *__restrict__ x, const float *__restrict__ Up,
-                                                               const float *__restrict__ bias, int H, int W,
-                                                               float *__restrict__ y) {
+// NW = waves per workgroup (16 output channels each), COUT = output channels of the layer: NW = COUT / 16 (one
+// workgroup makes all of them) or NW = 4 with COUT / 64 workgroups per tile block (blockIdx.x interleaves them, so the
+// ones sharing an input patch run side by side and the patch comes from L2).
+template <int NW, int COUT, bool RELU, bool POOL>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void wino2_fused_c64_kernel(const float *__restrict__ x,
+                                                                          const float *__restrict__ Up,
+                                                                          const float *__restrict__ bias, int H, int W,
+                                                                          float *__restrict__ y) {
+    constexpr int NT = 64 * NW;                  // threads
+    constexpr int NG = COUT / (16 * NW);         // workgroups per tile block
+    constexpr int NL = (4 * WF_NPIX + NT - 1) / NT;
     __shared__ __attribute__((aligned(16))) float s_d[WF_NPIX * WF_PS];
     __shared__ __attribute__((aligned(16))) float s_v[16 * WF_NT * WF_VS];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, g = lane >> 4;
-    const int bx = blockIdx.x, by = blockIdx.y;
+    const int bx = blockIdx.x / NG, by = blockIdx.y;
+    const int wave_g = (blockIdx.x % NG) * NW + wave;           // 16-channel group of the layer's output
     const int64_t b = blockIdx.z;
     const int gx0 = bx * (2 * WF_TBW) - 1, gy0 = by * (2 * WF_TBH) - 1;
     const float *xb = x + b * (int64_t)H * W * 64;
 
     // patch loader geometry: element e = (pixel, float4 f of the 16-channel quarter), 720 elements, <= 3 per thread
-    int p_off[3];          // LDS offset (floats), -1 = no element
-    int64_t p_src[3];      // global offset (floats) without the quarter, -1 = zero border
+    int p_off[NL];         // LDS offset (floats), -1 = no element
+    int64_t p_src[NL];     // global offset (floats) without the quarter, -1 = zero border
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int e = tid + 256 * i;
+    for (int i = 0; i < NL; ++i) {
+        const int e = tid + NT * i;
         const int pix = e >> 2, f = e & 3;
         const int pr = pix / WF_PW, pc = pix - pr * WF_PW;
         const int gy = gy0 + pr, gx = gx0 + pc;
@@ -61,11 +72,11 @@ __global__ __launch_bounds__(256, 2) void wino2_fused64_kernel(const float *__re
         p_off[i] = e < 4 * WF_NPIX ? pix * WF_PS + 4 * f : -1;
         p_src[i] = (e < 4 * WF_NPIX && in) ? ((int64_t)gy * W + gx) * 64 + 4 * f : -1;
     }
-    f4 pre[3];
+    f4 pre[NL];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) pre[i] = p_src[i] >= 0 ? *(const f4 *)(xb + p_src[i]) : (f4)(0.0f);
+    for (int i = 0; i < NL; ++i) pre[i] = p_src[i] >= 0 ? *(const f4 *)(xb + p_src[i]) : (f4)(0.0f);
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int i = 0; i < NL; ++i)
         if (p_off[i] >= 0) *(f4 *)(s_d + p_off[i]) = pre[i];
 
     f4 acc[16][2];
@@ -73,20 +84,20 @@ __global__ __launch_bounds__(256, 2) void wino2_fused64_kernel(const float *__re
     for (int xi = 0; xi < 16; ++xi) { acc[xi][0] = (f4)(0.0f); acc[xi][1] = (f4)(0.0f); }
 
     // transform geometry: this thread's tile and channel pair
-    const int t_tile = tid >> 3, t_cp = tid & 7;
+    const int t_tile = (tid >> 3) & 31, t_cp = tid & 7;        // (threads 256.. of an 8-wave workgroup sit P2 out)
     const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
     const float *t_src = s_d + ((2 * t_ty) * WF_PW + 2 * t_tx) * WF_PS + 2 * t_cp;
     float *t_dst = s_v + t_tile * WF_VS + 2 * t_cp;
     const float *a_src = s_v + r16 * WF_VS + 4 * g;
-    const f4 *up = (const f4 *)Up + wave * 64 + lane;          // + ((kq * 16 + xi) * 4) * 64
+    const f4 *up = (const f4 *)Up + wave_g * 64 + lane;        // + ((kq * 16 + xi) * (COUT / 16)) * 64
 
     __syncthreads();
     for (int kq = 0; kq < 4; ++kq) {
         // B fragments of the first half of the frequencies: in flight during the transform
         f4 bq[16];
 #pragma unroll
-        for (int xi = 0; xi < 8; ++xi) bq[xi] = up[(int64_t)((kq * 16 + xi) * 4) * 64];
-        {   // P2: V = B^T d B for (tile, channel pair)
+        for (int xi = 0; xi < 8; ++xi) bq[xi] = up[(int64_t)((((WF_ABL & 16) ? 0 : kq) * 16 + xi) * (COUT / 16)) * 64];
+        if (!(WF_ABL & 1) && (NW == 4 || tid < 256)) {   // P2: V = B^T d B for (tile, channel pair)
             f2 d[4][4], r[4][4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -108,20 +119,27 @@ __global__ __launch_bounds__(256, 2) void wino2_fused64_kernel(const float *__re
             }
         }
         __syncthreads();                                        // V complete; the patch buffer is free
-        if (kq < 3) {
+        if (kq < 3 && !(WF_ABL & 8)) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < NL; ++i)
                 pre[i] = p_src[i] >= 0 ? *(const f4 *)(xb + p_src[i] + (kq + 1) * 16) : (f4)(0.0f);
         }
 #pragma unroll
-        for (int xi = 8; xi < 16; ++xi) bq[xi] = up[(int64_t)((kq * 16 + xi) * 4) * 64];
+        for (int xi = 8; xi < 16; ++xi) bq[xi] = up[(int64_t)((((WF_ABL & 16) ? 0 : kq) * 16 + xi) * (COUT / 16)) * 64];
         // P3: 16 frequencies x 2 blocks of 16 tiles x 4 K-steps
+        // the A fragments of frequency xi + 1 are read while the MFMAs of xi run (an LDS read issued right before its
+        // consumer costs its whole latency: 16 times per quarter, a third of the MFMA time)
+        f4 a0 = *(const f4 *)(a_src), a1 = *(const f4 *)(a_src + 16 * WF_VS);
 #pragma unroll
-        for (int xi = 0; xi < 16; ++xi) {
+        for (int xi = 0; xi < ((WF_ABL & 2) ? 1 : 16); ++xi) {
+            f4 n0 = a0, n1 = a1;
+            if (xi < 15) {
+                n0 = *(const f4 *)(a_src + ((xi + 1) * WF_NT) * WF_VS);
+                n1 = *(const f4 *)(a_src + ((xi + 1) * WF_NT + 16) * WF_VS);
+            }
+            __builtin_amdgcn_sched_barrier(0);                  // (the scheduler would sink the reads back down)
             // the two tile blocks alternate so that no MFMA waits on the one issued just before it
             // (32-cycle issue, 40-cycle dependent latency)
-            const f4 a0 = *(const f4 *)(a_src + (xi * WF_NT) * WF_VS);
-            const f4 a1 = *(const f4 *)(a_src + (xi * WF_NT + 16) * WF_VS);
             acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bq[xi].x, acc[xi][0], 0, 0, 0);
             acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bq[xi].x, acc[xi][1], 0, 0, 0);
             acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bq[xi].y, acc[xi][0], 0, 0, 0);
@@ -130,20 +148,21 @@ __global__ __launch_bounds__(256, 2) void wino2_fused64_kernel(const float *__re
             acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bq[xi].z, acc[xi][1], 0, 0, 0);
             acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bq[xi].w, acc[xi][0], 0, 0, 0);
             acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bq[xi].w, acc[xi][1], 0, 0, 0);
+            a0 = n0; a1 = n1;
         }
         if (kq < 3) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < NL; ++i)
                 if (p_off[i] >= 0) *(f4 *)(s_d + p_off[i]) = pre[i];
         }
         __syncthreads();                                        // next patch visible; V free
     }
 
-    // epilogue: lane (r16, g) holds M_xi[tile = 16 mb + 4 g + v][channel 16 wave + r16] in acc[xi][mb][v]
-    const int co = 16 * wave + r16;
+    // epilogue: lane (r16, g) holds M_xi[tile = 16 mb + 4 g + v][channel 16 wave_g + r16] in acc[xi][mb][v]
+    const int co = 16 * wave_g + r16;
     const float bv = bias ? bias[co] : 0.0f;
     const int Ho = POOL ? H >> 1 : H, Wo = POOL ? W >> 1 : W;
-    float *yb = y + b * (int64_t)Ho * Wo * 64 + co;
+    float *yb = y + b * (int64_t)Ho * Wo * COUT + co;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
@@ -162,33 +181,50 @@ __global__ __launch_bounds__(256, 2) void wino2_fused64_kernel(const float *__re
             float y00 = t0[0] + t0[1] + t0[2] + bv, y01 = t0[1] - t0[2] - t0[3] + bv;
             float y10 = t1[0] + t1[1] + t1[2] + bv, y11 = t1[1] - t1[2] - t1[3] + bv;
             if (RELU) { y00 = fmaxf(y00, 0.0f); y01 = fmaxf(y01, 0.0f); y10 = fmaxf(y10, 0.0f); y11 = fmaxf(y11, 0.0f); }
+            if ((WF_ABL & 4) && y00 != 12345.678f) continue;
             if (POOL) {
                 const int py = by * WF_TBH + ty, px = bx * WF_TBW + tx;
-                if (py < Ho && px < Wo) yb[((int64_t)py * Wo + px) * 64] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));
+                if (py < Ho && px < Wo) yb[((int64_t)py * Wo + px) * COUT] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));
             } else {
                 const int oy = (by * WF_TBH + ty) * 2, ox = (bx * WF_TBW + tx) * 2;
-                if (oy < H && ox < W) yb[((int64_t)oy * W + ox) * 64] = y00;
-                if (oy < H && ox + 1 < W) yb[((int64_t)oy * W + ox + 1) * 64] = y01;
-                if (oy + 1 < H && ox < W) yb[((int64_t)(oy + 1) * W + ox) * 64] = y10;
-                if (oy + 1 < H && ox + 1 < W) yb[((int64_t)(oy + 1) * W + ox + 1) * 64] = y11;
+                if (oy < H && ox < W) yb[((int64_t)oy * W + ox) * COUT] = y00;
+                if (oy < H && ox + 1 < W) yb[((int64_t)oy * W + ox + 1) * COUT] = y01;
+                if (oy + 1 < H && ox < W) yb[((int64_t)(oy + 1) * W + ox) * COUT] = y10;
+                if (oy + 1 < H && ox + 1 < W) yb[((int64_t)(oy + 1) * W + ox + 1) * COUT] = y11;
             }
         }
     }
 }
 
-CSLAM_API int cslam_wino2_fused64_dev(const float *d_x, const float *d_Up, const float *d_bias, int B, int H, int W,
-                                      int relu, int pool, float *d_y, void *stream) {
+template <int NW, int COUT>
+static void launch_fused_c64(const float *d_x, const float *d_Up, const float *d_bias, int B, int H, int W, int relu,
+                             int pool, float *d_y, hipStream_t st) {
+    const int64_t gx = ceil_div64(W, 2 * WF_TBW) * (COUT / (16 * NW)), gy = ceil_div64(H, 2 * WF_TBH);
+    dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)B), block(64 * NW);
+    if (relu && pool) hipLaunchKernelGGL((wino2_fused_c64_kernel<NW, COUT, true, true>), grid, block, 0, st, d_x, d_Up, d_bias, H, W, d_y);
+    else if (relu) hipLaunchKernelGGL((wino2_fused_c64_kernel<NW, COUT, true, false>), grid, block, 0, st, d_x, d_Up, d_bias, H, W, d_y);
+    else if (pool) hipLaunchKernelGGL((wino2_fused_c64_kernel<NW, COUT, false, true>), grid, block, 0, st, d_x, d_Up, d_bias, H, W, d_y);
+    else hipLaunchKernelGGL((wino2_fused_c64_kernel<NW, COUT, false, false>), grid, block, 0, st, d_x, d_Up, d_bias, H, W, d_y);
+}
+
+CSLAM_API int cslam_wino2_fused_c64_dev(const float *d_x, const float *d_Up, const float *d_bias, int B, int H, int W,
+                                        int Cout, int relu, int pool, float *d_y, void *stream) {
     ARG_CHECK(d_x && d_Up && d_y, "NULL argument");
     ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
+    ARG_CHECK(Cout == 64 || Cout == 128, "Cout must be 64 or 128");
     ARG_CHECK(!pool || ((H % 2) == 0 && (W % 2) == 0), "pooling needs even H and W");
-    const int64_t gx = ceil_div64(W, 2 * WF_TBW), gy = ceil_div64(H, 2 * WF_TBH);
-    ARG_CHECK(gy <= 65535 && B <= 65535, "map too tall / batch too large for one launch");
-    dim3 grid((unsigned)gx, (unsigned)gy, (unsigned)B), block(256);
+    ARG_CHECK(ceil_div64(H, 2 * WF_TBH) <= 65535 && B <= 65535, "map too tall / batch too large for one launch");
     hipStream_t st = (hipStream_t)stream;
-    if (relu && pool) hipLaunchKernelGGL((wino2_fused64_kernel<true, true>), grid, block, 0, st, d_x, d_Up, d_bias, H, W, d_y);
-    else if (relu) hipLaunchKernelGGL((wino2_fused64_kernel<true, false>), grid, block, 0, st, d_x, d_Up, d_bias, H, W, d_y);
-    else if (pool) hipLaunchKernelGGL((wino2_fused64_kernel<false, true>), grid, block, 0, st, d_x, d_Up, d_bias, H, W, d_y);
-    else hipLaunchKernelGGL((wino2_fused64_kernel<false, false>), grid, block, 0, st, d_x, d_Up, d_bias, H, W, d_y);
+    const char *e = getenv("CSLAM_WF_WAVES");
+    const int wide = e ? atoi(e) : 4;
+    if (Cout == 64) launch_fused_c64<4, 64>(d_x, d_Up, d_bias, B, H, W, relu, pool, d_y, st);
+    else if (wide == 8) launch_fused_c64<8, 128>(d_x, d_Up, d_bias, B, H, W, relu, pool, d_y, st);
+    else launch_fused_c64<4, 128>(d_x, d_Up, d_bias, B, H, W, relu, pool, d_y, st);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
+}
+
+CSLAM_API int cslam_wino2_fused64_dev(const float *d_x, const float *d_Up, const float *d_bias, int B, int H, int W,
+                                      int relu, int pool, float *d_y, void *stream) {
+    return cslam_wino2_fused_c64_dev(d_x, d_Up, d_bias, B, H, W, 64, relu, pool, d_y, stream);
 }

@@ -35,20 +35,23 @@ def wino_weights(weight, tile=2):
 
 
 def fused64_weights(U):
-    """U [16, 64, 64] (F(2x2,3x3), `wino_weights(w, 2)`) -> the operand order of `cslam_wino2_fused64_dev`:
-    Up[kq][xi][w][g][c][s] = U[xi][16 kq + 4 g + s][16 w + c] (one float4 per MFMA lane and frequency)."""
-    assert tuple(U.shape) == (16, 64, 64)
-    return U.view(16, 4, 4, 4, 4, 16).permute(1, 0, 4, 2, 5, 3).contiguous()
+    """U [16, 64, Cout] (F(2x2,3x3), `wino_weights(w, 2)`; Cout 64 or 128) -> the operand order of
+    `cslam_wino2_fused_c64_dev`: Up[kq][xi][w][g][c][s] = U[xi][16 kq + 4 g + s][16 w + c] (one float4 per MFMA lane and
+    frequency)."""
+    assert U.shape[0] == 16 and U.shape[1] == 64 and U.shape[2] in (64, 128)
+    return U.view(16, 4, 4, 4, U.shape[2] // 16, 16).permute(1, 0, 4, 2, 5, 3).contiguous()
 
 
 def wino_fused64(x, Up, bias, relu, pool):
-    """64 -> 64 channel 3x3 convolution of x [B,64,H,W] (channels_last storage) as one kernel (csrc/wino_fused.hip)."""
+    """64 -> 64 / 128 channel 3x3 convolution of x [B,64,H,W] (channels_last storage) as one kernel
+    (csrc/wino_fused.hip); Up from `fused64_weights`."""
     lib = _lib.load()
     B, _, H, W = x.shape
+    Cout = Up.shape[2] * 16
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
-    y = torch.empty((B, 64, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    _lib.check(lib.cslam_wino2_fused64_dev(_p(x), _p(Up), _p(bias) if bias is not None else None, B, H, W, int(relu),
-                                           int(pool), _p(y), _stream(x)))
+    y = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    _lib.check(lib.cslam_wino2_fused_c64_dev(_p(x), _p(Up), _p(bias) if bias is not None else None, B, H, W, Cout,
+                                             int(relu), int(pool), _p(y), _stream(x)))
     return y
 
 
@@ -209,13 +212,14 @@ class WinogradTrunk(_Workspace):
 
     def __init__(self, encoder, min_in_channels=256, tile=2, fused64=None):
         """tile = 2: F(2x2,3x3) everywhere; tile = 4: F(4x4,3x3) on the maps whose sides are multiples of 4
-        (F(2x2,3x3) on the others).  fused64: run the 64 -> 64 channel layers (VGG-16 conv1_2) through the single
+        (F(2x2,3x3) on the others).  fused64: run the 64 -> 64 / 128 channel layers (VGG-16 conv1_2, conv2_1) through the single
         fused F(2x2,3x3) kernel instead of transform / GEMM / transform (default on; CSLAM_WINO_FUSED64=0 disables)."""
         super().__init__()
         self.encoder = encoder
         self.min_in_channels = int(min_in_channels)
         self.tile = int(tile)
         self.fused64 = (os.environ.get("CSLAM_WINO_FUSED64", "1") != "0") if fused64 is None else bool(fused64)
+        self.fused_couts = tuple(int(c) for c in os.environ.get("CSLAM_WINO_FUSED_COUTS", "64,128").split(","))
         use_tuned_gemms()
         self.refresh()
 
@@ -234,7 +238,7 @@ class WinogradTrunk(_Workspace):
                 st.kind, st.conv, st.relu, st.pool = "wino", m, False, False
                 st.U = wino_weights(m.weight).to(m.weight.device)
                 st.U4 = wino_weights(m.weight, 4).to(m.weight.device) if self.tile == 4 else None
-                if self.fused64 and m.in_channels == 64 and m.out_channels == 64:
+                if self.fused64 and m.in_channels == 64 and m.out_channels in self.fused_couts:
                     st.Up = fused64_weights(st.U)
                 st.bias = None if m.bias is None else m.bias.detach().to(torch.float32).contiguous()
                 i += 1

@@ -5,6 +5,7 @@ sklearn's PCA and Pillow (oracle/gen_golden_heads.py); the numpy oracle is check
 Tolerance: float32 kernels vs float32 reference modules, 1e-5 absolute on unit-norm outputs
 (north_star's fp32 gate); the integer resize is bit-exact.
 """
+import os
 import numpy as np
 import pytest
 
@@ -386,18 +387,32 @@ def test_vlad_init_params_matches_reference(T):
         assert y.shape == g[tag + "/y"].shape and np.max(np.abs(y - g[tag + "/y"])) < 1e-6
 
 
+@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("B,H,W,relu,pool,bias", [(2, 112, 112, True, False, True), (3, 37, 50, True, True, True),
+                                                  (1, 8, 16, False, True, False), (2, 1, 1, False, False, True)])
+def test_fused_winograd_64_to_128_equals_float64_and_unfused(T, B, H, W, relu, pool, bias, waves):
+    """The same for 64 -> 128 channels (VGG-16 conv2_1), in both workgroup shapes of the kernel (4 waves x 2
+    workgroups per tile block, or 8 waves)."""
+    _fused_case(T, 128, B, H, W, relu, pool, bias, waves)
+
+
 @pytest.mark.parametrize("B,H,W,relu,pool,bias", [(2, 224, 224, True, True, True), (3, 37, 50, True, False, True),
                                                   (1, 8, 16, False, True, False), (5, 16, 8, True, True, True),
                                                   (2, 1, 1, False, False, True), (1, 40, 70, True, True, True)])
 def test_fused_winograd_64_to_64_equals_float64_and_unfused(T, B, H, W, relu, pool, bias):
+    _fused_case(T, 64, B, H, W, relu, pool, bias, 4)
+
+
+def _fused_case(T, cout, B, H, W, relu, pool, bias, waves):
     """The single-kernel F(2x2,3x3) form of a 64 -> 64 channel layer (VGG-16 conv1_2: csrc/wino_fused.hip) against a
     float64 conv2d (+ ReLU + MaxPool2d) and against the transform / rocBLAS / transform pipeline it replaces; ragged
     tile blocks in both directions, with and without bias / ReLU / pooling."""
     torch, _ = T
     from torch import nn
     from cslam_amd.vpr.winograd import WinogradTrunk
+    os.environ["CSLAM_WF_WAVES"] = str(waves)
     torch.manual_seed(23)
-    mods = [nn.Conv2d(64, 64, 3, padding=1, bias=bias)] + ([nn.ReLU()] if relu else []) + \
+    mods = [nn.Conv2d(64, cout, 3, padding=1, bias=bias)] + ([nn.ReLU()] if relu else []) + \
         ([nn.MaxPool2d(2, 2)] if pool and relu else [])
     seq = nn.Sequential(*mods).cuda().eval()
     x = torch.randn((B, 64, H, W), device="cuda")
