@@ -30,8 +30,12 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #define WF_PW (2 * WF_TBW + 2)
 #define WF_PH (2 * WF_TBH + 2)
 #define WF_NPIX (WF_PW * WF_PH)
-#define WF_PS 20
-#define WF_VS 20
+#define WF_PS 24      // patch pixel pitch (floats): the transform's ds_read_b64 of two neighbouring tiles hit disjoint banks
+#define WF_VS 16      // V row pitch (floats): unpadded, the four 4-channel groups of tile row r rotated by (r & 15) >> 1 --
+                      // conflict-free for the ds_read_b128 lane groups of gfx950 ({0-3,12-15,20-27}, ...) and for the
+                      // transform's ds_write_b64 (pitch 20 unrotated cost 2x on both: SQ_LDS_BANK_CONFLICT = half of
+                      // SQ_LDS_IDX_ACTIVE)
+#define WF_VSW(tile, grp) (4 * (((((tile) & 15) >> 1) + (grp)) & 3))
 #ifndef WF_ABL
 #define WF_ABL 0      // timing experiments only (tools/exp_fused_ablation.sh): bit mask of phases to leave out
 #endif
@@ -87,8 +91,8 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void wino2_fused_c64_kernel(const 
     const int t_tile = (tid >> 3) & 31, t_cp = tid & 7;        // (threads 256.. of an 8-wave workgroup sit P2 out)
     const int t_ty = t_tile >> 3, t_tx = t_tile & 7;
     const float *t_src = s_d + ((2 * t_ty) * WF_PW + 2 * t_tx) * WF_PS + 2 * t_cp;
-    float *t_dst = s_v + t_tile * WF_VS + 2 * t_cp;
-    const float *a_src = s_v + r16 * WF_VS + 4 * g;
+    float *t_dst = s_v + t_tile * WF_VS + WF_VSW(t_tile, t_cp >> 1) + 2 * (t_cp & 1);
+    const float *a_src = s_v + r16 * WF_VS + WF_VSW(r16, g);
     const f4 *up = (const f4 *)Up + wave_g * 64 + lane;        // + ((kq * 16 + xi) * (COUT / 16)) * 64
 
     __syncthreads();
@@ -196,6 +200,220 @@ __global__ __launch_bounds__(64 * NW, 8 / NW) void wino2_fused_c64_kernel(const 
     }
 }
 
+// ---- producer / consumer form ----------------------------------------------------------------------------------------
+// Measured on the kernel above (tools/exp_fused_ablation.py): its two co-resident workgroups run their phases in
+// lock-step, so the transform / load / barrier time ADDS to the MFMA time (4.4 ms = 2.9 MFMA + 1.5 other per 256
+// frames of conv1_2) instead of hiding under it.  Here one persistent workgroup per compute unit has 8 waves with fixed
+// roles: waves 0..3 only multiply (wave w = output channels 16 w.. of the workgroup's 64), waves 4..7 only prepare V --
+// wave 4 + p owns tile row p of the 8 x 4 tile block: it loads the 4 x 18 pixel rows it needs into a private LDS strip
+// (no cross-wave synchronisation), transforms and writes V of the NEXT 16-channel quarter into the other half of a
+// double-buffered V while the MFMA waves consume the current one.  One barrier per quarter.  The quarter sequence runs
+// on across the workgroup's tile blocks (block = blockIdx.x, + gridDim.x, ...), so the first patch of the next block is
+// loaded and transformed under the last MFMAs of the current one; COUT = 128 is two virtual blocks per tile block.
+#define WP_STRIP (4 * WF_PW)                       // pixels of a producer wave's strip
+#define WP_NL ((4 * WP_STRIP + 63) / 64)           // float4 elements per lane
+
+struct WpBlock { int img, by, bx; };
+__device__ __forceinline__ WpBlock wp_decode(int vb, int gxb, int gyb, int NG) {
+    WpBlock r;
+    const int per_img = gxb * gyb * NG;
+    r.img = vb / per_img;
+    const int rem = vb - r.img * per_img;
+    r.by = rem / (gxb * NG);
+    r.bx = (rem - r.by * gxb * NG) / NG;
+    return r;
+}
+
+template <int COUT, bool RELU, bool POOL>
+__global__ __launch_bounds__(512, 1) void wino2_fused_c64_pipe_kernel(const float *__restrict__ x,
+                                                                      const float *__restrict__ Up,
+                                                                      const float *__restrict__ bias, int H, int W,
+                                                                      int gxb, int gyb, int nvb, float *__restrict__ y) {
+    constexpr int NG = COUT / 64;
+    __shared__ __attribute__((aligned(16))) float s_v[2][16 * WF_NT * WF_VS];
+    __shared__ __attribute__((aligned(16))) float s_d[4][WP_STRIP * WF_PS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nmine = (nvb - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = 4 * nmine;
+
+    if (wave >= 4) {
+        // ---------------- producer: V of quarter q = j + 1 during iteration j ----------------
+        const int pw = wave - 4;
+        float *sd = s_d[pw];
+        int p_off[WP_NL], p_pr[WP_NL], p_pc[WP_NL];
+#pragma unroll
+        for (int i = 0; i < WP_NL; ++i) {
+            const int e = lane + 64 * i;
+            const int pix = e >> 2, f = e & 3;
+            p_pr[i] = pix / WF_PW;
+            p_pc[i] = pix - p_pr[i] * WF_PW;
+            p_off[i] = e < 4 * WP_STRIP ? pix * WF_PS + 4 * f : -1;
+        }
+        int64_t p_src[WP_NL];
+        auto geometry = [&](int blk) {
+            const WpBlock c = wp_decode((int)blockIdx.x + blk * (int)gridDim.x, gxb, gyb, NG);
+            const int gx0 = c.bx * (2 * WF_TBW) - 1, gy0 = c.by * (2 * WF_TBH) - 1 + 2 * pw;
+#pragma unroll
+            for (int i = 0; i < WP_NL; ++i) {
+                const int gy = gy0 + p_pr[i], gx = gx0 + p_pc[i];
+                const bool in = (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W) & (p_off[i] >= 0);
+                p_src[i] = in ? ((int64_t)c.img * H * W + (int64_t)gy * W + gx) * 64 + (p_off[i] % WF_PS) : -1;
+            }
+        };
+        const int t_tx = lane >> 3, t_cp = lane & 7;
+        const float *t_src = sd + (2 * t_tx) * WF_PS + 2 * t_cp;
+        const int t_dst = (pw * WF_TBW + t_tx) * WF_VS + WF_VSW(pw * WF_TBW + t_tx, t_cp >> 1) + 2 * (t_cp & 1);
+        f4 pre[WP_NL];
+        geometry(0);
+#pragma unroll
+        for (int i = 0; i < WP_NL; ++i) pre[i] = p_src[i] >= 0 ? *(const f4 *)(x + p_src[i]) : (f4)(0.0f);
+        for (int j = -1; j < total; ++j) {
+            const int q = j + 1;
+            if (q < total && !(WF_ABL & 32)) {
+#pragma unroll
+                for (int i = 0; i < WP_NL; ++i)
+                    if (p_off[i] >= 0) *(f4 *)(sd + p_off[i]) = pre[i];
+                const int qn = q + 1;
+                if (qn < total) {
+                    if ((qn & 3) == 0) geometry(qn >> 2);
+#pragma unroll
+                    for (int i = 0; i < WP_NL; ++i)
+                        pre[i] = p_src[i] >= 0 ? *(const f4 *)(x + p_src[i] + (qn & 3) * 16) : (f4)(0.0f);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the strip is this wave's own
+                float *dst = s_v[q & 1] + t_dst;
+                f2 d[4][4], r[4][4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) d[i][jj] = *(const f2 *)(t_src + (i * WF_PW + jj) * WF_PS);
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    r[0][jj] = d[0][jj] - d[2][jj];
+                    r[1][jj] = d[1][jj] + d[2][jj];
+                    r[2][jj] = d[2][jj] - d[1][jj];
+                    r[3][jj] = d[1][jj] - d[3][jj];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    *(f2 *)(dst + (4 * i + 0) * WF_NT * WF_VS) = r[i][0] - r[i][2];
+                    *(f2 *)(dst + (4 * i + 1) * WF_NT * WF_VS) = r[i][1] + r[i][2];
+                    *(f2 *)(dst + (4 * i + 2) * WF_NT * WF_VS) = r[i][2] - r[i][1];
+                    *(f2 *)(dst + (4 * i + 3) * WF_NT * WF_VS) = r[i][1] - r[i][3];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // reads of the strip before its next fill
+            }
+            __syncthreads();
+        }
+    } else {
+        // ---------------- consumer: the MFMAs of quarter j during iteration j ----------------
+        const int r16 = lane & 15, g = lane >> 4;
+        const int wave_g = ((int)blockIdx.x % NG) * 4 + wave;           // gridDim.x is a multiple of NG
+        const int co = 16 * wave_g + r16;
+        const float bv = bias ? bias[co] : 0.0f;
+        const int Ho = POOL ? H >> 1 : H, Wo = POOL ? W >> 1 : W;
+        const f4 *up = (const f4 *)Up + wave_g * 64 + lane;
+        f4 bq[16];
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) bq[xi] = up[(int64_t)(xi * (COUT / 16)) * 64];
+        f4 acc[16][2];
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi) { acc[xi][0] = (f4)(0.0f); acc[xi][1] = (f4)(0.0f); }
+        __syncthreads();                                                // j = -1
+        for (int j = 0; j < total; ++j) {
+            const int kn = (j + 1) & 3;
+            const float *a_src = s_v[j & 1] + r16 * WF_VS + WF_VSW(r16, g);
+            f4 a0 = *(const f4 *)(a_src), a1 = *(const f4 *)(a_src + 16 * WF_VS);
+#pragma unroll
+            for (int xi = 0; xi < ((WF_ABL & 64) ? 1 : 16); ++xi) {
+                f4 n0 = a0, n1 = a1;
+                if (xi < 15) {
+                    n0 = *(const f4 *)(a_src + ((xi + 1) * WF_NT) * WF_VS);
+                    n1 = *(const f4 *)(a_src + ((xi + 1) * WF_NT + 16) * WF_VS);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bq[xi].x, acc[xi][0], 0, 0, 0);
+                acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bq[xi].x, acc[xi][1], 0, 0, 0);
+                acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bq[xi].y, acc[xi][0], 0, 0, 0);
+                acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bq[xi].y, acc[xi][1], 0, 0, 0);
+                acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bq[xi].z, acc[xi][0], 0, 0, 0);
+                acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bq[xi].z, acc[xi][1], 0, 0, 0);
+                acc[xi][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bq[xi].w, acc[xi][0], 0, 0, 0);
+                acc[xi][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bq[xi].w, acc[xi][1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                bq[xi] = up[(int64_t)((kn * 16 + xi) * (COUT / 16)) * 64];   // the next quarter's weights, in place
+                a0 = n0; a1 = n1;
+            }
+            if ((j & 3) == 3) {
+                // output transform of the finished block: lane (r16, g) holds M_xi[tile 16 mb + 4 g + v][channel co]
+                const WpBlock c = wp_decode((int)blockIdx.x + (j >> 2) * (int)gridDim.x, gxb, gyb, NG);
+                float *yb = y + (int64_t)c.img * Ho * Wo * COUT + co;
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int tile = 16 * mb + 4 * g + v;
+                        const int ty = tile >> 3, tx = tile & 7;
+                        float m[16];
+#pragma unroll
+                        for (int xi = 0; xi < 16; ++xi) m[xi] = acc[xi][mb][v];
+                        float t0[4], t1[4];
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            t0[jj] = m[0 + jj] + m[4 + jj] + m[8 + jj];
+                            t1[jj] = m[4 + jj] - m[8 + jj] - m[12 + jj];
+                        }
+                        float y00 = t0[0] + t0[1] + t0[2] + bv, y01 = t0[1] - t0[2] - t0[3] + bv;
+                        float y10 = t1[0] + t1[1] + t1[2] + bv, y11 = t1[1] - t1[2] - t1[3] + bv;
+                        if (RELU) {
+                            y00 = fmaxf(y00, 0.0f); y01 = fmaxf(y01, 0.0f);
+                            y10 = fmaxf(y10, 0.0f); y11 = fmaxf(y11, 0.0f);
+                        }
+                        if (POOL) {
+                            const int py = c.by * WF_TBH + ty, px = c.bx * WF_TBW + tx;
+                            if (py < Ho && px < Wo)
+                                yb[((int64_t)py * Wo + px) * COUT] = fmaxf(fmaxf(y00, y01), fmaxf(y10, y11));
+                        } else {
+                            const int oy = (c.by * WF_TBH + ty) * 2, ox = (c.bx * WF_TBW + tx) * 2;
+                            if (oy < H && ox < W) yb[((int64_t)oy * W + ox) * COUT] = y00;
+                            if (oy < H && ox + 1 < W) yb[((int64_t)oy * W + ox + 1) * COUT] = y01;
+                            if (oy + 1 < H && ox < W) yb[((int64_t)(oy + 1) * W + ox) * COUT] = y10;
+                            if (oy + 1 < H && ox + 1 < W) yb[((int64_t)(oy + 1) * W + ox + 1) * COUT] = y11;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int xi = 0; xi < 16; ++xi) { acc[xi][0] = (f4)(0.0f); acc[xi][1] = (f4)(0.0f); }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int COUT>
+static int launch_fused_pipe(const float *d_x, const float *d_Up, const float *d_bias, int B, int H, int W, int relu,
+                             int pool, float *d_y, hipStream_t st) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const int gxb = (int)ceil_div64(W, 2 * WF_TBW), gyb = (int)ceil_div64(H, 2 * WF_TBH);
+    const int64_t nvb = (int64_t)B * gxb * gyb * (COUT / 64);
+    ARG_CHECK(nvb < (1ll << 30), "too many tile blocks for one launch");
+    int grid_n = (int)(nvb < n_cu ? nvb : n_cu);
+    grid_n -= grid_n % (COUT / 64);
+    dim3 grid((unsigned)grid_n), block(512);
+    if (relu && pool) hipLaunchKernelGGL((wino2_fused_c64_pipe_kernel<COUT, true, true>), grid, block, 0, st, d_x, d_Up, d_bias, H, W, gxb, gyb, (int)nvb, d_y);
+    else if (relu) hipLaunchKernelGGL((wino2_fused_c64_pipe_kernel<COUT, true, false>), grid, block, 0, st, d_x, d_Up, d_bias, H, W, gxb, gyb, (int)nvb, d_y);
+    else if (pool) hipLaunchKernelGGL((wino2_fused_c64_pipe_kernel<COUT, false, true>), grid, block, 0, st, d_x, d_Up, d_bias, H, W, gxb, gyb, (int)nvb, d_y);
+    else hipLaunchKernelGGL((wino2_fused_c64_pipe_kernel<COUT, false, false>), grid, block, 0, st, d_x, d_Up, d_bias, H, W, gxb, gyb, (int)nvb, d_y);
+    return CSLAM_OK;
+}
+
 template <int NW, int COUT>
 static void launch_fused_c64(const float *d_x, const float *d_Up, const float *d_bias, int B, int H, int W, int relu,
                              int pool, float *d_y, hipStream_t st) {
@@ -216,8 +434,12 @@ CSLAM_API int cslam_wino2_fused_c64_dev(const float *d_x, const float *d_Up, con
     ARG_CHECK(ceil_div64(H, 2 * WF_TBH) <= 65535 && B <= 65535, "map too tall / batch too large for one launch");
     hipStream_t st = (hipStream_t)stream;
     const char *e = getenv("CSLAM_WF_WAVES");
-    const int wide = e ? atoi(e) : 4;
-    if (Cout == 64) launch_fused_c64<4, 64>(d_x, d_Up, d_bias, B, H, W, relu, pool, d_y, st);
+    const int wide = e ? atoi(e) : 0;
+    if (wide == 0) {
+        const int rc = Cout == 64 ? launch_fused_pipe<64>(d_x, d_Up, d_bias, B, H, W, relu, pool, d_y, st)
+                                  : launch_fused_pipe<128>(d_x, d_Up, d_bias, B, H, W, relu, pool, d_y, st);
+        if (rc != CSLAM_OK) return rc;
+    } else if (Cout == 64) launch_fused_c64<4, 64>(d_x, d_Up, d_bias, B, H, W, relu, pool, d_y, st);
     else if (wide == 8) launch_fused_c64<8, 128>(d_x, d_Up, d_bias, B, H, W, relu, pool, d_y, st);
     else launch_fused_c64<4, 128>(d_x, d_Up, d_bias, B, H, W, relu, pool, d_y, st);
     HIP_TRY(hipGetLastError());

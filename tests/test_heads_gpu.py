@@ -387,20 +387,24 @@ def test_vlad_init_params_matches_reference(T):
         assert y.shape == g[tag + "/y"].shape and np.max(np.abs(y - g[tag + "/y"])) < 1e-6
 
 
-@pytest.mark.parametrize("waves", [4, 8])
+@pytest.mark.parametrize("waves", [0, 4, 8])
 @pytest.mark.parametrize("B,H,W,relu,pool,bias", [(2, 112, 112, True, False, True), (3, 37, 50, True, True, True),
-                                                  (1, 8, 16, False, True, False), (2, 1, 1, False, False, True)])
+                                                  (1, 8, 16, False, True, False), (2, 1, 1, False, False, True),
+                                                  (300, 16, 16, True, False, True)])
 def test_fused_winograd_64_to_128_equals_float64_and_unfused(T, B, H, W, relu, pool, bias, waves):
-    """The same for 64 -> 128 channels (VGG-16 conv2_1), in both workgroup shapes of the kernel (4 waves x 2
-    workgroups per tile block, or 8 waves)."""
+    """The same for 64 -> 128 channels (VGG-16 conv2_1), in the three forms of the kernel: 0 = persistent producer /
+    consumer workgroups (the default; 600 virtual blocks > the compute units in the last case, so the block loop and its
+    odd remainders run), 4 / 8 = one tile block per workgroup of 4 / 8 waves."""
     _fused_case(T, 128, B, H, W, relu, pool, bias, waves)
 
 
 @pytest.mark.parametrize("B,H,W,relu,pool,bias", [(2, 224, 224, True, True, True), (3, 37, 50, True, False, True),
                                                   (1, 8, 16, False, True, False), (5, 16, 8, True, True, True),
-                                                  (2, 1, 1, False, False, True), (1, 40, 70, True, True, True)])
-def test_fused_winograd_64_to_64_equals_float64_and_unfused(T, B, H, W, relu, pool, bias):
-    _fused_case(T, 64, B, H, W, relu, pool, bias, 4)
+                                                  (2, 1, 1, False, False, True), (1, 40, 70, True, True, True),
+                                                  (7, 100, 36, True, True, True)])
+@pytest.mark.parametrize("waves", [0, 4])
+def test_fused_winograd_64_to_64_equals_float64_and_unfused(T, B, H, W, relu, pool, bias, waves):
+    _fused_case(T, 64, B, H, W, relu, pool, bias, waves)
 
 
 def _fused_case(T, cout, B, H, W, relu, pool, bias, waves):

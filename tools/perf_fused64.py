@@ -25,16 +25,22 @@ for f in (False, True):
     tr = WinogradTrunk(nv.encoder, 64, 4, fused64=f)
     print(f"whole trunk fused64={f}: {best(lambda: tr(x))*1e3:.3f} ms per 256 frames")
 del x
+x1 = torch.randn((256, 64, 224, 224), device="cuda").contiguous(memory_format=torch.channels_last)
+for waves in ("4", "0"):
+    os.environ["CSLAM_WF_WAVES"] = waves
+    tr = WinogradTrunk(sub, 64, 4, fused64=True)
+    print(f"conv1_2+relu+pool fused waves={waves}: {best(lambda: tr(x1))*1e3:.3f} ms per 256 frames")
+del x1
 x2 = torch.randn((256, 64, 112, 112), device="cuda").contiguous(memory_format=torch.channels_last)
 sub2 = nn.Sequential(*mods[5:7])
 print([type(m).__name__ for m in sub2], mods[5])
-for couts, waves in (("64", "4"), ("64,128", "4"), ("64,128", "8")):
+for couts, waves in (("64", "4"), ("64,128", "4"), ("64,128", "8"), ("64,128", "0")):
     os.environ["CSLAM_WINO_FUSED_COUTS"] = couts; os.environ["CSLAM_WF_WAVES"] = waves
     tr = WinogradTrunk(sub2, 64, 4, fused64=True)
     print(f"conv2_1+relu fused couts={couts} waves={waves}: {best(lambda: tr(x2))*1e3:.3f} ms per 256 frames")
 del x2
 x = torch.randn((256, 3, 224, 224), device="cuda")
-for couts, waves in (("64", "4"), ("64,128", "4"), ("64,128", "8")):
+for couts, waves in (("64", "4"), ("64,128", "4"), ("64", "0"), ("64,128", "0")):
     os.environ["CSLAM_WINO_FUSED_COUTS"] = couts; os.environ["CSLAM_WF_WAVES"] = waves
     tr = WinogradTrunk(nv.encoder, 64, 4, fused64=True)
     print(f"whole trunk fused couts={couts} waves={waves}: {best(lambda: tr(x))*1e3:.3f} ms per 256 frames")
