@@ -1,4 +1,4 @@
-// wino_fused.hip -- a 3x3 / stride 1 / pad 1 convolution with 64 input and 64 output channels as ONE kernel:
+// wino_fused.hip -- a 3x3 / stride 1 / pad 1 convolution with 64 input and 64 or 128 output channels as ONE kernel:
 // Winograd F(2x2, 3x3) input transform, the 16 per-frequency products on the fp32 MFMA pipe and the output
 // transform + bias + ReLU (+ the 2x2 max-pool that follows) without V or M ever leaving the compute unit (gfx950).
 //
@@ -9,11 +9,13 @@
 // pooled output once (4.1 GB per 256 frames); the work is then bound by the MFMA pipe: 16 * 64 * 64 * 2 flop per
 // 2x2-pixel tile = 4.2e11 flop per 256 frames = 2.7 ms at the 157 TFLOP/s fp32-MFMA peak.
 //
-// One workgroup (4 waves) owns 8 x 4 tiles (16 x 8 output pixels).  K is walked in four 16-channel quarters:
+// Two forms.  The default is the persistent producer / consumer kernel further down (wino2_fused_c64_pipe_kernel);
+// the first one (one tile block per workgroup) is kept as the A/B partner (CSLAM_WF_WAVES=4 or 8) and documents the
+// phases: one workgroup owns 8 x 4 tiles (16 x 8 output pixels), K is walked in four 16-channel quarters:
 //   P1  the 18 x 10 pixel patch of the quarter -> LDS (zero border = the convolution's padding)
-//   P2  every thread transforms one tile x channel pair: V = B^T d B -> LDS [16 xi][32 tiles][16 ch (+4 pad)]
+//   P2  every thread transforms one tile x channel pair: V = B^T d B -> LDS [16 xi][32 tiles][16 ch, groups rotated]
 //   P3  wave w multiplies the 32 tiles by U_xi[:, 16w..16w+15]: v_mfma_f32_16x16x4_f32, A from LDS as one
-//       ds_read_b128 per (xi, 16-tile block) (row pitch 20 floats: conflict-free), B straight from a pre-permuted
+//       ds_read_b128 per (xi, 16-tile block) (conflict-free: see WF_VS), B straight from a pre-permuted
 //       copy of U in global memory (262 KB, L2-resident; one float4 per lane per xi), 16 xi x 2 tile blocks x 4
 //       accumulator registers = 128 VGPRs.  The next quarter's patch is fetched under the MFMAs.
 // Epilogue: every lane holds all 16 frequencies of its 8 (tile, channel) pairs: A^T M A, bias, ReLU, max of the 2x2
@@ -227,7 +229,8 @@ __device__ __forceinline__ WpBlock wp_decode(int vb, int gxb, int gyb, int NG) {
 template <int COUT, bool RELU, bool POOL>
 __global__ __launch_bounds__(512, 1) void wino2_fused_c64_pipe_kernel(const float *__restrict__ x,
                                                                       const float *__restrict__ Up,
-                                                                      const float *__restrict__ bias, int H, int W,
+                                                                      const float *__restrict__ bias,
+                                                                      const float *__restrict__ res, int H, int W,
                                                                       int gxb, int gyb, int nvb, float *__restrict__ y) {
     constexpr int NG = COUT / 64;
     __shared__ __attribute__((aligned(16))) float s_v[2][16 * WF_NT * WF_VS];
@@ -350,6 +353,7 @@ __global__ __launch_bounds__(512, 1) void wino2_fused_c64_pipe_kernel(const floa
                 // output transform of the finished block: lane (r16, g) holds M_xi[tile 16 mb + 4 g + v][channel co]
                 const WpBlock c = wp_decode((int)blockIdx.x + (j >> 2) * (int)gridDim.x, gxb, gyb, NG);
                 float *yb = y + (int64_t)c.img * Ho * Wo * COUT + co;
+                const float *rb = res ? res + (int64_t)c.img * H * W * COUT + co : nullptr;   // shortcut (no pooling)
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
@@ -367,6 +371,13 @@ __global__ __launch_bounds__(512, 1) void wino2_fused_c64_pipe_kernel(const floa
                         }
                         float y00 = t0[0] + t0[1] + t0[2] + bv, y01 = t0[1] - t0[2] - t0[3] + bv;
                         float y10 = t1[0] + t1[1] + t1[2] + bv, y11 = t1[1] - t1[2] - t1[3] + bv;
+                        if (!POOL && rb) {
+                            const int oy = (c.by * WF_TBH + ty) * 2, ox = (c.bx * WF_TBW + tx) * 2;
+                            if (oy < H && ox < W) y00 += rb[((int64_t)oy * W + ox) * COUT];
+                            if (oy < H && ox + 1 < W) y01 += rb[((int64_t)oy * W + ox + 1) * COUT];
+                            if (oy + 1 < H && ox < W) y10 += rb[((int64_t)(oy + 1) * W + ox) * COUT];
+                            if (oy + 1 < H && ox + 1 < W) y11 += rb[((int64_t)(oy + 1) * W + ox + 1) * COUT];
+                        }
                         if (RELU) {
                             y00 = fmaxf(y00, 0.0f); y01 = fmaxf(y01, 0.0f);
                             y10 = fmaxf(y10, 0.0f); y11 = fmaxf(y11, 0.0f);
@@ -393,8 +404,8 @@ __global__ __launch_bounds__(512, 1) void wino2_fused_c64_pipe_kernel(const floa
 }
 
 template <int COUT>
-static int launch_fused_pipe(const float *d_x, const float *d_Up, const float *d_bias, int B, int H, int W, int relu,
-                             int pool, float *d_y, hipStream_t st) {
+static int launch_fused_pipe(const float *d_x, const float *d_Up, const float *d_bias, const float *d_res, int B, int H,
+                             int W, int relu, int pool, float *d_y, hipStream_t st) {
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;
@@ -407,10 +418,10 @@ static int launch_fused_pipe(const float *d_x, const float *d_Up, const float *d
     int grid_n = (int)(nvb < n_cu ? nvb : n_cu);
     grid_n -= grid_n % (COUT / 64);
     dim3 grid((unsigned)grid_n), block(512);
-    if (relu && pool) hipLaunchKernelGGL((wino2_fused_c64_pipe_kernel<COUT, true, true>), grid, block, 0, st, d_x, d_Up, d_bias, H, W, gxb, gyb, (int)nvb, d_y);
-    else if (relu) hipLaunchKernelGGL((wino2_fused_c64_pipe_kernel<COUT, true, false>), grid, block, 0, st, d_x, d_Up, d_bias, H, W, gxb, gyb, (int)nvb, d_y);
-    else if (pool) hipLaunchKernelGGL((wino2_fused_c64_pipe_kernel<COUT, false, true>), grid, block, 0, st, d_x, d_Up, d_bias, H, W, gxb, gyb, (int)nvb, d_y);
-    else hipLaunchKernelGGL((wino2_fused_c64_pipe_kernel<COUT, false, false>), grid, block, 0, st, d_x, d_Up, d_bias, H, W, gxb, gyb, (int)nvb, d_y);
+    if (relu && pool) hipLaunchKernelGGL((wino2_fused_c64_pipe_kernel<COUT, true, true>), grid, block, 0, st, d_x, d_Up, d_bias, d_res, H, W, gxb, gyb, (int)nvb, d_y);
+    else if (relu) hipLaunchKernelGGL((wino2_fused_c64_pipe_kernel<COUT, true, false>), grid, block, 0, st, d_x, d_Up, d_bias, d_res, H, W, gxb, gyb, (int)nvb, d_y);
+    else if (pool) hipLaunchKernelGGL((wino2_fused_c64_pipe_kernel<COUT, false, true>), grid, block, 0, st, d_x, d_Up, d_bias, d_res, H, W, gxb, gyb, (int)nvb, d_y);
+    else hipLaunchKernelGGL((wino2_fused_c64_pipe_kernel<COUT, false, false>), grid, block, 0, st, d_x, d_Up, d_bias, d_res, H, W, gxb, gyb, (int)nvb, d_y);
     return CSLAM_OK;
 }
 
@@ -425,19 +436,21 @@ static void launch_fused_c64(const float *d_x, const float *d_Up, const float *d
     else hipLaunchKernelGGL((wino2_fused_c64_kernel<NW, COUT, false, false>), grid, block, 0, st, d_x, d_Up, d_bias, H, W, d_y);
 }
 
-CSLAM_API int cslam_wino2_fused_c64_dev(const float *d_x, const float *d_Up, const float *d_bias, int B, int H, int W,
-                                        int Cout, int relu, int pool, float *d_y, void *stream) {
+CSLAM_API int cslam_wino2_fused_c64_dev(const float *d_x, const float *d_Up, const float *d_bias,
+                                        const float *d_residual, int B, int H, int W, int Cout, int relu, int pool,
+                                        float *d_y, void *stream) {
     ARG_CHECK(d_x && d_Up && d_y, "NULL argument");
     ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
     ARG_CHECK(Cout == 64 || Cout == 128, "Cout must be 64 or 128");
     ARG_CHECK(!pool || ((H % 2) == 0 && (W % 2) == 0), "pooling needs even H and W");
+    ARG_CHECK(!(pool && d_residual), "a shortcut cannot be added to a pooled output");
     ARG_CHECK(ceil_div64(H, 2 * WF_TBH) <= 65535 && B <= 65535, "map too tall / batch too large for one launch");
     hipStream_t st = (hipStream_t)stream;
     const char *e = getenv("CSLAM_WF_WAVES");
     const int wide = e ? atoi(e) : 0;
-    if (wide == 0) {
-        const int rc = Cout == 64 ? launch_fused_pipe<64>(d_x, d_Up, d_bias, B, H, W, relu, pool, d_y, st)
-                                  : launch_fused_pipe<128>(d_x, d_Up, d_bias, B, H, W, relu, pool, d_y, st);
+    if (wide == 0 || d_residual) {
+        const int rc = Cout == 64 ? launch_fused_pipe<64>(d_x, d_Up, d_bias, d_residual, B, H, W, relu, pool, d_y, st)
+                                  : launch_fused_pipe<128>(d_x, d_Up, d_bias, d_residual, B, H, W, relu, pool, d_y, st);
         if (rc != CSLAM_OK) return rc;
     } else if (Cout == 64) launch_fused_c64<4, 64>(d_x, d_Up, d_bias, B, H, W, relu, pool, d_y, st);
     else if (wide == 8) launch_fused_c64<8, 128>(d_x, d_Up, d_bias, B, H, W, relu, pool, d_y, st);
@@ -448,5 +461,5 @@ CSLAM_API int cslam_wino2_fused_c64_dev(const float *d_x, const float *d_Up, con
 
 CSLAM_API int cslam_wino2_fused64_dev(const float *d_x, const float *d_Up, const float *d_bias, int B, int H, int W,
                                       int relu, int pool, float *d_y, void *stream) {
-    return cslam_wino2_fused_c64_dev(d_x, d_Up, d_bias, B, H, W, 64, relu, pool, d_y, stream);
+    return cslam_wino2_fused_c64_dev(d_x, d_Up, d_bias, nullptr, B, H, W, 64, relu, pool, d_y, stream);
 }

@@ -42,7 +42,7 @@ def fused64_weights(U):
     return U.view(16, 4, 4, 4, U.shape[2] // 16, 16).permute(1, 0, 4, 2, 5, 3).contiguous()
 
 
-def wino_fused64(x, Up, bias, relu, pool):
+def wino_fused64(x, Up, bias, relu, pool, residual=None):
     """64 -> 64 / 128 channel 3x3 convolution of x [B,64,H,W] (channels_last storage) as one kernel
     (csrc/wino_fused.hip); Up from `fused64_weights`."""
     lib = _lib.load()
@@ -50,7 +50,11 @@ def wino_fused64(x, Up, bias, relu, pool):
     Cout = Up.shape[2] * 16
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
     y = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-    _lib.check(lib.cslam_wino2_fused_c64_dev(_p(x), _p(Up), _p(bias) if bias is not None else None, B, H, W, Cout,
+    if residual is not None:
+        residual = residual.contiguous(memory_format=torch.channels_last)
+        assert residual.shape == y.shape
+    _lib.check(lib.cslam_wino2_fused_c64_dev(_p(x), _p(Up), _p(bias) if bias is not None else None,
+                                             _p(residual) if residual is not None else None, B, H, W, Cout,
                                              int(relu), int(pool), _p(y), _stream(x)))
     return y
 
@@ -139,14 +143,19 @@ class _FoldedConv(object):
     def __init__(self, conv, bn, tile, min_in_channels):
         self.weight, self.bias = fold_bn(conv, bn)
         self.stride, self.padding = conv.stride, conv.padding
-        self.U = self.U4 = None
+        self.U = self.U4 = self.Up = None
         if (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
                 and conv.groups == 1 and conv.in_channels >= min_in_channels and conv.in_channels % 4 == 0
                 and conv.out_channels % 4 == 0 and conv.weight.is_cuda):
             self.U = wino_weights(self.weight).to(self.weight.device)
             self.U4 = wino_weights(self.weight, 4).to(self.weight.device) if tile == 4 else None
+            if (conv.in_channels == 64 and conv.out_channels in (64, 128)
+                    and os.environ.get("CSLAM_WINO_FUSED64", "1") != "0"):
+                self.Up = fused64_weights(self.U)        # layer1 of ResNet-18/34: one fused kernel (csrc/wino_fused.hip)
 
     def __call__(self, ws, x, relu, residual=None):
+        if self.Up is not None:
+            return wino_fused64(x.contiguous(memory_format=torch.channels_last), self.Up, self.bias, relu, False, residual)
         if self.U is not None:
             return wino_conv3x3(ws, x.contiguous(memory_format=torch.channels_last), self.U, self.U4, self.bias, relu,
                                 False, residual)

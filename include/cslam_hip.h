@@ -269,10 +269,12 @@ int cslam_wino4_output_dev(const float *d_M, const float *d_bias, const float *d
  * Up[kq][xi][w][g][c][s] = U[xi][16 kq + 4 g + s][16 w + c]; y [B,H,W,64] or [B,H/2,W/2,64] (pool). */
 int cslam_wino2_fused64_dev(const float *d_x, const float *d_Up, const float *d_bias, int B, int H, int W,
                             int relu, int pool, float *d_y, void *stream);
-/* The same kernel for 64 -> Cout channels, Cout = 64 or 128 (VGG-16 conv1_2 and conv2_1): Up = U [16,64,Cout] permuted
- * to [kq 4][xi 16][w Cout/16][g 4][c 16][s 4]; y [B,H,W,Cout] or [B,H/2,W/2,Cout] (pool). */
-int cslam_wino2_fused_c64_dev(const float *d_x, const float *d_Up, const float *d_bias, int B, int H, int W, int Cout,
-                              int relu, int pool, float *d_y, void *stream);
+/* The same kernel for 64 -> Cout channels, Cout = 64 or 128 (VGG-16 conv1_2 and conv2_1; the BasicBlock convolutions
+ * of ResNet-18/34 layer1, cosplace_utils/network.py:38-68, with d_residual [B,H,W,Cout] = the block's shortcut, added
+ * before the ReLU, or NULL): Up = U [16,64,Cout] permuted to [kq 4][xi 16][w Cout/16][g 4][c 16][s 4];
+ * y [B,H,W,Cout] or [B,H/2,W/2,Cout] (pool; not together with d_residual). */
+int cslam_wino2_fused_c64_dev(const float *d_x, const float *d_Up, const float *d_bias, const float *d_residual, int B,
+                              int H, int W, int Cout, int relu, int pool, float *d_y, void *stream);
 
 #ifdef __cplusplus
 }

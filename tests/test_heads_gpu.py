@@ -432,3 +432,26 @@ def _fused_case(T, cout, B, H, W, relu, pool, bias, waves):
     ef = (yf.double() - ref).abs().max().item() / scale
     ep = (yp.double() - ref).abs().max().item() / scale
     assert ef <= 3e-6 and ef <= 3 * ep + 1e-7, (ef, ep)
+
+
+@pytest.mark.parametrize("B,H,W,cout", [(3, 56, 56, 64), (300, 14, 10, 64), (2, 9, 7, 128)])
+def test_fused_winograd_shortcut_add(T, B, H, W, cout):
+    """The fused kernel with a BasicBlock shortcut (ResNet-18 layer1: conv2 + bn2 folded, + identity, ReLU) against
+    float64; also that a pooled output refuses a shortcut."""
+    torch, _ = T
+    from cslam_amd import _lib
+    from cslam_amd.vpr.winograd import fused64_weights, wino_fused64, wino_weights
+    os.environ.pop("CSLAM_WF_WAVES", None)
+    torch.manual_seed(5)
+    w = torch.randn((cout, 64, 3, 3), device="cuda") * 0.05
+    b = torch.randn(cout, device="cuda")
+    x = torch.randn((B, 64, H, W), device="cuda").contiguous(memory_format=torch.channels_last)
+    idt = torch.randn((B, cout, H, W), device="cuda").contiguous(memory_format=torch.channels_last)
+    Up = fused64_weights(wino_weights(w).cuda())
+    y = wino_fused64(x, Up, b, True, False, idt)
+    ref = torch.relu(torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1) + idt.double())
+    assert y.shape == ref.shape
+    assert (y.double() - ref).abs().max().item() <= 3e-6 * ref.abs().max().item()
+    if H % 2 == 0 and W % 2 == 0:
+        with pytest.raises(_lib.CslamHipError):
+            wino_fused64(x, Up, b, True, True, idt[:, :, ::2, ::2])
