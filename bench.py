@@ -261,6 +261,32 @@ def main():
                             "note": "largest hand-written kernel of the extract leg; the 36 GEMMs between the "
                                     "transforms are rocBLAS"}
         del xt, vt
+        # the largest single kernel of the extract leg: the one-kernel Winograd form of conv1_2 (csrc/wino_fused.hip),
+        # MFMA-bound; algorithmic flop = 16 frequencies x 2*64*64 per 2x2-pixel tile
+        fh = 224
+        xf = torch.randn((eb, fh, fh, 64), device=dev)
+        upf = torch.randn((4, 16, 4, 4, 16, 4), device=dev)
+        bf = torch.randn(64, device=dev)
+        yf = torch.empty((eb, fh // 2, fh // 2, 64), device=dev)
+
+        def fused():
+            _lib.check(lib.cslam_wino2_fused_c64_dev(xf.data_ptr(), upf.data_ptr(), bf.data_ptr(), None, eb, fh, fh, 64,
+                                                     1, 1, yf.data_ptr(), st))
+        fused()
+        e0.record()
+        for _ in range(5):
+            fused()
+        e1.record()
+        torch.cuda.synchronize()
+        fms = e0.elapsed_time(e1) / 5
+        fflop = eb * (fh // 2) * (fh // 2) * 16 * 2 * 64 * 64
+        extract_roofline["fused_conv"] = {
+            "bound": "mfma", "kernel": "wino2_fused_c64_pipe_kernel", "achieved": round(fflop / fms / 1e9, 1),
+            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fflop / fms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4),
+            "kernel_ms": round(fms, 3), "algorithmic_flop": fflop,
+            "algorithmic_bytes": (xf.numel() + yf.numel()) * 4,
+            "shape": f"x [{eb},{fh},{fh},64] -> conv 64->64 + bias + ReLU + MaxPool2d -> [{eb},{fh // 2},{fh // 2},64]"}
+        del xf, yf
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -149,9 +149,12 @@ class _FoldedConv(object):
                 and conv.out_channels % 4 == 0 and conv.weight.is_cuda):
             self.U = wino_weights(self.weight).to(self.weight.device)
             self.U4 = wino_weights(self.weight, 4).to(self.weight.device) if tile == 4 else None
+            # layer1 of ResNet-18/34 CAN run through the one-kernel form (csrc/wino_fused.hip, shortcut fused), but on
+            # its 56 x 56 maps V and M of a 250-frame chunk (0.45 GB each) largely stay in the 256 MB Infinity Cache and
+            # the F(4x4) pipeline wins: 31.8k vs 30.9k frames/s (profiles/r01_perf_c2.log) -- opt-in only
             if (conv.in_channels == 64 and conv.out_channels in (64, 128)
-                    and os.environ.get("CSLAM_WINO_FUSED64", "1") != "0"):
-                self.Up = fused64_weights(self.U)        # layer1 of ResNet-18/34: one fused kernel (csrc/wino_fused.hip)
+                    and os.environ.get("CSLAM_WINO_FUSED_RESNET", "0") == "1"):
+                self.Up = fused64_weights(self.U)
 
     def __call__(self, ws, x, relu, residual=None):
         if self.Up is not None:
