@@ -71,6 +71,7 @@ _SIGNATURES = {
     "cslam_wino4_output_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "cslam_wino2_fused64_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "cslam_wino2_fused_c64_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "cslam_wino4_fused_c64_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "cslam_scancontext_from_cloud_dev": (_i, [_vp, _vp, _i, _i, _i, C.c_double, _vp, _vp, _vp]),
 }
 

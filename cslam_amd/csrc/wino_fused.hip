@@ -425,6 +425,255 @@ static int launch_fused_pipe(const float *d_x, const float *d_Up, const float *d
     return CSLAM_OK;
 }
 
+// ---- F(4x4, 3x3) producer / consumer form ----------------------------------------------------------------------------
+// The same persistent role split with 6 x 6 input tiles and 4 x 4 output tiles: 36 frequencies, 1.78x fewer MFMAs per
+// output pixel than F(2x2) (144 per 256 pixels and 16 input channels against 128 per 128).  A workgroup block is 4 x 4
+// tiles (16 x 16 output pixels, one 16-row MFMA operand); the 36 x 4 accumulator registers per lane leave no room for a
+// quarter's 36 B fragments, so those stream through a 3-pair ring (refilled in place three pairs = 768 MFMA cycles ahead
+// of their use, across quarter boundaries), the A fragments one pair ahead; the two frequencies of a pair alternate so
+// that no MFMA waits on its predecessor.  Transform constants as in winograd.hip (wino4_bt / wino4_at), so the
+// arithmetic equals the three-kernel F(4x4) form up to the order of the K summation.
+#define W4_T 4                                     // tiles per block side
+#define W4_PW (4 * W4_T + 2)                       // 18 patch pixels per row
+#define W4_PS 20                                   // patch pixel pitch (floats): ds_read_b32 of two tiles conflict-free
+#define W4_STRIP (6 * W4_PW)                       // pixels of a producer wave's strip (the 6 rows of its tile row)
+#define W4_NL ((4 * W4_STRIP + 63) / 64)
+#define W4_NT (W4_T * W4_T)
+
+__device__ __forceinline__ void w4_bt(float &d0, float &d1, float &d2, float &d3, float &d4, float &d5) {
+    const float r0 = 4.0f * d0 - 5.0f * d2 + d4;
+    const float r1 = -4.0f * (d1 + d2) + d3 + d4;
+    const float r2 = 4.0f * (d1 - d2) - d3 + d4;
+    const float r3 = 2.0f * (d3 - d1) - d2 + d4;
+    const float r4 = 2.0f * (d1 - d3) - d2 + d4;
+    const float r5 = 4.0f * d1 - 5.0f * d3 + d5;
+    d0 = r0; d1 = r1; d2 = r2; d3 = r3; d4 = r4; d5 = r5;
+}
+__device__ __forceinline__ void w4_at(float m0, float m1, float m2, float m3, float m4, float m5, float &s0, float &s1,
+                                      float &s2, float &s3) {
+    const float a = m1 + m2, b = m1 - m2, c = m3 + m4, e = m3 - m4;
+    s0 = m0 + a + c;
+    s1 = b + 2.0f * e;
+    s2 = a + 4.0f * c;
+    s3 = b + 8.0f * e + m5;
+}
+
+template <int COUT, bool RELU, bool POOL>
+__global__ __launch_bounds__(512, 1) void wino4_fused_c64_pipe_kernel(const float *__restrict__ x,
+                                                                      const float *__restrict__ Up,
+                                                                      const float *__restrict__ bias,
+                                                                      const float *__restrict__ res, int H, int W,
+                                                                      int gxb, int gyb, int nvb, float *__restrict__ y) {
+    constexpr int NG = COUT / 64;
+    __shared__ __attribute__((aligned(16))) float s_v[2][36 * W4_NT * WF_VS];
+    __shared__ __attribute__((aligned(16))) float s_d[4][W4_STRIP * W4_PS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nmine = (nvb - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total = 4 * nmine;
+
+    if (wave >= 4) {
+        // ---------------- producer: V of quarter q = j + 1 during iteration j ----------------
+        const int pw = wave - 4;
+        float *sd = s_d[pw];
+        int p_off[W4_NL], p_pr[W4_NL], p_pc[W4_NL];
+#pragma unroll
+        for (int i = 0; i < W4_NL; ++i) {
+            const int e = lane + 64 * i;
+            const int pix = e >> 2, f = e & 3;
+            p_pr[i] = pix / W4_PW;
+            p_pc[i] = pix - p_pr[i] * W4_PW;
+            p_off[i] = e < 4 * W4_STRIP ? pix * W4_PS + 4 * f : -1;
+        }
+        int64_t p_src[W4_NL];
+        auto geometry = [&](int blk) {
+            const WpBlock c = wp_decode((int)blockIdx.x + blk * (int)gridDim.x, gxb, gyb, NG);
+            const int gx0 = c.bx * (4 * W4_T) - 1, gy0 = c.by * (4 * W4_T) - 1 + 4 * pw;
+#pragma unroll
+            for (int i = 0; i < W4_NL; ++i) {
+                const int gy = gy0 + p_pr[i], gx = gx0 + p_pc[i];
+                const bool in = (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W) & (p_off[i] >= 0);
+                p_src[i] = in ? ((int64_t)c.img * H * W + (int64_t)gy * W + gx) * 64 + (p_off[i] % W4_PS) : -1;
+            }
+        };
+        const int t_tx = lane >> 4, t_c = lane & 15;
+        const int t_tile = pw * W4_T + t_tx;
+        const float *t_src = sd + (4 * t_tx) * W4_PS + t_c;
+        const int t_dst = t_tile * WF_VS + WF_VSW(t_tile, t_c >> 2) + (t_c & 3);
+        f4 pre[W4_NL];
+        geometry(0);
+#pragma unroll
+        for (int i = 0; i < W4_NL; ++i) pre[i] = p_src[i] >= 0 ? *(const f4 *)(x + p_src[i]) : (f4)(0.0f);
+        for (int j = -1; j < total; ++j) {
+            const int q = j + 1;
+            if (q < total) {
+#pragma unroll
+                for (int i = 0; i < W4_NL; ++i)
+                    if (p_off[i] >= 0) *(f4 *)(sd + p_off[i]) = pre[i];
+                const int qn = q + 1;
+                if (qn < total) {
+                    if ((qn & 3) == 0) geometry(qn >> 2);
+#pragma unroll
+                    for (int i = 0; i < W4_NL; ++i)
+                        pre[i] = p_src[i] >= 0 ? *(const f4 *)(x + p_src[i] + (qn & 3) * 16) : (f4)(0.0f);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the strip is this wave's own
+                float *dst = s_v[q & 1] + t_dst;
+                float d[6][6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 6; ++jj) d[i][jj] = t_src[(i * W4_PW + jj) * W4_PS];
+#pragma unroll
+                for (int jj = 0; jj < 6; ++jj) w4_bt(d[0][jj], d[1][jj], d[2][jj], d[3][jj], d[4][jj], d[5][jj]);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) w4_bt(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < 6; ++jj) dst[(6 * i + jj) * W4_NT * WF_VS] = d[i][jj];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // reads of the strip before its next fill
+            }
+            __syncthreads();
+        }
+    } else {
+        // ---------------- consumer: the MFMAs of quarter j during iteration j ----------------
+        const int r16 = lane & 15, g = lane >> 4;
+        const int wave_g = ((int)blockIdx.x % NG) * 4 + wave;           // gridDim.x is a multiple of NG
+        const int co = 16 * wave_g + r16;
+        const float bv = bias ? bias[co] : 0.0f;
+        const int Ho = POOL ? H >> 1 : H, Wo = POOL ? W >> 1 : W;
+        const f4 *up = (const f4 *)Up + wave_g * 64 + lane;             // + ((kq * 36 + xi) * (COUT / 16)) * 64
+        f4 bq[3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            bq[p][0] = up[(int64_t)((2 * p) * (COUT / 16)) * 64];
+            bq[p][1] = up[(int64_t)((2 * p + 1) * (COUT / 16)) * 64];
+        }
+        f4 acc[36];
+#pragma unroll
+        for (int xi = 0; xi < 36; ++xi) acc[xi] = (f4)(0.0f);
+        __syncthreads();                                                // j = -1
+        for (int j = 0; j < total; ++j) {
+            const int kq = j & 3, kn = (j + 1) & 3;
+            const float *a_src = s_v[j & 1] + r16 * WF_VS + WF_VSW(r16, g);
+            f4 a0 = *(const f4 *)(a_src), a1 = *(const f4 *)(a_src + W4_NT * WF_VS);
+#pragma unroll
+            for (int p = 0; p < 18; ++p) {
+                f4 n0 = a0, n1 = a1;
+                if (p < 17) {
+                    n0 = *(const f4 *)(a_src + ((2 * p + 2) * W4_NT) * WF_VS);
+                    n1 = *(const f4 *)(a_src + ((2 * p + 3) * W4_NT) * WF_VS);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const f4 b0 = bq[p % 3][0], b1 = bq[p % 3][1];
+                acc[2 * p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[2 * p], 0, 0, 0);
+                acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc[2 * p + 1], 0, 0, 0);
+                acc[2 * p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[2 * p], 0, 0, 0);
+                acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc[2 * p + 1], 0, 0, 0);
+                acc[2 * p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc[2 * p], 0, 0, 0);
+                acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc[2 * p + 1], 0, 0, 0);
+                acc[2 * p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc[2 * p], 0, 0, 0);
+                acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc[2 * p + 1], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                {   // pair p + 3 (of this quarter or the next one) into the slot just used
+                    const int pn = p + 3 < 18 ? p + 3 : p + 3 - 18;
+                    const int kk = p + 3 < 18 ? kq : kn;
+                    bq[p % 3][0] = up[(int64_t)((kk * 36 + 2 * pn) * (COUT / 16)) * 64];
+                    bq[p % 3][1] = up[(int64_t)((kk * 36 + 2 * pn + 1) * (COUT / 16)) * 64];
+                }
+                a0 = n0; a1 = n1;
+            }
+            if (kq == 3) {
+                // output transform of the finished block: lane (r16, g) holds M_xi[tile (g, v)][channel co] in acc[xi][v]
+                const WpBlock c = wp_decode((int)blockIdx.x + (j >> 2) * (int)gridDim.x, gxb, gyb, NG);
+                float *yb = y + (int64_t)c.img * Ho * Wo * COUT + co;
+                const float *rb = res ? res + (int64_t)c.img * H * W * COUT + co : nullptr;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    float s[4][6], o[4][4];
+#pragma unroll
+                    for (int jj = 0; jj < 6; ++jj)
+                        w4_at(acc[jj][v], acc[6 + jj][v], acc[12 + jj][v], acc[18 + jj][v], acc[24 + jj][v],
+                              acc[30 + jj][v], s[0][jj], s[1][jj], s[2][jj], s[3][jj]);
+                    const int oy0 = (c.by * W4_T + g) * 4, ox0 = (c.bx * W4_T + v) * 4;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        w4_at(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o[i][0], o[i][1], o[i][2], o[i][3]);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            o[i][jj] += bv;
+                            if (!POOL && rb && oy0 + i < H && ox0 + jj < W)
+                                o[i][jj] += rb[((int64_t)(oy0 + i) * W + ox0 + jj) * COUT];
+                            if (RELU) o[i][jj] = fmaxf(o[i][jj], 0.0f);
+                        }
+                    }
+                    if (POOL) {
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int jj = 0; jj < 2; ++jj) {
+                                const int py = (oy0 >> 1) + i, px = (ox0 >> 1) + jj;
+                                if (py < Ho && px < Wo)
+                                    yb[((int64_t)py * Wo + px) * COUT] =
+                                        fmaxf(fmaxf(o[2 * i][2 * jj], o[2 * i][2 * jj + 1]),
+                                              fmaxf(o[2 * i + 1][2 * jj], o[2 * i + 1][2 * jj + 1]));
+                            }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj)
+                                if (oy0 + i < H && ox0 + jj < W) yb[((int64_t)(oy0 + i) * W + ox0 + jj) * COUT] = o[i][jj];
+                    }
+                }
+#pragma unroll
+                for (int xi = 0; xi < 36; ++xi) acc[xi] = (f4)(0.0f);
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int COUT>
+static int launch_fused4_pipe(const float *d_x, const float *d_Up, const float *d_bias, const float *d_res, int B, int H,
+                              int W, int relu, int pool, float *d_y, hipStream_t st) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    const int gxb = (int)ceil_div64(W, 4 * W4_T), gyb = (int)ceil_div64(H, 4 * W4_T);
+    const int64_t nvb = (int64_t)B * gxb * gyb * (COUT / 64);
+    ARG_CHECK(nvb < (1ll << 30), "too many tile blocks for one launch");
+    int grid_n = (int)(nvb < n_cu ? nvb : n_cu);
+    grid_n -= grid_n % (COUT / 64);
+    dim3 grid((unsigned)grid_n), block(512);
+    if (relu && pool) hipLaunchKernelGGL((wino4_fused_c64_pipe_kernel<COUT, true, true>), grid, block, 0, st, d_x, d_Up, d_bias, d_res, H, W, gxb, gyb, (int)nvb, d_y);
+    else if (relu) hipLaunchKernelGGL((wino4_fused_c64_pipe_kernel<COUT, true, false>), grid, block, 0, st, d_x, d_Up, d_bias, d_res, H, W, gxb, gyb, (int)nvb, d_y);
+    else if (pool) hipLaunchKernelGGL((wino4_fused_c64_pipe_kernel<COUT, false, true>), grid, block, 0, st, d_x, d_Up, d_bias, d_res, H, W, gxb, gyb, (int)nvb, d_y);
+    else hipLaunchKernelGGL((wino4_fused_c64_pipe_kernel<COUT, false, false>), grid, block, 0, st, d_x, d_Up, d_bias, d_res, H, W, gxb, gyb, (int)nvb, d_y);
+    return CSLAM_OK;
+}
+
+CSLAM_API int cslam_wino4_fused_c64_dev(const float *d_x, const float *d_Up, const float *d_bias,
+                                        const float *d_residual, int B, int H, int W, int Cout, int relu, int pool,
+                                        float *d_y, void *stream) {
+    ARG_CHECK(d_x && d_Up && d_y, "NULL argument");
+    ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
+    ARG_CHECK(Cout == 64 || Cout == 128, "Cout must be 64 or 128");
+    ARG_CHECK(!pool || ((H % 2) == 0 && (W % 2) == 0), "pooling needs even H and W");
+    ARG_CHECK(!(pool && d_residual), "a shortcut cannot be added to a pooled output");
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = Cout == 64 ? launch_fused4_pipe<64>(d_x, d_Up, d_bias, d_residual, B, H, W, relu, pool, d_y, st)
+                              : launch_fused4_pipe<128>(d_x, d_Up, d_bias, d_residual, B, H, W, relu, pool, d_y, st);
+    if (rc != CSLAM_OK) return rc;
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
 template <int NW, int COUT>
 static void launch_fused_c64(const float *d_x, const float *d_Up, const float *d_bias, int B, int H, int W, int relu,
                              int pool, float *d_y, hipStream_t st) {

@@ -35,16 +35,16 @@ def wino_weights(weight, tile=2):
 
 
 def fused64_weights(U):
-    """U [16, 64, Cout] (F(2x2,3x3), `wino_weights(w, 2)`; Cout 64 or 128) -> the operand order of
-    `cslam_wino2_fused_c64_dev`: Up[kq][xi][w][g][c][s] = U[xi][16 kq + 4 g + s][16 w + c] (one float4 per MFMA lane and
-    frequency)."""
-    assert U.shape[0] == 16 and U.shape[1] == 64 and U.shape[2] in (64, 128)
-    return U.view(16, 4, 4, 4, U.shape[2] // 16, 16).permute(1, 0, 4, 2, 5, 3).contiguous()
+    """U [16 | 36, 64, Cout] (`wino_weights(w, 2 | 4)`; Cout 64 or 128) -> the operand order of
+    `cslam_wino2_fused_c64_dev` / `cslam_wino4_fused_c64_dev`: Up[kq][xi][w][g][c][s] = U[xi][16 kq + 4 g + s][16 w + c]
+    (one float4 per MFMA lane and frequency)."""
+    assert U.shape[0] in (16, 36) and U.shape[1] == 64 and U.shape[2] in (64, 128)
+    return U.view(U.shape[0], 4, 4, 4, U.shape[2] // 16, 16).permute(1, 0, 4, 2, 5, 3).contiguous()
 
 
 def wino_fused64(x, Up, bias, relu, pool, residual=None):
     """64 -> 64 / 128 channel 3x3 convolution of x [B,64,H,W] (channels_last storage) as one kernel
-    (csrc/wino_fused.hip); Up from `fused64_weights`."""
+    (csrc/wino_fused.hip); Up from `fused64_weights` (16 frequencies: the F(2x2) kernel, 36: the F(4x4) one)."""
     lib = _lib.load()
     B, _, H, W = x.shape
     Cout = Up.shape[2] * 16
@@ -53,9 +53,9 @@ def wino_fused64(x, Up, bias, relu, pool, residual=None):
     if residual is not None:
         residual = residual.contiguous(memory_format=torch.channels_last)
         assert residual.shape == y.shape
-    _lib.check(lib.cslam_wino2_fused_c64_dev(_p(x), _p(Up), _p(bias) if bias is not None else None,
-                                             _p(residual) if residual is not None else None, B, H, W, Cout,
-                                             int(relu), int(pool), _p(y), _stream(x)))
+    fn = lib.cslam_wino4_fused_c64_dev if Up.shape[1] == 36 else lib.cslam_wino2_fused_c64_dev
+    _lib.check(fn(_p(x), _p(Up), _p(bias) if bias is not None else None,
+                  _p(residual) if residual is not None else None, B, H, W, Cout, int(relu), int(pool), _p(y), _stream(x)))
     return y
 
 
@@ -251,7 +251,9 @@ class WinogradTrunk(_Workspace):
                 st.U = wino_weights(m.weight).to(m.weight.device)
                 st.U4 = wino_weights(m.weight, 4).to(m.weight.device) if self.tile == 4 else None
                 if self.fused64 and m.in_channels == 64 and m.out_channels in self.fused_couts:
-                    st.Up = fused64_weights(st.U)
+                    # F(4x4) one-kernel form on the F(4x4) trunk (CSLAM_WINO_FUSED_TILE=2 keeps the F(2x2) one)
+                    t4 = self.tile == 4 and os.environ.get("CSLAM_WINO_FUSED_TILE", "4") == "4"
+                    st.Up = fused64_weights(st.U4 if t4 else st.U)
                 st.bias = None if m.bias is None else m.bias.detach().to(torch.float32).contiguous()
                 i += 1
                 if i < len(mods) and isinstance(mods[i], nn.ReLU):

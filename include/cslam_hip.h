@@ -275,6 +275,11 @@ int cslam_wino2_fused64_dev(const float *d_x, const float *d_Up, const float *d_
  * y [B,H,W,Cout] or [B,H/2,W/2,Cout] (pool; not together with d_residual). */
 int cslam_wino2_fused_c64_dev(const float *d_x, const float *d_Up, const float *d_bias, const float *d_residual, int B,
                               int H, int W, int Cout, int relu, int pool, float *d_y, void *stream);
+/* The F(4x4,3x3) form of the same one-kernel convolution (36 frequencies, 4 x 4 blocks of 4 x 4-pixel tiles per
+ * workgroup step; 1.78x fewer MFMAs per output pixel): Up = U [36,64,Cout] of the F(4x4) form permuted to
+ * [kq 4][xi 36][w Cout/16][g 4][c 16][s 4]; everything else as cslam_wino2_fused_c64_dev. */
+int cslam_wino4_fused_c64_dev(const float *d_x, const float *d_Up, const float *d_bias, const float *d_residual, int B,
+                              int H, int W, int Cout, int relu, int pool, float *d_y, void *stream);
 
 #ifdef __cplusplus
 }

@@ -455,3 +455,31 @@ def test_fused_winograd_shortcut_add(T, B, H, W, cout):
     if H % 2 == 0 and W % 2 == 0:
         with pytest.raises(_lib.CslamHipError):
             wino_fused64(x, Up, b, True, True, idt[:, :, ::2, ::2])
+
+
+@pytest.mark.parametrize("cout", [64, 128])
+@pytest.mark.parametrize("B,H,W,relu,pool,bias", [(2, 224, 224, True, True, True), (3, 37, 50, True, False, True),
+                                                  (1, 8, 16, False, True, False), (2, 1, 1, False, False, True),
+                                                  (300, 16, 16, True, True, True), (5, 100, 36, True, True, True)])
+def test_fused_winograd_f4_equals_float64(T, cout, B, H, W, relu, pool, bias):
+    """The F(4x4,3x3) one-kernel form (36 frequencies; csrc/wino_fused.hip `wino4_fused_c64_pipe_kernel`) against a
+    float64 conv2d (+ ReLU + MaxPool2d) at the F(4x4) tolerance of the three-kernel form (2e-5 of the largest
+    activation); ragged 16 x 16 blocks, block counts below and above the compute-unit count, both output widths."""
+    torch, _ = T
+    from torch import nn
+    from cslam_amd.vpr.winograd import WinogradTrunk
+    os.environ.pop("CSLAM_WF_WAVES", None)
+    torch.manual_seed(29)
+    mods = [nn.Conv2d(64, cout, 3, padding=1, bias=bias)] + ([nn.ReLU()] if relu else []) + \
+        ([nn.MaxPool2d(2, 2)] if pool and relu else [])
+    seq = nn.Sequential(*mods).cuda().eval()
+    x = torch.randn((B, 64, H, W), device="cuda")
+    fused = WinogradTrunk(seq, 64, 4, fused64=True)
+    assert fused.steps[0].Up is not None and fused.steps[0].Up.shape[1] == 36
+    yf = fused(x)
+    with torch.no_grad():
+        ref = seq.double()(x.double())
+    seq.float()
+    assert yf.shape == ref.shape
+    ef = (yf.double() - ref).abs().max().item() / ref.abs().max().item()
+    assert ef <= 2e-5, ef

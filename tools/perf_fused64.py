@@ -44,3 +44,19 @@ for couts, waves in (("64", "4"), ("64,128", "4"), ("64", "0"), ("64,128", "0"))
     os.environ["CSLAM_WINO_FUSED_COUTS"] = couts; os.environ["CSLAM_WF_WAVES"] = waves
     tr = WinogradTrunk(nv.encoder, 64, 4, fused64=True)
     print(f"whole trunk fused couts={couts} waves={waves}: {best(lambda: tr(x))*1e3:.3f} ms per 256 frames")
+for ft in ("2", "4"):
+    os.environ["CSLAM_WINO_FUSED_TILE"] = ft; os.environ["CSLAM_WINO_FUSED_COUTS"] = "64,128"; os.environ["CSLAM_WF_WAVES"] = "0"
+    tr = WinogradTrunk(nv.encoder, 64, 4, fused64=True)
+    print(f"whole trunk fused tile F({ft}x{ft}): {best(lambda: tr(x))*1e3:.3f} ms per 256 frames")
+del x
+x1 = torch.randn((256, 64, 224, 224), device="cuda").contiguous(memory_format=torch.channels_last)
+for ft in ("2", "4"):
+    os.environ["CSLAM_WINO_FUSED_TILE"] = ft
+    tr = WinogradTrunk(sub, 64, 4, fused64=True)
+    print(f"conv1_2+relu+pool fused tile F({ft}x{ft}): {best(lambda: tr(x1))*1e3:.3f} ms per 256 frames")
+del x1
+x2 = torch.randn((256, 64, 112, 112), device="cuda").contiguous(memory_format=torch.channels_last)
+for ft in ("2", "4"):
+    os.environ["CSLAM_WINO_FUSED_TILE"] = ft
+    tr = WinogradTrunk(sub2, 64, 4, fused64=True)
+    print(f"conv2_1+relu fused tile F({ft}x{ft}): {best(lambda: tr(x2))*1e3:.3f} ms per 256 frames")
