@@ -507,7 +507,7 @@ __global__ __launch_bounds__(512, 1) void wino4_fused_c64_pipe_kernel(const floa
         for (int i = 0; i < W4_NL; ++i) pre[i] = p_src[i] >= 0 ? *(const f4 *)(x + p_src[i]) : (f4)(0.0f);
         for (int j = -1; j < total; ++j) {
             const int q = j + 1;
-            if (q < total) {
+            if (q < total && !(WF_ABL & 32)) {
 #pragma unroll
                 for (int i = 0; i < W4_NL; ++i)
                     if (p_off[i] >= 0) *(f4 *)(sd + p_off[i]) = pre[i];
@@ -540,6 +540,8 @@ __global__ __launch_bounds__(512, 1) void wino4_fused_c64_pipe_kernel(const floa
     } else {
         // ---------------- consumer: the MFMAs of quarter j during iteration j ----------------
         const int r16 = lane & 15, g = lane >> 4;
+        // (s_setprio on either role and the A prefetch distance, 1 or 2 pairs, make no difference beyond the +-2 % run-to-run
+        // noise: profiles/r01_exp_fused_ablation.log)
         const int wave_g = ((int)blockIdx.x % NG) * 4 + wave;           // gridDim.x is a multiple of NG
         const int co = 16 * wave_g + r16;
         const float bv = bias ? bias[co] : 0.0f;
@@ -558,15 +560,18 @@ __global__ __launch_bounds__(512, 1) void wino4_fused_c64_pipe_kernel(const floa
         for (int j = 0; j < total; ++j) {
             const int kq = j & 3, kn = (j + 1) & 3;
             const float *a_src = s_v[j & 1] + r16 * WF_VS + WF_VSW(r16, g);
-            f4 a0 = *(const f4 *)(a_src), a1 = *(const f4 *)(a_src + W4_NT * WF_VS);
+            // A fragments two pairs (512 MFMA cycles) ahead of their use, ring of 3
+            f4 ar[3][2];
+            ar[0][0] = *(const f4 *)(a_src); ar[0][1] = *(const f4 *)(a_src + W4_NT * WF_VS);
+            ar[1][0] = *(const f4 *)(a_src + 2 * W4_NT * WF_VS); ar[1][1] = *(const f4 *)(a_src + 3 * W4_NT * WF_VS);
 #pragma unroll
-            for (int p = 0; p < 18; ++p) {
-                f4 n0 = a0, n1 = a1;
-                if (p < 17) {
-                    n0 = *(const f4 *)(a_src + ((2 * p + 2) * W4_NT) * WF_VS);
-                    n1 = *(const f4 *)(a_src + ((2 * p + 3) * W4_NT) * WF_VS);
+            for (int p = 0; p < ((WF_ABL & 64) ? 1 : 18); ++p) {
+                if (p < 16) {
+                    ar[(p + 2) % 3][0] = *(const f4 *)(a_src + ((2 * p + 4) * W4_NT) * WF_VS);
+                    ar[(p + 2) % 3][1] = *(const f4 *)(a_src + ((2 * p + 5) * W4_NT) * WF_VS);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                const f4 a0 = ar[p % 3][0], a1 = ar[p % 3][1];
                 const f4 b0 = bq[p % 3][0], b1 = bq[p % 3][1];
                 acc[2 * p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[2 * p], 0, 0, 0);
                 acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc[2 * p + 1], 0, 0, 0);
@@ -583,7 +588,6 @@ __global__ __launch_bounds__(512, 1) void wino4_fused_c64_pipe_kernel(const floa
                     bq[p % 3][0] = up[(int64_t)((kk * 36 + 2 * pn) * (COUT / 16)) * 64];
                     bq[p % 3][1] = up[(int64_t)((kk * 36 + 2 * pn + 1) * (COUT / 16)) * 64];
                 }
-                a0 = n0; a1 = n1;
             }
             if (kq == 3) {
                 // output transform of the finished block: lane (r16, g) holds M_xi[tile (g, v)][channel co] in acc[xi][v]
@@ -591,7 +595,7 @@ __global__ __launch_bounds__(512, 1) void wino4_fused_c64_pipe_kernel(const floa
                 float *yb = y + (int64_t)c.img * Ho * Wo * COUT + co;
                 const float *rb = res ? res + (int64_t)c.img * H * W * COUT + co : nullptr;
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
+                for (int v = 0; v < ((WF_ABL & 128) ? 0 : 4); ++v) {
                     float s[4][6], o[4][4];
 #pragma unroll
                     for (int jj = 0; jj < 6; ++jj)
