@@ -262,15 +262,15 @@ def main():
                                     "transforms are rocBLAS"}
         del xt, vt
         # the largest single kernel of the extract leg: the one-kernel Winograd form of conv1_2 (csrc/wino_fused.hip),
-        # MFMA-bound; algorithmic flop = 16 frequencies x 2*64*64 per 2x2-pixel tile
+        # MFMA-bound; algorithmic flop = 36 frequencies x 2*64*64 per 4x4-pixel tile
         fh = 224
         xf = torch.randn((eb, fh, fh, 64), device=dev)
-        upf = torch.randn((4, 16, 4, 4, 16, 4), device=dev)
+        upf = torch.randn((4, 36, 4, 4, 16, 4), device=dev)
         bf = torch.randn(64, device=dev)
         yf = torch.empty((eb, fh // 2, fh // 2, 64), device=dev)
 
         def fused():
-            _lib.check(lib.cslam_wino2_fused_c64_dev(xf.data_ptr(), upf.data_ptr(), bf.data_ptr(), None, eb, fh, fh, 64,
+            _lib.check(lib.cslam_wino4_fused_c64_dev(xf.data_ptr(), upf.data_ptr(), bf.data_ptr(), None, eb, fh, fh, 64,
                                                      1, 1, yf.data_ptr(), st))
         fused()
         e0.record()
@@ -279,9 +279,9 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         fms = e0.elapsed_time(e1) / 5
-        fflop = eb * (fh // 2) * (fh // 2) * 16 * 2 * 64 * 64
+        fflop = eb * (fh // 4) * (fh // 4) * 36 * 2 * 64 * 64
         extract_roofline["fused_conv"] = {
-            "bound": "mfma", "kernel": "wino2_fused_c64_pipe_kernel", "achieved": round(fflop / fms / 1e9, 1),
+            "bound": "mfma", "kernel": "wino4_fused_c64_pipe_kernel", "achieved": round(fflop / fms / 1e9, 1),
             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fflop / fms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4),
             "kernel_ms": round(fms, 3), "algorithmic_flop": fflop,
             "algorithmic_bytes": (xf.numel() + yf.numel()) * 4,

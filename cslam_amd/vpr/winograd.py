@@ -231,6 +231,7 @@ class WinogradTrunk(_Workspace):
         self.min_in_channels = int(min_in_channels)
         self.tile = int(tile)
         self.fused64 = (os.environ.get("CSLAM_WINO_FUSED64", "1") != "0") if fused64 is None else bool(fused64)
+        self.fused_min_blocks = int(os.environ.get("CSLAM_WINO_FUSED_MIN_BLOCKS", "256"))
         self.fused_couts = tuple(int(c) for c in os.environ.get("CSLAM_WINO_FUSED_COUTS", "64,128").split(","))
         use_tuned_gemms()
         self.refresh()
@@ -324,8 +325,13 @@ class WinogradTrunk(_Workspace):
                 continue
             x = x.contiguous(memory_format=torch.channels_last)
             if st.Up is not None and not (st.pool and (x.shape[2] % 2 or x.shape[3] % 2)):
-                x = wino_fused64(x, st.Up, st.bias, st.relu, st.pool)
-                continue
+                # one persistent workgroup per compute unit: worth it from one tile block per CU on (a single 224 x 224
+                # frame has 196: VGG-16 at B = 1 502 us through it, 459 us through the three-kernel form)
+                bh, bw = (16, 16) if st.Up.shape[1] == 36 else (8, 16)
+                nblk = x.shape[0] * -(-x.shape[2] // bh) * -(-x.shape[3] // bw) * st.Up.shape[2] // 4
+                if nblk >= self.fused_min_blocks:
+                    x = wino_fused64(x, st.Up, st.bias, st.relu, st.pool)
+                    continue
             y = wino_conv3x3(self, x, st.U, st.U4, st.bias, st.relu, st.pool)
             x = y
         return x

@@ -421,6 +421,7 @@ def _fused_case(T, cout, B, H, W, relu, pool, bias, waves):
     seq = nn.Sequential(*mods).cuda().eval()
     x = torch.randn((B, 64, H, W), device="cuda")
     fused = WinogradTrunk(seq, 64, 2, fused64=True)
+    fused.fused_min_blocks = 0                       # (the trunk's own rule: fused from one tile block per CU on)
     plain = WinogradTrunk(seq, 64, 2, fused64=False)
     assert fused.steps[0].Up is not None and plain.steps[0].Up is None
     yf, yp = fused(x), plain(x)
@@ -475,6 +476,7 @@ def test_fused_winograd_f4_equals_float64(T, cout, B, H, W, relu, pool, bias):
     seq = nn.Sequential(*mods).cuda().eval()
     x = torch.randn((B, 64, H, W), device="cuda")
     fused = WinogradTrunk(seq, 64, 4, fused64=True)
+    fused.fused_min_blocks = 0
     assert fused.steps[0].Up is not None and fused.steps[0].Up.shape[1] == 36
     yf = fused(x)
     with torch.no_grad():
