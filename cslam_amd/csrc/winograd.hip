@@ -373,7 +373,10 @@ __device__ __forceinline__ void wino4_bt(f2 &d0, f2 &d1, f2 &d2, f2 &d3, f2 &d4,
 __global__ __launch_bounds__(256) void wino4_input_kernel(const float *__restrict__ x, int B, int H, int W, int C,
                                                           float *__restrict__ V) {
     const int c2n = C >> 1;
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    // workgroups go to the 8 XCDs round-robin; give each XCD a contiguous run of tiles so that the 2 of 6 rows / columns
+    // a tile shares with each neighbour are found in that XCD's own L2 (gridDim.x is a multiple of 8)
+    const int64_t bid = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int64_t gid = bid * 256 + threadIdx.x;
     const int TH = (H + 3) >> 2, TW = (W + 3) >> 2;      // ragged maps: the last tile row / column is partly outside
     const int64_t T = (int64_t)B * TH * TW;
     if (gid >= T * c2n) return;
@@ -485,8 +488,8 @@ CSLAM_API int cslam_wino4_input_dev(const float *d_x, int B, int H, int W, int C
     ARG_CHECK(C >= 2 && (C % 2) == 0, "C must be even");
     const int64_t n = (int64_t)B * ((H + 3) / 4) * ((W + 3) / 4) * (C / 2);
     ARG_CHECK(ceil_div64(n, 256) < (1LL << 31), "too many tiles for one launch");
-    hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream, d_x, B,
-                       H, W, C, d_V);
+    hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)round_up64(ceil_div64(n, 256), 8)), dim3(256), 0,
+                       (hipStream_t)stream, d_x, B, H, W, C, d_V);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }
