@@ -439,6 +439,9 @@ static int launch_fused_pipe(const float *d_x, const float *d_Up, const float *d
 #define W4_STRIP (6 * W4_PW)                       // pixels of a producer wave's strip (the 6 rows of its tile row)
 #define W4_NL ((4 * W4_STRIP + 63) / 64)
 #define W4_NT (W4_T * W4_T)
+#ifndef W4_BR
+#define W4_BR 6                                    // B-fragment pairs in flight (divides 18)
+#endif
 
 __device__ __forceinline__ void w4_bt(float &d0, float &d1, float &d2, float &d3, float &d4, float &d5) {
     const float r0 = 4.0f * d0 - 5.0f * d2 + d4;
@@ -501,22 +504,28 @@ __global__ __launch_bounds__(512, 1) void wino4_fused_c64_pipe_kernel(const floa
         const int t_tile = pw * W4_T + t_tx;
         const float *t_src = sd + (4 * t_tx) * W4_PS + t_c;
         const int t_dst = t_tile * WF_VS + WF_VSW(t_tile, t_c >> 2) + (t_c & 3);
-        f4 pre[W4_NL];
+        // the patch of quarter q + 2 is requested while quarter q is transformed: one quarter (~2 us) ahead did not
+        // cover the latency of these 64-byte-per-pixel loads under load (0.5 ms of 3.0 on conv1_2)
+        f4 pre[W4_NL], pre2[W4_NL];
         geometry(0);
 #pragma unroll
         for (int i = 0; i < W4_NL; ++i) pre[i] = p_src[i] >= 0 ? *(const f4 *)(x + p_src[i]) : (f4)(0.0f);
+#pragma unroll
+        for (int i = 0; i < W4_NL; ++i) pre2[i] = p_src[i] >= 0 ? *(const f4 *)(x + p_src[i] + 16) : (f4)(0.0f);
         for (int j = -1; j < total; ++j) {
             const int q = j + 1;
             if (q < total && !(WF_ABL & 32)) {
 #pragma unroll
                 for (int i = 0; i < W4_NL; ++i)
                     if (p_off[i] >= 0) *(f4 *)(sd + p_off[i]) = pre[i];
-                const int qn = q + 1;
-                if (qn < total) {
+#pragma unroll
+                for (int i = 0; i < W4_NL; ++i) pre[i] = pre2[i];
+                const int qn = q + 2;
+                if (qn < total && !(WF_ABL & 2048)) {
                     if ((qn & 3) == 0) geometry(qn >> 2);
 #pragma unroll
                     for (int i = 0; i < W4_NL; ++i)
-                        pre[i] = p_src[i] >= 0 ? *(const f4 *)(x + p_src[i] + (qn & 3) * 16) : (f4)(0.0f);
+                        pre2[i] = p_src[i] >= 0 ? *(const f4 *)(x + p_src[i] + (qn & 3) * 16) : (f4)(0.0f);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // the strip is this wave's own
                 float *dst = s_v[q & 1] + t_dst;
@@ -525,10 +534,12 @@ __global__ __launch_bounds__(512, 1) void wino4_fused_c64_pipe_kernel(const floa
                 for (int i = 0; i < 6; ++i)
 #pragma unroll
                     for (int jj = 0; jj < 6; ++jj) d[i][jj] = t_src[(i * W4_PW + jj) * W4_PS];
+                if (!(WF_ABL & 1024)) {
 #pragma unroll
-                for (int jj = 0; jj < 6; ++jj) w4_bt(d[0][jj], d[1][jj], d[2][jj], d[3][jj], d[4][jj], d[5][jj]);
+                    for (int jj = 0; jj < 6; ++jj) w4_bt(d[0][jj], d[1][jj], d[2][jj], d[3][jj], d[4][jj], d[5][jj]);
 #pragma unroll
-                for (int i = 0; i < 6; ++i) w4_bt(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);
+                    for (int i = 0; i < 6; ++i) w4_bt(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);
+                }
 #pragma unroll
                 for (int i = 0; i < 6; ++i)
 #pragma unroll
@@ -547,9 +558,9 @@ __global__ __launch_bounds__(512, 1) void wino4_fused_c64_pipe_kernel(const floa
         const float bv = bias ? bias[co] : 0.0f;
         const int Ho = POOL ? H >> 1 : H, Wo = POOL ? W >> 1 : W;
         const f4 *up = (const f4 *)Up + wave_g * 64 + lane;             // + ((kq * 36 + xi) * (COUT / 16)) * 64
-        f4 bq[3][2];
+        f4 bq[W4_BR][2];
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+        for (int p = 0; p < W4_BR; ++p) {
             bq[p][0] = up[(int64_t)((2 * p) * (COUT / 16)) * 64];
             bq[p][1] = up[(int64_t)((2 * p + 1) * (COUT / 16)) * 64];
         }
@@ -572,7 +583,7 @@ __global__ __launch_bounds__(512, 1) void wino4_fused_c64_pipe_kernel(const floa
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 const f4 a0 = ar[p % 3][0], a1 = ar[p % 3][1];
-                const f4 b0 = bq[p % 3][0], b1 = bq[p % 3][1];
+                const f4 b0 = bq[p % W4_BR][0], b1 = bq[p % W4_BR][1];
                 acc[2 * p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc[2 * p], 0, 0, 0);
                 acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc[2 * p + 1], 0, 0, 0);
                 acc[2 * p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc[2 * p], 0, 0, 0);
@@ -582,11 +593,11 @@ __global__ __launch_bounds__(512, 1) void wino4_fused_c64_pipe_kernel(const floa
                 acc[2 * p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc[2 * p], 0, 0, 0);
                 acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc[2 * p + 1], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
-                {   // pair p + 3 (of this quarter or the next one) into the slot just used
-                    const int pn = p + 3 < 18 ? p + 3 : p + 3 - 18;
-                    const int kk = p + 3 < 18 ? kq : kn;
-                    bq[p % 3][0] = up[(int64_t)((kk * 36 + 2 * pn) * (COUT / 16)) * 64];
-                    bq[p % 3][1] = up[(int64_t)((kk * 36 + 2 * pn + 1) * (COUT / 16)) * 64];
+                {   // pair p + W4_BR (of this quarter or the next one) into the slot just used
+                    const int pn = p + W4_BR < 18 ? p + W4_BR : p + W4_BR - 18;
+                    const int kk = p + W4_BR < 18 ? kq : kn;
+                    bq[p % W4_BR][0] = up[(int64_t)((kk * 36 + 2 * pn) * (COUT / 16)) * 64];
+                    bq[p % W4_BR][1] = up[(int64_t)((kk * 36 + 2 * pn + 1) * (COUT / 16)) * 64];
                 }
             }
             if (kq == 3) {
