@@ -605,6 +605,13 @@ __global__ __launch_bounds__(512, 1) void wino4_fused_c64_pipe_kernel(const floa
                 const WpBlock c = wp_decode((int)blockIdx.x + (j >> 2) * (int)gridDim.x, gxb, gyb, NG);
                 float *yb = y + (int64_t)c.img * Ho * Wo * COUT + co;
                 const float *rb = res ? res + (int64_t)c.img * H * W * COUT + co : nullptr;
+                if (WF_ABL & 128) {      // timing only: the accumulators stay live through one sum and one store
+                    f4 t = acc[0];
+#pragma unroll
+                    for (int xi = 1; xi < 36; ++xi) t += acc[xi];
+                    if (c.by * 16 + 4 * g < Ho && c.bx * 16 < Wo)
+                        yb[((int64_t)(c.by * 16 + 4 * g) * Wo + c.bx * 16) * COUT] = t.x + t.y + t.z + t.w;
+                }
 #pragma unroll
                 for (int v = 0; v < ((WF_ABL & 128) ? 0 : 4); ++v) {
                     float s[4][6], o[4][4];
@@ -616,24 +623,28 @@ __global__ __launch_bounds__(512, 1) void wino4_fused_c64_pipe_kernel(const floa
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         w4_at(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o[i][0], o[i][1], o[i][2], o[i][3]);
+                        if (!POOL) {
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) {
-                            o[i][jj] += bv;
-                            if (!POOL && rb && oy0 + i < H && ox0 + jj < W)
-                                o[i][jj] += rb[((int64_t)(oy0 + i) * W + ox0 + jj) * COUT];
-                            if (RELU) o[i][jj] = fmaxf(o[i][jj], 0.0f);
+                            for (int jj = 0; jj < 4; ++jj) {
+                                o[i][jj] += bv;
+                                if (rb && oy0 + i < H && ox0 + jj < W)
+                                    o[i][jj] += rb[((int64_t)(oy0 + i) * W + ox0 + jj) * COUT];
+                                if (RELU) o[i][jj] = fmaxf(o[i][jj], 0.0f);
+                            }
                         }
                     }
                     if (POOL) {
+                        // bias and ReLU after the 2 x 2 maximum: rounding is monotone, so max(a + b, c + b) == max(a, c) + b
+                        // bit for bit, and ReLU commutes with max -- 4 instead of 16 of each per tile
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
 #pragma unroll
                             for (int jj = 0; jj < 2; ++jj) {
                                 const int py = (oy0 >> 1) + i, px = (ox0 >> 1) + jj;
-                                if (py < Ho && px < Wo)
-                                    yb[((int64_t)py * Wo + px) * COUT] =
-                                        fmaxf(fmaxf(o[2 * i][2 * jj], o[2 * i][2 * jj + 1]),
-                                              fmaxf(o[2 * i + 1][2 * jj], o[2 * i + 1][2 * jj + 1]));
+                                float m = fmaxf(fmaxf(o[2 * i][2 * jj], o[2 * i][2 * jj + 1]),
+                                                fmaxf(o[2 * i + 1][2 * jj], o[2 * i + 1][2 * jj + 1])) + bv;
+                                if (RELU) m = fmaxf(m, 0.0f);
+                                if (py < Ho && px < Wo) yb[((int64_t)py * Wo + px) * COUT] = m;
                             }
                     } else {
 #pragma unroll

@@ -6,7 +6,7 @@ B, H, W = 256, 224, 224
 x = torch.randn((B, H, W, 64), device="cuda"); Up = torch.randn((4, 36, 4, 4, 16, 4), device="cuda")
 bias = torch.randn(64, device="cuda"); y = torch.empty((B, H // 2, W // 2, 64), device="cuda")
 vp = C.c_void_p
-for m in (0, 32, 64, 96, 1024, 2048):
+for m in (0, 32, 64, 96, 128, 160, 1024, 2048):
     lib = C.CDLL(os.path.join(here, "_abl", f"libwf_{m}.so"))
     f = lib.cslam_wino4_fused_c64_dev; f.restype = C.c_int
     f.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]
