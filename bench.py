@@ -284,6 +284,7 @@ def main():
             "bound": "mfma", "kernel": "wino4_fused_c64_pipe_kernel", "achieved": round(fflop / fms / 1e9, 1),
             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fflop / fms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4),
             "kernel_ms": round(fms, 3), "algorithmic_flop": fflop,
+            "traffic": (ej.get("fused_conv") or {}).get("traffic_bytes") if (etraffic is not None) else None,
             "algorithmic_bytes": (xf.numel() + yf.numel()) * 4,
             "shape": f"x [{eb},{fh},{fh},64] -> conv 64->64 + bias + ReLU + MaxPool2d -> [{eb},{fh // 2},{fh // 2},64]"}
         del xf, yf
