@@ -69,6 +69,9 @@ _SIGNATURES = {
     "cslam_wino_output_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "cslam_wino4_input_dev": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "cslam_wino4_output_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "cslam_absmax_dev": (_i, [_vp, _i64, _vp, _vp]),
+    "cslam_wino4_input_h3_dev": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "cslam_wino4_output_scaled_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, C.c_float, _vp, _vp, _vp]),
     "cslam_wino2_fused64_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "cslam_wino2_fused_c64_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "cslam_wino4_fused_c64_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),

@@ -10,6 +10,7 @@
 // overlap is served by L2) and V / M are written / read exactly once.
 //   input  bytes per tile-channel: 16 B read (amortised) + 64 B written;   output: 64 B read + 16 B (4 B pooled) written
 #include "common.h"
+#include <hip/hip_fp16.h>
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -410,6 +411,78 @@ __global__ __launch_bounds__(256) void wino4_input_kernel(const float *__restric
         for (int j = 0; j < 6; ++j) __builtin_nontemporal_store(d[i][j], (f2 *)(o + (int64_t)(6 * i + j) * plane));
 }
 
+// ---- split-fp16 form of the 36 GEMMs (opt-in, vpr/winograd.py `split16`) ----
+// A float times a power of two splits exactly into an fp16 pair hi + lo (11 + 11 significant bits); fp16 x fp16 products
+// are exact in the MFMA's fp32 accumulator, so  V U = vh uh + vl uh + vh ul  (the dropped vl ul is 2^-22 of the product)
+// is an fp32-grade product at the fp16 MFMA rate: one GEMM with K' = 3 Cin over  A' = [vh | vl | vh],  B' = [uh ; uh ; ul].
+// The scale keeps max |V| (<= 100 max |x| for B^T d B) below 2^15: s = 2^floor(log2(2^15 / (100 amax))).
+__device__ __forceinline__ float wino_h3_scale(unsigned amax_bits) {
+    const float a = fminf(fmaxf(__uint_as_float(amax_bits), 1e-30f), 1e30f);
+    int e;
+    (void)frexpf(327.68f / a, &e);                        // r = m 2^e, m in [0.5, 1): floor(log2 r) = e - 1
+    return ldexpf(1.0f, e - 1);
+}
+
+// max |x| as float bits in *slot (non-negative floats order like their bit patterns); *slot must be 0 before the launch
+__global__ __launch_bounds__(256) void absmax_kernel(const float *__restrict__ x, int64_t n4, unsigned *__restrict__ slot) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const f4 v = __builtin_nontemporal_load((const f4 *)x + i);
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(slot, __float_as_uint(m));
+}
+
+__global__ __launch_bounds__(256) void wino4_input_h3_kernel(const float *__restrict__ x, int B, int H, int W, int C,
+                                                             const unsigned *__restrict__ amax, __half *__restrict__ V3) {
+    const int c2n = C >> 1;
+    const int64_t bid = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // as wino4_input_kernel
+    const int64_t gid = bid * 256 + threadIdx.x;
+    const int TH = (H + 3) >> 2, TW = (W + 3) >> 2;
+    const int64_t T = (int64_t)B * TH * TW;
+    if (gid >= T * c2n) return;
+    const int c2 = (int)(gid % c2n);
+    const int64_t t = gid / c2n;
+    const int tj = (int)(t % TW);
+    const int ti = (int)((t / TW) % TH);
+    const int b = (int)(t / ((int64_t)TW * TH));
+    const int h0 = 4 * ti - 1, w0 = 4 * tj - 1;
+    const float sc = wino_h3_scale(*amax);
+    f2 d[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int h = h0 + i;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int w = w0 + j;
+            const bool in = (h >= 0) & (h < H) & (w >= 0) & (w < W);
+            const f2 v = *((const f2 *)(x + (((int64_t)b * H + (in ? h : 0)) * W + (in ? w : 0)) * C) + c2);
+            d[i][j] = in ? v * sc : (f2)(0.0f);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) wino4_bt(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wino4_bt(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);
+    const int64_t plane = T * 3 * C;
+    __half *o = V3 + t * 3 * C + 2 * c2;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const __half2 hi = __floats2half2_rn(d[i][j].x, d[i][j].y);
+            const float2 hf = __half22float2(hi);
+            const __half2 lo = __floats2half2_rn(d[i][j].x - hf.x, d[i][j].y - hf.y);
+            __half *q = o + (int64_t)(6 * i + j) * plane;
+            *(__half2 *)q = hi;
+            *(__half2 *)(q + C) = lo;
+            *(__half2 *)(q + 2 * C) = hi;
+        }
+}
+
 __device__ __forceinline__ void wino4_at(const f2 m0, const f2 m1, const f2 m2, const f2 m3, const f2 m4, const f2 m5,
                                          f2 &s0, f2 &s1, f2 &s2, f2 &s3) {
     const f2 a = m1 + m2, bq = m1 - m2, c = m3 + m4, e = m3 - m4;
@@ -422,7 +495,8 @@ __device__ __forceinline__ void wino4_at(const f2 m0, const f2 m1, const f2 m2, 
 template <bool RELU, bool POOL>
 __global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restrict__ M, const float *__restrict__ bias,
                                                            const float *__restrict__ res, int B, int H, int W, int C,
-                                                           float *__restrict__ y) {
+                                                           float *__restrict__ y, const unsigned *__restrict__ amax,
+                                                           float inv_su, unsigned *__restrict__ amax_out) {
     const int c2n = C >> 1;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int TH = (H + 3) >> 2, TW = (W + 3) >> 2;      // ragged maps: the last tile row / column is partly outside
@@ -432,6 +506,8 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restri
     const int64_t t = gid / c2n;
     const int64_t plane = T * C;
     const float *p = M + t * C + 2 * c2;
+    // split-fp16 GEMM (wino4_input_h3_kernel): M arrives times sV sU, both powers of two -> the rescale is exact
+    const float inv = amax ? inv_su / wino_h3_scale(*amax) : 1.0f;
     f2 s[4][6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
@@ -450,11 +526,22 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restri
         wino4_at(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o[i][0], o[i][1], o[i][2], o[i][3]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            o[i][j] += bv;
+            o[i][j] = amax ? o[i][j] * inv + bv : o[i][j] + bv;
             if (res && 4 * ti + i < H && 4 * tj + j < W)
                 o[i][j] += *((const f2 *)(res + (((int64_t)b * H + 4 * ti + i) * W + 4 * tj + j) * C) + c2);
             if (RELU) o[i][j] = __builtin_elementwise_max(o[i][j], (f2)(0.0f));
         }
+    }
+    if (amax_out) {
+        // upper bound of max |y| for the next layer's split-fp16 scale (pre-pool values bound the pooled ones); the plain
+        // read keeps all but the first few record holders away from the atomic
+        float m = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (4 * ti + i < H && 4 * tj + j < W) m = fmaxf(m, fmaxf(fabsf(o[i][j].x), fabsf(o[i][j].y)));
+        if (m > __uint_as_float(*(volatile unsigned *)amax_out)) atomicMax(amax_out, __float_as_uint(m));
     }
     if (POOL) {
         const int Ho = H >> 1, Wo = W >> 1;
@@ -494,8 +581,9 @@ CSLAM_API int cslam_wino4_input_dev(const float *d_x, int B, int H, int W, int C
     return CSLAM_OK;
 }
 
-CSLAM_API int cslam_wino4_output_dev(const float *d_M, const float *d_bias, const float *d_res, int B, int H, int W,
-                                     int C, int relu, int pool, float *d_y, void *stream) {
+static int wino4_output_launch(const float *d_M, const float *d_bias, const float *d_res, int B, int H, int W, int C,
+                               int relu, int pool, float *d_y, const unsigned *d_amax, float inv_su, unsigned *d_amax_out,
+                               void *stream) {
     ARG_CHECK(d_M && d_y, "NULL argument");
     ARG_CHECK(!(d_res && pool), "a residual input cannot be combined with pooling");
     ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
@@ -504,10 +592,48 @@ CSLAM_API int cslam_wino4_output_dev(const float *d_M, const float *d_bias, cons
     ARG_CHECK(ceil_div64(n, 256) < (1LL << 31), "too many tiles for one launch");
     dim3 grid((unsigned)ceil_div64(n, 256)), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (relu && pool) hipLaunchKernelGGL((wino4_output_kernel<true, true>), grid, block, 0, st, d_M, d_bias, d_res, B, H, W, C, d_y);
-    else if (relu) hipLaunchKernelGGL((wino4_output_kernel<true, false>), grid, block, 0, st, d_M, d_bias, d_res, B, H, W, C, d_y);
-    else if (pool) hipLaunchKernelGGL((wino4_output_kernel<false, true>), grid, block, 0, st, d_M, d_bias, d_res, B, H, W, C, d_y);
-    else hipLaunchKernelGGL((wino4_output_kernel<false, false>), grid, block, 0, st, d_M, d_bias, d_res, B, H, W, C, d_y);
+    if (relu && pool) hipLaunchKernelGGL((wino4_output_kernel<true, true>), grid, block, 0, st, d_M, d_bias, d_res, B, H, W, C, d_y, d_amax, inv_su, d_amax_out);
+    else if (relu) hipLaunchKernelGGL((wino4_output_kernel<true, false>), grid, block, 0, st, d_M, d_bias, d_res, B, H, W, C, d_y, d_amax, inv_su, d_amax_out);
+    else if (pool) hipLaunchKernelGGL((wino4_output_kernel<false, true>), grid, block, 0, st, d_M, d_bias, d_res, B, H, W, C, d_y, d_amax, inv_su, d_amax_out);
+    else hipLaunchKernelGGL((wino4_output_kernel<false, false>), grid, block, 0, st, d_M, d_bias, d_res, B, H, W, C, d_y, d_amax, inv_su, d_amax_out);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
+}
+
+CSLAM_API int cslam_wino4_output_dev(const float *d_M, const float *d_bias, const float *d_res, int B, int H, int W,
+                                     int C, int relu, int pool, float *d_y, void *stream) {
+    return wino4_output_launch(d_M, d_bias, d_res, B, H, W, C, relu, pool, d_y, nullptr, 1.0f, nullptr, stream);
+}
+
+// ---- split-fp16 form: max |x| -> slot, input transform into [36, T, 3 C] fp16 (hi | lo | hi), output transform with the
+// exact power-of-two rescale 1 / (sV sU) ----
+CSLAM_API int cslam_absmax_dev(const float *d_x, int64_t n, unsigned *d_slot, void *stream) {
+    ARG_CHECK(d_x && d_slot, "NULL argument");
+    ARG_CHECK(n >= 4 && (n % 4) == 0, "n must be a positive multiple of 4");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(d_slot, 0, sizeof(unsigned), st));
+    const int64_t blocks = ceil_div64(n / 4, 256);
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, d_x, n / 4, d_slot);
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
+CSLAM_API int cslam_wino4_input_h3_dev(const float *d_x, int B, int H, int W, int C, const unsigned *d_amax, void *d_V3,
+                                       void *stream) {
+    ARG_CHECK(d_x && d_V3 && d_amax, "NULL argument");
+    ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
+    ARG_CHECK(C >= 2 && (C % 2) == 0, "C must be even");
+    const int64_t n = (int64_t)B * ((H + 3) / 4) * ((W + 3) / 4) * (C / 2);
+    ARG_CHECK(ceil_div64(n, 256) < (1LL << 31), "too many tiles for one launch");
+    hipLaunchKernelGGL(wino4_input_h3_kernel, dim3((unsigned)round_up64(ceil_div64(n, 256), 8)), dim3(256), 0,
+                       (hipStream_t)stream, d_x, B, H, W, C, d_amax, (__half *)d_V3);
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
+CSLAM_API int cslam_wino4_output_scaled_dev(const float *d_M, const float *d_bias, const float *d_res, int B, int H, int W,
+                                            int C, int relu, int pool, const unsigned *d_amax, float inv_su,
+                                            unsigned *d_amax_out, float *d_y, void *stream) {
+    ARG_CHECK(inv_su > 0.0f, "inv_su must be positive");
+    return wino4_output_launch(d_M, d_bias, d_res, B, H, W, C, relu, pool, d_y, d_amax, inv_su, d_amax_out, stream);
 }

@@ -12,6 +12,7 @@ The first convolution (3 input channels) stays on torch's direct form, with bias
 in one HIP pass (`cslam_bias_act_pool_dev`).
 """
 import ctypes as C
+import math
 import os
 
 import torch
@@ -32,6 +33,19 @@ def wino_weights(weight, tile=2):
     g = weight.detach().to(torch.float64).cpu()
     u = torch.einsum("ik,ockl,jl->ijco", G, g, G)              # [n,n,Cin,Cout]
     return u.reshape(G.shape[0] ** 2, g.shape[1], g.shape[0]).to(torch.float32).contiguous()
+
+
+def split16_weights(U4):
+    """U4 [36, Cin, Cout] float32 -> (U3 [36, 3 Cin, Cout] float16 = [uh ; uh ; ul], inv_su): the weight operand of the
+    split-fp16 GEMM (csrc/winograd.hip, `wino4_input_h3_kernel`): sU U = uh + ul exactly to 22 bits, sU the power of two
+    that brings max |U| into [2^14, 2^15); inv_su = 1 / sU."""
+    u = U4.detach().to(torch.float64)
+    amax = float(u.abs().max())
+    su = 2.0 ** (14 - math.floor(math.log2(amax))) if amax > 0 else 1.0
+    us = (u * su).to(torch.float32)                                  # exact: a power-of-two scale of float32 values
+    uh = us.to(torch.float16)
+    ul = (us - uh.to(torch.float32)).to(torch.float16)
+    return torch.cat((uh, uh, ul), dim=1).contiguous(), 1.0 / su
 
 
 def fused64_weights(U):
@@ -84,10 +98,15 @@ def use_tuned_gemms():
         warnings.warn("cslam_amd: tuned GEMM table not loaded (%s)" % e)
 
 
-def wino_conv3x3(ws, x, U, U4, bias, relu, pool=False, residual=None):
+def wino_conv3x3(ws, x, U, U4, bias, relu, pool=False, residual=None, U3=None, amax_in=None, amax_out=None):
     """3x3 / stride 1 / pad 1 convolution of x [B,Cin,H,W] (channels_last storage, any H and W) through the
     Winograd pipeline; U / U4 from `wino_weights` (U4 None = F(2x2,3x3) only).  bias [Cout] or None, residual
-    (channels_last, shaped like the output) is added before the ReLU.  `ws` owns the V / M workspaces."""
+    (channels_last, shaped like the output) is added before the ReLU.  `ws` owns the V / M workspaces.
+    U3 = `split16_weights(U4)`: the F(4x4) GEMMs run as one fp16 GEMM with fp32 accumulation over the exact hi / lo
+    split of both operands (three of the four partial products: fp32-grade, at the fp16 MFMA rate).
+    amax_in: 4-byte device slot already holding the bits of (a bound of) max |x| -- saves the pass over x; amax_out: zeroed
+    slot that receives the same for y from the F(4x4) output transform.  Returns y; `ws.amax_written` says whether amax_out
+    was filled (only the F(4x4) output kernel does it)."""
     lib = _lib.load()
     B, Cin, H, W = x.shape
     Cout = U.shape[2]
@@ -97,6 +116,27 @@ def wino_conv3x3(ws, x, U, U4, bias, relu, pool=False, residual=None):
     four = U4 is not None and B * t4h * t4w >= 512 and 16 * t4h * t4w <= 1.35 * H * W
     n2, Uu = (36, U4) if four else (16, U)
     T = B * t4h * t4w if four else B * t2h * t2w
+    if four and U3 is not None:
+        s = _stream(x)
+        slot = amax_in
+        if slot is None:
+            slot = ws._buf("amax", 1, x.device)                         # 4 bytes: bits of max |x|
+            _lib.check(lib.cslam_absmax_dev(_p(x), x.numel(), _p(slot), s))
+        V3 = ws._buf("V", (36 * T * 3 * Cin + 1) // 2, x.device).view(torch.float16)[:36 * T * 3 * Cin].view(36, T, 3 * Cin)
+        _lib.check(lib.cslam_wino4_input_h3_dev(_p(x), B, H, W, Cin, _p(slot), _p(V3), s))
+        M = torch.bmm(V3, U3[0], out_dtype=torch.float32)
+        Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+        y = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        if residual is not None:
+            residual = residual.contiguous(memory_format=torch.channels_last)
+            assert residual.shape == y.shape and not pool
+        _lib.check(lib.cslam_wino4_output_scaled_dev(
+            _p(M), _p(bias) if bias is not None else None, _p(residual) if residual is not None else None,
+            B, H, W, Cout, int(relu), int(pool), _p(slot), float(U3[1]), _p(amax_out) if amax_out is not None else None,
+            _p(y), s))
+        ws.amax_written = amax_out is not None
+        return y
+    ws.amax_written = False
     V = ws._buf("V", n2 * T * Cin, x.device).view(n2, T, Cin)
     M = ws._buf("M", n2 * T * Cout, x.device).view(n2, T, Cout)
     s = _stream(x)
@@ -109,6 +149,12 @@ def wino_conv3x3(ws, x, U, U4, bias, relu, pool=False, residual=None):
     if residual is not None:
         residual = residual.contiguous(memory_format=torch.channels_last)
         assert residual.shape == y.shape and not pool
+    if four and amax_out is not None:
+        _lib.check(lib.cslam_wino4_output_scaled_dev(
+            _p(M), _p(bias) if bias is not None else None, _p(residual) if residual is not None else None,
+            B, H, W, Cout, int(relu), int(pool), None, 1.0, _p(amax_out), _p(y), s))
+        ws.amax_written = True
+        return y
     _lib.check(fout(_p(M), _p(bias) if bias is not None else None, _p(residual) if residual is not None else None,
                     B, H, W, Cout, int(relu), int(pool), _p(y), s))
     return y
@@ -117,6 +163,7 @@ def wino_conv3x3(ws, x, U, U4, bias, relu, pool=False, residual=None):
 class _Workspace(object):
     def __init__(self):
         self._ws = {}
+        self.amax_written = False
 
     def _buf(self, name, numel, device):
         b = self._ws.get(name)
@@ -211,11 +258,11 @@ class WinogradResNet(_Workspace):
 
 
 class _Step(object):
-    __slots__ = ("kind", "module", "conv", "relu", "pool", "U", "U4", "Up", "bias")
+    __slots__ = ("kind", "module", "conv", "relu", "pool", "U", "U4", "U3", "Up", "bias")
 
     def __init__(self):
         self.kind, self.module, self.conv, self.relu, self.pool = "torch", None, None, False, False
-        self.U, self.U4, self.Up, self.bias = None, None, None, None
+        self.U, self.U4, self.U3, self.Up, self.bias = None, None, None, None, None
 
 
 class WinogradTrunk(_Workspace):
@@ -233,6 +280,8 @@ class WinogradTrunk(_Workspace):
         self.fused64 = (os.environ.get("CSLAM_WINO_FUSED64", "1") != "0") if fused64 is None else bool(fused64)
         self.fused_min_blocks = int(os.environ.get("CSLAM_WINO_FUSED_MIN_BLOCKS", "256"))
         self.fused_couts = tuple(int(c) for c in os.environ.get("CSLAM_WINO_FUSED_COUTS", "64,128").split(","))
+        # split-fp16 GEMMs on the F(4x4) layers from this many input channels on (0 = off); see `split16_weights`
+        self.split16_min_cin = int(os.environ.get("CSLAM_WINO_SPLIT16", "0"))
         use_tuned_gemms()
         self.refresh()
 
@@ -251,6 +300,8 @@ class WinogradTrunk(_Workspace):
                 st.kind, st.conv, st.relu, st.pool = "wino", m, False, False
                 st.U = wino_weights(m.weight).to(m.weight.device)
                 st.U4 = wino_weights(m.weight, 4).to(m.weight.device) if self.tile == 4 else None
+                if st.U4 is not None and 0 < self.split16_min_cin <= m.in_channels:
+                    st.U3 = split16_weights(st.U4)
                 if self.fused64 and m.in_channels == 64 and m.out_channels in self.fused_couts:
                     # F(4x4) one-kernel form on the F(4x4) trunk (CSLAM_WINO_FUSED_TILE=2 keeps the F(2x2) one)
                     t4 = self.tile == 4 and os.environ.get("CSLAM_WINO_FUSED_TILE", "4") == "4"
@@ -298,7 +349,13 @@ class WinogradTrunk(_Workspace):
     def __call__(self, x):
         """x [B,C,H,W] float32 (any memory format) -> [B,C',H',W'] float32, channels_last memory."""
         lib = _lib.load()
-        for st in self.steps:
+        # one 4-byte slot per step for max |activation| between consecutive split-fp16 layers
+        slots = amax_ready = None
+        if any(st.U3 is not None for st in self.steps):
+            slots = self._buf("amax_slots", len(self.steps) + 1, x.device)
+            slots.zero_()
+        for k, st in enumerate(self.steps):
+            have, amax_ready = amax_ready, None
             if st.kind == "c3":
                 x = x.contiguous()                                   # planar [B,3,H,W]
                 B, _, H, W = x.shape
@@ -332,6 +389,10 @@ class WinogradTrunk(_Workspace):
                 if nblk >= self.fused_min_blocks:
                     x = wino_fused64(x, st.Up, st.bias, st.relu, st.pool)
                     continue
-            y = wino_conv3x3(self, x, st.U, st.U4, st.bias, st.relu, st.pool)
+            nxt = self.steps[k + 1] if k + 1 < len(self.steps) else None
+            want = slots[k + 1:k + 2] if (nxt is not None and nxt.U3 is not None) else None
+            y = wino_conv3x3(self, x, st.U, st.U4, st.bias, st.relu, st.pool, U3=st.U3,
+                             amax_in=slots[k:k + 1] if have else None, amax_out=want)
+            amax_ready = want is not None and self.amax_written
             x = y
         return x

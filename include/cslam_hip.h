@@ -262,6 +262,19 @@ int cslam_wino_output_dev(const float *d_M, const float *d_bias, const float *d_
 int cslam_wino4_input_dev(const float *d_x, int B, int H, int W, int C, float *d_V, void *stream);
 int cslam_wino4_output_dev(const float *d_M, const float *d_bias, const float *d_residual, int B, int H, int W,
                            int C, int relu, int pool, float *d_y, void *stream);
+/* Split-fp16 form of the 36 per-frequency GEMMs of the same layer (opt-in; same fp32-grade result, fp16 MFMA rate):
+ * a float times a power of two is split exactly into an fp16 pair hi + lo, and V U = vh uh + vl uh + vh ul is ONE fp16
+ * GEMM with fp32 accumulation over K' = 3 C:  V3 [36, T, 3 C] fp16 rows = [vh | vl | vh],  U3 [36, 3 C, Cout] = [uh ; uh ; ul].
+ * cslam_absmax_dev: *d_slot = bits of max |x| (n a multiple of 4); the V scale sV = 2^floor(log2(2^15 / (100 max|x|))) is
+ * derived from it on the device by both transforms.  cslam_wino4_output_scaled_dev: as cslam_wino4_output_dev on
+ * M' = sV sU M, multiplied by inv_su / sV (inv_su = 1 / sU, a power of two: exact) before bias / residual / ReLU
+ * (d_amax NULL: M unscaled, inv_su ignored); d_amax_out (or NULL): atomic max of the bits of max |y| before pooling --
+ * the next layer's d_amax without another pass over y; the caller zeroes it beforehand. */
+int cslam_absmax_dev(const float *d_x, int64_t n, unsigned *d_slot, void *stream);
+int cslam_wino4_input_h3_dev(const float *d_x, int B, int H, int W, int C, const unsigned *d_amax, void *d_V3, void *stream);
+int cslam_wino4_output_scaled_dev(const float *d_M, const float *d_bias, const float *d_residual, int B, int H, int W,
+                                  int C, int relu, int pool, const unsigned *d_amax, float inv_su, unsigned *d_amax_out,
+                                  float *d_y, void *stream);
 /* The same 3x3 / stride 1 / pad 1 convolution for 64 -> 64 channels (VGG-16 conv1_2, netvlad.py:163-171 +
  * the call at :227) as ONE kernel: F(2x2,3x3) input transform, the 16 per-frequency products on the fp32 MFMA pipe
  * and output transform + bias + ReLU (+ MaxPool2d(2,2)) with V and M kept on the compute unit (csrc/wino_fused.hip).

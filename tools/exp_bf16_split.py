@@ -27,3 +27,29 @@ def run(M, K, N):
 
 for K in (128, 256, 512):
     run(2048, K, 512)
+
+
+def split2h(x):
+    """fp16 two-way split (11 + 11 significant bits); x scaled by a power of two so that max|x| < 2^15 (exact)."""
+    sc = 2.0 ** (14 - torch.floor(torch.log2(x.abs().max())))
+    xs = x * sc
+    h = xs.to(torch.float16).float()
+    l = (xs - h).to(torch.float16).float()
+    return h, l, sc
+
+
+def run_h(M, K, N, amp):
+    # activations with a wide range (post-ReLU times a Winograd-like amplification), weights O(1/sqrt(K))
+    A = torch.relu(torch.randn(M, K)) * torch.exp(2.0 * torch.randn(M, 1)) * amp
+    B = torch.randn(K, N) / K ** 0.5
+    ref = A.double() @ B.double()
+    s = ref.abs().max()
+    (ah, al, sa), (bh, bl, sb) = split2h(A), split2h(B)
+    c3 = ((ah @ bh) + ((ah @ bl) + (al @ bh))) / (sa * sb)
+    e = lambda c: float((c.double() - ref).abs().max() / s)
+    print(f"fp16 hi/lo x3, M={M} K={K} N={N} amp={amp:g}: fp32 {e(A @ B):.2e}   fp16x3 {e(c3):.2e}")
+
+
+for K in (128, 512):
+    for amp in (1.0, 100.0):
+        run_h(2048, K, 512, amp)
