@@ -179,6 +179,24 @@ def main():
     if extractor is not None:
         de = timed(extract, a.steps)
         extract_only = world * a.batch * a.steps / de
+    # the same extract leg with the trunk's GEMMs as plain fp32 (rocBLAS sgemm) instead of the default split-fp16 pairs
+    # (fp32-grade either way): reported beside `extract_only`, rank 0 at N = 1 only
+    extract_fp32_gemms = None
+    split16 = os.environ.get("CSLAM_WINO_SPLIT16", "256")
+    if extractor is not None and world == 1 and extractor.backbone_conv == "winograd" and split16 != "0":
+        os.environ["CSLAM_WINO_SPLIT16"] = "0"
+        try:
+            ex32 = NetVLAD({"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376,
+                            "frontend.netvlad.pca_dim": a.dim, "frontend.random_seed": 0,
+                            "frontend.backbone_conv": a.backbone_conv}, None)
+            ex32.compute_embeddings_device(frames[:a.extract_chunk], bdt)
+        finally:
+            os.environ["CSLAM_WINO_SPLIT16"] = split16
+        d32 = timed(lambda: [ex32.compute_embeddings_device(frames[s_:s_ + a.extract_chunk], bdt)
+                             for s_ in range(0, a.batch, a.extract_chunk)], a.steps)
+        extract_fp32_gemms = a.batch * a.steps / d32
+        del ex32
+        torch.cuda.empty_cache()
     nqm = a.match_queries
     mq = torch.randn((nqm, a.dim), generator=qgen, device=dev)
     mq /= mq.norm(dim=1, keepdim=True)
@@ -339,6 +357,12 @@ def main():
                                        else "1 robot bank per GPU, RCCL all-gather of new descriptors")},
             "extract_only": None if extract_only is None else round(extract_only, 2),
             "backbone_conv": None if extractor is None else extractor.backbone_conv,
+            "trunk_gemm": None if extractor is None or extractor.backbone_conv != "winograd" else (
+                "plain fp32 (rocBLAS sgemm)" if split16 == "0" else
+                "layers from %s input channels on: exact fp16 hi/lo pairs of both operands, 3 of the 4 partial products in ONE "
+                "fp16-MFMA GEMM with fp32 accumulation (error vs float64 = that of the fp32 GEMM, tests/test_heads_gpu.py::"
+                "test_split16_*); the others fp32" % split16),
+            "extract_only_fp32_gemms": None if extract_fp32_gemms is None else round(extract_fp32_gemms, 2),
             "match_only": round(match_only, 2),
             "match_only_queries": nqm,
             "uncertified_queries": int(uncertified),

@@ -280,8 +280,10 @@ class WinogradTrunk(_Workspace):
         self.fused64 = (os.environ.get("CSLAM_WINO_FUSED64", "1") != "0") if fused64 is None else bool(fused64)
         self.fused_min_blocks = int(os.environ.get("CSLAM_WINO_FUSED_MIN_BLOCKS", "256"))
         self.fused_couts = tuple(int(c) for c in os.environ.get("CSLAM_WINO_FUSED_COUTS", "64,128").split(","))
-        # split-fp16 GEMMs on the F(4x4) layers from this many input channels on (0 = off); see `split16_weights`
-        self.split16_min_cin = int(os.environ.get("CSLAM_WINO_SPLIT16", "0"))
+        # split-fp16 GEMMs on the F(4x4) layers from this many input channels on (0 = off: plain fp32 GEMMs); see
+        # `split16_weights`.  256 is the measured optimum on VGG-16 (profiles/r01_exp_split16.log): below it the 1.5x larger
+        # V costs more than the GEMM gains
+        self.split16_min_cin = int(os.environ.get("CSLAM_WINO_SPLIT16", "256"))
         use_tuned_gemms()
         self.refresh()
 

@@ -485,3 +485,87 @@ def test_fused_winograd_f4_equals_float64(T, cout, B, H, W, relu, pool, bias):
     assert yf.shape == ref.shape
     ef = (yf.double() - ref).abs().max().item() / ref.abs().max().item()
     assert ef <= 2e-5, ef
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,cin,cout,relu,pool,amp", [
+    (8, 56, 56, 128, 256, True, False, 1.0), (8, 56, 56, 128, 256, True, True, 1e3), (32, 14, 14, 512, 512, True, False, 1e-3),
+    (16, 28, 28, 256, 512, False, False, 1.0), (40, 13, 15, 256, 256, True, False, 1.0)])
+def test_split16_winograd_layer_is_fp32_grade(T, B, H, W, cin, cout, relu, pool, amp):
+    """Split-fp16 form of the 36 GEMMs (csrc/winograd.hip `wino4_input_h3_kernel`, vpr/winograd.py `split16_weights`):
+    against a float64 convolution its error is that of the plain-fp32 three-kernel form (within 1.5x, and inside the
+    F(4x4) tolerance of 2e-5 of the largest activation), at activation magnitudes six decades apart (the power-of-two
+    scale), with the ragged last tile row / column, and the max |y| slot written by the output transform is a bound."""
+    torch, _ = T
+    from cslam_amd.vpr import winograd as wg
+    torch.manual_seed(31)
+    x = (torch.relu(torch.randn(B, cin, H, W, device="cuda")) * amp).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(cout, cin, 3, 3, device="cuda") / (3 * cin ** 0.5)
+    b = torch.randn(cout, device="cuda") * amp
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+    ref = torch.relu(ref) if relu else ref
+    prepool = ref
+    ref = torch.nn.functional.max_pool2d(ref, 2, 2) if pool else ref
+    ws = wg._Workspace()
+    U, U4 = wg.wino_weights(w).cuda(), wg.wino_weights(w, 4).cuda()
+    U3 = wg.split16_weights(U4)
+    rec = (U3[0][:, :cin].double() + U3[0][:, 2 * cin:].double()) * U3[1]
+    assert (rec - U4.double()).abs().max().item() <= 2.0 ** -21 * U4.abs().max().item()
+    assert torch.equal(U3[0][:, :cin], U3[0][:, cin:2 * cin])
+    slot = torch.zeros(1, dtype=torch.float32, device="cuda")
+    y32 = wg.wino_conv3x3(ws, x, U, U4, b, relu, pool)
+    y16 = wg.wino_conv3x3(ws, x, U, U4, b, relu, pool, U3=U3, amax_out=slot)
+    assert ws.amax_written
+    s = ref.abs().max().item()
+    e32 = (y32.double() - ref).abs().max().item() / s
+    e16 = (y16.double() - ref).abs().max().item() / s
+    assert e16 <= 2e-5 and e16 <= 1.5 * e32 + 1e-7, (e16, e32)
+    bound = slot.item()
+    assert prepool.abs().max().item() * (1 - 1e-4) <= bound <= prepool.abs().max().item() * (1 + 1e-4)
+    # the slot as the next call's amax_in gives the same result as the separate pass over x (same scale either way
+    # whenever the bound and the exact maximum fall into the same power-of-two bucket; here they are the same number)
+    if not pool:
+        xs = y16
+        w2 = torch.randn(cout, cout, 3, 3, device="cuda") / (3 * cout ** 0.5)
+        V2, V4 = wg.wino_weights(w2).cuda(), wg.wino_weights(w2, 4).cuda()
+        V3 = wg.split16_weights(V4)
+        ya = wg.wino_conv3x3(ws, xs, V2, V4, None, True, False, U3=V3)
+        yb = wg.wino_conv3x3(ws, xs, V2, V4, None, True, False, U3=V3, amax_in=slot)
+        r2 = torch.relu(torch.nn.functional.conv2d(xs.double(), w2.double(), None, padding=1))
+        s2 = r2.abs().max().item()
+        assert (ya.double() - r2).abs().max().item() <= 2e-5 * s2
+        assert (yb.double() - r2).abs().max().item() <= 2e-5 * s2
+
+
+@pytest.mark.gpu
+def test_split16_trunk_equals_fp32_gemm_trunk(T):
+    """VGG-16 trunk with the split-fp16 GEMMs (default from 256 input channels) against the same trunk on plain fp32
+    GEMMs (CSLAM_WINO_SPLIT16=0) and against a float64 evaluation: the split form is not the less accurate of the two by
+    more than 1.5x, and both sit inside the trunk tolerance used for the fp32 form."""
+    torch, _ = T
+    from cslam_amd.vpr.backbones import vgg16_features_trunk
+    from cslam_amd.vpr.winograd import WinogradTrunk
+    torch.manual_seed(37)
+    enc = vgg16_features_trunk().cuda().eval()
+    x = torch.randn((32, 3, 224, 224), device="cuda")     # 32 frames: conv5_x (4 x 4 tiles per frame) reaches the 512-tile F(4x4) floor
+    old = os.environ.get("CSLAM_WINO_SPLIT16")
+    try:
+        os.environ["CSLAM_WINO_SPLIT16"] = "0"
+        t32 = WinogradTrunk(enc, 64, 4)
+        os.environ["CSLAM_WINO_SPLIT16"] = "256"
+        t16 = WinogradTrunk(enc, 64, 4)
+    finally:
+        if old is None:
+            os.environ.pop("CSLAM_WINO_SPLIT16", None)
+        else:
+            os.environ["CSLAM_WINO_SPLIT16"] = old
+    assert all(st.U3 is None for st in t32.steps)
+    assert sum(st.U3 is not None for st in t16.steps) == 8          # conv3_2 ... conv5_3
+    y32, y16 = t32(x), t16(x)
+    with torch.no_grad():
+        ref = enc.double()(x.double())
+    enc.float()
+    s = ref.abs().max().item()
+    e32 = (y32.double() - ref).abs().max().item() / s
+    e16 = (y16.double() - ref).abs().max().item() / s
+    assert e32 <= 2e-5 and e16 <= 2e-5 and e16 <= 1.5 * e32 + 1e-7, (e16, e32)
