@@ -124,6 +124,8 @@ def wino_conv3x3(ws, x, U, U4, bias, relu, pool=False, residual=None, U3=None, a
             _lib.check(lib.cslam_absmax_dev(_p(x), x.numel(), _p(slot), s))
         V3 = ws._buf("V", (36 * T * 3 * Cin + 1) // 2, x.device).view(torch.float16)[:36 * T * 3 * Cin].view(36, T, 3 * Cin)
         _lib.check(lib.cslam_wino4_input_h3_dev(_p(x), B, H, W, Cin, _p(slot), _p(V3), s))
+        # torch 2.10's TunableOp does not cover `bmm` with out_dtype; hipBLASLt's default solution is used.  Routing it to
+        # rocBLAS instead is 3-13 % faster on the isolated GEMMs and not measurable on the trunk (profiles/r01_exp_split16.log)
         M = torch.bmm(V3, U3[0], out_dtype=torch.float32)
         Ho, Wo = (H // 2, W // 2) if pool else (H, W)
         y = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
