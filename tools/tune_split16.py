@@ -1,4 +1,6 @@
-"""Extend vpr/tunableop_gfx950.csv with the fp16 -> fp32 strided-batched GEMM shapes of the split-fp16 trunk layers
+"""RESULT (torch 2.10 + ROCm 7.0): TunableOp does not intercept `bmm` with `out_dtype`, so this tunes nothing and the table
+comes back unchanged (profiles/r01_exp_split16.log); kept for the torch release that does.
+Intent: extend vpr/tunableop_gfx950.csv with the fp16 -> fp32 strided-batched GEMM shapes of the split-fp16 trunk layers
 (VGG-16 at the 256-frame chunk: conv3_2/3_3, conv4_1, conv4_2/4_3, conv5_x).  Existing entries are kept (read first),
 the table is rewritten after every shape so that a time-out loses only the shape in flight.  Run on the GPU box:
     python tools/tune_split16.py gpurun_out/tunableop_split16.csv"""
