@@ -497,6 +497,11 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restri
                                                            const float *__restrict__ res, int B, int H, int W, int C,
                                                            float *__restrict__ y, const unsigned *__restrict__ amax,
                                                            float inv_su, unsigned *__restrict__ amax_out) {
+    __shared__ unsigned wg_amax;
+    if (amax_out) {                                       // before any thread leaves: every wave of the workgroup is here
+        if (threadIdx.x == 0) wg_amax = 0u;
+        __syncthreads();
+    }
     const int c2n = C >> 1;
     const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int TH = (H + 3) >> 2, TW = (W + 3) >> 2;      // ragged maps: the last tile row / column is partly outside
@@ -533,15 +538,18 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restri
         }
     }
     if (amax_out) {
-        // upper bound of max |y| for the next layer's split-fp16 scale (pre-pool values bound the pooled ones); the plain
-        // read keeps all but the first few record holders away from the atomic
+        // upper bound of max |y| for the next layer's split-fp16 scale (pre-pool values bound the pooled ones): LDS maximum
+        // per workgroup, then one global atomic per workgroup and only if it would raise the slot.  Waves that left at the
+        // range check have ended and are not waited for; thread 0 of a workgroup with any live thread is live.
         float m = 0.0f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (4 * ti + i < H && 4 * tj + j < W) m = fmaxf(m, fmaxf(fabsf(o[i][j].x), fabsf(o[i][j].y)));
-        if (m > __uint_as_float(*(volatile unsigned *)amax_out)) atomicMax(amax_out, __float_as_uint(m));
+        atomicMax(&wg_amax, __float_as_uint(m));
+        __syncthreads();
+        if (threadIdx.x == 0 && wg_amax > *(volatile unsigned *)amax_out) atomicMax(amax_out, wg_amax);
     }
     if (POOL) {
         const int Ho = H >> 1, Wo = W >> 1;
