@@ -11,6 +11,7 @@
 //   input  bytes per tile-channel: 16 B read (amortised) + 64 B written;   output: 64 B read + 16 B (4 B pooled) written
 #include "common.h"
 #include <hip/hip_fp16.h>
+#include <cstdlib>
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -483,6 +484,69 @@ __global__ __launch_bounds__(256) void wino4_input_h3_kernel(const float *__rest
         }
 }
 
+typedef float wf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void wino4_bt4(wf4 &d0, wf4 &d1, wf4 &d2, wf4 &d3, wf4 &d4, wf4 &d5) {   // wino4_bt on 4 channels
+    const wf4 r0 = 4.0f * d0 - 5.0f * d2 + d4;
+    const wf4 r1 = -4.0f * (d1 + d2) + d3 + d4;
+    const wf4 r2 = 4.0f * (d1 - d2) - d3 + d4;
+    const wf4 r3 = 2.0f * (d3 - d1) - d2 + d4;
+    const wf4 r4 = 2.0f * (d1 - d3) - d2 + d4;
+    const wf4 r5 = 4.0f * d1 - 5.0f * d3 + d5;
+    d0 = r0; d1 = r1; d2 = r2; d3 = r3; d4 = r4; d5 = r5;
+}
+
+// wino4_input_h3_kernel with 4 consecutive channels per thread: 16-byte loads, 8-byte fp16 stores (C a multiple of 4)
+__global__ __launch_bounds__(256) void wino4_input_h3x4_kernel(const float *__restrict__ x, int B, int H, int W, int C,
+                                                               const unsigned *__restrict__ amax, __half *__restrict__ V3) {
+    const int c4n = C >> 2;
+    const int64_t bid = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int64_t gid = bid * 256 + threadIdx.x;
+    const int TH = (H + 3) >> 2, TW = (W + 3) >> 2;
+    const int64_t T = (int64_t)B * TH * TW;
+    if (gid >= T * c4n) return;
+    const int c4 = (int)(gid % c4n);
+    const int64_t t = gid / c4n;
+    const int tj = (int)(t % TW);
+    const int ti = (int)((t / TW) % TH);
+    const int b = (int)(t / ((int64_t)TW * TH));
+    const int h0 = 4 * ti - 1, w0 = 4 * tj - 1;
+    const float sc = wino_h3_scale(*amax);
+    wf4 d[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int h = h0 + i;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int w = w0 + j;
+            const bool in = (h >= 0) & (h < H) & (w >= 0) & (w < W);
+            const wf4 v = *((const wf4 *)(x + (((int64_t)b * H + (in ? h : 0)) * W + (in ? w : 0)) * C) + c4);
+            d[i][j] = in ? v * sc : (wf4)(0.0f);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) wino4_bt4(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wino4_bt4(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);
+    const int64_t plane = T * 3 * C;
+    __half *o = V3 + t * 3 * C + 4 * c4;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const wf4 v = d[i][j];
+            const __half2 h0v = __floats2half2_rn(v.x, v.y), h1v = __floats2half2_rn(v.z, v.w);
+            const float2 f0 = __half22float2(h0v), f1 = __half22float2(h1v);
+            const __half2 l0v = __floats2half2_rn(v.x - f0.x, v.y - f0.y), l1v = __floats2half2_rn(v.z - f1.x, v.w - f1.y);
+            uint2 hi, lo;
+            hi.x = *(const unsigned *)&h0v; hi.y = *(const unsigned *)&h1v;
+            lo.x = *(const unsigned *)&l0v; lo.y = *(const unsigned *)&l1v;
+            __half *q = o + (int64_t)(6 * i + j) * plane;
+            *(uint2 *)q = hi;
+            *(uint2 *)(q + C) = lo;
+            *(uint2 *)(q + 2 * C) = hi;
+        }
+}
+
 __device__ __forceinline__ void wino4_at(const f2 m0, const f2 m1, const f2 m2, const f2 m3, const f2 m4, const f2 m5,
                                          f2 &s0, f2 &s1, f2 &s2, f2 &s3) {
     const f2 a = m1 + m2, bq = m1 - m2, c = m3 + m4, e = m3 - m4;
@@ -633,8 +697,14 @@ CSLAM_API int cslam_wino4_input_h3_dev(const float *d_x, int B, int H, int W, in
     ARG_CHECK(C >= 2 && (C % 2) == 0, "C must be even");
     const int64_t n = (int64_t)B * ((H + 3) / 4) * ((W + 3) / 4) * (C / 2);
     ARG_CHECK(ceil_div64(n, 256) < (1LL << 31), "too many tiles for one launch");
-    hipLaunchKernelGGL(wino4_input_h3_kernel, dim3((unsigned)round_up64(ceil_div64(n, 256), 8)), dim3(256), 0,
-                       (hipStream_t)stream, d_x, B, H, W, C, d_amax, (__half *)d_V3);
+    if ((C % 4) == 0 && !getenv("CSLAM_H3_C2")) {
+        const int64_t n4 = n / 2;
+        hipLaunchKernelGGL(wino4_input_h3x4_kernel, dim3((unsigned)round_up64(ceil_div64(n4, 256), 8)), dim3(256), 0,
+                           (hipStream_t)stream, d_x, B, H, W, C, d_amax, (__half *)d_V3);
+    } else {
+        hipLaunchKernelGGL(wino4_input_h3_kernel, dim3((unsigned)round_up64(ceil_div64(n, 256), 8)), dim3(256), 0,
+                           (hipStream_t)stream, d_x, B, H, W, C, d_amax, (__half *)d_V3);
+    }
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }
