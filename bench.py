@@ -66,8 +66,26 @@ def parse():
     return ap.parse_args()
 
 
+def self_launch(a):
+    """`python bench.py --gpus N` (no launcher): re-exec under torch.distributed.run with N ranks, one per GPU.
+    Returns the child's exit code; never returns when the environment already carries a rank."""
+    import socket
+    import subprocess
+    with socket.socket() as s:                       # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(a))
     import torch
     import torch.distributed as dist
     from cslam_amd import nns_matching as nnm
@@ -77,6 +95,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: the launcher must create exactly "
+                         f"--gpus ranks (python bench.py --gpus N launches them itself)")
+    if not a.debug_shared_gpu and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py: --gpus {world} needs {world} visible GPUs, found {torch.cuda.device_count()} "
+                         f"(--debug-shared-gpu runs the N-rank control flow on one GPU, numbers meaningless)")
     if world > 1 and a.debug_shared_gpu:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         local_rank = 0
@@ -86,7 +110,6 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == a.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     torch.backends.cudnn.benchmark = True

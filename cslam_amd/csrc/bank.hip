@@ -23,6 +23,12 @@ void cslam_set_error(const char *fmt, ...) {
 CSLAM_API const char *cslam_last_error(void) { return g_err; }
 CSLAM_API int cslam_version(void) { return 100; }
 
+int cslam_visible_devices() {
+    static int n = -1;                      // a benign race: every thread computes the same value
+    if (n < 0) { int c = 0; n = (hipGetDeviceCount(&c) == hipSuccess) ? c : 0; if (n == 0) (void)hipGetLastError(); }
+    return n;
+}
+
 CSLAM_API int cslam_device_count(int *count) {
     ARG_CHECK(count, "count is NULL");
     HIP_TRY(hipGetDeviceCount(count));
@@ -58,6 +64,9 @@ static int bank_grow(cslam_bank *b, int64_t need) {
     HIP_TRY(hipMalloc((void **)&vv, (size_t)ncap * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&invn, (size_t)ncap * sizeof(float)));
     if (b->n > 0) {
+        // rows appended just before this call may still be in flight on a non-blocking stream, which the
+        // null-stream copies below are not ordered against: drain the device first (a grow happens log2(n) times)
+        HIP_TRY(hipDeviceSynchronize());
         HIP_TRY(hipMemcpy(rows, b->rows, (size_t)b->n * b->ld * sizeof(float), hipMemcpyDeviceToDevice));
         HIP_TRY(hipMemcpy(vv, b->vv, (size_t)b->n * sizeof(double), hipMemcpyDeviceToDevice));
         HIP_TRY(hipMemcpy(invn, b->invn, (size_t)b->n * sizeof(float), hipMemcpyDeviceToDevice));
@@ -72,7 +81,8 @@ static int bank_grow(cslam_bank *b, int64_t need) {
 CSLAM_API int cslam_bank_create(int device, int dim, int64_t capacity_hint, cslam_bank_t **out) {
     ARG_CHECK(out, "out is NULL");
     ARG_CHECK(dim > 0, "dim must be > 0");
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard _dev_guard(device);
+    if (!_dev_guard.ok) { cslam_set_error("hipSetDevice(%d) failed", device); return CSLAM_E_HIP; }
     cslam_bank *b = new (std::nothrow) cslam_bank();
     if (!b) { cslam_set_error("out of host memory"); return CSLAM_E_NOMEM; }
     b->device = 0; b->dim = 0; b->kd = 0; b->ld = 0; b->n = 0; b->cap = 0;
@@ -98,7 +108,7 @@ CSLAM_API int cslam_bank_create(int device, int dim, int64_t capacity_hint, csla
 
 CSLAM_API int cslam_bank_destroy(cslam_bank_t *b) {
     if (!b) return CSLAM_OK;
-    (void)hipSetDevice(b->device);
+    DeviceGuard _dev_guard(b->device);
     (void)hipDeviceSynchronize();
     if (b->rows) (void)hipFree(b->rows);
     if (b->vv) (void)hipFree(b->vv);
@@ -165,7 +175,7 @@ CSLAM_API int cslam_bank_add_host(cslam_bank_t *b, const void *vecs, int dtype, 
     ARG_CHECK(dtype == CSLAM_F32 || dtype == CSLAM_F64, "dtype must be CSLAM_F32 or CSLAM_F64");
     ARG_CHECK(n >= 0, "n < 0");
     if (n == 0) return CSLAM_OK;
-    HIP_TRY(hipSetDevice(b->device));
+    BANK_DEVICE(b);
     int rc = bank_grow(b, b->n + n);
     if (rc) return rc;
     size_t esz = dtype == CSLAM_F32 ? 4 : 8;
@@ -191,7 +201,7 @@ CSLAM_API int cslam_bank_add_host(cslam_bank_t *b, const void *vecs, int dtype, 
 CSLAM_API int cslam_bank_add_dev(cslam_bank_t *b, const float *d_vecs, int64_t ld, int64_t n, void *stream) {
     ARG_CHECK(b && (d_vecs || n == 0), "NULL argument");
     ARG_CHECK(n >= 0 && ld >= b->dim, "bad n / ld");
-    HIP_TRY(hipSetDevice(b->device));
+    BANK_DEVICE(b);
     int rc = bank_grow(b, b->n + n);
     if (rc) return rc;
     return bank_append_launch<float>(b, d_vecs, ld, n, (hipStream_t)stream);
@@ -201,7 +211,7 @@ CSLAM_API int cslam_bank_read_host(const cslam_bank_t *b, int64_t row0, int64_t 
     ARG_CHECK(b && (out || nrows == 0), "NULL argument");
     ARG_CHECK(row0 >= 0 && nrows >= 0 && row0 + nrows <= b->cap, "row range outside the bank");
     if (nrows == 0) return CSLAM_OK;
-    HIP_TRY(hipSetDevice(b->device));
+    BANK_DEVICE(b);
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy2D(out, (size_t)b->dim * 4, b->rows + row0 * b->ld, (size_t)b->ld * 4,
                         (size_t)b->dim * 4, (size_t)nrows, hipMemcpyDeviceToHost));
@@ -666,7 +676,7 @@ CSLAM_API int cslam_bank_search_dev(cslam_bank_t *b, const void *d_queries, int 
     ARG_CHECK(nq >= 0 && k >= 1, "nq must be >= 0 and k >= 1");
     ARG_CHECK(ldq >= b->dim, "ldq < dim");
     ARG_CHECK(nq < (1LL << 31) && b->n < (1LL << 31), "nq / bank rows must be < 2^31");
-    HIP_TRY(hipSetDevice(b->device));
+    BANK_DEVICE(b);
     hipStream_t st = (hipStream_t)stream;
     b->last_stream = st;
     b->stats[0] = 0; b->stats[2] = 0; b->stats[3] = 0;
@@ -690,7 +700,7 @@ CSLAM_API int cslam_bank_search_host(cslam_bank_t *b, const void *queries, int q
     ARG_CHECK(q_dtype == CSLAM_F32 || q_dtype == CSLAM_F64, "q_dtype must be CSLAM_F32 or CSLAM_F64");
     ARG_CHECK(nq >= 0 && k >= 1, "nq must be >= 0 and k >= 1");
     if (nq == 0) return CSLAM_OK;
-    HIP_TRY(hipSetDevice(b->device));
+    BANK_DEVICE(b);
     const size_t esz = q_dtype == CSLAM_F32 ? 4 : 8;
     const size_t qb = (size_t)nq * b->dim * esz;
     const size_t lb = row_limit ? (size_t)nq * 8 : 0;
@@ -720,7 +730,7 @@ CSLAM_API int cslam_bank_search_host(cslam_bank_t *b, const void *queries, int q
 
 CSLAM_API int cslam_bank_last_stats(cslam_bank_t *b, int64_t stats[4]) {
     ARG_CHECK(b && stats, "NULL argument");
-    HIP_TRY(hipSetDevice(b->device));
+    BANK_DEVICE(b);
     HIP_TRY(hipStreamSynchronize(b->last_stream));
     for (int i = 0; i < 4; ++i) stats[i] = b->stats[i];
     return CSLAM_OK;
@@ -775,6 +785,7 @@ __global__ __launch_bounds__(64) void topk_merge_kernel(const int64_t *__restric
 CSLAM_API int cslam_topk_merge_dev(const int64_t *d_idx, const double *d_sim, const int32_t *d_cnt,
                                    const int64_t *row_offset, int shards, int64_t nq, int k,
                                    int64_t *d_out_idx, double *d_out_sim, int32_t *d_out_cnt, void *stream) {
+    PTR_DEVICE(d_idx);
     ARG_CHECK(d_idx && d_sim && d_cnt && row_offset && d_out_idx && d_out_sim && d_out_cnt, "NULL argument");
     ARG_CHECK(shards >= 1 && shards <= 64, "shards must be in [1, 64]");
     ARG_CHECK(nq >= 0 && k >= 1, "nq >= 0 and k >= 1 required");

@@ -29,6 +29,42 @@ void cslam_set_error(const char *fmt, ...);
         }                                     \
     } while (0)
 
+// ---- device selection ------------------------------------------------------------------
+// Every entry point runs on the device that owns its data and leaves the caller's current device as it
+// found it (a process may hold banks on one GPU and run its extractor on another).
+struct DeviceGuard {
+    int prev;
+    bool ok;
+    explicit DeviceGuard(int dev) : prev(-1), ok(true) {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess) cur = -1;
+        if (dev >= 0 && dev != cur) {
+            ok = (hipSetDevice(dev) == hipSuccess);
+            if (ok) prev = cur;
+        }
+    }
+    ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
+int cslam_visible_devices();   // cached hipGetDeviceCount (bank.hip)
+
+// device owning a device pointer; -1 = unknown (null / host pointer) or only one device visible (nothing to choose)
+static inline int device_of_ptr(const void *p) {
+    if (!p || cslam_visible_devices() <= 1) return -1;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    return (a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged) ? a.device : -1;
+}
+
+#define BANK_DEVICE(b)                                              \
+    DeviceGuard _dev_guard((b)->device);                            \
+    if (!_dev_guard.ok) { cslam_set_error("hipSetDevice(%d) failed", (b)->device); return CSLAM_E_HIP; }
+#define PTR_DEVICE(p)                                               \
+    DeviceGuard _dev_guard(device_of_ptr(p));                       \
+    if (!_dev_guard.ok) { cslam_set_error("hipSetDevice failed for the device owning %s", #p); return CSLAM_E_HIP; }
+
 static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int64_t ceil_div64(int64_t x, int64_t m) { return (x + m - 1) / m; }
 

@@ -219,6 +219,7 @@ static int g_part_dev = -1;
 CSLAM_API int cslam_pca_project_dev(const float *d_x, int64_t ldx, const float *d_comp, int64_t ldc,
                                     const float *d_mean_proj, const float *d_inv_scale, int B, int Din, int Dout,
                                     float *d_out, void *stream) {
+    PTR_DEVICE(d_x);
     ARG_CHECK(d_x && d_comp && d_out, "NULL argument");
     ARG_CHECK(B >= 0 && Din >= TK && Dout >= 1 && Din % TK == 0, "Din must be a positive multiple of 32");
     ARG_CHECK(((uintptr_t)d_x % 16 == 0) && ((uintptr_t)d_comp % 16 == 0), "x / comp must be 16-byte aligned");

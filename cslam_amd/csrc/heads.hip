@@ -12,6 +12,7 @@
 // coalesced reads along the contiguous (pixel) axis, wave64 shuffle reductions, LDS for the
 // per-image intermediates.  float32 arithmetic like the reference's torch float32 modules.
 #include "common.h"
+#include <mutex>
 #include <vector>
 
 __device__ __forceinline__ float wave_sum_f32(float v) {
@@ -46,6 +47,7 @@ __global__ __launch_bounds__(256) void l2_normalize_kernel(float *__restrict__ x
 
 CSLAM_API int cslam_l2_normalize_dev(float *d_x, int64_t n, int d, int64_t ld, float eps,
                                      int zero_norm_to_one, void *stream) {
+    PTR_DEVICE(d_x);
     ARG_CHECK(d_x || n == 0, "NULL argument");
     ARG_CHECK(n >= 0 && d > 0 && ld >= d, "bad n / d / ld");
     if (n == 0) return CSLAM_OK;
@@ -508,6 +510,7 @@ static int g_vs_dev = -1;
 CSLAM_API int cslam_vlad_aggregate_dev(const float *d_feat, const float *d_assign_w, const float *d_assign_b,
                                        const float *d_centroids, int B, int C, int P, int K,
                                        float *d_out, int64_t ldo, void *stream) {
+    PTR_DEVICE(d_feat);
     ARG_CHECK(d_feat && d_assign_w && d_centroids && d_out, "NULL argument");
     ARG_CHECK(K == VK, "K must be 64 (reference: num_clusters=64, netvlad.py:176)");
     ARG_CHECK(C >= 1 && C <= 512 && P >= 1 && B >= 0, "need 1 <= C <= 512 (reference encoder_dim = 512, netvlad.py:162)");
@@ -601,6 +604,7 @@ __global__ __launch_bounds__(256) void gem_fc_kernel(const float *__restrict__ f
 CSLAM_API int cslam_gem_fc_head_dev(const float *d_feat, float p, float eps, const float *d_W,
                                     const float *d_b, int B, int C, int P, int Dout,
                                     float *d_out, void *stream) {
+    PTR_DEVICE(d_feat);
     ARG_CHECK(d_feat && d_W && d_out, "NULL argument");
     ARG_CHECK(B >= 0 && C >= 1 && P >= 1 && Dout >= 1, "bad sizes");
     size_t lds = (size_t)(P + C + Dout + 16) * 4;
@@ -674,10 +678,13 @@ __device__ __forceinline__ int clip8(int v) {
 // consecutive lanes on consecutive x.  HBM traffic per frame ~ crop*crop*3 (x1.3 row overlap between
 // tiles, absorbed by L2) + 3*out*out*4 bytes; the old two-kernel version moved the uint8
 // intermediate through memory and read single bytes.
-#define PP_TY 16
+// `ty` (PP_TY_MAX = 16 at the reference's 376 -> 224; smaller when a larger crop would not fit the 160 KiB of LDS) is a
+// launch parameter.  A frame smaller than the crop is zero-padded like torchvision's CenterCrop (`ptop`, `pleft` rows /
+// pixels of padding before the frame; `top`, `left` then address the padded frame).
+#define PP_TY_MAX 16
 __global__ __launch_bounds__(256) void preprocess_fused_kernel(
-    const uint8_t *__restrict__ img, int H, int W, int crop, int top, int left, int out_hw, int ksize,
-    int max_rows, const int *__restrict__ bounds, const int *__restrict__ kk,
+    const uint8_t *__restrict__ img, int H, int W, int crop, int top, int left, int ptop, int pleft, int ty,
+    int out_hw, int ksize, int max_rows, const int *__restrict__ bounds, const int *__restrict__ kk,
     float m0, float m1, float m2, float s0, float s1, float s2, float *__restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int in_row_bytes = (crop * 3 + 3) & ~3;        // padded to dwords
@@ -687,8 +694,8 @@ __global__ __launch_bounds__(256) void preprocess_fused_kernel(
     uint8_t *s_in = (uint8_t *)(s_kk + out_hw * ksize);              // [max_rows][in_row_bytes]
     uint8_t *s_tmp = s_in + (size_t)max_rows * in_row_bytes;         // [max_rows][tmp_row_bytes]
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int b = blockIdx.y, y0 = blockIdx.x * PP_TY;
-    const int ny = out_hw - y0 < PP_TY ? out_hw - y0 : PP_TY;
+    const int b = blockIdx.y, y0 = blockIdx.x * ty;
+    const int ny = out_hw - y0 < ty ? out_hw - y0 : ty;
     for (int e = tid; e < out_hw * 2; e += nt) s_bounds[e] = bounds[e];
     for (int e = tid; e < out_hw * ksize; e += nt) s_kk[e] = kk[e];
     const int rlo = bounds[y0 * 2];
@@ -696,9 +703,10 @@ __global__ __launch_bounds__(256) void preprocess_fused_kernel(
     const int rhi = bounds[ylast * 2] + bounds[ylast * 2 + 1];
     const int nrows = rhi - rlo;
     // ---- load the input rows (crop window) into LDS
-    const size_t row0 = ((size_t)b * H + top + rlo) * W * 3 + (size_t)left * 3;
+    const bool padded = (ptop | pleft) != 0 || H < crop || W < crop;
+    const size_t row0 = padded ? 0 : ((size_t)b * H + top + rlo) * W * 3 + (size_t)left * 3;
     const int row_bytes = crop * 3;
-    const bool aligned = ((((size_t)img + row0) & 3) == 0) && (((size_t)W * 3) % 4 == 0) && (row_bytes % 4 == 0);
+    const bool aligned = !padded && ((((size_t)img + row0) & 3) == 0) && (((size_t)W * 3) % 4 == 0) && (row_bytes % 4 == 0);
     // all loops below: one wave per row (or per (channel, output row) pair), lanes along the row --
     // no runtime integer divisions on the per-element path
     const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
@@ -721,10 +729,21 @@ __global__ __launch_bounds__(256) void preprocess_fused_kernel(
             for (int j = 0; j < 8; ++j)
                 if (base + j * nt + tid < total) ((uint32_t *)(s_in + (size_t)rr[j] * in_row_bytes))[cc[j]] = v[j];
         }
-    } else {
+    } else if (!padded) {
         for (int r = wave; r < nrows; r += nw)
             for (int c = lane; c < row_bytes; c += 64)
                 s_in[(size_t)r * in_row_bytes + c] = img[row0 + (size_t)r * W * 3 + c];
+    } else {
+        // CenterCrop of a frame smaller than the crop: zero fill outside the frame (torchvision pads, then crops)
+        const uint8_t *frame = img + (size_t)b * H * W * 3;
+        for (int r = wave; r < nrows; r += nw) {
+            const int sr = top + rlo + r - ptop;
+            for (int c = lane; c < row_bytes; c += 64) {
+                const int sc = left * 3 + c - pleft * 3;
+                const bool in = sr >= 0 && sr < H && sc >= 0 && sc < W * 3;
+                s_in[(size_t)r * in_row_bytes + c] = in ? frame[(size_t)sr * W * 3 + sc] : (uint8_t)0;
+            }
+        }
     }
     __syncthreads();
     // ---- horizontal pass (uint8 result, rounded + clipped like ImagingResampleHorizontal_8bpc);
@@ -770,9 +789,10 @@ __global__ __launch_bounds__(256) void preprocess_fused_kernel(
 }
 
 struct PreprocCache {
-    int device, crop, out_hw, ksize, max_rows;
+    int device, crop, out_hw, ksize, max_rows, ty;
     int *d_bounds, *d_kk;
 };
+static std::mutex g_pp_mutex;          // extractors on several threads share the tables
 // Coefficient tables per (device, crop, output size).  Entries are never freed or moved once built: the online
 // path captures this launch in a hipGraph, and a table pointer baked into a graph must stay valid when another
 // extractor with a different crop is used in between.
@@ -780,44 +800,58 @@ static std::vector<PreprocCache *> g_pp_all;
 
 CSLAM_API int cslam_preprocess_dev(const uint8_t *d_img, int B, int H, int W, int crop, int out_hw,
                                    const float mean[3], const float std_[3], float *d_out, void *stream) {
+    PTR_DEVICE(d_img);
     ARG_CHECK(d_img && d_out && mean && std_, "NULL argument");
     ARG_CHECK(B >= 0 && crop >= 1 && out_hw >= 1, "bad sizes");
-    ARG_CHECK(H >= crop && W >= crop, "image smaller than the crop (CenterCrop padding not supported)");
+    ARG_CHECK(H >= 1 && W >= 1, "empty frame");
     if (B == 0) return CSLAM_OK;
     hipStream_t st = (hipStream_t)stream;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
+    const size_t in_row_bytes = ((size_t)crop * 3 + 3) & ~(size_t)3;
     PreprocCache *pp = nullptr;
-    for (PreprocCache *c : g_pp_all)
-        if (c->device == dev && c->crop == crop && c->out_hw == out_hw) pp = c;
-    if (!pp) {
-        std::vector<int> bounds, kk;
-        int ksize = precompute_coeffs(crop, 0.0, (double)crop, out_hw, bounds, kk);
-        int max_rows = 0;
-        for (int y0 = 0; y0 < out_hw; y0 += PP_TY) {
-            int yl = y0 + PP_TY - 1 < out_hw - 1 ? y0 + PP_TY - 1 : out_hw - 1;
-            int span = bounds[yl * 2] + bounds[yl * 2 + 1] - bounds[y0 * 2];
-            if (span > max_rows) max_rows = span;
+    {
+        std::lock_guard<std::mutex> lock(g_pp_mutex);
+        for (PreprocCache *c : g_pp_all)
+            if (c->device == dev && c->crop == crop && c->out_hw == out_hw) pp = c;
+        if (!pp) {
+            std::vector<int> bounds, kk;
+            int ksize = precompute_coeffs(crop, 0.0, (double)crop, out_hw, bounds, kk);
+            // largest row tile whose input rows + uint8 intermediate fit the 160 KiB of LDS
+            int ty = PP_TY_MAX, max_rows = 0;
+            for (;; ty >>= 1) {
+                max_rows = 0;
+                for (int y0 = 0; y0 < out_hw; y0 += ty) {
+                    int yl = y0 + ty - 1 < out_hw - 1 ? y0 + ty - 1 : out_hw - 1;
+                    int span = bounds[yl * 2] + bounds[yl * 2 + 1] - bounds[y0 * 2];
+                    if (span > max_rows) max_rows = span;
+                }
+                size_t need = (size_t)out_hw * 2 * 4 + (size_t)out_hw * ksize * 4 +
+                              (size_t)max_rows * (in_row_bytes + (size_t)out_hw * 3);
+                if (need <= 160 * 1024 || ty == 1) break;
+            }
+            pp = new PreprocCache{dev, crop, out_hw, ksize, max_rows, ty, nullptr, nullptr};
+            HIP_TRY(hipMalloc((void **)&pp->d_bounds, bounds.size() * 4));
+            HIP_TRY(hipMalloc((void **)&pp->d_kk, kk.size() * 4));
+            HIP_TRY(hipMemcpy(pp->d_bounds, bounds.data(), bounds.size() * 4, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(pp->d_kk, kk.data(), kk.size() * 4, hipMemcpyHostToDevice));
+            g_pp_all.push_back(pp);
         }
-        pp = new PreprocCache{dev, crop, out_hw, ksize, max_rows, nullptr, nullptr};
-        HIP_TRY(hipMalloc((void **)&pp->d_bounds, bounds.size() * 4));
-        HIP_TRY(hipMalloc((void **)&pp->d_kk, kk.size() * 4));
-        HIP_TRY(hipMemcpy(pp->d_bounds, bounds.data(), bounds.size() * 4, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(pp->d_kk, kk.data(), kk.size() * 4, hipMemcpyHostToDevice));
-        g_pp_all.push_back(pp);
     }
     const PreprocCache &g_pp = *pp;
-    const size_t in_row_bytes = ((size_t)crop * 3 + 3) & ~(size_t)3;
     const size_t lds = (size_t)out_hw * 2 * 4 + (size_t)out_hw * g_pp.ksize * 4 +
                        (size_t)g_pp.max_rows * (in_row_bytes + (size_t)out_hw * 3);
-    ARG_CHECK(lds <= 160 * 1024, "crop / output size too large for the fused transform's LDS tile");
+    ARG_CHECK(lds <= 160 * 1024, "crop too large for the fused transform: one output row's input rows exceed the LDS");
     HIP_TRY(hipFuncSetAttribute((const void *)preprocess_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds));
-    // torchvision CenterCrop: top = round((H - crop) / 2), left = round((W - crop) / 2)
-    const int top = (int)lrint((H - crop) / 2.0), left = (int)lrint((W - crop) / 2.0);
-    hipLaunchKernelGGL(preprocess_fused_kernel, dim3((out_hw + PP_TY - 1) / PP_TY, B), dim3(256), lds, st, d_img, H,
-                       W, crop, top, left, out_hw, g_pp.ksize, g_pp.max_rows, g_pp.d_bounds, g_pp.d_kk, mean[0],
-                       mean[1], mean[2], std_[0], std_[1], std_[2], d_out);
+    // torchvision CenterCrop: a frame smaller than the crop is zero-padded first ((crop - H) / 2 rows on top, the
+    // odd row at the bottom), then top = round((H' - crop) / 2), left = round((W' - crop) / 2) on the padded frame
+    const int ptop = H < crop ? (crop - H) / 2 : 0, pleft = W < crop ? (crop - W) / 2 : 0;
+    const int Hp = H < crop ? crop : H, Wp = W < crop ? crop : W;
+    const int top = (int)lrint((Hp - crop) / 2.0), left = (int)lrint((Wp - crop) / 2.0);
+    hipLaunchKernelGGL(preprocess_fused_kernel, dim3((out_hw + g_pp.ty - 1) / g_pp.ty, B), dim3(256), lds, st, d_img, H,
+                       W, crop, top, left, ptop, pleft, g_pp.ty, out_hw, g_pp.ksize, g_pp.max_rows, g_pp.d_bounds,
+                       g_pp.d_kk, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], d_out);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }

@@ -16,6 +16,7 @@ __global__ __launch_bounds__(256) void mac_grad_kernel(const double *__restrict_
 
 CSLAM_API int cslam_mac_grad_dev(const double *d_fiedler, const int32_t *d_edge_i, const int32_t *d_edge_j,
                                  const double *d_weights, int64_t m, double *d_grad, void *stream) {
+    PTR_DEVICE(d_fiedler);
     ARG_CHECK(m >= 0, "m < 0");
     if (m == 0) return CSLAM_OK;
     ARG_CHECK(d_fiedler && d_edge_i && d_edge_j && d_weights && d_grad, "NULL argument");
@@ -43,6 +44,7 @@ __global__ __launch_bounds__(256) void csr_spmm_kernel(const int64_t *__restrict
 
 CSLAM_API int cslam_csr_spmm_dev(const int64_t *d_indptr, const int32_t *d_indices, const double *d_data,
                                  int64_t n, const double *d_x, int nvec, double *d_y, void *stream) {
+    PTR_DEVICE(d_indptr);
     ARG_CHECK(n >= 0 && nvec >= 1, "bad n / nvec");
     if (n == 0) return CSLAM_OK;
     ARG_CHECK(d_indptr && d_indices && d_data && d_x && d_y, "NULL argument");
@@ -265,6 +267,7 @@ CSLAM_API int cslam_chain_forward_dev(const double *d_b, const uint8_t *d_is_jun
                                       const int64_t *d_sa, const int64_t *d_sb, const double *d_Rl,
                                       double *d_Bn, double *d_Qn, double *d_tmp, double *d_scratch, double *d_bt,
                                       void *stream) {
+    PTR_DEVICE(d_b);
     ARG_CHECK(d_b && d_is_junction && d_r && d_J && d_Bn && d_Qn && d_tmp && d_scratch && d_bt, "NULL argument");
     ARG_CHECK(n >= 2 && nJ >= 1, "bad n / nJ");
     hipStream_t st = (hipStream_t)stream;
@@ -282,6 +285,7 @@ CSLAM_API int cslam_chain_forward_dev(const double *d_b, const uint8_t *d_is_jun
 CSLAM_API int cslam_chain_backward_dev(const double *d_xJ, const double *d_Bn, const double *d_Qn, const double *d_r,
                                        const double *d_Rn, const int *d_jid, const int *d_seg_of, const int64_t *d_sa,
                                        const int64_t *d_sb, const double *d_Rl, int64_t n, double *d_x, void *stream) {
+    PTR_DEVICE(d_xJ);
     ARG_CHECK(d_xJ && d_Bn && d_Qn && d_r && d_Rn && d_jid && d_seg_of && d_x, "NULL argument");
     hipLaunchKernelGGL(chain_back_subst_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream,
                        d_xJ, d_Bn, d_Qn, d_r, d_Rn, d_jid, d_seg_of, d_sa, d_sb, d_Rl, n, d_x);
@@ -309,6 +313,7 @@ __global__ __launch_bounds__(256) void csr_spmm4_kernel(const int64_t *__restric
 
 CSLAM_API int cslam_csr_spmm4_dev(const int64_t *d_indptr, const int32_t *d_indices, const double *d_data,
                                   int64_t n, const double *d_x, double *d_y, void *stream) {
+    PTR_DEVICE(d_indptr);
     ARG_CHECK(n >= 0, "n < 0");
     if (n == 0) return CSLAM_OK;
     ARG_CHECK(d_indptr && d_indices && d_data && d_x && d_y, "NULL argument");
@@ -409,6 +414,7 @@ __global__ void block4_sum_finish_kernel(const double *__restrict__ partial, int
 #define B4_GRID 1024
 CSLAM_API int cslam_block4_gram_dev(const double *d_A, const double *d_B, int64_t n, double *d_partial,
                                     double *d_out20, void *stream) {
+    PTR_DEVICE(d_A);
     ARG_CHECK(d_A && d_B && d_partial && d_out20 && n >= 1, "bad argument");
     hipStream_t st = (hipStream_t)stream;
     int grid = (int)ceil_div64(n, B4_BLOCK); if (grid > B4_GRID) grid = B4_GRID;
@@ -420,6 +426,7 @@ CSLAM_API int cslam_block4_gram_dev(const double *d_A, const double *d_B, int64_
 
 CSLAM_API int cslam_block4_affine_dev(const double *d_A, int64_t n, const double *d_M16, const double *d_shift4,
                                       double *d_out, void *stream) {
+    PTR_DEVICE(d_A);
     ARG_CHECK(d_A && d_M16 && d_out && n >= 1, "bad argument");
     hipLaunchKernelGGL(block4_affine_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream,
                        d_A, n, d_M16, d_shift4, d_out);
@@ -429,6 +436,7 @@ CSLAM_API int cslam_block4_affine_dev(const double *d_A, int64_t n, const double
 
 CSLAM_API int cslam_block4_residual_dev(const double *d_W, const double *d_X, int64_t n, const double *d_y4,
                                         double sigma, double *d_partial, double *d_out1, void *stream) {
+    PTR_DEVICE(d_W);
     ARG_CHECK(d_W && d_X && d_y4 && d_partial && d_out1 && n >= 1, "bad argument");
     hipStream_t st = (hipStream_t)stream;
     int grid = (int)ceil_div64(n, B4_BLOCK); if (grid > B4_GRID) grid = B4_GRID;

@@ -84,7 +84,8 @@ CSLAM_API int cslam_scbank_create(int device, int rings, int sectors, int64_t ca
     ARG_CHECK(out, "out is NULL");
     ARG_CHECK(rings >= 1 && rings <= SC_MAX_R, "rings must be in [1, 64]");
     ARG_CHECK(sectors >= 1 && sectors <= SC_MAX_S, "sectors must be in [1, 128]");
-    HIP_TRY(hipSetDevice(device));
+    DeviceGuard _dev_guard(device);
+    if (!_dev_guard.ok) { cslam_set_error("hipSetDevice(%d) failed", device); return CSLAM_E_HIP; }
     cslam_scbank *b = new (std::nothrow) cslam_scbank();
     if (!b) { cslam_set_error("host allocation failed"); return CSLAM_E_NOMEM; }
     b->device = device; b->R = rings; b->S = sectors; b->L = rings * sectors;
@@ -99,7 +100,7 @@ CSLAM_API int cslam_scbank_create(int device, int rings, int sectors, int64_t ca
 
 CSLAM_API int cslam_scbank_destroy(cslam_scbank_t *b) {
     if (!b) return CSLAM_OK;
-    (void)hipSetDevice(b->device);
+    DeviceGuard _dev_guard(b->device);
     (void)hipDeviceSynchronize();
     if (b->sc) (void)hipFree(b->sc);
     if (b->rk) (void)hipFree(b->rk);
@@ -182,7 +183,7 @@ static int sc_prep_launch(const double *d_sc, int64_t count, int R, int S, doubl
 CSLAM_API int cslam_scbank_add_dev(cslam_scbank_t *b, const double *d_sc, int64_t n, void *stream) {
     ARG_CHECK(b && (d_sc || n == 0), "NULL argument");
     ARG_CHECK(n >= 0 && b->n + n < (1LL << 31), "item count must stay below 2^31");
-    HIP_TRY(hipSetDevice(b->device));
+    BANK_DEVICE(b);
     hipStream_t st = (hipStream_t)stream;
     if (b->n + n > b->cap) {
         HIP_TRY(hipStreamSynchronize(st));
@@ -200,7 +201,7 @@ CSLAM_API int cslam_scbank_add_dev(cslam_scbank_t *b, const double *d_sc, int64_
 CSLAM_API int cslam_scbank_add_host(cslam_scbank_t *b, const double *sc, int64_t n) {
     ARG_CHECK(b && (sc || n == 0), "NULL argument");
     ARG_CHECK(n >= 0 && b->n + n < (1LL << 31), "item count must stay below 2^31");
-    HIP_TRY(hipSetDevice(b->device));
+    BANK_DEVICE(b);
     int rc = sc_grow(b, b->n + n);
     if (rc) return rc;
     if (n == 0) return CSLAM_OK;
@@ -216,7 +217,7 @@ CSLAM_API int cslam_scbank_read_host(const cslam_scbank_t *b, int64_t first, int
                                      double *rk_out) {
     ARG_CHECK(b, "bank is NULL");
     ARG_CHECK(first >= 0 && count >= 0 && first + count <= b->n, "range outside the bank");
-    HIP_TRY(hipSetDevice(b->device));
+    BANK_DEVICE(b);
     HIP_TRY(hipDeviceSynchronize());
     if (count == 0) return CSLAM_OK;
     if (sc_out) HIP_TRY(hipMemcpy(sc_out, b->sc + first * b->L, (size_t)count * b->L * 8, hipMemcpyDeviceToHost));
@@ -478,7 +479,7 @@ CSLAM_API int cslam_scbank_search_dev(cslam_scbank_t *b, const double *d_q, int6
     ARG_CHECK(num_candidates >= 1 && num_candidates <= SC_MAX_CAND, "num_candidates must be in [1, 64]");
     ARG_CHECK(nq >= 0 && nq <= 65535, "nq must be in [0, 65535] per call");
     if (nq == 0) return CSLAM_OK;
-    HIP_TRY(hipSetDevice(b->device));
+    BANK_DEVICE(b);
     hipStream_t st = (hipStream_t)stream;
     const int C = num_candidates, R = b->R, S = b->S;
     // row chunks per query (tile): enough workgroups to fill the chip, no more -- every chunk pays the
@@ -532,7 +533,7 @@ CSLAM_API int cslam_scbank_search_host(cslam_scbank_t *b, const double *queries,
     ARG_CHECK(b && (queries || nq == 0) && best_idx && best_sim && best_yaw, "NULL argument");
     ARG_CHECK(num_candidates >= 1 && num_candidates <= SC_MAX_CAND, "num_candidates must be in [1, 64]");
     ARG_CHECK(nq >= 0, "nq must be >= 0");
-    HIP_TRY(hipSetDevice(b->device));
+    BANK_DEVICE(b);
     const int C = num_candidates;
     const int64_t CH = 16384;
     for (int64_t q0 = 0; q0 < nq; q0 += CH) {
@@ -671,6 +672,7 @@ __global__ __launch_bounds__(SCD_WAVES * 64) void sc_from_cloud_kernel(
 CSLAM_API int cslam_scancontext_from_cloud_dev(const double *d_points, const int64_t *d_offsets, int n_frames,
                                                int rings, int sectors, double max_length, double *d_out,
                                                int32_t *d_status, void *stream) {
+    PTR_DEVICE(d_points);
     ARG_CHECK(d_offsets && d_out && d_status, "NULL argument");   // d_points may be NULL when every frame is empty
     ARG_CHECK(n_frames >= 0, "n_frames must be >= 0");
     ARG_CHECK(rings >= 1 && sectors >= 1 && rings * sectors <= SCD_MAX_BINS, "rings * sectors must be in [1, 2048]");

@@ -654,7 +654,7 @@ CSLAM_API int cslam_bank_last_kernel_ms(cslam_bank_t *b, float *ms) {
     ARG_CHECK(b && ms, "NULL argument");
     *ms = -1.0f;
     if (!b->ev_valid || b->stats[1] != CSLAM_MODE_MFMA) return CSLAM_OK;
-    HIP_TRY(hipSetDevice(b->device));
+    BANK_DEVICE(b);
     HIP_TRY(hipEventSynchronize(b->ev1));
     HIP_TRY(hipEventElapsedTime(ms, b->ev0, b->ev1));
     return CSLAM_OK;

@@ -687,6 +687,7 @@ static int launch_fused4_pipe(const float *d_x, const float *d_Up, const float *
 CSLAM_API int cslam_wino4_fused_c64_dev(const float *d_x, const float *d_Up, const float *d_bias,
                                         const float *d_residual, int B, int H, int W, int Cout, int relu, int pool,
                                         float *d_y, void *stream) {
+    PTR_DEVICE(d_x);
     ARG_CHECK(d_x && d_Up && d_y, "NULL argument");
     ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
     ARG_CHECK(Cout == 64 || Cout == 128, "Cout must be 64 or 128");
@@ -714,6 +715,7 @@ static void launch_fused_c64(const float *d_x, const float *d_Up, const float *d
 CSLAM_API int cslam_wino2_fused_c64_dev(const float *d_x, const float *d_Up, const float *d_bias,
                                         const float *d_residual, int B, int H, int W, int Cout, int relu, int pool,
                                         float *d_y, void *stream) {
+    PTR_DEVICE(d_x);
     ARG_CHECK(d_x && d_Up && d_y, "NULL argument");
     ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
     ARG_CHECK(Cout == 64 || Cout == 128, "Cout must be 64 or 128");
@@ -736,5 +738,6 @@ CSLAM_API int cslam_wino2_fused_c64_dev(const float *d_x, const float *d_Up, con
 
 CSLAM_API int cslam_wino2_fused64_dev(const float *d_x, const float *d_Up, const float *d_bias, int B, int H, int W,
                                       int relu, int pool, float *d_y, void *stream) {
+    PTR_DEVICE(d_x);
     return cslam_wino2_fused_c64_dev(d_x, d_Up, d_bias, nullptr, B, H, W, 64, relu, pool, d_y, stream);
 }

@@ -159,6 +159,7 @@ __global__ __launch_bounds__(256) void bias_act_pool_kernel(const float *__restr
 
 CSLAM_API int cslam_bias_act_pool_dev(const float *d_x, const float *d_bias, int B, int H, int W, int C, int relu,
                                       int pool, float *d_y, void *stream) {
+    PTR_DEVICE(d_x);
     ARG_CHECK(d_x && d_y, "NULL argument");
     ARG_CHECK(B >= 1 && H >= 1 && W >= 1 && C >= 4 && (C % 4) == 0, "C must be a multiple of 4");
     ARG_CHECK(!pool || ((H % 2) == 0 && (W % 2) == 0), "pooling needs even H and W");
@@ -303,6 +304,7 @@ __global__ __launch_bounds__(256) void conv3x3_c3_tile64_kernel(const float *__r
 
 CSLAM_API int cslam_conv3x3_c3_dev(const float *d_x, const float *d_wt, const float *d_bias, int B, int H, int W,
                                    int Cout, int relu, float *d_y, void *stream) {
+    PTR_DEVICE(d_x);
     ARG_CHECK(d_x && d_wt && d_y, "NULL argument");
     ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty input");
     ARG_CHECK(Cout >= 16 && (Cout % 16) == 0 && Cout <= 512, "Cout must be a multiple of 16, at most 512");
@@ -325,6 +327,7 @@ CSLAM_API int cslam_conv3x3_c3_dev(const float *d_x, const float *d_wt, const fl
 }
 
 CSLAM_API int cslam_wino_input_dev(const float *d_x, int B, int H, int W, int C, float *d_V, void *stream) {
+    PTR_DEVICE(d_x);
     ARG_CHECK(d_x && d_V, "NULL argument");
     ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
     ARG_CHECK(C >= 4 && (C % 4) == 0, "C must be a multiple of 4");
@@ -338,6 +341,7 @@ CSLAM_API int cslam_wino_input_dev(const float *d_x, int B, int H, int W, int C,
 
 CSLAM_API int cslam_wino_output_dev(const float *d_M, const float *d_bias, const float *d_res, int B, int H, int W,
                                     int C, int relu, int pool, float *d_y, void *stream) {
+    PTR_DEVICE(d_M);
     ARG_CHECK(d_M && d_y, "NULL argument");
     ARG_CHECK(!(d_res && pool), "a residual input cannot be combined with pooling");
     ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
@@ -562,15 +566,18 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restri
                                                            float *__restrict__ y, const unsigned *__restrict__ amax,
                                                            float inv_su, unsigned *__restrict__ amax_out) {
     __shared__ unsigned wg_amax;
-    if (amax_out) {                                       // before any thread leaves: every wave of the workgroup is here
+    if (amax_out) {
         if (threadIdx.x == 0) wg_amax = 0u;
         __syncthreads();
     }
     const int c2n = C >> 1;
-    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t gid0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int TH = (H + 3) >> 2, TW = (W + 3) >> 2;      // ragged maps: the last tile row / column is partly outside
     const int64_t T = (int64_t)B * TH * TW;
-    if (gid >= T * c2n) return;
+    // threads past the range (last workgroup only) stay until both barriers: they compute on element 0 and neither
+    // contribute to the maximum nor store
+    const bool live = gid0 < T * c2n;
+    const int64_t gid = live ? gid0 : 0;
     const int c2 = (int)(gid % c2n);
     const int64_t t = gid / c2n;
     const int64_t plane = T * C;
@@ -603,14 +610,13 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restri
     }
     if (amax_out) {
         // upper bound of max |y| for the next layer's split-fp16 scale (pre-pool values bound the pooled ones): LDS maximum
-        // per workgroup, then one global atomic per workgroup and only if it would raise the slot.  Waves that left at the
-        // range check have ended and are not waited for; thread 0 of a workgroup with any live thread is live.
+        // per workgroup, then one global atomic per workgroup and only if it would raise the slot
         float m = 0.0f;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (4 * ti + i < H && 4 * tj + j < W) m = fmaxf(m, fmaxf(fabsf(o[i][j].x), fabsf(o[i][j].y)));
+                if (live && 4 * ti + i < H && 4 * tj + j < W) m = fmaxf(m, fmaxf(fabsf(o[i][j].x), fabsf(o[i][j].y)));
         atomicMax(&wg_amax, __float_as_uint(m));
         __syncthreads();
         if (threadIdx.x == 0 && wg_amax > *(volatile unsigned *)amax_out) atomicMax(amax_out, wg_amax);
@@ -623,7 +629,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restri
             for (int j = 0; j < 2; ++j) {
                 f2 v = __builtin_elementwise_max(__builtin_elementwise_max(o[2 * i][2 * j], o[2 * i][2 * j + 1]),
                                                  __builtin_elementwise_max(o[2 * i + 1][2 * j], o[2 * i + 1][2 * j + 1]));
-                if (2 * ti + i < Ho && 2 * tj + j < Wo)
+                if (live && 2 * ti + i < Ho && 2 * tj + j < Wo)
                     *((f2 *)(y + (((int64_t)b * Ho + 2 * ti + i) * Wo + 2 * tj + j) * C) + c2) = v;
             }
     } else {
@@ -631,7 +637,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restri
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (4 * ti + i < H && 4 * tj + j < W)
+                if (live && 4 * ti + i < H && 4 * tj + j < W)
                     *((f2 *)(y + (((int64_t)b * H + 4 * ti + i) * W + 4 * tj + j) * C) + c2) = o[i][j];
     }
 }
@@ -642,6 +648,7 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restri
 // 3.9 ms per 256 frames against 1.2 ms (conv3x3_c3_kernel) + 2.0 ms (this kernel's conv1_2 launch) separately.
 
 CSLAM_API int cslam_wino4_input_dev(const float *d_x, int B, int H, int W, int C, float *d_V, void *stream) {
+    PTR_DEVICE(d_x);
     ARG_CHECK(d_x && d_V, "NULL argument");
     ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
     ARG_CHECK(C >= 2 && (C % 2) == 0, "C must be even");
@@ -674,12 +681,14 @@ static int wino4_output_launch(const float *d_M, const float *d_bias, const floa
 
 CSLAM_API int cslam_wino4_output_dev(const float *d_M, const float *d_bias, const float *d_res, int B, int H, int W,
                                      int C, int relu, int pool, float *d_y, void *stream) {
+    PTR_DEVICE(d_M);
     return wino4_output_launch(d_M, d_bias, d_res, B, H, W, C, relu, pool, d_y, nullptr, 1.0f, nullptr, stream);
 }
 
 // ---- split-fp16 form: max |x| -> slot, input transform into [36, T, 3 C] fp16 (hi | lo | hi), output transform with the
 // exact power-of-two rescale 1 / (sV sU) ----
 CSLAM_API int cslam_absmax_dev(const float *d_x, int64_t n, unsigned *d_slot, void *stream) {
+    PTR_DEVICE(d_x);
     ARG_CHECK(d_x && d_slot, "NULL argument");
     ARG_CHECK(n >= 4 && (n % 4) == 0, "n must be a positive multiple of 4");
     hipStream_t st = (hipStream_t)stream;
@@ -692,6 +701,7 @@ CSLAM_API int cslam_absmax_dev(const float *d_x, int64_t n, unsigned *d_slot, vo
 
 CSLAM_API int cslam_wino4_input_h3_dev(const float *d_x, int B, int H, int W, int C, const unsigned *d_amax, void *d_V3,
                                        void *stream) {
+    PTR_DEVICE(d_x);
     ARG_CHECK(d_x && d_V3 && d_amax, "NULL argument");
     ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
     ARG_CHECK(C >= 2 && (C % 2) == 0, "C must be even");
@@ -712,6 +722,7 @@ CSLAM_API int cslam_wino4_input_h3_dev(const float *d_x, int B, int H, int W, in
 CSLAM_API int cslam_wino4_output_scaled_dev(const float *d_M, const float *d_bias, const float *d_res, int B, int H, int W,
                                             int C, int relu, int pool, const unsigned *d_amax, float inv_su,
                                             unsigned *d_amax_out, float *d_y, void *stream) {
+    PTR_DEVICE(d_M);
     ARG_CHECK(inv_su > 0.0f, "inv_su must be positive");
     return wino4_output_launch(d_M, d_bias, d_res, B, H, W, C, relu, pool, d_y, d_amax, inv_su, d_amax_out, stream);
 }

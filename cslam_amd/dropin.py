@@ -13,6 +13,8 @@ cslam module (ROS glue, neighbour manager, lidar handler, ...) keeps coming from
 reference.
 """
 import importlib
+import importlib.abc
+import importlib.util
 import sys
 
 _MAP = {
@@ -30,6 +32,43 @@ _MAP = {
 
 
 def install():
+    """Eager form: import the ten replacements now and register them under the reference's names."""
     for ref_name, our_name in _MAP.items():
         sys.modules[ref_name] = importlib.import_module(our_name)
     return sorted(_MAP)
+
+
+class _DropinFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
+    """Lazy form: answers the import of one of the ten reference names with the cslam_amd module of `_MAP`, imported
+    at that moment (a process that never imports them -- every other ROS node sharing the PYTHONPATH -- pays nothing)."""
+
+    def find_spec(self, fullname, path=None, target=None):
+        if fullname in _MAP:
+            return importlib.util.spec_from_loader(fullname, self)
+        return None
+
+    def create_module(self, spec):
+        return importlib.import_module(_MAP[spec.name])
+
+    def exec_module(self, module):
+        pass
+
+
+def install_lazy():
+    """Register the finder ahead of the path-based one; idempotent.  This is what `cslam_amd/shim/sitecustomize.py`
+    (and the optional `.pth` line of INTEGRATION.md) calls, so that cslam itself stays unedited."""
+    for f in sys.meta_path:
+        if isinstance(f, _DropinFinder):
+            return f
+    f = _DropinFinder()
+    sys.meta_path.insert(0, f)
+    return f
+
+
+def uninstall():
+    """Undo install() / install_lazy() (tests)."""
+    sys.meta_path[:] = [f for f in sys.meta_path if not isinstance(f, _DropinFinder)]
+    for ref_name, our_name in _MAP.items():
+        m = sys.modules.get(ref_name)
+        if m is not None and getattr(m, "__name__", None) == our_name:
+            del sys.modules[ref_name]

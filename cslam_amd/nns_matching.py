@@ -45,6 +45,7 @@ class NearestNeighborsMatching(object):
         self.device = device
         self._bank = None
         self._lib = None
+        self._data_cache = (0, None)          # (rows already mirrored on the host, array) behind `.data`
         if dim is not None:
             self._create(dim)
 
@@ -67,17 +68,26 @@ class NearestNeighborsMatching(object):
 
     @property
     def data(self):
-        """Host copy of the bank storage, shape (capacity, dim) float32, zeros past `n`
-        (the reference's public array, cslam/nns_matching.py:21; [] before the first add)."""
+        """Host view of the bank storage, shape (capacity, dim) float32, zeros past `n` (the reference's public
+        array, cslam/nns_matching.py:21; [] before the first add).  The bank itself lives in HBM: the host copy is
+        made on first access and kept until the next add (only the rows appended since are downloaded), so callers
+        that touch `.data` freely, as the reference's tests do, do not pay a bank-sized transfer per access."""
         if self._bank is None:
             return []
         cap = 1000
         while cap < self.n:
             cap *= 2
-        out = np.zeros((cap, self.dim), dtype=np.float32)
-        if self.n:
-            _lib.check(self._lib.cslam_bank_read_host(self._bank, 0, self.n, out.ctypes.data_as(C.c_void_p)))
-        return out
+        have, arr = self._data_cache
+        if arr is None or arr.shape[0] != cap:
+            new = np.zeros((cap, self.dim), dtype=np.float32)
+            if arr is not None and have:
+                new[:have] = arr[:have]
+            arr = new
+        if have < self.n:
+            _lib.check(self._lib.cslam_bank_read_host(self._bank, have, self.n - have,
+                                                      arr[have:self.n].ctypes.data_as(C.c_void_p)))
+        self._data_cache = (self.n, arr)
+        return arr
 
     # ------------------------------------------------------- reference API ----
     def add_item(self, vector, item):

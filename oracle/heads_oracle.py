@@ -125,6 +125,13 @@ def pil_bicubic_resize_u8(img, out_size):
 def preprocess(img, crop, out_size, mean, std):
     """img [H,W,3] uint8 -> [3,out,out] float32"""
     H, W, _ = img.shape
+    if H < crop or W < crop:
+        # torchvision CenterCrop (functional.center_crop): zero-pad a frame smaller than the crop, (crop - H) // 2 rows
+        # before and (crop - H + 1) // 2 after, then crop the padded frame
+        pt, pl = ((crop - H) // 2 if H < crop else 0), ((crop - W) // 2 if W < crop else 0)
+        pb, pr = ((crop - H + 1) // 2 if H < crop else 0), ((crop - W + 1) // 2 if W < crop else 0)
+        img = np.pad(img, ((pt, pb), (pl, pr), (0, 0)))
+        H, W, _ = img.shape
     top, left = int(round((H - crop) / 2.0)), int(round((W - crop) / 2.0))
     c = img[top:top + crop, left:left + crop]
     r = pil_bicubic_resize_u8(c, out_size)
