@@ -155,6 +155,42 @@ class AlgebraicConnectivityMaximization(object):
             return
         self.add_candidate_edge(match)
 
+    def add_matches_arrays(self, robot0_id, robot0_keyframe_ids, robot1_ids, robot1_keyframe_ids, weights):
+        """`add_match(EdgeInterRobot(robot0_id, kf0[t], r1[t], kf1[t], w[t]))` for t = 0, 1, ... in that order, for the
+        batched matcher (thousands of matches per chunk): same candidate dict, same insertion order, same quirks
+        (reference :559-572 through :166-178), one EdgeInterRobot per match and no other per-match Python objects.
+        Returns the list of EdgeInterRobot (every match, kept or not -- what the sequential callers return)."""
+        r0 = int(robot0_id)
+        kf0 = np.asarray(robot0_keyframe_ids, dtype=np.int64)
+        r1 = np.asarray(robot1_ids, dtype=np.int64)
+        kf1 = np.asarray(robot1_keyframe_ids, dtype=np.int64)
+        w = np.asarray(weights, dtype=np.float64)
+        if len(kf0) == 0:
+            return []
+        if (r1 == r0).any():                         # not an inter-robot match: the general path
+            out = [EdgeInterRobot(r0, int(a), int(b), int(c), d) for a, b, c, d in zip(kf0, r1, kf1, w)]
+            for e in out:
+                self.add_match(e)
+            return out
+        edges = list(map(EdgeInterRobot._make, zip([r0] * len(kf0), kf0.tolist(), r1.tolist(), kf1.tolist(), list(w))))
+        cand, seen = self.candidate_edges, self.already_considered_matches
+        for e in edges:
+            if r0 < e[2]:
+                key = e[:4]                          # stored key == looked-up key: the larger weight wins (:565-568)
+                old = cand.get(key)
+                if old is not None and not (e[4] > old[4]):
+                    continue
+            else:
+                key = (e[2], e[3], r0, e[1])         # looked up un-normalised, i.e. never found: always replaced (quirk)
+            if key not in seen:
+                cand[key] = e
+        # update_nb_poses (:111-120).  Matches skipped above were candidates before (same keyframe ids), so taking
+        # the maximum over all of them gives the same counts as the per-match updates
+        self.nb_poses[r0] = max(self.nb_poses[r0], int(kf0.max()) + 1)
+        for rid in np.unique(r1).tolist():
+            self.nb_poses[rid] = max(self.nb_poses[rid], int(kf1[r1 == rid].max()) + 1)
+        return edges
+
     # ------------------------------------------------------------- initial guesses ----
     def greedy_initialization(self, nb_candidates_to_choose, edges):
         """One-hot vector of the nb_candidates_to_choose largest weights (reference :205-218)."""

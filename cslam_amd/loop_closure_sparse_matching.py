@@ -157,6 +157,25 @@ class LoopClosureSparseMatching(object):
             return rows.cpu().numpy(), sims.cpu().numpy(), cnt.cpu().numpy()
         return bank.search_batch(host, k, row_limit=row_limit)
 
+    def _intra_from_topk(self, rows, sims, cnt, ids, items):
+        """match_local_loop_closures' decision (lcsm.py:74-92) for a batch of top-k lists with array operations:
+        strip the keyframe itself when it heads its list, then the first entry in score order that is neither closer
+        than `intra_loop_min_inbetween_keyframes` nor below the threshold (a NaN similarity is not `< threshold`,
+        so it passes, as in the reference).  Returns a list of (kf_id, matched kf or None)."""
+        m, k = rows.shape
+        gap = self.params['frontend.intra_loop_min_inbetween_keyframes']
+        thr = self.params['frontend.similarity_threshold']
+        pos = np.arange(k)[None, :]
+        valid = pos < cnt[:, None]
+        kfs = items[np.where(valid, rows, 0)]
+        self_first = valid[:, 0] & (kfs[:, 0] == ids)
+        with np.errstate(invalid="ignore"):
+            ok = valid & ~(self_first[:, None] & (pos == 0)) & ~(np.abs(kfs - ids[:, None]) < gap) & ~(sims < thr)
+        first = ok.argmax(axis=1)
+        found = ok[np.arange(m), first]
+        hit = kfs[np.arange(m), first].tolist()
+        return [(i, (h if f else None)) for i, h, f in zip(ids.tolist(), hit, found.tolist())]
+
     def process_local_keyframes(self, embeddings, keyframe_ids, intra=True):
         """Batch equivalent of, for each keyframe in order (gdlcd.py:148-174):
                match_local_loop_closures(e, id); add_local_global_descriptor(e, id)
@@ -166,53 +185,72 @@ class LoopClosureSparseMatching(object):
         host, dev, m = self._stage(embeddings)
         ids = [int(i) for i in keyframe_ids]
         assert len(ids) == m
+        ids_arr = np.asarray(ids, dtype=np.int64)
         intra_out = []
         n0 = self.local_nnsm.n
         self._add(self.local_nnsm, host, dev, ids)
         thr = self.params['frontend.similarity_threshold']
-        if intra:
+        me = self.params['robot_id']
+        others = [i for i in range(self.params['max_nb_robots']) if i != me and self.other_robots_nnsm[i].n > 0]
+        # device banks: enqueue every search of the chunk first, read the results back afterwards
+        pending = [self.other_robots_nnsm[i].search_device(dev, 1) for i in others] if dev is not None else None
+        if intra and m > 0:
             k = int(self.params['frontend.nb_best_matches'])
             lim = n0 + np.arange(m, dtype=np.int64)           # keyframe j sees rows added before it
             rows, sims, cnt = self._search(self.local_nnsm, host, dev, k, lim)
-            rows_l, sims_l, cnt_l = rows.tolist(), sims.tolist(), cnt.tolist()   # plain lists: no numpy scalars below
-            items = self.local_nnsm.items
-            gap = self.params['frontend.intra_loop_min_inbetween_keyframes']
-            for j in range(m):
-                c = cnt_l[j]
-                kfs = [items[r] for r in rows_l[j][:c]]
-                s = sims_l[j][:c]
-                if c > 0 and kfs[0] == ids[j]:
-                    kfs, s = kfs[1:], s[1:]
-                kf = None
-                if len(kfs) > 0 and kfs[0] is not None:
-                    kf = self._first_valid(kfs, s, ids[j], gap, thr)
-                intra_out.append((ids[j], kf))
-        me = self.params['robot_id']
-        others = [i for i in range(self.params['max_nb_robots']) if i != me and self.other_robots_nnsm[i].n > 0]
+            item_arr = self.local_nnsm.item_array() if hasattr(self.local_nnsm, "item_array") else None
+            if item_arr is not None:
+                intra_out = self._intra_from_topk(rows, sims, cnt, ids_arr, item_arr)
+            else:                                              # items that are not keyframe numbers (or the lidar bank)
+                rows_l, sims_l, cnt_l = rows.tolist(), sims.tolist(), cnt.tolist()
+                items = self.local_nnsm.items
+                gap = self.params['frontend.intra_loop_min_inbetween_keyframes']
+                for j in range(m):
+                    c = cnt_l[j]
+                    kfs = [items[r] for r in rows_l[j][:c]]
+                    s = sims_l[j][:c]
+                    if c > 0 and kfs[0] == ids[j]:
+                        kfs, s = kfs[1:], s[1:]
+                    kf = None
+                    if len(kfs) > 0 and kfs[0] is not None:
+                        kf = self._first_valid(kfs, s, ids[j], gap, thr)
+                    intra_out.append((ids[j], kf))
         inter_out = []
-        if others:
+        if others and m > 0:
             # best-1 per other robot, thresholded with array operations; Python only touches the actual matches,
             # in the order the sequential calls produce them (keyframe-major, robot id ascending)
-            best_rows = np.empty((m, len(others)), dtype=np.int64)
+            best_kf = np.empty((m, len(others)), dtype=np.int64)
             best_sims = np.empty((m, len(others)), dtype=np.float64)
             hit = np.zeros((m, len(others)), dtype=bool)
-            # device banks: enqueue every search first, read the results back afterwards (no stall between launches)
-            pending = [self.other_robots_nnsm[i].search_device(dev, 1) for i in others] if dev is not None else None
+            generic = False
             for c, i in enumerate(others):
+                bank = self.other_robots_nnsm[i]
                 if pending is not None:
                     rows, sims, cnt = (t.cpu().numpy() for t in pending[c])
                 else:
-                    rows, sims, cnt = self._search(self.other_robots_nnsm[i], host, dev, 1)
-                best_rows[:, c], best_sims[:, c] = rows[:, 0], sims[:, 0]
+                    rows, sims, cnt = self._search(bank, host, dev, 1)
                 with np.errstate(invalid="ignore"):
                     hit[:, c] = (cnt > 0) & (sims[:, 0] >= thr)
+                best_sims[:, c] = sims[:, 0]
+                item_arr = bank.item_array() if hasattr(bank, "item_array") else None
+                if item_arr is not None:
+                    best_kf[:, c] = item_arr[np.where(hit[:, c], rows[:, 0], 0)]
+                else:
+                    generic = True
+                    best_kf[:, c] = rows[:, 0]                 # rows for now, items resolved per match below
             jj, cc = np.nonzero(hit)                           # row-major: j ascending, then robot ascending
-            add_match = self.candidate_selector.add_match
-            for j, c, r, sv in zip(jj.tolist(), cc.tolist(), best_rows[jj, cc].tolist(), best_sims[jj, cc].tolist()):
-                i = others[c]
-                match = EdgeInterRobot(me, ids[j], i, self.other_robots_nnsm[i].items[r], np.float64(sv))
-                add_match(match)
-                inter_out.append(match)
+            if not generic:
+                inter_out = self.candidate_selector.add_matches_arrays(
+                    me, ids_arr[jj], np.asarray(others, dtype=np.int64)[cc], best_kf[jj, cc], best_sims[jj, cc])
+            else:
+                add_match = self.candidate_selector.add_match
+                for j, c, r, sv in zip(jj.tolist(), cc.tolist(), best_kf[jj, cc].tolist(), best_sims[jj, cc]):
+                    i = others[c]
+                    bank = self.other_robots_nnsm[i]
+                    kf = r if (hasattr(bank, "item_array") and bank.item_array() is not None) else bank.items[r]
+                    match = EdgeInterRobot(me, ids[j], i, kf, sv)
+                    add_match(match)
+                    inter_out.append(match)
         return intra_out, inter_out
 
     def process_remote_descriptors(self, robot_id, descriptors, keyframe_ids):
@@ -226,14 +264,20 @@ class LoopClosureSparseMatching(object):
         ids = [int(i) for i in keyframe_ids]
         self._add(self.other_robots_nnsm[robot_id], host, dev, ids)
         out = []
-        if self.local_nnsm.n == 0:
+        if self.local_nnsm.n == 0 or m == 0:
             return out
         rows, sims, cnt = self._search(self.local_nnsm, host, dev, 1)
         with np.errstate(invalid="ignore"):
             jj = np.nonzero((cnt > 0) & (sims[:, 0] >= self.params['frontend.similarity_threshold']))[0]
-        items, me = self.local_nnsm.items, self.params['robot_id']
-        for j, r, sv in zip(jj.tolist(), rows[jj, 0].tolist(), sims[jj, 0].tolist()):
-            match = EdgeInterRobot(me, items[r], robot_id, ids[j], np.float64(sv))
+        me = self.params['robot_id']
+        item_arr = self.local_nnsm.item_array() if hasattr(self.local_nnsm, "item_array") else None
+        if item_arr is not None:
+            return self.candidate_selector.add_matches_arrays(
+                me, item_arr[rows[jj, 0]], np.full(len(jj), int(robot_id), dtype=np.int64),
+                np.asarray(ids, dtype=np.int64)[jj], sims[jj, 0])
+        items = self.local_nnsm.items
+        for j, r, sv in zip(jj.tolist(), rows[jj, 0].tolist(), sims[jj, 0]):
+            match = EdgeInterRobot(me, items[r], robot_id, ids[j], sv)
             self.candidate_selector.add_match(match)
             out.append(match)
         return out

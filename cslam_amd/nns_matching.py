@@ -46,6 +46,7 @@ class NearestNeighborsMatching(object):
         self._bank = None
         self._lib = None
         self._data_cache = (0, None)          # (rows already mirrored on the host, array) behind `.data`
+        self._item_ids = (0, np.zeros(0, dtype=np.int64))     # (rows covered, int64 items) behind item_array()
         if dim is not None:
             self._create(dim)
 
@@ -226,6 +227,21 @@ class NearestNeighborsMatching(object):
             int(mode), C.c_void_p(out[0].data_ptr()), C.c_void_p(out[1].data_ptr()),
             C.c_void_p(out[2].data_ptr()), C.c_void_p(st)))
         return out
+
+    def item_array(self):
+        """items of rows [0, n) as an int64 array when every item is an int (keyframe ids), else None: lets the
+        batched callers map result rows to keyframe ids with one gather instead of a dict lookup per row."""
+        have, arr = self._item_ids
+        if arr is None:
+            return None
+        if have < self.n:
+            fresh = [self.items[r] for r in range(have, self.n)]
+            if not all(isinstance(x, (int, np.integer)) for x in fresh):
+                self._item_ids = (0, None)           # some item is not a keyframe number: dict lookups from now on
+                return None
+            arr = np.concatenate((arr[:have], np.asarray(fresh, dtype=np.int64)))
+            self._item_ids = (self.n, arr)
+        return arr
 
     def last_stats(self):
         """(uncertified queries re-done by the scan, mode used, bank segments, query tiles)."""

@@ -28,29 +28,83 @@ def all_gather_rows(local, world_size, group=None):
     return out
 
 
+class _Done(object):
+    """Handle of a collective that has already completed (injected synchronous functions, world size 1)."""
+
+    def wait(self):
+        return True
+
+
+def all_gather_rows_async(local, world_size, group=None):
+    """all_gather_rows issued without waiting: returns (out, handle).  On RCCL the collective runs on the process
+    group's own stream, ordered after what the current stream has enqueued so far; `handle.wait()` makes the current
+    stream wait for it -- kernels launched between the two overlap with the transfer."""
+    if world_size == 1:
+        return local, _Done()
+    out = torch.empty((world_size * local.shape[0], local.shape[1]), dtype=local.dtype, device=local.device)
+    return out, dist.all_gather_into_tensor(out, local.contiguous(), group=group, async_op=True)
+
+
+def exchange_lists_async(packed, world_size, group=None):
+    """exchange_lists (below) issued without waiting: (out, handle)."""
+    if world_size == 1:
+        return packed, _Done()
+    out = torch.empty_like(packed)
+    return out, dist.all_to_all_single(out, packed.contiguous(), group=group, async_op=True)
+
+
+def _chunk_bounds(m, chunks):
+    """[0, m) cut into at most `chunks` equal pieces (the same cut on every rank: m is equal on all ranks)."""
+    c = max(1, min(int(chunks), m)) if m > 0 else 1
+    step = -(-m // c) if m > 0 else 0
+    return [(a, min(a + step, m)) for a in range(0, m, step)] if m > 0 else [(0, 0)]
+
+
 class ShardedInterRobotMatcher(object):
-    def __init__(self, rank, world_size, search_fn, k_intra=5, gather_fn=all_gather_rows):
+    def __init__(self, rank, world_size, search_fn, k_intra=5, gather_fn=None, chunks=2):
         """search_fn(queries [nq,d], k) -> (rows [nq,k], sims [nq,k], cnt [nq]) against THIS
-        rank's bank (e.g. NearestNeighborsMatching.search_device)."""
+        rank's bank (e.g. NearestNeighborsMatching.search_device).
+        chunks: the step's descriptors are exchanged and scored in this many pieces, the all-gather of piece
+        t+1 in flight while piece t is scored (SURVEY 8e "double-buffer query chunks"); 1 = one gather, one launch.
+        gather_fn: injected synchronous all-gather (tests, host-staged debug runs); None = RCCL, asynchronous."""
         self.rank, self.world = rank, world_size
         self.search_fn, self.gather_fn, self.k_intra = search_fn, gather_fn, k_intra
+        self.chunks = int(chunks) if world_size > 1 else 1
+
+    def _gather(self, x):
+        if self.gather_fn is not None:
+            return self.gather_fn(x, self.world), _Done()
+        return all_gather_rows_async(x, self.world)
 
     def step(self, local_desc):
         """local_desc [m, d]: this robot's new descriptors.  Returns
         (intra (rows, sims, cnt) for the m local queries,
-         inter (rows, sims, cnt, robot_of_query [nq_remote]) for all other robots' queries)."""
+         inter (rows, sims, cnt, robot_of_query [nq_remote]) for all other robots' queries, robot-major)."""
         m = local_desc.shape[0]
-        allq = self.gather_fn(local_desc, self.world)
         if self.world == 1:
-            return self.search_fn(allq, self.k_intra), None
-        # ONE launch over every robot's new descriptors: the best-1 the remote rows need is the head of the
-        # same top-k list the local rows need in full (same scores, same order), so nothing is computed twice
-        rows, sims, cnt = self.search_fn(allq, self.k_intra)
-        lo, hi = self.rank * m, (self.rank + 1) * m
-        intra = (rows[lo:hi], sims[lo:hi], cnt[lo:hi])
-        robot = torch.arange(self.world, device=allq.device).repeat_interleave(m)
-        cut = lambda t: torch.cat((t[:lo], t[hi:]))             # noqa: E731 -- everyone's rows except this robot's
-        inter = (cut(rows)[:, :1], cut(sims)[:, :1], cut(cnt).clamp(max=1), cut(robot))
+            return self.search_fn(local_desc, self.k_intra), None
+        bounds = _chunk_bounds(m, self.chunks)
+        inflight = self._gather(local_desc[bounds[0][0]:bounds[0][1]])
+        parts = []
+        for t, (a, b) in enumerate(bounds):
+            allq, handle = inflight
+            if t + 1 < len(bounds):                                  # next piece on the wire before this one is scored
+                inflight = self._gather(local_desc[bounds[t + 1][0]:bounds[t + 1][1]])
+            handle.wait()
+            # ONE launch over every robot's piece: the best-1 the remote rows need is the head of the same top-k
+            # list the local rows need in full (same scores, same order), so nothing is computed twice
+            rows, sims, cnt = self.search_fn(allq, self.k_intra)
+            c = b - a
+            parts.append((rows.view(self.world, c, -1), sims.view(self.world, c, -1), cnt.view(self.world, c)))
+        rows = torch.cat([p[0] for p in parts], dim=1)               # [world, m, k], robot-major like one big gather
+        sims = torch.cat([p[1] for p in parts], dim=1)
+        cnt = torch.cat([p[2] for p in parts], dim=1)
+        intra = (rows[self.rank], sims[self.rank], cnt[self.rank])
+        keep = [g for g in range(self.world) if g != self.rank]
+        robot = torch.tensor(keep, device=rows.device).repeat_interleave(m)
+        k = rows.shape[2]
+        inter = (rows[keep].reshape(-1, k)[:, :1], sims[keep].reshape(-1, k)[:, :1],
+                 cnt[keep].reshape(-1).clamp(max=1), robot)
         return intra, inter
 
 
@@ -101,23 +155,56 @@ class RowShardedBankMatcher(object):
         4. `cslam_topk_merge_dev`: k best of the world*k contenders per query, global row numbers.
     `search_fn`, `gather_fn`, `exchange_fn`, `merge_fn` are injectable (CPU control-flow tests with gloo)."""
 
-    def __init__(self, rank, world_size, search_fn, row_offsets, k=5, gather_fn=all_gather_rows,
-                 exchange_fn=exchange_lists, merge_fn=merge_topk_device):
+    def __init__(self, rank, world_size, search_fn, row_offsets, k=5, gather_fn=None, exchange_fn=None,
+                 merge_fn=merge_topk_device, chunks=2):
+        """chunks: pieces per step.  The all-gather of piece t+1 and the all-to-all of piece t-1's lists are in
+        flight while piece t is scored; both collectives of a piece are issued in the same order on every rank.
+        gather_fn / exchange_fn: injected synchronous collectives (tests, host-staged debug runs); None = RCCL,
+        asynchronous."""
         assert len(row_offsets) >= world_size
         self.rank, self.world, self.k = rank, world_size, int(k)
         self.row_offsets = [int(o) for o in row_offsets[:world_size]]
         self.search_fn, self.gather_fn, self.exchange_fn, self.merge_fn = search_fn, gather_fn, exchange_fn, merge_fn
+        self.chunks = int(chunks) if world_size > 1 else 1
+
+    def _gather(self, x):
+        if self.gather_fn is not None:
+            return self.gather_fn(x, self.world), _Done()
+        return all_gather_rows_async(x, self.world)
+
+    def _exchange(self, packed):
+        if self.exchange_fn is not None:
+            return self.exchange_fn(packed, self.world), _Done()
+        return exchange_lists_async(packed, self.world)
+
+    def _merge_piece(self, got, handle):
+        handle.wait()
+        k = self.k
+        return self.merge_fn(got[:, :, :k].contiguous(), got[:, :, k:2 * k].contiguous().view(torch.float64),
+                             got[:, :, 2 * k].to(torch.int32).contiguous(), self.row_offsets)
 
     def step(self, local_desc):
         """local_desc [m, d] -> (rows [m,k] int64 global (-1 padded), sims [m,k] float64, cnt [m] int32)."""
         m, k, G = local_desc.shape[0], self.k, self.world
-        allq = self.gather_fn(local_desc, G)
-        rows, sims, cnt = self.search_fn(allq, k)                       # shard-local rows, [G*m, k]
         if G == 1:
+            rows, sims, cnt = self.search_fn(local_desc, k)
             return self.merge_fn(rows[None], sims[None], cnt[None], self.row_offsets) if self.row_offsets[0] else \
                 (rows, sims, cnt)
-        # one int64 buffer per query: k rows | k score bit patterns | count  -> ONE collective
-        packed = torch.cat((rows, sims.contiguous().view(torch.int64), cnt.to(torch.int64)[:, None]), dim=1)
-        got = self.exchange_fn(packed.view(G, m, 2 * k + 1), G)          # [G shards, m own queries, 2k+1]
-        return self.merge_fn(got[:, :, :k].contiguous(), got[:, :, k:2 * k].contiguous().view(torch.float64),
-                             got[:, :, 2 * k].to(torch.int32).contiguous(), self.row_offsets)
+        bounds = _chunk_bounds(m, self.chunks)
+        inflight = self._gather(local_desc[bounds[0][0]:bounds[0][1]])
+        lists, out = None, []
+        for t, (a, b) in enumerate(bounds):
+            allq, handle = inflight
+            if t + 1 < len(bounds):
+                inflight = self._gather(local_desc[bounds[t + 1][0]:bounds[t + 1][1]])
+            handle.wait()
+            rows, sims, cnt = self.search_fn(allq, k)                    # shard-local rows, [G*(b-a), k]
+            if lists is not None:                                        # previous piece's lists arrived meanwhile
+                out.append(self._merge_piece(*lists))
+            # one int64 buffer per query: k rows | k score bit patterns | count  -> ONE collective per piece
+            packed = torch.cat((rows, sims.contiguous().view(torch.int64), cnt.to(torch.int64)[:, None]), dim=1)
+            lists = self._exchange(packed.view(G, b - a, 2 * k + 1))     # -> [G shards, own queries of the piece, 2k+1]
+        out.append(self._merge_piece(*lists))
+        if len(out) == 1:
+            return out[0]
+        return tuple(torch.cat([o[i] for o in out]) for i in range(3))

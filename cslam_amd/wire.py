@@ -128,8 +128,19 @@ class PackedDescriptorBuffer(object):
         self._n += 1
 
     def extend(self, keyframe_ids, embeddings):
-        for k, e in zip(keyframe_ids, np.asarray(embeddings)):
-            self.append(k, e)
+        """append() for a batch; new keyframe ids arriving in ascending order after the last stored one (the
+        normal case: keyframes are produced in order) are copied in one block."""
+        e = np.asarray(embeddings)
+        k = np.asarray(keyframe_ids, dtype=np.int64)
+        if e.ndim == 2 and len(k) == e.shape[0] and len(k) > 0 and np.all(k[1:] > k[:-1]) and \
+                (self._n == 0 or k[0] > self._ids[self._n - 1]):
+            self._reserve(len(k), e.shape[1])
+            self._ids[self._n:self._n + len(k)] = k
+            self._rows[self._n:self._n + len(k)] = e
+            self._n += len(k)
+            return
+        for ki, ei in zip(k.tolist(), e):
+            self.append(ki, ei)
 
     def chunks(self, start, chunk_size):
         """`dict_to_list_chunks(buffer, start, chunk_size)` (utils/misc.py:21-32): the entries whose

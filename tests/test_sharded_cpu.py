@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 from conftest import ROOT
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, chunks=2):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -27,7 +27,7 @@ def _worker(rank, world, port, outdir):
         i, s, c = pyoracle.nns_search(bank, q.numpy(), k)
         return torch.from_numpy(i), torch.from_numpy(s), torch.from_numpy(c)
 
-    m = ShardedInterRobotMatcher(rank, world, search, k_intra=5)
+    m = ShardedInterRobotMatcher(rank, world, search, k_intra=5, chunks=chunks)
     local = torch.from_numpy(unit_rows(np.random.default_rng(4321 + rank), 40, 64))
     intra, inter = m.step(local)
     np.savez(os.path.join(outdir, f"r{rank}.npz"), intra_rows=intra[0].numpy(), intra_sims=intra[1].numpy(),
@@ -36,21 +36,26 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_step(tmp_path):
+@pytest.mark.parametrize("world,chunks", [(2, 1), (2, 2), (4, 3), (8, 2)])
+def test_gloo_one_bank_per_rank_step(tmp_path, world, chunks):
+    """2 / 4 / 8 ranks (config 4 has 8 robots), one piece or several overlapped pieces per step: every rank's own
+    keyframes get their top-5 and every other robot's keyframes their best-1 against this rank's bank, equal to the
+    oracle; the asynchronous gloo all-gather is the default path (no injected gather)."""
     from helpers import unit_rows
     from oracle import pyoracle
-    world, port = 2, 29500 + (os.getpid() % 1000)
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    port = 29500 + (os.getpid() % 1000) + 7 * world + chunks
+    mp.spawn(_worker, args=(world, port, str(tmp_path), chunks), nprocs=world, join=True)
     banks = [unit_rows(np.random.default_rng(1234 + r), 500, 64) for r in range(world)]
     qs = [unit_rows(np.random.default_rng(4321 + r), 40, 64) for r in range(world)]
     for r in range(world):
         got = np.load(tmp_path / f"r{r}.npz")
         i, s, _ = pyoracle.nns_search(banks[r], qs[r], 5)           # own keyframes vs own bank
         assert np.array_equal(got["intra_rows"], i) and np.array_equal(got["intra_sims"], s)
-        o = 1 - r
-        i, s, _ = pyoracle.nns_search(banks[r], qs[o], 1)           # the other robot's keyframes vs own bank
+        others = [o for o in range(world) if o != r]
+        oq = np.concatenate([qs[o] for o in others])                # the other robots' keyframes vs own bank
+        i, s, _ = pyoracle.nns_search(banks[r], oq, 1)
         assert np.array_equal(got["inter_rows"], i) and np.array_equal(got["inter_sims"], s)
-        assert np.all(got["inter_robot"] == o)
+        assert np.array_equal(got["inter_robot"], np.repeat(others, 40))
 
 
 def test_single_rank_is_passthrough():
@@ -84,7 +89,7 @@ def _host_merge(rows, sims, cnt, row_offsets):
     return torch.from_numpy(out_r), torch.from_numpy(out_s), torch.from_numpy(out_c)
 
 
-def _row_worker(rank, world, port, outdir, shard_rows):
+def _row_worker(rank, world, port, outdir, shard_rows, chunks=2):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -102,7 +107,7 @@ def _row_worker(rank, world, port, outdir, shard_rows):
         return torch.from_numpy(i), torch.from_numpy(s), torch.from_numpy(c)
 
     merge = lambda r, s, c, o: _host_merge(r.numpy(), s.numpy(), c.numpy(), o)      # noqa: E731
-    m = RowShardedBankMatcher(rank, world, search, offs[:world], k=5, merge_fn=merge)
+    m = RowShardedBankMatcher(rank, world, search, offs[:world], k=5, merge_fn=merge, chunks=chunks)
     local = torch.from_numpy(unit_rows(np.random.default_rng(4321 + rank), 40, 64))
     rows, sims, cnt = m.step(local)
     np.savez(os.path.join(outdir, f"s{rank}.npz"), rows=rows.numpy(), sims=sims.numpy(), cnt=cnt.numpy())
@@ -110,14 +115,16 @@ def _row_worker(rank, world, port, outdir, shard_rows):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("shard_rows", [(300, 300), (597, 3)])
-def test_two_rank_gloo_row_sharded_bank(tmp_path, shard_rows):
-    """Each rank's keyframes get the top-k of the WHOLE bank: indices and float64 scores identical to the
-    oracle on the unsharded bank (the 3-row shard returns fewer than k entries to the merge)."""
+@pytest.mark.parametrize("shard_rows,chunks", [((300, 300), 1), ((597, 3), 2), ((150, 150, 200, 100), 3),
+                                               ((75, 75, 75, 75, 75, 75, 147, 3), 2)])
+def test_gloo_row_sharded_bank(tmp_path, shard_rows, chunks):
+    """2 / 4 / 8 ranks: each rank's keyframes get the top-k of the WHOLE bank: indices and float64 scores identical
+    to the oracle on the unsharded bank (the 3-row shard returns fewer than k entries to the merge); one piece or
+    several overlapped pieces per step, collectives through the default asynchronous path."""
     from helpers import unit_rows
     from oracle import pyoracle
-    world, port = 2, 30500 + (os.getpid() % 1000)
-    mp.spawn(_row_worker, args=(world, port, str(tmp_path), shard_rows), nprocs=world, join=True)
+    world, port = len(shard_rows), 30500 + (os.getpid() % 1000) + 11 * len(shard_rows) + chunks
+    mp.spawn(_row_worker, args=(world, port, str(tmp_path), shard_rows, chunks), nprocs=world, join=True)
     whole = unit_rows(np.random.default_rng(99), sum(shard_rows), 64)
     for r in range(world):
         q = unit_rows(np.random.default_rng(4321 + r), 40, 64)
