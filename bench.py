@@ -34,7 +34,60 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: dense f32-input MFMA peak
+FP16_MFMA_PEAK_TFLOPS = 2500.0     # same guide: dense fp16/bf16 MFMA peak (never the 2:1-sparsity figure)
 HBM_PEAK_GBS = 8000.0              # same guide: HBM3E ~8 TB/s
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_by_kernel.json")
+
+
+def pmc_entry(kernel, **match):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_by_kernel.json,
+    keyed by kernel name -- no globbing), only if the entry was collected on exactly the launch timed here."""
+    try:
+        e = json.load(open(PMC_FILE)).get(kernel)
+    except Exception:
+        return None
+    if not e or any(e.get("match", {}).get(k) != v for k, v in match.items()):
+        return None
+    return e
+
+
+def measure_peaks(torch, dev):
+    """What THIS box sustains, in the same run: a streaming copy (HBM) and register-resident MFMA loops
+    (csrc/peaks.hip), HIP-event timed.  BASELINE.md section 4: fractions are printed against nominal AND measured."""
+    import ctypes as C
+    from cslam_amd import _lib
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    nbytes = 2 << 30                                          # 2 GiB each way: well past the 256 MB Infinity Cache
+    src = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+    dst = torch.empty_like(src)
+    best = 0.0
+    for rep in range(4):
+        e0.record()
+        for _ in range(3):
+            _lib.check(lib.cslam_peak_copy_dev(src.data_ptr(), dst.data_ptr(), nbytes, st))
+        e1.record()
+        torch.cuda.synchronize()
+        if rep:                                               # first round warms up
+            best = max(best, 3 * 2.0 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del src, dst
+    out = {"hbm_copy_GBs": round(best, 1), "hbm_copy_note": "16 B/lane non-temporal copy of 2 GiB, read + write bytes"}
+    scratch = torch.zeros(64, dtype=torch.float32, device=dev)
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    for kind, name, iters in ((0, "mfma_f32_TFLOPs", 4000), (1, "mfma_f16_TFLOPs", 16000)):
+        flop = C.c_double(0.0)
+        best = 0.0
+        for rep in range(3):
+            e0.record()
+            _lib.check(lib.cslam_peak_mfma_dev(kind, iters, 2 * ncu, scratch.data_ptr(), C.byref(flop), st))
+            e1.record()
+            torch.cuda.synchronize()
+            if rep:
+                best = max(best, flop.value / (e0.elapsed_time(e1) * 1e-3) / 1e12)
+        out[name] = round(best, 1)
+    out["mfma_note"] = "register-resident loops, 4 independent 32x32 accumulators per wave, 2 waves per SIMD, non-zero operands"
+    return out
 
 
 def parse():
@@ -51,7 +104,8 @@ def parse():
     ap.add_argument("--extract-chunk", type=int, default=256, help="frames per backbone forward")
     ap.add_argument("--backbone-conv", default="winograd", choices=["winograd", "winograd2", "direct"],
                     help="execution of the wide 3x3 backbone convolutions (vpr/winograd.py)")
-    ap.add_argument("--cpu-queries", type=int, default=48, help="cpu_baseline sample size (queries)")
+    ap.add_argument("--cpu-queries", type=int, default=48, help="cpu_baseline sample size of the match leg (queries)")
+    ap.add_argument("--cpu-frames", type=int, default=8, help="cpu_baseline sample size of the extract leg (frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extract", action="store_true", help="debug: time the match leg only")
     ap.add_argument("--shard-mode", default="rows", choices=["rows", "robots"],
@@ -202,9 +256,9 @@ def main():
     if extractor is not None:
         de = timed(extract, a.steps)
         extract_only = world * a.batch * a.steps / de
-    # the same extract leg with the trunk's GEMMs as plain fp32 (rocBLAS sgemm) instead of the default split-fp16 pairs
-    # (fp32-grade either way): reported beside `extract_only`, rank 0 at N = 1 only
-    extract_fp32_gemms = None
+    # the same leg AND the same whole step with the trunk's GEMMs as plain fp32 (rocBLAS sgemm) instead of the default
+    # split-fp16 pairs (fp32-grade either way): reported beside `extract_only` / `value`, N = 1 only
+    extract_fp32_gemms = value_fp32_gemms = None
     split16 = os.environ.get("CSLAM_WINO_SPLIT16", "256")
     if extractor is not None and world == 1 and extractor.backbone_conv == "winograd" and split16 != "0":
         os.environ["CSLAM_WINO_SPLIT16"] = "0"
@@ -215,11 +269,17 @@ def main():
             ex32.compute_embeddings_device(frames[:a.extract_chunk], bdt)
         finally:
             os.environ["CSLAM_WINO_SPLIT16"] = split16
-        d32 = timed(lambda: [ex32.compute_embeddings_device(frames[s_:s_ + a.extract_chunk], bdt)
-                             for s_ in range(0, a.batch, a.extract_chunk)], a.steps)
+
+        def extract32():
+            return torch.cat([ex32.compute_embeddings_device(frames[s_:s_ + a.extract_chunk], bdt)
+                              for s_ in range(0, a.batch, a.extract_chunk)])
+        d32 = timed(extract32, a.steps)
         extract_fp32_gemms = a.batch * a.steps / d32
+        dv32 = timed(lambda: matcher.step(extract32()), a.steps)
+        value_fp32_gemms = a.batch * a.steps / dv32
         del ex32
         torch.cuda.empty_cache()
+    kernel_ms.clear()
     nqm = a.match_queries
     mq = torch.randn((nqm, a.dim), generator=qgen, device=dev)
     mq /= mq.norm(dim=1, keepdim=True)
@@ -243,22 +303,18 @@ def main():
     in_step = None
     if step_kernel_ms and world == 1:
         in_step = round(2.0 * nq_step * local_rows * a.dim / (np.mean(step_kernel_ms) * 1e-3) / 1e12, 2)
-    # HBM-side traffic per launch comes from the committed rocprofv3 PMC passes of this same
-    # match leg (tools/gpu_pmc.sh + tools/pmc_summary.py; FETCH_SIZE x2 correction per the
-    # MI355X guide); it cannot be collected inside an unprofiled run.
-    traffic, traffic_src = None, None
-    try:
-        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
-        if cands and local_rows == 100_000 and a.dim == 4096:
-            pm = json.load(open(cands[-1]))
-            traffic = pm.get("traffic_bytes")
-            traffic_src = os.path.basename(cands[-1]) + " (100k-query launch; L2 hit rate %.2f)" % pm.get("l2_hit_rate", float("nan"))
-    except Exception:
-        pass
+    # HBM-side traffic per launch: the committed rocprofv3 PMC passes of this same launch (profiles/pmc_by_kernel.json,
+    # looked up by kernel name and launch shape; FETCH_SIZE x2 correction per the MI355X guide) -- it cannot be
+    # collected inside an unprofiled run
+    peaks = measure_peaks(torch, dev) if rank == 0 else None
+    pm = pmc_entry("sim_topk_mfma_kernel", queries=nqm, bank_rows=local_rows, dim=a.dim)
     roofline = {"bound": "mfma", "kernel": "sim_topk_mfma_kernel", "achieved": round(ach, 2),
                 "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": traffic, "traffic_source": traffic_src, "source": src,
-                "kernel_ms": round(match_kernel_ms, 3), "in_step_achieved": in_step}
+                "traffic": pm["traffic_bytes"] if pm else None,
+                "traffic_source": (pm["source"] + "; L2 hit rate %.2f" % pm.get("l2_hit_rate", float("nan"))) if pm else None,
+                "source": src, "kernel_ms": round(match_kernel_ms, 3), "in_step_achieved": in_step,
+                "peak_measured": peaks and peaks["mfma_f32_TFLOPs"],
+                "frac_of_measured": round(ach / peaks["mfma_f32_TFLOPs"], 4) if peaks and peaks["mfma_f32_TFLOPs"] else None}
 
     # the hand-written kernels of the extract leg are the Winograd transforms (HBM-bound streaming): time the
     # largest one on its real shape with HIP events on the launch stream.  Algorithmic bytes per launch:
@@ -284,21 +340,16 @@ def main():
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / 5
         nbytes = (xt.numel() + vt.numel()) * 4
-        # HBM-side bytes of this very launch shape from the committed FETCH_SIZE / WRITE_SIZE passes
-        # (tools/gpu_round4.sh + tools/pmc_extract_summary.py), like roofline.traffic above
-        etraffic, esrc = None, None
-        try:
-            efiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_extract_pmc_summary.json")))
-            if efiles and eb == 256:
-                ej = json.load(open(efiles[-1]))
-                etraffic, esrc = ej.get("traffic_bytes"), os.path.basename(efiles[-1])
-        except Exception:
-            pass
-        extract_roofline = {"bound": "hbm", "kernel": "wino4_input_kernel", "achieved": round(nbytes / ms / 1e6, 1),
-                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+        shape_in = f"x [{eb},{eh},{eh},{ec}] -> V [36,{vt.shape[1]},{ec}]"
+        pe = pmc_entry("wino4_input_kernel", shape=shape_in)
+        etraffic, esrc = (pe["traffic_bytes"], pe["source"]) if pe else (None, None)
+        gbs = nbytes / ms / 1e6
+        extract_roofline = {"bound": "hbm", "kernel": "wino4_input_kernel", "achieved": round(gbs, 1),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                            "peak_measured": peaks["hbm_copy_GBs"],
+                            "frac_of_measured": round(gbs / peaks["hbm_copy_GBs"], 4) if peaks["hbm_copy_GBs"] else None,
                             "traffic": etraffic, "traffic_source": esrc, "algorithmic_bytes": nbytes,
-                            "kernel_ms": round(ms, 3),
-                            "shape": f"x [{eb},{eh},{eh},{ec}] -> V [36,{vt.shape[1]},{ec}]",
+                            "kernel_ms": round(ms, 3), "shape": shape_in,
                             "note": "largest hand-written kernel of the extract leg; the 36 GEMMs between the "
                                     "transforms are rocBLAS"}
         del xt, vt
@@ -325,13 +376,18 @@ def main():
             "bound": "mfma", "kernel": "wino4_fused_c64_pipe_kernel", "achieved": round(fflop / fms / 1e9, 1),
             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fflop / fms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4),
             "kernel_ms": round(fms, 3), "algorithmic_flop": fflop,
-            "traffic": (ej.get("fused_conv") or {}).get("traffic_bytes") if (etraffic is not None) else None,
+            "traffic": (pmc_entry("wino4_fused_c64_pipe_kernel", shape=f"x [{eb},{fh},{fh},64] -> conv 64->64 + bias + ReLU + MaxPool2d") or {}).get("traffic_bytes"),
             "algorithmic_bytes": (xf.numel() + yf.numel()) * 4,
+            "peak_measured": peaks["mfma_f32_TFLOPs"],
+            "frac_of_measured": round(fflop / fms / 1e9 / peaks["mfma_f32_TFLOPs"], 4) if peaks["mfma_f32_TFLOPs"] else None,
             "shape": f"x [{eb},{fh},{fh},64] -> conv 64->64 + bias + ReLU + MaxPool2d -> [{eb},{fh // 2},{fh // 2},64]"}
         del xf, yf
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        # The reference's CPU path for the step `value` times: NetVLAD extract on host cores (the reference runs the CNN
+        # on the CPU when no CUDA device is present, cslam/vpr/netvlad.py:157-160) + the per-row cosine scan of
+        # nns_matching.py:42-61.  Both legs are oracle restatements ("port"), timed on a bounded sample.
         from oracle import pyoracle
         hb = bank.cpu().numpy()
         hq = mq[:a.cpu_queries].cpu().numpy()
@@ -339,12 +395,38 @@ def main():
         oi, os_, oc = pyoracle.nns_search(hb, hq, a.k)
         tc = time.perf_counter() - t0
         same = bool(np.array_equal(oi, mout[0][:a.cpu_queries].cpu().numpy()))
-        cpu = {"value": round(a.cpu_queries / tc, 3), "unit": "keyframes/sec", "cores": 1, "kind": "port",
-               "sample": f"match leg only: {a.cpu_queries} of the match-only queries against the same "
-                         f"{a.bank_rows}x{a.dim} bank, top-{a.k}, oracle/nns_oracle.c (scalar C restatement of "
-                         f"nns_matching.py:42-61); extract has no CPU leg (VGG-16 on host cores is not the reference's "
-                         f"deployment)", "topk_equal_to_gpu": same,
-               "host_cpus": os.cpu_count()}
+        match_leg = {"value": round(a.cpu_queries / tc, 3), "unit": "keyframes/sec", "cores": 1,
+                     "sample": f"{a.cpu_queries} of the match-only queries against the same {a.bank_rows}x{a.dim} bank, "
+                               f"top-{a.k}, oracle/nns_oracle.c (scalar C restatement of nns_matching.py:42-61)",
+                     "topk_equal_to_gpu": same}
+        cpu = dict(match_leg, kind="port", host_cpus=os.cpu_count(), match_leg=match_leg)
+        if extractor is not None:
+            from oracle import extract_oracle
+            ncf = max(1, a.cpu_frames)
+            threads = torch.get_num_threads()
+            convs = [(m.weight.detach().float().cpu().contiguous(memory_format=torch.contiguous_format),
+                      m.bias.detach().float().cpu()) for m in extractor.encoder if isinstance(m, torch.nn.Conv2d)]
+            vw, vc = extractor.pool.conv_weight.cpu(), extractor.pool.centroids.cpu()
+            comp = extractor.pca_components[:, :64 * 512].cpu().numpy()
+            pmean = np.zeros(64 * 512, dtype=np.float32)          # random_init: zero mean
+            hf = frames[:ncf].cpu().numpy()
+            gd = extractor.compute_embeddings_device(frames[:ncf], bdt).cpu().numpy()
+            extract_oracle.netvlad_embed(hf[0], 376, convs, vw, vc, comp, pmean)     # warm-up (thread pools, page-in)
+            t0 = time.perf_counter()
+            cd = np.stack([extract_oracle.netvlad_embed(f, 376, convs, vw, vc, comp, pmean) for f in hf])
+            te = (time.perf_counter() - t0) / ncf
+            extract_leg = {"value": round(1.0 / te, 3), "unit": "keyframes/sec", "cores": threads,
+                           "sample": f"{ncf} of the step's frames, one at a time like the reference: PIL-equivalent "
+                                     f"transform + VGG-16 on torch CPU ({threads} threads) + NetVLADLayer with its "
+                                     f"64-cluster loop + PCA 32768->{a.dim} + L2 (oracle/extract_oracle.py, restating "
+                                     f"netvlad.py:212-241), same weights as the GPU extractor",
+                           "max_abs_diff_vs_gpu_descriptor": float(np.abs(cd - gd).max())}
+            tm = tc / a.cpu_queries
+            cpu.update({"value": round(1.0 / (te + tm), 3), "cores": threads, "extract_leg": extract_leg,
+                        "sample": f"extract+match per keyframe = {te * 1e3:.1f} ms extract ({ncf} frames, {threads} torch "
+                                  f"threads) + {tm * 1e3:.1f} ms match ({a.cpu_queries} queries, 1 core: the reference's "
+                                  f"scan is a single-threaded Python loop) against the same {a.bank_rows}x{a.dim} bank"})
+            del convs, comp
         # the strongest plain-numpy host formulation (SURVEY 8(d) "vectorised" flavour): one BLAS sgemm over
         # the bank on every host core + argpartition; reported beside the faithful scalar port, never as it
         nb = min(512, nqm)
@@ -378,6 +460,9 @@ def main():
                                        "one %d-row bank split by rows over %d GPUs: RCCL all-gather of the new descriptors, "
                                        "local top-k, all-to-all of the lists, HIP merge" % (a.bank_rows, world) if rows_mode
                                        else "1 robot bank per GPU, RCCL all-gather of new descriptors")},
+            "ranks": world, "collective_backend": None if world == 1 else ("gloo via host (debug)" if a.debug_shared_gpu else "nccl (RCCL)"),
+            "value_fp32_gemms": None if value_fp32_gemms is None else round(value_fp32_gemms, 2),
+            "peaks_measured": peaks,
             "extract_only": None if extract_only is None else round(extract_only, 2),
             "backbone_conv": None if extractor is None else extractor.backbone_conv,
             "trunk_gemm": None if extractor is None or extractor.backbone_conv != "winograd" else (

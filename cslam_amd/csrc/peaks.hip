@@ -1,0 +1,89 @@
+// peaks.hip -- in-run re-measurement of the peaks the rooflines are priced against (gfx950).
+//
+// bench.py prints every roofline fraction against the nominal MI355X figures of
+// /opt/skills/guides/MI355X_MICROARCH.md (HBM 8 TB/s, f32-input MFMA 157.3 TFLOP/s, fp16 MFMA 2.5 PFLOP/s) AND against
+// what this very box sustains, measured in the same run with the two kernels below:
+//   peak_copy_kernel  16-byte-per-lane streaming copy, grid-stride, non-temporal: achievable HBM bandwidth
+//   peak_mfma_kernel  register-resident MFMA loop, 4 independent accumulators per wave, 2 waves per SIMD:
+//                     achievable matrix rate for f32 inputs (v_mfma_f32_32x32x2_f32) and fp16 inputs
+//                     (v_mfma_f32_32x32x16_f16), operands non-zero (zero operands clock higher: guide rule 25)
+// Diagnostics only: nothing on the extract / match path calls them.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void peak_copy_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst,
+                                                        int64_t n16) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {          // 4 independent 16-byte loads in flight per lane
+        f32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+        f32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+        __builtin_nontemporal_store(a, dst + i);
+        __builtin_nontemporal_store(b, dst + i + stride);
+        __builtin_nontemporal_store(c, dst + i + 2 * stride);
+        __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    }
+    for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+}
+
+CSLAM_API int cslam_peak_copy_dev(const void *d_src, void *d_dst, int64_t bytes, void *stream) {
+    PTR_DEVICE(d_src);
+    ARG_CHECK(d_src && d_dst && bytes >= 0 && bytes % 16 == 0, "NULL pointer or size not a multiple of 16");
+    ARG_CHECK((((uintptr_t)d_src | (uintptr_t)d_dst) & 15) == 0, "pointers must be 16-byte aligned");
+    if (bytes == 0) return CSLAM_OK;
+    const int64_t n16 = bytes / 16;
+    int64_t blocks = ceil_div64(n16, 256 * 4);
+    if (blocks > 256 * 16) blocks = 256 * 16;                // 16 workgroups per compute unit, grid-stride beyond
+    hipLaunchKernelGGL(peak_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const f32x4 *)d_src, (f32x4 *)d_dst, n16);
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void peak_mfma_kernel(int iters, float *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    f32x16 acc[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.0f;
+    if (KIND == 0) {
+        float av = 1.0f + 0.001f * lane, bv = 0.5f - 0.002f * lane;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[a], 0, 0, 0);
+            av = -av;                                          // keeps the sums bounded without leaving the registers
+        }
+    } else {
+        f16x8 av, bv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { av[e] = (_Float16)(0.5f + 0.01f * (lane + e)); bv[e] = (_Float16)(0.25f - 0.003f * (lane - e)); }
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, acc[a], 0, 0, 0);
+            av = -av;
+        }
+    }
+    float s = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[a][r];
+    if (s == 12345.678f) out[0] = s;                            // never true: keeps the loop alive
+}
+
+// kind 0: f32 inputs (2*32*32*2 flop per MFMA), kind 1: fp16 inputs (2*32*32*16).  `flop_out` receives the flop count of
+// the launch: blocks x 4 waves x iters x 4 MFMAs.
+CSLAM_API int cslam_peak_mfma_dev(int kind, int iters, int blocks, float *d_scratch, double *flop_out, void *stream) {
+    PTR_DEVICE(d_scratch);
+    ARG_CHECK((kind == 0 || kind == 1) && iters > 0 && blocks > 0 && d_scratch, "bad arguments");
+    if (kind == 0) hipLaunchKernelGGL(peak_mfma_kernel<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, d_scratch);
+    else hipLaunchKernelGGL(peak_mfma_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, d_scratch);
+    HIP_TRY(hipGetLastError());
+    if (flop_out) *flop_out = (double)blocks * 4.0 * iters * 4.0 * 2.0 * 32 * 32 * (kind == 0 ? 2 : 16);
+    return CSLAM_OK;
+}

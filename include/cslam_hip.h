@@ -294,6 +294,16 @@ int cslam_wino2_fused_c64_dev(const float *d_x, const float *d_Up, const float *
 int cslam_wino4_fused_c64_dev(const float *d_x, const float *d_Up, const float *d_bias, const float *d_residual, int B,
                               int H, int W, int Cout, int relu, int pool, float *d_y, void *stream);
 
+/* ---- diagnostics: in-run re-measurement of the peaks rooflines are priced against (csrc/peaks.hip) ---------------
+ * Not on the extract / match path and without a reference counterpart: bench.py reports every roofline fraction against
+ * the nominal MI355X peaks and against what these two kernels sustain on the box in the same run.
+ * cslam_peak_copy_dev: 16-byte-per-lane non-temporal streaming copy of `bytes` (multiple of 16) bytes.
+ * cslam_peak_mfma_dev: register-resident MFMA loop; kind 0 = f32 inputs (v_mfma_f32_32x32x2_f32), 1 = fp16 inputs
+ * (v_mfma_f32_32x32x16_f16); `blocks` workgroups of 4 waves, `iters` x 4 independent MFMAs per wave; *flop_out = flop
+ * of the launch.  The caller times both with HIP events on `stream`. */
+int cslam_peak_copy_dev(const void *d_src, void *d_dst, int64_t bytes, void *stream);
+int cslam_peak_mfma_dev(int kind, int iters, int blocks, float *d_scratch, double *flop_out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -86,3 +86,34 @@ def test_vlad_init_params_host_logic_matches_reference():
         assert (b is None) == (tag + "/conv_b" not in g.files)
         y = ho.vlad_forward(g["x"], layer.conv_weight.numpy(), b, layer.centroids.numpy())
         assert np.max(np.abs(y - g[tag + "/y"])) < 1e-6
+
+
+def test_extract_oracle_vlad_loop_matches_reference_golden():
+    """oracle/extract_oracle.py (the cpu_baseline of the extract leg) restates NetVLADLayer.forward with the
+    reference's per-cluster loop; pinned by G3, the outputs of the real reference layer (oracle/gen_golden_heads.py)."""
+    import torch
+    from oracle import extract_oracle
+    g = np.load(GOLDEN + "/heads_g.npz")
+    w, c = torch.from_numpy(g["vlad/conv_w"]), torch.from_numpy(g["vlad/centroids"])
+    for case in ("vlad_a", "vlad_b"):
+        y = extract_oracle.netvlad_layer_forward(torch.from_numpy(g[case + "/x"]), w, c).numpy()
+        assert np.abs(y - g[case + "/y"]).max() <= 2e-7
+
+
+def test_extract_oracle_vgg16_is_the_reference_layer_list():
+    """features[:-2] of torchvision's VGG-16 (netvlad.py:163-171): 13 convolutions, the last one without ReLU / pool,
+    four 2x2 poolings -> [1, 512, 14, 14] for a 224 px input; equal to the product's trunk module on the same weights
+    (the module whose parameter names carry the reference's checkpoints)."""
+    import torch
+    from oracle import extract_oracle
+    from cslam_amd.vpr.backbones import vgg16_features_trunk
+    torch.manual_seed(0)
+    trunk = vgg16_features_trunk().eval()
+    convs = [m for m in trunk if isinstance(m, torch.nn.Conv2d)]
+    assert len(convs) == 13
+    params = [(m.weight.detach(), m.bias.detach()) for m in convs]
+    x = torch.randn(1, 3, 64, 64)
+    with torch.no_grad():
+        a, b = extract_oracle.vgg16_encoder(x, params), trunk(x)
+    assert a.shape == (1, 512, 4, 4) and torch.equal(a, b)
+    assert (a < 0).any()                                   # no ReLU after conv5_3
