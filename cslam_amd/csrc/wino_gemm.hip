@@ -1,0 +1,352 @@
+// wino_gemm.hip -- the 36 per-frequency products of the F(4x4, 3x3) Winograd convolution as ONE persistent kernel on the
+// fp16 matrix pipe with fp32-grade results (gfx950), and the input transform that feeds it.
+//
+// Replaces, for the wide layers of the VGG-16 trunk (conv2_2 ... conv5_3, cslam/vpr/netvlad.py:163-171,227 through
+// torchvision's Conv2d), the library GEMM between wino4_input_* and wino4_output_* (winograd.hip):
+//     M[xi] = V[xi] U[xi],  xi = 0..35,  V[xi] [T tiles, Cin],  U[xi] [Cin, Cout],  M[xi] [T, Cout] float32.
+// A float times a power of two splits exactly into an fp16 pair hi + lo (11 + 11 significant bits); fp16 x fp16 products
+// are exact in the MFMA's fp32 accumulator, so  V U = vh uh + vl uh + vh ul  (the dropped vl ul is 2^-22 of the product)
+// is an fp32-grade product at the fp16 MFMA rate.  Round 1 ran this as one library GEMM over K' = 3 Cin with operands
+// [vh | vl | vh] x [uh ; uh ; ul]: V was written and read at 1.5x its fp32 size.  Here the operands are stored ONCE as
+// pairs -- 4 bytes per value, the fp32 size -- and every fragment read from LDS feeds two of the three products:
+//     acc += vh uh;  acc += vl uh;  acc += vh ul        (v_mfma_f32_32x32x16_f16, fp32 accumulate)
+//
+// Layout (both operands, K-major rows):  row r of V2[xi] / U2[xi] = Cin/32 blocks of 128 bytes, block kb =
+// [hi of channels 32 kb .. 32 kb + 31 | lo of the same channels] as fp16.  V2 rows are tiles, U2 rows are OUTPUT channels
+// (U transposed), so one loader, one LDS image and one fragment addressing serve both.  A K stage = one block of every
+// row of the workgroup tile = [256 | TN rows][128 B], moved by global_load_lds_dwordx4 into an XOR-swizzled image (the
+// 16-byte chunk index ^ (row >> 1 & 7), on the per-lane SOURCE address and on the read: conflict-free ds_read_b128, as in
+// sim_topk_mfma.hip), double-buffered, the next stage's loads issued between this stage's MFMAs.
+//
+// Work: one item = (xi, 256-tile row block, TN-channel column block); a persistent workgroup (8 waves as 2 x 4, wave tile
+// 128 x TN/4 = 4 x {1,2} MFMA tiles) walks its share of the item list with the K loops of consecutive items fused, so the
+// first stage of the next item lands while this item's 256 x TN results are stored.  Items are xi-major and every XCD
+// owns a contiguous run of them: the U2[xi] it needs (<= 1 MB) stays in its L2, V2 is streamed once per column block.
+// Bound: HBM for Cin <= 256 (V2 in + M out = 4 (Cin + Cout) bytes per tile row and frequency against 6 Cin Cout flop),
+// about balanced at 512 x 512.
+#include "common.h"
+#include <hip/hip_fp16.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float wf4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned wu2 __attribute__((ext_vector_type(2)));
+
+#define WG_TM 256                      // tile rows per workgroup
+#define WG_ROWB 128                    // bytes of one K block of one row: 32 hi + 32 lo halfs
+
+__device__ __forceinline__ void wg_glds16(const char *g, char *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+
+struct WinoGemmArgs {
+    const char *V2;        // [36][T][Cin/32][128 B]
+    const char *U2;        // [36][Cout][Cin/32][128 B]
+    float *M;              // [36][T][Cout]
+    int T, Cin, Cout;
+    int nk;                // Cin / 32
+    int n_mt, n_nt;        // row blocks = ceil(T / 256), column blocks = Cout / TN
+    int n_items;           // 36 * n_mt * n_nt
+};
+
+// TN = 128 or 256 output channels per workgroup tile; DBG: timing-only ablations (1 = no stores, 2 = no loads after the
+// first stage) selected by CSLAM_WGEMM_DBG, never by the product path
+template <int TN, int DBG>
+__global__ __launch_bounds__(512, 2) void wino_gemm_h2_kernel(WinoGemmArgs p) {
+    constexpr int NT = TN / 128;                       // 32-column MFMA tiles per wave (wave tile 128 x TN/4)
+    constexpr int OPA = WG_TM * WG_ROWB;               // 32 KiB
+    constexpr int OPB = TN * WG_ROWB;
+    constexpr int STAGE = OPA + OPB;
+    constexpr int NLA = WG_TM * 8 / 512;               // 16-byte chunks per thread per stage: A 4, B 4 | 2
+    constexpr int NLB = TN * 8 / 512;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    // this workgroup's items: XCD x (= blockIdx % 8) owns the contiguous run [x I / 8, (x + 1) I / 8) of the xi-major list,
+    // its workgroups take them round-robin
+    const int xcd = blockIdx.x & 7, j8 = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int q8 = p.n_items >> 3, r8 = p.n_items & 7;
+    const int x_beg = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int x_cnt = q8 + (xcd < r8 ? 1 : 0);
+    const int n_mine = j8 < x_cnt ? (x_cnt - j8 + per_xcd - 1) / per_xcd : 0;
+    if (n_mine == 0) return;
+
+    const int64_t pitch = (int64_t)p.nk * WG_ROWB;     // bytes per row (both operands)
+    // loader geometry: chunk pch = i * 512 + tid -> row pch >> 3, physical slot pch & 7 holding logical chunk slot ^ swz(row)
+    int rowA[NLA], offA[NLA], rowB[NLB], offB[NLB];
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+        const int pch = i * 512 + tid, r = pch >> 3, slot = pch & 7;
+        rowA[i] = r; offA[i] = (slot ^ ((r >> 1) & 7)) << 4;
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+        const int pch = i * 512 + tid, r = pch >> 3, slot = pch & 7;
+        rowB[i] = r; offB[i] = (slot ^ ((r >> 1) & 7)) << 4;
+    }
+    const int wave_chunk = wave * 1024;
+
+    struct Item { int xi, mt, nt; };
+    auto decode = [&](int k) {
+        const int it = x_beg + j8 + k * per_xcd;
+        Item c;
+        c.nt = it % p.n_nt;
+        const int rest = it / p.n_nt;
+        c.mt = rest % p.n_mt;
+        c.xi = rest / p.n_mt;
+        return c;
+    };
+    auto load_part_a = [&](int stage, const Item &c, int kt, int i) {
+        int64_t row = (int64_t)c.mt * WG_TM + rowA[i];
+        if (row > p.T - 1) row = p.T - 1;
+        const char *g = p.V2 + ((int64_t)c.xi * p.T + row) * pitch + (int64_t)kt * WG_ROWB + offA[i];
+        wg_glds16(g, smem + stage * STAGE + i * (512 * 16) + wave_chunk);
+    };
+    auto load_part_b = [&](int stage, const Item &c, int kt, int i) {
+        const int64_t row = (int64_t)c.nt * TN + rowB[i];
+        const char *g = p.U2 + ((int64_t)c.xi * p.Cout + row) * pitch + (int64_t)kt * WG_ROWB + offB[i];
+        wg_glds16(g, smem + stage * STAGE + OPA + i * (512 * 16) + wave_chunk);
+    };
+
+    // fragment read offsets: row * 128 + ((chunk) ^ swz) * 16, chunk = 4 * lo + 2 * s + h for K step s of the stage
+    const int swz = (lane >> 1) & 7;
+    int foff[2][2];                                    // [s][lo]
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int lo = 0; lo < 2; ++lo) foff[s][lo] = ((4 * lo + 2 * s + h) ^ swz) << 4;
+    const int arow0 = (wm * 128 + l31) * WG_ROWB;
+    const int brow0 = (wn * (32 * NT) + l31) * WG_ROWB;
+
+    f32x16 acc[4][NT];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    Item cur_item = decode(0);
+    {
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) load_part_a(0, cur_item, 0, i);
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) load_part_b(0, cur_item, 0, i);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+
+    const int total = n_mine * p.nk;
+    int k_item = 0, kt = 0, cur = 0;
+    for (int it = 0; it < total; ++it) {
+        // the stage after this one: the next K block of this item, or block 0 of the next item
+        int nkt = kt + 1, nk_item = k_item;
+        if (nkt == p.nk) { nkt = 0; nk_item = k_item + 1; }
+        const bool more = it + 1 < total;
+        const Item nxt = (more && nk_item != k_item) ? decode(nk_item) : cur_item;
+        const int lkt = more ? nkt : kt;               // the very last step re-fetches its own stage into the idle buffer
+
+        const char *sA = smem + cur * STAGE;
+        const char *sB = sA + OPA;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 ah[4], al[4], bh[NT], bl[NT];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                ah[m] = *(const f16x8 *)(sA + arow0 + m * 32 * WG_ROWB + foff[s][0]);
+                al[m] = *(const f16x8 *)(sA + arow0 + m * 32 * WG_ROWB + foff[s][1]);
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                bh[n] = *(const f16x8 *)(sB + brow0 + n * 32 * WG_ROWB + foff[s][0]);
+                bl[n] = *(const f16x8 *)(sB + brow0 + n * 32 * WG_ROWB + foff[s][1]);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+            // half of the next stage's LDS-DMA per K step, issued between this step's MFMAs (sim_topk_mfma.hip: a
+            // global_load_lds costs 60-180 issue cycles; back to back after the barrier they idle the matrix pipe)
+            if (DBG != 2) {
+#pragma unroll
+                for (int i = s * (NLA / 2); i < (s + 1) * (NLA / 2); ++i) load_part_a(cur ^ 1, nxt, lkt, i);
+#pragma unroll
+                for (int i = s * (NLB / 2); i < (s + 1) * (NLB / 2); ++i) load_part_b(cur ^ 1, nxt, lkt, i);
+            }
+            constexpr int G = 4 * NT * 3;              // MFMAs per K step (12 or 24)
+            constexpr int L = NLA / 2 + NLB / 2;       // LDS-DMA instructions per K step (3 or 4)
+            __builtin_amdgcn_sched_group_barrier(0x008, G / 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, G / 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, G / 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, L - 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, G / 4, 0);
+        }
+
+        if (kt == p.nk - 1) {
+            // ---- item done: store the 128 x TN/4 wave tile (lane = column, 128-byte runs per row) and clear
+            const int row_base = cur_item.mt * WG_TM + wm * 128 + 4 * h;
+            const int col = cur_item.nt * TN + wn * (32 * NT) + l31;
+            float *mo = p.M + ((int64_t)cur_item.xi * p.T) * p.Cout + col;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_base + m * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        if ((DBG != 1 || p.T < 0) && row < p.T) __builtin_nontemporal_store(acc[m][n][r], mo + (int64_t)row * p.Cout + 32 * n);
+                        acc[m][n][r] = 0.0f;
+                    }
+                }
+        }
+        __builtin_amdgcn_s_waitcnt(0);                 // next stage landed (vmcnt(0)); also drains the stores
+        __syncthreads();
+        cur ^= 1;
+        kt = nkt;
+        if (nk_item != k_item) { k_item = nk_item; cur_item = nxt; }
+    }
+}
+
+// ---- input transform into the pair layout ------------------------------------------------------------------------------
+__device__ __forceinline__ float wg_h_scale(unsigned amax_bits) {       // = wino_h3_scale (winograd.hip)
+    const float a = fminf(fmaxf(__uint_as_float(amax_bits), 1e-30f), 1e30f);
+    int e;
+    (void)frexpf(327.68f / a, &e);
+    return ldexpf(1.0f, e - 1);
+}
+__device__ __forceinline__ void wg_bt4(wf4 &d0, wf4 &d1, wf4 &d2, wf4 &d3, wf4 &d4, wf4 &d5) {   // = wino4_bt4
+    const wf4 r0 = 4.0f * d0 - 5.0f * d2 + d4;
+    const wf4 r1 = -4.0f * (d1 + d2) + d3 + d4;
+    const wf4 r2 = 4.0f * (d1 - d2) - d3 + d4;
+    const wf4 r3 = 2.0f * (d3 - d1) - d2 + d4;
+    const wf4 r4 = 2.0f * (d1 - d3) - d2 + d4;
+    const wf4 r5 = 4.0f * d1 - 5.0f * d3 + d5;
+    d0 = r0; d1 = r1; d2 = r2; d3 = r3; d4 = r4; d5 = r5;
+}
+
+// V = B^T d B of every 6 x 6 input tile of x [B,H,W,C] (NHWC, times the power-of-two scale derived from *amax), split into
+// fp16 pairs and stored as V2 [36][T][C/32][hi 32 | lo 32].  One thread = one tile x 4 consecutive channels: 16-byte
+// loads, two 8-byte stores per frequency (hi and lo of its 4 channels); the 8 lanes of a 32-channel block fill one 64-byte
+// half of a 128-byte line with each store, the other store the other half.
+__global__ __launch_bounds__(256) void wino4_input_h2_kernel(const float *__restrict__ x, int B, int H, int W, int C,
+                                                             const unsigned *__restrict__ amax, __half *__restrict__ V2) {
+    const int c4n = C >> 2;
+    const int64_t bid = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);   // XCD-contiguous tiles
+    const int64_t gid = bid * 256 + threadIdx.x;
+    const int TH = (H + 3) >> 2, TW = (W + 3) >> 2;
+    const int64_t T = (int64_t)B * TH * TW;
+    if (gid >= T * c4n) return;
+    const int c4 = (int)(gid % c4n);
+    const int64_t t = gid / c4n;
+    const int tj = (int)(t % TW);
+    const int ti = (int)((t / TW) % TH);
+    const int b = (int)(t / ((int64_t)TW * TH));
+    const int h0 = 4 * ti - 1, w0 = 4 * tj - 1;
+    const float sc = wg_h_scale(*amax);
+    wf4 d[6][6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int hh = h0 + i;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int ww = w0 + j;
+            const bool in = (hh >= 0) & (hh < H) & (ww >= 0) & (ww < W);
+            const wf4 v = *((const wf4 *)(x + (((int64_t)b * H + (in ? hh : 0)) * W + (in ? ww : 0)) * C) + c4);
+            d[i][j] = in ? v * sc : (wf4)(0.0f);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) wg_bt4(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) wg_bt4(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);
+    const int64_t plane = T * 2 * C;                                  // halfs per frequency
+    const int c = 4 * c4;
+    __half *o = V2 + t * 2 * C + (c >> 5) * 64 + (c & 31);
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const wf4 v = d[i][j];
+            const __half2 h0v = __floats2half2_rn(v.x, v.y), h1v = __floats2half2_rn(v.z, v.w);
+            const float2 f0 = __half22float2(h0v), f1 = __half22float2(h1v);
+            const __half2 l0v = __floats2half2_rn(v.x - f0.x, v.y - f0.y), l1v = __floats2half2_rn(v.z - f1.x, v.w - f1.y);
+            wu2 hi, lo;
+            hi.x = *(const unsigned *)&h0v; hi.y = *(const unsigned *)&h1v;
+            lo.x = *(const unsigned *)&l0v; lo.y = *(const unsigned *)&l1v;
+            __half *q = o + (int64_t)(6 * i + j) * plane;
+            __builtin_nontemporal_store(hi, (wu2 *)q);
+            __builtin_nontemporal_store(lo, (wu2 *)(q + 32));
+        }
+}
+
+CSLAM_API int cslam_wino4_input_h2_dev(const float *d_x, int B, int H, int W, int C, const unsigned *d_amax, void *d_V2,
+                                       void *stream) {
+    PTR_DEVICE(d_x);
+    ARG_CHECK(d_x && d_V2 && d_amax, "NULL argument");
+    ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
+    ARG_CHECK(C >= 32 && (C % 32) == 0, "C must be a multiple of 32");
+    const int64_t n4 = (int64_t)B * ((H + 3) / 4) * ((W + 3) / 4) * (C / 4);
+    ARG_CHECK(ceil_div64(n4, 256) < (1LL << 31), "too many tiles for one launch");
+    hipLaunchKernelGGL(wino4_input_h2_kernel, dim3((unsigned)round_up64(ceil_div64(n4, 256), 8)), dim3(256), 0,
+                       (hipStream_t)stream, d_x, B, H, W, C, d_amax, (__half *)d_V2);
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
+template <int TN>
+static int wino_gemm_launch(const WinoGemmArgs &a, int dbg, hipStream_t st) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        if (n_cu < 8) n_cu = 8;
+    }
+    constexpr int lds = 2 * (WG_TM + TN) * WG_ROWB;
+    int grid = n_cu - n_cu % 8;                                      // one persistent workgroup per CU, 8 | grid
+    if ((int64_t)grid > round_up64(a.n_items, 8)) grid = (int)round_up64(a.n_items, 8);
+    const void *fn = dbg == 1 ? (const void *)wino_gemm_h2_kernel<TN, 1> : dbg == 2 ? (const void *)wino_gemm_h2_kernel<TN, 2>
+                                                                                      : (const void *)wino_gemm_h2_kernel<TN, 0>;
+    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if (dbg == 1) hipLaunchKernelGGL((wino_gemm_h2_kernel<TN, 1>), dim3(grid), dim3(512), lds, st, a);
+    else if (dbg == 2) hipLaunchKernelGGL((wino_gemm_h2_kernel<TN, 2>), dim3(grid), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((wino_gemm_h2_kernel<TN, 0>), dim3(grid), dim3(512), lds, st, a);
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
+CSLAM_API int cslam_wino_gemm_h2_dev(const void *d_V2, const void *d_U2, int64_t T, int Cin, int Cout, float *d_M,
+                                     void *stream) {
+    PTR_DEVICE(d_V2);
+    ARG_CHECK(d_V2 && d_U2 && d_M, "NULL argument");
+    ARG_CHECK(T >= 1 && T < (1LL << 31), "T out of range");
+    ARG_CHECK(Cin >= 32 && (Cin % 32) == 0, "Cin must be a multiple of 32");
+    ARG_CHECK(Cout >= 128 && (Cout % 128) == 0, "Cout must be a multiple of 128");
+    WinoGemmArgs a;
+    a.V2 = (const char *)d_V2; a.U2 = (const char *)d_U2; a.M = d_M;
+    a.T = (int)T; a.Cin = Cin; a.Cout = Cout; a.nk = Cin / 32;
+    a.n_mt = (int)ceil_div64(T, WG_TM);
+    const bool wide = (Cout % 256) == 0;
+    a.n_nt = Cout / (wide ? 256 : 128);
+    const int64_t items = (int64_t)36 * a.n_mt * a.n_nt;
+    ARG_CHECK(items < (1LL << 31), "too many work items");
+    a.n_items = (int)items;
+    static int dbg = -1;
+    if (dbg < 0) { const char *e = getenv("CSLAM_WGEMM_DBG"); dbg = e ? atoi(e) : 0; }
+    return wide ? wino_gemm_launch<256>(a, dbg, (hipStream_t)stream) : wino_gemm_launch<128>(a, dbg, (hipStream_t)stream);
+}

@@ -335,8 +335,10 @@ def test_row_sharded_matcher_single_process(nnm):
     packed = {}
 
     def run(g, sink):
+        # chunks=1: the stand-in gather returns the whole step's descriptors whatever piece it is handed (the chunked,
+        # overlapped form runs over real collectives in tests/test_sharded_cpu.py and tests/test_sharded_gpu.py)
         m = RowShardedBankMatcher(g, 2, lambda q, k: shards[g].search_device(q, k, mode=nnm.MODE_MFMA), offs, k=5,
-                                  gather_fn=lambda local, w: allq, exchange_fn=sink)
+                                  gather_fn=lambda local, w: allq, exchange_fn=sink, chunks=1)
         return m.step(qs[g])
 
     class _Stop(Exception):
