@@ -76,6 +76,8 @@ _SIGNATURES = {
     "cslam_wino2_fused_c64_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "cslam_wino4_fused_c64_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "cslam_scancontext_from_cloud_dev": (_i, [_vp, _vp, _i, _i, _i, C.c_double, _vp, _vp, _vp]),
+    "cslam_wino4_input_h2_dev": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "cslam_wino_gemm_h2_dev": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "cslam_peak_copy_dev": (_i, [_vp, _vp, _i64, _vp]),
     "cslam_peak_mfma_dev": (_i, [_i, _i, _i, _vp, C.POINTER(C.c_double), _vp]),
 }

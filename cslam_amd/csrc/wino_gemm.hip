@@ -101,16 +101,24 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_h2_kernel(WinoGemmArgs p) {
         c.xi = rest / p.n_mt;
         return c;
     };
-    auto load_part_a = [&](int stage, const Item &c, int kt, int i) {
-        int64_t row = (int64_t)c.mt * WG_TM + rowA[i];
-        if (row > p.T - 1) row = p.T - 1;
-        const char *g = p.V2 + ((int64_t)c.xi * p.T + row) * pitch + (int64_t)kt * WG_ROWB + offA[i];
-        wg_glds16(g, smem + stage * STAGE + i * (512 * 16) + wave_chunk);
+    // per-lane source addresses of K block 0 of the item the NEXT stage belongs to (recomputed only at item boundaries)
+    const char *gA[NLA], *gB[NLB];
+    auto point_at = [&](const Item &c) {
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            int64_t row = (int64_t)c.mt * WG_TM + rowA[i];
+            if (row > p.T - 1) row = p.T - 1;
+            gA[i] = p.V2 + ((int64_t)c.xi * p.T + row) * pitch + offA[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NLB; ++i)
+            gB[i] = p.U2 + ((int64_t)c.xi * p.Cout + (int64_t)c.nt * TN + rowB[i]) * pitch + offB[i];
     };
-    auto load_part_b = [&](int stage, const Item &c, int kt, int i) {
-        const int64_t row = (int64_t)c.nt * TN + rowB[i];
-        const char *g = p.U2 + ((int64_t)c.xi * p.Cout + row) * pitch + (int64_t)kt * WG_ROWB + offB[i];
-        wg_glds16(g, smem + stage * STAGE + OPA + i * (512 * 16) + wave_chunk);
+    auto load_part_a = [&](int stage, int kt, int i) {
+        wg_glds16(gA[i] + kt * WG_ROWB, smem + stage * STAGE + i * (512 * 16) + wave_chunk);
+    };
+    auto load_part_b = [&](int stage, int kt, int i) {
+        wg_glds16(gB[i] + kt * WG_ROWB, smem + stage * STAGE + OPA + i * (512 * 16) + wave_chunk);
     };
 
     // fragment read offsets: row * 128 + ((chunk) ^ swz) * 16, chunk = 4 * lo + 2 * s + h for K step s of the stage
@@ -132,11 +140,12 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_h2_kernel(WinoGemmArgs p) {
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
     Item cur_item = decode(0);
+    point_at(cur_item);
     {
 #pragma unroll
-        for (int i = 0; i < NLA; ++i) load_part_a(0, cur_item, 0, i);
+        for (int i = 0; i < NLA; ++i) load_part_a(0, 0, i);
 #pragma unroll
-        for (int i = 0; i < NLB; ++i) load_part_b(0, cur_item, 0, i);
+        for (int i = 0; i < NLB; ++i) load_part_b(0, 0, i);
     }
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
@@ -148,7 +157,8 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_h2_kernel(WinoGemmArgs p) {
         int nkt = kt + 1, nk_item = k_item;
         if (nkt == p.nk) { nkt = 0; nk_item = k_item + 1; }
         const bool more = it + 1 < total;
-        const Item nxt = (more && nk_item != k_item) ? decode(nk_item) : cur_item;
+        Item nxt = cur_item;
+        if (more && nk_item != k_item) { nxt = decode(nk_item); point_at(nxt); }
         const int lkt = more ? nkt : kt;               // the very last step re-fetches its own stage into the idle buffer
 
         const char *sA = smem + cur * STAGE;
@@ -182,9 +192,9 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_h2_kernel(WinoGemmArgs p) {
             // global_load_lds costs 60-180 issue cycles; back to back after the barrier they idle the matrix pipe)
             if (DBG != 2) {
 #pragma unroll
-                for (int i = s * (NLA / 2); i < (s + 1) * (NLA / 2); ++i) load_part_a(cur ^ 1, nxt, lkt, i);
+                for (int i = s * (NLA / 2); i < (s + 1) * (NLA / 2); ++i) load_part_a(cur ^ 1, lkt, i);
 #pragma unroll
-                for (int i = s * (NLB / 2); i < (s + 1) * (NLB / 2); ++i) load_part_b(cur ^ 1, nxt, lkt, i);
+                for (int i = s * (NLB / 2); i < (s + 1) * (NLB / 2); ++i) load_part_b(cur ^ 1, lkt, i);
             }
             constexpr int G = 4 * NT * 3;              // MFMAs per K step (12 or 24)
             constexpr int L = NLA / 2 + NLB / 2;       // LDS-DMA instructions per K step (3 or 4)
@@ -201,18 +211,34 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_h2_kernel(WinoGemmArgs p) {
             // ---- item done: store the 128 x TN/4 wave tile (lane = column, 128-byte runs per row) and clear
             const int row_base = cur_item.mt * WG_TM + wm * 128 + 4 * h;
             const int col = cur_item.nt * TN + wn * (32 * NT) + l31;
-            float *mo = p.M + ((int64_t)cur_item.xi * p.T) * p.Cout + col;
+            float *mo = p.M + ((int64_t)cur_item.xi * p.T + row_base) * p.Cout + col;
+            const bool full = cur_item.mt * WG_TM + wm * 128 + 128 <= p.T;       // wave-uniform: no per-row test
+            const bool st_on = DBG != 1 || p.T < 0;                              // DBG 1: stores compiled, never executed
+            if (full) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            if (st_on) __builtin_nontemporal_store(acc[m][n][r], mo + (int64_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * p.Cout + 32 * n);
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ro = m * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+                        for (int n = 0; n < NT; ++n)
+                            if (st_on && row_base + ro < p.T) __builtin_nontemporal_store(acc[m][n][r], mo + (int64_t)ro * p.Cout + 32 * n);
+                    }
+            }
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row_base + m * 32 + (r & 3) + 8 * (r >> 2);
+                for (int n = 0; n < NT; ++n)
 #pragma unroll
-                    for (int n = 0; n < NT; ++n) {
-                        if ((DBG != 1 || p.T < 0) && row < p.T) __builtin_nontemporal_store(acc[m][n][r], mo + (int64_t)row * p.Cout + 32 * n);
-                        acc[m][n][r] = 0.0f;
-                    }
-                }
+                    for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
         }
         __builtin_amdgcn_s_waitcnt(0);                 // next stage landed (vmcnt(0)); also drains the stores
         __syncthreads();

@@ -48,6 +48,23 @@ def split16_weights(U4):
     return torch.cat((uh, uh, ul), dim=1).contiguous(), 1.0 / su
 
 
+def split16_pair_weights(U4):
+    """U4 [36, Cin, Cout] float32 -> (U2 [36, Cout, Cin/32, 2, 32] float16, inv_su): the weight operand of this library's
+    split-fp16 GEMM (csrc/wino_gemm.hip): rows are OUTPUT channels, every 32-channel block of a row holds its hi halves
+    then its lo halves; sU U = uh + ul exactly to 22 bits, sU the power of two that brings max |U| into [2^14, 2^15)."""
+    n, cin, cout = U4.shape
+    assert cin % 32 == 0
+    u = U4.detach().to(torch.float64)
+    amax = float(u.abs().max())
+    su = 2.0 ** (14 - math.floor(math.log2(amax))) if amax > 0 else 1.0
+    us = (u * su).to(torch.float32)                                  # exact: a power-of-two scale of float32 values
+    uh = us.to(torch.float16)
+    ul = (us - uh.to(torch.float32)).to(torch.float16)
+    pair = torch.stack((uh, ul), dim=0)                              # [2, 36, Cin, Cout]
+    pair = pair.view(2, n, cin // 32, 32, cout).permute(1, 4, 2, 0, 3)   # [36, Cout, Cin/32, 2, 32]
+    return pair.contiguous(), 1.0 / su
+
+
 def fused64_weights(U):
     """U [16 | 36, 64, Cout] (`wino_weights(w, 2 | 4)`; Cout 64 or 128) -> the operand order of
     `cslam_wino2_fused_c64_dev` / `cslam_wino4_fused_c64_dev`: Up[kq][xi][w][g][c][s] = U[xi][16 kq + 4 g + s][16 w + c]
@@ -98,12 +115,15 @@ def use_tuned_gemms():
         warnings.warn("cslam_amd: tuned GEMM table not loaded (%s)" % e)
 
 
-def wino_conv3x3(ws, x, U, U4, bias, relu, pool=False, residual=None, U3=None, amax_in=None, amax_out=None):
+def wino_conv3x3(ws, x, U, U4, bias, relu, pool=False, residual=None, U3=None, amax_in=None, amax_out=None, U2=None):
     """3x3 / stride 1 / pad 1 convolution of x [B,Cin,H,W] (channels_last storage, any H and W) through the
     Winograd pipeline; U / U4 from `wino_weights` (U4 None = F(2x2,3x3) only).  bias [Cout] or None, residual
     (channels_last, shaped like the output) is added before the ReLU.  `ws` owns the V / M workspaces.
-    U3 = `split16_weights(U4)`: the F(4x4) GEMMs run as one fp16 GEMM with fp32 accumulation over the exact hi / lo
-    split of both operands (three of the four partial products: fp32-grade, at the fp16 MFMA rate).
+    U2 = `split16_pair_weights(U4)` (the default for wide layers): the 36 F(4x4) products run in this library's GEMM
+    (csrc/wino_gemm.hip) over the exact fp16 hi / lo pairs of both operands, three of the four partial products in fp32
+    accumulators: fp32-grade, at the fp16 MFMA rate, V and M at their fp32 sizes.
+    U3 = `split16_weights(U4)` (round 1's form, CSLAM_WINO_H3=1): the same arithmetic as ONE library fp16 GEMM over
+    K' = 3 Cin, operands [vh | vl | vh] x [uh ; uh ; ul].
     amax_in: 4-byte device slot already holding the bits of (a bound of) max |x| -- saves the pass over x; amax_out: zeroed
     slot that receives the same for y from the F(4x4) output transform.  Returns y; `ws.amax_written` says whether amax_out
     was filled (only the F(4x4) output kernel does it)."""
@@ -116,6 +136,28 @@ def wino_conv3x3(ws, x, U, U4, bias, relu, pool=False, residual=None, U3=None, a
     four = U4 is not None and B * t4h * t4w >= 512 and 16 * t4h * t4w <= 1.35 * H * W
     n2, Uu = (36, U4) if four else (16, U)
     T = B * t4h * t4w if four else B * t2h * t2w
+    if four and U2 is not None:
+        # this library's GEMM on exact fp16 pairs (csrc/wino_gemm.hip): V stored once at its fp32 size, M in fp32
+        s = _stream(x)
+        slot = amax_in
+        if slot is None:
+            slot = ws._buf("amax", 1, x.device)
+            _lib.check(lib.cslam_absmax_dev(_p(x), x.numel(), _p(slot), s))
+        V2 = ws._buf("V", 36 * T * Cin, x.device)                      # 36 x T x 2 Cin halfs
+        M = ws._buf("M", 36 * T * Cout, x.device)
+        _lib.check(lib.cslam_wino4_input_h2_dev(_p(x), B, H, W, Cin, _p(slot), _p(V2), s))
+        _lib.check(lib.cslam_wino_gemm_h2_dev(_p(V2), _p(U2[0]), T, Cin, Cout, _p(M), s))
+        Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+        y = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        if residual is not None:
+            residual = residual.contiguous(memory_format=torch.channels_last)
+            assert residual.shape == y.shape and not pool
+        _lib.check(lib.cslam_wino4_output_scaled_dev(
+            _p(M), _p(bias) if bias is not None else None, _p(residual) if residual is not None else None,
+            B, H, W, Cout, int(relu), int(pool), _p(slot), float(U2[1]), _p(amax_out) if amax_out is not None else None,
+            _p(y), s))
+        ws.amax_written = amax_out is not None
+        return y
     if four and U3 is not None:
         s = _stream(x)
         slot = amax_in
@@ -260,11 +302,11 @@ class WinogradResNet(_Workspace):
 
 
 class _Step(object):
-    __slots__ = ("kind", "module", "conv", "relu", "pool", "U", "U4", "U3", "Up", "bias")
+    __slots__ = ("kind", "module", "conv", "relu", "pool", "U", "U4", "U3", "U2", "Up", "bias")
 
     def __init__(self):
         self.kind, self.module, self.conv, self.relu, self.pool = "torch", None, None, False, False
-        self.U, self.U4, self.U3, self.Up, self.bias = None, None, None, None, None
+        self.U, self.U4, self.U3, self.U2, self.Up, self.bias = None, None, None, None, None, None
 
 
 class WinogradTrunk(_Workspace):
@@ -282,10 +324,12 @@ class WinogradTrunk(_Workspace):
         self.fused64 = (os.environ.get("CSLAM_WINO_FUSED64", "1") != "0") if fused64 is None else bool(fused64)
         self.fused_min_blocks = int(os.environ.get("CSLAM_WINO_FUSED_MIN_BLOCKS", "256"))
         self.fused_couts = tuple(int(c) for c in os.environ.get("CSLAM_WINO_FUSED_COUTS", "64,128").split(","))
-        # split-fp16 GEMMs on the F(4x4) layers from this many input channels on (0 = off: plain fp32 GEMMs); see
-        # `split16_weights`.  256 is the measured optimum on VGG-16 (profiles/r01_exp_split16.log): below it the 1.5x larger
-        # V costs more than the GEMM gains
-        self.split16_min_cin = int(os.environ.get("CSLAM_WINO_SPLIT16", "256"))
+        # split-fp16 GEMMs on the F(4x4) layers from this many input channels on (0 = off: plain fp32 library GEMMs).
+        # Default: this library's pair GEMM (`split16_pair_weights`, csrc/wino_gemm.hip) from 128 channels on -- V is no
+        # larger than its fp32 form, so every layer the three-kernel form runs gains.  CSLAM_WINO_H3=1 selects round 1's
+        # library GEMM over [vh | vl | vh] instead, whose measured optimum was 256 (profiles/r01_exp_split16.log).
+        self.split16_h3 = os.environ.get("CSLAM_WINO_H3", "0") == "1"
+        self.split16_min_cin = int(os.environ.get("CSLAM_WINO_SPLIT16", "256" if self.split16_h3 else "128"))
         use_tuned_gemms()
         self.refresh()
 
@@ -305,7 +349,10 @@ class WinogradTrunk(_Workspace):
                 st.U = wino_weights(m.weight).to(m.weight.device)
                 st.U4 = wino_weights(m.weight, 4).to(m.weight.device) if self.tile == 4 else None
                 if st.U4 is not None and 0 < self.split16_min_cin <= m.in_channels:
-                    st.U3 = split16_weights(st.U4)
+                    if not self.split16_h3 and m.in_channels % 32 == 0 and m.out_channels % 128 == 0:
+                        st.U2 = split16_pair_weights(st.U4)
+                    else:
+                        st.U3 = split16_weights(st.U4)
                 if self.fused64 and m.in_channels == 64 and m.out_channels in self.fused_couts:
                     # F(4x4) one-kernel form on the F(4x4) trunk (CSLAM_WINO_FUSED_TILE=2 keeps the F(2x2) one)
                     t4 = self.tile == 4 and os.environ.get("CSLAM_WINO_FUSED_TILE", "4") == "4"
@@ -355,7 +402,7 @@ class WinogradTrunk(_Workspace):
         lib = _lib.load()
         # one 4-byte slot per step for max |activation| between consecutive split-fp16 layers
         slots = amax_ready = None
-        if any(st.U3 is not None for st in self.steps):
+        if any(st.U3 is not None or st.U2 is not None for st in self.steps):
             slots = self._buf("amax_slots", len(self.steps) + 1, x.device)
             slots.zero_()
         for k, st in enumerate(self.steps):
@@ -394,8 +441,8 @@ class WinogradTrunk(_Workspace):
                     x = wino_fused64(x, st.Up, st.bias, st.relu, st.pool)
                     continue
             nxt = self.steps[k + 1] if k + 1 < len(self.steps) else None
-            want = slots[k + 1:k + 2] if (nxt is not None and nxt.U3 is not None) else None
-            y = wino_conv3x3(self, x, st.U, st.U4, st.bias, st.relu, st.pool, U3=st.U3,
+            want = slots[k + 1:k + 2] if (nxt is not None and (nxt.U3 is not None or nxt.U2 is not None)) else None
+            y = wino_conv3x3(self, x, st.U, st.U4, st.bias, st.relu, st.pool, U3=st.U3, U2=st.U2,
                              amax_in=slots[k:k + 1] if have else None, amax_out=want)
             amax_ready = want is not None and self.amax_written
             x = y

@@ -294,6 +294,21 @@ int cslam_wino2_fused_c64_dev(const float *d_x, const float *d_Up, const float *
 int cslam_wino4_fused_c64_dev(const float *d_x, const float *d_Up, const float *d_bias, const float *d_residual, int B,
                               int H, int W, int Cout, int relu, int pool, float *d_y, void *stream);
 
+/* ---- split-fp16 Winograd GEMM of this library (csrc/wino_gemm.hip) ------------------------------------------------
+ * The 36 per-frequency products M[xi] = V[xi] U[xi] of the F(4x4,3x3) form of the trunk's wide 3x3 convolutions
+ * (the Conv2d layers of cslam/vpr/netvlad.py:163-171 / cosplace_utils/network.py:38-68) on the fp16 matrix pipe with
+ * fp32-grade results: both operands are exact fp16 pairs hi + lo of the (power-of-two scaled) float32 values and
+ * vh uh + vl uh + vh ul is accumulated in fp32.  Operand layout, both sides: row r = Cin/32 blocks of 128 bytes,
+ * block kb = [hi of channels 32 kb .. 32 kb + 31 | lo of the same] as fp16; V2 [36][T][Cin/32][64] (rows = tiles),
+ * U2 [36][Cout][Cin/32][64] (rows = OUTPUT channels, i.e. U transposed).
+ * cslam_wino4_input_h2_dev: x [B,H,W,C] NHWC float32 -> V2 (scaled by the power of two derived from *d_amax, the bits
+ *   of a bound of max |x|, as cslam_wino4_input_h3_dev); C a multiple of 32.
+ * cslam_wino_gemm_h2_dev: M [36][T][Cout] float32 = (sV V)(sU U); Cin a multiple of 32, Cout of 128.  The result carries
+ *   the two scales; cslam_wino4_output_scaled_dev removes them. */
+int cslam_wino4_input_h2_dev(const float *d_x, int B, int H, int W, int C, const unsigned *d_amax, void *d_V2,
+                             void *stream);
+int cslam_wino_gemm_h2_dev(const void *d_V2, const void *d_U2, int64_t T, int Cin, int Cout, float *d_M, void *stream);
+
 /* ---- diagnostics: in-run re-measurement of the peaks rooflines are priced against (csrc/peaks.hip) ---------------
  * Not on the extract / match path and without a reference counterpart: bench.py reports every roofline fraction against
  * the nominal MI355X peaks and against what these two kernels sustain on the box in the same run.

@@ -487,16 +487,24 @@ def test_fused_winograd_f4_equals_float64(T, cout, B, H, W, relu, pool, bias):
     assert ef <= 2e-5, ef
 
 
+def _rel_rms(y, ref):
+    """||y - ref||_2 / ||ref||_2 in float64: unlike the max-norm bar it does not let small activations hide."""
+    return float(((y.double() - ref) ** 2).sum().sqrt() / (ref ** 2).sum().sqrt())
+
+
 @pytest.mark.gpu
+@pytest.mark.parametrize("form", ["pair", "h3"])
 @pytest.mark.parametrize("B,H,W,cin,cout,relu,pool,amp", [
     (8, 56, 56, 128, 256, True, False, 1.0), (8, 56, 56, 128, 256, True, True, 1e3), (32, 14, 14, 512, 512, True, False, 1e-3),
     (16, 28, 28, 256, 512, False, False, 1.0), (40, 13, 15, 256, 256, True, False, 1.0),
     (57, 12, 12, 256, 384, True, False, 1.0)])     # 513 tiles x 192 channel pairs: the last workgroup of the output transform is part empty
-def test_split16_winograd_layer_is_fp32_grade(T, B, H, W, cin, cout, relu, pool, amp):
-    """Split-fp16 form of the 36 GEMMs (csrc/winograd.hip `wino4_input_h3_kernel`, vpr/winograd.py `split16_weights`):
-    against a float64 convolution its error is that of the plain-fp32 three-kernel form (within 1.5x, and inside the
-    F(4x4) tolerance of 2e-5 of the largest activation), at activation magnitudes six decades apart (the power-of-two
-    scale), with the ragged last tile row / column, and the max |y| slot written by the output transform is a bound."""
+def test_split16_winograd_layer_is_fp32_grade(T, form, B, H, W, cin, cout, relu, pool, amp):
+    """Split-fp16 forms of the 36 GEMMs -- "pair": this library's GEMM over exact hi/lo pairs (csrc/wino_gemm.hip,
+    `split16_pair_weights`, the default); "h3": round 1's library GEMM over [vh | vl | vh] (`split16_weights`) --
+    against a float64 convolution: the error is that of the plain-fp32 three-kernel form (within 1.5x, in the max norm
+    AND in the relative 2-norm over all activations, and inside the F(4x4) tolerance of 2e-5 of the largest activation /
+    5e-6 relative 2-norm), at activation magnitudes six decades apart (the power-of-two scale), with the ragged last
+    tile row / column, and the max |y| slot written by the output transform is a bound."""
     torch, _ = T
     from cslam_amd.vpr import winograd as wg
     torch.manual_seed(31)
@@ -509,18 +517,24 @@ def test_split16_winograd_layer_is_fp32_grade(T, B, H, W, cin, cout, relu, pool,
     ref = torch.nn.functional.max_pool2d(ref, 2, 2) if pool else ref
     ws = wg._Workspace()
     U, U4 = wg.wino_weights(w).cuda(), wg.wino_weights(w, 4).cuda()
-    U3 = wg.split16_weights(U4)
-    rec = (U3[0][:, :cin].double() + U3[0][:, 2 * cin:].double()) * U3[1]
-    assert (rec - U4.double()).abs().max().item() <= 2.0 ** -21 * U4.abs().max().item()
-    assert torch.equal(U3[0][:, :cin], U3[0][:, cin:2 * cin])
+    if form == "h3":
+        U3 = wg.split16_weights(U4)
+        rec = (U3[0][:, :cin].double() + U3[0][:, 2 * cin:].double()) * U3[1]
+        assert (rec - U4.double()).abs().max().item() <= 2.0 ** -21 * U4.abs().max().item()
+        assert torch.equal(U3[0][:, :cin], U3[0][:, cin:2 * cin])
+        kw = {"U3": U3}
+    else:
+        kw = {"U2": wg.split16_pair_weights(U4)}
     slot = torch.zeros(1, dtype=torch.float32, device="cuda")
     y32 = wg.wino_conv3x3(ws, x, U, U4, b, relu, pool)
-    y16 = wg.wino_conv3x3(ws, x, U, U4, b, relu, pool, U3=U3, amax_out=slot)
+    y16 = wg.wino_conv3x3(ws, x, U, U4, b, relu, pool, amax_out=slot, **kw)
     assert ws.amax_written
     s = ref.abs().max().item()
     e32 = (y32.double() - ref).abs().max().item() / s
     e16 = (y16.double() - ref).abs().max().item() / s
     assert e16 <= 2e-5 and e16 <= 1.5 * e32 + 1e-7, (e16, e32)
+    r32, r16 = _rel_rms(y32, ref), _rel_rms(y16, ref)
+    assert r16 <= 5e-6 and r16 <= 1.5 * r32 + 1e-8, (r16, r32)
     bound = slot.item()
     assert prepool.abs().max().item() * (1 - 1e-4) <= bound <= prepool.abs().max().item() * (1 + 1e-4)
     # the slot as the next call's amax_in gives the same result as the separate pass over x (same scale either way
@@ -529,44 +543,52 @@ def test_split16_winograd_layer_is_fp32_grade(T, B, H, W, cin, cout, relu, pool,
         xs = y16
         w2 = torch.randn(cout, cout, 3, 3, device="cuda") / (3 * cout ** 0.5)
         V2, V4 = wg.wino_weights(w2).cuda(), wg.wino_weights(w2, 4).cuda()
-        V3 = wg.split16_weights(V4)
-        ya = wg.wino_conv3x3(ws, xs, V2, V4, None, True, False, U3=V3)
-        yb = wg.wino_conv3x3(ws, xs, V2, V4, None, True, False, U3=V3, amax_in=slot)
+        kw2 = {"U3": wg.split16_weights(V4)} if form == "h3" else {"U2": wg.split16_pair_weights(V4)}
+        ya = wg.wino_conv3x3(ws, xs, V2, V4, None, True, False, **kw2)
+        yb = wg.wino_conv3x3(ws, xs, V2, V4, None, True, False, amax_in=slot, **kw2)
         r2 = torch.relu(torch.nn.functional.conv2d(xs.double(), w2.double(), None, padding=1))
         s2 = r2.abs().max().item()
         assert (ya.double() - r2).abs().max().item() <= 2e-5 * s2
         assert (yb.double() - r2).abs().max().item() <= 2e-5 * s2
+        assert _rel_rms(ya, r2) <= 5e-6 and _rel_rms(yb, r2) <= 5e-6
 
 
 @pytest.mark.gpu
 def test_split16_trunk_equals_fp32_gemm_trunk(T):
-    """VGG-16 trunk with the split-fp16 GEMMs (default from 256 input channels) against the same trunk on plain fp32
-    GEMMs (CSLAM_WINO_SPLIT16=0) and against a float64 evaluation: the split form is not the less accurate of the two by
-    more than 1.5x, and both sit inside the trunk tolerance used for the fp32 form."""
+    """VGG-16 trunk with the split-fp16 GEMMs -- the default pair form from 128 input channels on (conv2_2 ... conv5_3,
+    this library's GEMM) and round 1's h3 form from 256 on (CSLAM_WINO_H3=1) -- against the same trunk on plain fp32
+    GEMMs (CSLAM_WINO_SPLIT16=0) and against a float64 evaluation: neither split form is less accurate than the fp32 one
+    by more than 1.5x (max norm and relative 2-norm), and all sit inside the trunk tolerance used for the fp32 form."""
     torch, _ = T
     from cslam_amd.vpr.backbones import vgg16_features_trunk
     from cslam_amd.vpr.winograd import WinogradTrunk
     torch.manual_seed(37)
     enc = vgg16_features_trunk().cuda().eval()
     x = torch.randn((32, 3, 224, 224), device="cuda")     # 32 frames: conv5_x (4 x 4 tiles per frame) reaches the 512-tile F(4x4) floor
-    old = os.environ.get("CSLAM_WINO_SPLIT16")
+    old = {k: os.environ.get(k) for k in ("CSLAM_WINO_SPLIT16", "CSLAM_WINO_H3")}
     try:
+        os.environ.pop("CSLAM_WINO_H3", None)
         os.environ["CSLAM_WINO_SPLIT16"] = "0"
         t32 = WinogradTrunk(enc, 64, 4)
-        os.environ["CSLAM_WINO_SPLIT16"] = "256"
-        t16 = WinogradTrunk(enc, 64, 4)
+        os.environ.pop("CSLAM_WINO_SPLIT16", None)
+        t2 = WinogradTrunk(enc, 64, 4)
+        os.environ["CSLAM_WINO_H3"] = "1"
+        t3 = WinogradTrunk(enc, 64, 4)
     finally:
-        if old is None:
-            os.environ.pop("CSLAM_WINO_SPLIT16", None)
-        else:
-            os.environ["CSLAM_WINO_SPLIT16"] = old
-    assert all(st.U3 is None for st in t32.steps)
-    assert sum(st.U3 is not None for st in t16.steps) == 8          # conv3_2 ... conv5_3
-    y32, y16 = t32(x), t16(x)
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    assert all(st.U3 is None and st.U2 is None for st in t32.steps)
+    assert sum(st.U2 is not None for st in t2.steps) == 10 and all(st.U3 is None for st in t2.steps)    # conv2_2 ... conv5_3
+    assert sum(st.U3 is not None for st in t3.steps) == 8 and all(st.U2 is None for st in t3.steps)     # conv3_2 ... conv5_3
+    y32, y2, y3 = t32(x), t2(x), t3(x)
     with torch.no_grad():
         ref = enc.double()(x.double())
     enc.float()
     s = ref.abs().max().item()
-    e32 = (y32.double() - ref).abs().max().item() / s
-    e16 = (y16.double() - ref).abs().max().item() / s
-    assert e32 <= 2e-5 and e16 <= 2e-5 and e16 <= 1.5 * e32 + 1e-7, (e16, e32)
+    e32, e2, e3 = ((y.double() - ref).abs().max().item() / s for y in (y32, y2, y3))
+    assert e32 <= 2e-5 and e2 <= 2e-5 and e3 <= 2e-5 and max(e2, e3) <= 1.5 * e32 + 1e-7, (e2, e3, e32)
+    r32, r2, r3 = _rel_rms(y32, ref), _rel_rms(y2, ref), _rel_rms(y3, ref)
+    assert r32 <= 1e-5 and max(r2, r3) <= 1.5 * r32 + 1e-8, (r2, r3, r32)

@@ -19,6 +19,14 @@ torch.backends.cudnn.benchmark = True
 nv = NetVLAD({"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376, "frontend.netvlad.pca_dim": 4096,
               "frontend.backbone_conv": a.backbone_conv}, None)
 fr = torch.randint(0, 256, (a.batch, 480, 640, 3), device="cuda", dtype=torch.uint8)
-for _ in range(2 + a.iters):
+import time
+for _ in range(2):
     nv.compute_embeddings_device(fr)
 torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(a.iters):
+    nv.compute_embeddings_device(fr)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / a.iters
+print("extract leg: %.2f ms per %d frames = %.0f frames/s  (CSLAM_WINO_H3=%s CSLAM_WINO_SPLIT16=%s)"
+      % (dt * 1e3, a.batch, a.batch / dt, os.environ.get("CSLAM_WINO_H3", "0"), os.environ.get("CSLAM_WINO_SPLIT16", "default")))
