@@ -38,6 +38,7 @@ _SIGNATURES = {
     "cslam_bank_device_ptr": (_i, [_vp, C.POINTER(_vp), C.POINTER(_i64)]),
     "cslam_bank_search_host": (_i, [_vp, _vp, _i, _i64, _i, _vp, _i, _vp, _vp, _vp]),
     "cslam_bank_search_dev": (_i, [_vp, _vp, _i, _i64, _i64, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "cslam_bank_search_multi_dev": (_i, [_vp, _i, _vp, _i, _i64, _i64, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "cslam_bank_last_stats": (_i, [_vp, C.POINTER(_i64 * 4)]),
     "cslam_bank_last_kernel_ms": (_i, [_vp, C.POINTER(_f)]),
     "cslam_topk_merge_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp]),
@@ -78,7 +79,7 @@ _SIGNATURES = {
     "cslam_scancontext_from_cloud_dev": (_i, [_vp, _vp, _i, _i, _i, C.c_double, _vp, _vp, _vp]),
     "cslam_wino4_input_h2_dev": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "cslam_wino_gemm_h2_dev": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
-    "cslam_peak_copy_dev": (_i, [_vp, _vp, _i64, _vp]),
+    "cslam_peak_copy_dev": (_i, [_vp, _vp, _i64, _i, _vp]),
     "cslam_peak_mfma_dev": (_i, [_i, _i, _i, _vp, C.POINTER(C.c_double), _vp]),
 }
 

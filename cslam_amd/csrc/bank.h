@@ -25,6 +25,9 @@ struct cslam_bank {
     int num_cu;
     std::vector<int> item_map_host;   // cached work-item order of the MFMA path (see sim_topk_mfma.hip)
     int item_map_key[4];
+    int *h_nflag;                     // pinned: count of uncertified queries of the last enqueued MFMA search
+    int *pending_flag_list;           // device list those queries are in (bank workspace)
+    int pending_dbg;
 };
 
 int bank_ws_reserve(cslam_bank *b, int slot, size_t bytes);
@@ -36,7 +39,13 @@ int scan_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, const 
                 int64_t nsel, int k, const int64_t *d_row_limit, int64_t *d_out_idx,
                 double *d_out_sim, int32_t *d_out_cnt, hipStream_t st);
 
-// fp32-MFMA candidate search + fp64 rescoring (sim_topk_mfma.hip)
+// fp32-MFMA candidate search + fp64 rescoring (sim_topk_mfma.hip).  mfma_search = enqueue + stream synchronisation +
+// finish; a group of searches on different banks can enqueue all of them and synchronise once (cslam_bank_search_multi_dev)
+int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_t nq, int k,
+                        const int64_t *d_row_limit, int64_t *d_out_idx, double *d_out_sim,
+                        int32_t *d_out_cnt, hipStream_t st);
+int mfma_search_finish(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int k, const int64_t *d_row_limit,
+                       int64_t *d_out_idx, double *d_out_sim, int32_t *d_out_cnt, hipStream_t st);
 int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_t nq, int k,
                 const int64_t *d_row_limit, int64_t *d_out_idx, double *d_out_sim,
                 int32_t *d_out_cnt, hipStream_t st);

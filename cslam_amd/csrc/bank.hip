@@ -89,6 +89,7 @@ CSLAM_API int cslam_bank_create(int device, int dim, int64_t capacity_hint, csla
     b->rows = nullptr; b->vv = nullptr; b->invn = nullptr;
     for (int s = 0; s < 3; ++s) { b->ws[s] = nullptr; b->ws_bytes[s] = 0; }
     b->stage = nullptr; b->stage_bytes = 0; b->last_stream = nullptr; b->ev_valid = false;
+    b->h_nflag = nullptr; b->pending_flag_list = nullptr; b->pending_dbg = 0;
     for (int s = 0; s < 4; ++s) { b->stats[s] = 0; b->item_map_key[s] = -1; }
     b->num_cu = 0;
     b->device = device; b->dim = dim; b->kd = (int)round_up64(dim, 32);
@@ -115,6 +116,7 @@ CSLAM_API int cslam_bank_destroy(cslam_bank_t *b) {
     if (b->invn) (void)hipFree(b->invn);
     for (int s = 0; s < 3; ++s) if (b->ws[s]) (void)hipFree(b->ws[s]);
     if (b->stage) (void)hipFree(b->stage);
+    if (b->h_nflag) (void)hipHostFree(b->h_nflag);
     if (b->ev_valid) { (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1); }
     delete b;
     return CSLAM_OK;
@@ -691,6 +693,52 @@ CSLAM_API int cslam_bank_search_dev(cslam_bank_t *b, const void *d_queries, int 
         return scan_search(b, d_queries, q_dtype, ldq, nullptr, nq, k, d_row_limit, d_out_idx, d_out_sim,
                            d_out_cnt, st);
     return mfma_search(b, d_queries, q_dtype, ldq, nq, k, d_row_limit, d_out_idx, d_out_sim, d_out_cnt, st);
+}
+
+// One batch of queries against SEVERAL banks of one device (a robot's local bank and its copies of the other robots'
+// banks: lcsm.py:21-31, searched one after the other by lcsm.py:45-53 / gdlcd.py:157-160): every bank's kernels are
+// enqueued first, ONE stream synchronisation serves all the uncertified-query counts, then the (rare) exact-scan
+// fallbacks run.  Results are those of nb separate cslam_bank_search_dev calls.
+CSLAM_API int cslam_bank_search_multi_dev(cslam_bank_t *const *banks, int nb, const void *d_queries, int q_dtype,
+                                          int64_t ldq, int64_t nq, const int *k, const int64_t *const *d_row_limit,
+                                          int mode, int64_t *const *d_out_idx, double *const *d_out_sim,
+                                          int32_t *const *d_out_cnt, void *stream) {
+    ARG_CHECK(banks && nb >= 1 && nb <= 64 && k && d_out_idx && d_out_sim && d_out_cnt, "bad bank list");
+    ARG_CHECK((d_queries || nq == 0) && nq >= 0, "NULL queries");
+    ARG_CHECK(q_dtype == CSLAM_F32 || q_dtype == CSLAM_F64, "q_dtype must be CSLAM_F32 or CSLAM_F64");
+    for (int i = 0; i < nb; ++i) {
+        ARG_CHECK(banks[i] && d_out_idx[i] && d_out_sim[i] && d_out_cnt[i] && k[i] >= 1, "NULL bank / output or k < 1");
+        ARG_CHECK(banks[i]->device == banks[0]->device && banks[i]->dim == banks[0]->dim, "banks must share device and dimension");
+        ARG_CHECK(ldq >= banks[i]->dim, "ldq smaller than the descriptor dimension");
+    }
+    if (nq == 0) return CSLAM_OK;
+    BANK_DEVICE(banks[0]);
+    hipStream_t st = (hipStream_t)stream;
+    bool deferred[64];
+    for (int i = 0; i < nb; ++i) {
+        cslam_bank *b = banks[i];
+        const int64_t *lim = d_row_limit ? d_row_limit[i] : nullptr;
+        b->last_stream = st;
+        b->stats[0] = 0; b->stats[2] = 0; b->stats[3] = 0;
+        int use = mode;
+        if (use == CSLAM_MODE_AUTO) use = (nq <= 8 || k[i] > 16 || b->n < 256) ? CSLAM_MODE_SCAN : CSLAM_MODE_MFMA;
+        if (use == CSLAM_MODE_MFMA && (k[i] > 16 || b->n < 1)) use = CSLAM_MODE_SCAN;
+        b->stats[1] = use;
+        deferred[i] = use == CSLAM_MODE_MFMA;
+        int rc = deferred[i] ? mfma_search_enqueue(b, d_queries, q_dtype, ldq, nq, k[i], lim, d_out_idx[i], d_out_sim[i], d_out_cnt[i], st)
+                             : scan_search(b, d_queries, q_dtype, ldq, nullptr, nq, k[i], lim, d_out_idx[i], d_out_sim[i], d_out_cnt[i], st);
+        if (rc) return rc;
+    }
+    bool any = false;
+    for (int i = 0; i < nb; ++i) any |= deferred[i];
+    if (any) HIP_TRY(hipStreamSynchronize(st));
+    for (int i = 0; i < nb; ++i) {
+        if (!deferred[i]) continue;
+        int rc = mfma_search_finish(banks[i], d_queries, q_dtype, ldq, k[i], d_row_limit ? d_row_limit[i] : nullptr,
+                                    d_out_idx[i], d_out_sim[i], d_out_cnt[i], st);
+        if (rc) return rc;
+    }
+    return CSLAM_OK;
 }
 
 CSLAM_API int cslam_bank_search_host(cslam_bank_t *b, const void *queries, int q_dtype, int64_t nq,

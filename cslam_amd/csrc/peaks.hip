@@ -3,7 +3,8 @@
 // bench.py prints every roofline fraction against the nominal MI355X figures of
 // /opt/skills/guides/MI355X_MICROARCH.md (HBM 8 TB/s, f32-input MFMA 157.3 TFLOP/s, fp16 MFMA 2.5 PFLOP/s) AND against
 // what this very box sustains, measured in the same run with the two kernels below:
-//   peak_copy_kernel  16-byte-per-lane streaming copy, grid-stride, non-temporal: achievable HBM bandwidth
+//   peak_copy_*       16-byte-per-lane streaming copies (one element per thread; grid-stride, plain or non-temporal; the
+//                     caller keeps the best): achievable HBM bandwidth
 //   peak_mfma_kernel  register-resident MFMA loop, 4 independent accumulators per wave, 2 waves per SIMD:
 //                     achievable matrix rate for f32 inputs (v_mfma_f32_32x32x2_f32) and fp16 inputs
 //                     (v_mfma_f32_32x32x16_f16), operands non-zero (zero operands clock higher: guide rule 25)
@@ -14,31 +15,55 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+// NT: non-temporal loads / stores.  Four independent 16-byte loads in flight per lane, grid-stride.
+template <bool NT>
 __global__ __launch_bounds__(256) void peak_copy_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst,
                                                         int64_t n16) {
     const int64_t stride = (int64_t)gridDim.x * 256;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {          // 4 independent 16-byte loads in flight per lane
-        f32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
-        f32x4 c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
-        __builtin_nontemporal_store(a, dst + i);
-        __builtin_nontemporal_store(b, dst + i + stride);
-        __builtin_nontemporal_store(c, dst + i + 2 * stride);
-        __builtin_nontemporal_store(d, dst + i + 3 * stride);
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        f32x4 a, b, c, d;
+        if (NT) {
+            a = __builtin_nontemporal_load(src + i); b = __builtin_nontemporal_load(src + i + stride);
+            c = __builtin_nontemporal_load(src + i + 2 * stride); d = __builtin_nontemporal_load(src + i + 3 * stride);
+            __builtin_nontemporal_store(a, dst + i);
+            __builtin_nontemporal_store(b, dst + i + stride);
+            __builtin_nontemporal_store(c, dst + i + 2 * stride);
+            __builtin_nontemporal_store(d, dst + i + 3 * stride);
+        } else {
+            a = src[i]; b = src[i + stride]; c = src[i + 2 * stride]; d = src[i + 3 * stride];
+            dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+        }
     }
-    for (; i < n16; i += stride) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+    for (; i < n16; i += stride) dst[i] = src[i];
 }
 
-CSLAM_API int cslam_peak_copy_dev(const void *d_src, void *d_dst, int64_t bytes, void *stream) {
+// one 16-byte element per thread, as many workgroups as it takes (the plain "float4 copy" of the MI355X guide)
+__global__ __launch_bounds__(256) void peak_copy_flat_kernel(const f32x4 *__restrict__ src, f32x4 *__restrict__ dst,
+                                                             int64_t n16) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+}
+
+// variant 0: one element per thread; 1 / 2: grid-stride with 16 workgroups per compute unit, plain / non-temporal
+CSLAM_API int cslam_peak_copy_dev(const void *d_src, void *d_dst, int64_t bytes, int variant, void *stream) {
     PTR_DEVICE(d_src);
     ARG_CHECK(d_src && d_dst && bytes >= 0 && bytes % 16 == 0, "NULL pointer or size not a multiple of 16");
     ARG_CHECK((((uintptr_t)d_src | (uintptr_t)d_dst) & 15) == 0, "pointers must be 16-byte aligned");
+    ARG_CHECK(variant >= 0 && variant <= 2, "variant must be 0, 1 or 2");
     if (bytes == 0) return CSLAM_OK;
     const int64_t n16 = bytes / 16;
-    int64_t blocks = ceil_div64(n16, 256 * 4);
-    if (blocks > 256 * 16) blocks = 256 * 16;                // 16 workgroups per compute unit, grid-stride beyond
-    hipLaunchKernelGGL(peak_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const f32x4 *)d_src, (f32x4 *)d_dst, n16);
+    hipStream_t st = (hipStream_t)stream;
+    if (variant == 0) {
+        ARG_CHECK(ceil_div64(n16, 256) < (1LL << 31), "too large for one launch");
+        hipLaunchKernelGGL(peak_copy_flat_kernel, dim3((unsigned)ceil_div64(n16, 256)), dim3(256), 0, st,
+                           (const f32x4 *)d_src, (f32x4 *)d_dst, n16);
+    } else {
+        int64_t blocks = ceil_div64(n16, 256 * 4);
+        if (blocks > 256 * 16) blocks = 256 * 16;
+        if (variant == 1) hipLaunchKernelGGL(peak_copy_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, (const f32x4 *)d_src, (f32x4 *)d_dst, n16);
+        else hipLaunchKernelGGL(peak_copy_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, (const f32x4 *)d_src, (f32x4 *)d_dst, n16);
+    }
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }

@@ -501,9 +501,9 @@ static int launch_stage1(const MfmaArgs &a, int dbg, int ilv, hipStream_t st) {
     return CSLAM_OK;
 }
 
-int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_t nq, int k,
-                const int64_t *d_row_limit, int64_t *d_out_idx, double *d_out_sim,
-                int32_t *d_out_cnt, hipStream_t st) {
+int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_t nq, int k,
+                        const int64_t *d_row_limit, int64_t *d_out_idx, double *d_out_sim,
+                        int32_t *d_out_cnt, hipStream_t st) {
     static int dbg = -1, tile_env = -1, ilv_env = -1;
     if (dbg < 0) {
         const char *v = getenv("CSLAM_MFMA_DBG");       // timing-only ablations, see the kernel
@@ -639,15 +639,34 @@ int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_
                            err_bound, d_out_idx, d_out_sim, d_out_cnt, flag_list, flag_count);
     HIP_TRY(hipGetLastError());
 
-    // uncertified queries -> exact scan (needs the count on the host: one 4-byte readback)
-    int nflag = 0;
-    HIP_TRY(hipMemcpyAsync(&nflag, flag_count, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    b->stats[0] = nflag; b->stats[2] = nseg; b->stats[3] = nqt;
-    if (nflag > 0 && dbg == 0)
-        return scan_search(b, d_q, q_dtype, ldq, flag_list, nflag, k, d_row_limit, d_out_idx, d_out_sim,
+    // uncertified queries -> exact scan (needs the count on the host: one 4-byte readback into pinned memory, read by
+    // mfma_search_finish after the caller's synchronisation -- one per search, or one for a whole group of searches)
+    if (!b->h_nflag) HIP_TRY(hipHostMalloc((void **)&b->h_nflag, sizeof(int), hipHostMallocDefault));
+    *b->h_nflag = 0;
+    HIP_TRY(hipMemcpyAsync(b->h_nflag, flag_count, 4, hipMemcpyDeviceToHost, st));
+    b->stats[2] = nseg; b->stats[3] = nqt;
+    b->pending_flag_list = flag_list;
+    b->pending_dbg = dbg;
+    return CSLAM_OK;
+}
+
+int mfma_search_finish(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int k, const int64_t *d_row_limit,
+                       int64_t *d_out_idx, double *d_out_sim, int32_t *d_out_cnt, hipStream_t st) {
+    const int nflag = b->h_nflag ? *b->h_nflag : 0;        // valid once `st` has been synchronised
+    b->stats[0] = nflag;
+    if (nflag > 0 && b->pending_dbg == 0)
+        return scan_search(b, d_q, q_dtype, ldq, b->pending_flag_list, nflag, k, d_row_limit, d_out_idx, d_out_sim,
                            d_out_cnt, st);
     return CSLAM_OK;
+}
+
+int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_t nq, int k,
+                const int64_t *d_row_limit, int64_t *d_out_idx, double *d_out_sim,
+                int32_t *d_out_cnt, hipStream_t st) {
+    int rc = mfma_search_enqueue(b, d_q, q_dtype, ldq, nq, k, d_row_limit, d_out_idx, d_out_sim, d_out_cnt, st);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
+    return mfma_search_finish(b, d_q, q_dtype, ldq, k, d_row_limit, d_out_idx, d_out_sim, d_out_cnt, st);
 }
 
 CSLAM_API int cslam_bank_last_kernel_ms(cslam_bank_t *b, float *ms) {

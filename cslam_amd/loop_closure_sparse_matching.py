@@ -192,12 +192,27 @@ class LoopClosureSparseMatching(object):
         thr = self.params['frontend.similarity_threshold']
         me = self.params['robot_id']
         others = [i for i in range(self.params['max_nb_robots']) if i != me and self.other_robots_nnsm[i].n > 0]
-        # device banks: enqueue every search of the chunk first, read the results back afterwards
-        pending = [self.other_robots_nnsm[i].search_device(dev, 1) for i in others] if dev is not None else None
+        # device banks: the local top-k and the best-1 of every other robot's bank in ONE library call (all kernels
+        # enqueued before the single host synchronisation, three result copies for the whole chunk)
+        results = None
+        if dev is not None and m > 0 and (intra or others):
+            import torch
+            from cslam_amd.nns_matching import search_multi_device
+            k = int(self.params['frontend.nb_best_matches'])
+            banks, ks, lims = [], [], []
+            if intra:
+                lim = torch.arange(n0, n0 + m, dtype=torch.int64, device=dev.device)   # keyframe j sees rows added before it
+                banks.append(self.local_nnsm); ks.append(k); lims.append(lim)
+            for i in others:
+                banks.append(self.other_robots_nnsm[i]); ks.append(1); lims.append(None)
+            results = search_multi_device(banks, dev, ks, lims)
         if intra and m > 0:
             k = int(self.params['frontend.nb_best_matches'])
-            lim = n0 + np.arange(m, dtype=np.int64)           # keyframe j sees rows added before it
-            rows, sims, cnt = self._search(self.local_nnsm, host, dev, k, lim)
+            if results is not None:
+                rows, sims, cnt = results[0]
+            else:
+                lim = n0 + np.arange(m, dtype=np.int64)       # keyframe j sees rows added before it
+                rows, sims, cnt = self._search(self.local_nnsm, host, dev, k, lim)
             item_arr = self.local_nnsm.item_array() if hasattr(self.local_nnsm, "item_array") else None
             if item_arr is not None:
                 intra_out = self._intra_from_topk(rows, sims, cnt, ids_arr, item_arr)
@@ -225,8 +240,8 @@ class LoopClosureSparseMatching(object):
             generic = False
             for c, i in enumerate(others):
                 bank = self.other_robots_nnsm[i]
-                if pending is not None:
-                    rows, sims, cnt = (t.cpu().numpy() for t in pending[c])
+                if results is not None:
+                    rows, sims, cnt = results[c + (1 if intra else 0)]
                 else:
                     rows, sims, cnt = self._search(bank, host, dev, 1)
                 with np.errstate(invalid="ignore"):

@@ -253,3 +253,41 @@ class NearestNeighborsMatching(object):
         ms = C.c_float(-1.0)
         _lib.check(self._lib.cslam_bank_last_kernel_ms(self._bank, C.byref(ms)))
         return float(ms.value)
+
+
+def search_multi_device(banks, queries, ks, row_limits=None, mode=MODE_AUTO):
+    """One batch of device-resident queries against several banks of the same GPU in ONE library call
+    (`cslam_bank_search_multi_dev`): the kernels of every bank are enqueued before the single host synchronisation,
+    and the results come back in three copies.  banks: NearestNeighborsMatching objects (populated, same dim and
+    device); ks: k per bank; row_limits: per bank None or an int64 CUDA tensor [nq].
+    Returns a list of (rows [nq,k] int64, sims [nq,k] float64, cnt [nq] int32) NUMPY arrays, one per bank -- what
+    `search_device` of each bank would give, downloaded."""
+    import torch
+    assert queries.is_cuda and queries.dim() == 2 and queries.stride(1) == 1
+    assert queries.dtype in (torch.float32, torch.float64)
+    nb, nq = len(banks), queries.shape[0]
+    assert nb >= 1 and len(ks) == nb and all(b._bank is not None for b in banks)
+    lib = banks[0]._lib
+    dt = _lib.F32 if queries.dtype == torch.float32 else _lib.F64
+    ks = [int(k) for k in ks]
+    offs = np.concatenate(([0], np.cumsum([nq * k for k in ks]))).tolist()
+    dev = queries.device
+    idx = torch.empty(offs[-1], dtype=torch.int64, device=dev)
+    sims = torch.empty(offs[-1], dtype=torch.float64, device=dev)
+    cnt = torch.empty(nb * nq, dtype=torch.int32, device=dev)
+    handles = (C.c_void_p * nb)(*[b._bank for b in banks])
+    kk = (C.c_int * nb)(*ks)
+    lims = None
+    if row_limits is not None and any(r is not None for r in row_limits):
+        for r in row_limits:
+            assert r is None or (r.is_cuda and r.dtype == torch.int64 and r.is_contiguous() and r.shape == (nq,))
+        lims = (C.c_void_p * nb)(*[None if r is None else r.data_ptr() for r in row_limits])
+    p_idx = (C.c_void_p * nb)(*[idx.data_ptr() + 8 * offs[i] for i in range(nb)])
+    p_sim = (C.c_void_p * nb)(*[sims.data_ptr() + 8 * offs[i] for i in range(nb)])
+    p_cnt = (C.c_void_p * nb)(*[cnt.data_ptr() + 4 * nq * i for i in range(nb)])
+    st = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(lib.cslam_bank_search_multi_dev(handles, nb, C.c_void_p(queries.data_ptr()), dt, queries.stride(0), nq, kk,
+                                               lims, int(mode), p_idx, p_sim, p_cnt, C.c_void_p(st)))
+    h_idx, h_sims, h_cnt = idx.cpu().numpy(), sims.cpu().numpy(), cnt.cpu().numpy()
+    return [(h_idx[offs[i]:offs[i + 1]].reshape(nq, ks[i]), h_sims[offs[i]:offs[i + 1]].reshape(nq, ks[i]),
+             h_cnt[i * nq:(i + 1) * nq]) for i in range(nb)]

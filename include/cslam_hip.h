@@ -90,6 +90,16 @@ int cslam_bank_search_dev(cslam_bank_t *bank, const void *d_queries, int q_dtype
                           int64_t nq, int k, const int64_t *d_row_limit, int mode,
                           int64_t *d_out_idx, double *d_out_sim, int32_t *d_out_cnt,
                           void *stream);
+
+/* One batch of queries against nb banks of one device -- a robot's own bank and its copies of the other robots' banks
+ * (cslam/loop_closure_sparse_matching.py:21-31), which the reference searches one after the other for every keyframe
+ * (lcsm.py:45-53 best-1 per other robot, lcsm.py:74-76 top-k in the local bank).  Same results as nb calls of
+ * cslam_bank_search_dev with (k[i], d_row_limit[i], d_out_*[i]); all kernels are enqueued before the single host
+ * synchronisation the uncertified-query counts need.  d_row_limit may be NULL (no limits) or hold NULL entries. */
+int cslam_bank_search_multi_dev(cslam_bank_t *const *banks, int nb, const void *d_queries, int q_dtype, int64_t ldq,
+                                int64_t nq, const int *k, const int64_t *const *d_row_limit, int mode,
+                                int64_t *const *d_out_idx, double *const *d_out_sim, int32_t *const *d_out_cnt,
+                                void *stream);
 /* statistics of the last search on this bank (for tests / bench):
  * stats[0] = queries that failed the fp32 certificate and were re-done by the scan,
  * stats[1] = mode actually used (CSLAM_MODE_*), stats[2] = bank segments,
@@ -312,11 +322,12 @@ int cslam_wino_gemm_h2_dev(const void *d_V2, const void *d_U2, int64_t T, int Ci
 /* ---- diagnostics: in-run re-measurement of the peaks rooflines are priced against (csrc/peaks.hip) ---------------
  * Not on the extract / match path and without a reference counterpart: bench.py reports every roofline fraction against
  * the nominal MI355X peaks and against what these two kernels sustain on the box in the same run.
- * cslam_peak_copy_dev: 16-byte-per-lane non-temporal streaming copy of `bytes` (multiple of 16) bytes.
+ * cslam_peak_copy_dev: 16-byte-per-lane streaming copy of `bytes` (multiple of 16) bytes; variant 0 = one element per
+ *   thread, 1 / 2 = grid-stride with plain / non-temporal accesses (the caller keeps the fastest).
  * cslam_peak_mfma_dev: register-resident MFMA loop; kind 0 = f32 inputs (v_mfma_f32_32x32x2_f32), 1 = fp16 inputs
  * (v_mfma_f32_32x32x16_f16); `blocks` workgroups of 4 waves, `iters` x 4 independent MFMAs per wave; *flop_out = flop
  * of the launch.  The caller times both with HIP events on `stream`. */
-int cslam_peak_copy_dev(const void *d_src, void *d_dst, int64_t bytes, void *stream);
+int cslam_peak_copy_dev(const void *d_src, void *d_dst, int64_t bytes, int variant, void *stream);
 int cslam_peak_mfma_dev(int kind, int iters, int blocks, float *d_scratch, double *flop_out, void *stream);
 
 #ifdef __cplusplus
