@@ -50,16 +50,24 @@ struct WinoGemmArgs {
     int n_items;           // 36 * n_mt * n_nt
 };
 
-// TN = 128 or 256 output channels per workgroup tile; DBG: timing-only ablations (1 = no stores, 2 = no loads after the
-// first stage) selected by CSLAM_WGEMM_DBG, never by the product path
-template <int TN, int DBG>
+// s_waitcnt with only the vector-memory counter: gfx9 simm16 = vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14
+#define WG_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
+
+// TM x TN = workgroup tile (tile rows x output channels), 8 waves as 2 x 4, wave tile TM/2 x TN/4 = MT x NT MFMA tiles.
+// NS = LDS stages: 2 = double buffer (the loads of stage t+1 are issued during stage t and drained at its end);
+// 3 = ring, loads two stages ahead, `s_waitcnt vmcnt(L)` (L = loads per thread per stage) leaves the newest stage in
+// flight across the raw s_barrier -- the loads of a stage then have a whole stage of MFMAs to land.
+// A finished item's results are stored right AFTER the barrier that ends its last stage, so the stores drain under the
+// next stage's MFMAs instead of in front of a wait.
+// DBG: timing-only ablations (1 = no stores, 2 = no loads after the prologue), CSLAM_WGEMM_DBG; never the product path.
+template <int TM, int TN, int NS, int DBG>
 __global__ __launch_bounds__(512, 2) void wino_gemm_h2_kernel(WinoGemmArgs p) {
-    constexpr int NT = TN / 128;                       // 32-column MFMA tiles per wave (wave tile 128 x TN/4)
-    constexpr int OPA = WG_TM * WG_ROWB;               // 32 KiB
-    constexpr int OPB = TN * WG_ROWB;
+    constexpr int MT = TM / 64, NT = TN / 128;
+    constexpr int OPA = TM * WG_ROWB, OPB = TN * WG_ROWB;
     constexpr int STAGE = OPA + OPB;
-    constexpr int NLA = WG_TM * 8 / 512;               // 16-byte chunks per thread per stage: A 4, B 4 | 2
-    constexpr int NLB = TN * 8 / 512;
+    constexpr int NLA = TM * 8 / 512, NLB = TN * 8 / 512;   // 16-byte chunks per thread per stage
+    constexpr int L = NLA + NLB;
+    static_assert(NLA >= 2 && NLB >= 2 && (NS == 2 || NS == 3), "tile / ring shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -101,12 +109,12 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_h2_kernel(WinoGemmArgs p) {
         c.xi = rest / p.n_mt;
         return c;
     };
-    // per-lane source addresses of K block 0 of the item the NEXT stage belongs to (recomputed only at item boundaries)
+    // per-lane source addresses of K block 0 of the item the loader is in (recomputed only at item boundaries)
     const char *gA[NLA], *gB[NLB];
     auto point_at = [&](const Item &c) {
 #pragma unroll
         for (int i = 0; i < NLA; ++i) {
-            int64_t row = (int64_t)c.mt * WG_TM + rowA[i];
+            int64_t row = (int64_t)c.mt * TM + rowA[i];
             if (row > p.T - 1) row = p.T - 1;
             gA[i] = p.V2 + ((int64_t)c.xi * p.T + row) * pitch + offA[i];
         }
@@ -128,95 +136,58 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_h2_kernel(WinoGemmArgs p) {
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int lo = 0; lo < 2; ++lo) foff[s][lo] = ((4 * lo + 2 * s + h) ^ swz) << 4;
-    const int arow0 = (wm * 128 + l31) * WG_ROWB;
+    const int arow0 = (wm * (TM / 2) + l31) * WG_ROWB;
     const int brow0 = (wn * (32 * NT) + l31) * WG_ROWB;
 
-    f32x16 acc[4][NT];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
+    // the loader runs NS - 1 stages ahead of the MFMAs: (l_item, l_kt) = the next stage to fetch
+    const int total = n_mine * p.nk;
+    int l_item = 0, l_kt = 0, l_stage = 0, fetched = 0;
     Item cur_item = decode(0);
     point_at(cur_item);
-    {
+    auto advance_loader = [&]() {
+        ++fetched;
+        l_stage = l_stage + 1 == NS ? 0 : l_stage + 1;
+        if (++l_kt == p.nk) {
+            l_kt = 0; ++l_item;
+            if (fetched < total) point_at(decode(l_item));
+        }
+    };
+#pragma unroll 1
+    for (int pre = 0; pre < NS - 1; ++pre) {
+        if (fetched < total) {
 #pragma unroll
-        for (int i = 0; i < NLA; ++i) load_part_a(0, 0, i);
+            for (int i = 0; i < NLA; ++i) load_part_a(l_stage, l_kt, i);
 #pragma unroll
-        for (int i = 0; i < NLB; ++i) load_part_b(0, 0, i);
+            for (int i = 0; i < NLB; ++i) load_part_b(l_stage, l_kt, i);
+            advance_loader();
+        }
     }
-    __builtin_amdgcn_s_waitcnt(0);
+    if (NS == 2 || total == 1) __builtin_amdgcn_s_waitcnt(0); else WG_VMCNT(L);   // stage 0 landed
     __syncthreads();
 
-    const int total = n_mine * p.nk;
     int k_item = 0, kt = 0, cur = 0;
+    bool store_pending = false;
+    Item st_item = cur_item;
     for (int it = 0; it < total; ++it) {
-        // the stage after this one: the next K block of this item, or block 0 of the next item
-        int nkt = kt + 1, nk_item = k_item;
-        if (nkt == p.nk) { nkt = 0; nk_item = k_item + 1; }
-        const bool more = it + 1 < total;
-        Item nxt = cur_item;
-        if (more && nk_item != k_item) { nxt = decode(nk_item); point_at(nxt); }
-        const int lkt = more ? nkt : kt;               // the very last step re-fetches its own stage into the idle buffer
-
-        const char *sA = smem + cur * STAGE;
-        const char *sB = sA + OPA;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            f16x8 ah[4], al[4], bh[NT], bl[NT];
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                ah[m] = *(const f16x8 *)(sA + arow0 + m * 32 * WG_ROWB + foff[s][0]);
-                al[m] = *(const f16x8 *)(sA + arow0 + m * 32 * WG_ROWB + foff[s][1]);
-            }
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                bh[n] = *(const f16x8 *)(sB + brow0 + n * 32 * WG_ROWB + foff[s][0]);
-                bl[n] = *(const f16x8 *)(sB + brow0 + n * 32 * WG_ROWB + foff[s][1]);
-            }
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
-            // half of the next stage's LDS-DMA per K step, issued between this step's MFMAs (sim_topk_mfma.hip: a
-            // global_load_lds costs 60-180 issue cycles; back to back after the barrier they idle the matrix pipe)
-            if (DBG != 2) {
-#pragma unroll
-                for (int i = s * (NLA / 2); i < (s + 1) * (NLA / 2); ++i) load_part_a(cur ^ 1, lkt, i);
-#pragma unroll
-                for (int i = s * (NLB / 2); i < (s + 1) * (NLB / 2); ++i) load_part_b(cur ^ 1, lkt, i);
-            }
-            constexpr int G = 4 * NT * 3;              // MFMAs per K step (12 or 24)
-            constexpr int L = NLA / 2 + NLB / 2;       // LDS-DMA instructions per K step (3 or 4)
-            __builtin_amdgcn_sched_group_barrier(0x008, G / 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, G / 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, G / 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, L - 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, G / 4, 0);
-        }
-
-        if (kt == p.nk - 1) {
-            // ---- item done: store the 128 x TN/4 wave tile (lane = column, 128-byte runs per row) and clear
-            const int row_base = cur_item.mt * WG_TM + wm * 128 + 4 * h;
-            const int col = cur_item.nt * TN + wn * (32 * NT) + l31;
-            float *mo = p.M + ((int64_t)cur_item.xi * p.T + row_base) * p.Cout + col;
-            const bool full = cur_item.mt * WG_TM + wm * 128 + 128 <= p.T;       // wave-uniform: no per-row test
-            const bool st_on = DBG != 1 || p.T < 0;                              // DBG 1: stores compiled, never executed
+        if (store_pending) {
+            // ---- the item finished in the previous stage: store the TM/2 x TN/4 wave tile (lane = column, 128-byte runs per
+            // row) and clear; issued behind the barrier, drains under this stage's MFMAs
+            const int row_base = st_item.mt * TM + wm * (TM / 2) + 4 * h;
+            const int col = st_item.nt * TN + wn * (32 * NT) + l31;
+            float *mo = p.M + ((int64_t)st_item.xi * p.T + row_base) * p.Cout + col;
+            const bool full = st_item.mt * TM + wm * (TM / 2) + TM / 2 <= p.T;    // wave-uniform: no per-row test
+            const bool st_on = DBG != 1 || p.T < 0;                               // DBG 1: stores compiled, never executed
             if (full) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
 #pragma unroll
@@ -224,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_h2_kernel(WinoGemmArgs p) {
                             if (st_on) __builtin_nontemporal_store(acc[m][n][r], mo + (int64_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * p.Cout + 32 * n);
             } else {
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int ro = m * 32 + (r & 3) + 8 * (r >> 2);
@@ -234,17 +205,74 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_h2_kernel(WinoGemmArgs p) {
                     }
             }
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int n = 0; n < NT; ++n)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+            store_pending = false;
         }
-        __builtin_amdgcn_s_waitcnt(0);                 // next stage landed (vmcnt(0)); also drains the stores
-        __syncthreads();
-        cur ^= 1;
-        kt = nkt;
-        if (nk_item != k_item) { k_item = nk_item; cur_item = nxt; }
+        const bool fetch = (DBG != 2) && fetched < total;    // wave-uniform
+        const char *sA = smem + cur * STAGE;
+        const char *sB = sA + OPA;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                ah[m] = *(const f16x8 *)(sA + arow0 + m * 32 * WG_ROWB + foff[s][0]);
+                al[m] = *(const f16x8 *)(sA + arow0 + m * 32 * WG_ROWB + foff[s][1]);
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                bh[n] = *(const f16x8 *)(sB + brow0 + n * 32 * WG_ROWB + foff[s][0]);
+                bl[n] = *(const f16x8 *)(sB + brow0 + n * 32 * WG_ROWB + foff[s][1]);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[n], acc[m][n], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+            // half of the fetched stage's LDS-DMA per K step, issued between this step's MFMAs (sim_topk_mfma.hip: a
+            // global_load_lds costs 60-180 issue cycles; back to back after the barrier they idle the matrix pipe)
+            if (fetch) {
+#pragma unroll
+                for (int i = s * (NLA / 2); i < (s + 1) * (NLA / 2); ++i) load_part_a(l_stage, l_kt, i);
+#pragma unroll
+                for (int i = s * (NLB / 2); i < (s + 1) * (NLB / 2); ++i) load_part_b(l_stage, l_kt, i);
+            }
+        }
+        if (fetch) advance_loader();
+
+        if (kt == p.nk - 1) { store_pending = true; st_item = cur_item; }
+        // the next stage must have landed: with the double buffer that is everything; with the ring only the loads issued
+        // during THIS stage may stay in flight (loads return in order; stores issued at the top of the stage are older)
+        if (NS == 2 || !fetch) __builtin_amdgcn_s_waitcnt(0); else WG_VMCNT(L);
+        __builtin_amdgcn_s_barrier();
+        cur = cur + 1 == NS ? 0 : cur + 1;
+        if (++kt == p.nk) { kt = 0; ++k_item; if (it + 1 < total) cur_item = decode(k_item); }
+    }
+    if (store_pending) {
+        const int row_base = st_item.mt * TM + wm * (TM / 2) + 4 * h;
+        const int col = st_item.nt * TN + wn * (32 * NT) + l31;
+        float *mo = p.M + ((int64_t)st_item.xi * p.T + row_base) * p.Cout + col;
+        const bool st_on = DBG != 1 || p.T < 0;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = m * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    if (st_on && row_base + ro < p.T) __builtin_nontemporal_store(acc[m][n][r], mo + (int64_t)ro * p.Cout + 32 * n);
+            }
     }
 }
 
@@ -334,8 +362,8 @@ CSLAM_API int cslam_wino4_input_h2_dev(const float *d_x, int B, int H, int W, in
     return CSLAM_OK;
 }
 
-template <int TN>
-static int wino_gemm_launch(const WinoGemmArgs &a, int dbg, hipStream_t st) {
+template <int TM, int TN, int NS>
+static int wino_gemm_launch(WinoGemmArgs a, int dbg, hipStream_t st) {
     static int n_cu = 0;
     if (!n_cu) {
         int dev = 0;
@@ -343,15 +371,24 @@ static int wino_gemm_launch(const WinoGemmArgs &a, int dbg, hipStream_t st) {
         HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
         if (n_cu < 8) n_cu = 8;
     }
-    constexpr int lds = 2 * (WG_TM + TN) * WG_ROWB;
+    a.n_mt = (int)ceil_div64(a.T, TM);
+    a.n_nt = a.Cout / TN;
+    const int64_t items = (int64_t)36 * a.n_mt * a.n_nt;
+    ARG_CHECK(items < (1LL << 31), "too many work items");
+    a.n_items = (int)items;
+    constexpr int lds = NS * (TM + TN) * WG_ROWB;
     int grid = n_cu - n_cu % 8;                                      // one persistent workgroup per CU, 8 | grid
     if ((int64_t)grid > round_up64(a.n_items, 8)) grid = (int)round_up64(a.n_items, 8);
-    const void *fn = dbg == 1 ? (const void *)wino_gemm_h2_kernel<TN, 1> : dbg == 2 ? (const void *)wino_gemm_h2_kernel<TN, 2>
-                                                                                      : (const void *)wino_gemm_h2_kernel<TN, 0>;
-    HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    if (dbg == 1) hipLaunchKernelGGL((wino_gemm_h2_kernel<TN, 1>), dim3(grid), dim3(512), lds, st, a);
-    else if (dbg == 2) hipLaunchKernelGGL((wino_gemm_h2_kernel<TN, 2>), dim3(grid), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((wino_gemm_h2_kernel<TN, 0>), dim3(grid), dim3(512), lds, st, a);
+    static bool attr = false;
+    if (!attr) {
+        HIP_TRY(hipFuncSetAttribute((const void *)wino_gemm_h2_kernel<TM, TN, NS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)wino_gemm_h2_kernel<TM, TN, NS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)wino_gemm_h2_kernel<TM, TN, NS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        attr = true;
+    }
+    if (dbg == 1) hipLaunchKernelGGL((wino_gemm_h2_kernel<TM, TN, NS, 1>), dim3(grid), dim3(512), lds, st, a);
+    else if (dbg == 2) hipLaunchKernelGGL((wino_gemm_h2_kernel<TM, TN, NS, 2>), dim3(grid), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((wino_gemm_h2_kernel<TM, TN, NS, 0>), dim3(grid), dim3(512), lds, st, a);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }
@@ -366,13 +403,19 @@ CSLAM_API int cslam_wino_gemm_h2_dev(const void *d_V2, const void *d_U2, int64_t
     WinoGemmArgs a;
     a.V2 = (const char *)d_V2; a.U2 = (const char *)d_U2; a.M = d_M;
     a.T = (int)T; a.Cin = Cin; a.Cout = Cout; a.nk = Cin / 32;
-    a.n_mt = (int)ceil_div64(T, WG_TM);
+    a.n_mt = a.n_nt = a.n_items = 0;
+    // read on every call (two getenv, ~100 ns) so that tests and experiments can switch shapes inside one process
+    const char *e = getenv("CSLAM_WGEMM_DBG"), *c = getenv("CSLAM_WGEMM_CFG");
+    const int dbg = e ? atoi(e) : 0;            // timing-only ablations
+    const int cfg = c ? atoi(c) : 0;            // force a tile / ring shape (1..4 below); 0 = default
+    hipStream_t st = (hipStream_t)stream;
     const bool wide = (Cout % 256) == 0;
-    a.n_nt = Cout / (wide ? 256 : 128);
-    const int64_t items = (int64_t)36 * a.n_mt * a.n_nt;
-    ARG_CHECK(items < (1LL << 31), "too many work items");
-    a.n_items = (int)items;
-    static int dbg = -1;
-    if (dbg < 0) { const char *e = getenv("CSLAM_WGEMM_DBG"); dbg = e ? atoi(e) : 0; }
-    return wide ? wino_gemm_launch<256>(a, dbg, (hipStream_t)stream) : wino_gemm_launch<128>(a, dbg, (hipStream_t)stream);
+    int use = cfg;
+    if (use < 1 || use > 4 || ((use == 1 || use == 3) && !wide)) use = wide ? 1 : 2;
+    switch (use) {
+    case 1: return wino_gemm_launch<256, 256, 2>(a, dbg, st);      // double buffer, 256 x 256
+    case 2: return wino_gemm_launch<256, 128, 3>(a, dbg, st);      // ring of 3, 256 x 128
+    case 3: return wino_gemm_launch<128, 256, 3>(a, dbg, st);      // ring of 3, 128 x 256
+    default: return wino_gemm_launch<256, 128, 2>(a, dbg, st);     // double buffer, 256 x 128 (round-2 first form)
+    }
 }

@@ -356,3 +356,45 @@ def test_row_sharded_matcher_single_process(nnm):
         rows, sims, cnt = run(g, lambda p, w: torch.stack([packed[s][g] for s in range(2)]))
         oi, os_, oc = pyoracle.nns_search(bank, qs[g].cpu().numpy(), 5)
         assert_topk_equal(rows.cpu().numpy(), sims.cpu().numpy(), cnt.cpu().numpy(), oi, os_, oc, 1e-12)
+
+
+def test_multi_bank_search_equals_separate_searches(nnm):
+    """cslam_bank_search_multi_dev (a robot's local bank + its copies of the other robots' banks in one call, one host
+    synchronisation): same rows / scores / counts as one cslam_bank_search_dev per bank and as the oracle -- banks of
+    different sizes (one below the MFMA floor -> exact scan, one EMPTY but created), top-k with a causal row limit on
+    the first bank, best-1 on the others, float32 and float64 queries, and a bank whose near-duplicate rows send
+    queries through the certificate fallback AFTER the shared synchronisation."""
+    import torch
+    rng = np.random.default_rng(77)
+    d = 256
+    sizes = [3000, 120, 1500, 0, 700]
+    banks_h = [unit_rows(np.random.default_rng(80 + i), max(n, 1), d)[:n] for i, n in enumerate(sizes)]
+    base = unit_rows(rng, 1, d)[0]
+    dup = np.tile(base, (700, 1)).astype(np.float32)                     # bank 4: unresolvable near-ties
+    for i in range(700):
+        dup[i, i % d] = np.nextafter(dup[i, i % d], np.float32(1.0)) if i % 3 else dup[i, i % d]
+    banks_h[4] = dup
+    banks = []
+    for i, bh in enumerate(banks_h):
+        nn = nnm.NearestNeighborsMatching(dim=d)
+        if len(bh):
+            nn.add_items(bh, range(len(bh)))
+        banks.append(nn)
+    m = 300
+    for dtype in (np.float32, np.float64):
+        q = unit_rows(rng, m, d).astype(dtype)
+        qd = torch.from_numpy(q).cuda()
+        lim = np.minimum(np.arange(m, dtype=np.int64) * 10, sizes[0])
+        ks = [10, 1, 1, 1, 1]
+        lims = [torch.from_numpy(lim).cuda(), None, None, None, None]
+        got = nnm.search_multi_device(banks, qd, ks, lims)
+        assert banks[4].last_stats()[0] > 0, "the near-duplicate bank should have needed the exact fallback"
+        for i, nn in enumerate(banks):
+            r, s, c = (t.cpu().numpy() for t in nn.search_device(qd, ks[i], row_limit=lims[i]))
+            assert np.array_equal(got[i][0], r) and np.array_equal(got[i][2], c)
+            assert np.array_equal(got[i][1], s, equal_nan=True)
+            if sizes[i]:
+                oi, os_, oc = pyoracle.nns_search(banks_h[i], q, ks[i], row_limit=lim if i == 0 else None)
+                assert_topk_equal(got[i][0], got[i][1], got[i][2], oi, os_, oc, 1e-12)
+            else:
+                assert np.all(got[i][2] == 0) and np.all(got[i][0] == -1)

@@ -31,9 +31,10 @@ def _pairs_rows(v):
     return torch.stack((hi.view(n, r, k // 32, 32), lo.view(n, r, k // 32, 32)), dim=3).contiguous(), hi, lo
 
 
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("rows,cin,cout", [(300, 128, 128), (1024, 256, 256), (257, 512, 512), (5000, 128, 256),
-                                           (2049, 256, 512), (64, 32, 128)])
-def test_pair_gemm_equals_float64(T, rows, cin, cout):
+                                           (2049, 256, 512), (64, 32, 128), (70000, 64, 256)])
+def test_pair_gemm_equals_float64(T, rows, cin, cout, cfg, monkeypatch):
     """M = (vh + vl)(uh + ul) - vl ul, every frequency, ragged row counts, both tile widths (Cout 128 -> 128-column
     tiles, multiples of 256 -> 256-column tiles), one to sixteen K stages.  The three fp16 x fp16 products are exact in
     fp32, so the only error is the fp32 accumulation: <= 2e-6 of sum |terms| (K <= 512 terms x 3), checked per element
@@ -41,6 +42,10 @@ def test_pair_gemm_equals_float64(T, rows, cin, cout):
     torch, _lib = T
     from cslam_amd.vpr import winograd as wg
     lib = _lib.load()
+    if cfg:
+        monkeypatch.setenv("CSLAM_WGEMM_CFG", str(cfg))
+    else:
+        monkeypatch.delenv("CSLAM_WGEMM_CFG", raising=False)
     g = torch.Generator(device="cuda").manual_seed(rows + cin)
     v = (torch.randn((36, rows, cin), generator=g, device="cuda") * 3000.0).clamp_(-30000, 30000)
     U4 = torch.randn((36, cin, cout), generator=g, device="cuda") / cin ** 0.5

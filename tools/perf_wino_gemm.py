@@ -41,7 +41,8 @@ def main():
     lib = _lib.load()
     st = torch.cuda.current_stream().cuda_stream
     tot = {"pair": 0.0, "h3": 0.0, "f32": 0.0}
-    print(f"B = {B} frames; CSLAM_WGEMM_DBG = {os.environ.get('CSLAM_WGEMM_DBG', '0')}")
+    print(f"B = {B} frames; CSLAM_WGEMM_DBG = {os.environ.get('CSLAM_WGEMM_DBG', '0')}; pair GEMM shapes CSLAM_WGEMM_CFG: "
+          f"1 = 256x256 double buffer, 2 = 256x128 ring of 3, 3 = 128x256 ring of 3, 4 = 256x128 double buffer")
     for name, hw, cin, cout in LAYERS:
         torch.manual_seed(1)
         x = torch.relu(torch.randn((B, cin, hw, hw), device="cuda")).contiguous(memory_format=torch.channels_last)
@@ -57,6 +58,13 @@ def main():
         V = torch.empty((36, T, cin), device="cuda")
         M = torch.empty((36, T, cout), device="cuda")
         t_in2 = timed(lambda: _lib.check(lib.cslam_wino4_input_h2_dev(p(x), B, hw, hw, cin, p(slot), p(V2), st)))
+        t_cfg = {}
+        for cfg in (1, 2, 3, 4):
+            if cfg in (1, 3) and cout % 256:
+                continue
+            os.environ["CSLAM_WGEMM_CFG"] = str(cfg)
+            t_cfg[cfg] = timed(lambda: _lib.check(lib.cslam_wino_gemm_h2_dev(p(V2), p(U2[0]), T, cin, cout, p(M), st)))
+        os.environ.pop("CSLAM_WGEMM_CFG", None)
         t_g2 = timed(lambda: _lib.check(lib.cslam_wino_gemm_h2_dev(p(V2), p(U2[0]), T, cin, cout, p(M), st)))
         M2 = M.clone()
         t_in3 = timed(lambda: _lib.check(lib.cslam_wino4_input_h3_dev(p(x), B, hw, hw, cin, p(slot), p(V3), st)))
@@ -69,7 +77,8 @@ def main():
         gbytes = 36.0 * T * (cin + cout) * 4
         print(f"{name:8s} T={T:6d} {cin:3d}->{cout:3d} | pair: in {t_in2:.3f} gemm {t_g2:.3f} ms = {flop / t_g2 / 1e9:6.1f} TF32eq "
               f"({3 * flop / t_g2 / 1e9:6.0f} TF16) {gbytes / t_g2 / 1e6:5.0f} GB/s | h3: in {t_in3:.3f} gemm {t_g3:.3f} | "
-              f"f32: in {t_in1:.3f} gemm {t_g1:.3f} | pair vs h3 rel diff {agree:.1e}")
+              f"f32: in {t_in1:.3f} gemm {t_g1:.3f} | pair vs h3 rel diff {agree:.1e} | pair by shape: "
+              + " ".join(f"cfg{c} {t:.3f}" for c, t in t_cfg.items()))
         rep = {"conv3_2": 2, "conv4_2": 2, "conv5_1": 3}.get(name, 1)        # conv3_3, conv4_3, conv5_2/3 have the same shape
         tot["pair"] += rep * (t_in2 + t_g2); tot["h3"] += rep * (t_in3 + t_g3); tot["f32"] += rep * (t_in1 + t_g1)
         del x, V2, V3, V, M, M2, M3
