@@ -77,6 +77,8 @@ _SIGNATURES = {
     "cslam_wino2_fused_c64_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "cslam_wino4_fused_c64_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "cslam_scancontext_from_cloud_dev": (_i, [_vp, _vp, _i, _i, _i, C.c_double, _vp, _vp, _vp]),
+    "cslam_wino4_fused_c64_h_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, C.c_float, _vp, _vp, _vp]),
+    "cslam_conv3x3_c3_amax_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "cslam_wino4_input_h2_dev": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "cslam_wino_gemm_h2_dev": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "cslam_peak_copy_dev": (_i, [_vp, _vp, _i64, _i, _vp]),

@@ -1,0 +1,336 @@
+// wino_fused_h.hip -- the one-kernel F(4x4, 3x3) Winograd convolution of the 64-input-channel layers (VGG-16 conv1_2,
+// conv2_1: cslam/vpr/netvlad.py:163-171,227) on the fp16 matrix pipe with fp32-grade results (gfx950).
+//
+// wino_fused.hip runs the same convolution on the f32-input MFMA (1/16 of the fp16 rate), where it is bound by the
+// matrix pipe at half of its peak.  Here the Winograd-domain operands are exact fp16 pairs, as in wino_gemm.hip:
+//   V = B^T (sV x) B  ->  (vh, vl) with vh + vl = V to 22 bits, packed as ONE dword per value [vh | vl << 16]
+//   U = sU G g G^T    ->  (uh, ul), packed the same way (vpr/winograd.py `fused64_pair_weights`)
+// A lane's 8-half MFMA operand is then (vh, vl) of 4 consecutive channels, and with the B operand built in registers as
+// (uh, uh) resp. (ul, ul) of the same channels -- one v_perm_b32 per dword --
+//   acc += A . dup(uh)      = sum (vh + vl) uh
+//   acc += A . dup(ul)      = sum (vh + vl) ul        (v_mfma_f32_16x16x32_f16, fp32 accumulate)
+// is the full product (the 2^-22 term vl ul included) with TWO matrix instructions of 16 cycles per frequency and
+// 16-channel quarter, against four f32 instructions of 32 cycles: the matrix phase shrinks 4x and the kernel becomes
+// bound by what it moves (activation in, pooled activation out, the packed U stream from L2).
+//
+// Structure: all 8 waves of a persistent workgroup are alike (no producer / consumer roles: with the matrix phase this
+// short the registers that a weight ring deep enough to cover L2 latency would need are better spent on a second wave per
+// SIMD).  One iteration = NB blocks of 4 x 4 tiles side by side (16 x 16 output pixels each); wave w owns output
+// channels 16 (w % (COUT/16)) .. + 15 of block w / (COUT/16): COUT = 64 -> NB = 2, COUT = 128 -> NB = 1; the two waves
+// that share a weight fragment (COUT = 64) find it in the compute unit's L1.  Per 16-channel quarter:
+//   (a) the patch rows prefetched into registers -> LDS, barrier;
+//   (b) thread (tile, channel): V = B^T d B from 36 ds_read_b32, split, 36 ds_write_b32, barrier;
+//   (c) the next quarter's patch is requested, then 36 x 2 MFMAs per wave with A = one ds_read_b128 per frequency and B
+//       from the packed, L2-resident U (ring of WH_BR pairs), barrier.
+// After the fourth quarter every lane holds all 36 frequencies of its 4 (tile, channel) pairs: A^T M A, exact rescale by
+// 1 / (sV sU), bias, (shortcut), ReLU, 2x2 max, NHWC stores, max |y| for the next layer's scale.
+#include "common.h"
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+
+#define WH_PS 16                       // patch pixel pitch in floats: the LDS-DMA image is lane-linear, so no padding (the
+                                       // transform's ds_read_b32 of two tiles of a 32-lane group then collide 2-way)
+#define WH_VS 16                       // V row = 16 dwords (16 channels x [hi | lo]), 16-byte groups rotated by (tile & 15) >> 1
+#define WH_VSW(tile, grp) (4 * (((((tile) & 15) >> 1) + (grp)) & 3))
+#ifndef WH_BR
+#define WH_BR 3                        // weight fragments in flight, in pairs of frequencies
+#endif
+
+__device__ __forceinline__ void wh_glds16(const float *g, float *lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
+                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ float wh_scale(unsigned amax_bits) {          // = wino_h3_scale (winograd.hip)
+    const float a = fminf(fmaxf(__uint_as_float(amax_bits), 1e-30f), 1e30f);
+    int e;
+    (void)frexpf(327.68f / a, &e);
+    return ldexpf(1.0f, e - 1);
+}
+__device__ __forceinline__ void wh_bt(float &d0, float &d1, float &d2, float &d3, float &d4, float &d5) {
+    const float r0 = 4.0f * d0 - 5.0f * d2 + d4;
+    const float r1 = -4.0f * (d1 + d2) + d3 + d4;
+    const float r2 = 4.0f * (d1 - d2) - d3 + d4;
+    const float r3 = 2.0f * (d3 - d1) - d2 + d4;
+    const float r4 = 2.0f * (d1 - d3) - d2 + d4;
+    const float r5 = 4.0f * d1 - 5.0f * d3 + d5;
+    d0 = r0; d1 = r1; d2 = r2; d3 = r3; d4 = r4; d5 = r5;
+}
+__device__ __forceinline__ void wh_at(float m0, float m1, float m2, float m3, float m4, float m5, float &s0, float &s1,
+                                      float &s2, float &s3) {
+    const float a = m1 + m2, b = m1 - m2, c = m3 + m4, e = m3 - m4;
+    s0 = m0 + a + c;
+    s1 = b + 2.0f * e;
+    s2 = a + 4.0f * c;
+    s3 = b + 8.0f * e + m5;
+}
+__device__ __forceinline__ unsigned wh_pack(float v) {                    // [fp16(v) | fp16(v - fp16(v)) << 16]
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (float)hi);
+    return (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
+}
+
+template <int COUT, bool RELU, bool POOL>
+__global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
+    const float *__restrict__ x, const unsigned *__restrict__ Uh, const float *__restrict__ bias,
+    const float *__restrict__ res, int H, int W, int gxs, int gyb, int nsb, const unsigned *__restrict__ amax_in,
+    float inv_su, unsigned *__restrict__ amax_out, const float *__restrict__ zero16, float *__restrict__ y) {
+    constexpr int NG = COUT / 16;                  // 16-channel output groups: 4 or 8
+    constexpr int NB = 8 / NG;                     // blocks per iteration: 2 or 1
+    constexpr int NT = 16 * NB;                    // tiles per iteration
+    constexpr int PWX = 16 * NB + 2;               // patch width in pixels
+    constexpr int NPIX = 18 * PWX;
+    constexpr int NL = (4 * NPIX + 511) / 512;     // 16-byte patch elements per thread and quarter (5 | 3)
+    constexpr int PBUF = NL * 512 * 4;             // floats per patch buffer (whole LDS-DMA rounds)
+    extern __shared__ __attribute__((aligned(16))) char wh_smem[];
+    float *s_p = (float *)wh_smem;                                  // [2][PBUF]
+    unsigned *s_v = (unsigned *)(wh_smem + 2 * PBUF * 4);           // [36][NT][16]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const float sc = wh_scale(*amax_in);
+    const float inv = inv_su / sc;
+
+    // ---- patch loader: element e = i * 512 + tid = (pixel e >> 2, float4 e & 3 of the 16-channel quarter), LDS-DMA into the
+    // lane-linear image [pixel][16 floats]; pixels outside the map (the convolution's zero padding, ragged blocks) and the
+    // round-up elements read 16 zero bytes
+    int p_src[NL];                                 // float offset into x without the quarter, -1 = zeros
+    int c_img = 0, c_by = 0, c_sx = 0;             // the iteration the loader geometry points at
+    auto geometry = [&](int sb) {
+        const int per_img = gxs * gyb;
+        c_img = sb / per_img;
+        const int rem = sb - c_img * per_img;
+        c_by = rem / gxs;
+        c_sx = rem - c_by * gxs;
+        const int gx0 = c_sx * (16 * NB) - 1, gy0 = c_by * 16 - 1;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = tid + 512 * i;
+            const int pix = e >> 2, f = e & 3;
+            const int pr = pix / PWX, pc = pix - pr * PWX;
+            const int gy = gy0 + pr, gx = gx0 + pc;
+            const bool in = (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W) & (pix < NPIX);
+            p_src[i] = in ? ((c_img * H + gy) * W + gx) * 64 + 4 * f : -1;
+        }
+    };
+    auto fetch = [&](int buf, int kq) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+            wh_glds16(p_src[i] >= 0 ? x + p_src[i] + kq * 16 : zero16, s_p + buf * PBUF + i * (512 * 4) + wave * 256);
+    };
+    // ---- transform geometry: thread = (tile, channel of the quarter); COUT = 128: threads 256.. sit the transform out
+    const int t_tile = tid >> 4, t_c = tid & 15;
+    const bool t_on = t_tile < NT;
+    const int t_bl = (t_tile >> 4) & (NB - 1), t_tt = t_tile & 15;
+    const int t_src = ((4 * (t_tt >> 2)) * PWX + 16 * t_bl + 4 * (t_tt & 3)) * WH_PS + t_c;
+    const int t_dst = t_tile * WH_VS + WH_VSW(t_tile, t_c >> 2) + (t_c & 3);
+    // ---- MFMA geometry
+    const int r16 = lane & 15, g = lane >> 4;
+    const int m_bl = NB == 2 ? wave >> 2 : 0, m_grp = NB == 2 ? wave & 3 : wave;
+    const int co = 16 * m_grp + r16;
+    const float bv = bias ? bias[co] : 0.0f;
+    const int Ho = POOL ? H >> 1 : H, Wo = POOL ? W >> 1 : W;
+    const u4 *up = (const u4 *)Uh + m_grp * 64 + lane;              // + ((kq * 36 + xi) * NG) * 64
+    const unsigned *a_src = s_v + (16 * m_bl + r16) * WH_VS + WH_VSW(r16, g);
+
+    f4 acc[36];
+#pragma unroll
+    for (int xi = 0; xi < 36; ++xi) acc[xi] = (f4)(0.0f);
+    float my_amax = 0.0f;
+
+    const int n_mine = (nsb - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    if (n_mine > 0) {
+        geometry((int)blockIdx.x);
+        fetch(0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    int pb = 0;                                                     // patch buffer holding the current quarter
+    for (int it = 0; it < n_mine; ++it) {
+        const int o_img = c_img, o_by = c_by, o_sx = c_sx;          // this iteration's block (the loader moves on in quarter 3)
+#pragma unroll 1
+        for (int kq = 0; kq < 4; ++kq) {
+            // the next quarter's patch (of this iteration, or quarter 0 of the next one) -> the other buffer, in flight
+            // during the transform and the MFMAs of this quarter
+            {
+                const bool more = kq < 3 || it + 1 < n_mine;
+                if (kq == 3 && more) geometry((int)blockIdx.x + (it + 1) * (int)gridDim.x);
+                if (more) fetch(pb ^ 1, (kq + 1) & 3);
+            }
+            // (b) V = B^T (sV d) B, split into fp16 pairs
+            if (t_on) {
+                const float *src = s_p + pb * PBUF + t_src;
+                float d[6][6];
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) d[i][j] = src[(i * PWX + j) * WH_PS] * sc;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) wh_bt(d[0][j], d[1][j], d[2][j], d[3][j], d[4][j], d[5][j]);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) wh_bt(d[i][0], d[i][1], d[i][2], d[i][3], d[i][4], d[i][5]);
+#pragma unroll
+                for (int i = 0; i < 6; ++i)
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) s_v[(6 * i + j) * NT * WH_VS + t_dst] = wh_pack(d[i][j]);
+            }
+            __syncthreads();
+            // (c) 36 frequencies x 2 MFMAs, weight fragments WH_BR pairs ahead
+            u4 bq[WH_BR][2];
+#pragma unroll
+            for (int p = 0; p < WH_BR; ++p) {
+                bq[p][0] = up[(int64_t)((kq * 36 + 2 * p) * NG) * 64];
+                bq[p][1] = up[(int64_t)((kq * 36 + 2 * p + 1) * NG) * 64];
+            }
+#pragma unroll
+            for (int p = 0; p < 18; ++p) {
+                const u4 a0 = *(const u4 *)(a_src + (2 * p) * NT * WH_VS);
+                const u4 a1 = *(const u4 *)(a_src + (2 * p + 1) * NT * WH_VS);
+                const u4 b0 = bq[p % WH_BR][0], b1 = bq[p % WH_BR][1];
+                u4 h0, l0, h1, l1;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    h0[e] = __builtin_amdgcn_perm(b0[e], b0[e], 0x01000100u);      // (uh, uh)
+                    l0[e] = __builtin_amdgcn_perm(b0[e], b0[e], 0x03020302u);      // (ul, ul)
+                    h1[e] = __builtin_amdgcn_perm(b1[e], b1[e], 0x01000100u);
+                    l1[e] = __builtin_amdgcn_perm(b1[e], b1[e], 0x03020302u);
+                }
+                const h8 A0 = __builtin_bit_cast(h8, a0), A1 = __builtin_bit_cast(h8, a1);
+                acc[2 * p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0, __builtin_bit_cast(h8, h0), acc[2 * p], 0, 0, 0);
+                acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1, __builtin_bit_cast(h8, h1), acc[2 * p + 1], 0, 0, 0);
+                acc[2 * p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0, __builtin_bit_cast(h8, l0), acc[2 * p], 0, 0, 0);
+                acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1, __builtin_bit_cast(h8, l1), acc[2 * p + 1], 0, 0, 0);
+                if (p + WH_BR < 18) {
+                    bq[p % WH_BR][0] = up[(int64_t)((kq * 36 + 2 * (p + WH_BR)) * NG) * 64];
+                    bq[p % WH_BR][1] = up[(int64_t)((kq * 36 + 2 * (p + WH_BR) + 1) * NG) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);                  // keep the ring WH_BR deep: no hoisting of later loads
+            }
+            if (kq == 3) {
+                // ---- output transform: lane (r16, g) holds M_xi[tile (g, v)][channel co] in acc[xi][v].  32-bit element
+                // offsets inside the image (H W COUT < 2^31), one wave-uniform test for blocks that lie inside the map
+                float *yb = y + (int64_t)o_img * Ho * Wo * COUT + co;
+                const float *rb = res ? res + (int64_t)o_img * H * W * COUT + co : nullptr;
+                const int bx = o_sx * NB + m_bl;
+                const bool inside = (o_by * 16 + 16 <= H) & (bx * 16 + 16 <= W);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    __builtin_amdgcn_sched_barrier(0);              // one tile at a time: 40 live values beside the accumulators
+                    float s[4][6], o[4][4];
+#pragma unroll
+                    for (int jj = 0; jj < 6; ++jj)
+                        wh_at(acc[jj][v], acc[6 + jj][v], acc[12 + jj][v], acc[18 + jj][v], acc[24 + jj][v],
+                              acc[30 + jj][v], s[0][jj], s[1][jj], s[2][jj], s[3][jj]);
+                    const int oy0 = (o_by * 4 + g) * 4, ox0 = (bx * 4 + v) * 4;
+                    const int e00 = (oy0 * W + ox0) * COUT;         // element offset of the tile's first pixel (unpooled map)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        wh_at(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o[i][0], o[i][1], o[i][2], o[i][3]);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const bool in = inside || (oy0 + i < H && ox0 + jj < W);
+                            o[i][jj] = o[i][jj] * inv + bv;                       // exact power-of-two rescale, then bias
+                            if (!POOL && rb && in) o[i][jj] += rb[e00 + (i * W + jj) * COUT];
+                            if (RELU) o[i][jj] = fmaxf(o[i][jj], 0.0f);
+                            if (in) my_amax = fmaxf(my_amax, fabsf(o[i][jj]));
+                        }
+                    }
+                    if (POOL) {
+                        const int p00 = ((oy0 >> 1) * Wo + (ox0 >> 1)) * COUT;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+#pragma unroll
+                            for (int jj = 0; jj < 2; ++jj) {
+                                const float m = fmaxf(fmaxf(o[2 * i][2 * jj], o[2 * i][2 * jj + 1]),
+                                                      fmaxf(o[2 * i + 1][2 * jj], o[2 * i + 1][2 * jj + 1]));
+                                if (inside || ((oy0 >> 1) + i < Ho && (ox0 >> 1) + jj < Wo)) yb[p00 + (i * Wo + jj) * COUT] = m;
+                            }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj)
+                                if (inside || (oy0 + i < H && ox0 + jj < W)) yb[e00 + (i * W + jj) * COUT] = o[i][jj];
+                    }
+                }
+#pragma unroll
+                for (int xi = 0; xi < 36; ++xi) acc[xi] = (f4)(0.0f);
+            }
+            __builtin_amdgcn_s_waitcnt(0);                          // the other patch buffer has landed (and the stores drained)
+            __syncthreads();                                        // V is free again, the next patch visible to everyone
+            pb ^= 1;
+        }
+    }
+    if (amax_out) {
+        // max |y| of everything this workgroup wrote (pre-pool values bound the pooled ones): wave maximum, LDS maximum,
+        // one global atomic per workgroup and only if it would raise the slot
+        unsigned *s_amax = s_v;                                     // V is no longer needed
+        if (tid == 0) *s_amax = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) my_amax = fmaxf(my_amax, __shfl_xor(my_amax, o, 64));
+        if (lane == 0) atomicMax(s_amax, __float_as_uint(my_amax));
+        __syncthreads();
+        if (tid == 0 && *s_amax > *(volatile unsigned *)amax_out) atomicMax(amax_out, *s_amax);
+    }
+}
+
+template <int COUT>
+static int launch_fused_h(const float *d_x, const unsigned *d_Uh, const float *d_bias, const float *d_res, int B, int H, int W,
+                          int relu, int pool, const unsigned *d_amax, float inv_su, unsigned *d_amax_out, float *d_y,
+                          hipStream_t st) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    constexpr int NB = 8 / (COUT / 16);
+    const int gxs = (int)ceil_div64(W, 16 * NB), gyb = (int)ceil_div64(H, 16);
+    const int64_t nsb = (int64_t)B * gxs * gyb;
+    ARG_CHECK(nsb < (1ll << 30), "too many tile blocks for one launch");
+    ARG_CHECK((int64_t)B * H * W * 64 < (1ll << 31), "activation too large for the 32-bit patch offsets");
+    const int grid_n = (int)(nsb < n_cu ? nsb : n_cu);
+    dim3 grid((unsigned)grid_n), block(512);
+    constexpr int NPIX = 18 * (16 * NB + 2), NL = (4 * NPIX + 511) / 512;
+    constexpr int lds = 2 * NL * 512 * 16 + 36 * 16 * NB * 64;
+    static float *zero16 = nullptr;                                 // 16 zero bytes per device the kernel has run on
+    static int zero_dev = -1;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (!zero16 || zero_dev != dev) {
+        HIP_TRY(hipMalloc((void **)&zero16, 256));                  // never freed: a captured graph may point at it
+        HIP_TRY(hipMemset(zero16, 0, 256));
+        zero_dev = dev;
+    }
+#define WH_LAUNCH(R, P) do { \
+        HIP_TRY(hipFuncSetAttribute((const void *)wino4_fused_c64_h_kernel<COUT, R, P>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+        hipLaunchKernelGGL((wino4_fused_c64_h_kernel<COUT, R, P>), grid, block, lds, st, d_x, d_Uh, d_bias, d_res, \
+                           H, W, gxs, gyb, (int)nsb, d_amax, inv_su, d_amax_out, zero16, d_y); } while (0)
+    if (relu && pool) WH_LAUNCH(true, true);
+    else if (relu) WH_LAUNCH(true, false);
+    else if (pool) WH_LAUNCH(false, true);
+    else WH_LAUNCH(false, false);
+#undef WH_LAUNCH
+    return CSLAM_OK;
+}
+
+CSLAM_API int cslam_wino4_fused_c64_h_dev(const float *d_x, const void *d_Uh, const float *d_bias, const float *d_residual,
+                                          int B, int H, int W, int Cout, int relu, int pool, const unsigned *d_amax,
+                                          float inv_su, unsigned *d_amax_out, float *d_y, void *stream) {
+    PTR_DEVICE(d_x);
+    ARG_CHECK(d_x && d_Uh && d_y && d_amax, "NULL argument");
+    ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
+    ARG_CHECK(Cout == 64 || Cout == 128, "Cout must be 64 or 128");
+    ARG_CHECK(!pool || ((H % 2) == 0 && (W % 2) == 0), "pooling needs even H and W");
+    ARG_CHECK(!(pool && d_residual), "a shortcut cannot be added to a pooled output");
+    ARG_CHECK(inv_su > 0.0f, "inv_su must be positive");
+    hipStream_t st = (hipStream_t)stream;
+    const int rc = Cout == 64
+        ? launch_fused_h<64>(d_x, (const unsigned *)d_Uh, d_bias, d_residual, B, H, W, relu, pool, d_amax, inv_su, d_amax_out, d_y, st)
+        : launch_fused_h<128>(d_x, (const unsigned *)d_Uh, d_bias, d_residual, B, H, W, relu, pool, d_amax, inv_su, d_amax_out, d_y, st);
+    if (rc != CSLAM_OK) return rc;
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}

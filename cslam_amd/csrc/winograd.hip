@@ -250,10 +250,12 @@ __global__ __launch_bounds__(256) void conv3x3_c3_kernel(const float *__restrict
 #define C3T_PW (C3T_W + 2)
 __global__ __launch_bounds__(256) void conv3x3_c3_tile64_kernel(const float *__restrict__ x, const float *__restrict__ wt,
                                                                 const float *__restrict__ bias, int H, int W, int relu,
-                                                                float *__restrict__ y) {
+                                                                float *__restrict__ y, unsigned *__restrict__ amax_out) {
     constexpr int COUT = 64, P = COUT + 4;
     __shared__ float s_in[3 * (C3T_H + 2) * C3T_PW];            // [ci][row][col], zero border included
     __shared__ __attribute__((aligned(16))) float s_t[C3T_W * C3T_H * P];
+    __shared__ unsigned s_amax;
+    if (amax_out && threadIdx.x == 0) s_amax = 0u;              // ordered before its use by the two barriers below
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int w0 = blockIdx.x * C3T_W, h0 = blockIdx.y * C3T_H;
@@ -292,18 +294,36 @@ __global__ __launch_bounds__(256) void conv3x3_c3_tile64_kernel(const float *__r
         *((f4 *)(s_t + lane * P + co0 + j)) = o;
     }
     __syncthreads();
+    float vmax = 0.0f;
 #pragma unroll
     for (int i = 0; i < (C3T_W * C3T_H * (COUT / 4)) / 256; ++i) {
         const int e = threadIdx.x + 256 * i;
         const int p = e >> 4, c4 = e & 15;                      // COUT / 4 = 16 float4 per pixel
         const int hh = h0 + (p >> 5), ww = w0 + (p & 31);
-        if (hh < H && ww < W)
-            *((f4 *)(y + ((b * H + hh) * (int64_t)W + ww) * COUT) + c4) = *((const f4 *)(s_t + p * P) + c4);
+        if (hh < H && ww < W) {
+            const f4 o = *((const f4 *)(s_t + p * P) + c4);
+            *((f4 *)(y + ((b * H + hh) * (int64_t)W + ww) * COUT) + c4) = o;
+            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+        }
+    }
+    if (amax_out) {
+        // max |y| for the scale of a split-fp16 layer behind this one: wave maximum, LDS maximum, one global atomic per
+        // workgroup and only if it would raise the slot (as wino4_output_kernel)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+        if (lane == 0) atomicMax(&s_amax, __float_as_uint(vmax));
+        __syncthreads();
+        if (threadIdx.x == 0 && s_amax > *(volatile unsigned *)amax_out) atomicMax(amax_out, s_amax);
     }
 }
 
 CSLAM_API int cslam_conv3x3_c3_dev(const float *d_x, const float *d_wt, const float *d_bias, int B, int H, int W,
                                    int Cout, int relu, float *d_y, void *stream) {
+    return cslam_conv3x3_c3_amax_dev(d_x, d_wt, d_bias, B, H, W, Cout, relu, d_y, nullptr, stream);
+}
+
+CSLAM_API int cslam_conv3x3_c3_amax_dev(const float *d_x, const float *d_wt, const float *d_bias, int B, int H, int W,
+                                        int Cout, int relu, float *d_y, unsigned *d_amax_out, void *stream) {
     PTR_DEVICE(d_x);
     ARG_CHECK(d_x && d_wt && d_y, "NULL argument");
     ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty input");
@@ -313,10 +333,11 @@ CSLAM_API int cslam_conv3x3_c3_dev(const float *d_x, const float *d_wt, const fl
     ARG_CHECK(ceil_div64(n, 64) < (1LL << 31), "too many pixels for one launch");
     if (Cout == 64 && B <= 65535 && ceil_div64(H, C3T_H) <= 65535) {
         hipLaunchKernelGGL(conv3x3_c3_tile64_kernel, dim3((unsigned)ceil_div64(W, C3T_W), (unsigned)ceil_div64(H, C3T_H), (unsigned)B),
-                           dim3(256), 0, (hipStream_t)stream, d_x, d_wt, d_bias, H, W, relu, d_y);
+                           dim3(256), 0, (hipStream_t)stream, d_x, d_wt, d_bias, H, W, relu, d_y, d_amax_out);
         HIP_TRY(hipGetLastError());
         return CSLAM_OK;
     }
+    ARG_CHECK(!d_amax_out, "max |y| is only delivered by the 64-channel first-layer kernel");
     const size_t lds = (size_t)64 * (Cout + 4) * 4;
     ARG_CHECK(lds <= 160 * 1024, "Cout too large for the LDS tile");
     HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_c3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

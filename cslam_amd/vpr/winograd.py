@@ -73,6 +73,40 @@ def fused64_weights(U):
     return U.view(U.shape[0], 4, 4, 4, U.shape[2] // 16, 16).permute(1, 0, 4, 2, 5, 3).contiguous()
 
 
+def fused64_pair_weights(U4):
+    """U4 [36, 64, Cout] float32 (`wino_weights(w, 4)`; Cout 64 or 128) -> (Uh int32 [4, 36, Cout/16, 4, 16, 4], inv_su):
+    the weight operand of `cslam_wino4_fused_c64_h_dev` (csrc/wino_fused_h.hip): sU U split into exact fp16 pairs and
+    packed one dword per value, [uh | ul << 16], in the lane order of `fused64_weights`."""
+    assert U4.shape[0] == 36 and U4.shape[1] == 64 and U4.shape[2] in (64, 128)
+    u = U4.detach().to(torch.float64)
+    amax = float(u.abs().max())
+    su = 2.0 ** (14 - math.floor(math.log2(amax))) if amax > 0 else 1.0
+    us = (u * su).to(torch.float32)
+    uh = us.to(torch.float16)
+    ul = (us - uh.to(torch.float32)).to(torch.float16)
+    packed = (uh.view(torch.int16).to(torch.int32) & 0xFFFF) | (ul.view(torch.int16).to(torch.int32) << 16)
+    cout = U4.shape[2]
+    return packed.view(36, 4, 4, 4, cout // 16, 16).permute(1, 0, 4, 2, 5, 3).contiguous(), 1.0 / su
+
+
+def wino_fused64_h(x, Uh, bias, relu, pool, amax_in, amax_out=None, residual=None):
+    """The fp16-pair form of `wino_fused64` (csrc/wino_fused_h.hip): Uh = `fused64_pair_weights(U4)`; amax_in = 4-byte
+    device slot holding the bits of (a bound of) max |x|; amax_out (zeroed slot or None) receives those of max |y|."""
+    lib = _lib.load()
+    B, _, H, W = x.shape
+    Cout = Uh[0].shape[2] * 16
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    y = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if residual is not None:
+        residual = residual.contiguous(memory_format=torch.channels_last)
+        assert residual.shape == y.shape
+    _lib.check(lib.cslam_wino4_fused_c64_h_dev(
+        _p(x), _p(Uh[0]), _p(bias) if bias is not None else None, _p(residual) if residual is not None else None,
+        B, H, W, Cout, int(relu), int(pool), _p(amax_in), float(Uh[1]), _p(amax_out) if amax_out is not None else None,
+        _p(y), _stream(x)))
+    return y
+
+
 def wino_fused64(x, Up, bias, relu, pool, residual=None):
     """64 -> 64 / 128 channel 3x3 convolution of x [B,64,H,W] (channels_last storage) as one kernel
     (csrc/wino_fused.hip); Up from `fused64_weights` (16 frequencies: the F(2x2) kernel, 36: the F(4x4) one)."""
@@ -302,11 +336,11 @@ class WinogradResNet(_Workspace):
 
 
 class _Step(object):
-    __slots__ = ("kind", "module", "conv", "relu", "pool", "U", "U4", "U3", "U2", "Up", "bias")
+    __slots__ = ("kind", "module", "conv", "relu", "pool", "U", "U4", "U3", "U2", "Up", "Uph", "bias")
 
     def __init__(self):
         self.kind, self.module, self.conv, self.relu, self.pool = "torch", None, None, False, False
-        self.U, self.U4, self.U3, self.U2, self.Up, self.bias = None, None, None, None, None, None
+        self.U, self.U4, self.U3, self.U2, self.Up, self.Uph, self.bias = None, None, None, None, None, None, None
 
 
 class WinogradTrunk(_Workspace):
@@ -357,6 +391,10 @@ class WinogradTrunk(_Workspace):
                     # F(4x4) one-kernel form on the F(4x4) trunk (CSLAM_WINO_FUSED_TILE=2 keeps the F(2x2) one)
                     t4 = self.tile == 4 and os.environ.get("CSLAM_WINO_FUSED_TILE", "4") == "4"
                     st.Up = fused64_weights(st.U4 if t4 else st.U)
+                    # the fp16-pair form of the one-kernel convolution (csrc/wino_fused_h.hip); CSLAM_WINO_FUSED_H=0 keeps
+                    # the f32-MFMA kernel
+                    if t4 and os.environ.get("CSLAM_WINO_FUSED_H", "1") != "0":
+                        st.Uph = fused64_pair_weights(st.U4)
                 st.bias = None if m.bias is None else m.bias.detach().to(torch.float32).contiguous()
                 i += 1
                 if i < len(mods) and isinstance(mods[i], nn.ReLU):
@@ -400,20 +438,27 @@ class WinogradTrunk(_Workspace):
     def __call__(self, x):
         """x [B,C,H,W] float32 (any memory format) -> [B,C',H',W'] float32, channels_last memory."""
         lib = _lib.load()
-        # one 4-byte slot per step for max |activation| between consecutive split-fp16 layers
+        # one 4-byte slot per step for max |activation| between consecutive split-fp16 layers: slot k holds max |input of
+        # step k|, written by the step before it when that step can (first-layer kernel, fused fp16 kernel, F(4x4) output
+        # transform); otherwise the consumer makes its own pass over x
         slots = amax_ready = None
-        if any(st.U3 is not None or st.U2 is not None for st in self.steps):
+        wants = lambda st_: st_ is not None and (st_.U3 is not None or st_.U2 is not None or st_.Uph is not None)   # noqa: E731
+        if any(wants(st) for st in self.steps):
             slots = self._buf("amax_slots", len(self.steps) + 1, x.device)
             slots.zero_()
         for k, st in enumerate(self.steps):
             have, amax_ready = amax_ready, None
+            nxt = self.steps[k + 1] if k + 1 < len(self.steps) else None
             if st.kind == "c3":
                 x = x.contiguous()                                   # planar [B,3,H,W]
                 B, _, H, W = x.shape
                 Cout = st.conv.out_channels
                 y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-                _lib.check(lib.cslam_conv3x3_c3_dev(_p(x), _p(st.U), _p(st.bias) if st.bias is not None else None,
-                                                    B, H, W, Cout, int(st.relu), _p(y), _stream(x)))
+                want = slots[k + 1:k + 2] if (wants(nxt) and Cout == 64) else None
+                _lib.check(lib.cslam_conv3x3_c3_amax_dev(_p(x), _p(st.U), _p(st.bias) if st.bias is not None else None,
+                                                         B, H, W, Cout, int(st.relu), _p(y),
+                                                         _p(want) if want is not None else None, _stream(x)))
+                amax_ready = want is not None
                 x = y
                 continue
             x = x.contiguous(memory_format=torch.channels_last)
@@ -438,10 +483,17 @@ class WinogradTrunk(_Workspace):
                 bh, bw = (16, 16) if st.Up.shape[1] == 36 else (8, 16)
                 nblk = x.shape[0] * -(-x.shape[2] // bh) * -(-x.shape[3] // bw) * st.Up.shape[2] // 4
                 if nblk >= self.fused_min_blocks:
-                    x = wino_fused64(x, st.Up, st.bias, st.relu, st.pool)
+                    if st.Uph is not None and x.numel() < 2 ** 31:
+                        slot = slots[k:k + 1]
+                        if not have:
+                            _lib.check(lib.cslam_absmax_dev(_p(x), x.numel(), _p(slot), _stream(x)))
+                        want = slots[k + 1:k + 2] if wants(nxt) else None
+                        x = wino_fused64_h(x, st.Uph, st.bias, st.relu, st.pool, slot, want)
+                        amax_ready = want is not None
+                    else:
+                        x = wino_fused64(x, st.Up, st.bias, st.relu, st.pool)
                     continue
-            nxt = self.steps[k + 1] if k + 1 < len(self.steps) else None
-            want = slots[k + 1:k + 2] if (nxt is not None and (nxt.U3 is not None or nxt.U2 is not None)) else None
+            want = slots[k + 1:k + 2] if wants(nxt) else None
             y = wino_conv3x3(self, x, st.U, st.U4, st.bias, st.relu, st.pool, U3=st.U3, U2=st.U2,
                              amax_in=slots[k:k + 1] if have else None, amax_out=want)
             amax_ready = want is not None and self.amax_written

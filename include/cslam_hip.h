@@ -319,6 +319,21 @@ int cslam_wino4_input_h2_dev(const float *d_x, int B, int H, int W, int C, const
                              void *stream);
 int cslam_wino_gemm_h2_dev(const void *d_V2, const void *d_U2, int64_t T, int Cin, int Cout, float *d_M, void *stream);
 
+/* The one-kernel F(4x4,3x3) convolution of the 64-input-channel layers (cslam_wino4_fused_c64_dev above) on the fp16
+ * matrix pipe with fp32-grade results (csrc/wino_fused_h.hip): V and U as exact fp16 pairs packed [hi | lo << 16] per
+ * value, two v_mfma_f32_16x16x32_f16 per frequency and 16-channel quarter.  d_Uh = U [36,64,Cout] of the F(4x4) form,
+ * scaled by the power of two sU, split and permuted to [kq 4][xi 36][w Cout/16][g 4][c 16][s 4] uint32 with
+ * Uh[kq][xi][w][g][c][s] = pack(U[xi][16 kq + 4 g + s][16 w + c]) (vpr/winograd.py `fused64_pair_weights`), inv_su = 1/sU;
+ * *d_amax = float bits of (a bound of) max |x| (fixes the power-of-two scale of V, as cslam_wino4_input_h2_dev);
+ * d_amax_out (optional, zeroed by the caller) receives the bits of max |y| before pooling.  B H W 64 < 2^31. */
+int cslam_wino4_fused_c64_h_dev(const float *d_x, const void *d_Uh, const float *d_bias, const float *d_residual, int B,
+                                int H, int W, int Cout, int relu, int pool, const unsigned *d_amax, float inv_su,
+                                unsigned *d_amax_out, float *d_y, void *stream);
+/* cslam_conv3x3_c3_dev that also delivers max |y| (float bits, into the zeroed 4-byte slot d_amax_out; NULL = off):
+ * the first trunk layer feeds the scale of the fused fp16 layer behind it without a separate pass over its output. */
+int cslam_conv3x3_c3_amax_dev(const float *d_x, const float *d_wt, const float *d_bias, int B, int H, int W, int Cout,
+                              int relu, float *d_y, unsigned *d_amax_out, void *stream);
+
 /* ---- diagnostics: in-run re-measurement of the peaks rooflines are priced against (csrc/peaks.hip) ---------------
  * Not on the extract / match path and without a reference counterpart: bench.py reports every roofline fraction against
  * the nominal MI355X peaks and against what these two kernels sustain on the box in the same run.

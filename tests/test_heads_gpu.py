@@ -458,18 +458,21 @@ def test_fused_winograd_shortcut_add(T, B, H, W, cout):
             wino_fused64(x, Up, b, True, True, idt[:, :, ::2, ::2])
 
 
+@pytest.mark.parametrize("form", ["h", "f32"])
 @pytest.mark.parametrize("cout", [64, 128])
 @pytest.mark.parametrize("B,H,W,relu,pool,bias", [(2, 224, 224, True, True, True), (3, 37, 50, True, False, True),
-                                                  (1, 8, 16, False, True, False), (2, 1, 1, False, False, True),
-                                                  (300, 16, 16, True, True, True), (5, 100, 36, True, True, True)])
-def test_fused_winograd_f4_equals_float64(T, cout, B, H, W, relu, pool, bias):
-    """The F(4x4,3x3) one-kernel form (36 frequencies; csrc/wino_fused.hip `wino4_fused_c64_pipe_kernel`) against a
-    float64 conv2d (+ ReLU + MaxPool2d) at the F(4x4) tolerance of the three-kernel form (2e-5 of the largest
-    activation); ragged 16 x 16 blocks, block counts below and above the compute-unit count, both output widths."""
+                                                  (300, 16, 16, False, False, False), (1, 8, 90, True, True, False)])
+def test_fused_winograd_f4_equals_float64(T, form, cout, B, H, W, relu, pool, bias, monkeypatch):
+    """The F(4x4,3x3) one-kernel forms -- "f32": f32-input MFMA (csrc/wino_fused.hip `wino4_fused_c64_pipe_kernel`); "h":
+    exact fp16 pairs on the fp16 matrix pipe (csrc/wino_fused_h.hip, the default) -- against a float64 conv2d (+ ReLU +
+    MaxPool2d) at the F(4x4) tolerance of the three-kernel form (2e-5 of the largest activation, 5e-6 in the relative
+    2-norm); ragged 16 x 16 blocks, odd block counts per row (the fp16 form takes two blocks per step at 64 output
+    channels), block counts below and above the compute-unit count, both output widths."""
     torch, _ = T
     from torch import nn
     from cslam_amd.vpr.winograd import WinogradTrunk
     os.environ.pop("CSLAM_WF_WAVES", None)
+    monkeypatch.setenv("CSLAM_WINO_FUSED_H", "1" if form == "h" else "0")
     torch.manual_seed(29)
     mods = [nn.Conv2d(64, cout, 3, padding=1, bias=bias)] + ([nn.ReLU()] if relu else []) + \
         ([nn.MaxPool2d(2, 2)] if pool and relu else [])
@@ -478,13 +481,62 @@ def test_fused_winograd_f4_equals_float64(T, cout, B, H, W, relu, pool, bias):
     fused = WinogradTrunk(seq, 64, 4, fused64=True)
     fused.fused_min_blocks = 0
     assert fused.steps[0].Up is not None and fused.steps[0].Up.shape[1] == 36
+    assert (fused.steps[0].Uph is not None) == (form == "h")
     yf = fused(x)
     with torch.no_grad():
         ref = seq.double()(x.double())
     seq.float()
     assert yf.shape == ref.shape
     ef = (yf.double() - ref).abs().max().item() / ref.abs().max().item()
-    assert ef <= 2e-5, ef
+    rf = float(((yf.double() - ref) ** 2).sum().sqrt() / (ref ** 2).sum().sqrt())
+    assert ef <= 2e-5 and rf <= 5e-6, (ef, rf)
+
+
+@pytest.mark.parametrize("cout,B,H,W,pool,amp", [(64, 4, 64, 48, True, 1.0), (128, 3, 40, 56, False, 1e3), (64, 2, 30, 22, False, 1e-3)])
+def test_fused_winograd_h_scales_shortcut_and_amax(T, cout, B, H, W, pool, amp):
+    """cslam_wino4_fused_c64_h_dev called directly: activations six decades apart (the power-of-two scale from the max |x|
+    slot), the max |y| slot it writes (a bound of the pre-pool maximum, as the output transform's), the shortcut add of the
+    non-pooled form, and max |y| out of the first-layer kernel feeding it."""
+    torch, _lib = T
+    from cslam_amd.vpr import winograd as wg
+    lib = _lib.load()
+    import ctypes as C
+    torch.manual_seed(41)
+    x = (torch.relu(torch.randn(B, 64, H, W, device="cuda")) * amp).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(cout, 64, 3, 3, device="cuda") / 24.0
+    b = torch.randn(cout, device="cuda") * amp
+    res = None if pool else (torch.randn(B, cout, H, W, device="cuda") * amp).contiguous(memory_format=torch.channels_last)
+    U4 = wg.wino_weights(w, 4).cuda()
+    Uh = wg.fused64_pair_weights(U4)
+    Uh = (Uh[0].cuda(), Uh[1])
+    st = torch.cuda.current_stream().cuda_stream
+    slot = torch.zeros(1, dtype=torch.float32, device="cuda")
+    _lib.check(lib.cslam_absmax_dev(C.c_void_p(x.data_ptr()), x.numel(), C.c_void_p(slot.data_ptr()), st))
+    out_slot = torch.zeros(1, dtype=torch.float32, device="cuda")
+    y = wg.wino_fused64_h(x, Uh, b, True, pool, slot, out_slot, res)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), b.double(), padding=1)
+    if res is not None:
+        ref = ref + res.double()
+    ref = torch.relu(ref)
+    prepool = ref
+    ref = torch.nn.functional.max_pool2d(ref, 2, 2) if pool else ref
+    s = ref.abs().max().item()
+    assert (y.double() - ref).abs().max().item() <= 2e-5 * s
+    assert float(((y.double() - ref) ** 2).sum().sqrt() / (ref ** 2).sum().sqrt()) <= 5e-6
+    m = prepool.abs().max().item()
+    assert m * (1 - 1e-4) <= out_slot.item() <= m * (1 + 1e-4)
+    # first-layer kernel: max |y| delivered with the convolution
+    x3 = torch.randn(B, 3, H, W, device="cuda") * amp
+    w3 = torch.randn(64, 3, 3, 3, device="cuda") / 5.0
+    b3 = torch.randn(64, device="cuda") * amp
+    wt = w3.permute(1, 2, 3, 0).reshape(27, 64).contiguous()
+    y3 = torch.empty((B, 64, H, W), device="cuda", memory_format=torch.channels_last)
+    s3 = torch.zeros(1, dtype=torch.float32, device="cuda")
+    p = lambda t: C.c_void_p(t.data_ptr())      # noqa: E731
+    _lib.check(lib.cslam_conv3x3_c3_amax_dev(p(x3), p(wt), p(b3), B, H, W, 64, 1, p(y3), p(s3), st))
+    r3 = torch.relu(torch.nn.functional.conv2d(x3.double(), w3.double(), b3.double(), padding=1))
+    assert (y3.double() - r3).abs().max().item() <= 1e-5 * r3.abs().max().item()
+    assert s3.item() == y3.abs().max().item()
 
 
 def _rel_rms(y, ref):
