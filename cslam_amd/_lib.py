@@ -81,6 +81,12 @@ _SIGNATURES = {
     "cslam_conv3x3_c3_amax_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "cslam_wino4_input_h2_dev": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "cslam_wino_gemm_h2_dev": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
+    "cslam_comm_unique_id": (_i, [_vp]),
+    "cslam_comm_init": (_i, [_i, _i, _vp, _i, C.POINTER(_vp)]),
+    "cslam_comm_destroy": (_i, [_vp]),
+    "cslam_comm_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i)]),
+    "cslam_allgather_queries_dev": (_i, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "cslam_exchange_lists_dev": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "cslam_peak_copy_dev": (_i, [_vp, _vp, _i64, _i, _vp]),
     "cslam_peak_mfma_dev": (_i, [_i, _i, _i, _vp, C.POINTER(C.c_double), _vp]),
 }

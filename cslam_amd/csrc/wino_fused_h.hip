@@ -24,6 +24,7 @@
 //       from the packed, L2-resident U (ring of WH_BR pairs), barrier.
 // After the fourth quarter every lane holds all 36 frequencies of its 4 (tile, channel) pairs: A^T M A, exact rescale by
 // 1 / (sV sU), bias, (shortcut), ReLU, 2x2 max, NHWC stores, max |y| for the next layer's scale.
+#include <stdlib.h>
 #include "common.h"
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -71,7 +72,9 @@ __device__ __forceinline__ unsigned wh_pack(float v) {                    // [fp
     return (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
 }
 
-template <int COUT, bool RELU, bool POOL>
+// DBG: timing-only ablations (wrong results), CSLAM_WFH_DBG: 1 = every weight fragment from ONE address (L1 hits: no L2
+// latency), 2 = no input transform, 4 = no MFMAs, 8 = no patch loads after the first, 16 = no output transform / stores
+template <int COUT, bool RELU, bool POOL, int DBG>
 __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
     const float *__restrict__ x, const unsigned *__restrict__ Uh, const float *__restrict__ bias,
     const float *__restrict__ res, int H, int W, int gxs, int gyb, int nsb, const unsigned *__restrict__ amax_in,
@@ -156,10 +159,10 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
             {
                 const bool more = kq < 3 || it + 1 < n_mine;
                 if (kq == 3 && more) geometry((int)blockIdx.x + (it + 1) * (int)gridDim.x);
-                if (more) fetch(pb ^ 1, (kq + 1) & 3);
+                if (more && !(DBG & 8)) fetch(pb ^ 1, (kq + 1) & 3);
             }
             // (b) V = B^T (sV d) B, split into fp16 pairs
-            if (t_on) {
+            if (t_on && !(DBG & 2)) {
                 const float *src = s_p + pb * PBUF + t_src;
                 float d[6][6];
 #pragma unroll
@@ -180,11 +183,11 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
             u4 bq[WH_BR][2];
 #pragma unroll
             for (int p = 0; p < WH_BR; ++p) {
-                bq[p][0] = up[(int64_t)((kq * 36 + 2 * p) * NG) * 64];
-                bq[p][1] = up[(int64_t)((kq * 36 + 2 * p + 1) * NG) * 64];
+                bq[p][0] = up[(DBG & 1) ? 0 : (int64_t)((kq * 36 + 2 * p) * NG) * 64];
+                bq[p][1] = up[(DBG & 1) ? 0 : (int64_t)((kq * 36 + 2 * p + 1) * NG) * 64];
             }
 #pragma unroll
-            for (int p = 0; p < 18; ++p) {
+            for (int p = 0; p < ((DBG & 4) ? 1 : 18); ++p) {
                 const u4 a0 = *(const u4 *)(a_src + (2 * p) * NT * WH_VS);
                 const u4 a1 = *(const u4 *)(a_src + (2 * p + 1) * NT * WH_VS);
                 const u4 b0 = bq[p % WH_BR][0], b1 = bq[p % WH_BR][1];
@@ -202,12 +205,20 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
                 acc[2 * p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0, __builtin_bit_cast(h8, l0), acc[2 * p], 0, 0, 0);
                 acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1, __builtin_bit_cast(h8, l1), acc[2 * p + 1], 0, 0, 0);
                 if (p + WH_BR < 18) {
-                    bq[p % WH_BR][0] = up[(int64_t)((kq * 36 + 2 * (p + WH_BR)) * NG) * 64];
-                    bq[p % WH_BR][1] = up[(int64_t)((kq * 36 + 2 * (p + WH_BR) + 1) * NG) * 64];
+                    bq[p % WH_BR][0] = up[(DBG & 1) ? 0 : (int64_t)((kq * 36 + 2 * (p + WH_BR)) * NG) * 64];
+                    bq[p % WH_BR][1] = up[(DBG & 1) ? 0 : (int64_t)((kq * 36 + 2 * (p + WH_BR) + 1) * NG) * 64];
                 }
                 __builtin_amdgcn_sched_barrier(0);                  // keep the ring WH_BR deep: no hoisting of later loads
             }
-            if (kq == 3) {
+            if (kq == 3 && (DBG & 16)) {
+                f4 t = acc[0];
+#pragma unroll
+                for (int xi = 1; xi < 36; ++xi) t += acc[xi];
+                if (t.x + t.y + t.z + t.w == 1.2345e-30f) y[0] = t.x;       // keeps the accumulators live
+#pragma unroll
+                for (int xi = 0; xi < 36; ++xi) acc[xi] = (f4)(0.0f);
+            }
+            if (kq == 3 && !(DBG & 16)) {
                 // ---- output transform: lane (r16, g) holds M_xi[tile (g, v)][channel co] in acc[xi][v].  32-bit element
                 // offsets inside the image (H W COUT < 2^31), one wave-uniform test for blocks that lie inside the map
                 float *yb = y + (int64_t)o_img * Ho * Wo * COUT + co;
@@ -304,15 +315,28 @@ static int launch_fused_h(const float *d_x, const unsigned *d_Uh, const float *d
         HIP_TRY(hipMemset(zero16, 0, 256));
         zero_dev = dev;
     }
-#define WH_LAUNCH(R, P) do { \
-        HIP_TRY(hipFuncSetAttribute((const void *)wino4_fused_c64_h_kernel<COUT, R, P>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
-        hipLaunchKernelGGL((wino4_fused_c64_h_kernel<COUT, R, P>), grid, block, lds, st, d_x, d_Uh, d_bias, d_res, \
+    const char *dbg_env = getenv("CSLAM_WFH_DBG");                  // timing-only ablations, relu + pool form only
+    const int dbg = dbg_env ? atoi(dbg_env) : 0;
+#define WH_LAUNCH_D(R, P, D) do { \
+        HIP_TRY(hipFuncSetAttribute((const void *)wino4_fused_c64_h_kernel<COUT, R, P, D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+        hipLaunchKernelGGL((wino4_fused_c64_h_kernel<COUT, R, P, D>), grid, block, lds, st, d_x, d_Uh, d_bias, d_res, \
                            H, W, gxs, gyb, (int)nsb, d_amax, inv_su, d_amax_out, zero16, d_y); } while (0)
+#define WH_LAUNCH(R, P) WH_LAUNCH_D(R, P, 0)
+    if (dbg && relu) {
+        if (pool) { switch (dbg) { case 1: WH_LAUNCH_D(true, true, 1); break; case 2: WH_LAUNCH_D(true, true, 2); break; case 4: WH_LAUNCH_D(true, true, 4); break;
+                                   case 5: WH_LAUNCH_D(true, true, 5); break; case 8: WH_LAUNCH_D(true, true, 8); break; case 16: WH_LAUNCH_D(true, true, 16); break;
+                                   case 6: WH_LAUNCH_D(true, true, 6); break; default: WH_LAUNCH_D(true, true, 31); } }
+        else { switch (dbg) { case 1: WH_LAUNCH_D(true, false, 1); break; case 2: WH_LAUNCH_D(true, false, 2); break; case 4: WH_LAUNCH_D(true, false, 4); break;
+                              case 5: WH_LAUNCH_D(true, false, 5); break; case 8: WH_LAUNCH_D(true, false, 8); break; case 16: WH_LAUNCH_D(true, false, 16); break;
+                              case 6: WH_LAUNCH_D(true, false, 6); break; default: WH_LAUNCH_D(true, false, 31); } }
+        return CSLAM_OK;
+    }
     if (relu && pool) WH_LAUNCH(true, true);
     else if (relu) WH_LAUNCH(true, false);
     else if (pool) WH_LAUNCH(false, true);
     else WH_LAUNCH(false, false);
 #undef WH_LAUNCH
+#undef WH_LAUNCH_D
     return CSLAM_OK;
 }
 

@@ -38,6 +38,7 @@ extern "C" {
 #define CSLAM_E_HIP (-2)      /* HIP runtime error (message in cslam_last_error) */
 #define CSLAM_E_NOMEM (-3)
 #define CSLAM_E_DIM (-4)      /* descriptor dimension mismatch */
+#define CSLAM_E_UNSUPPORTED (-5) /* an optional run-time dependency (RCCL) is not available on this host */
 
 #define CSLAM_F32 0
 #define CSLAM_F64 1
@@ -48,6 +49,7 @@ extern "C" {
 #define CSLAM_MODE_MFMA 2  /* fp32-MFMA candidates + fp64 re-score + certificate (+ scan fallback) */
 
 typedef struct cslam_bank cslam_bank_t;
+typedef struct cslam_comm cslam_comm_t;   /* one rank of the multi-GPU exchange (RCCL communicator), see the end of the file */
 
 const char *cslam_last_error(void);
 int cslam_version(void);
@@ -333,6 +335,26 @@ int cslam_wino4_fused_c64_h_dev(const float *d_x, const void *d_Uh, const float 
  * the first trunk layer feeds the scale of the fused fp16 layer behind it without a separate pass over its output. */
 int cslam_conv3x3_c3_amax_dev(const float *d_x, const float *d_wt, const float *d_bias, int B, int H, int W, int Cout,
                               int relu, float *d_y, unsigned *d_amax_out, void *stream);
+
+/* ---- multi-GPU exchange (csrc/comm.hip): RCCL over xGMI, one process per GPU ---------------------------------------
+ * Replaces, inside one node, the ROS 2 transport of descriptors between robots
+ * (cslam/global_descriptor_loop_closure_detection.py:198-227 publish GlobalDescriptors, :407-422 receive): rank g owns
+ * robot g's bank (BASELINE config 4) or a row shard of ONE bank (the metric's bank at N > 1 GPUs).  Per step: ONE
+ * all-gather of the new descriptors; every rank searches all of them in its bank (cslam_bank_search_dev); for a
+ * row-sharded bank ONE all-to-all returns the (rows | score bits | count) lists to the keyframes' owners, who merge them
+ * with cslam_topk_merge_dev.  cslam_amd/sharded.py is the Python twin over torch.distributed.
+ * RCCL is looked up at run time (dlopen); without it these return CSLAM_E_UNSUPPORTED and nothing else is affected.
+ *   cslam_comm_unique_id   rank 0: 128 bytes to hand to every rank (file, socket, launcher environment ...)
+ *   cslam_comm_init        collective over all `world` processes; `device` = this rank's HIP device
+ *   cslam_allgather_queries_dev  d_local [rows][row_bytes] -> d_all [world * rows][row_bytes], rank-major, on `stream`
+ *   cslam_exchange_lists_dev     slice r of d_send [world][bytes_per_rank] goes to rank r; slice s of d_recv came from s */
+int cslam_comm_unique_id(void *id128);
+int cslam_comm_init(int world, int rank, const void *id128, int device, cslam_comm_t **out);
+int cslam_comm_destroy(cslam_comm_t *comm);
+int cslam_comm_info(const cslam_comm_t *comm, int *world, int *rank);
+int cslam_allgather_queries_dev(cslam_comm_t *comm, const void *d_local, int64_t rows, int64_t row_bytes, void *d_all,
+                                void *stream);
+int cslam_exchange_lists_dev(cslam_comm_t *comm, const void *d_send, void *d_recv, int64_t bytes_per_rank, void *stream);
 
 /* ---- diagnostics: in-run re-measurement of the peaks rooflines are priced against (csrc/peaks.hip) ---------------
  * Not on the extract / match path and without a reference counterpart: bench.py reports every roofline fraction against

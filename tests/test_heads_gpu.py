@@ -497,7 +497,8 @@ def test_fused_winograd_h_scales_shortcut_and_amax(T, cout, B, H, W, pool, amp):
     """cslam_wino4_fused_c64_h_dev called directly: activations six decades apart (the power-of-two scale from the max |x|
     slot), the max |y| slot it writes (a bound of the pre-pool maximum, as the output transform's), the shortcut add of the
     non-pooled form, and max |y| out of the first-layer kernel feeding it."""
-    torch, _lib = T
+    torch, _ = T
+    from cslam_amd import _lib
     from cslam_amd.vpr import winograd as wg
     lib = _lib.load()
     import ctypes as C

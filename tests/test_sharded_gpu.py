@@ -63,3 +63,32 @@ def test_two_processes_row_sharded_bank_on_one_gpu(tmp_path):
         oi, os_, oc = pyoracle.nns_search(whole, q, K)
         got = np.load(tmp_path / f"g{r}.npz")
         assert_topk_equal(got["rows"], got["sims"], got["cnt"], oi, os_, oc, 1e-12)
+
+
+def test_c_abi_exchange_single_rank():
+    """cslam_comm_* / cslam_allgather_queries_dev / cslam_exchange_lists_dev (csrc/comm.hip): the C-ABI twin of the two
+    collectives of cslam_amd/sharded.py.  A 1-GPU box can only form a one-rank RCCL communicator, where both collectives
+    are copies; the N-rank forms run on the driver's 8-GPU node through bench.py (torch.distributed, same RCCL)."""
+    import ctypes as C
+    import torch
+    from cslam_amd import _lib
+    lib = _lib.load()
+    ident = (C.c_char * 128)()
+    _lib.check(lib.cslam_comm_unique_id(ident))
+    comm = C.c_void_p()
+    _lib.check(lib.cslam_comm_init(1, 0, ident, 0, C.byref(comm)))
+    w, r = C.c_int(-1), C.c_int(-1)
+    _lib.check(lib.cslam_comm_info(comm, C.byref(w), C.byref(r)))
+    assert (w.value, r.value) == (1, 0)
+    q = torch.randn((33, 4096), device="cuda")
+    allq = torch.zeros_like(q)
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.cslam_allgather_queries_dev(comm, C.c_void_p(q.data_ptr()), 33, 4096 * 4, C.c_void_p(allq.data_ptr()), st))
+    lists = torch.randint(0, 2 ** 40, (1, 33, 11), device="cuda", dtype=torch.int64)
+    got = torch.zeros_like(lists)
+    _lib.check(lib.cslam_exchange_lists_dev(comm, C.c_void_p(lists.data_ptr()), C.c_void_p(got.data_ptr()), 33 * 11 * 8, st))
+    torch.cuda.synchronize()
+    assert torch.equal(allq, q) and torch.equal(got, lists)
+    _lib.check(lib.cslam_comm_destroy(comm))
+    # wrong rank is refused before RCCL is asked
+    assert lib.cslam_comm_init(2, 2, ident, 0, C.byref(comm)) != 0
