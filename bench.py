@@ -264,16 +264,22 @@ def main():
     # the same leg AND the same whole step with the trunk's GEMMs as plain fp32 (rocBLAS sgemm) instead of the default
     # split-fp16 pairs (fp32-grade either way): reported beside `extract_only` / `value`, N = 1 only
     extract_fp32_gemms = value_fp32_gemms = None
-    split16 = os.environ.get("CSLAM_WINO_SPLIT16", "256")
+    split16 = os.environ.get("CSLAM_WINO_SPLIT16", "128")
     if extractor is not None and world == 1 and extractor.backbone_conv == "winograd" and split16 != "0":
-        os.environ["CSLAM_WINO_SPLIT16"] = "0"
+        saved = {k: os.environ.get(k) for k in ("CSLAM_WINO_SPLIT16", "CSLAM_WINO_FUSED_H")}
+        os.environ["CSLAM_WINO_SPLIT16"] = "0"          # library sgemm between the transforms
+        os.environ["CSLAM_WINO_FUSED_H"] = "0"          # conv1_2 / conv2_1 on the f32-input MFMA
         try:
             ex32 = NetVLAD({"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376,
                             "frontend.netvlad.pca_dim": a.dim, "frontend.random_seed": 0,
                             "frontend.backbone_conv": a.backbone_conv}, None)
             ex32.compute_embeddings_device(frames[:a.extract_chunk], bdt)
         finally:
-            os.environ["CSLAM_WINO_SPLIT16"] = split16
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
 
         def extract32():
             return torch.cat([ex32.compute_embeddings_device(frames[s_:s_ + a.extract_chunk], bdt)
@@ -355,9 +361,41 @@ def main():
                             "frac_of_measured": round(gbs / peaks["hbm_copy_GBs"], 4) if peaks["hbm_copy_GBs"] else None,
                             "traffic": etraffic, "traffic_source": esrc, "algorithmic_bytes": nbytes,
                             "kernel_ms": round(ms, 3), "shape": shape_in,
-                            "note": "largest hand-written kernel of the extract leg; the 36 GEMMs between the "
-                                    "transforms are rocBLAS"}
+                            "note": "fp32 input transform on conv2_2's shape (the round-1 reference point); the trunk "
+                                    "now runs wino4_input_h2_kernel + wino_gemm_h2_kernel there (pair_gemm below)"}
         del xt, vt
+        # this library's split-fp16 GEMM between the transforms (csrc/wino_gemm.hip), on the two regimes of the trunk:
+        # conv2_2 (128 -> 128 channels, 200704 tile rows: HBM-bound, V2 in + M out) and conv4_2 (512 -> 512, 12544 rows:
+        # the matrix pipe matters; 3 fp16 MFMA products per fp32-grade product)
+        def time_ms(fn, n=5):
+            fn()
+            e0.record()
+            for _ in range(n):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / n
+        gem = {}
+        for tag, hw, cin, cout in (("conv2_2", 112, 128, 128), ("conv4_2", 28, 512, 512)):
+            T_ = eb * (hw // 4) * (hw // 4)
+            v2 = (torch.randn((36 * T_ * 2 * cin,), device=dev) * 100.0).to(torch.float16)
+            u2 = (torch.randn((36 * cout * 2 * cin,), device=dev) * 100.0).to(torch.float16)
+            mo = torch.empty((36, T_, cout), device=dev)
+            gms = time_ms(lambda: _lib.check(lib.cslam_wino_gemm_h2_dev(v2.data_ptr(), u2.data_ptr(), T_, cin, cout,
+                                                                        mo.data_ptr(), st)))
+            gb = 36.0 * T_ * (cin + cout) * 4 + 36.0 * cin * cout * 4
+            fl16 = 3 * 2.0 * 36 * T_ * cin * cout
+            gem[tag] = {"kernel": "wino_gemm_h2_kernel", "shape": f"36 x [{T_},{cin}] x [{cin},{cout}]", "kernel_ms": round(gms, 3),
+                        "hbm": {"achieved": round(gb / gms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": round(gb / gms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes": gb,
+                                "frac_of_measured": round(gb / gms / 1e6 / peaks["hbm_copy_GBs"], 4)},
+                        "mfma": {"achieved": round(fl16 / gms / 1e9, 1), "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (fp16, 3 products)",
+                                 "frac": round(fl16 / gms / 1e9 / FP16_MFMA_PEAK_TFLOPS, 4),
+                                 "frac_of_measured": round(fl16 / gms / 1e9 / peaks["mfma_f16_TFLOPs"], 4),
+                                 "fp32_equivalent_TFLOPs": round(fl16 / 3 / gms / 1e9, 1)},
+                        "bound": "hbm" if tag == "conv2_2" else "mfma"}
+            del v2, u2, mo
+        extract_roofline["pair_gemm"] = gem
         # the largest single kernel of the extract leg: the one-kernel Winograd form of conv1_2 (csrc/wino_fused.hip),
         # MFMA-bound; algorithmic flop = 36 frequencies x 2*64*64 per 4x4-pixel tile
         fh = 224
@@ -472,9 +510,10 @@ def main():
             "backbone_conv": None if extractor is None else extractor.backbone_conv,
             "trunk_gemm": None if extractor is None or extractor.backbone_conv != "winograd" else (
                 "plain fp32 (rocBLAS sgemm)" if split16 == "0" else
-                "layers from %s input channels on: exact fp16 hi/lo pairs of both operands, 3 of the 4 partial products in ONE "
-                "fp16-MFMA GEMM with fp32 accumulation (error vs float64 = that of the fp32 GEMM, tests/test_heads_gpu.py::"
-                "test_split16_*); the others fp32" % split16),
+                "conv2_2 ... conv5_3 (from 128 input channels on): this library's GEMM (csrc/wino_gemm.hip) over exact fp16 hi/lo "
+                "pairs of both operands, 3 of the 4 partial products on the fp16 MFMA pipe with fp32 accumulation (error vs "
+                "float64 = that of the fp32 GEMM, tests/test_heads_gpu.py::test_split16_*, tests/test_wino_gemm_gpu.py); "
+                "conv1_2 / conv2_1: one-kernel Winograd convolutions on fp16 pairs (csrc/wino_fused_h.hip)"),
             "extract_only_fp32_gemms": None if extract_fp32_gemms is None else round(extract_fp32_gemms, 2),
             "match_only": round(match_only, 2),
             "match_only_queries": nqm,

@@ -35,9 +35,8 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
                                        // transform's ds_read_b32 of two tiles of a 32-lane group then collide 2-way)
 #define WH_VS 16                       // V row = 16 dwords (16 channels x [hi | lo]), 16-byte groups rotated by (tile & 15) >> 1
 #define WH_VSW(tile, grp) (4 * (((((tile) & 15) >> 1) + (grp)) & 3))
-#ifndef WH_BR
-#define WH_BR 3                        // weight fragments in flight, in pairs of frequencies
-#endif
+#define WH_BR_DEFAULT 3                // weight fragments in flight, in pairs of frequencies (template parameter WH_BR;
+                                       // CSLAM_WFH_BR = 2 | 4 selects the other instantiations for experiments)
 
 __device__ __forceinline__ void wh_glds16(const float *g, float *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
@@ -74,7 +73,7 @@ __device__ __forceinline__ unsigned wh_pack(float v) {                    // [fp
 
 // DBG: timing-only ablations (wrong results), CSLAM_WFH_DBG: 1 = every weight fragment from ONE address (L1 hits: no L2
 // latency), 2 = no input transform, 4 = no MFMAs, 8 = no patch loads after the first, 16 = no output transform / stores
-template <int COUT, bool RELU, bool POOL, int DBG>
+template <int COUT, bool RELU, bool POOL, int DBG, int WH_BR>
 __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
     const float *__restrict__ x, const unsigned *__restrict__ Uh, const float *__restrict__ bias,
     const float *__restrict__ res, int H, int W, int gxs, int gyb, int nsb, const unsigned *__restrict__ amax_in,
@@ -143,24 +142,40 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
     float my_amax = 0.0f;
 
     const int n_mine = (nsb - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int total_q = 4 * n_mine;                                 // quarters this workgroup walks
+    // The patch of quarter Q + 2 is requested at the END of the MFMAs of quarter Q (its buffer, that of quarter Q, was
+    // consumed by Q's transform), BEHIND the first weight fragments of quarter Q + 1: a wave's loads return in order, so
+    // anything issued after an HBM-latency LDS-DMA waits for it -- with the patch requested at the top of a quarter every
+    // weight fragment of that quarter queued behind it (0.4 ms of 2.6 on conv1_2, profiles/r02_v5_fused_h_ablation.log).
+    int l_q = 0;                                                    // next quarter to request
+    int n_img = 0, n_by = 0, n_sx = 0;                              // block the loader has most recently moved to
+    auto request_next = [&]() {
+        if (l_q < total_q && !((DBG & 8) && l_q >= 2)) {
+            if ((l_q & 3) == 0) {
+                geometry((int)blockIdx.x + (l_q >> 2) * (int)gridDim.x);
+                n_img = c_img; n_by = c_by; n_sx = c_sx;
+            }
+            fetch(l_q & 1, l_q & 3);
+        }
+        ++l_q;
+    };
     if (n_mine > 0) {
-        geometry((int)blockIdx.x);
-        fetch(0, 0);
+        request_next();
+        request_next();
+    }
+    int o_img = n_img, o_by = n_by, o_sx = n_sx;                    // block of iteration 0
+    u4 bq[WH_BR][2];
+#pragma unroll
+    for (int p = 0; p < WH_BR; ++p) {
+        bq[p][0] = up[(int64_t)((2 * p) * NG) * 64];
+        bq[p][1] = up[(int64_t)((2 * p + 1) * NG) * 64];
     }
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
-    int pb = 0;                                                     // patch buffer holding the current quarter
     for (int it = 0; it < n_mine; ++it) {
-        const int o_img = c_img, o_by = c_by, o_sx = c_sx;          // this iteration's block (the loader moves on in quarter 3)
 #pragma unroll 1
         for (int kq = 0; kq < 4; ++kq) {
-            // the next quarter's patch (of this iteration, or quarter 0 of the next one) -> the other buffer, in flight
-            // during the transform and the MFMAs of this quarter
-            {
-                const bool more = kq < 3 || it + 1 < n_mine;
-                if (kq == 3 && more) geometry((int)blockIdx.x + (it + 1) * (int)gridDim.x);
-                if (more && !(DBG & 8)) fetch(pb ^ 1, (kq + 1) & 3);
-            }
+            const int pb = kq & 1;                                  // 4 quarters per iteration: the buffer parity is kq's
             // (b) V = B^T (sV d) B, split into fp16 pairs
             if (t_on && !(DBG & 2)) {
                 const float *src = s_p + pb * PBUF + t_src;
@@ -178,14 +193,14 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
 #pragma unroll
                     for (int j = 0; j < 6; ++j) s_v[(6 * i + j) * NT * WH_VS + t_dst] = wh_pack(d[i][j]);
             }
-            __syncthreads();
-            // (c) 36 frequencies x 2 MFMAs, weight fragments WH_BR pairs ahead
-            u4 bq[WH_BR][2];
-#pragma unroll
-            for (int p = 0; p < WH_BR; ++p) {
-                bq[p][0] = up[(DBG & 1) ? 0 : (int64_t)((kq * 36 + 2 * p) * NG) * 64];
-                bq[p][1] = up[(DBG & 1) ? 0 : (int64_t)((kq * 36 + 2 * p + 1) * NG) * 64];
-            }
+            // V complete: LDS stores drained, then a RAW barrier -- __syncthreads() would also wait for the LDS-DMA of the
+            // next patch (a pending LDS write), which is meant to stay in flight across this barrier
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0) only
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            // (c) 36 frequencies x 2 MFMAs, weight fragments WH_BR pairs ahead (the first WH_BR pairs were requested at the
+            // end of the previous quarter)
 #pragma unroll
             for (int p = 0; p < ((DBG & 4) ? 1 : 18); ++p) {
                 const u4 a0 = *(const u4 *)(a_src + (2 * p) * NT * WH_VS);
@@ -209,6 +224,16 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
                     bq[p % WH_BR][1] = up[(DBG & 1) ? 0 : (int64_t)((kq * 36 + 2 * (p + WH_BR) + 1) * NG) * 64];
                 }
                 __builtin_amdgcn_sched_barrier(0);                  // keep the ring WH_BR deep: no hoisting of later loads
+            }
+            // first weight fragments of the next quarter, THEN the patch of the quarter after it (see request_next)
+            {
+                const int nkq = (kq + 1) & 3;
+#pragma unroll
+                for (int p = 0; p < WH_BR; ++p) {                  // every ring slot is free here: pair p of the next quarter -> slot p
+                    bq[p][0] = up[(DBG & 1) ? 0 : (int64_t)((nkq * 36 + 2 * p) * NG) * 64];
+                    bq[p][1] = up[(DBG & 1) ? 0 : (int64_t)((nkq * 36 + 2 * p + 1) * NG) * 64];
+                }
+                request_next();                                     // quarter 4 it + kq + 2 (at kq = 2 the loader moves to the next block)
             }
             if (kq == 3 && (DBG & 16)) {
                 f4 t = acc[0];
@@ -236,46 +261,58 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
                     const int oy0 = (o_by * 4 + g) * 4, ox0 = (bx * 4 + v) * 4;
                     const int e00 = (oy0 * W + ox0) * COUT;         // element offset of the tile's first pixel (unpooled map)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < 4; ++i)
                         wh_at(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o[i][0], o[i][1], o[i][2], o[i][3]);
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) {
-                            const bool in = inside || (oy0 + i < H && ox0 + jj < W);
-                            o[i][jj] = o[i][jj] * inv + bv;                       // exact power-of-two rescale, then bias
-                            if (!POOL && rb && in) o[i][jj] += rb[e00 + (i * W + jj) * COUT];
-                            if (RELU) o[i][jj] = fmaxf(o[i][jj], 0.0f);
-                            if (in) my_amax = fmaxf(my_amax, fabsf(o[i][jj]));
-                        }
-                    }
                     if (POOL) {
+                        // 2 x 2 maximum FIRST, then rescale, bias, ReLU on the 4 survivors instead of all 16: the rescale is a
+                        // multiplication by a positive power of two (exact, monotone) and x -> x + b rounds monotonically, so
+                        // max(a s + b, c s + b) == max(a, c) s + b bit for bit, and ReLU commutes with max.  The maximum of
+                        // the pooled values is exactly max |next layer's input|.
                         const int p00 = ((oy0 >> 1) * Wo + (ox0 >> 1)) * COUT;
 #pragma unroll
                         for (int i = 0; i < 2; ++i)
 #pragma unroll
                             for (int jj = 0; jj < 2; ++jj) {
-                                const float m = fmaxf(fmaxf(o[2 * i][2 * jj], o[2 * i][2 * jj + 1]),
-                                                      fmaxf(o[2 * i + 1][2 * jj], o[2 * i + 1][2 * jj + 1]));
-                                if (inside || ((oy0 >> 1) + i < Ho && (ox0 >> 1) + jj < Wo)) yb[p00 + (i * Wo + jj) * COUT] = m;
+                                float m = fmaxf(fmaxf(o[2 * i][2 * jj], o[2 * i][2 * jj + 1]),
+                                                fmaxf(o[2 * i + 1][2 * jj], o[2 * i + 1][2 * jj + 1]));
+                                m = m * inv + bv;
+                                if (RELU) m = fmaxf(m, 0.0f);
+                                if (inside || ((oy0 >> 1) + i < Ho && (ox0 >> 1) + jj < Wo)) {
+                                    my_amax = fmaxf(my_amax, fabsf(m));
+                                    yb[p00 + (i * Wo + jj) * COUT] = m;
+                                }
                             }
                     } else {
 #pragma unroll
                         for (int i = 0; i < 4; ++i)
 #pragma unroll
-                            for (int jj = 0; jj < 4; ++jj)
-                                if (inside || (oy0 + i < H && ox0 + jj < W)) yb[e00 + (i * W + jj) * COUT] = o[i][jj];
+                            for (int jj = 0; jj < 4; ++jj) {
+                                const bool in = inside || (oy0 + i < H && ox0 + jj < W);
+                                o[i][jj] = o[i][jj] * inv + bv;                   // exact power-of-two rescale, then bias
+                                if (rb && in) o[i][jj] += rb[e00 + (i * W + jj) * COUT];
+                                if (RELU) o[i][jj] = fmaxf(o[i][jj], 0.0f);
+                                if (in) {
+                                    my_amax = fmaxf(my_amax, fabsf(o[i][jj]));
+                                    yb[e00 + (i * W + jj) * COUT] = o[i][jj];
+                                }
+                            }
                     }
                 }
 #pragma unroll
                 for (int xi = 0; xi < 36; ++xi) acc[xi] = (f4)(0.0f);
             }
-            __builtin_amdgcn_s_waitcnt(0);                          // the other patch buffer has landed (and the stores drained)
-            __syncthreads();                                        // V is free again, the next patch visible to everyone
-            pb ^= 1;
+            // The patch of the NEXT quarter was requested one quarter ago, ahead of every weight fragment this quarter used:
+            // loads return in order, so it has landed in this wave; the barrier makes that true for all waves.  (Still
+            // outstanding, deliberately: the weight fragments and the patch requested just above.)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_s_barrier();                           // V is free again, the next patch visible to everyone
+            asm volatile("" ::: "memory");
         }
+        o_img = n_img; o_by = n_by; o_sx = n_sx;
     }
     if (amax_out) {
-        // max |y| of everything this workgroup wrote (pre-pool values bound the pooled ones): wave maximum, LDS maximum,
-        // one global atomic per workgroup and only if it would raise the slot
+        // max |y| of everything this workgroup wrote: wave maximum, LDS maximum, one global atomic per workgroup and only if
+        // it would raise the slot
         unsigned *s_amax = s_v;                                     // V is no longer needed
         if (tid == 0) *s_amax = 0u;
         __syncthreads();
@@ -317,11 +354,14 @@ static int launch_fused_h(const float *d_x, const unsigned *d_Uh, const float *d
     }
     const char *dbg_env = getenv("CSLAM_WFH_DBG");                  // timing-only ablations, relu + pool form only
     const int dbg = dbg_env ? atoi(dbg_env) : 0;
-#define WH_LAUNCH_D(R, P, D) do { \
-        HIP_TRY(hipFuncSetAttribute((const void *)wino4_fused_c64_h_kernel<COUT, R, P, D>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
-        hipLaunchKernelGGL((wino4_fused_c64_h_kernel<COUT, R, P, D>), grid, block, lds, st, d_x, d_Uh, d_bias, d_res, \
+#define WH_LAUNCH_DB(R, P, D, BR) do { \
+        HIP_TRY(hipFuncSetAttribute((const void *)wino4_fused_c64_h_kernel<COUT, R, P, D, BR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+        hipLaunchKernelGGL((wino4_fused_c64_h_kernel<COUT, R, P, D, BR>), grid, block, lds, st, d_x, d_Uh, d_bias, d_res, \
                            H, W, gxs, gyb, (int)nsb, d_amax, inv_su, d_amax_out, zero16, d_y); } while (0)
-#define WH_LAUNCH(R, P) WH_LAUNCH_D(R, P, 0)
+#define WH_LAUNCH_D(R, P, D) WH_LAUNCH_DB(R, P, D, WH_BR_DEFAULT)
+    const char *br_env = getenv("CSLAM_WFH_BR");
+    const int br = br_env ? atoi(br_env) : WH_BR_DEFAULT;
+#define WH_LAUNCH(R, P) do { if (br == 2) WH_LAUNCH_DB(R, P, 0, 2); else if (br == 4) WH_LAUNCH_DB(R, P, 0, 4); else WH_LAUNCH_DB(R, P, 0, WH_BR_DEFAULT); } while (0)
     if (dbg && relu) {
         if (pool) { switch (dbg) { case 1: WH_LAUNCH_D(true, true, 1); break; case 2: WH_LAUNCH_D(true, true, 2); break; case 4: WH_LAUNCH_D(true, true, 4); break;
                                    case 5: WH_LAUNCH_D(true, true, 5); break; case 8: WH_LAUNCH_D(true, true, 8); break; case 16: WH_LAUNCH_D(true, true, 16); break;
@@ -337,6 +377,7 @@ static int launch_fused_h(const float *d_x, const unsigned *d_Uh, const float *d
     else WH_LAUNCH(false, false);
 #undef WH_LAUNCH
 #undef WH_LAUNCH_D
+#undef WH_LAUNCH_DB
     return CSLAM_OK;
 }
 

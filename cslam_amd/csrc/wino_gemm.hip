@@ -409,9 +409,11 @@ CSLAM_API int cslam_wino_gemm_h2_dev(const void *d_V2, const void *d_U2, int64_t
     const int dbg = e ? atoi(e) : 0;            // timing-only ablations
     const int cfg = c ? atoi(c) : 0;            // force a tile / ring shape (1..4 below); 0 = default
     hipStream_t st = (hipStream_t)stream;
+    // default: 256 x 128 tiles with the ring of three stages -- the fastest or within 4 % of the fastest shape on every
+    // layer of the VGG-16 trunk at the 256-frame chunk (interleaved medians, profiles/r02_v4_perf_wino_gemm.log)
     const bool wide = (Cout % 256) == 0;
     int use = cfg;
-    if (use < 1 || use > 4 || ((use == 1 || use == 3) && !wide)) use = wide ? 1 : 2;
+    if (use < 1 || use > 4 || ((use == 1 || use == 3) && !wide)) use = 2;
     switch (use) {
     case 1: return wino_gemm_launch<256, 256, 2>(a, dbg, st);      // double buffer, 256 x 256
     case 2: return wino_gemm_launch<256, 128, 3>(a, dbg, st);      // ring of 3, 256 x 128
