@@ -396,35 +396,35 @@ def main():
                         "bound": "hbm" if tag == "conv2_2" else "mfma"}
             del v2, u2, mo
         extract_roofline["pair_gemm"] = gem
-        # the largest single kernel of the extract leg: the one-kernel Winograd form of conv1_2 (csrc/wino_fused.hip),
-        # MFMA-bound; algorithmic flop = 36 frequencies x 2*64*64 per 4x4-pixel tile
+        # the largest single kernel of the extract leg: the one-kernel Winograd convolution conv1_2 in its fp16-pair form
+        # (csrc/wino_fused_h.hip).  Its floor is what it moves: activation in + pooled activation out (HBM); the matrix
+        # work is 3 fp16 products' worth folded into 2 MFMAs per frequency and quarter
         fh = 224
-        xf = torch.randn((eb, fh, fh, 64), device=dev)
-        upf = torch.randn((4, 36, 4, 4, 16, 4), device=dev)
+        xf = torch.relu(torch.randn((eb, 64, fh, fh), device=dev)).contiguous(memory_format=torch.channels_last)
+        from cslam_amd.vpr import winograd as wg
+        wf = torch.randn((64, 64, 3, 3), device=dev) / 24.0
+        U4f = wg.wino_weights(wf, 4).to(dev)
+        Uhf, Upf = wg.fused64_pair_weights(U4f), wg.fused64_weights(U4f)
         bf = torch.randn(64, device=dev)
-        yf = torch.empty((eb, fh // 2, fh // 2, 64), device=dev)
-
-        def fused():
-            _lib.check(lib.cslam_wino4_fused_c64_dev(xf.data_ptr(), upf.data_ptr(), bf.data_ptr(), None, eb, fh, fh, 64,
-                                                     1, 1, yf.data_ptr(), st))
-        fused()
-        e0.record()
-        for _ in range(5):
-            fused()
-        e1.record()
-        torch.cuda.synchronize()
-        fms = e0.elapsed_time(e1) / 5
+        slot = torch.zeros(1, dtype=torch.float32, device=dev)
+        _lib.check(lib.cslam_absmax_dev(xf.data_ptr(), xf.numel(), slot.data_ptr(), st))
+        fms = time_ms(lambda: wg.wino_fused64_h(xf, Uhf, bf, True, True, slot, None))
+        fms32 = time_ms(lambda: wg.wino_fused64(xf, Upf, bf, True, True))
         fflop = eb * (fh // 4) * (fh // 4) * 36 * 2 * 64 * 64
+        fbytes = (xf.numel() + xf.numel() // 4) * 4
+        shape_f = f"x [{eb},{fh},{fh},64] -> conv 64->64 + bias + ReLU + MaxPool2d"
+        pf = pmc_entry("wino4_fused_c64_h_kernel/conv1_2", shape=shape_f)
         extract_roofline["fused_conv"] = {
-            "bound": "mfma", "kernel": "wino4_fused_c64_pipe_kernel", "achieved": round(fflop / fms / 1e9, 1),
-            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(fflop / fms / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4),
-            "kernel_ms": round(fms, 3), "algorithmic_flop": fflop,
-            "traffic": (pmc_entry("wino4_fused_c64_pipe_kernel", shape=f"x [{eb},{fh},{fh},64] -> conv 64->64 + bias + ReLU + MaxPool2d") or {}).get("traffic_bytes"),
-            "algorithmic_bytes": (xf.numel() + yf.numel()) * 4,
-            "peak_measured": peaks["mfma_f32_TFLOPs"],
-            "frac_of_measured": round(fflop / fms / 1e9 / peaks["mfma_f32_TFLOPs"], 4) if peaks["mfma_f32_TFLOPs"] else None,
-            "shape": f"x [{eb},{fh},{fh},64] -> conv 64->64 + bias + ReLU + MaxPool2d -> [{eb},{fh // 2},{fh // 2},64]"}
-        del xf, yf
+            "bound": "hbm", "kernel": "wino4_fused_c64_h_kernel", "achieved": round(fbytes / fms / 1e6, 1),
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fbytes / fms / 1e6 / HBM_PEAK_GBS, 4),
+            "peak_measured": peaks["hbm_copy_GBs"], "frac_of_measured": round(fbytes / fms / 1e6 / peaks["hbm_copy_GBs"], 4),
+            "kernel_ms": round(fms, 3), "algorithmic_bytes": fbytes, "traffic": pf["traffic_bytes"] if pf else None,
+            "traffic_source": pf["source"] if pf else None,
+            "fp32_equivalent_TFLOPs": round(fflop / fms / 1e9, 1),
+            "f32_mfma_form_ms": round(fms32, 3),
+            "f32_mfma_form_frac_of_f32_mfma_peak": round(fflop / fms32 / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4),
+            "shape": shape_f + f" -> [{eb},{fh // 2},{fh // 2},64]"}
+        del xf
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -35,7 +35,7 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
                                        // transform's ds_read_b32 of two tiles of a 32-lane group then collide 2-way)
 #define WH_VS 16                       // V row = 16 dwords (16 channels x [hi | lo]), 16-byte groups rotated by (tile & 15) >> 1
 #define WH_VSW(tile, grp) (4 * (((((tile) & 15) >> 1) + (grp)) & 3))
-#define WH_BR_DEFAULT 3                // weight fragments in flight, in pairs of frequencies (template parameter WH_BR;
+#define WH_BR_DEFAULT 2                // weight fragments in flight, in pairs of frequencies (template parameter WH_BR;
                                        // CSLAM_WFH_BR = 2 | 4 selects the other instantiations for experiments)
 
 __device__ __forceinline__ void wh_glds16(const float *g, float *lds_wave_base) {
@@ -73,7 +73,7 @@ __device__ __forceinline__ unsigned wh_pack(float v) {                    // [fp
 
 // DBG: timing-only ablations (wrong results), CSLAM_WFH_DBG: 1 = every weight fragment from ONE address (L1 hits: no L2
 // latency), 2 = no input transform, 4 = no MFMAs, 8 = no patch loads after the first, 16 = no output transform / stores
-template <int COUT, bool RELU, bool POOL, int DBG, int WH_BR>
+template <int COUT, bool RELU, bool POOL, int DBG, int WH_BR, bool RES = false>
 __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
     const float *__restrict__ x, const unsigned *__restrict__ Uh, const float *__restrict__ bias,
     const float *__restrict__ res, int H, int W, int gxs, int gyb, int nsb, const unsigned *__restrict__ amax_in,
@@ -201,29 +201,40 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
             asm volatile("" ::: "memory");
             // (c) 36 frequencies x 2 MFMAs, weight fragments WH_BR pairs ahead (the first WH_BR pairs were requested at the
             // end of the previous quarter)
+            // A fragments (LDS) two pairs ahead of their use: issued right before its consumer a ds_read costs its whole
+            // latency 18 times per quarter (the matrix work of a pair is only 64 cycles)
+            u4 ar[3][2];
+            ar[0][0] = *(const u4 *)(a_src); ar[0][1] = *(const u4 *)(a_src + NT * WH_VS);
+            ar[1][0] = *(const u4 *)(a_src + 2 * NT * WH_VS); ar[1][1] = *(const u4 *)(a_src + 3 * NT * WH_VS);
 #pragma unroll
             for (int p = 0; p < ((DBG & 4) ? 1 : 18); ++p) {
-                const u4 a0 = *(const u4 *)(a_src + (2 * p) * NT * WH_VS);
-                const u4 a1 = *(const u4 *)(a_src + (2 * p + 1) * NT * WH_VS);
+                if (p < 16) {
+                    ar[(p + 2) % 3][0] = *(const u4 *)(a_src + (2 * p + 4) * NT * WH_VS);
+                    ar[(p + 2) % 3][1] = *(const u4 *)(a_src + (2 * p + 5) * NT * WH_VS);
+                }
+                const u4 a0 = ar[p % 3][0], a1 = ar[p % 3][1];
                 const u4 b0 = bq[p % WH_BR][0], b1 = bq[p % WH_BR][1];
-                u4 h0, l0, h1, l1;
+                const h8 A0 = __builtin_bit_cast(h8, a0), A1 = __builtin_bit_cast(h8, a1);
+                u4 t0, t1;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    h0[e] = __builtin_amdgcn_perm(b0[e], b0[e], 0x01000100u);      // (uh, uh)
-                    l0[e] = __builtin_amdgcn_perm(b0[e], b0[e], 0x03020302u);      // (ul, ul)
-                    h1[e] = __builtin_amdgcn_perm(b1[e], b1[e], 0x01000100u);
-                    l1[e] = __builtin_amdgcn_perm(b1[e], b1[e], 0x03020302u);
+                    t0[e] = __builtin_amdgcn_perm(b0[e], b0[e], 0x01000100u);      // (uh, uh)
+                    t1[e] = __builtin_amdgcn_perm(b1[e], b1[e], 0x01000100u);
                 }
-                const h8 A0 = __builtin_bit_cast(h8, a0), A1 = __builtin_bit_cast(h8, a1);
-                acc[2 * p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0, __builtin_bit_cast(h8, h0), acc[2 * p], 0, 0, 0);
-                acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1, __builtin_bit_cast(h8, h1), acc[2 * p + 1], 0, 0, 0);
-                acc[2 * p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0, __builtin_bit_cast(h8, l0), acc[2 * p], 0, 0, 0);
-                acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1, __builtin_bit_cast(h8, l1), acc[2 * p + 1], 0, 0, 0);
+                acc[2 * p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0, __builtin_bit_cast(h8, t0), acc[2 * p], 0, 0, 0);
+                acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1, __builtin_bit_cast(h8, t1), acc[2 * p + 1], 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    t0[e] = __builtin_amdgcn_perm(b0[e], b0[e], 0x03020302u);      // (ul, ul)
+                    t1[e] = __builtin_amdgcn_perm(b1[e], b1[e], 0x03020302u);
+                }
+                acc[2 * p] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0, __builtin_bit_cast(h8, t0), acc[2 * p], 0, 0, 0);
+                acc[2 * p + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1, __builtin_bit_cast(h8, t1), acc[2 * p + 1], 0, 0, 0);
                 if (p + WH_BR < 18) {
                     bq[p % WH_BR][0] = up[(DBG & 1) ? 0 : (int64_t)((kq * 36 + 2 * (p + WH_BR)) * NG) * 64];
                     bq[p % WH_BR][1] = up[(DBG & 1) ? 0 : (int64_t)((kq * 36 + 2 * (p + WH_BR) + 1) * NG) * 64];
                 }
-                __builtin_amdgcn_sched_barrier(0);                  // keep the ring WH_BR deep: no hoisting of later loads
+                __builtin_amdgcn_sched_barrier(0);                  // keep the rings as deep as written: no hoisting of later loads
             }
             // first weight fragments of the next quarter, THEN the patch of the quarter after it (see request_next)
             {
@@ -247,7 +258,7 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
                 // ---- output transform: lane (r16, g) holds M_xi[tile (g, v)][channel co] in acc[xi][v].  32-bit element
                 // offsets inside the image (H W COUT < 2^31), one wave-uniform test for blocks that lie inside the map
                 float *yb = y + (int64_t)o_img * Ho * Wo * COUT + co;
-                const float *rb = res ? res + (int64_t)o_img * H * W * COUT + co : nullptr;
+                const float *rb = (RES && !POOL) ? res + (int64_t)o_img * H * W * COUT + co : nullptr;
                 const int bx = o_sx * NB + m_bl;
                 const bool inside = (o_by * 16 + 16 <= H) & (bx * 16 + 16 <= W);
 #pragma unroll
@@ -260,10 +271,10 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
                               acc[30 + jj][v], s[0][jj], s[1][jj], s[2][jj], s[3][jj]);
                     const int oy0 = (o_by * 4 + g) * 4, ox0 = (bx * 4 + v) * 4;
                     const int e00 = (oy0 * W + ox0) * COUT;         // element offset of the tile's first pixel (unpooled map)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        wh_at(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o[i][0], o[i][1], o[i][2], o[i][3]);
                     if (POOL) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            wh_at(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o[i][0], o[i][1], o[i][2], o[i][3]);
                         // 2 x 2 maximum FIRST, then rescale, bias, ReLU on the 4 survivors instead of all 16: the rescale is a
                         // multiplication by a positive power of two (exact, monotone) and x -> x + b rounds monotonically, so
                         // max(a s + b, c s + b) == max(a, c) s + b bit for bit, and ReLU commutes with max.  The maximum of
@@ -283,19 +294,24 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
                                 }
                             }
                     } else {
+                        // one output row at a time (4 live values beside s[][])
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
+                        for (int i = 0; i < 4; ++i) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            wh_at(s[i][0], s[i][1], s[i][2], s[i][3], s[i][4], s[i][5], o[i][0], o[i][1], o[i][2], o[i][3]);
+                            const int er = e00 + i * W * COUT;
 #pragma unroll
                             for (int jj = 0; jj < 4; ++jj) {
                                 const bool in = inside || (oy0 + i < H && ox0 + jj < W);
-                                o[i][jj] = o[i][jj] * inv + bv;                   // exact power-of-two rescale, then bias
-                                if (rb && in) o[i][jj] += rb[e00 + (i * W + jj) * COUT];
-                                if (RELU) o[i][jj] = fmaxf(o[i][jj], 0.0f);
+                                float val = o[i][jj] * inv + bv;                  // exact power-of-two rescale, then bias
+                                if (RES && in) val += rb[er + jj * COUT];
+                                if (RELU) val = fmaxf(val, 0.0f);
                                 if (in) {
-                                    my_amax = fmaxf(my_amax, fabsf(o[i][jj]));
-                                    yb[e00 + (i * W + jj) * COUT] = o[i][jj];
+                                    my_amax = fmaxf(my_amax, fabsf(val));
+                                    yb[er + jj * COUT] = val;
                                 }
                             }
+                        }
                     }
                 }
 #pragma unroll
@@ -369,6 +385,16 @@ static int launch_fused_h(const float *d_x, const unsigned *d_Uh, const float *d
         else { switch (dbg) { case 1: WH_LAUNCH_D(true, false, 1); break; case 2: WH_LAUNCH_D(true, false, 2); break; case 4: WH_LAUNCH_D(true, false, 4); break;
                               case 5: WH_LAUNCH_D(true, false, 5); break; case 8: WH_LAUNCH_D(true, false, 8); break; case 16: WH_LAUNCH_D(true, false, 16); break;
                               case 6: WH_LAUNCH_D(true, false, 6); break; default: WH_LAUNCH_D(true, false, 31); } }
+        return CSLAM_OK;
+    }
+    if (d_res) {                                                    // shortcut add (never pooled): its own instantiation
+        const void *fr = relu ? (const void *)wino4_fused_c64_h_kernel<COUT, true, false, 0, WH_BR_DEFAULT, true>
+                              : (const void *)wino4_fused_c64_h_kernel<COUT, false, false, 0, WH_BR_DEFAULT, true>;
+        HIP_TRY(hipFuncSetAttribute(fr, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        if (relu) hipLaunchKernelGGL((wino4_fused_c64_h_kernel<COUT, true, false, 0, WH_BR_DEFAULT, true>), grid, block, lds, st, d_x, d_Uh,
+                                     d_bias, d_res, H, W, gxs, gyb, (int)nsb, d_amax, inv_su, d_amax_out, zero16, d_y);
+        else hipLaunchKernelGGL((wino4_fused_c64_h_kernel<COUT, false, false, 0, WH_BR_DEFAULT, true>), grid, block, lds, st, d_x, d_Uh,
+                                d_bias, d_res, H, W, gxs, gyb, (int)nsb, d_amax, inv_su, d_amax_out, zero16, d_y);
         return CSLAM_OK;
     }
     if (relu && pool) WH_LAUNCH(true, true);
