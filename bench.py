@@ -385,7 +385,10 @@ def main():
                                                                         mo.data_ptr(), st)))
             gb = 36.0 * T_ * (cin + cout) * 4 + 36.0 * cin * cout * 4
             fl16 = 3 * 2.0 * 36 * T_ * cin * cout
-            gem[tag] = {"kernel": "wino_gemm_h2_kernel", "shape": f"36 x [{T_},{cin}] x [{cin},{cout}]", "kernel_ms": round(gms, 3),
+            gshape = f"36 x [{T_},{cin}] x [{cin},{cout}]"
+            pg = pmc_entry("wino_gemm_h2_kernel/" + tag, shape=gshape)
+            gem[tag] = {"kernel": "wino_gemm_h2_kernel", "shape": gshape, "kernel_ms": round(gms, 3),
+                        "traffic": pg["traffic_bytes"] if pg else None, "traffic_source": pg["source"] if pg else None,
                         "hbm": {"achieved": round(gb / gms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": round(gb / gms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes": gb,
                                 "frac_of_measured": round(gb / gms / 1e6 / peaks["hbm_copy_GBs"], 4)},

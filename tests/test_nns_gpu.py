@@ -398,3 +398,33 @@ def test_multi_bank_search_equals_separate_searches(nnm):
                 assert_topk_equal(got[i][0], got[i][1], got[i][2], oi, os_, oc, 1e-12)
             else:
                 assert np.all(got[i][2] == 0) and np.all(got[i][0] == -1)
+
+
+def test_entry_points_leave_the_callers_device_alone(nnm):
+    """Every C-ABI entry point runs on the device that owns its data and restores the caller's current device (a process
+    may keep its banks on one GPU and run its extractor on another).  With one visible GPU this checks the guard is
+    transparent; the cross-device half needs two."""
+    import torch
+    from cslam_amd.vpr import heads
+    n_dev = torch.cuda.device_count()
+    bank_dev = 1 if n_dev >= 2 else 0
+    torch.cuda.set_device(0)
+    bank = unit_rows(np.random.default_rng(5), 600, 128)
+    nn = nnm.NearestNeighborsMatching(device=bank_dev)
+    nn.add_items(bank, range(600))
+    assert torch.cuda.current_device() == 0
+    q = unit_rows(np.random.default_rng(6), 40, 128)
+    idx, sims, cnt = nn.search_batch(q, 3)
+    assert torch.cuda.current_device() == 0
+    oi, os_, oc = pyoracle.nns_search(bank, q, 3)
+    assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
+    qd = torch.from_numpy(q).to(f"cuda:{bank_dev}")
+    r, s, c = nn.search_device(qd, 3)
+    assert torch.cuda.current_device() == 0 and np.array_equal(r.cpu().numpy(), oi)
+    # a head kernel on cuda:0 right after a bank call on the other device
+    x = torch.randn((5, 64), device="cuda:0")
+    y = heads.l2_normalize_(x.clone())
+    assert y.device.index == 0 and torch.allclose(y.norm(dim=1), torch.ones(5, device="cuda:0"), atol=1e-5)
+    assert nn.data.shape[1] == 128 and torch.cuda.current_device() == 0
+    if n_dev < 2:
+        pytest.skip("cross-device half needs 2 GPUs (the transparent half passed)")
