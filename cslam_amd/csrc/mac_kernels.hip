@@ -445,3 +445,175 @@ CSLAM_API int cslam_block4_residual_dev(const double *d_W, const double *d_X, in
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }
+
+// =====================================================================================
+// x = (L L^T)^-1 b for the dense lower Cholesky factor of the grounded junction Laplacian, 4 right-hand sides
+// (the inner solve of every TraceMIN iteration: networkx `_tracemin_fiedler` calls SuperLU's solve there, cslam/mac/mac.py:52-58).
+// Blocked substitution with pre-inverted diagonal blocks: per block column one product with the inverted diagonal block and one
+// update of the rows below (forward) / the columns before (backward).  Both are matrix x [bs][4] products that read the factor
+// exactly once at HBM speed; the library's thin-right-hand-side GEMMs took 8 ms per solve on 32k junctions (2 x 4.3 GB = 1.4 ms
+// of traffic).  No atomics: a fixed summation order per output element (deterministic iterates).
+#define CS4_THREADS 256
+#define CS4_RPW 4                      // rows per wave and pass of the row form
+
+// out[r][:] (-)= sum_c M[r][c] xin[c][:]   r < nrows, c < ncols <= bs; xin is staged in LDS.  One wave per CS4_RPW rows,
+// lanes stride the columns (512 contiguous bytes per wave load), butterfly reduction.  copy_to: if set, workgroup 0 also
+// writes xin there (lets the caller keep the substitution in place).
+template <bool SUB>
+__global__ __launch_bounds__(CS4_THREADS) void cs4_rows_kernel(const double *__restrict__ M, int64_t ldm, int64_t nrows, int ncols,
+                                                               const double *__restrict__ xin, double *__restrict__ out,
+                                                               double *__restrict__ copy_to) {
+    extern __shared__ __attribute__((aligned(16))) double cs4_x[];              // [ncols_pad][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ncp = (ncols + 63) & ~63;
+    for (int i = tid; i < ncp * 4; i += CS4_THREADS) cs4_x[i] = i < ncols * 4 ? xin[i] : 0.0;
+    if (copy_to && blockIdx.x == 0)
+        for (int i = tid; i < ncols * 4; i += CS4_THREADS) copy_to[i] = xin[i];
+    __syncthreads();
+    const int64_t rows_per_pass = (int64_t)gridDim.x * (CS4_THREADS / 64) * CS4_RPW;
+    for (int64_t r0 = ((int64_t)blockIdx.x * (CS4_THREADS / 64) + wave) * CS4_RPW; r0 < nrows; r0 += rows_per_pass) {
+        double acc[CS4_RPW][4];
+#pragma unroll
+        for (int i = 0; i < CS4_RPW; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+        const double *mp[CS4_RPW];
+#pragma unroll
+        for (int i = 0; i < CS4_RPW; ++i) mp[i] = M + (r0 + i < nrows ? r0 + i : nrows - 1) * ldm;
+        for (int c = lane; c < ncp; c += 64) {
+            const bool in = c < ncols;
+            double m[CS4_RPW];
+#pragma unroll
+            for (int i = 0; i < CS4_RPW; ++i) m[i] = in ? mp[i][c] : 0.0;
+            const double x0 = cs4_x[4 * c], x1 = cs4_x[4 * c + 1], x2 = cs4_x[4 * c + 2], x3 = cs4_x[4 * c + 3];
+#pragma unroll
+            for (int i = 0; i < CS4_RPW; ++i) {
+                acc[i][0] += m[i] * x0; acc[i][1] += m[i] * x1; acc[i][2] += m[i] * x2; acc[i][3] += m[i] * x3;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < CS4_RPW; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                double v = acc[i][j];
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+                acc[i][j] = v;
+            }
+        if (lane < CS4_RPW * 4) {
+            const int i = lane >> 2, j = lane & 3;
+            double v = 0.0;
+#pragma unroll
+            for (int a = 0; a < CS4_RPW; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) v = (a == i && b == j) ? acc[a][b] : v;
+            if (r0 + i < nrows) {
+                double *o = out + (r0 + i) * 4 + j;
+                *o = SUB ? *o - v : v;
+            }
+        }
+    }
+}
+
+// out[c][:] (-)= sum_r M[r][c] xin[r][:]   (the transposed product)  r < nrows <= bs, c < ncols.  One workgroup per 64 columns,
+// its 4 waves take the rows round robin, lanes = consecutive columns (coalesced), xin broadcast from LDS; fixed-order LDS
+// reduction over the waves.
+template <bool SUB>
+__global__ __launch_bounds__(CS4_THREADS) void cs4_cols_kernel(const double *__restrict__ M, int64_t ldm, int nrows, int64_t ncols,
+                                                               const double *__restrict__ xin, double *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double cs4_x[];              // [nrows][4], then [4 waves][64][4] for the reduction
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < nrows * 4; i += CS4_THREADS) cs4_x[i] = xin[i];
+    __syncthreads();
+    const int64_t c = (int64_t)blockIdx.x * 64 + lane;
+    const bool in = c < ncols;
+    const double *mp = M + (in ? c : ncols - 1);
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int r = wave;
+    for (; r + 12 < nrows; r += 16) {                               // 4 rows of this wave in flight
+        const double m0 = mp[(int64_t)r * ldm], m1 = mp[(int64_t)(r + 4) * ldm], m2 = mp[(int64_t)(r + 8) * ldm],
+                     m3 = mp[(int64_t)(r + 12) * ldm];
+        const double *x = cs4_x + 4 * r;
+        a0 += m0 * x[0]; a1 += m0 * x[1]; a2 += m0 * x[2]; a3 += m0 * x[3];
+        a0 += m1 * x[16]; a1 += m1 * x[17]; a2 += m1 * x[18]; a3 += m1 * x[19];
+        a0 += m2 * x[32]; a1 += m2 * x[33]; a2 += m2 * x[34]; a3 += m2 * x[35];
+        a0 += m3 * x[48]; a1 += m3 * x[49]; a2 += m3 * x[50]; a3 += m3 * x[51];
+    }
+    for (; r < nrows; r += 4) {
+        const double m0 = mp[(int64_t)r * ldm];
+        const double *x = cs4_x + 4 * r;
+        a0 += m0 * x[0]; a1 += m0 * x[1]; a2 += m0 * x[2]; a3 += m0 * x[3];
+    }
+    __syncthreads();                                                // xin no longer needed: reuse the LDS for the reduction
+    double *red = cs4_x;
+    red[(wave * 64 + lane) * 4 + 0] = a0; red[(wave * 64 + lane) * 4 + 1] = a1;
+    red[(wave * 64 + lane) * 4 + 2] = a2; red[(wave * 64 + lane) * 4 + 3] = a3;
+    __syncthreads();
+    if (tid < 256) {
+        const int cc = tid >> 2, j = tid & 3;
+        const int64_t gc = (int64_t)blockIdx.x * 64 + cc;
+        if (gc < ncols) {
+            const double v = ((red[(0 * 64 + cc) * 4 + j] + red[(1 * 64 + cc) * 4 + j]) + red[(2 * 64 + cc) * 4 + j]) + red[(3 * 64 + cc) * 4 + j];
+            double *o = out + gc * 4 + j;
+            *o = SUB ? *o - v : v;
+        }
+    }
+}
+
+CSLAM_API int cslam_chol_solve4_dev(const double *d_L, int64_t m, int64_t ld, int col_major, const double *d_dinv, int bs,
+                                    double *d_x, double *d_tmp, void *stream) {
+    PTR_DEVICE(d_L);
+    ARG_CHECK(d_L && d_dinv && d_x && d_tmp, "NULL argument");
+    ARG_CHECK(m >= 1 && ld >= m, "bad m / ld");
+    ARG_CHECK(bs >= 64 && bs <= 4096 && (bs % 64) == 0, "block size must be a multiple of 64 in [64, 4096]");
+    hipStream_t st = (hipStream_t)stream;
+    const int lds_rows = bs * 4 * 8, lds_cols = (bs * 4 * 8 > 4 * 64 * 4 * 8) ? bs * 4 * 8 : 4 * 64 * 4 * 8;
+    static bool attr = false;
+    if (!attr) {
+        HIP_TRY(hipFuncSetAttribute((const void *)cs4_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
+        HIP_TRY(hipFuncSetAttribute((const void *)cs4_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
+        HIP_TRY(hipFuncSetAttribute((const void *)cs4_cols_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
+        HIP_TRY(hipFuncSetAttribute((const void *)cs4_cols_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
+        attr = true;
+    }
+    const int64_t nb = ceil_div64(m, bs);
+    auto row_grid = [](int64_t rows) { int64_t g = ceil_div64(rows, (CS4_THREADS / 64) * CS4_RPW); return (unsigned)(g > 2048 ? 2048 : (g < 1 ? 1 : g)); };
+    // With a column-major factor the memory image is the row-major UPPER factor L^T: the forward update reads it by columns
+    // (cols form), the backward update by rows.
+    // forward: L y = b
+    for (int64_t t = 0; t < nb; ++t) {
+        const int64_t k = t * bs, e = (k + bs < m) ? k + bs : m;
+        const int bw = (int)(e - k);
+        // y_t = Dinv_t x[k:e]  -> tmp, then back to x[k:e] (by workgroup 0 of the row-form update, or a copy)
+        hipLaunchKernelGGL(cs4_rows_kernel<false>, dim3(row_grid(bw)), dim3(CS4_THREADS), lds_rows, st,
+                           d_dinv + (size_t)t * bs * bs, (int64_t)bs, (int64_t)bw, bw, d_x + k * 4, d_tmp, (double *)nullptr);
+        if (e < m && !col_major) {
+            hipLaunchKernelGGL(cs4_rows_kernel<true>, dim3(row_grid(m - e)), dim3(CS4_THREADS), lds_rows, st,
+                               d_L + e * ld + k, ld, m - e, bw, d_tmp, d_x + e * 4, d_x + k * 4);
+        } else {
+            HIP_TRY(hipMemcpyAsync(d_x + k * 4, d_tmp, (size_t)bw * 32, hipMemcpyDeviceToDevice, st));
+            if (e < m)
+                hipLaunchKernelGGL(cs4_cols_kernel<true>, dim3((unsigned)ceil_div64(m - e, 64)), dim3(CS4_THREADS), lds_cols, st,
+                                   d_L + k * ld + e, ld, bw, m - e, d_tmp, d_x + e * 4);
+        }
+    }
+    // backward: L^T x = y
+    for (int64_t t = nb - 1; t >= 0; --t) {
+        const int64_t k = t * bs, e = (k + bs < m) ? k + bs : m;
+        const int bw = (int)(e - k);
+        // x_t = Dinv_t^T y_t -> tmp -> x[k:e]
+        hipLaunchKernelGGL(cs4_cols_kernel<false>, dim3((unsigned)ceil_div64(bw, 64)), dim3(CS4_THREADS), lds_cols, st,
+                           d_dinv + (size_t)t * bs * bs, (int64_t)bs, bw, (int64_t)bw, d_x + k * 4, d_tmp);
+        HIP_TRY(hipMemcpyAsync(d_x + k * 4, d_tmp, (size_t)bw * 32, hipMemcpyDeviceToDevice, st));
+        if (k > 0) {
+            if (!col_major)
+                hipLaunchKernelGGL(cs4_cols_kernel<true>, dim3((unsigned)ceil_div64(k, 64)), dim3(CS4_THREADS), lds_cols, st,
+                                   d_L + k * ld, ld, bw, k, d_tmp, d_x);
+            else
+                hipLaunchKernelGGL(cs4_rows_kernel<true>, dim3(row_grid(k)), dim3(CS4_THREADS), lds_rows, st,
+                                   d_L + k, ld, k, bw, d_tmp, d_x, (double *)nullptr);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}

@@ -73,11 +73,27 @@ __device__ __forceinline__ unsigned wh_pack(float v) {                    // [fp
 
 // DBG: timing-only ablations (wrong results), CSLAM_WFH_DBG: 1 = every weight fragment from ONE address (L1 hits: no L2
 // latency), 2 = no input transform, 4 = no MFMAs, 8 = no patch loads after the first, 16 = no output transform / stores
-template <int COUT, bool RELU, bool POOL, int DBG, int WH_BR, bool RES = false>
+// STEM (COUT = 64 only): the 64-channel input of this convolution is itself the 3 -> 64 channel first convolution of the
+// trunk (+ bias + ReLU), computed HERE from the planar 3-channel image instead of being written to HBM by one kernel and read
+// back by this one (VGG-16 conv1_1 -> conv1_2: 3.3 GB each way per 256 frames, and the patch bursts every wave's weight loads
+// queued behind).  Per iteration the 20 x 36 x 3 image patch of the block is loaded once, split into fp16 pairs and kept in
+// LDS; per 16-channel quarter the 18 x 34 patch of first-layer outputs is 39 row tiles of v_mfma_f32_16x16x32_f16 over the
+// 27 taps (3 products: xh wh + xl wh + xh wl, fp32-grade like everything else here), written to the single patch buffer
+// behind the quarter's main MFMAs.  x = the planar image [B][3][H][W]; st_w1 = `stem_pair_weights` (scaled by the power of
+// two 1 / st_inv_sw); amax_in holds max |image|: the input scale s1 is the power of two with max |image| s1 <= 2^14, and the
+// scale of THIS layer's V comes from the rigorous bound max_co(|b1[co]| + max |image| * st_sumw[co]), st_sumw[co] = the sum
+// of |first-layer weights| of channel co (its true maximum is only known after the kernel has run).
+#define ST_IW 36
+#define ST_IPL (20 * ST_IW)
+#define ST_IMG (3 * ST_IPL)
+#define ST_PAD 768                     // zero dwords behind the image: the unused K slots of lane group 3 read there
+template <int COUT, bool RELU, bool POOL, int DBG, int WH_BR, bool RES = false, bool STEM = false>
 __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
     const float *__restrict__ x, const unsigned *__restrict__ Uh, const float *__restrict__ bias,
     const float *__restrict__ res, int H, int W, int gxs, int gyb, int nsb, const unsigned *__restrict__ amax_in,
-    float inv_su, unsigned *__restrict__ amax_out, const float *__restrict__ zero16, float *__restrict__ y) {
+    float inv_su, unsigned *__restrict__ amax_out, const float *__restrict__ zero16, float *__restrict__ y,
+    const unsigned *__restrict__ st_w1, const float *__restrict__ st_b1, const float *__restrict__ st_sumw, float st_inv_sw) {
+    static_assert(!STEM || (COUT == 64 && !RES), "the stem form is the 3 -> 64 -> 64 channel pair only");
     constexpr int NG = COUT / 16;                  // 16-channel output groups: 4 or 8
     constexpr int NB = 8 / NG;                     // blocks per iteration: 2 or 1
     constexpr int NT = 16 * NB;                    // tiles per iteration
@@ -86,12 +102,28 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
     constexpr int NL = (4 * NPIX + 511) / 512;     // 16-byte patch elements per thread and quarter (5 | 3)
     constexpr int PBUF = NL * 512 * 4;             // floats per patch buffer (whole LDS-DMA rounds)
     extern __shared__ __attribute__((aligned(16))) char wh_smem[];
-    float *s_p = (float *)wh_smem;                                  // [2][PBUF]
-    unsigned *s_v = (unsigned *)(wh_smem + 2 * PBUF * 4);           // [36][NT][16]
+    constexpr int NPB = STEM ? 1 : 2;                               // patch buffers
+    float *s_p = (float *)wh_smem;                                  // [NPB][PBUF]
+    unsigned *s_v = (unsigned *)(wh_smem + NPB * PBUF * 4);         // [36][NT][16]
+    unsigned *s_img = s_v + 36 * NT * WH_VS;                        // STEM: [20][36][3] packed [hi | lo] image patch + ST_PAD zeros
+    float *s_raw = (float *)(s_img + ST_IMG + ST_PAD);              // STEM: [NL * 512] the same patch as it arrives (planar order)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const float sc = wh_scale(*amax_in);
+    float sc_, st_s1 = 1.0f, st_inv1 = 1.0f;
+    if constexpr (STEM) {
+        const float a0 = fminf(fmaxf(__uint_as_float(*amax_in), 1e-30f), 1e30f);
+        int e;
+        (void)frexpf(16384.0f / a0, &e);
+        st_s1 = ldexpf(1.0f, e - 1);
+        st_inv1 = st_inv_sw / st_s1;
+        float bound = 0.0f;
+        for (int c = 0; c < 64; ++c) bound = fmaxf(bound, fabsf(st_b1 ? st_b1[c] : 0.0f) + a0 * st_sumw[c]);
+        sc_ = wh_scale(__float_as_uint(bound));
+    } else {
+        sc_ = wh_scale(*amax_in);
+    }
+    const float sc = sc_;
     const float inv = inv_su / sc;
 
     // ---- patch loader: element e = i * 512 + tid = (pixel e >> 2, float4 e & 3 of the 16-channel quarter), LDS-DMA into the
@@ -106,6 +138,20 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
         c_by = rem / gxs;
         c_sx = rem - c_by * gxs;
         const int gx0 = c_sx * (16 * NB) - 1, gy0 = c_by * 16 - 1;
+        if constexpr (STEM) {
+            // element e = i * 512 + tid of the planar 3 x 20 x 36 image patch whose origin is one pixel up / left of the patch
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int e = tid + 512 * i;
+                const int ci = (e >= ST_IPL) + (e >= 2 * ST_IPL);
+                const int rem = e - ci * ST_IPL;
+                const int r = (rem * 1821) >> 16, c = rem - ST_IW * r;             // rem / 36 for rem < 2200
+                const int gy = gy0 - 1 + r, gx = gx0 - 1 + c;
+                const bool in = (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W) & (e < ST_IMG);
+                p_src[i] = in ? ((c_img * 3 + ci) * H + gy) * W + gx : -1;
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             const int e = tid + 512 * i;
@@ -120,6 +166,66 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
 #pragma unroll
         for (int i = 0; i < NL; ++i)
             wh_glds16(p_src[i] >= 0 ? x + p_src[i] + kq * 16 : zero16, s_p + buf * PBUF + i * (512 * 4) + wave * 256);
+    };
+    // ---- STEM: image patch in (one dword per lane by LDS-DMA: no registers held across the phases), split, first layer
+    auto img_request = [&]() {
+#pragma unroll
+        for (int i = 0; i < NL; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(p_src[i] >= 0 ? x + p_src[i] : zero16),
+                                             (__attribute__((address_space(3))) void *)(s_raw + i * 512 + wave * 64), 4, 0, 0);
+    };
+    auto img_split = [&]() {                       // raw planar patch -> [row][col][channel] packed fp16 pairs of st_s1 * x
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int e = tid + 512 * i;
+            if (e < ST_IMG) {
+                const int ci = (e >= ST_IPL) + (e >= 2 * ST_IPL);
+                const int rem = e - ci * ST_IPL;
+                s_img[3 * rem + ci] = wh_pack(s_raw[e] * st_s1);
+            }
+        }
+    };
+    // K slots of the first layer's MFMA (lane group gq = lane >> 4, slot j): gq < 3: tap (ky = gq, kx = j / 3, ci = j % 3), the
+    // 8 dwords are CONSECUTIVE in the [row][col][channel] image; gq = 3, j < 3: the ninth tap (kx = 2, ci = 2) of row ky = j
+    // (stride one image row), j >= 3: zero weights, the reads land in the zero padding behind the image
+    const int st_gq = lane >> 4;
+    const int st_lane_off = st_gq < 3 ? st_gq * (3 * ST_IW) : 8;
+    const int st_lane_stride = st_gq < 3 ? 1 : 3 * ST_IW;
+    auto produce = [&](int kq, int b_by, int b_sx) {               // patch quarter kq of block (b_by, b_sx) -> s_p
+        const int gx0 = b_sx * (16 * NB) - 1, gy0 = b_by * 16 - 1;
+        const u4 w1h = ((const u4 *)st_w1)[(kq * 2 + 0) * 64 + lane], w1l = ((const u4 *)st_w1)[(kq * 2 + 1) * 64 + lane];
+        const float b1 = st_b1 ? st_b1[16 * kq + (lane & 15)] : 0.0f;
+        const h8 Bh = __builtin_bit_cast(h8, w1h), Bl = __builtin_bit_cast(h8, w1l);
+#pragma unroll 1
+        for (int mt = wave; mt < (NPIX + 15) / 16; mt += 8) {
+            int p = 16 * mt + (lane & 15);
+            p = p < NPIX ? p : NPIX - 1;
+            const int pr = (p * 1928) >> 16, pc = p - PWX * pr;                    // p / 34 for p < 700
+            const unsigned *ib = s_img + (pr * ST_IW + pc) * 3 + st_lane_off;
+            unsigned pk[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pk[j] = ib[j * st_lane_stride];
+            u4 ah, al;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                ah[d] = __builtin_amdgcn_perm(pk[2 * d + 1], pk[2 * d], 0x05040100u);     // (hi, hi) of slots 2d, 2d + 1
+                al[d] = __builtin_amdgcn_perm(pk[2 * d + 1], pk[2 * d], 0x07060302u);     // (lo, lo)
+            }
+            const h8 Ah = __builtin_bit_cast(h8, ah), Al = __builtin_bit_cast(h8, al);
+            f4 c = (f4)(0.0f);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl, c, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int p2 = 16 * mt + 4 * st_gq + i;                            // lane holds rows 4 gq + i of column lane & 15
+                const int pr2 = (p2 * 1928) >> 16, pc2 = p2 - PWX * pr2;
+                const int gy = gy0 + pr2, gx = gx0 + pc2;
+                const bool in = (p2 < NPIX) & (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W);
+                const float v = fmaxf(c[i] * st_inv1 + b1, 0.0f);                  // exact power-of-two rescale, bias, ReLU
+                s_p[p2 * WH_PS + (lane & 15)] = in ? v : 0.0f;                     // outside the map: the second layer's zero padding
+            }
+        }
     };
     // ---- transform geometry: thread = (tile, channel of the quarter); COUT = 128: threads 256.. sit the transform out
     const int t_tile = tid >> 4, t_c = tid & 15;
@@ -159,7 +265,19 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
         }
         ++l_q;
     };
-    if (n_mine > 0) {
+    if constexpr (STEM) {
+        for (int i = tid; i < ST_PAD; i += 512) s_img[ST_IMG + i] = 0u;
+        if (n_mine > 0) {
+            geometry((int)blockIdx.x);
+            n_img = c_img; n_by = c_by; n_sx = c_sx;
+            img_request();
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            img_split();
+            __syncthreads();
+            produce(0, n_by, n_sx);
+        }
+    } else if (n_mine > 0) {
         request_next();
         request_next();
     }
@@ -175,7 +293,7 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
     for (int it = 0; it < n_mine; ++it) {
 #pragma unroll 1
         for (int kq = 0; kq < 4; ++kq) {
-            const int pb = kq & 1;                                  // 4 quarters per iteration: the buffer parity is kq's
+            const int pb = STEM ? 0 : kq & 1;                       // 4 quarters per iteration: the buffer parity is kq's
             // (b) V = B^T (sV d) B, split into fp16 pairs
             if (t_on && !(DBG & 2)) {
                 const float *src = s_p + pb * PBUF + t_src;
@@ -244,7 +362,27 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
                     bq[p][0] = up[(DBG & 1) ? 0 : (int64_t)((nkq * 36 + 2 * p) * NG) * 64];
                     bq[p][1] = up[(DBG & 1) ? 0 : (int64_t)((nkq * 36 + 2 * p + 1) * NG) * 64];
                 }
-                request_next();                                     // quarter 4 it + kq + 2 (at kq = 2 the loader moves to the next block)
+                if constexpr (!STEM) request_next();                // quarter 4 it + kq + 2 (at kq = 2 the loader moves to the next block)
+            }
+            if constexpr (STEM) {
+                // The patch of the NEXT quarter is computed here, behind this quarter's MFMAs (its buffer was consumed by this
+                // quarter's transform, two barriers ago).  The image patch of the next block is requested behind the third
+                // quarter's MFMAs (one LDS-DMA round per iteration instead of four per-quarter bursts), lands under the fourth
+                // quarter and is split into pairs before the next block's first patch quarter needs it.
+                const bool more = it + 1 < n_mine;
+                if (kq < 3) produce(kq + 1, o_by, o_sx);
+                if (kq == 2 && more) {                              // AFTER produce(): its weight loads must not queue behind the DMA
+                    geometry((int)blockIdx.x + (it + 1) * (int)gridDim.x);
+                    n_img = c_img; n_by = c_by; n_sx = c_sx;
+                    img_request();
+                }
+                if (kq == 3 && more) {
+                    __builtin_amdgcn_s_waitcnt(0x0F70 | 2 * WH_BR);     // vmcnt: all but the weight fragments just requested
+                    __syncthreads();                                // every wave's share of the raw patch has landed; the last
+                    img_split();                                    // reader of s_img (quarter 3's patch) is two barriers back
+                    __syncthreads();
+                    produce(0, n_by, n_sx);
+                }
             }
             if (kq == 3 && (DBG & 16)) {
                 f4 t = acc[0];
@@ -373,7 +511,7 @@ static int launch_fused_h(const float *d_x, const unsigned *d_Uh, const float *d
 #define WH_LAUNCH_DB(R, P, D, BR) do { \
         HIP_TRY(hipFuncSetAttribute((const void *)wino4_fused_c64_h_kernel<COUT, R, P, D, BR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
         hipLaunchKernelGGL((wino4_fused_c64_h_kernel<COUT, R, P, D, BR>), grid, block, lds, st, d_x, d_Uh, d_bias, d_res, \
-                           H, W, gxs, gyb, (int)nsb, d_amax, inv_su, d_amax_out, zero16, d_y); } while (0)
+                           H, W, gxs, gyb, (int)nsb, d_amax, inv_su, d_amax_out, zero16, d_y, (const unsigned *)nullptr, (const float *)nullptr, (const float *)nullptr, 0.0f); } while (0)
 #define WH_LAUNCH_D(R, P, D) WH_LAUNCH_DB(R, P, D, WH_BR_DEFAULT)
     const char *br_env = getenv("CSLAM_WFH_BR");
     const int br = br_env ? atoi(br_env) : WH_BR_DEFAULT;
@@ -392,9 +530,9 @@ static int launch_fused_h(const float *d_x, const unsigned *d_Uh, const float *d
                               : (const void *)wino4_fused_c64_h_kernel<COUT, false, false, 0, WH_BR_DEFAULT, true>;
         HIP_TRY(hipFuncSetAttribute(fr, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         if (relu) hipLaunchKernelGGL((wino4_fused_c64_h_kernel<COUT, true, false, 0, WH_BR_DEFAULT, true>), grid, block, lds, st, d_x, d_Uh,
-                                     d_bias, d_res, H, W, gxs, gyb, (int)nsb, d_amax, inv_su, d_amax_out, zero16, d_y);
+                                     d_bias, d_res, H, W, gxs, gyb, (int)nsb, d_amax, inv_su, d_amax_out, zero16, d_y, (const unsigned *)nullptr, (const float *)nullptr, (const float *)nullptr, 0.0f);
         else hipLaunchKernelGGL((wino4_fused_c64_h_kernel<COUT, false, false, 0, WH_BR_DEFAULT, true>), grid, block, lds, st, d_x, d_Uh,
-                                d_bias, d_res, H, W, gxs, gyb, (int)nsb, d_amax, inv_su, d_amax_out, zero16, d_y);
+                                d_bias, d_res, H, W, gxs, gyb, (int)nsb, d_amax, inv_su, d_amax_out, zero16, d_y, (const unsigned *)nullptr, (const float *)nullptr, (const float *)nullptr, 0.0f);
         return CSLAM_OK;
     }
     if (relu && pool) WH_LAUNCH(true, true);
@@ -421,6 +559,51 @@ CSLAM_API int cslam_wino4_fused_c64_h_dev(const float *d_x, const void *d_Uh, co
     const int rc = Cout == 64
         ? launch_fused_h<64>(d_x, (const unsigned *)d_Uh, d_bias, d_residual, B, H, W, relu, pool, d_amax, inv_su, d_amax_out, d_y, st)
         : launch_fused_h<128>(d_x, (const unsigned *)d_Uh, d_bias, d_residual, B, H, W, relu, pool, d_amax, inv_su, d_amax_out, d_y, st);
+    if (rc != CSLAM_OK) return rc;
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
+// The stem form: conv 3 -> 64 + bias + ReLU -> conv 64 -> 64 + bias + ReLU (+ MaxPool2d) in one launch.
+static int launch_stem_h(const float *d_x0, const unsigned *d_w1, const float *d_b1, const float *d_sumw, float inv_sw, const unsigned *d_Uh,
+                         const float *d_bias, int B, int H, int W, int pool, const unsigned *d_amax, float inv_su,
+                         unsigned *d_amax_out, float *d_y, hipStream_t st) {
+    int dev = 0, n_cu = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    const int gxs = (int)ceil_div64(W, 32), gyb = (int)ceil_div64(H, 16);
+    const int64_t nsb = (int64_t)B * gxs * gyb;
+    ARG_CHECK(nsb < (1ll << 30), "too many tile blocks for one launch");
+    ARG_CHECK((int64_t)B * H * W * 3 < (1ll << 31), "image batch too large for the 32-bit patch offsets");
+    const int grid_n = (int)(nsb < n_cu ? nsb : n_cu);
+    constexpr int NPIX = 18 * 34, NL = (4 * NPIX + 511) / 512;
+    constexpr int lds = NL * 512 * 16 + 36 * 32 * 64 + (ST_IMG + ST_PAD) * 4 + NL * 512 * 4;
+    static float *zero16[16] = {nullptr};                           // 16 zero bytes per device
+    ARG_CHECK(dev < 16, "device index");
+    if (!zero16[dev]) {
+        HIP_TRY(hipMalloc((void **)&zero16[dev], 256));             // never freed: a captured graph may point at it
+        HIP_TRY(hipMemset(zero16[dev], 0, 256));
+    }
+    dim3 grid((unsigned)grid_n), block(512);
+#define ST_LAUNCH(P) do { \
+        HIP_TRY(hipFuncSetAttribute((const void *)wino4_fused_c64_h_kernel<64, true, P, 0, WH_BR_DEFAULT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+        hipLaunchKernelGGL((wino4_fused_c64_h_kernel<64, true, P, 0, WH_BR_DEFAULT, false, true>), grid, block, lds, st, d_x0, d_Uh, d_bias, \
+                           (const float *)nullptr, H, W, gxs, gyb, (int)nsb, d_amax, inv_su, d_amax_out, zero16[dev], d_y, d_w1, d_b1, d_sumw, inv_sw); } while (0)
+    if (pool) ST_LAUNCH(true); else ST_LAUNCH(false);
+#undef ST_LAUNCH
+    return CSLAM_OK;
+}
+
+CSLAM_API int cslam_wino4_stem_c64_h_dev(const float *d_x0, const void *d_w1, const float *d_b1, const float *d_sumw, float inv_sw,
+                                         const void *d_Uh, const float *d_bias, int B, int H, int W, int pool,
+                                         const unsigned *d_amax_x0, float inv_su, unsigned *d_amax_out, float *d_y, void *stream) {
+    PTR_DEVICE(d_x0);
+    ARG_CHECK(d_x0 && d_w1 && d_sumw && d_Uh && d_y && d_amax_x0, "NULL argument");
+    ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
+    ARG_CHECK(!pool || ((H % 2) == 0 && (W % 2) == 0), "pooling needs even H and W");
+    ARG_CHECK(inv_sw > 0.0f && inv_su > 0.0f, "scales must be positive");
+    const int rc = launch_stem_h(d_x0, (const unsigned *)d_w1, d_b1, d_sumw, inv_sw, (const unsigned *)d_Uh, d_bias, B, H, W, pool,
+                                 d_amax_x0, inv_su, d_amax_out, d_y, (hipStream_t)stream);
     if (rc != CSLAM_OK) return rc;
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;

@@ -23,9 +23,10 @@ def _p(t):
 
 def blocked_cholesky_(A, bs=2048):
     """In-place lower Cholesky factor of a symmetric positive definite float64 device matrix, right-
-    looking by blocks: small diagonal factorisations + one triangular solve + one plain GEMM
-    (hipBLASLt fp64) per block column.  The library potrf ran at ~4 TFLOP/s on 32k junctions; the
-    trailing GEMMs run an order of magnitude faster.  Only the lower triangle of the result is valid."""
+    looking by blocks: small diagonal factorisations + one triangular solve per block column, and the
+    trailing update as plain GEMMs (hipBLASLt fp64) over the LOWER block trapezoid only (the full
+    square update did twice the flops).  The library potrf ran at ~4 TFLOP/s on 32k junctions.
+    Only the lower triangle of the result is valid."""
     import torch
     m = A.shape[0]
     for k in range(0, m, bs):
@@ -35,37 +36,42 @@ def blocked_cholesky_(A, bs=2048):
             L11 = A[k:e, k:e]
             A[e:, k:e] = torch.linalg.solve_triangular(L11, A[e:, k:e].T, upper=False).T     # L21 = A21 L11^-T
             L21 = A[e:, k:e]
-            A[e:, e:] -= L21 @ L21.T
+            for j in range(e, m, 2 * bs):                      # block columns of the trailing matrix, rows from the diagonal down
+                je = min(j + 2 * bs, m)
+                A[j:, j:je].addmm_(L21[j - e:], L21[j - e:je - e].T, alpha=-1.0)
     return A
 
 
 class BlockedCholeskySolve(object):
-    """x = (L L^T)^-1 b for a dense lower factor L and a thin right-hand side (4 columns): the
-    diagonal blocks are inverted once, after which forward and backward substitution are plain
-    GEMMs that stream L twice per solve (the library potrs/trsm path took ~0.1 s per call on 32k
-    junctions with 4 columns)."""
+    """x = (L L^T)^-1 b for a dense lower factor L and 4 right-hand sides: the diagonal blocks are
+    inverted once, after which forward and backward substitution are `cslam_chol_solve4_dev`
+    (csrc/mac_kernels.hip): matrix x [bs][4] products that stream L exactly twice per solve at HBM
+    speed (library potrs/trsm: ~0.1 s per call on 32k junctions; thin-right-hand-side GEMMs: 8 ms)."""
 
     def __init__(self, L, bs=2048):
         import torch
         self.L, self.bs, self.m = L, bs, L.shape[0]
-        self.starts = list(range(0, self.m, bs))
-        eye = lambda k: torch.eye(k, dtype=L.dtype, device=L.device)
-        self.dinv = [torch.linalg.solve_triangular(L[k:min(k + bs, self.m), k:min(k + bs, self.m)],
-                                                  eye(min(k + bs, self.m) - k), upper=False) for k in self.starts]
+        assert L.dim() == 2 and L.shape[0] == L.shape[1] and 1 in L.stride()
+        # library factorisations come back column-major (element (r, c) at c * ld + r); the blocked one above is row-major
+        self.col_major = int(L.stride(1) != 1)
+        self.ld = L.stride(0) if not self.col_major else L.stride(1)
+        self.lib = _lib.load()
+        nb = (self.m + bs - 1) // bs
+        self.dinv = torch.zeros((nb, bs, bs), dtype=L.dtype, device=L.device)
+        for t in range(nb):
+            k = t * bs
+            e = min(k + bs, self.m)
+            eye = torch.eye(e - k, dtype=L.dtype, device=L.device)
+            self.dinv[t, :e - k, :e - k] = torch.linalg.solve_triangular(L[k:e, k:e], eye, upper=False)
+        self.tmp = torch.empty((bs, 4), dtype=L.dtype, device=L.device)
 
     def solve(self, b):
-        x = b.clone()
-        L, m, bs = self.L, self.m, self.bs
-        for t, k in enumerate(self.starts):                       # forward: L y = b
-            e = min(k + bs, m)
-            x[k:e] = self.dinv[t] @ x[k:e]
-            if e < m:
-                x[e:] -= L[e:, k:e] @ x[k:e]
-        for t in range(len(self.starts) - 1, -1, -1):              # backward: L^T x = y
-            k = self.starts[t]; e = min(k + bs, m)
-            x[k:e] = self.dinv[t].T @ x[k:e]
-            if k > 0:
-                x[:k] -= L[k:e, :k].T @ x[k:e]
+        import torch
+        assert b.shape == (self.m, 4) and b.dtype == torch.float64
+        x = b.contiguous().clone()
+        st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
+        _lib.check(self.lib.cslam_chol_solve4_dev(_p(self.L), self.m, max(self.ld, self.m), self.col_major, _p(self.dinv), self.bs,
+                                                  _p(x), _p(self.tmp), st))
         return x
 
 
@@ -128,10 +134,13 @@ class ChainReducedSolverGPU(object):
             Sf.index_put_((fi[both], fj[both]), -rw[both], accumulate=True)
             Sf.index_put_((fj[both], fi[both]), -rw[both], accumulate=True)
             _lap('assemble nJ=%d' % nJ)
-            self.chol = torch.linalg.cholesky(Sf)
+            if m > 4096 and os.environ.get('CSLAM_MAC_CHOL', 'blocked') == 'blocked':
+                self.chol = blocked_cholesky_(Sf)              # in place: the upper triangle keeps stale values, never read
+            else:
+                self.chol = torch.linalg.cholesky(Sf)
             del Sf
             _lap('cholesky')
-            self.tri = BlockedCholeskySolve(self.chol) if m > 4096 else None
+            self.tri = BlockedCholeskySolve(self.chol, 2048 if m > 4096 else 512) if m >= 64 else None
         else:
             host.factorize()
         _lap('block inverses')

@@ -89,6 +89,51 @@ def fused64_pair_weights(U4):
     return packed.view(36, 4, 4, 4, cout // 16, 16).permute(1, 0, 4, 2, 5, 3).contiguous(), 1.0 / su
 
 
+def stem_pair_weights(weight):
+    """First-layer weights [64, 3, 3, 3] float32 -> (W1 int32 [4, 2, 64, 4], inv_sw, sumw float32 [64]): the operand of the
+    3 -> 64 channel convolution folded into `cslam_wino4_stem_c64_h_dev` (csrc/wino_fused_h.hip).  sW w is split into exact
+    fp16 pairs (sW the power of two that brings max |w| into [2^14, 2^15)); K slot (lane group g, slot j) of the 16x16x32
+    MFMA holds tap (ky = g, kx = j // 3, ci = j % 3) for g < 3 and the ninth tap (ky = j, kx = 2, ci = 2) of every row for
+    g = 3, j < 3 (zeros elsewhere); W1[kq][0 | 1][16 g + n][d] = halves 2d, 2d + 1 of the hi | lo parts for output channel
+    16 kq + n.  sumw[co] = sum |w[co]| (float64, rounded up to float32): the kernel bounds max |first-layer output| with it."""
+    assert tuple(weight.shape) == (64, 3, 3, 3)
+    w = weight.detach().to(torch.float64).cpu()
+    amax = float(w.abs().max())
+    sw = 2.0 ** (14 - math.floor(math.log2(amax))) if amax > 0 else 1.0
+    ws = (w * sw).to(torch.float32)
+    wh = ws.to(torch.float16)
+    wl = (ws - wh.to(torch.float32)).to(torch.float16)
+    slots = torch.zeros((2, 64, 4, 8), dtype=torch.float16)              # [hi | lo][co][g][j]
+    for g in range(3):
+        for j in range(8):
+            slots[0, :, g, j] = wh[:, j % 3, g, j // 3]
+            slots[1, :, g, j] = wl[:, j % 3, g, j // 3]
+    for j in range(3):
+        slots[0, :, 3, j] = wh[:, 2, j, 2]
+        slots[1, :, 3, j] = wl[:, 2, j, 2]
+    bits = slots.view(torch.int16).to(torch.int32) & 0xFFFF
+    packed = bits[..., 0::2] | (bits[..., 1::2] << 16)                   # [2][64][4 g][4 d]
+    W1 = packed.view(2, 4, 16, 4, 4).permute(1, 0, 3, 2, 4).reshape(4, 2, 64, 4).contiguous()   # [kq][hl][16 g + n][d]
+    sumw = torch.nextafter(w.abs().sum(dim=(1, 2, 3)).to(torch.float32), torch.tensor(float("inf")))
+    return W1.to(weight.device), 1.0 / sw, sumw.to(weight.device).contiguous()
+
+
+def wino_stem64_h(x0, stem, bias1, Uh, bias, pool, amax_x0, amax_out=None):
+    """VGG-16's first two convolutions as ONE kernel (`cslam_wino4_stem_c64_h_dev`): x0 planar [B,3,H,W] float32,
+    stem = `stem_pair_weights(conv1_1.weight)`, Uh = `fused64_pair_weights` of the 64 -> 64 layer; amax_x0 = 4-byte device
+    slot with the bits of max |x0|.  Returns ReLU(conv(ReLU(conv(x0) + bias1)) + bias) (+ MaxPool2d), channels_last."""
+    lib = _lib.load()
+    B, C3, H, W = x0.shape
+    assert C3 == 3 and x0.is_contiguous() and Uh[0].shape[2] == 4
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    y = torch.empty((B, 64, Ho, Wo), dtype=torch.float32, device=x0.device, memory_format=torch.channels_last)
+    _lib.check(lib.cslam_wino4_stem_c64_h_dev(
+        _p(x0), _p(stem[0]), _p(bias1) if bias1 is not None else None, _p(stem[2]), float(stem[1]), _p(Uh[0]),
+        _p(bias) if bias is not None else None, B, H, W, int(pool), _p(amax_x0), float(Uh[1]),
+        _p(amax_out) if amax_out is not None else None, _p(y), _stream(x0)))
+    return y
+
+
 def wino_fused64_h(x, Uh, bias, relu, pool, amax_in, amax_out=None, residual=None):
     """The fp16-pair form of `wino_fused64` (csrc/wino_fused_h.hip): Uh = `fused64_pair_weights(U4)`; amax_in = 4-byte
     device slot holding the bits of (a bound of) max |x|; amax_out (zeroed slot or None) receives those of max |y|."""
@@ -336,11 +381,11 @@ class WinogradResNet(_Workspace):
 
 
 class _Step(object):
-    __slots__ = ("kind", "module", "conv", "relu", "pool", "U", "U4", "U3", "U2", "Up", "Uph", "bias")
+    __slots__ = ("kind", "module", "conv", "relu", "pool", "U", "U4", "U3", "U2", "Up", "Uph", "bias", "stem")
 
     def __init__(self):
         self.kind, self.module, self.conv, self.relu, self.pool = "torch", None, None, False, False
-        self.U, self.U4, self.U3, self.U2, self.Up, self.Uph, self.bias = None, None, None, None, None, None, None
+        self.U, self.U4, self.U3, self.U2, self.Up, self.Uph, self.bias, self.stem = None, None, None, None, None, None, None, None
 
 
 class WinogradTrunk(_Workspace):
@@ -432,6 +477,13 @@ class WinogradTrunk(_Workspace):
                 st.kind, st.module = "torch", m
                 i += 1
             self.steps.append(st)
+        # first layer (3 -> 64, ReLU) followed by a one-kernel fp16-pair layer (64 -> 64, ReLU): both in ONE kernel, the
+        # 64-channel map between them never reaches HBM (csrc/wino_fused_h.hip, STEM; CSLAM_WINO_STEM=0 keeps them apart)
+        if os.environ.get("CSLAM_WINO_STEM", "1") != "0":
+            for a, b in zip(self.steps, self.steps[1:]):
+                if (a.kind == "c3" and a.relu and a.conv.out_channels == 64 and b.kind == "wino" and b.Uph is not None
+                        and b.relu and b.conv.out_channels == 64):
+                    a.stem = stem_pair_weights(a.conv.weight)
         return self
 
     @torch.no_grad()
@@ -446,12 +498,26 @@ class WinogradTrunk(_Workspace):
         if any(wants(st) for st in self.steps):
             slots = self._buf("amax_slots", len(self.steps) + 1, x.device)
             slots.zero_()
+        skip = False
         for k, st in enumerate(self.steps):
+            if skip:                                                 # this step ran inside the previous one (stem kernel)
+                skip = False
+                continue
             have, amax_ready = amax_ready, None
             nxt = self.steps[k + 1] if k + 1 < len(self.steps) else None
             if st.kind == "c3":
                 x = x.contiguous()                                   # planar [B,3,H,W]
                 B, _, H, W = x.shape
+                if (st.stem is not None and B * -(-H // 16) * -(-W // 16) * 16 >= self.fused_min_blocks
+                        and not (nxt.pool and (H % 2 or W % 2)) and B * H * W * 64 < 2 ** 31):
+                    slot = slots[k:k + 1]
+                    _lib.check(lib.cslam_absmax_dev(_p(x), x.numel(), _p(slot), _stream(x)))
+                    nn2 = self.steps[k + 2] if k + 2 < len(self.steps) else None
+                    want = slots[k + 2:k + 3] if wants(nn2) else None
+                    x = wino_stem64_h(x, st.stem, st.bias, nxt.Uph, nxt.bias, nxt.pool, slot, want)
+                    amax_ready = want is not None
+                    skip = True
+                    continue
                 Cout = st.conv.out_channels
                 y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
                 want = slots[k + 1:k + 2] if (wants(nxt) and Cout == 64) else None

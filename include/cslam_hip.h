@@ -200,6 +200,14 @@ int cslam_chain_forward_dev(const double *d_b, const uint8_t *d_is_junction, con
 int cslam_chain_backward_dev(const double *d_xJ, const double *d_Bn, const double *d_Qn, const double *d_r,
                              const double *d_Rn, const int *d_jid, const int *d_seg_of, const int64_t *d_sa,
                              const int64_t *d_sb, const double *d_Rl, int64_t n, double *d_x, void *stream);
+/* x <- (L L^T)^-1 x for the dense lower Cholesky factor L [m][ld] (float64, row-major; only the lower triangle is
+ * read; col_major != 0: element (r, c) at c * ld + r instead of r * ld + c, the layout LAPACK-style library
+ * factorisations return) of the grounded junction Laplacian, x [m][4]: the junction solve inside every TraceMIN iteration (SuperLU's
+ * solve in networkx `_tracemin_fiedler`, called at cslam/mac/mac.py:52-58).  d_dinv: inverses of the bs x bs diagonal
+ * blocks of L, [ceil(m / bs)][bs][bs] (a ragged last block in the top-left corner of its slot); d_tmp: [bs][4]
+ * scratch.  Blocked substitution, every factor element read exactly once per sweep, fixed summation order. */
+int cslam_chol_solve4_dev(const double *d_L, int64_t m, int64_t ld, int col_major, const double *d_dinv, int bs,
+                          double *d_x, double *d_tmp, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Lidar place recognition: ScanContext bank.
@@ -335,6 +343,15 @@ int cslam_wino4_fused_c64_h_dev(const float *d_x, const void *d_Uh, const float 
  * the first trunk layer feeds the scale of the fused fp16 layer behind it without a separate pass over its output. */
 int cslam_conv3x3_c3_amax_dev(const float *d_x, const float *d_wt, const float *d_bias, int B, int H, int W, int Cout,
                               int relu, float *d_y, unsigned *d_amax_out, void *stream);
+
+/* The same kernel with the trunk's FIRST convolution folded in (VGG-16 conv1_1 -> conv1_2, cslam/vpr/netvlad.py:163-171,227):
+ * y = [MaxPool2d](ReLU(conv3x3_{64->64}(ReLU(conv3x3_{3->64}(x0) + b1)) + bias)).  d_x0: planar image batch [B][3][H][W] f32;
+ * d_w1 / inv_sw / d_sumw: the first layer's weights as packed fp16 pairs, the inverse of their power-of-two scale, and
+ * sum |w| per output channel [64] (`stem_pair_weights` in cslam_amd/vpr/winograd.py); d_amax_x0: 4-byte slot holding the bits of
+ * max |x0|; the 64-channel intermediate never exists in HBM.  d_Uh / inv_su / d_amax_out / d_y as in cslam_wino4_fused_c64_h_dev. */
+int cslam_wino4_stem_c64_h_dev(const float *d_x0, const void *d_w1, const float *d_b1, const float *d_sumw, float inv_sw,
+                               const void *d_Uh, const float *d_bias, int B, int H, int W, int pool,
+                               const unsigned *d_amax_x0, float inv_su, unsigned *d_amax_out, float *d_y, void *stream);
 
 /* ---- multi-GPU exchange (csrc/comm.hip): RCCL over xGMI, one process per GPU ---------------------------------------
  * Replaces, inside one node, the ROS 2 transport of descriptors between robots

@@ -645,3 +645,43 @@ def test_split16_trunk_equals_fp32_gemm_trunk(T):
     assert e32 <= 2e-5 and e2 <= 2e-5 and e3 <= 2e-5 and max(e2, e3) <= 1.5 * e32 + 1e-7, (e2, e3, e32)
     r32, r2, r3 = _rel_rms(y32, ref), _rel_rms(y2, ref), _rel_rms(y3, ref)
     assert r32 <= 1e-5 and max(r2, r3) <= 1.5 * r32 + 1e-8, (r2, r3, r32)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,pool,amp", [(2, 224, 224, True, 1.0), (3, 37, 50, False, 1.0), (5, 64, 96, True, 1e-3),
+                                            (300, 16, 32, True, 1.0), (2, 30, 22, False, 40.0), (1, 18, 34, True, 1.0)])
+def test_stem_kernel_first_two_convolutions_equal_float64_and_separate_kernels(T, B, H, W, pool, amp, monkeypatch):
+    """cslam_wino4_stem_c64_h_dev (conv 3 -> 64 + ReLU folded into the one-kernel 64 -> 64 convolution + ReLU (+ MaxPool2d);
+    VGG-16 conv1_1 / conv1_2, cslam/vpr/netvlad.py:163-171) against a float64 evaluation of the two layers at the tolerance
+    of the one-kernel form, and against the two separate kernels (fp32-grade: within 2e-6 of the largest activation).
+    Ragged blocks, maps narrower than one block pair, block counts below / above the compute-unit count, image scales."""
+    torch, _ = T
+    from torch import nn
+    from cslam_amd.vpr.winograd import WinogradTrunk
+    torch.manual_seed(57)
+    mods = [nn.Conv2d(3, 64, 3, padding=1), nn.ReLU(), nn.Conv2d(64, 64, 3, padding=1), nn.ReLU()] + \
+        ([nn.MaxPool2d(2, 2)] if pool else [])
+    seq = nn.Sequential(*mods).cuda().eval()
+    x = (torch.rand((B, 3, H, W), device="cuda") * 4.8 - 2.2) * amp       # the range of a normalised image
+    monkeypatch.setenv("CSLAM_WINO_STEM", "1")
+    stem = WinogradTrunk(seq, 64, 4, fused64=True)
+    stem.fused_min_blocks = 0
+    assert stem.steps[0].stem is not None and stem.steps[1].Uph is not None
+    ys = stem(x)
+    monkeypatch.setenv("CSLAM_WINO_STEM", "0")
+    apart = WinogradTrunk(seq, 64, 4, fused64=True)
+    apart.fused_min_blocks = 0
+    assert apart.steps[0].stem is None
+    ya = apart(x)
+    with torch.no_grad():
+        ref = seq.double()(x.double())
+    seq.float()
+    assert ys.shape == ref.shape == ya.shape
+    top = ref.abs().max().item()
+    es = (ys.double() - ref).abs().max().item() / top
+    rs = float(((ys.double() - ref) ** 2).sum().sqrt() / (ref ** 2).sum().sqrt())
+    ea = (ya.double() - ref).abs().max().item() / top
+    ra = float(((ya.double() - ref) ** 2).sum().sqrt() / (ref ** 2).sum().sqrt())
+    assert es <= 2e-5 and rs <= 5e-6, (es, rs)
+    assert es <= max(2.0 * ea, 2e-6) and rs <= max(2.0 * ra, 5e-7), (es, ea, rs, ra)
+    assert (ys - ya).abs().max().item() <= 4e-6 * top

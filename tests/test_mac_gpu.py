@@ -113,3 +113,26 @@ def test_selection_with_gpu_solver_equals_reference(tag, R, K):
     sel = ac.select_candidates(K, {r: True for r in range(R)}, greedy_initialization=True)
     got = np.array([tuple(e) for e in sel], dtype=np.float64).reshape(-1, 5)
     assert np.array_equal(got, g7[tag + "/selected"])
+
+
+@pytest.mark.parametrize("m,bs", [(64, 64), (700, 64), (1000, 512), (5000, 2048), (4097, 2048)])
+def test_dense_cholesky_solve4_matches_library(m, bs):
+    """cslam_chol_solve4_dev (the junction solve of every TraceMIN iteration) against torch.cholesky_solve, for both the
+    row-major factor of `blocked_cholesky_` and the column-major one library factorisations return; ragged last block."""
+    import torch
+    from cslam_amd.mac.chain_solver_gpu import BlockedCholeskySolve, blocked_cholesky_
+    g = torch.Generator(device="cuda").manual_seed(m)
+    B = torch.randn((m, 96), generator=g, device="cuda", dtype=torch.float64)
+    A = B @ B.T + torch.eye(m, device="cuda", dtype=torch.float64) * 50.0
+    rhs = torch.randn((m, 4), generator=g, device="cuda", dtype=torch.float64)
+    L_lib = torch.linalg.cholesky(A)
+    ref = torch.cholesky_solve(rhs, L_lib)
+    L_row = blocked_cholesky_(A.clone(), bs=256)                     # upper triangle keeps stale values: must never be read
+    L_col = torch.tril(L_lib).T.contiguous().T                       # element (r, c) at c * m + r
+    assert L_col.stride(0) == 1 and L_row.stride(1) == 1
+    for L in (L_row, L_col):
+        x = BlockedCholeskySolve(L, bs).solve(rhs)
+        assert float((x - ref).abs().max() / ref.abs().max()) < 1e-11
+        assert float((A @ x - rhs).abs().max()) < 1e-9 * float(A.abs().max())
+    x2 = BlockedCholeskySolve(L_row, bs).solve(rhs)                   # fixed summation order: bit-identical repeats
+    assert torch.equal(x2, BlockedCholeskySolve(L_row, bs).solve(rhs))
