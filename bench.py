@@ -266,9 +266,10 @@ def main():
     extract_fp32_gemms = value_fp32_gemms = None
     split16 = os.environ.get("CSLAM_WINO_SPLIT16", "128")
     if extractor is not None and world == 1 and extractor.backbone_conv == "winograd" and split16 != "0":
-        saved = {k: os.environ.get(k) for k in ("CSLAM_WINO_SPLIT16", "CSLAM_WINO_FUSED_H")}
+        saved = {k: os.environ.get(k) for k in ("CSLAM_WINO_SPLIT16", "CSLAM_WINO_FUSED_H", "CSLAM_WINO_STEM")}
         os.environ["CSLAM_WINO_SPLIT16"] = "0"          # library sgemm between the transforms
         os.environ["CSLAM_WINO_FUSED_H"] = "0"          # conv1_2 / conv2_1 on the f32-input MFMA
+        os.environ["CSLAM_WINO_STEM"] = "0"             # conv1_1 as its own fp32 kernel
         try:
             ex32 = NetVLAD({"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376,
                             "frontend.netvlad.pca_dim": a.dim, "frontend.random_seed": 0,
@@ -428,6 +429,35 @@ def main():
             "f32_mfma_form_frac_of_f32_mfma_peak": round(fflop / fms32 / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4),
             "shape": shape_f + f" -> [{eb},{fh // 2},{fh // 2},64]"}
         del xf
+        # the trunk's first TWO convolutions as one launch (conv1_1 folded into the kernel above, csrc/wino_fused_h.hip STEM):
+        # the 64-channel map between them (3.3 GB per 256 frames, written and read back) never exists in HBM.  Its floor is the
+        # matrix work: 36 x 2 MFMA pairs per tile and quarter + the first layer's 27-tap products; HBM sees image in + pooled out
+        x0 = torch.rand((eb, 3, fh, fh), device=dev) * 4.8 - 2.2
+        w1 = torch.randn((64, 3, 3, 3), device=dev) / 5.0
+        b1 = torch.randn(64, device=dev)
+        stemw = wg.stem_pair_weights(w1)
+        s0 = torch.zeros(1, dtype=torch.float32, device=dev)
+        _lib.check(lib.cslam_absmax_dev(x0.data_ptr(), x0.numel(), s0.data_ptr(), st))
+        sms = time_ms(lambda: wg.wino_stem64_h(x0, stemw, b1, Uhf, bf, True, s0, None))
+        y1 = torch.empty((eb, 64, fh, fh), device=dev, memory_format=torch.channels_last)
+        w1k = w1.permute(1, 2, 3, 0).reshape(27, 64).contiguous()
+        c1ms = time_ms(lambda: _lib.check(lib.cslam_conv3x3_c3_amax_dev(x0.data_ptr(), w1k.data_ptr(), b1.data_ptr(), eb, fh, fh, 64,
+                                                                       1, y1.data_ptr(), None, st)))
+        sbytes = (x0.numel() + eb * 64 * (fh // 2) * (fh // 2)) * 4
+        ps = pmc_entry("wino4_fused_c64_h_kernel/stem", shape=f"x0 [{eb},3,{fh},{fh}] -> conv 3->64 + ReLU -> conv 64->64 + ReLU + MaxPool2d")
+        sflop16 = eb * (fh // 4) * (fh // 4) * 36 * 2 * 64 * 64 * 4 + eb * fh * fh * 1.2 * 2 * 32 * 64 * 3
+        extract_roofline["stem_conv"] = {
+            "bound": "mfma", "kernel": "wino4_fused_c64_h_kernel<STEM>", "kernel_ms": round(sms, 3),
+            "separate_kernels_ms": round(c1ms + fms, 3), "first_layer_kernel_ms": round(c1ms, 3),
+            "achieved": round(sflop16 / sms / 1e9, 1), "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (fp16 MFMA issued)",
+            "frac": round(sflop16 / sms / 1e9 / FP16_MFMA_PEAK_TFLOPS, 4),
+            "frac_of_measured": round(sflop16 / sms / 1e9 / peaks["mfma_f16_TFLOPs"], 4),
+            "hbm_algorithmic_bytes": sbytes, "hbm_GBs": round(sbytes / sms / 1e6, 1),
+            "traffic": ps["traffic_bytes"] if ps else None, "traffic_source": ps["source"] if ps else None,
+            "note": "latency-bound (per-phase cycle counts: profiles/r02_v18_fused_h_phases.log): the matrix pipe is busy 15 % of "
+                    "the kernel; fp16 flops = 4 products per frequency (2 MFMAs on duplicated weights) + 3 per first-layer tap",
+            "shape": f"x0 [{eb},3,{fh},{fh}] -> conv 3->64 + ReLU -> conv 64->64 + ReLU + MaxPool2d -> [{eb},{fh // 2},{fh // 2},64]"}
+        del x0, y1
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -516,7 +546,8 @@ def main():
                 "conv2_2 ... conv5_3 (from 128 input channels on): this library's GEMM (csrc/wino_gemm.hip) over exact fp16 hi/lo "
                 "pairs of both operands, 3 of the 4 partial products on the fp16 MFMA pipe with fp32 accumulation (error vs "
                 "float64 = that of the fp32 GEMM, tests/test_heads_gpu.py::test_split16_*, tests/test_wino_gemm_gpu.py); "
-                "conv1_2 / conv2_1: one-kernel Winograd convolutions on fp16 pairs (csrc/wino_fused_h.hip)"),
+                "conv1_1 + conv1_2: ONE kernel (first layer folded into the one-kernel Winograd convolution, fp16 pairs), conv2_1: "
+                "one-kernel Winograd convolution on fp16 pairs (csrc/wino_fused_h.hip)"),
             "extract_only_fp32_gemms": None if extract_fp32_gemms is None else round(extract_fp32_gemms, 2),
             "match_only": round(match_only, 2),
             "match_only_queries": nqm,

@@ -53,9 +53,12 @@ _SIGNATURES = {
     "cslam_block4_gram_dev": (_i, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "cslam_block4_affine_dev": (_i, [_vp, _i64, _vp, _vp, _vp, _vp]),
     "cslam_block4_residual_dev": (_i, [_vp, _vp, _i64, _vp, C.c_double, _vp, _vp, _vp]),
+    "cslam_block4_gram_sync": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "cslam_block4_affine_host": (_i, [_vp, _i64, _vp, _vp, _vp, _vp]),
+    "cslam_block4_residual_sync": (_i, [_vp, _vp, _i64, _vp, C.c_double, _vp, _vp, _vp, _vp]),
     "cslam_chain_forward_dev": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cslam_chain_backward_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
-    "cslam_chol_solve4_dev": (_i, [_vp, _i64, _i64, _i, _vp, _i, _vp, _vp, _vp]),
+    "cslam_chol_solve4_dev": (_i, [_vp, _i64, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "cslam_scbank_create": (_i, [_i, _i, _i, _i64, _vp]),
     "cslam_scbank_destroy": (_i, [_vp]),
     "cslam_scbank_size": (_i, [_vp, _vp, _vp, _vp]),
@@ -80,9 +83,11 @@ _SIGNATURES = {
     "cslam_scancontext_from_cloud_dev": (_i, [_vp, _vp, _i, _i, _i, C.c_double, _vp, _vp, _vp]),
     "cslam_wino4_fused_c64_h_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, C.c_float, _vp, _vp, _vp]),
     "cslam_wino4_stem_c64_h_dev": (_i, [_vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _i, _i, _i, _i, _vp, C.c_float, _vp, _vp, _vp]),
+    "cslam_debug_wfh_prof_dev": (_i, [_vp]),
     "cslam_conv3x3_c3_amax_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "cslam_wino4_input_h2_dev": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
     "cslam_wino_gemm_h2_dev": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
+    "cslam_wino_gemm_h2r_dev": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "cslam_comm_unique_id": (_i, [_vp]),
     "cslam_comm_init": (_i, [_i, _i, _vp, _i, C.POINTER(_vp)]),
     "cslam_comm_destroy": (_i, [_vp]),

@@ -146,15 +146,31 @@ __global__ __launch_bounds__(SCAN_BLOCK) void segscan_local_kernel(const double 
     }
 }
 
-// phase 2: one wave walks the chunk aggregates and produces each chunk's carry-in
-__global__ void segscan_carry_kernel(const double *__restrict__ agg_s, const int *__restrict__ agg_f, int nchunks,
-                                     double *__restrict__ carry) {
-    if (threadIdx.x >= CQ) return;
-    const int c = threadIdx.x;
-    double run = 0.0;
-    for (int b = 0; b < nchunks; ++b) {
-        carry[(size_t)b * CQ + c] = run;
-        run = agg_f[b] ? agg_s[(size_t)b * CQ + c] : run + agg_s[(size_t)b * CQ + c];
+// phase 2: the chunk aggregates -> each chunk's carry-in.  The walk is serial (one lane per column), but over LDS: staged
+// by the whole block in parallel first -- walking global memory cost one L2 round trip per chunk (0.2 ms at 1e6 poses, more
+// than all streaming passes of a solve together).
+#define CARRY_TILE 1024
+__global__ __launch_bounds__(256) void segscan_carry_kernel(const double *__restrict__ agg_s, const int *__restrict__ agg_f, int nchunks,
+                                                            double *__restrict__ carry) {
+    __shared__ double ts[CARRY_TILE * CQ];
+    __shared__ int tf[CARRY_TILE];
+    double run = 0.0;                                              // lanes 0..3: the running carry of their column
+    for (int b0 = 0; b0 < nchunks; b0 += CARRY_TILE) {
+        const int nb = nchunks - b0 < CARRY_TILE ? nchunks - b0 : CARRY_TILE;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb * CQ; i += 256) ts[i] = agg_s[(size_t)b0 * CQ + i];
+        for (int i = threadIdx.x; i < nb; i += 256) tf[i] = agg_f[b0 + i];
+        __syncthreads();
+        if (threadIdx.x < CQ) {
+            const int c = threadIdx.x;
+            for (int b = 0; b < nb; ++b) {
+                const double a = ts[b * CQ + c];
+                ts[b * CQ + c] = run;
+                run = tf[b] ? a : run + a;
+            }
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < nb * CQ; i += 256) carry[(size_t)b0 * CQ + i] = ts[i];
     }
 }
 
@@ -190,7 +206,7 @@ static int segscan4(const double *d_v, const uint8_t *d_flag, int64_t n, double 
     double *carry = d_scratch + (size_t)nchunks * CQ;            // [nchunks][4]
     int *agg_f = (int *)(d_scratch + (size_t)2 * nchunks * CQ);  // [nchunks]
     hipLaunchKernelGGL(segscan_local_kernel, dim3(nchunks), dim3(SCAN_BLOCK), 0, st, d_v, d_flag, n, d_out, agg_s, agg_f);
-    hipLaunchKernelGGL(segscan_carry_kernel, dim3(1), dim3(64), 0, st, agg_s, agg_f, nchunks, carry);
+    hipLaunchKernelGGL(segscan_carry_kernel, dim3(1), dim3(256), 0, st, agg_s, agg_f, nchunks, carry);
     hipLaunchKernelGGL(segscan_fix_kernel, dim3(nchunks), dim3(SCAN_BLOCK), 0, st, d_flag, n, carry, d_out);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
@@ -358,12 +374,23 @@ __global__ __launch_bounds__(B4_BLOCK) void block4_gram_kernel(const double *__r
         partial[(size_t)blockIdx.x * 20 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
-__global__ void block4_gram_finish_kernel(const double *__restrict__ partial, int nblocks, double *__restrict__ out20) {
-    const int i = threadIdx.x;
-    if (i >= 20) return;
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * 20 + i];   // fixed order: deterministic
-    out20[i] = s;
+// out20[i] = sum over the blocks of partial[b][i]: lane t of a 256-thread block adds the blocks b = t, t + 256, ... in order,
+// then a fixed tree over the lanes (deterministic).  One thread per output walking 1024 partials was a chain of 1024 L2 round
+// trips: 0.36 ms per call, six calls per TraceMIN iteration.
+__global__ __launch_bounds__(256) void block4_gram_finish_kernel(const double *__restrict__ partial, int nblocks, double *__restrict__ out20) {
+    __shared__ double red[256];
+    for (int i = 0; i < 20; ++i) {
+        double s = 0.0;
+        for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[(size_t)b * 20 + i];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        for (int w = 128; w >= 1; w >>= 1) {
+            if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) out20[i] = red[0];
+        __syncthreads();
+    }
 }
 
 // out[k][:] = A[k][:] * M (4x4, row-major) - shift[:]
@@ -404,11 +431,17 @@ __global__ __launch_bounds__(B4_BLOCK) void block4_residual_kernel(const double 
     if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
 }
 
-__global__ void block4_sum_finish_kernel(const double *__restrict__ partial, int nblocks, double *__restrict__ out1) {
-    if (threadIdx.x != 0) return;
+__global__ __launch_bounds__(256) void block4_sum_finish_kernel(const double *__restrict__ partial, int nblocks, double *__restrict__ out1) {
+    __shared__ double red[256];
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[b];
-    out1[0] = s;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[b];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out1[0] = red[0];
 }
 
 #define B4_GRID 1024
@@ -419,7 +452,7 @@ CSLAM_API int cslam_block4_gram_dev(const double *d_A, const double *d_B, int64_
     hipStream_t st = (hipStream_t)stream;
     int grid = (int)ceil_div64(n, B4_BLOCK); if (grid > B4_GRID) grid = B4_GRID;
     hipLaunchKernelGGL(block4_gram_kernel, dim3(grid), dim3(B4_BLOCK), 0, st, d_A, d_B, n, d_partial);
-    hipLaunchKernelGGL(block4_gram_finish_kernel, dim3(1), dim3(64), 0, st, d_partial, grid, d_out20);
+    hipLaunchKernelGGL(block4_gram_finish_kernel, dim3(1), dim3(256), 0, st, d_partial, grid, d_out20);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }
@@ -441,8 +474,87 @@ CSLAM_API int cslam_block4_residual_dev(const double *d_W, const double *d_X, in
     hipStream_t st = (hipStream_t)stream;
     int grid = (int)ceil_div64(n, B4_BLOCK); if (grid > B4_GRID) grid = B4_GRID;
     hipLaunchKernelGGL(block4_residual_kernel, dim3(grid), dim3(B4_BLOCK), 0, st, d_W, d_X, n, d_y4, sigma, d_partial);
-    hipLaunchKernelGGL(block4_sum_finish_kernel, dim3(1), dim3(64), 0, st, d_partial, grid, d_out1);
+    hipLaunchKernelGGL(block4_sum_finish_kernel, dim3(1), dim3(256), 0, st, d_partial, grid, d_out1);
     HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
+// ---- host-synchronous twins for the TraceMIN outer loop: the 4 x 4 algebra between the streaming passes runs on the host
+// (LAPACK, as in the reference), so every pass ends in a tiny read-back or starts from a tiny matrix.  Passing those through
+// torch tensors cost ~2 ms per iteration in copies, allocations and synchronisations (of ~0.3 ms of kernels at 1e6 poses): here
+// the small operands travel as kernel ARGUMENTS, and a read-back is one 160-byte copy + one stream synchronisation in the call.
+struct B4Mat { double m[16]; double s[4]; };
+
+__global__ __launch_bounds__(256) void block4_affine_val_kernel(const double *__restrict__ A, int64_t n, B4Mat mv,
+                                                                double *__restrict__ out) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    double a[CQ], o[CQ];
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) a[c] = A[k * CQ + c];
+#pragma unroll
+    for (int j = 0; j < CQ; ++j) {
+        double s = -mv.s[j];
+#pragma unroll
+        for (int i = 0; i < CQ; ++i) s += a[i] * mv.m[i * CQ + j];
+        o[j] = s;
+    }
+#pragma unroll
+    for (int c = 0; c < CQ; ++c) out[k * CQ + c] = o[c];
+}
+
+__global__ __launch_bounds__(B4_BLOCK) void block4_residual_val_kernel(const double *__restrict__ W, const double *__restrict__ X,
+                                                                       int64_t n, double y0, double y1, double y2, double y3,
+                                                                       double sigma, double *__restrict__ partial) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int64_t k = (int64_t)blockIdx.x * B4_BLOCK + threadIdx.x; k < n; k += (int64_t)gridDim.x * B4_BLOCK) {
+        double w = W[k * CQ] * y0 + W[k * CQ + 1] * y1 + W[k * CQ + 2] * y2 + W[k * CQ + 3] * y3;
+        acc += fabs(w - sigma * X[k * CQ]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+CSLAM_API int cslam_block4_gram_sync(const double *d_A, const double *d_B, int64_t n, double *d_partial, double *d_out20,
+                                     double *h_out20, void *stream) {
+    PTR_DEVICE(d_A);
+    ARG_CHECK(d_A && d_B && d_partial && d_out20 && h_out20 && n >= 1, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    int grid = (int)ceil_div64(n, B4_BLOCK); if (grid > B4_GRID) grid = B4_GRID;
+    hipLaunchKernelGGL(block4_gram_kernel, dim3(grid), dim3(B4_BLOCK), 0, st, d_A, d_B, n, d_partial);
+    hipLaunchKernelGGL(block4_gram_finish_kernel, dim3(1), dim3(256), 0, st, d_partial, grid, d_out20);
+    HIP_TRY(hipMemcpyAsync(h_out20, d_out20, 20 * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return CSLAM_OK;
+}
+
+CSLAM_API int cslam_block4_affine_host(const double *d_A, int64_t n, const double *h_M16, const double *h_shift4, double *d_out,
+                                       void *stream) {
+    PTR_DEVICE(d_A);
+    ARG_CHECK(d_A && h_M16 && d_out && n >= 1, "bad argument");
+    B4Mat mv;
+    for (int i = 0; i < 16; ++i) mv.m[i] = h_M16[i];
+    for (int i = 0; i < 4; ++i) mv.s[i] = h_shift4 ? h_shift4[i] : 0.0;
+    hipLaunchKernelGGL(block4_affine_val_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, (hipStream_t)stream, d_A, n, mv, d_out);
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
+CSLAM_API int cslam_block4_residual_sync(const double *d_W, const double *d_X, int64_t n, const double *h_y4, double sigma,
+                                         double *d_partial, double *d_out1, double *h_out1, void *stream) {
+    PTR_DEVICE(d_W);
+    ARG_CHECK(d_W && d_X && h_y4 && d_partial && d_out1 && h_out1 && n >= 1, "bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    int grid = (int)ceil_div64(n, B4_BLOCK); if (grid > B4_GRID) grid = B4_GRID;
+    hipLaunchKernelGGL(block4_residual_val_kernel, dim3(grid), dim3(B4_BLOCK), 0, st, d_W, d_X, n, h_y4[0], h_y4[1], h_y4[2],
+                       h_y4[3], sigma, d_partial);
+    hipLaunchKernelGGL(block4_sum_finish_kernel, dim3(1), dim3(256), 0, st, d_partial, grid, d_out1);
+    HIP_TRY(hipMemcpyAsync(h_out1, d_out1, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return CSLAM_OK;
 }
 
@@ -454,12 +566,12 @@ CSLAM_API int cslam_block4_residual_dev(const double *d_W, const double *d_X, in
 // exactly once at HBM speed; the library's thin-right-hand-side GEMMs took 8 ms per solve on 32k junctions (2 x 4.3 GB = 1.4 ms
 // of traffic).  No atomics: a fixed summation order per output element (deterministic iterates).
 #define CS4_THREADS 256
-#define CS4_RPW 4                      // rows per wave and pass of the row form
+#define CS4_CT 512                     // threads of the column form: 8 waves, 8 rows each in flight
 
-// out[r][:] (-)= sum_c M[r][c] xin[c][:]   r < nrows, c < ncols <= bs; xin is staged in LDS.  One wave per CS4_RPW rows,
+// out[r][:] (-)= sum_c M[r][c] xin[c][:]   r < nrows, c < ncols <= bs; xin is staged in LDS.  One wave per RPW rows,
 // lanes stride the columns (512 contiguous bytes per wave load), butterfly reduction.  copy_to: if set, workgroup 0 also
 // writes xin there (lets the caller keep the substitution in place).
-template <bool SUB>
+template <bool SUB, int RPW>
 __global__ __launch_bounds__(CS4_THREADS) void cs4_rows_kernel(const double *__restrict__ M, int64_t ldm, int64_t nrows, int ncols,
                                                                const double *__restrict__ xin, double *__restrict__ out,
                                                                double *__restrict__ copy_to) {
@@ -470,29 +582,30 @@ __global__ __launch_bounds__(CS4_THREADS) void cs4_rows_kernel(const double *__r
     if (copy_to && blockIdx.x == 0)
         for (int i = tid; i < ncols * 4; i += CS4_THREADS) copy_to[i] = xin[i];
     __syncthreads();
-    const int64_t rows_per_pass = (int64_t)gridDim.x * (CS4_THREADS / 64) * CS4_RPW;
-    for (int64_t r0 = ((int64_t)blockIdx.x * (CS4_THREADS / 64) + wave) * CS4_RPW; r0 < nrows; r0 += rows_per_pass) {
-        double acc[CS4_RPW][4];
+    const int64_t rows_per_pass = (int64_t)gridDim.x * (CS4_THREADS / 64) * RPW;
+    for (int64_t r0 = ((int64_t)blockIdx.x * (CS4_THREADS / 64) + wave) * RPW; r0 < nrows; r0 += rows_per_pass) {
+        double acc[RPW][4];
 #pragma unroll
-        for (int i = 0; i < CS4_RPW; ++i)
+        for (int i = 0; i < RPW; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
-        const double *mp[CS4_RPW];
+        const double *mp[RPW];
 #pragma unroll
-        for (int i = 0; i < CS4_RPW; ++i) mp[i] = M + (r0 + i < nrows ? r0 + i : nrows - 1) * ldm;
+        for (int i = 0; i < RPW; ++i) mp[i] = M + (r0 + i < nrows ? r0 + i : nrows - 1) * ldm;
+#pragma unroll 2
         for (int c = lane; c < ncp; c += 64) {
             const bool in = c < ncols;
-            double m[CS4_RPW];
+            double m[RPW];
 #pragma unroll
-            for (int i = 0; i < CS4_RPW; ++i) m[i] = in ? mp[i][c] : 0.0;
+            for (int i = 0; i < RPW; ++i) m[i] = in ? mp[i][c] : 0.0;
             const double x0 = cs4_x[4 * c], x1 = cs4_x[4 * c + 1], x2 = cs4_x[4 * c + 2], x3 = cs4_x[4 * c + 3];
 #pragma unroll
-            for (int i = 0; i < CS4_RPW; ++i) {
+            for (int i = 0; i < RPW; ++i) {
                 acc[i][0] += m[i] * x0; acc[i][1] += m[i] * x1; acc[i][2] += m[i] * x2; acc[i][3] += m[i] * x3;
             }
         }
 #pragma unroll
-        for (int i = 0; i < CS4_RPW; ++i)
+        for (int i = 0; i < RPW; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 double v = acc[i][j];
@@ -500,11 +613,11 @@ __global__ __launch_bounds__(CS4_THREADS) void cs4_rows_kernel(const double *__r
                 for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
                 acc[i][j] = v;
             }
-        if (lane < CS4_RPW * 4) {
+        if (lane < RPW * 4) {
             const int i = lane >> 2, j = lane & 3;
             double v = 0.0;
 #pragma unroll
-            for (int a = 0; a < CS4_RPW; ++a)
+            for (int a = 0; a < RPW; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) v = (a == i && b == j) ? acc[a][b] : v;
             if (r0 + i < nrows) {
@@ -516,30 +629,35 @@ __global__ __launch_bounds__(CS4_THREADS) void cs4_rows_kernel(const double *__r
 }
 
 // out[c][:] (-)= sum_r M[r][c] xin[r][:]   (the transposed product)  r < nrows <= bs, c < ncols.  One workgroup per 64 columns,
-// its 4 waves take the rows round robin, lanes = consecutive columns (coalesced), xin broadcast from LDS; fixed-order LDS
-// reduction over the waves.
+// its 8 waves take the rows round robin with 8 rows each in flight, lanes = consecutive columns (coalesced), xin broadcast from
+// LDS; fixed-order LDS reduction over the waves.  copy_to as above.
 template <bool SUB>
-__global__ __launch_bounds__(CS4_THREADS) void cs4_cols_kernel(const double *__restrict__ M, int64_t ldm, int nrows, int64_t ncols,
-                                                               const double *__restrict__ xin, double *__restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) double cs4_x[];              // [nrows][4], then [4 waves][64][4] for the reduction
+__global__ __launch_bounds__(CS4_CT) void cs4_cols_kernel(const double *__restrict__ M, int64_t ldm, int nrows, int64_t ncols,
+                                                          const double *__restrict__ xin, double *__restrict__ out,
+                                                          double *__restrict__ copy_to) {
+    extern __shared__ __attribute__((aligned(16))) double cs4_x[];              // [nrows][4], then [8 waves][64][4] for the reduction
+    constexpr int NW = CS4_CT / 64;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < nrows * 4; i += CS4_THREADS) cs4_x[i] = xin[i];
+    for (int i = tid; i < nrows * 4; i += CS4_CT) cs4_x[i] = xin[i];
+    if (copy_to && blockIdx.x == 0)
+        for (int i = tid; i < nrows * 4; i += CS4_CT) copy_to[i] = xin[i];
     __syncthreads();
     const int64_t c = (int64_t)blockIdx.x * 64 + lane;
     const bool in = c < ncols;
     const double *mp = M + (in ? c : ncols - 1);
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     int r = wave;
-    for (; r + 12 < nrows; r += 16) {                               // 4 rows of this wave in flight
-        const double m0 = mp[(int64_t)r * ldm], m1 = mp[(int64_t)(r + 4) * ldm], m2 = mp[(int64_t)(r + 8) * ldm],
-                     m3 = mp[(int64_t)(r + 12) * ldm];
-        const double *x = cs4_x + 4 * r;
-        a0 += m0 * x[0]; a1 += m0 * x[1]; a2 += m0 * x[2]; a3 += m0 * x[3];
-        a0 += m1 * x[16]; a1 += m1 * x[17]; a2 += m1 * x[18]; a3 += m1 * x[19];
-        a0 += m2 * x[32]; a1 += m2 * x[33]; a2 += m2 * x[34]; a3 += m2 * x[35];
-        a0 += m3 * x[48]; a1 += m3 * x[49]; a2 += m3 * x[50]; a3 += m3 * x[51];
+    for (; r + 7 * NW < nrows; r += 8 * NW) {
+        double m[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) m[u] = mp[(int64_t)(r + u * NW) * ldm];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const double *x = cs4_x + 4 * (r + u * NW);
+            a0 += m[u] * x[0]; a1 += m[u] * x[1]; a2 += m[u] * x[2]; a3 += m[u] * x[3];
+        }
     }
-    for (; r < nrows; r += 4) {
+    for (; r < nrows; r += NW) {
         const double m0 = mp[(int64_t)r * ldm];
         const double *x = cs4_x + 4 * r;
         a0 += m0 * x[0]; a1 += m0 * x[1]; a2 += m0 * x[2]; a3 += m0 * x[3];
@@ -553,66 +671,65 @@ __global__ __launch_bounds__(CS4_THREADS) void cs4_cols_kernel(const double *__r
         const int cc = tid >> 2, j = tid & 3;
         const int64_t gc = (int64_t)blockIdx.x * 64 + cc;
         if (gc < ncols) {
-            const double v = ((red[(0 * 64 + cc) * 4 + j] + red[(1 * 64 + cc) * 4 + j]) + red[(2 * 64 + cc) * 4 + j]) + red[(3 * 64 + cc) * 4 + j];
+            double v = 0.0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += red[(w * 64 + cc) * 4 + j];
             double *o = out + gc * 4 + j;
             *o = SUB ? *o - v : v;
         }
     }
 }
 
-CSLAM_API int cslam_chol_solve4_dev(const double *d_L, int64_t m, int64_t ld, int col_major, const double *d_dinv, int bs,
-                                    double *d_x, double *d_tmp, void *stream) {
+CSLAM_API int cslam_chol_solve4_dev(const double *d_L, int64_t m, int64_t ld, int col_major, const double *d_dinv,
+                                    const double *d_dinvT, int bs, double *d_x, double *d_tmp, void *stream) {
     PTR_DEVICE(d_L);
-    ARG_CHECK(d_L && d_dinv && d_x && d_tmp, "NULL argument");
+    ARG_CHECK(d_L && d_dinv && d_dinvT && d_x && d_tmp, "NULL argument");
     ARG_CHECK(m >= 1 && ld >= m, "bad m / ld");
     ARG_CHECK(bs >= 64 && bs <= 4096 && (bs % 64) == 0, "block size must be a multiple of 64 in [64, 4096]");
     hipStream_t st = (hipStream_t)stream;
-    const int lds_rows = bs * 4 * 8, lds_cols = (bs * 4 * 8 > 4 * 64 * 4 * 8) ? bs * 4 * 8 : 4 * 64 * 4 * 8;
+    const int lds_rows = bs * 4 * 8, lds_cols = (bs * 4 * 8 > (CS4_CT / 64) * 64 * 4 * 8) ? bs * 4 * 8 : (CS4_CT / 64) * 64 * 4 * 8;
     static bool attr = false;
     if (!attr) {
-        HIP_TRY(hipFuncSetAttribute((const void *)cs4_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
-        HIP_TRY(hipFuncSetAttribute((const void *)cs4_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
-        HIP_TRY(hipFuncSetAttribute((const void *)cs4_cols_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
+        HIP_TRY(hipFuncSetAttribute((const void *)cs4_rows_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
+        HIP_TRY(hipFuncSetAttribute((const void *)cs4_rows_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
         HIP_TRY(hipFuncSetAttribute((const void *)cs4_cols_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
         attr = true;
     }
     const int64_t nb = ceil_div64(m, bs);
-    auto row_grid = [](int64_t rows) { int64_t g = ceil_div64(rows, (CS4_THREADS / 64) * CS4_RPW); return (unsigned)(g > 2048 ? 2048 : (g < 1 ? 1 : g)); };
+    auto row_grid = [](int64_t rows, int rpw) { int64_t g = ceil_div64(rows, (CS4_THREADS / 64) * rpw); return (unsigned)(g > 2048 ? 2048 : (g < 1 ? 1 : g)); };
     // With a column-major factor the memory image is the row-major UPPER factor L^T: the forward update reads it by columns
-    // (cols form), the backward update by rows.
+    // (cols form), the backward update by rows.  The products with the inverted diagonal blocks are always in the row form
+    // (dinv forward, its transpose dinvT backward: one row per wave, 4 rows per workgroup, so that even one 2048-row block
+    // fills the chip).  The block's result goes to tmp; the update launch that consumes it also copies it back into x.
     // forward: L y = b
     for (int64_t t = 0; t < nb; ++t) {
         const int64_t k = t * bs, e = (k + bs < m) ? k + bs : m;
         const int bw = (int)(e - k);
-        // y_t = Dinv_t x[k:e]  -> tmp, then back to x[k:e] (by workgroup 0 of the row-form update, or a copy)
-        hipLaunchKernelGGL(cs4_rows_kernel<false>, dim3(row_grid(bw)), dim3(CS4_THREADS), lds_rows, st,
+        hipLaunchKernelGGL((cs4_rows_kernel<false, 1>), dim3(row_grid(bw, 1)), dim3(CS4_THREADS), lds_rows, st,
                            d_dinv + (size_t)t * bs * bs, (int64_t)bs, (int64_t)bw, bw, d_x + k * 4, d_tmp, (double *)nullptr);
-        if (e < m && !col_major) {
-            hipLaunchKernelGGL(cs4_rows_kernel<true>, dim3(row_grid(m - e)), dim3(CS4_THREADS), lds_rows, st,
-                               d_L + e * ld + k, ld, m - e, bw, d_tmp, d_x + e * 4, d_x + k * 4);
-        } else {
+        if (e >= m)
             HIP_TRY(hipMemcpyAsync(d_x + k * 4, d_tmp, (size_t)bw * 32, hipMemcpyDeviceToDevice, st));
-            if (e < m)
-                hipLaunchKernelGGL(cs4_cols_kernel<true>, dim3((unsigned)ceil_div64(m - e, 64)), dim3(CS4_THREADS), lds_cols, st,
-                                   d_L + k * ld + e, ld, bw, m - e, d_tmp, d_x + e * 4);
-        }
+        else if (!col_major)
+            hipLaunchKernelGGL((cs4_rows_kernel<true, 4>), dim3(row_grid(m - e, 4)), dim3(CS4_THREADS), lds_rows, st,
+                               d_L + e * ld + k, ld, m - e, bw, d_tmp, d_x + e * 4, d_x + k * 4);
+        else
+            hipLaunchKernelGGL(cs4_cols_kernel<true>, dim3((unsigned)ceil_div64(m - e, 64)), dim3(CS4_CT), lds_cols, st,
+                               d_L + k * ld + e, ld, bw, m - e, d_tmp, d_x + e * 4, d_x + k * 4);
     }
     // backward: L^T x = y
     for (int64_t t = nb - 1; t >= 0; --t) {
         const int64_t k = t * bs, e = (k + bs < m) ? k + bs : m;
         const int bw = (int)(e - k);
-        // x_t = Dinv_t^T y_t -> tmp -> x[k:e]
-        hipLaunchKernelGGL(cs4_cols_kernel<false>, dim3((unsigned)ceil_div64(bw, 64)), dim3(CS4_THREADS), lds_cols, st,
-                           d_dinv + (size_t)t * bs * bs, (int64_t)bs, bw, (int64_t)bw, d_x + k * 4, d_tmp);
-        HIP_TRY(hipMemcpyAsync(d_x + k * 4, d_tmp, (size_t)bw * 32, hipMemcpyDeviceToDevice, st));
-        if (k > 0) {
-            if (!col_major)
-                hipLaunchKernelGGL(cs4_cols_kernel<true>, dim3((unsigned)ceil_div64(k, 64)), dim3(CS4_THREADS), lds_cols, st,
-                                   d_L + k * ld, ld, bw, k, d_tmp, d_x);
-            else
-                hipLaunchKernelGGL(cs4_rows_kernel<true>, dim3(row_grid(k)), dim3(CS4_THREADS), lds_rows, st,
-                                   d_L + k, ld, k, bw, d_tmp, d_x, (double *)nullptr);
-        }
+        hipLaunchKernelGGL((cs4_rows_kernel<false, 1>), dim3(row_grid(bw, 1)), dim3(CS4_THREADS), lds_rows, st,
+                           d_dinvT + (size_t)t * bs * bs, (int64_t)bs, (int64_t)bw, bw, d_x + k * 4, d_tmp, (double *)nullptr);
+        if (k == 0)
+            HIP_TRY(hipMemcpyAsync(d_x + k * 4, d_tmp, (size_t)bw * 32, hipMemcpyDeviceToDevice, st));
+        else if (!col_major)
+            hipLaunchKernelGGL(cs4_cols_kernel<true>, dim3((unsigned)ceil_div64(k, 64)), dim3(CS4_CT), lds_cols, st,
+                               d_L + k * ld, ld, bw, k, d_tmp, d_x, d_x + k * 4);
+        else
+            hipLaunchKernelGGL((cs4_rows_kernel<true, 4>), dim3(row_grid(k, 4)), dim3(CS4_THREADS), lds_rows, st,
+                               d_L + k, ld, k, bw, d_tmp, d_x, d_x + k * 4);
     }
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;

@@ -71,6 +71,10 @@ __device__ __forceinline__ unsigned wh_pack(float v) {                    // [fp
     return (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, lo) << 16);
 }
 
+// DBG & 32 (CSLAM_WFH_PROF=1, results stay correct): waves 0 and 4 of workgroup 0 add up the shader cycles (s_memtime) they
+// spend in each phase of a quarter and leave them in the buffer `cslam_debug_wfh_prof_dev` points the kernel at:
+// [wave 0 | wave 4][transform, barrier 1, matrix loop, prefetch + stem work, output transform, barrier 2, quarters]
+__device__ unsigned long long *wfh_prof = nullptr;
 // DBG: timing-only ablations (wrong results), CSLAM_WFH_DBG: 1 = every weight fragment from ONE address (L1 hits: no L2
 // latency), 2 = no input transform, 4 = no MFMAs, 8 = no patch loads after the first, 16 = no output transform / stores
 // STEM (COUT = 64 only): the 64-channel input of this convolution is itself the 3 -> 64 channel first convolution of the
@@ -86,6 +90,7 @@ __device__ __forceinline__ unsigned wh_pack(float v) {                    // [fp
 #define ST_IW 36
 #define ST_IPL (20 * ST_IW)
 #define ST_IMG (3 * ST_IPL)
+#define ST_GRP 2                       // row tiles of the first layer a wave works on at once
 #define ST_PAD 768                     // zero dwords behind the image: the unused K slots of lane group 3 read there
 template <int COUT, bool RELU, bool POOL, int DBG, int WH_BR, bool RES = false, bool STEM = false>
 __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
@@ -107,6 +112,7 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
     unsigned *s_v = (unsigned *)(wh_smem + NPB * PBUF * 4);         // [36][NT][16]
     unsigned *s_img = s_v + 36 * NT * WH_VS;                        // STEM: [20][36][3] packed [hi | lo] image patch + ST_PAD zeros
     float *s_raw = (float *)(s_img + ST_IMG + ST_PAD);              // STEM: [NL * 512] the same patch as it arrives (planar order)
+    unsigned *s_w1 = (unsigned *)(s_raw + NL * 512);                // STEM: first-layer weights [4 quarters][hi | lo][64 lanes][4] + bias [64]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -193,37 +199,60 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
     const int st_lane_stride = st_gq < 3 ? 1 : 3 * ST_IW;
     auto produce = [&](int kq, int b_by, int b_sx) {               // patch quarter kq of block (b_by, b_sx) -> s_p
         const int gx0 = b_sx * (16 * NB) - 1, gy0 = b_by * 16 - 1;
-        const u4 w1h = ((const u4 *)st_w1)[(kq * 2 + 0) * 64 + lane], w1l = ((const u4 *)st_w1)[(kq * 2 + 1) * 64 + lane];
-        const float b1 = st_b1 ? st_b1[16 * kq + (lane & 15)] : 0.0f;
+        // weights and bias from LDS (8 KB, staged once): as global loads they queued behind the next quarter's weight fragments
+        const u4 w1h = ((const u4 *)s_w1)[(kq * 2 + 0) * 64 + lane], w1l = ((const u4 *)s_w1)[(kq * 2 + 1) * 64 + lane];
+        const float b1 = __uint_as_float(s_w1[2048 + 16 * kq + (lane & 15)]);
+        // blocks whose 18 x 34 patch lies inside the map (61 % of a 224 x 224 frame's) skip the per-pixel tests
+        const bool whole = (gy0 >= 0) & (gy0 + 18 <= H) & (gx0 >= 0) & (gx0 + PWX <= W);
+        constexpr int NMT = (NPIX + 15) / 16;                       // 39 row tiles of 16 pixels, wave w takes w, w + 8, ...
+        constexpr int PER = (NMT + 7) / 8;
+        // a wave's row tiles TWO at a time: the image reads of both are in flight before the first MFMA and their three-MFMA
+        // chains interleave (one tile at a time the phase is a chain of LDS and MFMA latencies; all five at once spill)
         const h8 Bh = __builtin_bit_cast(h8, w1h), Bl = __builtin_bit_cast(h8, w1l);
 #pragma unroll 1
-        for (int mt = wave; mt < (NPIX + 15) / 16; mt += 8) {
-            int p = 16 * mt + (lane & 15);
-            p = p < NPIX ? p : NPIX - 1;
-            const int pr = (p * 1928) >> 16, pc = p - PWX * pr;                    // p / 34 for p < 700
-            const unsigned *ib = s_img + (pr * ST_IW + pc) * 3 + st_lane_off;
-            unsigned pk[8];
+        for (int i0 = 0; i0 < PER; i0 += ST_GRP) {
+            unsigned pk[ST_GRP][8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pk[j] = ib[j * st_lane_stride];
-            u4 ah, al;
+            for (int i = 0; i < ST_GRP; ++i) {
+                const int mt = wave + 8 * (i0 + i);
+                int p = 16 * mt + (lane & 15);
+                p = p < NPIX ? p : NPIX - 1;
+                const int pr = (p * 1928) >> 16, pc = p - PWX * pr;                // p / 34 for p < 700
+                const unsigned *ib = s_img + (pr * ST_IW + pc) * 3 + st_lane_off;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                ah[d] = __builtin_amdgcn_perm(pk[2 * d + 1], pk[2 * d], 0x05040100u);     // (hi, hi) of slots 2d, 2d + 1
-                al[d] = __builtin_amdgcn_perm(pk[2 * d + 1], pk[2 * d], 0x07060302u);     // (lo, lo)
+                for (int j = 0; j < 8; ++j) pk[i][j] = ib[j * st_lane_stride];
             }
-            const h8 Ah = __builtin_bit_cast(h8, ah), Al = __builtin_bit_cast(h8, al);
-            f4 c = (f4)(0.0f);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh, c, 0, 0, 0);
-            c = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl, c, 0, 0, 0);
+            f4 c[ST_GRP];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int p2 = 16 * mt + 4 * st_gq + i;                            // lane holds rows 4 gq + i of column lane & 15
-                const int pr2 = (p2 * 1928) >> 16, pc2 = p2 - PWX * pr2;
-                const int gy = gy0 + pr2, gx = gx0 + pc2;
-                const bool in = (p2 < NPIX) & (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W);
-                const float v = fmaxf(c[i] * st_inv1 + b1, 0.0f);                  // exact power-of-two rescale, bias, ReLU
-                s_p[p2 * WH_PS + (lane & 15)] = in ? v : 0.0f;                     // outside the map: the second layer's zero padding
+            for (int i = 0; i < ST_GRP; ++i) {
+                u4 ah, al;
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    ah[d] = __builtin_amdgcn_perm(pk[i][2 * d + 1], pk[i][2 * d], 0x05040100u); // (hi, hi) of slots 2d, 2d + 1
+                    al[d] = __builtin_amdgcn_perm(pk[i][2 * d + 1], pk[i][2 * d], 0x07060302u); // (lo, lo)
+                }
+                const h8 Ah = __builtin_bit_cast(h8, ah), Al = __builtin_bit_cast(h8, al);
+                c[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Al, Bh, (f4)(0.0f), 0, 0, 0);
+                c[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bl, c[i], 0, 0, 0);
+                c[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Ah, Bh, c[i], 0, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < ST_GRP; ++i) {
+                const int mt = wave + 8 * (i0 + i);
+                if (mt < NMT) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int p2 = 16 * mt + 4 * st_gq + r;                    // lane holds rows 4 gq + r of column lane & 15
+                        const float v = fmaxf(c[i][r] * st_inv1 + b1, 0.0f);       // exact power-of-two rescale, bias, ReLU
+                        bool in = true;
+                        if (!whole) {
+                            const int pr2 = (p2 * 1928) >> 16, pc2 = p2 - PWX * pr2;
+                            const int gy = gy0 + pr2, gx = gx0 + pc2;
+                            in = (gy >= 0) & (gy < H) & (gx >= 0) & (gx < W);
+                        }
+                        s_p[p2 * WH_PS + (lane & 15)] = in ? v : 0.0f;             // outside the map: the second layer's zero padding
+                    }
+                }
             }
         }
     };
@@ -246,6 +275,12 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
 #pragma unroll
     for (int xi = 0; xi < 36; ++xi) acc[xi] = (f4)(0.0f);
     float my_amax = 0.0f;
+    unsigned long long *prof = nullptr;
+    unsigned long long tacc[7] = {0, 0, 0, 0, 0, 0, 0}, tl = 0;
+    if constexpr ((DBG & 32) != 0) {
+        if (blockIdx.x == 0 && (tid & 255) == 0) prof = wfh_prof;
+    }
+#define WH_TICK(i) do { if constexpr ((DBG & 32) != 0) { if (prof) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); tacc[i] += t_ - tl; tl = t_; } } } while (0)
 
     const int n_mine = (nsb - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int total_q = 4 * n_mine;                                 // quarters this workgroup walks
@@ -267,6 +302,8 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
     };
     if constexpr (STEM) {
         for (int i = tid; i < ST_PAD; i += 512) s_img[ST_IMG + i] = 0u;
+        for (int i = tid; i < 2048; i += 512) s_w1[i] = st_w1[i];
+        if (tid < 64) s_w1[2048 + tid] = st_b1 ? __float_as_uint(st_b1[tid]) : 0u;
         if (n_mine > 0) {
             geometry((int)blockIdx.x);
             n_img = c_img; n_by = c_by; n_sx = c_sx;
@@ -294,6 +331,7 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
 #pragma unroll 1
         for (int kq = 0; kq < 4; ++kq) {
             const int pb = STEM ? 0 : kq & 1;                       // 4 quarters per iteration: the buffer parity is kq's
+            if constexpr ((DBG & 32) != 0) { if (prof) { tl = __builtin_amdgcn_s_memtime(); tacc[6] += 1; } }
             // (b) V = B^T (sV d) B, split into fp16 pairs
             if (t_on && !(DBG & 2)) {
                 const float *src = s_p + pb * PBUF + t_src;
@@ -313,10 +351,12 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
             }
             // V complete: LDS stores drained, then a RAW barrier -- __syncthreads() would also wait for the LDS-DMA of the
             // next patch (a pending LDS write), which is meant to stay in flight across this barrier
+            WH_TICK(0);
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0) only
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            WH_TICK(1);
             // (c) 36 frequencies x 2 MFMAs, weight fragments WH_BR pairs ahead (the first WH_BR pairs were requested at the
             // end of the previous quarter)
             // A fragments (LDS) two pairs ahead of their use: issued right before its consumer a ds_read costs its whole
@@ -354,6 +394,7 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
                 }
                 __builtin_amdgcn_sched_barrier(0);                  // keep the rings as deep as written: no hoisting of later loads
             }
+            WH_TICK(2);
             // first weight fragments of the next quarter, THEN the patch of the quarter after it (see request_next)
             {
                 const int nkq = (kq + 1) & 3;
@@ -384,6 +425,7 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
                     produce(0, n_by, n_sx);
                 }
             }
+            WH_TICK(3);
             if (kq == 3 && (DBG & 16)) {
                 f4 t = acc[0];
 #pragma unroll
@@ -455,15 +497,22 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
 #pragma unroll
                 for (int xi = 0; xi < 36; ++xi) acc[xi] = (f4)(0.0f);
             }
+            WH_TICK(4);
             // The patch of the NEXT quarter was requested one quarter ago, ahead of every weight fragment this quarter used:
             // loads return in order, so it has landed in this wave; the barrier makes that true for all waves.  (Still
             // outstanding, deliberately: the weight fragments and the patch requested just above.)
             asm volatile("" ::: "memory");
             __builtin_amdgcn_s_barrier();                           // V is free again, the next patch visible to everyone
             asm volatile("" ::: "memory");
+            WH_TICK(5);
         }
         o_img = n_img; o_by = n_by; o_sx = n_sx;
     }
+    if constexpr ((DBG & 32) != 0) {
+        if (prof)
+            for (int i = 0; i < 7; ++i) prof[(tid >> 8) * 8 + i] = tacc[i];
+    }
+#undef WH_TICK
     if (amax_out) {
         // max |y| of everything this workgroup wrote: wave maximum, LDS maximum, one global atomic per workgroup and only if
         // it would raise the slot
@@ -535,6 +584,11 @@ static int launch_fused_h(const float *d_x, const unsigned *d_Uh, const float *d
                                 d_bias, d_res, H, W, gxs, gyb, (int)nsb, d_amax, inv_su, d_amax_out, zero16, d_y, (const unsigned *)nullptr, (const float *)nullptr, (const float *)nullptr, 0.0f);
         return CSLAM_OK;
     }
+    const char *prof_env = getenv("CSLAM_WFH_PROF");
+    if (prof_env && atoi(prof_env) && relu && !d_res) {             // per-phase cycle counts of workgroup 0 (conv1_2's / conv2_1's forms)
+        if (COUT == 64 && pool) { WH_LAUNCH_DB(true, true, 32, WH_BR_DEFAULT); return CSLAM_OK; }
+        if (COUT == 128 && !pool) { WH_LAUNCH_DB(true, false, 32, WH_BR_DEFAULT); return CSLAM_OK; }
+    }
     if (relu && pool) WH_LAUNCH(true, true);
     else if (relu) WH_LAUNCH(true, false);
     else if (pool) WH_LAUNCH(false, true);
@@ -577,7 +631,7 @@ static int launch_stem_h(const float *d_x0, const unsigned *d_w1, const float *d
     ARG_CHECK((int64_t)B * H * W * 3 < (1ll << 31), "image batch too large for the 32-bit patch offsets");
     const int grid_n = (int)(nsb < n_cu ? nsb : n_cu);
     constexpr int NPIX = 18 * 34, NL = (4 * NPIX + 511) / 512;
-    constexpr int lds = NL * 512 * 16 + 36 * 32 * 64 + (ST_IMG + ST_PAD) * 4 + NL * 512 * 4;
+    constexpr int lds = NL * 512 * 16 + 36 * 32 * 64 + (ST_IMG + ST_PAD) * 4 + NL * 512 * 4 + (2048 + 64) * 4;
     static float *zero16[16] = {nullptr};                           // 16 zero bytes per device
     ARG_CHECK(dev < 16, "device index");
     if (!zero16[dev]) {
@@ -585,11 +639,14 @@ static int launch_stem_h(const float *d_x0, const unsigned *d_w1, const float *d
         HIP_TRY(hipMemset(zero16[dev], 0, 256));
     }
     dim3 grid((unsigned)grid_n), block(512);
-#define ST_LAUNCH(P) do { \
-        HIP_TRY(hipFuncSetAttribute((const void *)wino4_fused_c64_h_kernel<64, true, P, 0, WH_BR_DEFAULT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
-        hipLaunchKernelGGL((wino4_fused_c64_h_kernel<64, true, P, 0, WH_BR_DEFAULT, false, true>), grid, block, lds, st, d_x0, d_Uh, d_bias, \
+#define ST_LAUNCH(P, D) do { \
+        HIP_TRY(hipFuncSetAttribute((const void *)wino4_fused_c64_h_kernel<64, true, P, D, WH_BR_DEFAULT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+        hipLaunchKernelGGL((wino4_fused_c64_h_kernel<64, true, P, D, WH_BR_DEFAULT, false, true>), grid, block, lds, st, d_x0, d_Uh, d_bias, \
                            (const float *)nullptr, H, W, gxs, gyb, (int)nsb, d_amax, inv_su, d_amax_out, zero16[dev], d_y, d_w1, d_b1, d_sumw, inv_sw); } while (0)
-    if (pool) ST_LAUNCH(true); else ST_LAUNCH(false);
+    const char *prof_env = getenv("CSLAM_WFH_PROF");
+    if (prof_env && atoi(prof_env) && pool) ST_LAUNCH(true, 32);
+    else if (pool) ST_LAUNCH(true, 0);
+    else ST_LAUNCH(false, 0);
 #undef ST_LAUNCH
     return CSLAM_OK;
 }
@@ -606,5 +663,12 @@ CSLAM_API int cslam_wino4_stem_c64_h_dev(const float *d_x0, const void *d_w1, co
                                  d_amax_x0, inv_su, d_amax_out, d_y, (hipStream_t)stream);
     if (rc != CSLAM_OK) return rc;
     HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
+/* diagnostics: where CSLAM_WFH_PROF=1 launches leave their per-phase cycle counts (16 x 8 bytes, device memory; NULL = off) */
+CSLAM_API int cslam_debug_wfh_prof_dev(void *d_buf16) {
+    unsigned long long *p = (unsigned long long *)d_buf16;
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(wfh_prof), &p, sizeof(p)));
     return CSLAM_OK;
 }

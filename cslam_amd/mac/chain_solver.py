@@ -31,11 +31,17 @@ class ChainReducedSolver:
         L = sp.csr_matrix(L, dtype=np.float64)
         n = L.shape[0]
         self.n, self.ground = n, int(ground)
-        c = np.zeros(max(n - 1, 0))                      # chain conductances c[i] of edge (i, i+1)
+        # chain conductances c[i] of edge (i, i+1) and the loop edges |i - j| >= 2, straight from the CSR arrays (row-major
+        # order, as `sp.triu(L, 2).tocoo()` / `L.diagonal(1)` gave them: those two calls were half of this constructor)
+        L.sum_duplicates()                                  # no-op for the canonical matrices MAC builds
+        rows = np.repeat(np.arange(n, dtype=L.indices.dtype), np.diff(L.indptr))
+        d = L.indices - rows                                # column - row of every stored entry
+        c = np.zeros(max(n - 1, 0))
         if n > 1:
-            c = -np.asarray(L.diagonal(1), dtype=np.float64)
-        coo = sp.triu(L, k=2).tocoo()                     # loop edges: |i - j| >= 2
-        li, lj, lw = coo.row.astype(np.int64), coo.col.astype(np.int64), -coo.data
+            sup = np.flatnonzero(d == 1)
+            c[rows[sup]] = -L.data[sup]
+        up = np.flatnonzero(d >= 2)
+        li, lj, lw = rows[up].astype(np.int64), L.indices[up].astype(np.int64), -L.data[up]
         keep = lw != 0
         li, lj, lw = li[keep], lj[keep], lw[keep]
         is_j = np.zeros(n, dtype=bool)

@@ -63,6 +63,7 @@ class BlockedCholeskySolve(object):
             e = min(k + bs, self.m)
             eye = torch.eye(e - k, dtype=L.dtype, device=L.device)
             self.dinv[t, :e - k, :e - k] = torch.linalg.solve_triangular(L[k:e, k:e], eye, upper=False)
+        self.dinvT = self.dinv.transpose(1, 2).contiguous()
         self.tmp = torch.empty((bs, 4), dtype=L.dtype, device=L.device)
 
     def solve(self, b):
@@ -70,9 +71,33 @@ class BlockedCholeskySolve(object):
         assert b.shape == (self.m, 4) and b.dtype == torch.float64
         x = b.contiguous().clone()
         st = C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream)
-        _lib.check(self.lib.cslam_chol_solve4_dev(_p(self.L), self.m, max(self.ld, self.m), self.col_major, _p(self.dinv), self.bs,
-                                                  _p(x), _p(self.tmp), st))
+        _lib.check(self.lib.cslam_chol_solve4_dev(_p(self.L), self.m, max(self.ld, self.m), self.col_major, _p(self.dinv), _p(self.dinvT),
+                                                  self.bs, _p(x), _p(self.tmp), st))
         return x
+
+
+class _DensePool(object):
+    """Float64 device buffers for the dense junction matrix, handed from one solver to the next: MAC builds a new, slightly
+    larger system in every Frank-Wolfe iteration, and a fresh multi-gigabyte hipMalloc / hipFree per system cost up to 0.1 s."""
+    free = []
+
+    @classmethod
+    def take(cls, numel, device):
+        import torch
+        best = None
+        for t in cls.free:
+            if t.device == device and t.numel() >= numel and (best is None or t.numel() < best.numel()):
+                best = t
+        if best is not None:
+            cls.free.remove(best)
+            return best
+        cls.free[:] = [t for t in cls.free if t.device != device]          # too small: let them go before growing
+        return torch.empty(int(numel * 1.3) + 1024, dtype=torch.float64, device=device)
+
+    @classmethod
+    def give(cls, t):
+        if t is not None and len(cls.free) < 2:
+            cls.free.append(t)
 
 
 class ChainReducedSolverGPU(object):
@@ -123,7 +148,9 @@ class ChainReducedSolverGPU(object):
             # (a 40k-junction matrix is 12.8 GB: never materialised on the host)
             g = int(host.jid[host.ground])
             m = nJ - 1
-            Sf = torch.zeros((m, m), dtype=torch.float64, device=dev)
+            self._pool_buf = _DensePool.take(m * m, dev)
+            Sf = self._pool_buf[:m * m].view(m, m)
+            Sf.zero_()
             ri, rj, rw = t(host.red_i, np.int64), t(host.red_j, np.int64), t(host.red_w, np.float64)
             fi = ri - (ri > g).to(torch.int64)
             fj = rj - (rj > g).to(torch.int64)
@@ -147,8 +174,14 @@ class ChainReducedSolverGPU(object):
         if os.environ.get('CSLAM_MAC_TIMING'):
             print(flush=True)
 
-    def solve(self, X):
-        """X [n,4] float64 device tensor -> A^-1 X (row `ground` = 0)."""
+    def __del__(self):
+        try:
+            _DensePool.give(getattr(self, '_pool_buf', None))
+        except Exception:
+            pass
+
+    def solve(self, X, out=None):
+        """X [n,4] float64 device tensor -> A^-1 X (row `ground` = 0), into `out` when given."""
         torch = self.torch
         assert X.shape == (self.n, 4) and X.dtype == torch.float64 and X.is_contiguous()
         st = C.c_void_p(torch.cuda.current_stream(X.device).cuda_stream)
@@ -156,14 +189,17 @@ class ChainReducedSolverGPU(object):
             _p(X), _p(self.is_j), _p(self.r), self.n, _p(self.J), self.nJ, _p(self.seg_start_of),
             _p(self.seg_end_of), _p(self.sa), _p(self.sb), _p(self.Rl), _p(self.Bn), _p(self.Qn), _p(self.tmp),
             _p(self.scratch), _p(self.bt), st))
-        xJ = torch.zeros((self.nJ, 4), dtype=torch.float64, device=X.device)
+        if getattr(self, '_xJ', None) is None:
+            self._xJ = torch.zeros((self.nJ, 4), dtype=torch.float64, device=X.device)     # the grounded row stays 0
+        xJ = self._xJ
         if self.nJ > 1:
             rhs = self.bt[self.free]
             if self.dense:
                 xJ[self.free] = self.tri.solve(rhs) if self.tri is not None else torch.cholesky_solve(rhs, self.chol)
             else:
                 xJ[self.free] = torch.from_numpy(self.host.lu.solve(rhs.cpu().numpy())).to(X.device)
-        out = torch.empty_like(X)
+        if out is None:
+            out = torch.empty_like(X)
         _lib.check(self.lib.cslam_chain_backward_dev(
             _p(xJ), _p(self.Bn), _p(self.Qn), _p(self.r), _p(self.Rn), _p(self.jid), _p(self.seg_of), _p(self.sa),
             _p(self.sb), _p(self.Rl), self.n, _p(out), st))
@@ -176,11 +212,19 @@ _START_CACHE = {}
 def fiedler_tracemin_chain_gpu(L, tol=1e-8, seed=None, device="cuda", stats=None):
     """TraceMIN-Fiedler (same start block, projection and stopping rule as the reference's
     networkx call, see fiedler.py) with every O(n) step on the GPU.  Returns (lambda_2, v numpy)."""
+    import os
+    import time as _time
     import torch
+    _tt = [_time.perf_counter()]
+
+    def _lap(tag):
+        if os.environ.get('CSLAM_MAC_TIMING') == '2':
+            torch.cuda.synchronize(); _tt.append(_time.perf_counter()); print(f'      <{tag} {(_tt[-1] - _tt[-2]) * 1e3:.0f} ms>', end='', flush=True)
     if seed is None:
         seed = np.random.RandomState(7)
     L = sp.csr_matrix(L, dtype=np.float64)
     L.sort_indices()
+    _lap('csr')
     n = L.shape[0]
     assert n > 4, "use the host solver for tiny graphs"
     dev = torch.device(device)
@@ -192,32 +236,51 @@ def fiedler_tracemin_chain_gpu(L, tol=1e-8, seed=None, device="cuda", stats=None
         _START_CACHE['X0'] = torch.from_numpy(np.ascontiguousarray(np.asarray(seed.normal(size=(4, n))).T)).to(dev)
     X = _START_CACHE['X0'].clone()
     ground = int((L.indptr[1:] - L.indptr[:-1]).argmax())
+    _lap('start block')
     solver = ChainReducedSolverGPU(L, ground, device)
+    _lap('solver')
     indptr = torch.from_numpy(L.indptr.astype(np.int64)).to(dev)
     indices = torch.from_numpy(L.indices.astype(np.int32)).to(dev)
     data = torch.from_numpy(L.data).to(dev)
-    Lnorm = float(abs(L).sum(axis=1).max())
+    _lap('csr upload')
+    # max row sum of |L| (the stopping rule's scale): segment sums over the CSR arrays (`abs(L).sum(axis=1)` builds two
+    # temporaries of the matrix); an empty row would pick up its successor's first entry, so those are masked
+    if L.nnz:
+        starts = np.minimum(L.indptr[:-1], L.nnz - 1)
+        rs = np.add.reduceat(np.abs(L.data), starts)
+        rs[L.indptr[1:] == L.indptr[:-1]] = 0.0
+        Lnorm = float(rs.max())
+    else:
+        Lnorm = 0.0
+    _lap('norm')
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     W = torch.empty_like(X)
     partial = torch.empty(20 * 1024, dtype=torch.float64, device=dev)
     out20 = torch.empty(20, dtype=torch.float64, device=dev)
-    small = torch.empty(16 + 4, dtype=torch.float64, device=dev)       # 4x4 matrix + 4-vector staging
+    # The 4 x 4 algebra between the streaming passes stays on the host (LAPACK, as in the reference); its operands travel as
+    # kernel arguments and its inputs come back as one 160-byte copy per pass (`cslam_block4_*_sync / _host`): no torch
+    # tensors are created inside the loop, X ping-pongs between two resident buffers.
+    h20 = np.empty(20, dtype=np.float64)
+    h20_p = h20.ctypes.data_as(C.c_void_p)
+    pool = [torch.empty_like(X), torch.empty_like(X)]         # free [n,4] buffers (X itself is the third)
 
     def gram(A, B):
         """(A^T B as numpy 4x4, column sums of B)"""
-        _lib.check(lib.cslam_block4_gram_dev(_p(A), _p(B), n, _p(partial), _p(out20), st))
-        h = out20.cpu().numpy()
-        return h[:16].reshape(4, 4).copy(), h[16:].copy()
+        _lib.check(lib.cslam_block4_gram_sync(_p(A), _p(B), n, _p(partial), _p(out20), h20_p, st))
+        return h20[:16].reshape(4, 4).copy(), h20[16:].copy()
+
+    def affine_into(out, A, M, shift=None):
+        """out = A @ M - shift (one streaming pass; out must not be A)"""
+        Mc = np.ascontiguousarray(M, dtype=np.float64)
+        sc_ = None if shift is None else np.ascontiguousarray(shift, dtype=np.float64)
+        _lib.check(lib.cslam_block4_affine_host(_p(A), n, Mc.ctypes.data_as(C.c_void_p),
+                                                None if sc_ is None else sc_.ctypes.data_as(C.c_void_p), _p(out), st))
+        return out
 
     def affine(A, M, shift=None):
-        """A @ M - shift, one streaming pass"""
-        small[:16] = torch.from_numpy(np.ascontiguousarray(M, dtype=np.float64).reshape(-1)).to(dev)
-        sp_ = None
-        if shift is not None:
-            small[16:] = torch.from_numpy(np.ascontiguousarray(shift, dtype=np.float64)).to(dev)
-            sp_ = C.c_void_p(small.data_ptr() + 16 * 8)
-        out = torch.empty_like(A)
-        _lib.check(lib.cslam_block4_affine_dev(_p(A), n, _p(small), sp_, _p(out), st))
+        """A @ M - shift into a free buffer; A's buffer becomes free"""
+        out = affine_into(pool.pop(), A, M, shift)
+        pool.append(A)
         return out
 
     def orthonormalise(X):
@@ -234,6 +297,7 @@ def fiedler_tracemin_chain_gpu(L, tol=1e-8, seed=None, device="cuda", stats=None
         stats['nJ'] = solver.nJ; t_loop = time.perf_counter()
     _, cs = gram(X, X)
     X = affine(X, np.eye(4), cs / n)                         # project out the constant vector
+    h1 = np.empty(1, dtype=np.float64)
     while True:
         if stats is not None:
             stats['iters'] += 1
@@ -242,16 +306,19 @@ def fiedler_tracemin_chain_gpu(L, tol=1e-8, seed=None, device="cuda", stats=None
         H, _ = gram(X, W)
         sigma, Y = scipy.linalg.eigh(0.5 * (H + H.T))
         X = affine(X, Y)
-        small[:4] = torch.from_numpy(np.ascontiguousarray(Y[:, 0])).to(dev)
-        _lib.check(lib.cslam_block4_residual_dev(_p(W), _p(X), n, _p(small), float(sigma[0]), _p(partial), _p(out20), st))
-        res = float(out20[0].item()) / Lnorm
+        y0 = np.ascontiguousarray(Y[:, 0], dtype=np.float64)
+        _lib.check(lib.cslam_block4_residual_sync(_p(W), _p(X), n, y0.ctypes.data_as(C.c_void_p), float(sigma[0]), _p(partial),
+                                                  _p(out20), h1.ctypes.data_as(C.c_void_p), st))
+        res = float(h1[0]) / Lnorm
         if res < tol:
             break
-        Wi = solver.solve(X)
-        M, _ = gram(Wi, X)                                   # W^T X
-        X = affine(Wi, np.linalg.inv(M).T)
-        _, cs = gram(X, X)
-        X = affine(X, np.eye(4), cs / n)
+        Wi = solver.solve(X, out=pool.pop())
+        # X <- Wi (Wi^T X)^-1, then minus its column means: the column sums of the product are those of Wi times the same
+        # matrix, so one pass over (X, Wi) gives both and one pass writes the projected block (over the old X)
+        Mt, csW = gram(X, Wi)                                # X^T Wi = (Wi^T X)^T and the column sums of Wi
+        Minv_T = np.linalg.inv(Mt.T).T
+        affine_into(X, Wi, Minv_T, (csW @ Minv_T) / n)
+        pool.append(Wi)
     if stats is not None:
         torch.cuda.synchronize(); stats['loop_s'] = time.perf_counter() - t_loop
     return float(sigma[0]), X[:, 0].cpu().numpy()

@@ -34,7 +34,15 @@ class MAC:
         """(lambda_2(L), v_2(L)); reference mac.py:35-59."""
         assert method == 'tracemin_lu'
         if self.fiedler_solver == 'chain_gpu':
+            import os
             from .chain_solver_gpu import fiedler_tracemin_chain_gpu
+            if os.environ.get('CSLAM_MAC_TIMING'):
+                import time
+                st = {'t0': time.perf_counter()}
+                out = fiedler_tracemin_chain_gpu(L, tol=tol, seed=np.random.RandomState(7), stats=st)
+                print('      [fiedler: nJ=%d setup %.0f ms, %d TraceMIN iterations %.0f ms = %.2f ms each]' % (
+                    st['nJ'], st['setup_s'] * 1e3, st['iters'], st['loop_s'] * 1e3, st['loop_s'] * 1e3 / max(st['iters'], 1)), flush=True)
+                return out
             return fiedler_tracemin_chain_gpu(L, tol=tol, seed=np.random.RandomState(7))
         if self.fiedler_solver == 'chain':
             return fiedler_tracemin_chain(L, tol=tol, seed=np.random.RandomState(7))

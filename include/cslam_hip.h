@@ -184,6 +184,16 @@ int cslam_block4_affine_dev(const double *d_A, int64_t n, const double *d_M16, c
 int cslam_block4_residual_dev(const double *d_W, const double *d_X, int64_t n, const double *d_y4,
                               double sigma, double *d_partial, double *d_out1, void *stream);
 
+/* Host-synchronous twins of the three calls above for the TraceMIN outer loop, whose 4 x 4 algebra runs on the host
+ * (LAPACK, as in networkx): the 4 x 4 matrix / shift / Ritz vector are HOST pointers passed on as kernel arguments, and the
+ * 20-double (1-double) result is copied to h_out and the stream synchronised inside the call. */
+int cslam_block4_gram_sync(const double *d_A, const double *d_B, int64_t n, double *d_partial, double *d_out20,
+                           double *h_out20, void *stream);
+int cslam_block4_affine_host(const double *d_A, int64_t n, const double *h_M16, const double *h_shift4, double *d_out,
+                             void *stream);
+int cslam_block4_residual_sync(const double *d_W, const double *d_X, int64_t n, const double *h_y4, double sigma,
+                               double *d_partial, double *d_out1, double *h_out1, void *stream);
+
 /* Chain-reduced Laplacian solve (cslam_amd/mac/chain_solver.py): replaces the sparse-LU solves inside
  * networkx `_tracemin_fiedler` that cslam/mac/mac.py:52-58 calls (85 % of MAC's time).  Vectors are
  * [n][4] float64 row-major.  forward: segmented prefix sums of the right-hand side along the odometry
@@ -204,10 +214,11 @@ int cslam_chain_backward_dev(const double *d_xJ, const double *d_Bn, const doubl
  * read; col_major != 0: element (r, c) at c * ld + r instead of r * ld + c, the layout LAPACK-style library
  * factorisations return) of the grounded junction Laplacian, x [m][4]: the junction solve inside every TraceMIN iteration (SuperLU's
  * solve in networkx `_tracemin_fiedler`, called at cslam/mac/mac.py:52-58).  d_dinv: inverses of the bs x bs diagonal
- * blocks of L, [ceil(m / bs)][bs][bs] (a ragged last block in the top-left corner of its slot); d_tmp: [bs][4]
+ * blocks of L, [ceil(m / bs)][bs][bs] (a ragged last block in the top-left corner of its slot), d_dinvT: the same
+ * blocks transposed; d_tmp: [bs][4]
  * scratch.  Blocked substitution, every factor element read exactly once per sweep, fixed summation order. */
-int cslam_chol_solve4_dev(const double *d_L, int64_t m, int64_t ld, int col_major, const double *d_dinv, int bs,
-                          double *d_x, double *d_tmp, void *stream);
+int cslam_chol_solve4_dev(const double *d_L, int64_t m, int64_t ld, int col_major, const double *d_dinv,
+                          const double *d_dinvT, int bs, double *d_x, double *d_tmp, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Lidar place recognition: ScanContext bank.
@@ -328,6 +339,10 @@ int cslam_wino4_fused_c64_dev(const float *d_x, const float *d_Up, const float *
 int cslam_wino4_input_h2_dev(const float *d_x, int B, int H, int W, int C, const unsigned *d_amax, void *d_V2,
                              void *stream);
 int cslam_wino_gemm_h2_dev(const void *d_V2, const void *d_U2, int64_t T, int Cin, int Cout, float *d_M, void *stream);
+/* The same 36 products for the layers bound by the matrix pipe (512 channels): weight fragments straight from L2 into
+ * registers, V2 alone staged through LDS (wino_gemm_h2r_kernel).  d_U2r: the weights in the per-lane order
+ * [36][Cout/32][Cin/32][2 K steps][64 lanes][hi 8 | lo 8] fp16 (`split16_pair_weights_r`); Cout a multiple of 256. */
+int cslam_wino_gemm_h2r_dev(const void *d_V2, const void *d_U2r, int64_t T, int Cin, int Cout, float *d_M, void *stream);
 
 /* The one-kernel F(4x4,3x3) convolution of the 64-input-channel layers (cslam_wino4_fused_c64_dev above) on the fp16
  * matrix pipe with fp32-grade results (csrc/wino_fused_h.hip): V and U as exact fp16 pairs packed [hi | lo << 16] per
@@ -352,6 +367,11 @@ int cslam_conv3x3_c3_amax_dev(const float *d_x, const float *d_wt, const float *
 int cslam_wino4_stem_c64_h_dev(const float *d_x0, const void *d_w1, const float *d_b1, const float *d_sumw, float inv_sw,
                                const void *d_Uh, const float *d_bias, int B, int H, int W, int pool,
                                const unsigned *d_amax_x0, float inv_su, unsigned *d_amax_out, float *d_y, void *stream);
+
+/* diagnostics of the kernel above: with CSLAM_WFH_PROF=1 in the environment its conv1_2-shaped launches (ReLU + pool, 64
+ * output channels; stem or not) add up, for waves 0 and 4 of workgroup 0, the shader cycles spent per phase of a quarter into
+ * d_buf16 [2][8] uint64 = (transform, barrier, matrix loop, prefetch + stem work, output transform, barrier, quarters, -). */
+int cslam_debug_wfh_prof_dev(void *d_buf16);
 
 /* ---- multi-GPU exchange (csrc/comm.hip): RCCL over xGMI, one process per GPU ---------------------------------------
  * Replaces, inside one node, the ROS 2 transport of descriptors between robots

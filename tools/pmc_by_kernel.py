@@ -26,6 +26,9 @@ TARGETS = [   # (json key, kernel-name substring, group index among that substri
      {"shape": "x [256,224,224,64] -> conv 64->64 + bias + ReLU + MaxPool2d"}, (256 * 224 * 224 * 64 + 256 * 112 * 112 * 64) * 4),
     ("wino4_fused_c64_h_kernel/conv2_1", "wino4_fused_c64_h_kernel<128", 0,
      {"shape": "x [256,112,112,64] -> conv 64->128 + bias + ReLU"}, (256 * 112 * 112 * 64 + 256 * 112 * 112 * 128) * 4),
+    ("wino4_fused_c64_h_kernel/stem", "wino4_fused_c64_h_kernel<64", 1,
+     {"shape": "x0 [256,3,224,224] -> conv 3->64 + ReLU -> conv 64->64 + ReLU + MaxPool2d"},
+     (256 * 3 * 224 * 224 + 256 * 112 * 112 * 64) * 4),
 ]
 
 

@@ -7,6 +7,7 @@ them in the counter CSV by kernel name and order of appearance:
   wino_gemm_h2_kernel     conv4_2 shape      36 x [12544,512] x [512,512]         (second group)
   wino4_fused_c64_h_kernel<64>  conv1_2      x [256,224,224,64] -> pooled [256,112,112,64]
   wino4_fused_c64_h_kernel<128> conv2_1      x [256,112,112,64] -> [256,112,112,128]
+  wino4_fused_c64_h_kernel<64, .., STEM> conv1_1 + conv1_2   x0 [256,3,224,224] -> pooled [256,112,112,64]  (second <64 group)
 """
 import ctypes as C
 import os
@@ -56,6 +57,16 @@ def main():
         for _ in range(REPS):
             wg.wino_fused64_h(xf, Uh, b, True, pool, slot, None)
         del xf
+    x0 = torch.rand((B, 3, 224, 224), device="cuda") * 4.8 - 2.2
+    w1 = torch.randn((64, 3, 3, 3), device="cuda") / 5.0
+    b1 = torch.randn(64, device="cuda")
+    stem = wg.stem_pair_weights(w1)
+    w = torch.randn((64, 64, 3, 3), device="cuda") / 24.0
+    Uh = wg.fused64_pair_weights(wg.wino_weights(w, 4).cuda())
+    b = torch.randn(64, device="cuda")
+    _lib.check(lib.cslam_absmax_dev(p(x0), x0.numel(), p(slot), st))
+    for _ in range(REPS):
+        wg.wino_stem64_h(x0, stem, b1, Uh, b, True, slot, None)
     torch.cuda.synchronize()
 
 
