@@ -22,6 +22,8 @@
 // 128 x TN/4 = 4 x {1,2} MFMA tiles) walks its share of the item list with the K loops of consecutive items fused, so the
 // first stage of the next item lands while this item's 256 x TN results are stored.  Items are xi-major and every XCD
 // owns a contiguous run of them: the U2[xi] it needs (<= 1 MB) stays in its L2, V2 is streamed once per column block.
+// (Measured and rejected: the weight fragments loaded from L2 straight into registers with V2 alone in LDS -- 0.94 vs 0.73 ms
+// on conv4_2, profiles/r02_v20_perf_wino_gemm_registers_rejected.log; LDS bandwidth is not what bounds the 512-channel layers.)
 // Bound: HBM for Cin <= 256 (V2 in + M out = 4 (Cin + Cout) bytes per tile row and frequency against 6 Cin Cout flop),
 // about balanced at 512 x 512.
 #include "common.h"
@@ -276,224 +278,6 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_h2_kernel(WinoGemmArgs p) {
     }
 }
 
-// ---- the same products with the WEIGHT fragments in registers (512-channel layers) ------------------------------------------
-// At 512 x 512 the kernel above is bound by LDS bandwidth, not by the matrix pipe: a 128 x 32 wave tile reads 10 fragments
-// (1 KB each) for 12 MFMAs of 32 cycles, 104 B/cycle per compute unit + 31 B/cycle of LDS-DMA writes against a peak of 128.
-// Here only V2 goes through LDS (256-row stages, double-buffered); a wave's weight fragments come straight from the
-// L2-resident U2 into registers, one K step ahead, from a layout in which a wave reads 2 KB contiguous per fragment pair
-// (`split16_pair_weights_r`): U2r[xi][Cout/32][Cin/32][2 K steps][64 lanes][hi 8 | lo 8].  Wave tile 128 x 64 (4 x 2 MFMA tiles):
-// 8 A fragments per 24 MFMAs = 43 B/cycle of LDS reads + 21 of DMA, the weights 21 B/cycle through the vector memory path.
-template <int DBG>
-__global__ __launch_bounds__(512, 2) void wino_gemm_h2r_kernel(WinoGemmArgs p) {
-    constexpr int TM = 256, TN = 256, MT = 4, NT = 2;
-    constexpr int STAGE = TM * WG_ROWB;                // 32 KB: V2 only
-    constexpr int NLA = TM * 8 / 512;                  // 16-byte chunks per thread per stage
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    const int h = lane >> 5, l31 = lane & 31;
-    const int xcd = blockIdx.x & 7, j8 = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
-    const int q8 = p.n_items >> 3, r8 = p.n_items & 7;
-    const int x_beg = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
-    const int x_cnt = q8 + (xcd < r8 ? 1 : 0);
-    const int n_mine = j8 < x_cnt ? (x_cnt - j8 + per_xcd - 1) / per_xcd : 0;
-    if (n_mine == 0) return;
-    const int64_t pitch = (int64_t)p.nk * WG_ROWB;
-    int rowA[NLA], offA[NLA];
-#pragma unroll
-    for (int i = 0; i < NLA; ++i) {
-        const int pch = i * 512 + tid, r = pch >> 3, slot = pch & 7;
-        rowA[i] = r; offA[i] = (slot ^ ((r >> 1) & 7)) << 4;
-    }
-    const int wave_chunk = wave * 1024;
-    struct Item { int xi, mt, nt; };
-    auto decode = [&](int k) {
-        const int it = x_beg + j8 + k * per_xcd;
-        Item c;
-        c.nt = it % p.n_nt;
-        const int rest = it / p.n_nt;
-        c.mt = rest % p.n_mt;
-        c.xi = rest / p.n_mt;
-        return c;
-    };
-    const char *gA[NLA];
-    auto point_at = [&](const Item &c) {
-#pragma unroll
-        for (int i = 0; i < NLA; ++i) {
-            int64_t row = (int64_t)c.mt * TM + rowA[i];
-            if (row > p.T - 1) row = p.T - 1;
-            gA[i] = p.V2 + ((int64_t)c.xi * p.T + row) * pitch + offA[i];
-        }
-    };
-    // weight fragments of (item, K block kb, K step s) for this wave's two 32-column groups: 32 bytes per lane each
-    auto b_ptr = [&](const Item &c, int n, int kb, int s) {
-        const int64_t cb = (int64_t)c.nt * (TN / 32) + wn * NT + n;
-        return p.U2 + (((((int64_t)c.xi * (p.Cout / 32) + cb) * p.nk + kb) * 2 + s) * 64 + lane) * 32;
-    };
-    const int swz = (lane >> 1) & 7;
-    int foff[2][2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int lo = 0; lo < 2; ++lo) foff[s][lo] = ((4 * lo + 2 * s + h) ^ swz) << 4;
-    const int arow0 = (wm * (TM / 2) + l31) * WG_ROWB;
-
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-
-    const int total = n_mine * p.nk;
-    int l_item = 0, l_kt = 0, l_stage = 0, fetched = 0;
-    Item cur_item = decode(0);
-    point_at(cur_item);
-    auto advance_loader = [&]() {
-        ++fetched;
-        l_stage ^= 1;
-        if (++l_kt == p.nk) {
-            l_kt = 0; ++l_item;
-            if (fetched < total) point_at(decode(l_item));
-        }
-    };
-#pragma unroll
-    for (int i = 0; i < NLA; ++i) wg_glds16(gA[i], smem + i * (512 * 16) + wave_chunk);
-    advance_loader();
-    f16x8 b0[NT][2], b1[NT][2];                        // [column group][hi | lo] of the even / odd K step
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const char *q = b_ptr(cur_item, n, 0, 0);
-        b0[n][0] = *(const f16x8 *)q; b0[n][1] = *(const f16x8 *)(q + 16);
-    }
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-
-    int k_item = 0, kt = 0, cur = 0;
-    bool store_pending = false;
-    Item st_item = cur_item;
-    for (int it = 0; it < total; ++it) {
-        if (store_pending) {
-            const int row_base = st_item.mt * TM + wm * (TM / 2) + 4 * h;
-            const int col = st_item.nt * TN + wn * (32 * NT) + l31;
-            float *mo = p.M + ((int64_t)st_item.xi * p.T + row_base) * p.Cout + col;
-            const bool full = st_item.mt * TM + wm * (TM / 2) + TM / 2 <= p.T;
-            const bool st_on = DBG != 1 || p.T < 0;
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ro = m * 32 + (r & 3) + 8 * (r >> 2);
-#pragma unroll
-                    for (int n = 0; n < NT; ++n)
-                        if (st_on && (full || row_base + ro < p.T)) __builtin_nontemporal_store(acc[m][n][r], mo + (int64_t)ro * p.Cout + 32 * n);
-                }
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
-            store_pending = false;
-        }
-        const bool fetch = (DBG != 2) && fetched < total;
-        const char *sA = smem + cur * STAGE;
-        // ---- K step 0: weights b0 (requested one step ago); request step 1's into b1
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const char *q = b_ptr(cur_item, n, kt, 1);
-            b1[n][0] = *(const f16x8 *)q; b1[n][1] = *(const f16x8 *)(q + 16);
-        }
-        {
-            f16x8 ah[MT], al[MT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                ah[m] = *(const f16x8 *)(sA + arow0 + m * 32 * WG_ROWB + foff[0][0]);
-                al[m] = *(const f16x8 *)(sA + arow0 + m * 32 * WG_ROWB + foff[0][1]);
-            }
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], b0[n][0], acc[m][n], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], b0[n][0], acc[m][n], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], b0[n][1], acc[m][n], 0, 0, 0);
-        }
-        if (fetch) {
-#pragma unroll
-            for (int i = 0; i < NLA / 2; ++i) wg_glds16(gA[i] + l_kt * WG_ROWB, smem + l_stage * STAGE + i * (512 * 16) + wave_chunk);
-        }
-        // ---- K step 1: weights b1; request the next stage's step 0 into b0 (the next K block, or block 0 of the next item)
-        if (it + 1 < total) {
-            const bool same = kt + 1 < p.nk;
-            const Item nx = same ? cur_item : decode(k_item + 1);
-            const int nkb = same ? kt + 1 : 0;
-#pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const char *q = b_ptr(nx, n, nkb, 0);
-                b0[n][0] = *(const f16x8 *)q; b0[n][1] = *(const f16x8 *)(q + 16);
-            }
-        }
-        {
-            f16x8 ah[MT], al[MT];
-#pragma unroll
-            for (int m = 0; m < MT; ++m) {
-                ah[m] = *(const f16x8 *)(sA + arow0 + m * 32 * WG_ROWB + foff[1][0]);
-                al[m] = *(const f16x8 *)(sA + arow0 + m * 32 * WG_ROWB + foff[1][1]);
-            }
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], b1[n][0], acc[m][n], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], b1[n][0], acc[m][n], 0, 0, 0);
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], b1[n][1], acc[m][n], 0, 0, 0);
-        }
-        if (fetch) {
-#pragma unroll
-            for (int i = NLA / 2; i < NLA; ++i) wg_glds16(gA[i] + l_kt * WG_ROWB, smem + l_stage * STAGE + i * (512 * 16) + wave_chunk);
-            advance_loader();
-        }
-        if (kt == p.nk - 1) { store_pending = true; st_item = cur_item; }
-        // Only the LDS-DMA of the next stage has to have landed (4 per thread, the oldest of what is in flight: loads return
-        // in order); the 4 weight loads requested in this stage's second step stay in flight across the barrier.  DMA and
-        // weight loads are issued in program order (the DMA builtin is not reordered), so: everything but the newest 2 + 4
-        // ... the second DMA half was issued AFTER the weight loads, so waiting for it waits for them too: vmcnt(0).
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_s_barrier();
-        cur ^= 1;
-        if (++kt == p.nk) { kt = 0; ++k_item; if (it + 1 < total) cur_item = decode(k_item); }
-    }
-    if (store_pending) {
-        const int row_base = st_item.mt * TM + wm * (TM / 2) + 4 * h;
-        const int col = st_item.nt * TN + wn * (32 * NT) + l31;
-        float *mo = p.M + ((int64_t)st_item.xi * p.T + row_base) * p.Cout + col;
-        const bool st_on = DBG != 1 || p.T < 0;
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ro = m * 32 + (r & 3) + 8 * (r >> 2);
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    if (st_on && row_base + ro < p.T) __builtin_nontemporal_store(acc[m][n][r], mo + (int64_t)ro * p.Cout + 32 * n);
-            }
-    }
-}
-
 // ---- input transform into the pair layout ------------------------------------------------------------------------------
 __device__ __forceinline__ float wg_h_scale(unsigned amax_bits) {       // = wino_h3_scale (winograd.hip)
     const float a = fminf(fmaxf(__uint_as_float(amax_bits), 1e-30f), 1e30f);
@@ -638,47 +422,4 @@ CSLAM_API int cslam_wino_gemm_h2_dev(const void *d_V2, const void *d_U2, int64_t
     case 3: return wino_gemm_launch<128, 256, 3>(a, dbg, st);      // ring of 3, 128 x 256
     default: return wino_gemm_launch<256, 128, 2>(a, dbg, st);     // double buffer, 256 x 128 (round-2 first form)
     }
-}
-
-/* The 512-channel form: weight fragments in registers (wino_gemm_h2r_kernel above); d_U2r from `split16_pair_weights_r`. */
-CSLAM_API int cslam_wino_gemm_h2r_dev(const void *d_V2, const void *d_U2r, int64_t T, int Cin, int Cout, float *d_M,
-                                      void *stream) {
-    PTR_DEVICE(d_V2);
-    ARG_CHECK(d_V2 && d_U2r && d_M, "NULL argument");
-    ARG_CHECK(T >= 1 && T < (1LL << 31), "T out of range");
-    ARG_CHECK(Cin >= 32 && (Cin % 32) == 0, "Cin must be a multiple of 32");
-    ARG_CHECK(Cout >= 256 && (Cout % 256) == 0, "Cout must be a multiple of 256");
-    WinoGemmArgs a;
-    a.V2 = (const char *)d_V2; a.U2 = (const char *)d_U2r; a.M = d_M;
-    a.T = (int)T; a.Cin = Cin; a.Cout = Cout; a.nk = Cin / 32;
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        if (n_cu < 8) n_cu = 8;
-    }
-    a.n_mt = (int)ceil_div64(a.T, 256);
-    a.n_nt = Cout / 256;
-    const int64_t items = (int64_t)36 * a.n_mt * a.n_nt;
-    ARG_CHECK(items < (1LL << 31), "too many work items");
-    a.n_items = (int)items;
-    constexpr int lds = 2 * 256 * WG_ROWB;
-    int grid = n_cu - n_cu % 8;
-    if ((int64_t)grid > round_up64(a.n_items, 8)) grid = (int)round_up64(a.n_items, 8);
-    const char *e = getenv("CSLAM_WGEMM_DBG");
-    const int dbg = e ? atoi(e) : 0;
-    hipStream_t st = (hipStream_t)stream;
-    static bool attr = false;
-    if (!attr) {
-        HIP_TRY(hipFuncSetAttribute((const void *)wino_gemm_h2r_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_TRY(hipFuncSetAttribute((const void *)wino_gemm_h2r_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_TRY(hipFuncSetAttribute((const void *)wino_gemm_h2r_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr = true;
-    }
-    if (dbg == 1) hipLaunchKernelGGL(wino_gemm_h2r_kernel<1>, dim3(grid), dim3(512), lds, st, a);
-    else if (dbg == 2) hipLaunchKernelGGL(wino_gemm_h2r_kernel<2>, dim3(grid), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL(wino_gemm_h2r_kernel<0>, dim3(grid), dim3(512), lds, st, a);
-    HIP_TRY(hipGetLastError());
-    return CSLAM_OK;
 }

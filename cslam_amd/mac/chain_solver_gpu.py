@@ -34,7 +34,8 @@ def blocked_cholesky_(A, bs=2048):
         A[k:e, k:e] = torch.linalg.cholesky(A[k:e, k:e])
         if e < m:
             L11 = A[k:e, k:e]
-            A[e:, k:e] = torch.linalg.solve_triangular(L11, A[e:, k:e].T, upper=False).T     # L21 = A21 L11^-T
+            # L21 = A21 L11^-T as a right-hand solve on the stored layouts (no transposed copies of the 30k x 2048 panel)
+            A[e:, k:e] = torch.linalg.solve_triangular(L11.T, A[e:, k:e], upper=True, left=False)
             L21 = A[e:, k:e]
             for j in range(e, m, 2 * bs):                      # block columns of the trailing matrix, rows from the diagonal down
                 je = min(j + 2 * bs, m)

@@ -37,6 +37,13 @@ def preprocess(frames_u8, crop, out_hw=224, mean=IMAGENET_DEFAULT_MEAN, std=IMAG
     return out
 
 
+def normalised_image_bound(mean=IMAGENET_DEFAULT_MEAN, std=IMAGENET_DEFAULT_STD):
+    """max |(v - mean) / std| over v in [0, 1] and the three channels: a rigorous bound of |preprocess(...)| (float32
+    arithmetic of the kernel included: one ulp of slack)."""
+    b = max(max(abs(0.0 - m) / s, abs(1.0 - m) / s) for m, s in zip(mean, std))
+    return float(b) * (1.0 + 2.0 ** -20)
+
+
 def padded_rows(n, d, device, dtype=torch.float32):
     """[n, d] view whose row pitch avoids multiples of 256 floats (power-of-two pitches put the same
     column of every row into the same L2 set; see csrc/bank.hip)."""

@@ -212,6 +212,8 @@ class NetVLAD(object):
                 if self.trunk is None:
                     self.trunk = WinogradTrunk(self.encoder, min_in_channels=64,
                                                tile=4 if self.backbone_conv == 'winograd' else 2)
+                    # a normalised 8-bit image is bounded by its normalisation constants: saves the trunk a pass over it
+                    self.trunk.input_bound = heads.normalised_image_bound()
                 f = self.trunk(x)
         else:
             f = self.encoder(x)

@@ -65,24 +65,6 @@ def split16_pair_weights(U4):
     return pair.contiguous(), 1.0 / su
 
 
-def split16_pair_weights_r(U4):
-    """U4 [36, Cin, Cout] float32 -> (U2r [36, Cout/32, Cin/32, 2, 64, 2, 8] float16, inv_su): the same exact fp16 pairs as
-    `split16_pair_weights`, in the order `cslam_wino_gemm_h2r_dev` loads them straight into registers: lane 32 h + l of the
-    wave that owns output channels 32 cb .. 32 cb + 31 reads, for K block kb and K step s, 8 hi then 8 lo halfs of output
-    channel 32 cb + l and input channels 32 kb + 16 s + 8 h .. + 7 (a wave reads 2 KB contiguous)."""
-    n, cin, cout = U4.shape
-    assert cin % 32 == 0 and cout % 32 == 0
-    u = U4.detach().to(torch.float64)
-    amax = float(u.abs().max())
-    su = 2.0 ** (14 - math.floor(math.log2(amax))) if amax > 0 else 1.0
-    us = (u * su).to(torch.float32)
-    uh = us.to(torch.float16)
-    ul = (us - uh.to(torch.float32)).to(torch.float16)
-    pair = torch.stack((uh, ul), dim=0)                              # [2, 36, Cin, Cout]
-    pair = pair.view(2, n, cin // 32, 2, 2, 8, cout // 32, 32)       # [hl, xi, kb, s, h, e, cb, l]
-    return pair.permute(1, 6, 2, 3, 4, 7, 0, 5).contiguous(), 1.0 / su   # [xi, cb, kb, s, h, l, hl, e]
-
-
 def fused64_weights(U):
     """U [16 | 36, 64, Cout] (`wino_weights(w, 2 | 4)`; Cout 64 or 128) -> the operand order of
     `cslam_wino2_fused_c64_dev` / `cslam_wino4_fused_c64_dev`: Up[kq][xi][w][g][c][s] = U[xi][16 kq + 4 g + s][16 w + c]
@@ -243,10 +225,7 @@ def wino_conv3x3(ws, x, U, U4, bias, relu, pool=False, residual=None, U3=None, a
         V2 = ws._buf("V", 36 * T * Cin, x.device)                      # 36 x T x 2 Cin halfs
         M = ws._buf("M", 36 * T * Cout, x.device)
         _lib.check(lib.cslam_wino4_input_h2_dev(_p(x), B, H, W, Cin, _p(slot), _p(V2), s))
-        if len(U2) > 2 and U2[2] is not None:                          # 512-channel layers: weight fragments in registers
-            _lib.check(lib.cslam_wino_gemm_h2r_dev(_p(V2), _p(U2[2]), T, Cin, Cout, _p(M), s))
-        else:
-            _lib.check(lib.cslam_wino_gemm_h2_dev(_p(V2), _p(U2[0]), T, Cin, Cout, _p(M), s))
+        _lib.check(lib.cslam_wino_gemm_h2_dev(_p(V2), _p(U2[0]), T, Cin, Cout, _p(M), s))
         Ho, Wo = (H // 2, W // 2) if pool else (H, W)
         y = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
         if residual is not None:
@@ -428,6 +407,9 @@ class WinogradTrunk(_Workspace):
         # Default: this library's pair GEMM (`split16_pair_weights`, csrc/wino_gemm.hip) from 128 channels on -- V is no
         # larger than its fp32 form, so every layer the three-kernel form runs gains.  CSLAM_WINO_H3=1 selects round 1's
         # library GEMM over [vh | vl | vh] instead, whose measured optimum was 256 (profiles/r01_exp_split16.log).
+        # a known bound of max |input| (e.g. a normalised 8-bit image: heads.normalised_image_bound()) spares the stem kernel
+        # its pass over the input; None = measured per call
+        self.input_bound = None
         self.split16_h3 = os.environ.get("CSLAM_WINO_H3", "0") == "1"
         self.split16_min_cin = int(os.environ.get("CSLAM_WINO_SPLIT16", "256" if self.split16_h3 else "128"))
         use_tuned_gemms()
@@ -451,11 +433,6 @@ class WinogradTrunk(_Workspace):
                 if st.U4 is not None and 0 < self.split16_min_cin <= m.in_channels:
                     if not self.split16_h3 and m.in_channels % 32 == 0 and m.out_channels % 128 == 0:
                         st.U2 = split16_pair_weights(st.U4)
-                        # layers bound by the matrix pipe (from CSLAM_WGEMM_REG_MIN_CIN input channels, default 512): the
-                        # GEMM form with the weight fragments in registers (csrc/wino_gemm.hip, wino_gemm_h2r_kernel)
-                        rmin = int(os.environ.get("CSLAM_WGEMM_REG_MIN_CIN", "512"))
-                        if 0 < rmin <= m.in_channels and m.out_channels % 256 == 0:
-                            st.U2 = (st.U2[0], st.U2[1], split16_pair_weights_r(st.U4)[0])
                     else:
                         st.U3 = split16_weights(st.U4)
                 if self.fused64 and m.in_channels == 64 and m.out_channels in self.fused_couts:
@@ -534,10 +511,12 @@ class WinogradTrunk(_Workspace):
             if st.kind == "c3":
                 x = x.contiguous()                                   # planar [B,3,H,W]
                 B, _, H, W = x.shape
-                if (st.stem is not None and B * -(-H // 16) * -(-W // 16) * 16 >= self.fused_min_blocks
+                if (st.stem is not None and B * -(-H // 16) * -(-W // 16) >= self.fused_min_blocks
                         and not (nxt.pool and (H % 2 or W % 2)) and B * H * W * 64 < 2 ** 31):
                     slot = slots[k:k + 1]
-                    if x.numel() % 4 == 0:
+                    if self.input_bound is not None:
+                        slot.fill_(float(self.input_bound))
+                    elif x.numel() % 4 == 0:
                         _lib.check(lib.cslam_absmax_dev(_p(x), x.numel(), _p(slot), _stream(x)))
                     else:                                            # odd image sizes: the streaming kernel wants whole float4s
                         slot.copy_(x.abs().max().reshape(1))

@@ -339,10 +339,6 @@ int cslam_wino4_fused_c64_dev(const float *d_x, const float *d_Up, const float *
 int cslam_wino4_input_h2_dev(const float *d_x, int B, int H, int W, int C, const unsigned *d_amax, void *d_V2,
                              void *stream);
 int cslam_wino_gemm_h2_dev(const void *d_V2, const void *d_U2, int64_t T, int Cin, int Cout, float *d_M, void *stream);
-/* The same 36 products for the layers bound by the matrix pipe (512 channels): weight fragments straight from L2 into
- * registers, V2 alone staged through LDS (wino_gemm_h2r_kernel).  d_U2r: the weights in the per-lane order
- * [36][Cout/32][Cin/32][2 K steps][64 lanes][hi 8 | lo 8] fp16 (`split16_pair_weights_r`); Cout a multiple of 256. */
-int cslam_wino_gemm_h2r_dev(const void *d_V2, const void *d_U2r, int64_t T, int Cin, int Cout, float *d_M, void *stream);
 
 /* The one-kernel F(4x4,3x3) convolution of the 64-input-channel layers (cslam_wino4_fused_c64_dev above) on the fp16
  * matrix pipe with fp32-grade results (csrc/wino_fused_h.hip): V and U as exact fp16 pairs packed [hi | lo << 16] per

@@ -99,35 +99,3 @@ def test_input_transform_pair_layout(T, B, H, W, C):
     tol = 2.0 ** -22 * V.double().abs() + 2.0 ** -25           # fp16 subnormal spacing 2^-24 at the bottom of lo's range
     assert ((rec - V.double()).abs() <= tol).all()
 
-
-@pytest.mark.parametrize("rows,cin,cout", [(257, 512, 512), (1024, 256, 256), (2049, 256, 512), (64, 32, 256), (70000, 64, 256),
-                                           (12544, 512, 512)])
-def test_register_weight_gemm_equals_lds_form_and_float64(T, rows, cin, cout):
-    """`cslam_wino_gemm_h2r_dev` (weight fragments in registers, V2 alone through LDS: the 512-channel layers' form) against
-    a float64 evaluation of the same three products (<= 2e-6 of sum |terms|) and against the LDS form of the same kernel
-    family -- same products in the same K order, so the results are required to be bit-identical; ragged row counts, one
-    to sixteen K blocks, one and two column blocks."""
-    torch, _lib = T
-    from cslam_amd.vpr import winograd as wg
-    lib = _lib.load()
-    g = torch.Generator(device="cuda").manual_seed(rows + cin + 1)
-    v = (torch.randn((36, rows, cin), generator=g, device="cuda") * 3000.0).clamp_(-30000, 30000)
-    U4 = torch.randn((36, cin, cout), generator=g, device="cuda") / cin ** 0.5
-    V2, vh, vl = _pairs_rows(v)
-    U2, inv_su = wg.split16_pair_weights(U4)
-    U2r, inv_su_r = wg.split16_pair_weights_r(U4)
-    assert inv_su == inv_su_r
-    M = torch.full((36, rows, cout), float("nan"), device="cuda")
-    Mr = torch.full((36, rows, cout), float("nan"), device="cuda")
-    st = torch.cuda.current_stream().cuda_stream
-    _lib.check(lib.cslam_wino_gemm_h2_dev(_p(V2), _p(U2), rows, cin, cout, _p(M), st))
-    _lib.check(lib.cslam_wino_gemm_h2r_dev(_p(V2), _p(U2r), rows, cin, cout, _p(Mr), st))
-    torch.cuda.synchronize()
-    assert torch.isfinite(Mr).all()
-    assert torch.equal(M, Mr)
-    uh = U2[:, :, :, 0, :].reshape(36, cout, cin).transpose(1, 2).double()
-    ul = U2[:, :, :, 1, :].reshape(36, cout, cin).transpose(1, 2).double()
-    vhd, vld = vh.double(), vl.double()
-    want = vhd @ uh + vld @ uh + vhd @ ul
-    mag = vhd.abs() @ uh.abs() + vld.abs() @ uh.abs() + vhd.abs() @ ul.abs()
-    assert ((Mr.double() - want).abs() <= 2e-6 * mag + 1e-30).all()
