@@ -106,7 +106,9 @@ def parse():
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--match-queries", type=int, default=100_000, help="queries of the match-only leg")
     ap.add_argument("--backbone-dtype", default="fp32", choices=["fp32", "bf16"])
-    ap.add_argument("--extract-chunk", type=int, default=256, help="frames per backbone forward")
+    ap.add_argument("--extract-chunk", type=int, default=512,
+                    help="frames per backbone forward (512: +2-3 %% over 256, profiles/r02_v23_extract_chunk.log; the per-kernel "
+                         "rooflines below are priced on 256-frame launches, the shapes of the committed PMC passes)")
     ap.add_argument("--backbone-conv", default="winograd", choices=["winograd", "winograd2", "direct"],
                     help="execution of the wide 3x3 backbone convolutions (vpr/winograd.py)")
     ap.add_argument("--cpu-queries", type=int, default=48, help="cpu_baseline sample size of the match leg (queries)")
@@ -336,7 +338,7 @@ def main():
         import ctypes as C
         from cslam_amd import _lib
         lib = _lib.load()
-        eb, eh, ec = a.extract_chunk, 112, 128                      # conv2_2's input at the bench chunk size
+        eb, eh, ec = 256, 112, 128                                  # conv2_2's input at 256 frames (the PMC passes' shape)
         xt = torch.randn((eb, eh, eh, ec), device=dev)
         vt = torch.empty((36, eb * (eh // 4) * (eh // 4), ec), device=dev)
         st = torch.cuda.current_stream().cuda_stream

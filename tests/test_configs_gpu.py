@@ -14,13 +14,13 @@ def test_c2_cosplace_extract_and_causal_matching():
     from cslam_amd import nns_matching as nnm
     from cslam_amd.vpr.cosplace import CosPlace
     from oracle import pyoracle
-    n = 2000                                    # config 2 uses 10k frames; 2k keeps the test short
+    n = 10_000                                  # config 2 at its size: 10k synthetic 640x480 frames (~1 s of extraction)
     cp = CosPlace({"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376,
                    "frontend.cosplace.descriptor_dim": 512, "frontend.cosplace.backbone": "resnet18"}, None)
     gen = torch.Generator(device="cuda").manual_seed(7)
     descs = []
-    for s in range(0, n, 100):
-        frames = torch.randint(0, 256, (100, 480, 640, 3), generator=gen, device="cuda", dtype=torch.uint8)
+    for s in range(0, n, 250):
+        frames = torch.randint(0, 256, (250, 480, 640, 3), generator=gen, device="cuda", dtype=torch.uint8)
         descs.append(cp.compute_embeddings_device(frames))
     d = torch.cat(descs)
     assert d.shape == (n, 512) and torch.allclose(d.norm(dim=1), torch.ones(n, device="cuda"), atol=1e-5)
@@ -33,7 +33,7 @@ def test_c2_cosplace_extract_and_causal_matching():
     assert torch.all(rows[valid] < lim[:, None].expand(-1, 5)[valid])       # causal: only earlier keyframes
     assert torch.all(sims[:, :-1][valid[:, 1:]] >= sims[:, 1:][valid[:, 1:]])
     hd = d.cpu().numpy()
-    sel = np.arange(0, n, 97)
+    sel = np.arange(0, n, 197)                  # 51 keyframes spread over the run, the last ones against ~10k rows
     oi, os_, oc = pyoracle.nns_search(hd, hd[sel], 5, row_limit=sel.astype(np.int64))
     assert np.array_equal(rows.cpu().numpy()[sel], oi) and np.array_equal(cnt.cpu().numpy()[sel], oc)
     assert np.nanmax(np.abs(sims.cpu().numpy()[sel] - os_)) < 1e-12
