@@ -257,7 +257,8 @@ __global__ __launch_bounds__(512, 2) void wino4_fused_c64_h_kernel(
         }
     };
     // ---- transform geometry: thread = (tile, channel of the quarter); COUT = 128: threads 256.. sit the transform out
-    // (measured and rejected for NB = 1, where half the threads sit the transform out: two threads per (tile, channel), three
+    // (measured and rejected: the stem producer's row tiles interleaved into the matrix loop -- 110 spilled registers, 5.7 ms
+    // against 3.2, profiles/r02_v26_stem_interleave_rejected.log; for NB = 1, where half the threads sit the transform out: two threads per (tile, channel), three
     // frequency rows each -- and the output stores staged through LDS as whole pixels: 1.50 / 1.49 ms against 1.43,
     // profiles/r02_v21_fused_h_conv2_1_ab_rejected.log)
     const int t_tile = tid >> 4, t_c = tid & 15;
