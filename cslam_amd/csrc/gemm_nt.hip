@@ -152,6 +152,38 @@ __global__ __launch_bounds__(256) void pca_epilogue_kernel(const float *__restri
     for (int d = threadIdx.x; d < M; d += blockDim.x) out[(size_t)b * M + d] /= den;
 }
 
+// the same epilogue for the pair products: their power-of-two input scale is recomputed from the max |x| slot
+__global__ __launch_bounds__(256) void pca_epilogue_pairs_kernel(const float *__restrict__ part, int S, int N, int M,
+                                                                 const float *__restrict__ mean_proj,
+                                                                 const float *__restrict__ inv_scale, float *__restrict__ out,
+                                                                 const unsigned *__restrict__ amax, float a_given, float inv_sw) {
+    __shared__ float red[16];
+    const float a = fminf(fmaxf(amax ? __uint_as_float(*amax) : a_given, 1e-30f), 1e30f);
+    int e;
+    (void)frexpf(16384.0f / a, &e);
+    const float ps = inv_sw / ldexpf(1.0f, e - 1);
+    const int b = blockIdx.x;
+    float ss = 0.0f;
+    for (int d = threadIdx.x; d < M; d += blockDim.x) {
+        float v = 0.0f;
+        for (int s = 0; s < S; ++s) v += part[((size_t)s * N + b) * M + d];
+        v *= ps;
+        if (mean_proj) v -= mean_proj[d];
+        if (inv_scale) v *= inv_scale[d];
+        out[(size_t)b * M + d] = v;
+        ss += v * v;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    float t = 0.0f;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += red[w];
+    const float nrm = sqrtf(t);
+    const float den = nrm == 0.0f ? 1.0f : nrm;
+    for (int d = threadIdx.x; d < M; d += blockDim.x) out[(size_t)b * M + d] /= den;
+}
+
 // Small batches (the online path: one keyframe per call): the projection is a matrix-vector product bound by
 // streaming the 512 MB component matrix once.  One wave per pair of output rows, 16-byte loads, 8 KiB per row
 // in flight per wave (2048 waves -> 32 MB in flight), float32 accumulation per lane, xor-shuffle reduction in a
@@ -265,6 +297,96 @@ CSLAM_API int cslam_pca_project_dev(const float *d_x, int64_t ldx, const float *
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(pca_epilogue_kernel, dim3(B), dim3(256), 0, st, g_part, S, B, Dout, d_mean_proj, d_inv_scale,
                        d_out);
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
+// ---- the projection on the fp16 matrix pipe (batches): x and the components as exact fp16 hi / lo pairs, three of the four
+// partial products in fp32 accumulators -- the arithmetic of the trunk's Winograd GEMM (csrc/wino_gemm.hip), whose kernel runs
+// it: K = Din is cut into S splits that take the place of the 36 frequencies, pca_epilogue_kernel sums them.  The f32-input
+// MFMA form above holds 120 TFLOP/s (0.58 ms per 256 frames at 32768 -> 4096); this one is bound by the 512 MB of weights.
+int cslam_pair_gemm_launch(const void *d_A2, const void *d_B2, int nxi, int64_t T, int K, int N, float *d_M, hipStream_t st);
+
+// x [B][Din] (pitch ldx) -> A2 [S][B][Din / S / 32][hi 32 | lo 32] fp16 pairs of s x, s = the power of two with max |x| s <= 2^14
+__global__ __launch_bounds__(256) void pca_pairs_rows_kernel(const float *__restrict__ x, int64_t ldx, int B, int Din, int S,
+                                                             const unsigned *__restrict__ amax, float a_given,
+                                                             unsigned short *__restrict__ A2) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    const int c4n = Din >> 2;
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (int64_t)B * c4n) return;
+    const int b = (int)(gid / c4n), c = 4 * (int)(gid % c4n);
+    const float a = fminf(fmaxf(amax ? __uint_as_float(*amax) : a_given, 1e-30f), 1e30f);
+    int e;
+    (void)frexpf(16384.0f / a, &e);
+    const float sc = ldexpf(1.0f, e - 1);
+    const f4 v = *(const f4 *)(x + (int64_t)b * ldx + c) * sc;
+    const int ks = Din / S, s = c / ks, cc = c - s * ks;
+    unsigned short *o = A2 + (((int64_t)s * B + b) * (ks >> 5) + (cc >> 5)) * 64 + (cc & 31);
+    unsigned short h[4], l[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const _Float16 hi = (_Float16)v[i];
+        const _Float16 lo = (_Float16)(v[i] - (float)hi);
+        h[i] = __builtin_bit_cast(unsigned short, hi); l[i] = __builtin_bit_cast(unsigned short, lo);
+    }
+    u2 hv, lv;
+    hv.x = h[0] | ((unsigned)h[1] << 16); hv.y = h[2] | ((unsigned)h[3] << 16);
+    lv.x = l[0] | ((unsigned)l[1] << 16); lv.y = l[2] | ((unsigned)l[3] << 16);
+    *(u2 *)o = hv;
+    *(u2 *)(o + 32) = lv;
+}
+
+__global__ __launch_bounds__(256) void pca_absmax_kernel(const float *__restrict__ x, int64_t ldx, int B, int Din, unsigned *__restrict__ slot) {
+    float m = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)B * Din; i += (int64_t)gridDim.x * 256)
+        m = fmaxf(m, fabsf(x[(i / Din) * ldx + (i % Din)]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(slot, __float_as_uint(m));
+}
+
+// x_bound > 0: a known bound of max |x| (e.g. 1 for L2-normalised VLAD vectors) instead of a pass over x.
+// out = normalize_row(((x - 0) W^T - mean_proj) * inv_scale) with W given as pairs: d_W2 [S][Dout][Din / S / 32][hi 32 | lo 32] of
+// sW W (`pca_pair_weights`), inv_sw = 1 / sW.  Workspaces (A2, partials, the max |x| slot) live in the grow-only scratch.
+CSLAM_API int cslam_pca_project_pairs_dev(const float *d_x, int64_t ldx, float x_bound, const void *d_W2, float inv_sw, int S,
+                                          const float *d_mean_proj, const float *d_inv_scale, int B, int Din, int Dout,
+                                          float *d_out, void *stream) {
+    PTR_DEVICE(d_x);
+    ARG_CHECK(d_x && d_W2 && d_out, "NULL argument");
+    ARG_CHECK(B >= 1 && S >= 1 && Din >= 32 * S && (Din % (32 * S)) == 0, "Din must be a multiple of 32 S");
+    ARG_CHECK(Dout >= 128 && (Dout % 128) == 0, "Dout must be a multiple of 128");
+    ARG_CHECK(((uintptr_t)d_x % 16 == 0) && ldx >= Din && ldx % 4 == 0, "x must be 16-byte aligned with a pitch that is a multiple of 4 floats");
+    ARG_CHECK(inv_sw > 0.0f, "inv_sw must be positive");
+    hipStream_t st = (hipStream_t)stream;
+    int dev = 0; HIP_TRY(hipGetDevice(&dev));
+    const size_t a2_bytes = (size_t)B * Din * 4, part_bytes = (size_t)S * B * Dout * 4;
+    const size_t need = a2_bytes + part_bytes + 256;
+    if (need > g_part_bytes || g_part_dev != dev) {
+        size_t want = need > 2 * g_part_bytes ? need : 2 * g_part_bytes;
+        if (want < ((size_t)64 << 20)) want = (size_t)64 << 20;
+        float *fresh = nullptr;
+        HIP_TRY(hipMalloc((void **)&fresh, want));      // the previous buffer is left alive on purpose (see above)
+        g_part = fresh; g_part_bytes = want; g_part_dev = dev;
+    }
+    unsigned *slot = (unsigned *)g_part;
+    unsigned short *A2 = (unsigned short *)((char *)g_part + 256);
+    float *part = (float *)((char *)g_part + 256 + a2_bytes);
+    if (!(x_bound > 0.0f)) {                                       // no bound given: one pass over x for max |x|
+        HIP_TRY(hipMemsetAsync(slot, 0, 4, st));
+        hipLaunchKernelGGL(pca_absmax_kernel, dim3(1024), dim3(256), 0, st, d_x, ldx, B, Din, slot);
+    } else {
+        slot = nullptr;
+    }
+    hipLaunchKernelGGL(pca_pairs_rows_kernel, dim3((unsigned)ceil_div64((int64_t)B * (Din / 4), 256)), dim3(256), 0, st, d_x, ldx, B,
+                       Din, S, slot, x_bound, A2);
+    HIP_TRY(hipGetLastError());
+    const int rc = cslam_pair_gemm_launch(A2, d_W2, S, B, Din / S, Dout, part, st);
+    if (rc != CSLAM_OK) return rc;
+    // the input scale is only known on the device: the epilogue undoes it from the same slot
+    hipLaunchKernelGGL(pca_epilogue_pairs_kernel, dim3(B), dim3(256), 0, st, part, S, B, Dout, d_mean_proj, d_inv_scale, d_out, slot,
+                       x_bound, inv_sw);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }

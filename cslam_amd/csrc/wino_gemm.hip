@@ -49,7 +49,8 @@ struct WinoGemmArgs {
     int T, Cin, Cout;
     int nk;                // Cin / 32
     int n_mt, n_nt;        // row blocks = ceil(T / 256), column blocks = Cout / TN
-    int n_items;           // 36 * n_mt * n_nt
+    int n_items;           // nxi * n_mt * n_nt
+    int nxi;               // independent products in the launch: 36 Winograd frequencies, or the K splits of a projection
 };
 
 // s_waitcnt with only the vector-memory counter: gfx9 simm16 = vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14
@@ -297,8 +298,9 @@ __device__ __forceinline__ void wg_bt4(wf4 &d0, wf4 &d1, wf4 &d2, wf4 &d3, wf4 &
 
 // V = B^T d B of every 6 x 6 input tile of x [B,H,W,C] (NHWC, times the power-of-two scale derived from *amax), split into
 // fp16 pairs and stored as V2 [36][T][C/32][hi 32 | lo 32].  One thread = one tile x 4 consecutive channels: 16-byte
-// loads, two 8-byte stores per frequency (hi and lo of its 4 channels); the 8 lanes of a 32-channel block fill one 64-byte
-// half of a 128-byte line with each store, the other store the other half.
+// loads; per frequency the hi and the lo halves of its 4 channels (8 bytes each) -- lanes 2k / 2k + 1 trade them (DPP) so that
+// the even lane stores 16 bytes of hi halves and the odd lane 16 bytes of lo halves (PAIR16), instead of two 8-byte stores each.
+template <bool PAIR16>
 __global__ __launch_bounds__(256) void wino4_input_h2_kernel(const float *__restrict__ x, int B, int H, int W, int C,
                                                              const unsigned *__restrict__ amax, __half *__restrict__ V2) {
     const int c4n = C >> 2;
@@ -345,8 +347,22 @@ __global__ __launch_bounds__(256) void wino4_input_h2_kernel(const float *__rest
             hi.x = *(const unsigned *)&h0v; hi.y = *(const unsigned *)&h1v;
             lo.x = *(const unsigned *)&l0v; lo.y = *(const unsigned *)&l1v;
             __half *q = o + (int64_t)(6 * i + j) * plane;
-            __builtin_nontemporal_store(hi, (wu2 *)q);
-            __builtin_nontemporal_store(lo, (wu2 *)(q + 32));
+            if (PAIR16) {
+                // 16-byte stores: lanes 2k / 2k + 1 hold channels 8k .. 8k + 7 of this block between them; the even lane stores
+                // the hi halves of all eight (its own + the partner's), the odd lane the lo halves
+                const bool odd = threadIdx.x & 1;
+                wu2 give = odd ? hi : lo, got;
+                got.x = (unsigned)__builtin_amdgcn_mov_dpp((int)give.x, 0xB1, 0xF, 0xF, true);       // quad_perm [1, 0, 3, 2]
+                got.y = (unsigned)__builtin_amdgcn_mov_dpp((int)give.y, 0xB1, 0xF, 0xF, true);
+                typedef unsigned wu4 __attribute__((ext_vector_type(4)));
+                wu4 v16;
+                if (odd) { v16.x = got.x; v16.y = got.y; v16.z = lo.x; v16.w = lo.y; }
+                else { v16.x = hi.x; v16.y = hi.y; v16.z = got.x; v16.w = got.y; }
+                __builtin_nontemporal_store(v16, (wu4 *)(odd ? q + 32 - 4 : q));
+            } else {
+                __builtin_nontemporal_store(hi, (wu2 *)q);
+                __builtin_nontemporal_store(lo, (wu2 *)(q + 32));
+            }
         }
 }
 
@@ -358,8 +374,15 @@ CSLAM_API int cslam_wino4_input_h2_dev(const float *d_x, int B, int H, int W, in
     ARG_CHECK(C >= 32 && (C % 32) == 0, "C must be a multiple of 32");
     const int64_t n4 = (int64_t)B * ((H + 3) / 4) * ((W + 3) / 4) * (C / 4);
     ARG_CHECK(ceil_div64(n4, 256) < (1LL << 31), "too many tiles for one launch");
-    hipLaunchKernelGGL(wino4_input_h2_kernel, dim3((unsigned)round_up64(ceil_div64(n4, 256), 8)), dim3(256), 0,
-                       (hipStream_t)stream, d_x, B, H, W, C, d_amax, (__half *)d_V2);
+    // 16-byte stores through a lane-pair exchange (default; CSLAM_WIN_PAIR16=0: two 8-byte stores per thread and frequency):
+    // 5.0 -> 5.3 TB/s on the trunk's shapes, profiles/r02_v28_input_transform_pair16_ab.log
+    const char *pe = getenv("CSLAM_WIN_PAIR16");
+    if (!(pe && atoi(pe) == 0))
+        hipLaunchKernelGGL(wino4_input_h2_kernel<true>, dim3((unsigned)round_up64(ceil_div64(n4, 256), 8)), dim3(256), 0,
+                           (hipStream_t)stream, d_x, B, H, W, C, d_amax, (__half *)d_V2);
+    else
+        hipLaunchKernelGGL(wino4_input_h2_kernel<false>, dim3((unsigned)round_up64(ceil_div64(n4, 256), 8)), dim3(256), 0,
+                           (hipStream_t)stream, d_x, B, H, W, C, d_amax, (__half *)d_V2);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }
@@ -375,7 +398,7 @@ static int wino_gemm_launch(WinoGemmArgs a, int dbg, hipStream_t st) {
     }
     a.n_mt = (int)ceil_div64(a.T, TM);
     a.n_nt = a.Cout / TN;
-    const int64_t items = (int64_t)36 * a.n_mt * a.n_nt;
+    const int64_t items = (int64_t)a.nxi * a.n_mt * a.n_nt;
     ARG_CHECK(items < (1LL << 31), "too many work items");
     a.n_items = (int)items;
     constexpr int lds = NS * (TM + TN) * WG_ROWB;
@@ -406,6 +429,7 @@ CSLAM_API int cslam_wino_gemm_h2_dev(const void *d_V2, const void *d_U2, int64_t
     a.V2 = (const char *)d_V2; a.U2 = (const char *)d_U2; a.M = d_M;
     a.T = (int)T; a.Cin = Cin; a.Cout = Cout; a.nk = Cin / 32;
     a.n_mt = a.n_nt = a.n_items = 0;
+    a.nxi = 36;
     // read on every call (two getenv, ~100 ns) so that tests and experiments can switch shapes inside one process
     const char *e = getenv("CSLAM_WGEMM_DBG"), *c = getenv("CSLAM_WGEMM_CFG");
     const int dbg = e ? atoi(e) : 0;            // timing-only ablations
@@ -422,4 +446,20 @@ CSLAM_API int cslam_wino_gemm_h2_dev(const void *d_V2, const void *d_U2, int64_t
     case 3: return wino_gemm_launch<128, 256, 3>(a, dbg, st);      // ring of 3, 128 x 256
     default: return wino_gemm_launch<256, 128, 2>(a, dbg, st);     // double buffer, 256 x 128 (round-2 first form)
     }
+}
+
+/* The same kernel as a general batch of `nxi` independent pair products M[i] = A2[i] B2[i]^T (rows x K) x (N x K): used by the
+ * PCA projection of the NetVLAD head (csrc/gemm_nt.hip: its K = 32768 is cut into nxi splits whose partial products the
+ * epilogue sums).  Layouts as cslam_wino_gemm_h2_dev with 36 -> nxi. */
+int cslam_pair_gemm_launch(const void *d_A2, const void *d_B2, int nxi, int64_t T, int K, int N, float *d_M, hipStream_t st) {
+    ARG_CHECK(d_A2 && d_B2 && d_M, "NULL argument");
+    ARG_CHECK(nxi >= 1 && T >= 1 && T < (1LL << 31), "nxi / T out of range");
+    ARG_CHECK(K >= 32 && (K % 32) == 0, "K must be a multiple of 32");
+    ARG_CHECK(N >= 128 && (N % 128) == 0, "N must be a multiple of 128");
+    WinoGemmArgs a;
+    a.V2 = (const char *)d_A2; a.U2 = (const char *)d_B2; a.M = d_M;
+    a.T = (int)T; a.Cin = K; a.Cout = N; a.nk = K / 32;
+    a.n_mt = a.n_nt = a.n_items = 0;
+    a.nxi = nxi;
+    return wino_gemm_launch<256, 128, 3>(a, 0, st);
 }

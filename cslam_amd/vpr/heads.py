@@ -77,8 +77,41 @@ def gem_fc_head(feat, p, eps, W, b):
     return out
 
 
-def pca_project(x, components, mean_proj, inv_scale):
-    """[B,Din] -> normalised [B,Dout] (netvlad.py:234-236); x / components may be pitched views."""
+PCA_PAIR_SPLITS = 16            # K splits of the pair form of the projection (the "frequencies" of the pair GEMM)
+PCA_PAIR_MIN_BATCH = 32         # below this the f32 forms (matrix-vector / f32-MFMA tile) are used
+
+
+def pca_pair_weights(components, splits=PCA_PAIR_SPLITS):
+    """components [Dout, Din] float32 -> (W2 [S, Dout, Din/S/32, 2, 32] float16, inv_sw) for `cslam_pca_project_pairs_dev`:
+    sW * components split into exact fp16 hi / lo pairs (sW the power of two that brings max |W| into [2^14, 2^15)), rows
+    = output components, every 32-wide block of a row's K split holds its hi halves then its lo halves.  None when the
+    shape does not fit (Din a multiple of 32 S, Dout of 128)."""
+    import math
+    dout, din = components.shape
+    if din % (32 * splits) or dout % 128:
+        return None
+    w = components.detach().to(torch.float32)
+    amax = float(w.abs().max())
+    sw = 2.0 ** (14 - math.floor(math.log2(amax))) if amax > 0 else 1.0
+    ws = w * sw
+    wh = ws.to(torch.float16)
+    wl = (ws - wh.to(torch.float32)).to(torch.float16)
+    ks = din // splits
+    pair = torch.stack((wh.view(dout, splits, ks // 32, 32), wl.view(dout, splits, ks // 32, 32)), dim=3)   # [Dout,S,kb,2,32]
+    return pair.permute(1, 0, 2, 3, 4).contiguous(), 1.0 / sw
+
+
+def pca_project(x, components, mean_proj, inv_scale, pairs=None, x_bound=0.0):
+    """[B,Din] -> normalised [B,Dout] (netvlad.py:234-236); x / components may be pitched views.  pairs =
+    `pca_pair_weights(components)`: batches run on the fp16 matrix pipe from exact hi / lo pairs (fp32-grade); x_bound > 0 =
+    a known bound of max |x| (1 for L2-normalised VLAD vectors)."""
+    if pairs is not None and x.shape[0] >= PCA_PAIR_MIN_BATCH and x.is_cuda and x.dtype == torch.float32 and x.stride(1) == 1:
+        out = torch.empty((x.shape[0], components.shape[0]), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().cslam_pca_project_pairs_dev(_p(x), x.stride(0), float(x_bound), _p(pairs[0]), float(pairs[1]), pairs[0].shape[0],
+                                                           _p(mean_proj) if mean_proj is not None else None,
+                                                           _p(inv_scale) if inv_scale is not None else None,
+                                                           x.shape[0], x.shape[1], components.shape[0], _p(out), _stream(out)))
+        return out
     for t in (x, components):
         if not (t.is_cuda and t.dtype == torch.float32 and t.stride(1) == 1):
             raise _lib.CslamHipError("pca_project needs float32 device tensors with unit column stride")

@@ -120,6 +120,7 @@ class NetVLAD(object):
         self._online_trunk = None
         self.pool = NetVLADLayer(num_clusters=64, dim=512, device=self.device)
         self.pca_components = None     # [Dout, Din] device
+        self.pca_pairs = None          # the same as exact fp16 hi / lo pairs (heads.pca_pair_weights): batches
         self.pca_mean_proj = None      # [Dout] = mean @ components.T
         self.pca_inv_scale = None
         for p in self.encoder.parameters():
@@ -160,6 +161,7 @@ class NetVLAD(object):
         mean = np.asarray(mean, dtype=np.float32)
         self.pca_components = heads.padded_rows(comp.shape[0], comp.shape[1], self.device)
         self.pca_components.copy_(torch.from_numpy(comp))
+        self.pca_pairs = heads.pca_pair_weights(self.pca_components) if os.environ.get("CSLAM_PCA_PAIRS", "1") != "0" else None
         self.pca_mean_proj = torch.from_numpy((mean.reshape(1, -1) @ comp.T).reshape(-1).astype(np.float32)).to(self.device)
         self.pca_inv_scale = None
         if whiten:
@@ -191,6 +193,7 @@ class NetVLAD(object):
         comp = torch.randn((pca_dim, din), generator=g, dtype=torch.float32) / din ** 0.5
         self.pca_components = heads.padded_rows(pca_dim, din, self.device)
         self.pca_components.copy_(comp)
+        self.pca_pairs = heads.pca_pair_weights(self.pca_components) if os.environ.get("CSLAM_PCA_PAIRS", "1") != "0" else None
         self.pca_mean_proj = torch.zeros(pca_dim, dtype=torch.float32, device=self.device)
         self.pca_inv_scale = None
 
@@ -218,7 +221,8 @@ class NetVLAD(object):
         else:
             f = self.encoder(x)
         v = self.pool(f)
-        return heads.pca_project(v, self.pca_components, self.pca_mean_proj, self.pca_inv_scale)
+        # the VLAD vector is L2-normalised (netvlad.py:130): |v| <= 1 (one ulp of slack) spares the projection its max-pass
+        return heads.pca_project(v, self.pca_components, self.pca_mean_proj, self.pca_inv_scale, self.pca_pairs, 1.0 + 2.0 ** -20)
 
     def compute_embedding(self, keyframe):
         """Global image descriptor of one RGB keyframe (reference :212-245)."""

@@ -150,6 +150,14 @@ int cslam_gem_fc_head_dev(const float *d_feat, float p, float eps, const float *
 int cslam_pca_project_dev(const float *d_x, int64_t ldx, const float *d_comp, int64_t ldc,
                           const float *d_mean_proj, const float *d_inv_scale, int B, int Din, int Dout,
                           float *d_out, void *stream);
+/* The same projection for batches on the fp16 matrix pipe with fp32-grade results: x and the components as exact fp16 hi / lo
+ * pairs, three partial products in fp32 accumulators (the arithmetic and the kernel of cslam_wino_gemm_h2_dev; Din is cut into
+ * S splits whose partial products the epilogue sums).  d_W2: [S][Dout][Din / S / 32][hi 32 | lo 32] fp16 of sW * components
+ * (`pca_pair_weights` in cslam_amd/vpr/heads.py), inv_sw = 1 / sW; Din a multiple of 32 S, Dout of 128.  x_bound > 0: a known
+ * bound of max |x| (1 for the L2-normalised VLAD vectors of netvlad.py:130) spares the pass that measures it. */
+int cslam_pca_project_pairs_dev(const float *d_x, int64_t ldx, float x_bound, const void *d_W2, float inv_sw, int S,
+                                const float *d_mean_proj, const float *d_inv_scale, int B, int Din, int Dout,
+                                float *d_out, void *stream);
 /* image transform, cslam/vpr/netvlad.py:202-208 / cosplace.py:73-79:
  * CenterCrop(crop) -> Resize(out_hw, PIL bicubic, antialiased, 8-bit intermediate) ->
  * ToTensor (/255, HWC->CHW) -> Normalize(mean, std).

@@ -685,3 +685,31 @@ def test_stem_kernel_first_two_convolutions_equal_float64_and_separate_kernels(T
     assert es <= 2e-5 and rs <= 5e-6, (es, rs)
     assert es <= max(2.0 * ea, 2e-6) and rs <= max(2.0 * ra, 5e-7), (es, ea, rs, ra)
     assert (ys - ya).abs().max().item() <= 1e-5 * top
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,din,dout,whiten", [(130, 32768, 4096, False), (256, 32768, 4096, True), (33, 2048, 256, False),
+                                               (700, 8192, 128, True)])
+def test_pca_project_on_fp16_pairs_is_fp32_grade(T, B, din, dout, whiten):
+    """cslam_pca_project_pairs_dev (the batched projection on the fp16 matrix pipe: x and the components as exact hi / lo
+    pairs, the pair GEMM of the trunk with the K splits in place of its 36 frequencies) against a float64 evaluation and
+    against the f32-MFMA form: within 1e-5 absolute on unit-norm outputs (actual ~1e-7), no further from float64 than 2x
+    the f32 form; ragged batches, mean / whitening terms, inputs two decades apart (the power-of-two input scale)."""
+    torch, heads = T
+    gen = torch.Generator(device="cuda").manual_seed(B + dout)
+    x = torch.randn((B, din), generator=gen, device="cuda")
+    x[B // 2:] *= 0.01
+    comp = torch.randn((dout, din), generator=gen, device="cuda") / din ** 0.5
+    mp = torch.randn(dout, generator=gen, device="cuda") * 0.1
+    inv = (torch.rand(dout, generator=gen, device="cuda") + 0.5) if whiten else None
+    pairs = heads.pca_pair_weights(comp)
+    assert pairs is not None and pairs[0].shape[0] == heads.PCA_PAIR_SPLITS
+    yp = heads.pca_project(x, comp, mp, inv, pairs)
+    yf = heads.pca_project(x, comp, mp, inv)
+    ref = x.double() @ comp.double().T - mp.double()
+    if inv is not None:
+        ref = ref * inv.double()
+    ref = ref / ref.norm(dim=1, keepdim=True)
+    ep, ef = float((yp.double() - ref).abs().max()), float((yf.double() - ref).abs().max())
+    assert ep < 1e-5 and ep <= max(2.0 * ef, 5e-7), (ep, ef)
+    assert float((yp.norm(dim=1) - 1.0).abs().max()) < 1e-5
