@@ -44,6 +44,7 @@ _SIGNATURES = {
     "cslam_topk_merge_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp]),
     "cslam_l2_normalize_dev": (_i, [_vp, _i64, _i, _i64, _f, _i, _vp]),
     "cslam_vlad_aggregate_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp]),
+    "cslam_vlad_aggregate_nhwc_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp]),
     "cslam_gem_fc_head_dev": (_i, [_vp, _f, _f, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "cslam_pca_project_dev": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "cslam_pca_project_pairs_dev": (_i, [_vp, _i64, C.c_float, _vp, C.c_float, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -183,6 +183,9 @@ __global__ __launch_bounds__(512) void vlad_generic_kernel(const float *__restri
 #define VL_CC 32
 #define VL_PMAX 256
 #define VL_PPAD 257
+// NHWC: the feature map is [P][C] (channels_last storage, what the Winograd trunk writes) instead of [C][P]: a slab element is
+// then (pixel e / 32, channel e % 32) -- 128-byte runs per pixel -- and the layout conversion pass before the head is gone.
+template <bool NHWC>
 __global__ __launch_bounds__(512) void vlad_fast_kernel(const float *__restrict__ feat, const float *__restrict__ W,
                                                         const float *__restrict__ bias, const float *__restrict__ cent,
                                                         int C, int P, float *__restrict__ out, int64_t ldo) {
@@ -205,12 +208,25 @@ __global__ __launch_bounds__(512) void vlad_fast_kernel(const float *__restrict_
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             int e = i * 512 + tid;
-            pf[i] = (e < slab_elems && base + e < limit) ? x[base + e] : 0.0f;
+            if (NHWC) {
+                const int pp = e >> 5, cc = e & 31, c = sl * VL_CC + cc;
+                pf[i] = (pp < P && c < C) ? x[(size_t)pp * C + c] : 0.0f;
+            } else {
+                pf[i] = (e < slab_elems && base + e < limit) ? x[base + e] : 0.0f;
+            }
         }
     };
     // slab element e = i*512 + tid lives at (channel e / P, pixel e % P): walk it incrementally
     const int cc_start = tid / P, pp_start = tid - cc_start * P, dq = 512 / P, dr = 512 - dq * P;
     auto commit = [&]() {
+        if (NHWC) {
+#pragma unroll
+            for (int i = 0; i < NPF; ++i) {
+                const int e = i * 512 + tid, pp = e >> 5, cc = e & 31;
+                if (pp < P) xs[cc * VL_PPAD + pp] = pf[i];
+            }
+            return;
+        }
         int cc = cc_start, pp = pp_start;
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
@@ -507,15 +523,24 @@ static float *g_vs = nullptr;
 static size_t g_vs_floats = 0;
 static int g_vs_dev = -1;
 
-CSLAM_API int cslam_vlad_aggregate_dev(const float *d_feat, const float *d_assign_w, const float *d_assign_b,
-                                       const float *d_centroids, int B, int C, int P, int K,
-                                       float *d_out, int64_t ldo, void *stream) {
+static int vlad_aggregate(const float *d_feat, const float *d_assign_w, const float *d_assign_b,
+                          const float *d_centroids, int B, int C, int P, int K,
+                          float *d_out, int64_t ldo, void *stream, bool nhwc) {
     PTR_DEVICE(d_feat);
     ARG_CHECK(d_feat && d_assign_w && d_centroids && d_out, "NULL argument");
     ARG_CHECK(K == VK, "K must be 64 (reference: num_clusters=64, netvlad.py:176)");
     ARG_CHECK(C >= 1 && C <= 512 && P >= 1 && B >= 0, "need 1 <= C <= 512 (reference encoder_dim = 512, netvlad.py:162)");
     ARG_CHECK(ldo >= (int64_t)K * C, "output pitch smaller than K*C");
     if (B == 0) return CSLAM_OK;
+    if (nhwc) {
+        ARG_CHECK(P <= VL_PMAX && B > 8, "the channels-last form is the batch kernel's (B > 8, P <= 256)");
+        size_t lds = (size_t)(VL_PMAX * VK + VL_CC * VL_PPAD + VL_CC * VK + VL_PMAX + VK + VK + 16) * 4;
+        HIP_TRY(hipFuncSetAttribute((const void *)vlad_fast_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(vlad_fast_kernel<true>, dim3(B), dim3(512), lds, (hipStream_t)stream, d_feat, d_assign_w,
+                           d_assign_b, d_centroids, C, P, d_out, ldo);
+        HIP_TRY(hipGetLastError());
+        return CSLAM_OK;
+    }
     if (B <= 8 && P <= VL_PMAX) {
         hipStream_t st = (hipStream_t)stream;
         int dev = 0;
@@ -545,8 +570,8 @@ CSLAM_API int cslam_vlad_aggregate_dev(const float *d_feat, const float *d_assig
     }
     if (P <= VL_PMAX) {
         size_t lds = (size_t)(VL_PMAX * VK + VL_CC * VL_PPAD + VL_CC * VK + VL_PMAX + VK + VK + 16) * 4;
-        HIP_TRY(hipFuncSetAttribute((const void *)vlad_fast_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(vlad_fast_kernel, dim3(B), dim3(512), lds, (hipStream_t)stream, d_feat, d_assign_w,
+        HIP_TRY(hipFuncSetAttribute((const void *)vlad_fast_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(vlad_fast_kernel<false>, dim3(B), dim3(512), lds, (hipStream_t)stream, d_feat, d_assign_w,
                            d_assign_b, d_centroids, C, P, d_out, ldo);
     } else {
         int threads = (int)round_up64(C > VPCH ? C : VPCH, 64);
@@ -557,6 +582,18 @@ CSLAM_API int cslam_vlad_aggregate_dev(const float *d_feat, const float *d_assig
     }
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
+}
+
+CSLAM_API int cslam_vlad_aggregate_dev(const float *d_feat, const float *d_assign_w, const float *d_assign_b,
+                                       const float *d_centroids, int B, int C, int P, int K,
+                                       float *d_out, int64_t ldo, void *stream) {
+    return vlad_aggregate(d_feat, d_assign_w, d_assign_b, d_centroids, B, C, P, K, d_out, ldo, stream, false);
+}
+
+CSLAM_API int cslam_vlad_aggregate_nhwc_dev(const float *d_feat, const float *d_assign_w, const float *d_assign_b,
+                                            const float *d_centroids, int B, int C, int P, int K,
+                                            float *d_out, int64_t ldo, void *stream) {
+    return vlad_aggregate(d_feat, d_assign_w, d_assign_b, d_centroids, B, C, P, K, d_out, ldo, stream, true);
 }
 
 // ------------------------------------------------------------ CosPlace head ----

@@ -157,10 +157,15 @@ class ChainReducedSolverGPU(object):
             fj = rj - (rj > g).to(torch.int64)
             ki, kj = ri != g, rj != g
             both = ki & kj
-            Sf.index_put_((fi[ki], fi[ki]), rw[ki], accumulate=True)
-            Sf.index_put_((fj[kj], fj[kj]), rw[kj], accumulate=True)
-            Sf.index_put_((fi[both], fj[both]), -rw[both], accumulate=True)
-            Sf.index_put_((fj[both], fi[both]), -rw[both], accumulate=True)
+            # every entry's terms are added in a FIXED order (stable sort by entry, sequential sum per entry): scattering with
+            # atomic adds left the order of the ~3 terms of an entry to the scheduler, a 1e-16 run-to-run jitter in the matrix
+            ii = torch.cat((fi[ki], fj[kj], fi[both], fj[both]))
+            jj = torch.cat((fi[ki], fj[kj], fj[both], fi[both]))
+            vv = torch.cat((rw[ki], rw[kj], -rw[both], -rw[both]))
+            key, order = torch.sort(ii * m + jj, stable=True)
+            ukey, counts = torch.unique_consecutive(key, return_counts=True)
+            sums = torch.segment_reduce(vv[order], "sum", lengths=counts)
+            Sf.view(-1)[ukey] = sums
             _lap('assemble nJ=%d' % nJ)
             if m > 4096 and os.environ.get('CSLAM_MAC_CHOL', 'blocked') == 'blocked':
                 self.chol = blocked_cholesky_(Sf)              # in place: the upper triangle keeps stale values, never read

@@ -52,14 +52,23 @@ def padded_rows(n, d, device, dtype=torch.float32):
 
 
 def vlad_aggregate(feat, assign_w, assign_b, centroids, out=None):
-    """[B,C,h,w] -> [B, 64*C]  NetVLADLayer.forward (netvlad.py:94-130)."""
-    _chk(feat); _chk(assign_w); _chk(centroids)
+    """[B,C,h,w] -> [B, 64*C]  NetVLADLayer.forward (netvlad.py:94-130).  A channels_last feature map (what the Winograd trunk
+    writes) is used in place by the batch kernel (B > 8, h w <= 256); otherwise the map must be contiguous NCHW."""
+    _chk(assign_w); _chk(centroids)
     B, Cc = feat.shape[:2]
     P = feat.shape[2] * feat.shape[3]
     K = centroids.shape[0]
     if out is None:
         out = padded_rows(B, K * Cc, feat.device)
     assert out.shape == (B, K * Cc) and out.stride(1) == 1
+    if (B > 8 and P <= 256 and feat.is_cuda and feat.dtype == torch.float32 and not feat.is_contiguous()
+            and feat.is_contiguous(memory_format=torch.channels_last)):
+        _lib.check(_lib.load().cslam_vlad_aggregate_nhwc_dev(
+            _p(feat), _p(assign_w), _p(assign_b) if assign_b is not None else None, _p(centroids), B, Cc, P, K, _p(out),
+            out.stride(0), _stream(out)))
+        return out
+    feat = feat.contiguous()
+    _chk(feat)
     _lib.check(_lib.load().cslam_vlad_aggregate_dev(_p(feat), _p(assign_w), _p(assign_b) if assign_b is not None else None,
                                                     _p(centroids), B, Cc, P, K, _p(out), out.stride(0), _stream(out)))
     return out

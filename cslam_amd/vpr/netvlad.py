@@ -82,7 +82,7 @@ class NetVLADLayer(object):
         return self
 
     def forward(self, x):
-        return heads.vlad_aggregate(x.contiguous(), self.conv_weight, self.conv_bias, self.centroids)
+        return heads.vlad_aggregate(x, self.conv_weight, self.conv_bias, self.centroids)
 
     __call__ = forward
 

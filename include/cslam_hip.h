@@ -135,6 +135,11 @@ int cslam_l2_normalize_dev(float *d_x, int64_t n, int d, int64_t ld, float eps,
 int cslam_vlad_aggregate_dev(const float *d_feat, const float *d_assign_w, const float *d_assign_b,
                              const float *d_centroids, int B, int C, int P, int K,
                              float *d_out, int64_t ldo, void *stream);
+/* The same layer on a channels-last feature map d_feat [B][P][C] (what the Winograd trunk writes): batches only (B > 8,
+ * P <= 256); spares the layout conversion in front of the head. */
+int cslam_vlad_aggregate_nhwc_dev(const float *d_feat, const float *d_assign_w, const float *d_assign_b,
+                                  const float *d_centroids, int B, int C, int P, int K,
+                                  float *d_out, int64_t ldo, void *stream);
 /* CosPlace aggregation head, cslam/vpr/cosplace_utils/network.py:23-29 + layers.py:8-36:
  * L2Norm(C) -> GeM(p, eps) -> Flatten -> Linear(W [Dout, C], b [Dout]) -> L2Norm.
  * feat [B, C, P]; out [B, Dout]. */

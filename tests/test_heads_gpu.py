@@ -713,3 +713,24 @@ def test_pca_project_on_fp16_pairs_is_fp32_grade(T, B, din, dout, whiten):
     ep, ef = float((yp.double() - ref).abs().max()), float((yf.double() - ref).abs().max())
     assert ep < 1e-5 and ep <= max(2.0 * ef, 5e-7), (ep, ef)
     assert float((yp.norm(dim=1) - 1.0).abs().max()) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,C,H,W", [(12, 512, 14, 14), (9, 96, 16, 16), (40, 500, 5, 3), (33, 64, 1, 1)])
+def test_vlad_channels_last_feature_map_equals_nchw(T, B, C, H, W):
+    """cslam_vlad_aggregate_nhwc_dev: the batch kernel on the channels_last map the Winograd trunk writes, against the same
+    kernel on the converted NCHW map (same arithmetic in the same order: bit-identical) and the numpy restatement of
+    NetVLADLayer.forward (netvlad.py:94-130); ragged last slab (C not a multiple of 32), bias, P = 1."""
+    torch, heads = T
+    rng = np.random.default_rng(B + C)
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    w = rng.standard_normal((64, C)).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    c = rng.random((64, C)).astype(np.float32)
+    xd = dev(T, x)
+    xl = xd.contiguous(memory_format=torch.channels_last)
+    assert not xl.is_contiguous() or H * W == 1
+    y_nchw = heads.vlad_aggregate(xd, dev(T, w), dev(T, b), dev(T, c))
+    y_nhwc = heads.vlad_aggregate(xl, dev(T, w), dev(T, b), dev(T, c))
+    assert torch.equal(y_nchw, y_nhwc)
+    assert np.max(np.abs(y_nhwc.cpu().numpy() - ho.vlad_forward(x, w, b, c))) < 1e-6

@@ -136,3 +136,13 @@ def test_dense_cholesky_solve4_matches_library(m, bs):
         assert float((A @ x - rhs).abs().max()) < 1e-9 * float(A.abs().max())
     x2 = BlockedCholeskySolve(L_row, bs).solve(rhs)                   # fixed summation order: bit-identical repeats
     assert torch.equal(x2, BlockedCholeskySolve(L_row, bs).solve(rhs))
+
+
+def test_chain_gpu_fiedler_pair_is_reproducible_bit_for_bit():
+    """Two runs of the HIP Fiedler solver on the same Laplacian give the same bits: the junction matrix is assembled in a
+    fixed order (no atomic scatter), every reduction kernel sums in a fixed order, the dense solve has no atomics."""
+    from cslam_amd.mac.chain_solver_gpu import fiedler_tracemin_chain_gpu
+    L = _pose_graph(4, 6000, 900, 11)
+    l1, v1 = fiedler_tracemin_chain_gpu(L)
+    l2, v2 = fiedler_tracemin_chain_gpu(L)
+    assert l1 == l2 and np.array_equal(v1, v2)
