@@ -61,6 +61,9 @@ _SIGNATURES = {
     "cslam_chain_forward_dev": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cslam_chain_backward_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "cslam_chol_solve4_dev": (_i, [_vp, _i64, _i64, _i, _vp, _vp, _i, _vp, _vp, _vp]),
+    "cslam_fiedler": (_i, [_i64, _vp, _vp, _vp, _vp, C.c_uint32, C.c_double, _i, _vp, _vp, _vp, _vp]),
+    "cslam_fiedler_start_block": (_i, [C.c_uint32, _i64, _vp]),
+    "cslam_fiedler_release": (_i, []),
     "cslam_scbank_create": (_i, [_i, _i, _i, _i64, _vp]),
     "cslam_scbank_destroy": (_i, [_vp]),
     "cslam_scbank_size": (_i, [_vp, _vp, _vp, _vp]),

@@ -315,7 +315,7 @@ class AlgebraicConnectivityMaximization(object):
     # ----------------------------------------------------------------------- solve ----
     def _fiedler_solver(self):
         """Inner solver of the Fiedler computation: 'frontend.mac_fiedler_solver' in the params
-        ('tracemin_lu' | 'chain' | 'chain_gpu' | 'auto').  'auto' keeps the reference's sparse-LU path for
+        ('tracemin_lu' | 'chain' | 'chain_gpu' | 'chain_hip' | 'auto').  'auto' keeps the reference's sparse-LU path for
         small graphs (bit-compatible selections) and moves graphs of >= 20000 poses to the chain-reduced
         HIP solver when a GPU is visible."""
         choice = self.params.get('frontend.mac_fiedler_solver', 'auto') if hasattr(self.params, 'get') else 'auto'

@@ -328,3 +328,35 @@ def fiedler_tracemin_chain_gpu(L, tol=1e-8, seed=None, device="cuda", stats=None
     if stats is not None:
         torch.cuda.synchronize(); stats['loop_s'] = time.perf_counter() - t_loop
     return float(sigma[0]), X[:, 0].cpu().numpy()
+
+
+def fiedler_tracemin_hip(L, tol=1e-8, seed=7, device="cuda", stats=None, x0=None, max_iters=0):
+    """The same computation through the C ABI's one-call entry point `cslam_fiedler` (csrc/fiedler.hip): chain / junction
+    structure, dense factor (rocBLAS / rocSOLVER), TraceMIN loop and its 4 x 4 algebra all in native code -- what a host
+    without Python calls in place of cslam/mac/mac.py:35-59.  `seed` is the integer the reference seeds RandomState with
+    (7, mac.py:56-58).  Returns (lambda_2, v numpy)."""
+    import time
+    import torch
+    L = sp.csr_matrix(L, dtype=np.float64)
+    L.sum_duplicates()
+    L.sort_indices()
+    n = L.shape[0]
+    lib = _lib.load()
+    indptr = np.ascontiguousarray(L.indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(L.indices, dtype=np.int32)
+    data = np.ascontiguousarray(L.data, dtype=np.float64)
+    lam, iters, v = C.c_double(0.0), C.c_int(0), np.empty(n, dtype=np.float64)
+    x0p = None if x0 is None else np.ascontiguousarray(x0, dtype=np.float64)
+    assert x0p is None or x0p.shape == (n, 4)
+    dev = torch.device(device)
+    t0 = time.perf_counter()
+    with torch.cuda.device(dev):
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.cslam_fiedler(n, indptr.ctypes.data_as(C.c_void_p), indices.ctypes.data_as(C.c_void_p),
+                                     data.ctypes.data_as(C.c_void_p), None if x0p is None else x0p.ctypes.data_as(C.c_void_p),
+                                     int(seed), float(tol), int(max_iters), C.byref(lam), v.ctypes.data_as(C.c_void_p),
+                                     C.byref(iters), st))
+    if stats is not None:
+        stats['iters'] = iters.value
+        stats['total_s'] = time.perf_counter() - t0
+    return float(lam.value), v

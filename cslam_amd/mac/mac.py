@@ -23,6 +23,7 @@ class MAC:
         # 'tracemin_lu'  sparse LU inner solves, the reference's path (networkx + SuperLU)
         # 'chain'        chain-reduced inner solves, host numpy (same iterates to ~1e-15)
         # 'chain_gpu'    chain-reduced inner solves and every O(n) step in HIP (large graphs)
+        # 'chain_hip'    the same computation behind the C ABI's one-call `cslam_fiedler` (native host code, no torch ops)
         self.fiedler_solver = fiedler_solver
         self.L_odom = weight_graph_lap_from_edge_list(fixed_measurements, num_poses)
         self.num_poses = num_poses
@@ -44,6 +45,14 @@ class MAC:
                     st['nJ'], st['setup_s'] * 1e3, st['iters'], st['loop_s'] * 1e3, st['loop_s'] * 1e3 / max(st['iters'], 1)), flush=True)
                 return out
             return fiedler_tracemin_chain_gpu(L, tol=tol, seed=np.random.RandomState(7))
+        if self.fiedler_solver == 'chain_hip':
+            import os
+            from .chain_solver_gpu import fiedler_tracemin_hip
+            st = {} if os.environ.get('CSLAM_MAC_TIMING') else None
+            out = fiedler_tracemin_hip(L, tol=tol, seed=7, stats=st)
+            if st is not None:
+                print('      [fiedler (cslam_fiedler): %d TraceMIN iterations, %.0f ms in all]' % (st['iters'], st['total_s'] * 1e3), flush=True)
+            return out
         if self.fiedler_solver == 'chain':
             return fiedler_tracemin_chain(L, tol=tol, seed=np.random.RandomState(7))
         return fiedler_tracemin_lu(L, tol=tol, seed=np.random.RandomState(7))

@@ -233,6 +233,24 @@ int cslam_chain_backward_dev(const double *d_xJ, const double *d_Bn, const doubl
 int cslam_chol_solve4_dev(const double *d_L, int64_t m, int64_t ld, int col_major, const double *d_dinv,
                           const double *d_dinvT, int bs, double *d_x, double *d_tmp, void *stream);
 
+/* (lambda_2, v_2) of a pose-graph Laplacian in ONE call, for a host without Python: replaces the whole of
+ * cslam/mac/mac.py:35-59 (MAC.find_fiedler_pair -> networkx algebraic_connectivity / fiedler_vector with
+ * method='tracemin_lu', seed RandomState(7)).  The Laplacian is a HOST CSR matrix (both triangles, column indices sorted
+ * and unique within a row -- what mac.py:61-77 builds), n > 4 nodes, connected.  Same TraceMIN iteration as
+ * cslam_amd/mac/fiedler.py; the inner solves run by the chain reduction above with the junction system factorised densely
+ * on the GPU (rocBLAS / rocSOLVER, looked up at run time: CSLAM_E_UNSUPPORTED without them; at most 64000 junctions).
+ *   h_x0        start block [n][4] row-major, or NULL = numpy RandomState(seed).normal(size=(4, n)).T (bit-identical;
+ *               cslam_fiedler_start_block writes that block to a host buffer)
+ *   tol         stopping rule ||L v - lambda v||_1 / ||L||_inf < tol (mac.py passes 1e-8)
+ *   max_iters   <= 0: no practical limit (the reference has none); otherwise CSLAM_E_INVALID when exceeded
+ *   h_lambda2, h_v [n], h_iters (optional): results on the host.  The sign of v is arbitrary (as in the reference).
+ * Work runs on the CURRENT device and `stream`; device memory is a workspace kept between calls (MAC calls this once per
+ * Frank-Wolfe iteration), freed by cslam_fiedler_release.  Calls are serialised by a lock. */
+int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h_indices, const double *h_data, const double *h_x0,
+                  uint32_t seed, double tol, int max_iters, double *h_lambda2, double *h_v, int *h_iters, void *stream);
+int cslam_fiedler_start_block(uint32_t seed, int64_t n, double *h_x0);
+int cslam_fiedler_release(void);
+
 /* ------------------------------------------------------------------------------------------------
  * Lidar place recognition: ScanContext bank.
  * Replaces cslam/lidar_pr/scancontext_matching.py:5-104 (ScanContextMatching) with its helpers

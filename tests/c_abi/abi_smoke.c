@@ -53,6 +53,29 @@ int main(void) {
     if (cslam_bank_search_host(b, q32, 7, NQ, K, NULL, 0, idx, sim, cnt) != CSLAM_E_INVALID) { printf("bad dtype accepted\n"); return 1; }
     cslam_bank_destroy(b);
     free(bank); free(q32); free(q64);
+    /* MAC's Fiedler pair in one call (mac.py:35-59) on a cycle of RING nodes = an odometry chain closed by one loop edge:
+     * lambda_2 = 2 - 2 cos(2 pi / RING) in closed form */
+    {
+        enum { RING = 500 };
+        int64_t indptr[RING + 1]; int32_t indices[3 * RING]; double data[3 * RING], v[RING], lam = 0.0; int iters = 0;
+        int64_t p = 0;
+        for (int i = 0; i < RING; ++i) {
+            int nb[3] = {(i + RING - 1) % RING, i, (i + 1) % RING};
+            for (int a = 0; a < 3; ++a) for (int c = a + 1; c < 3; ++c) if (nb[c] < nb[a]) { int t = nb[a]; nb[a] = nb[c]; nb[c] = t; }
+            indptr[i] = p;
+            for (int a = 0; a < 3; ++a) { indices[p] = nb[a]; data[p] = nb[a] == i ? 2.0 : -1.0; ++p; }
+        }
+        indptr[RING] = p;
+        int rc = cslam_fiedler(RING, indptr, indices, data, NULL, 7u, 1e-8, 0, &lam, v, &iters, NULL);
+        if (rc != CSLAM_OK) { printf("fiedler: %s\n", cslam_last_error()); return 1; }
+        double want = 2.0 - 2.0 * cos(2.0 * 3.14159265358979323846 / RING), nrm = 0.0, sum = 0.0;
+        for (int i = 0; i < RING; ++i) { nrm += v[i] * v[i]; sum += v[i]; }
+        if (fabs(lam - want) > 1e-7 * want || fabs(nrm - 1.0) > 1e-9 || fabs(sum) > 1e-9 || iters < 1) {
+            printf("fiedler: lambda_2 %.12e, expected %.12e (|v|^2 %.12f, sum %.3e, %d iterations)\n", lam, want, nrm, sum, iters);
+            return 1;
+        }
+        cslam_fiedler_release();
+    }
     printf("C ABI smoke ok (version %d)\n", cslam_version());
     return 0;
 }

@@ -282,3 +282,16 @@ def test_selection_with_chain_solver_equals_reference(g7, tag, R, K):
     sel = ac.select_candidates(K, {r: True for r in range(R)}, greedy_initialization=True)
     got = np.array([tuple(e) for e in sel], dtype=np.float64).reshape(-1, 5)
     assert np.array_equal(got, g7[tag + "/selected"])
+
+
+def test_c_abi_start_block_is_numpy_randomstate_normal_bit_for_bit():
+    """cslam_fiedler's built-in start block (host code: MT19937 + the legacy polar Box-Muller) equals
+    np.random.RandomState(seed).normal(size=(4, n)).T, the block networkx draws for the reference (mac.py:56-58)."""
+    import ctypes as C
+    from cslam_amd import _lib
+    lib = _lib.load()
+    for seed, n in ((7, 1), (7, 1237), (7, 50001), (2**32 - 1, 333), (0, 64)):
+        x = np.empty((n, 4))
+        assert lib.cslam_fiedler_start_block(seed, n, x.ctypes.data_as(C.c_void_p)) == 0
+        assert np.array_equal(x, np.random.RandomState(seed).normal(size=(4, n)).T)
+    assert lib.cslam_fiedler_start_block(7, 0, None) == -1

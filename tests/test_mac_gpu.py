@@ -146,3 +146,72 @@ def test_chain_gpu_fiedler_pair_is_reproducible_bit_for_bit():
     l1, v1 = fiedler_tracemin_chain_gpu(L)
     l2, v2 = fiedler_tracemin_chain_gpu(L)
     assert l1 == l2 and np.array_equal(v1, v2)
+
+
+@pytest.mark.parametrize("R,P,m", [(1, 40, 3), (3, 100, 30), (8, 400, 600), (8, 2000, 2000), (2, 4097, 3), (4, 6000, 5200)])
+def test_one_call_c_abi_fiedler_matches_reference_algorithm(R, P, m):
+    """`cslam_fiedler` (host structure, dense junction factor through rocBLAS / rocSOLVER, TraceMIN loop and its 4 x 4 algebra
+    all behind ONE C call) against the sparse-LU restatement of the reference's networkx call (mac.py:35-59) and against
+    the torch-driven device solver.  (4, 6000, 5200): > 4096 junctions, the blocked factorisation with 2048 blocks."""
+    from cslam_amd.mac.chain_solver_gpu import fiedler_tracemin_chain_gpu, fiedler_tracemin_hip
+    from cslam_amd.mac.fiedler import fiedler_tracemin_lu
+    L = _pose_graph(R, P, m, 7)
+    l1, v1 = fiedler_tracemin_lu(L)
+    st = {}
+    l2, v2 = fiedler_tracemin_hip(L, stats=st)
+    assert abs(l1 - l2) < 1e-9 * abs(l1) + 1e-13
+    assert min(np.max(np.abs(v1 - v2)), np.max(np.abs(v1 + v2))) < 1e-6
+    assert np.linalg.norm(L @ v2 - l2 * v2, 1) / abs(L).sum(axis=1).max() < 1e-8
+    if L.shape[0] > 4:
+        l3, v3 = fiedler_tracemin_chain_gpu(L)
+        assert abs(l3 - l2) < 1e-10 * abs(l3) + 1e-13
+    # deterministic: no atomics with more than two terms, fixed reduction orders
+    l4, v4 = fiedler_tracemin_hip(L)
+    assert l4 == l2 and np.array_equal(v4, v2)
+    # the caller's start block is honoured: numpy's own block gives the same bits as the built-in generator
+    x0 = np.random.RandomState(7).normal(size=(4, L.shape[0])).T
+    l5, v5 = fiedler_tracemin_hip(L, x0=x0)
+    assert l5 == l2 and np.array_equal(v5, v2)
+    assert st['iters'] >= 1
+
+
+def test_one_call_c_abi_fiedler_argument_errors_and_disconnected_graph():
+    import scipy.sparse as sp
+    from cslam_amd import _lib
+    from cslam_amd._lib import CslamHipError
+    from cslam_amd.mac.chain_solver_gpu import fiedler_tracemin_hip
+    lib = _lib.load()
+    with pytest.raises(CslamHipError, match="n must be"):
+        fiedler_tracemin_hip(sp.csr_matrix(np.array([[1.0, -1.0], [-1.0, 1.0]])))
+    # two components: the grounded junction Laplacian is singular -> reported, not a wrong answer
+    n = 60
+    i = np.array([k for k in range(n - 1) if k != 29])
+    W = sp.coo_matrix((np.ones(len(i)), (i, i + 1)), shape=(n, n))
+    W = W + W.T
+    L = sp.csr_matrix(sp.diags(np.asarray(W.sum(axis=1)).ravel()) - W)
+    with pytest.raises(CslamHipError):
+        fiedler_tracemin_hip(L, max_iters=50)
+    # unsorted column indices are refused
+    indptr = np.array([0, 2, 4, 6, 8, 10, 12], dtype=np.int64)
+    indices = np.array([1, 0] * 6, dtype=np.int32)
+    data = np.ones(12)
+    lam, v = C.c_double(), np.empty(6)
+    rc = lib.cslam_fiedler(6, indptr.ctypes.data_as(C.c_void_p), indices.ctypes.data_as(C.c_void_p), data.ctypes.data_as(C.c_void_p),
+                           None, 7, 1e-8, 0, C.byref(lam), v.ctypes.data_as(C.c_void_p), None, None)
+    assert rc == -1 and b"sorted" in lib.cslam_last_error()
+    assert lib.cslam_fiedler_release() == 0
+
+
+@pytest.mark.parametrize("tag,R,K", [("mac_R3_P100_C100_K10", 3, 10), ("mac_R8_P400_C600_K60", 8, 60)])
+def test_selection_with_one_call_solver_equals_reference(tag, R, K):
+    from helpers import GOLDEN
+    from cslam_amd.algebraic_connectivity_maximization import AlgebraicConnectivityMaximization, EdgeInterRobot
+    g7 = np.load(GOLDEN + "/mac_g7.npz")
+    ed = lambda arr: [EdgeInterRobot(int(a), int(b), int(c), int(d), float(w)) for a, b, c, d, w in arr]
+    params = {"frontend.enable_sparsification": True, "evaluation.enable_sparsification_comparison": False,
+              "frontend.mac_fiedler_solver": "chain_hip"}
+    ac = AlgebraicConnectivityMaximization(robot_id=0, max_nb_robots=R, extra_params=params)
+    ac.set_graph(ed(g7[tag + "/fixed"]), ed(g7[tag + "/cand"]))
+    sel = ac.select_candidates(K, {r: True for r in range(R)}, greedy_initialization=True)
+    got = np.array([tuple(e) for e in sel], dtype=np.float64).reshape(-1, 5)
+    assert np.array_equal(got, g7[tag + "/selected"])
