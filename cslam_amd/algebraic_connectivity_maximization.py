@@ -317,7 +317,8 @@ class AlgebraicConnectivityMaximization(object):
         """Inner solver of the Fiedler computation: 'frontend.mac_fiedler_solver' in the params
         ('tracemin_lu' | 'chain' | 'chain_gpu' | 'chain_hip' | 'auto').  'auto' keeps the reference's sparse-LU path for
         small graphs (bit-compatible selections) and moves graphs of >= 20000 poses to the chain-reduced
-        HIP solver when a GPU is visible."""
+        HIP solver when a GPU is visible ('chain_hip': the C ABI's one-call `cslam_fiedler`; 'chain_gpu' is the
+        same computation driven from torch)."""
         choice = self.params.get('frontend.mac_fiedler_solver', 'auto') if hasattr(self.params, 'get') else 'auto'
         if choice != 'auto':
             return choice
@@ -325,7 +326,7 @@ class AlgebraicConnectivityMaximization(object):
             try:
                 import torch
                 if torch.cuda.is_available():
-                    return 'chain_gpu'
+                    return 'chain_hip'
             except ImportError:
                 pass
         return 'tracemin_lu'

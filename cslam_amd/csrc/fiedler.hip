@@ -85,7 +85,7 @@ struct Blas {
     void *hb = nullptr, *hs = nullptr;
     fn_create create = nullptr; fn_set_stream set_stream = nullptr; fn_dgemm dgemm = nullptr; fn_dtrsm dtrsm = nullptr;
     fn_dpotrf dpotrf = nullptr;
-    rb_handle handle = nullptr;
+    rb_handle handle = nullptr, handle2 = nullptr, handle3 = nullptr;
     int handle_dev = -1;
 } g_blas;
 
@@ -148,7 +148,18 @@ struct Workspace {
     int device = -1;
     Buf arena, dense, inv, x0;
     int64_t x0_n = -1; uint32_t x0_seed = 0;
-    void release() { arena.release(); dense.release(); inv.release(); x0.release(); x0_n = -1; device = -1; }
+    hipStream_t stream = nullptr;                              // used when the caller passes no stream (no implicit ordering against the null stream)
+    hipStream_t stream2 = nullptr, stream3 = nullptr;          // look-ahead of the blocked factorisation: panels / block inverses
+    hipEvent_t ev_row = nullptr, ev_panel = nullptr, ev_inv = nullptr;
+    void release() {
+        arena.release(); dense.release(); inv.release(); x0.release(); x0_n = -1; device = -1;
+        if (stream) { (void)hipStreamDestroy(stream); stream = nullptr; }
+        if (stream2) {
+            (void)hipStreamDestroy(stream2); (void)hipStreamDestroy(stream3);
+            (void)hipEventDestroy(ev_row); (void)hipEventDestroy(ev_panel); (void)hipEventDestroy(ev_inv);
+            stream2 = stream3 = nullptr;
+        }
+    }
 } g_ws;
 std::mutex g_mu;
 
@@ -274,10 +285,11 @@ CSLAM_API int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h
     std::lock_guard<std::mutex> lock(g_mu);
     int rc = blas_load();
     if (rc) return rc;
-    hipStream_t st = (hipStream_t)stream;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
     if (g_ws.device != dev) { if (g_ws.device >= 0) { DeviceGuard guard(g_ws.device); g_ws.release(); } g_ws.device = dev; }
+    if (!stream && !g_ws.stream) HIP_TRY(hipStreamCreateWithFlags(&g_ws.stream, hipStreamNonBlocking));
+    hipStream_t st = stream ? (hipStream_t)stream : g_ws.stream;
     if (!g_blas.handle || g_blas.handle_dev != dev) { RB_TRY(g_blas.create(&g_blas.handle)); g_blas.handle_dev = dev; }
     RB_TRY(g_blas.set_stream(g_blas.handle, st));
     Laps laps;
@@ -409,40 +421,88 @@ CSLAM_API int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h
         hipLaunchKernelGGL(fj_diag_kernel, dim3((m + 255) / 256), dim3(256), 0, st, d_diag, m, A, ld);
         HIP_TRY(hipGetLastError());
         laps.lap("assemble", st);
-        // the row-major lower factor L is the column-major upper factor U = L^T of the same buffer: A = U^T U, right-looking
+        // the row-major lower factor L is the column-major upper factor U = L^T of the same buffer: A = U^T U, right-looking.
+        // Look-ahead: as soon as the block row of the NEXT panel has its update, its diagonal factorisation (potrf: a chain of
+        // small kernels) and its panel solve run on a second, high-priority stream under the GEMMs that update the rest of
+        // the trailing matrix; the inversions of the diagonal blocks (needed only by the solves afterwards) on a third.
         const double one = 1.0, minus = -1.0;
         const int cb = m > 4096 ? bs : m;                                           // small systems: one potrf
-        int ib = 0;
-        for (int k = 0; k < m; k += cb, ++ib) {
-            const int e = k + cb < m ? k + cb : m, bw = e - k;
-            RB_TRY(g_blas.dpotrf(g_blas.handle, RB_UPPER, bw, A + (size_t)k * ld + k, (int)ld, d_info + ib));
-            if (e < m) {
-                RB_TRY(g_blas.dtrsm(g_blas.handle, RB_LEFT, RB_UPPER, RB_OP_T, RB_NON_UNIT, bw, m - e, &one, A + (size_t)k * ld + k, (int)ld,
-                                    A + (size_t)e * ld + k, (int)ld));
-                for (int j = e; j < m; j += 2 * cb) {
-                    const int je = j + 2 * cb < m ? j + 2 * cb : m;
-                    RB_TRY(g_blas.dgemm(g_blas.handle, RB_OP_T, RB_OP_N, je - j, m - j, bw, &minus, A + (size_t)j * ld + k, (int)ld,
-                                        A + (size_t)j * ld + k, (int)ld, &one, A + (size_t)j * ld + j, (int)ld));
-                }
+        const char *lenv = getenv("CSLAM_FIEDLER_LOOKAHEAD");
+        const bool la = m > cb && !(lenv && lenv[0] == '0');
+        if (la) {
+            if (!g_ws.stream2) {
+                int least = 0, greatest = 0;                                            // the panel chain must not queue behind the GEMM's workgroups
+                HIP_TRY(hipDeviceGetStreamPriorityRange(&least, &greatest));
+                HIP_TRY(hipStreamCreateWithPriority(&g_ws.stream2, hipStreamNonBlocking, greatest));
+                HIP_TRY(hipStreamCreateWithFlags(&g_ws.stream3, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&g_ws.ev_row, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&g_ws.ev_panel, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&g_ws.ev_inv, hipEventDisableTiming));
             }
+            if (!g_blas.handle2) { RB_TRY(g_blas.create(&g_blas.handle2)); RB_TRY(g_blas.create(&g_blas.handle3)); }
+            RB_TRY(g_blas.set_stream(g_blas.handle2, g_ws.stream2));
+            RB_TRY(g_blas.set_stream(g_blas.handle3, g_ws.stream3));
+        }
+        int ib = 0;
+        auto panel = [&](rb_handle h, hipStream_t hs, int k) -> int {               // diagonal block k: factor, panel row, block inverses
+            const int e = k + cb < m ? k + cb : m, bw = e - k;
+            RB_TRY(g_blas.dpotrf(h, RB_UPPER, bw, A + (size_t)k * ld + k, (int)ld, d_info + ib++));
+            if (e < m)
+                RB_TRY(g_blas.dtrsm(h, RB_LEFT, RB_UPPER, RB_OP_T, RB_NON_UNIT, bw, m - e, &one, A + (size_t)k * ld + k, (int)ld,
+                                    A + (size_t)e * ld + k, (int)ld));
+            return CSLAM_OK;
+        };
+        auto inverses = [&](rb_handle h, hipStream_t hs, int k0, int k1) -> int {   // inverted bs-blocks of the diagonal in [k0, k1)
+            for (int k = k0; k < k1; k += bs) {
+                const int t = k / bs, e = k + bs < m ? k + bs : m, bw = e - k;
+                double *Dt = dinv + (size_t)t * bs * bs, *DtT = dinvT + (size_t)t * bs * bs;
+                const unsigned grid = (unsigned)(((int64_t)bs * bs + 255) / 256);
+                hipLaunchKernelGGL(fj_identity_kernel, dim3(grid), dim3(256), 0, hs, Dt, bs, bw);
+                hipLaunchKernelGGL(fj_identity_kernel, dim3(grid), dim3(256), 0, hs, DtT, bs, bw);
+                // column-major U^-1 is the row-major L^-1; column-major U^-T its transpose
+                RB_TRY(g_blas.dtrsm(h, RB_LEFT, RB_UPPER, RB_OP_N, RB_NON_UNIT, bw, bw, &one, A + (size_t)k * ld + k, (int)ld, Dt, bs));
+                RB_TRY(g_blas.dtrsm(h, RB_LEFT, RB_UPPER, RB_OP_T, RB_NON_UNIT, bw, bw, &one, A + (size_t)k * ld + k, (int)ld, DtT, bs));
+            }
+            return CSLAM_OK;
+        };
+        auto update = [&](int k, int bw, int j, int je) -> int {                   // C[j:je, j:m] -= U[k:k+bw, j:je]^T U[k:k+bw, j:m]
+            RB_TRY(g_blas.dgemm(g_blas.handle, RB_OP_T, RB_OP_N, je - j, m - j, bw, &minus, A + (size_t)j * ld + k, (int)ld,
+                                A + (size_t)j * ld + k, (int)ld, &one, A + (size_t)j * ld + j, (int)ld));
+            return CSLAM_OK;
+        };
+        if ((rc = panel(g_blas.handle, st, 0))) return rc;
+        if (!la) { if ((rc = inverses(g_blas.handle, st, 0, cb < m ? cb : m))) return rc; }
+        else {                                                                      // the block inverses are needed last: a stream of their own
+            HIP_TRY(hipEventRecord(g_ws.ev_row, st)); HIP_TRY(hipStreamWaitEvent(g_ws.stream3, g_ws.ev_row, 0));
+            if ((rc = inverses(g_blas.handle3, g_ws.stream3, 0, cb))) return rc;
+        }
+        for (int k = 0; k + cb < m; k += cb) {
+            const int e = k + cb, e2 = e + cb < m ? e + cb : m;
+            if ((rc = update(k, cb, e, e2))) return rc;                             // the next panel's block row first
+            if (la) HIP_TRY(hipEventRecord(g_ws.ev_row, st));
+            for (int j = e2; j < m; j += 2 * cb) {                                  // queued BEFORE the panel calls: should one of
+                const int je = j + 2 * cb < m ? j + 2 * cb : m;                     // them block the host, the GPU already has these
+                if ((rc = update(k, cb, j, je))) return rc;
+            }
+            if (la) {
+                HIP_TRY(hipStreamWaitEvent(g_ws.stream2, g_ws.ev_row, 0));
+                if ((rc = panel(g_blas.handle2, g_ws.stream2, e))) return rc;
+                HIP_TRY(hipEventRecord(g_ws.ev_panel, g_ws.stream2));
+                HIP_TRY(hipStreamWaitEvent(g_ws.stream3, g_ws.ev_panel, 0));
+                if ((rc = inverses(g_blas.handle3, g_ws.stream3, e, e2))) return rc;
+                HIP_TRY(hipStreamWaitEvent(st, g_ws.ev_panel, 0));
+            }
+            else { if ((rc = panel(g_blas.handle, st, e))) return rc; if ((rc = inverses(g_blas.handle, st, e, e2))) return rc; }
+        }
+        if (la) {                                                                   // the last inverses join the main stream
+            HIP_TRY(hipEventRecord(g_ws.ev_inv, g_ws.stream3)); HIP_TRY(hipStreamWaitEvent(st, g_ws.ev_inv, 0));
         }
         std::vector<int> info(ib);
         HIP_TRY(hipMemcpyAsync(info.data(), d_info, ib * sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         for (int i = 0; i < ib; ++i)
             if (info[i] != 0) { cslam_set_error("the grounded junction Laplacian is not positive definite (graph not connected?)"); return CSLAM_E_INVALID; }
-        laps.lap("cholesky", st);
-        for (int t = 0; t < nb; ++t) {
-            const int k = t * bs, e = k + bs < m ? k + bs : m, bw = e - k;
-            double *Dt = dinv + (size_t)t * bs * bs, *DtT = dinvT + (size_t)t * bs * bs;
-            const unsigned grid = (unsigned)(((int64_t)bs * bs + 255) / 256);
-            hipLaunchKernelGGL(fj_identity_kernel, dim3(grid), dim3(256), 0, st, Dt, bs, bw);
-            hipLaunchKernelGGL(fj_identity_kernel, dim3(grid), dim3(256), 0, st, DtT, bs, bw);
-            // column-major U^-1 is the row-major L^-1; column-major U^-T its transpose
-            RB_TRY(g_blas.dtrsm(g_blas.handle, RB_LEFT, RB_UPPER, RB_OP_N, RB_NON_UNIT, bw, bw, &one, A + (size_t)k * ld + k, (int)ld, Dt, bs));
-            RB_TRY(g_blas.dtrsm(g_blas.handle, RB_LEFT, RB_UPPER, RB_OP_T, RB_NON_UNIT, bw, bw, &one, A + (size_t)k * ld + k, (int)ld, DtT, bs));
-        }
-        laps.lap("block inverses", st);
+        laps.lap("cholesky + block inverses", st);
     }
 
     // ---- TraceMIN (fiedler.py / chain_solver_gpu.py, same order of operations) ----

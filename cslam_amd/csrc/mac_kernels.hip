@@ -378,19 +378,18 @@ __global__ __launch_bounds__(B4_BLOCK) void block4_gram_kernel(const double *__r
 // then a fixed tree over the lanes (deterministic).  One thread per output walking 1024 partials was a chain of 1024 L2 round
 // trips: 0.36 ms per call, six calls per TraceMIN iteration.
 __global__ __launch_bounds__(256) void block4_gram_finish_kernel(const double *__restrict__ partial, int nblocks, double *__restrict__ out20) {
+    // one workgroup per output value (20 of them side by side: 28 -> ~6 us); the summation order of a value is unchanged
     __shared__ double red[256];
-    for (int i = 0; i < 20; ++i) {
-        double s = 0.0;
-        for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[(size_t)b * 20 + i];
-        red[threadIdx.x] = s;
-        __syncthreads();
-        for (int w = 128; w >= 1; w >>= 1) {
-            if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) out20[i] = red[0];
+    const int i = blockIdx.x;
+    double s = 0.0;
+    for (int b = threadIdx.x; b < nblocks; b += 256) s += partial[(size_t)b * 20 + i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w >= 1; w >>= 1) {
+        if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
         __syncthreads();
     }
+    if (threadIdx.x == 0) out20[i] = red[0];
 }
 
 // out[k][:] = A[k][:] * M (4x4, row-major) - shift[:]
@@ -452,7 +451,7 @@ CSLAM_API int cslam_block4_gram_dev(const double *d_A, const double *d_B, int64_
     hipStream_t st = (hipStream_t)stream;
     int grid = (int)ceil_div64(n, B4_BLOCK); if (grid > B4_GRID) grid = B4_GRID;
     hipLaunchKernelGGL(block4_gram_kernel, dim3(grid), dim3(B4_BLOCK), 0, st, d_A, d_B, n, d_partial);
-    hipLaunchKernelGGL(block4_gram_finish_kernel, dim3(1), dim3(256), 0, st, d_partial, grid, d_out20);
+    hipLaunchKernelGGL(block4_gram_finish_kernel, dim3(20), dim3(256), 0, st, d_partial, grid, d_out20);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }
@@ -526,7 +525,7 @@ CSLAM_API int cslam_block4_gram_sync(const double *d_A, const double *d_B, int64
     hipStream_t st = (hipStream_t)stream;
     int grid = (int)ceil_div64(n, B4_BLOCK); if (grid > B4_GRID) grid = B4_GRID;
     hipLaunchKernelGGL(block4_gram_kernel, dim3(grid), dim3(B4_BLOCK), 0, st, d_A, d_B, n, d_partial);
-    hipLaunchKernelGGL(block4_gram_finish_kernel, dim3(1), dim3(256), 0, st, d_partial, grid, d_out20);
+    hipLaunchKernelGGL(block4_gram_finish_kernel, dim3(20), dim3(256), 0, st, d_partial, grid, d_out20);
     HIP_TRY(hipMemcpyAsync(h_out20, d_out20, 20 * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return CSLAM_OK;
@@ -566,6 +565,12 @@ CSLAM_API int cslam_block4_residual_sync(const double *d_W, const double *d_X, i
 // exactly once at HBM speed; the library's thin-right-hand-side GEMMs took 8 ms per solve on 32k junctions (2 x 4.3 GB = 1.4 ms
 // of traffic).  No atomics: a fixed summation order per output element (deterministic iterates).
 #define CS4_THREADS 256
+#ifndef CS4_ROWS_UNROLL
+#define CS4_ROWS_UNROLL 4
+#endif
+#ifndef CS4_ROWS_GRID
+#define CS4_ROWS_GRID 512
+#endif
 #define CS4_CT 512                     // threads of the column form: 8 waves, 8 rows each in flight
 
 // out[r][:] (-)= sum_c M[r][c] xin[c][:]   r < nrows, c < ncols <= bs; xin is staged in LDS.  One wave per RPW rows,
@@ -592,7 +597,7 @@ __global__ __launch_bounds__(CS4_THREADS) void cs4_rows_kernel(const double *__r
         const double *mp[RPW];
 #pragma unroll
         for (int i = 0; i < RPW; ++i) mp[i] = M + (r0 + i < nrows ? r0 + i : nrows - 1) * ldm;
-#pragma unroll 2
+#pragma unroll CS4_ROWS_UNROLL
         for (int c = lane; c < ncp; c += 64) {
             const bool in = c < ncols;
             double m[RPW];
@@ -625,6 +630,36 @@ __global__ __launch_bounds__(CS4_THREADS) void cs4_rows_kernel(const double *__r
                 *o = SUB ? *o - v : v;
             }
         }
+    }
+}
+
+// out[r][:] = sum_c T[r][c] xin[c][:] for a TRIANGULAR bw x bw block T (row stride ldm) -- the products with the inverted
+// diagonal blocks.  UPPER = false: only columns <= r are read, true: only columns >= r (the other triangle is zero by
+// construction and is not even loaded: half the bytes of the full-block form).  One wave per row, rows dealt round robin so
+// that long and short rows mix in every workgroup; xin staged in LDS.
+template <bool UPPER>
+__global__ __launch_bounds__(CS4_THREADS) void cs4_tri_kernel(const double *__restrict__ T, int64_t ldm, int bw,
+                                                              const double *__restrict__ xin, double *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) double cs4_x[];              // [bw_pad][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ncp = (bw + 63) & ~63;
+    for (int i = tid; i < ncp * 4; i += CS4_THREADS) cs4_x[i] = i < bw * 4 ? xin[i] : 0.0;
+    __syncthreads();
+    const int rows_per_pass = gridDim.x * (CS4_THREADS / 64);
+    for (int r = blockIdx.x * (CS4_THREADS / 64) + wave; r < bw; r += rows_per_pass) {
+        const double *mp = T + (int64_t)r * ldm;
+        const int c_lo = UPPER ? (r & ~63) : 0, c_hi = UPPER ? bw : r + 1;       // columns [c_lo, c_hi) hold the row's non-zeros
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 4
+        for (int c = c_lo + lane; c < c_hi; c += 64) {
+            const double mv = (!UPPER || c >= r) ? mp[c] : 0.0;
+            a0 += mv * cs4_x[4 * c]; a1 += mv * cs4_x[4 * c + 1]; a2 += mv * cs4_x[4 * c + 2]; a3 += mv * cs4_x[4 * c + 3];
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            a0 += __shfl_xor(a0, off, 64); a1 += __shfl_xor(a1, off, 64); a2 += __shfl_xor(a2, off, 64); a3 += __shfl_xor(a3, off, 64);
+        }
+        if (lane == 0) { double *o = out + (int64_t)r * 4; o[0] = a0; o[1] = a1; o[2] = a2; o[3] = a3; }
     }
 }
 
@@ -690,13 +725,14 @@ CSLAM_API int cslam_chol_solve4_dev(const double *d_L, int64_t m, int64_t ld, in
     const int lds_rows = bs * 4 * 8, lds_cols = (bs * 4 * 8 > (CS4_CT / 64) * 64 * 4 * 8) ? bs * 4 * 8 : (CS4_CT / 64) * 64 * 4 * 8;
     static bool attr = false;
     if (!attr) {
-        HIP_TRY(hipFuncSetAttribute((const void *)cs4_rows_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
+        HIP_TRY(hipFuncSetAttribute((const void *)cs4_tri_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
+        HIP_TRY(hipFuncSetAttribute((const void *)cs4_tri_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
         HIP_TRY(hipFuncSetAttribute((const void *)cs4_rows_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
         HIP_TRY(hipFuncSetAttribute((const void *)cs4_cols_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
         attr = true;
     }
     const int64_t nb = ceil_div64(m, bs);
-    auto row_grid = [](int64_t rows, int rpw) { int64_t g = ceil_div64(rows, (CS4_THREADS / 64) * rpw); return (unsigned)(g > 2048 ? 2048 : (g < 1 ? 1 : g)); };
+    auto row_grid = [](int64_t rows, int rpw) { int64_t g = ceil_div64(rows, (CS4_THREADS / 64) * rpw); return (unsigned)(g > CS4_ROWS_GRID ? CS4_ROWS_GRID : (g < 1 ? 1 : g)); };
     // With a column-major factor the memory image is the row-major UPPER factor L^T: the forward update reads it by columns
     // (cols form), the backward update by rows.  The products with the inverted diagonal blocks are always in the row form
     // (dinv forward, its transpose dinvT backward: one row per wave, 4 rows per workgroup, so that even one 2048-row block
@@ -705,8 +741,8 @@ CSLAM_API int cslam_chol_solve4_dev(const double *d_L, int64_t m, int64_t ld, in
     for (int64_t t = 0; t < nb; ++t) {
         const int64_t k = t * bs, e = (k + bs < m) ? k + bs : m;
         const int bw = (int)(e - k);
-        hipLaunchKernelGGL((cs4_rows_kernel<false, 1>), dim3(row_grid(bw, 1)), dim3(CS4_THREADS), lds_rows, st,
-                           d_dinv + (size_t)t * bs * bs, (int64_t)bs, (int64_t)bw, bw, d_x + k * 4, d_tmp, (double *)nullptr);
+        hipLaunchKernelGGL(cs4_tri_kernel<false>, dim3(row_grid(bw, 1)), dim3(CS4_THREADS), lds_rows, st,
+                           d_dinv + (size_t)t * bs * bs, (int64_t)bs, bw, d_x + k * 4, d_tmp);
         if (e >= m)
             HIP_TRY(hipMemcpyAsync(d_x + k * 4, d_tmp, (size_t)bw * 32, hipMemcpyDeviceToDevice, st));
         else if (!col_major)
@@ -720,8 +756,8 @@ CSLAM_API int cslam_chol_solve4_dev(const double *d_L, int64_t m, int64_t ld, in
     for (int64_t t = nb - 1; t >= 0; --t) {
         const int64_t k = t * bs, e = (k + bs < m) ? k + bs : m;
         const int bw = (int)(e - k);
-        hipLaunchKernelGGL((cs4_rows_kernel<false, 1>), dim3(row_grid(bw, 1)), dim3(CS4_THREADS), lds_rows, st,
-                           d_dinvT + (size_t)t * bs * bs, (int64_t)bs, (int64_t)bw, bw, d_x + k * 4, d_tmp, (double *)nullptr);
+        hipLaunchKernelGGL(cs4_tri_kernel<true>, dim3(row_grid(bw, 1)), dim3(CS4_THREADS), lds_rows, st,
+                           d_dinvT + (size_t)t * bs * bs, (int64_t)bs, bw, d_x + k * 4, d_tmp);
         if (k == 0)
             HIP_TRY(hipMemcpyAsync(d_x + k * 4, d_tmp, (size_t)bw * 32, hipMemcpyDeviceToDevice, st));
         else if (!col_major)

@@ -47,9 +47,16 @@ class MAC:
             return fiedler_tracemin_chain_gpu(L, tol=tol, seed=np.random.RandomState(7))
         if self.fiedler_solver == 'chain_hip':
             import os
-            from .chain_solver_gpu import fiedler_tracemin_hip
+            from .._lib import CslamHipError
+            from .chain_solver_gpu import fiedler_tracemin_chain_gpu, fiedler_tracemin_hip
             st = {} if os.environ.get('CSLAM_MAC_TIMING') else None
-            out = fiedler_tracemin_hip(L, tol=tol, seed=7, stats=st)
+            try:
+                out = fiedler_tracemin_hip(L, tol=tol, seed=7, stats=st)
+            except CslamHipError as e:
+                if 'junctions' not in str(e):
+                    raise
+                # more junctions than the dense factor takes: the torch-driven solver's sparse-LU junction solve
+                return fiedler_tracemin_chain_gpu(L, tol=tol, seed=np.random.RandomState(7))
             if st is not None:
                 print('      [fiedler (cslam_fiedler): %d TraceMIN iterations, %.0f ms in all]' % (st['iters'], st['total_s'] * 1e3), flush=True)
             return out

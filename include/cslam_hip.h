@@ -228,8 +228,8 @@ int cslam_chain_backward_dev(const double *d_xJ, const double *d_Bn, const doubl
  * factorisations return) of the grounded junction Laplacian, x [m][4]: the junction solve inside every TraceMIN iteration (SuperLU's
  * solve in networkx `_tracemin_fiedler`, called at cslam/mac/mac.py:52-58).  d_dinv: inverses of the bs x bs diagonal
  * blocks of L, [ceil(m / bs)][bs][bs] (a ragged last block in the top-left corner of its slot), d_dinvT: the same
- * blocks transposed; d_tmp: [bs][4]
- * scratch.  Blocked substitution, every factor element read exactly once per sweep, fixed summation order. */
+ * blocks transposed (only the lower triangle of a d_dinv block and the upper triangle of a d_dinvT block are read);
+ * d_tmp: [bs][4] scratch.  Blocked substitution, every factor element read exactly once per sweep, fixed summation order. */
 int cslam_chol_solve4_dev(const double *d_L, int64_t m, int64_t ld, int col_major, const double *d_dinv,
                           const double *d_dinvT, int bs, double *d_x, double *d_tmp, void *stream);
 
@@ -244,7 +244,8 @@ int cslam_chol_solve4_dev(const double *d_L, int64_t m, int64_t ld, int col_majo
  *   tol         stopping rule ||L v - lambda v||_1 / ||L||_inf < tol (mac.py passes 1e-8)
  *   max_iters   <= 0: no practical limit (the reference has none); otherwise CSLAM_E_INVALID when exceeded
  *   h_lambda2, h_v [n], h_iters (optional): results on the host.  The sign of v is arbitrary (as in the reference).
- * Work runs on the CURRENT device and `stream`; device memory is a workspace kept between calls (MAC calls this once per
+ * Work runs on the CURRENT device and `stream` (NULL: a non-blocking stream of the library's own; the blocked factorisation
+ * also uses two side streams for its look-ahead, CSLAM_FIEDLER_LOOKAHEAD=0 keeps it on one); device memory is a workspace kept between calls (MAC calls this once per
  * Frank-Wolfe iteration), freed by cslam_fiedler_release.  Calls are serialised by a lock. */
 int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h_indices, const double *h_data, const double *h_x0,
                   uint32_t seed, double tol, int max_iters, double *h_lambda2, double *h_v, int *h_iters, void *stream);

@@ -145,6 +145,7 @@ def test_inter_robot_best1_equals_the_oracle_both_directions(c5):
 
 def test_select_candidates_1000_of_100k_poses_chain_gpu(c5, monkeypatch):
     from cslam_amd.mac import mac as mac_mod
+    from cslam_amd.mac.chain_solver_gpu import fiedler_tracemin_hip
     from cslam_amd.mac.fiedler import fiedler_tracemin_lu
     sel = c5["lc"][0].candidate_selector
     in_range = {r: True for r in range(R)}
@@ -181,6 +182,10 @@ def test_select_candidates_1000_of_100k_poses_chain_gpu(c5, monkeypatch):
         assert f > 0 and abs(f - f_ref) <= 1e-9 * abs(f_ref), (f, f_ref)
         # the Fiedler vector up to sign (gradient uses (v_i - v_j)^2): both unit norm
         assert min(np.abs(v - v_ref).max(), np.abs(v + v_ref).max()) <= 1e-6
+        # and the C ABI's one-call solver (what a host without Python runs in place of mac.py:35-59) on the same Laplacian
+        f_c, v_c = fiedler_tracemin_hip(L)
+        assert abs(f_c - f_ref) <= 1e-9 * abs(f_ref), (f_c, f_ref)
+        assert min(np.abs(v_c - v_ref).max(), np.abs(v_c + v_ref).max()) <= 1e-6
     # the objective never decreases below the first iterate's by more than round-off at the final rounding: the
     # selection is at least as connected as the greedy start
     sel.candidate_edges_to_fixed(list(second))
