@@ -427,8 +427,16 @@ CSLAM_API int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h
         // the trailing matrix; the inversions of the diagonal blocks (needed only by the solves afterwards) on a third.
         const double one = 1.0, minus = -1.0;
         const int cb = m > 4096 ? bs : m;                                           // small systems: one potrf
-        const char *lenv = getenv("CSLAM_FIEDLER_LOOKAHEAD");
-        const bool la = m > cb && !(lenv && lenv[0] == '0');
+        const char *lenv = getenv("CSLAM_FIEDLER_LOOKAHEAD"), *tenv = getenv("CSLAM_MAC_TIMING");
+        const bool split = tenv && tenv[0] == '2';                                 // per-category times: one stream, a sync after every call
+        const bool la = m > cb && !(lenv && lenv[0] == '0') && !split;
+        double t_cat[4] = {0, 0, 0, 0};                                             // potrf, panel trsm, trailing gemm, block inverses
+        auto tick = [&](int cat, std::chrono::steady_clock::time_point t0) {
+            if (!split) return;
+            (void)hipStreamSynchronize(st);
+            t_cat[cat] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        };
+        auto now = [&]() { if (split) (void)hipStreamSynchronize(st); return std::chrono::steady_clock::now(); };
         if (la) {
             if (!g_ws.stream2) {
                 int least = 0, greatest = 0;                                            // the panel chain must not queue behind the GEMM's workgroups
@@ -446,13 +454,17 @@ CSLAM_API int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h
         int ib = 0;
         auto panel = [&](rb_handle h, hipStream_t hs, int k) -> int {               // diagonal block k: factor, panel row, block inverses
             const int e = k + cb < m ? k + cb : m, bw = e - k;
+            auto t0 = now();
             RB_TRY(g_blas.dpotrf(h, RB_UPPER, bw, A + (size_t)k * ld + k, (int)ld, d_info + ib++));
+            tick(0, t0); t0 = now();
             if (e < m)
                 RB_TRY(g_blas.dtrsm(h, RB_LEFT, RB_UPPER, RB_OP_T, RB_NON_UNIT, bw, m - e, &one, A + (size_t)k * ld + k, (int)ld,
                                     A + (size_t)e * ld + k, (int)ld));
+            tick(1, t0);
             return CSLAM_OK;
         };
         auto inverses = [&](rb_handle h, hipStream_t hs, int k0, int k1) -> int {   // inverted bs-blocks of the diagonal in [k0, k1)
+            auto t0 = now();
             for (int k = k0; k < k1; k += bs) {
                 const int t = k / bs, e = k + bs < m ? k + bs : m, bw = e - k;
                 double *Dt = dinv + (size_t)t * bs * bs, *DtT = dinvT + (size_t)t * bs * bs;
@@ -463,11 +475,14 @@ CSLAM_API int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h
                 RB_TRY(g_blas.dtrsm(h, RB_LEFT, RB_UPPER, RB_OP_N, RB_NON_UNIT, bw, bw, &one, A + (size_t)k * ld + k, (int)ld, Dt, bs));
                 RB_TRY(g_blas.dtrsm(h, RB_LEFT, RB_UPPER, RB_OP_T, RB_NON_UNIT, bw, bw, &one, A + (size_t)k * ld + k, (int)ld, DtT, bs));
             }
+            tick(3, t0);
             return CSLAM_OK;
         };
         auto update = [&](int k, int bw, int j, int je) -> int {                   // C[j:je, j:m] -= U[k:k+bw, j:je]^T U[k:k+bw, j:m]
+            auto t0 = now();
             RB_TRY(g_blas.dgemm(g_blas.handle, RB_OP_T, RB_OP_N, je - j, m - j, bw, &minus, A + (size_t)j * ld + k, (int)ld,
                                 A + (size_t)j * ld + k, (int)ld, &one, A + (size_t)j * ld + j, (int)ld));
+            tick(2, t0);
             return CSLAM_OK;
         };
         if ((rc = panel(g_blas.handle, st, 0))) return rc;
@@ -503,6 +518,7 @@ CSLAM_API int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h
         for (int i = 0; i < ib; ++i)
             if (info[i] != 0) { cslam_set_error("the grounded junction Laplacian is not positive definite (graph not connected?)"); return CSLAM_E_INVALID; }
         laps.lap("cholesky + block inverses", st);
+        if (split) fprintf(stderr, " {potrf %.1f, panel trsm %.1f, trailing gemm %.1f, block inverses %.1f ms}", t_cat[0], t_cat[1], t_cat[2], t_cat[3]);
     }
 
     // ---- TraceMIN (fiedler.py / chain_solver_gpu.py, same order of operations) ----

@@ -734,3 +734,83 @@ def test_vlad_channels_last_feature_map_equals_nchw(T, B, C, H, W):
     y_nhwc = heads.vlad_aggregate(xl, dev(T, w), dev(T, b), dev(T, c))
     assert torch.equal(y_nchw, y_nhwc)
     assert np.max(np.abs(y_nhwc.cpu().numpy() - ho.vlad_forward(x, w, b, c))) < 1e-6
+
+
+@pytest.mark.gpu
+def test_netvlad_batch_path_descriptors_against_float64_model_on_distinct_frames(T):
+    """Descriptor-level gate on the path the bench times: config 3's extractor (4096-D projection) on 96 DISTINCT frames
+    -- block patterns of every scale, contrast, brightness and noise level, so small activations are covered -- through the batch forms (stem kernel, fp16-pair
+    trunk GEMMs, one-kernel convolutions, channels-last VLAD, pair PCA), against the SAME weights evaluated in float64
+    (torch, double precision convolutions) from the same preprocessed input.  north_star's gate: |component| error <= 1e-5 on
+    unit-norm descriptors."""
+    torch, _ = T
+    import copy
+    import torch.nn.functional as Fn
+    from cslam_amd.vpr import heads
+    from cslam_amd.vpr.netvlad import NetVLAD
+    rng = np.random.default_rng(11)
+    imgs = []
+    for i in range(96):                                        # block patterns of every scale, contrast, brightness and noise level
+        bsz = (6, 10, 16, 24, 40, 64, 96, 160)[i % 8]
+        low = rng.random((-(-480 // bsz), -(-640 // bsz), 3)).astype(np.float32)
+        img = np.kron(low, np.ones((bsz, bsz, 1), dtype=np.float32))[:480, :640]
+        contrast, bright, sigma = rng.uniform(0.05, 1.0), rng.uniform(20.0, 230.0), rng.uniform(0.0, 40.0) * (i % 3 == 0)
+        img = bright + contrast * (img - 0.5) * 255.0 * rng.uniform(0.3, 1.0, size=(1, 1, 3)) + rng.normal(0.0, 1.0, size=img.shape) * sigma
+        imgs.append(np.clip(img, 0, 255).astype(np.uint8))
+    frames = torch.from_numpy(np.stack(imgs)).cuda()
+    nv = NetVLAD({"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376, "frontend.netvlad.pca_dim": 4096,
+                  "frontend.random_seed": 3}, None)
+    got = nv.compute_embeddings_device(frames).double()
+    assert nv.trunk is not None and any(getattr(st, "stem", False) for st in nv.trunk.steps), "the stem kernel did not run"
+    assert nv.pca_pairs is not None
+    x = heads.preprocess(frames.contiguous(), nv.crop)
+    enc = copy.deepcopy(nv.encoder).double()
+    W, b, cent = nv.pool.conv_weight.double(), nv.pool.conv_bias, nv.pool.centroids.double()
+    comp = nv.pca_components[:4096].double()
+    ref = []
+    with torch.no_grad():
+        for s in range(0, x.shape[0], 16):
+            f = enc(x[s:s + 16].double())
+            xf = Fn.normalize(f, p=2.0, dim=1).flatten(2)
+            sa = torch.einsum("kc,ncp->nkp", W.reshape(W.shape[0], -1), xf)
+            if b is not None:
+                sa = sa + b.double().reshape(1, -1, 1)
+            a = torch.softmax(sa, dim=1)
+            v = torch.einsum("nkp,ncp->nkc", a, xf) - a.sum(2)[:, :, None] * cent[None]
+            v = Fn.normalize(Fn.normalize(v, p=2.0, dim=2).flatten(1), p=2.0, dim=1)
+            y = v @ comp.T - nv.pca_mean_proj.double()[None]
+            ref.append(Fn.normalize(y, p=2.0, dim=1))
+    ref = torch.cat(ref)
+    err = (got - ref).abs()
+    worst = err.max().item()
+    cos = (got * ref).sum(1)
+    # With random weights the descriptors of different images are close (cosine > 0.999: He-initialised ReLU features are
+    # dominated by their mean), so the gate above says little about the image-DEPENDENT part.  Two checks that do:
+    # (i) the error against the distance of a descriptor from the mean descriptor, (ii) the neighbour ranking among the 96
+    # frames -- what the matcher consumes -- is the float64 model's wherever its similarities are 2e-5 apart.
+    centred = ref - ref.mean(0, keepdim=True)
+    rel = ((got - ref).norm(dim=1) / centred.norm(dim=1)).max().item()
+    g_ref = ref @ ref.T
+    g_got = got @ got.T
+    eye = torch.eye(ref.shape[0], device=ref.device, dtype=torch.bool)
+    g_ref.masked_fill_(eye, -2.0); g_got.masked_fill_(eye, -2.0)
+    top_ref = torch.topk(g_ref, 4, dim=1)
+    top_got = torch.topk(g_got, 4, dim=1)
+    clear = (top_ref.values[:, :3] - top_ref.values[:, 1:4]) > 2e-5          # rank r is separated from rank r + 1
+    same = top_ref.indices[:, :3] == top_got.indices[:, :3]
+    prefix_clear = torch.cumprod(clear.to(torch.int32), dim=1).bool()
+    print("descriptor error vs float64: max %.2e, max 1-cos %.1e; pair cosines %.6f .. %.6f, "
+          "error / distance from the mean descriptor %.2e; %d of %d top-3 ranks clearly separated, all equal: %s" % (
+              worst, float((1.0 - cos).max()), g_ref[~eye].min().item(), g_ref.max().item(), rel, int(prefix_clear.sum()),
+              prefix_clear.numel(), bool(same[prefix_clear].all())), flush=True)
+    # the same extractor through torch's own fp32 convolutions (MIOpen), the yardstick for "fp32-grade"
+    nd = NetVLAD({"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376, "frontend.netvlad.pca_dim": 4096,
+                  "frontend.random_seed": 3, "frontend.backbone_conv": "direct"}, None)
+    e_direct = (nd.compute_embeddings_device(frames).double() - ref).abs().max().item()
+    print("   torch fp32 (direct convolutions) against the same float64 model: max %.2e" % e_direct, flush=True)
+    assert worst <= 1e-5, worst
+    assert worst <= 1.5 * e_direct + 1e-6, (worst, e_direct)
+    assert float((1.0 - cos).max()) <= 2e-7
+    assert rel <= 2e-2, rel
+    assert int(prefix_clear.sum()) >= 150 and bool(same[prefix_clear].all())
+    assert float((g_got - g_ref)[~eye].abs().max()) <= 1e-6                  # similarities themselves: well inside the 1e-5 gate
