@@ -315,3 +315,50 @@ class LoopClosureSparseMatching(object):
             desc = desc.astype(np.float64)
         matches = self.process_remote_descriptors(chunk.robot_id, desc, np.asarray(chunk.keyframe_ids)[rows])
         return matches, last
+
+    def process_remote_chunks(self, messages):
+        """A drained subscription queue: several received GlobalDescriptors messages at once, [(chunk, last keyframe
+        received from that robot), ...] -> [(matches, updated last-received id), ...] in message order.  Same result as
+        `process_remote_chunk` message by message (gdlcd.py:407-422 each): every sender's rows go to that sender's bank,
+        but the matching against the LOCAL bank -- the same bank for all of them, and untouched by those adds -- is ONE search
+        over the concatenated rows instead of one launch + one read-back per message."""
+        if not hasattr(self.local_nnsm, "search_device"):
+            return [self.process_remote_chunk(c, l) for c, l in messages]
+        import torch
+        from cslam_amd.wire import unknown_rows
+        devname = "cuda:%d" % self.local_nnsm.device
+        staged, out = [], []
+        for chunk, last_received in messages:
+            rows, last = unknown_rows(chunk, last_received)
+            out.append(([], last))
+            if len(rows) == 0:
+                continue
+            dev = torch.from_numpy(np.ascontiguousarray(chunk.descriptors[rows])).to(devname).double()
+            ids = np.asarray(chunk.keyframe_ids)[rows].astype(np.int64)
+            self._add(self.other_robots_nnsm[chunk.robot_id], None, dev, [int(i) for i in ids])
+            staged.append((len(out) - 1, int(chunk.robot_id), ids, dev))
+        if not staged or self.local_nnsm.n == 0:
+            return out
+        rows, sims, cnt = self._search(self.local_nnsm, None, torch.cat([d for _, _, _, d in staged]) if len(staged) > 1 else staged[0][3], 1)
+        me = self.params['robot_id']
+        thr = self.params['frontend.similarity_threshold']
+        item_arr = self.local_nnsm.item_array() if hasattr(self.local_nnsm, "item_array") else None
+        items = self.local_nnsm.items if item_arr is None else None
+        at = 0
+        for slot, robot_id, ids, dev in staged:
+            m = len(ids)
+            r, sv, c = rows[at:at + m, 0], sims[at:at + m, 0], cnt[at:at + m]
+            at += m
+            with np.errstate(invalid="ignore"):
+                jj = np.nonzero((c > 0) & (sv >= thr))[0]
+            if item_arr is not None:
+                matches = self.candidate_selector.add_matches_arrays(me, item_arr[r[jj]], np.full(len(jj), robot_id, dtype=np.int64),
+                                                                     ids[jj], sv[jj])
+            else:
+                matches = []
+                for j in jj.tolist():
+                    match = EdgeInterRobot(me, items[r[j]], robot_id, int(ids[j]), sv[j])
+                    self.candidate_selector.add_match(match)
+                    matches.append(match)
+            out[slot] = (matches, out[slot][1])
+        return out

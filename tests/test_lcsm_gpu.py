@@ -184,3 +184,57 @@ def test_packed_wire_path_equals_per_message_callbacks():
     assert last == T - 1 and a.other_robots_nnsm[1].n == T and b.other_robots_nnsm[1].n == T
     assert [tuple(m) for m in seq] == [tuple(m) for m in bat] and len(seq) > 0
     assert np.array_equal(a.other_robots_nnsm[1].data, b.other_robots_nnsm[1].data)
+
+
+def test_drained_queue_of_remote_messages_equals_one_message_at_a_time():
+    """`process_remote_chunks` (several robots' messages in one call: one search of the local bank) against
+    `process_remote_chunk` message by message: same matches, same last-received ids, same banks, same candidate
+    edges -- with re-sent rows and messages that arrive before the local bank has a row."""
+    from cslam_amd.loop_closure_sparse_matching import LoopClosureSparseMatching
+    from cslam_amd.wire import DescriptorChunk, PackedDescriptorBuffer
+    g = np.load(GOLDEN + "/seq_g2.npz")
+    desc = g["thr0.1/desc"]
+    R, T, D = desc.shape
+    assert R >= 3 and T > 50
+    a = LoopClosureSparseMatching(make_params(0, R, 0.1))
+    b = LoopClosureSparseMatching(make_params(0, R, 0.1))
+    bufs = {o: PackedDescriptorBuffer(robot_id=o) for o in range(1, R)}
+    last_a = {o: -1 for o in bufs}
+    last_b = dict(last_a)
+    seq, bat = [], []
+    lsent = rsent = 0
+    for lupto, rupto in ((0, 5), (20, 25), (45, 50), (T, T)):   # first round: messages before the local bank has a row
+        if lupto > lsent:
+            for x in (a, b):
+                x.process_local_keyframes(desc[0, lsent:lupto], list(range(lsent, lupto)), intra=False)
+        msgs = []
+        for o, buf in bufs.items():
+            for t in range(rsent, rupto):
+                buf.append(t, desc[o, t])
+            for ch in buf.chunks(max(0, rsent - 7 * o), 16):     # robot o re-sends its last 7 o rows
+                msgs.append(DescriptorChunk.from_bytes(ch.to_bytes()))
+        lsent, rsent = lupto, rupto
+        for wire in msgs:
+            m, last_a[wire.robot_id] = a.process_remote_chunk(wire, last_a[wire.robot_id])
+            seq += [tuple(e) for e in m]
+        # the batched API takes the last-received id per message, so a node draining its queue hands over one message per
+        # robot per call (a robot's second message must see the id its first one left)
+        pending = list(msgs)
+        while pending:
+            call, rest, seen = [], [], set()
+            for wire in pending:
+                (rest if wire.robot_id in seen else call).append(wire)
+                seen.add(wire.robot_id)
+            res = b.process_remote_chunks([(w, last_b[w.robot_id]) for w in call])
+            for w, (m, new_last) in zip(call, res):
+                last_b[w.robot_id] = new_last
+                bat += [tuple(e) for e in m]
+            pending = rest
+    assert last_a == last_b and all(v == T - 1 for v in last_a.values())
+    for o in bufs:
+        assert a.other_robots_nnsm[o].n == b.other_robots_nnsm[o].n == T
+        assert np.array_equal(a.other_robots_nnsm[o].data, b.other_robots_nnsm[o].data)
+    assert len(seq) > 0 and sorted(seq) == sorted(bat)          # the calls reorder messages of different robots only
+    ea = sorted(tuple(e) for e in a.candidate_selector.candidate_edges.values())
+    eb = sorted(tuple(e) for e in b.candidate_selector.candidate_edges.values())
+    assert ea == eb and len(ea) > 0

@@ -5,7 +5,7 @@ the reference's causal order through the batched LoopClosureSparseMatching calls
 between the robots, and the budgeted candidate selection (algebraic connectivity maximisation) on the broker.
 In the 8-GPU configuration every robot owns a GPU; here the eight robots take turns on one.
 
-    python tools/perf_c5.py [keyframes_per_robot=12500] [robots=8] [budget=1000] [chunk=250]
+    python tools/perf_c5.py [keyframes_per_robot=12500] [robots=8] [budget=1000] [chunk=250] [drain]
 """
 import os
 import sys
@@ -21,6 +21,7 @@ def main():
     R = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     K = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
     CH = int(sys.argv[4]) if len(sys.argv) > 4 else 250
+    DRAIN = len(sys.argv) > 5 and sys.argv[5] == "drain"     # receivers take a step's remote messages in one call
     import torch
     from cslam_amd.loop_closure_sparse_matching import LoopClosureSparseMatching
     from cslam_amd.vpr.netvlad import NetVLAD
@@ -90,13 +91,24 @@ def main():
             n_inter += len(inter)
             t2 = time.perf_counter()
             bufs[r].extend(ids, desc)
-            for chunk in bufs[r].chunks(s, 10 ** 9):              # one packed message per chunk of new keyframes
-                for o in range(R):
-                    if o != r:
-                        n_inter += len(lc[o].process_remote_chunk(chunk, s - 1)[0])
-            bufs[r].delete_below(s + m)
+            if not DRAIN:
+                for chunk in bufs[r].chunks(s, 10 ** 9):          # one packed message per chunk of new keyframes
+                    for o in range(R):
+                        if o != r:
+                            n_inter += len(lc[o].process_remote_chunk(chunk, s - 1)[0])
+                bufs[r].delete_below(s + m)
             t3 = time.perf_counter()
             t_ext += t1 - t0; t_loc += t2 - t1; t_rem += t3 - t2
+        if DRAIN:
+            # every receiver drains its queue once per step: the step's messages of its 7 peers in one call (one search)
+            t2 = time.perf_counter()
+            msgs = {r: bufs[r].chunks(s, 10 ** 9) for r in range(R)}
+            for o in range(R):
+                queue = [(c, s - 1) for r in range(R) if r != o for c in msgs[r]]
+                n_inter += sum(len(mm) for mm, _ in lc[o].process_remote_chunks(queue))
+            for r in range(R):
+                bufs[r].delete_below(s + m)
+            t_rem += time.perf_counter() - t2
     t_front = time.perf_counter() - t_start
     sel = lc[0].candidate_selector
     n_cand = len(sel.candidate_edges)
