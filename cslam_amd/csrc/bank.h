@@ -21,6 +21,8 @@ struct cslam_bank {
     hipStream_t last_stream;
     hipEvent_t ev0, ev1;
     bool ev_valid;
+    hipStream_t side;         // cslam_bank_search_multi_dev: the searches of a bank list run side by side, one stream per bank
+    hipEvent_t ev_fork, ev_side;
     int64_t stats[4];
     int num_cu;
     std::vector<int> item_map_host;   // cached work-item order of the MFMA path (see sim_topk_mfma.hip)

@@ -89,6 +89,7 @@ CSLAM_API int cslam_bank_create(int device, int dim, int64_t capacity_hint, csla
     b->rows = nullptr; b->vv = nullptr; b->invn = nullptr;
     for (int s = 0; s < 3; ++s) { b->ws[s] = nullptr; b->ws_bytes[s] = 0; }
     b->stage = nullptr; b->stage_bytes = 0; b->last_stream = nullptr; b->ev_valid = false;
+    b->side = nullptr; b->ev_fork = nullptr; b->ev_side = nullptr;
     b->h_nflag = nullptr; b->pending_flag_list = nullptr; b->pending_dbg = 0;
     for (int s = 0; s < 4; ++s) { b->stats[s] = 0; b->item_map_key[s] = -1; }
     b->num_cu = 0;
@@ -118,6 +119,7 @@ CSLAM_API int cslam_bank_destroy(cslam_bank_t *b) {
     if (b->stage) (void)hipFree(b->stage);
     if (b->h_nflag) (void)hipHostFree(b->h_nflag);
     if (b->ev_valid) { (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1); }
+    if (b->side) { (void)hipStreamDestroy(b->side); (void)hipEventDestroy(b->ev_fork); (void)hipEventDestroy(b->ev_side); }
     delete b;
     return CSLAM_OK;
 }
@@ -715,9 +717,27 @@ CSLAM_API int cslam_bank_search_multi_dev(cslam_bank_t *const *banks, int nb, co
     BANK_DEVICE(banks[0]);
     hipStream_t st = (hipStream_t)stream;
     bool deferred[64];
+    // The searches of the list are independent and, on chunk-sized query batches against banks of a few thousand rows, far
+    // too small to fill the chip one after the other (250 queries x 12 500 rows = 49 workgroups): each bank enqueues on a
+    // stream of its own, forked from and joined back into the caller's stream.  CSLAM_MULTI_STREAMS=0: one after the other.
+    static const bool side_by_side = [] { const char *e = getenv("CSLAM_MULTI_STREAMS"); return !(e && e[0] == '0'); }();
+    const bool fork = side_by_side && nb > 1;
+    if (fork) {
+        for (int i = 0; i < nb; ++i) {
+            cslam_bank *b = banks[i];
+            if (!b->side) {
+                HIP_TRY(hipStreamCreateWithFlags(&b->side, hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&b->ev_side, hipEventDisableTiming));
+            }
+        }
+        HIP_TRY(hipEventRecord(banks[0]->ev_fork, st));
+    }
     for (int i = 0; i < nb; ++i) {
         cslam_bank *b = banks[i];
         const int64_t *lim = d_row_limit ? d_row_limit[i] : nullptr;
+        hipStream_t st_call = st;
+        if (fork) { HIP_TRY(hipStreamWaitEvent(b->side, banks[0]->ev_fork, 0)); st_call = b->side; }
         b->last_stream = st;
         b->stats[0] = 0; b->stats[2] = 0; b->stats[3] = 0;
         int use = mode;
@@ -725,8 +745,12 @@ CSLAM_API int cslam_bank_search_multi_dev(cslam_bank_t *const *banks, int nb, co
         if (use == CSLAM_MODE_MFMA && (k[i] > 16 || b->n < 1)) use = CSLAM_MODE_SCAN;
         b->stats[1] = use;
         deferred[i] = use == CSLAM_MODE_MFMA;
-        int rc = deferred[i] ? mfma_search_enqueue(b, d_queries, q_dtype, ldq, nq, k[i], lim, d_out_idx[i], d_out_sim[i], d_out_cnt[i], st)
-                             : scan_search(b, d_queries, q_dtype, ldq, nullptr, nq, k[i], lim, d_out_idx[i], d_out_sim[i], d_out_cnt[i], st);
+        int rc = deferred[i] ? mfma_search_enqueue(b, d_queries, q_dtype, ldq, nq, k[i], lim, d_out_idx[i], d_out_sim[i], d_out_cnt[i], st_call)
+                             : scan_search(b, d_queries, q_dtype, ldq, nullptr, nq, k[i], lim, d_out_idx[i], d_out_sim[i], d_out_cnt[i], st_call);
+        if (fork) {                                                 // joined even when the enqueue failed: the caller's stream stays ordered
+            (void)hipEventRecord(b->ev_side, b->side);
+            (void)hipStreamWaitEvent(st, b->ev_side, 0);
+        }
         if (rc) return rc;
     }
     bool any = false;

@@ -234,7 +234,13 @@ def test_drained_queue_of_remote_messages_equals_one_message_at_a_time():
     for o in bufs:
         assert a.other_robots_nnsm[o].n == b.other_robots_nnsm[o].n == T
         assert np.array_equal(a.other_robots_nnsm[o].data, b.other_robots_nnsm[o].data)
-    assert len(seq) > 0 and sorted(seq) == sorted(bat)          # the calls reorder messages of different robots only
-    ea = sorted(tuple(e) for e in a.candidate_selector.candidate_edges.values())
-    eb = sorted(tuple(e) for e in b.candidate_selector.candidate_edges.values())
-    assert ea == eb and len(ea) > 0
+    # same matches (the calls reorder messages of different robots only).  The similarity of a pair may differ in its last
+    # bits: a message with <= 8 new rows takes the exact scan, the same rows inside a larger batch the MFMA search whose
+    # float64 rescoring sums in another order
+    def same(x, y):
+        x, y = sorted(x), sorted(y)
+        return len(x) == len(y) and all(p[:4] == q[:4] and abs(p[4] - q[4]) <= 1e-12 for p, q in zip(x, y))
+    assert len(seq) > 0 and same(seq, bat)
+    ea = [tuple(e) for e in a.candidate_selector.candidate_edges.values()]
+    eb = [tuple(e) for e in b.candidate_selector.candidate_edges.values()]
+    assert len(ea) > 0 and same(ea, eb)
