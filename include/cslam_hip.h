@@ -97,7 +97,9 @@ int cslam_bank_search_dev(cslam_bank_t *bank, const void *d_queries, int q_dtype
  * (cslam/loop_closure_sparse_matching.py:21-31), which the reference searches one after the other for every keyframe
  * (lcsm.py:45-53 best-1 per other robot, lcsm.py:74-76 top-k in the local bank).  Same results as nb calls of
  * cslam_bank_search_dev with (k[i], d_row_limit[i], d_out_*[i]); all kernels are enqueued before the single host
- * synchronisation the uncertified-query counts need.  d_row_limit may be NULL (no limits) or hold NULL entries. */
+ * synchronisation the uncertified-query counts need, each bank's on a stream of its own forked from and joined back into
+ * `stream` (chunk-sized searches do not fill the chip one after the other; CSLAM_MULTI_STREAMS=0 keeps them on `stream`).
+ * d_row_limit may be NULL (no limits) or hold NULL entries. */
 int cslam_bank_search_multi_dev(cslam_bank_t *const *banks, int nb, const void *d_queries, int q_dtype, int64_t ldq,
                                 int64_t nq, const int *k, const int64_t *const *d_row_limit, int mode,
                                 int64_t *const *d_out_idx, double *const *d_out_sim, int32_t *const *d_out_cnt,
