@@ -564,7 +564,12 @@ CSLAM_API int cslam_block4_residual_sync(const double *d_W, const double *d_X, i
 // update of the rows below (forward) / the columns before (backward).  Both are matrix x [bs][4] products that read the factor
 // exactly once at HBM speed; the library's thin-right-hand-side GEMMs took 8 ms per solve on 32k junctions (2 x 4.3 GB = 1.4 ms
 // of traffic).  No atomics: a fixed summation order per output element (deterministic iterates).
-#define CS4_THREADS 256
+#ifndef CS4_THREADS
+#define CS4_THREADS 512                 // 2 workgroups x 8 waves per compute unit next to 64 KB of staged x each: 2.48 -> 2.24 ms at 32k junctions
+#endif
+#ifndef CS4_RPW
+#define CS4_RPW 4
+#endif
 #ifndef CS4_ROWS_UNROLL
 #define CS4_ROWS_UNROLL 4
 #endif
@@ -727,7 +732,7 @@ CSLAM_API int cslam_chol_solve4_dev(const double *d_L, int64_t m, int64_t ld, in
     if (!attr) {
         HIP_TRY(hipFuncSetAttribute((const void *)cs4_tri_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
         HIP_TRY(hipFuncSetAttribute((const void *)cs4_tri_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
-        HIP_TRY(hipFuncSetAttribute((const void *)cs4_rows_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
+        HIP_TRY(hipFuncSetAttribute((const void *)cs4_rows_kernel<true, CS4_RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
         HIP_TRY(hipFuncSetAttribute((const void *)cs4_cols_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
         attr = true;
     }
@@ -746,7 +751,7 @@ CSLAM_API int cslam_chol_solve4_dev(const double *d_L, int64_t m, int64_t ld, in
         if (e >= m)
             HIP_TRY(hipMemcpyAsync(d_x + k * 4, d_tmp, (size_t)bw * 32, hipMemcpyDeviceToDevice, st));
         else if (!col_major)
-            hipLaunchKernelGGL((cs4_rows_kernel<true, 4>), dim3(row_grid(m - e, 4)), dim3(CS4_THREADS), lds_rows, st,
+            hipLaunchKernelGGL((cs4_rows_kernel<true, CS4_RPW>), dim3(row_grid(m - e, CS4_RPW)), dim3(CS4_THREADS), lds_rows, st,
                                d_L + e * ld + k, ld, m - e, bw, d_tmp, d_x + e * 4, d_x + k * 4);
         else
             hipLaunchKernelGGL(cs4_cols_kernel<true>, dim3((unsigned)ceil_div64(m - e, 64)), dim3(CS4_CT), lds_cols, st,
@@ -764,7 +769,7 @@ CSLAM_API int cslam_chol_solve4_dev(const double *d_L, int64_t m, int64_t ld, in
             hipLaunchKernelGGL(cs4_cols_kernel<true>, dim3((unsigned)ceil_div64(k, 64)), dim3(CS4_CT), lds_cols, st,
                                d_L + k * ld, ld, bw, k, d_tmp, d_x, d_x + k * 4);
         else
-            hipLaunchKernelGGL((cs4_rows_kernel<true, 4>), dim3(row_grid(k, 4)), dim3(CS4_THREADS), lds_rows, st,
+            hipLaunchKernelGGL((cs4_rows_kernel<true, CS4_RPW>), dim3(row_grid(k, CS4_RPW)), dim3(CS4_THREADS), lds_rows, st,
                                d_L + k, ld, k, bw, d_tmp, d_x, d_x + k * 4);
     }
     HIP_TRY(hipGetLastError());

@@ -10,8 +10,8 @@ for m in (8192, 32768):
     L_row = blocked_cholesky_(A.clone())
     L_col = torch.linalg.cholesky(A)
     ref = torch.cholesky_solve(rhs, L_col)
-    for name, L in (("row-major", L_row), ("column-major", L_col)):
-        s = BlockedCholeskySolve(L)
+    for name, L, bs in (("row-major", L_row, 2048), ("column-major", L_col, 2048), ("row-major bs=1024", L_row, 1024), ("row-major bs=512", L_row, 512)):
+        s = BlockedCholeskySolve(L, bs)
         x = s.solve(rhs); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(20): x = s.solve(rhs)
