@@ -64,6 +64,7 @@ _SIGNATURES = {
     "cslam_fiedler": (_i, [_i64, _vp, _vp, _vp, _vp, C.c_uint32, C.c_double, _i, _vp, _vp, _vp, _vp]),
     "cslam_fiedler_start_block": (_i, [C.c_uint32, _i64, _vp]),
     "cslam_fiedler_release": (_i, []),
+    "cslam_mac_fw_subset": (_i, [_i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     "cslam_scbank_create": (_i, [_i, _i, _i, _i64, _vp]),
     "cslam_scbank_destroy": (_i, [_vp]),
     "cslam_scbank_size": (_i, [_vp, _vp, _vp, _vp]),

@@ -11,6 +11,7 @@
 // larger junction system each time; a fresh 8 GB hipMalloc/hipFree per call cost ~0.1 s); cslam_fiedler_release frees it.
 #include <dlfcn.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <chrono>
 #include <mutex>
 #include <vector>
@@ -582,5 +583,128 @@ CSLAM_API int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h
     *h_lambda2 = sigma[0];
     if (h_iters) *h_iters = iters;
     if (laps.on) { laps.lap("tracemin", st); fprintf(stderr, " (nJ=%d, %d iterations)\n", nJ, iters); }
+    return CSLAM_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// cslam_mac_fw_subset: the Frank-Wolfe loop of the sparsifier (cslam/mac/mac.py:191-233 `MAC.fw_subset`, with
+// :61-77 combined Laplacian, :112-130 gradient, :132-147 / :168-189 roundings) around cslam_fiedler, for a host without
+// Python: fixed edges + weighted candidate edges in, the rounded selection out.
+namespace {
+struct Csr {
+    int64_t n = 0;
+    std::vector<int64_t> indptr;
+    std::vector<int32_t> indices;
+    std::vector<double> data;
+};
+// weighted graph Laplacian of an edge list (mac/utils.py:47-126): per edge the triplets (i,i,w) (j,j,w) (i,j,-w) (j,i,-w),
+// duplicates summed in edge order, columns sorted within a row
+void laplacian_csr(int64_t n, int64_t m, const int64_t *ei, const int64_t *ej, const double *ew, const uint8_t *use, Csr &L) {
+    L.n = n;
+    std::vector<int64_t> cnt(n + 1, 0);
+    for (int64_t e = 0; e < m; ++e) if (!use || use[e]) { cnt[ei[e] + 1] += 2; cnt[ej[e] + 1] += 2; }
+    for (int64_t r = 0; r < n; ++r) cnt[r + 1] += cnt[r];
+    const int64_t raw = cnt[n];
+    std::vector<int32_t> col(raw); std::vector<double> val(raw);
+    std::vector<int64_t> pos(cnt.begin(), cnt.end() - 1);
+    for (int64_t e = 0; e < m; ++e) {
+        if (use && !use[e]) continue;
+        const int64_t i = ei[e], j = ej[e]; const double w = ew[e];
+        col[pos[i]] = (int32_t)i; val[pos[i]++] = w;
+        col[pos[j]] = (int32_t)j; val[pos[j]++] = w;
+        col[pos[i]] = (int32_t)j; val[pos[i]++] = -w;
+        col[pos[j]] = (int32_t)i; val[pos[j]++] = -w;
+    }
+    L.indptr.assign(n + 1, 0); L.indices.clear(); L.data.clear();
+    L.indices.reserve(raw / 2 + n); L.data.reserve(raw / 2 + n);
+    for (int64_t r = 0; r < n; ++r) {
+        const int64_t a = cnt[r], b = cnt[r + 1];
+        for (int64_t p = a + 1; p < b; ++p) {                                    // stable insertion sort by column (rows are short)
+            const int32_t c = col[p]; const double v = val[p];
+            int64_t q = p;
+            while (q > a && col[q - 1] > c) { col[q] = col[q - 1]; val[q] = val[q - 1]; --q; }
+            col[q] = c; val[q] = v;
+        }
+        for (int64_t p = a; p < b;) {
+            int64_t q = p; double s = 0.0;
+            while (q < b && col[q] == col[p]) s += val[q++];
+            L.indices.push_back(col[p]); L.data.push_back(s);
+            p = q;
+        }
+        L.indptr[r + 1] = (int64_t)L.indices.size();
+    }
+}
+void csr_add(const Csr &A, const Csr &B, Csr &C) {                                // C = A + B, rows merged by column
+    const int64_t n = A.n;
+    C.n = n; C.indptr.assign(n + 1, 0); C.indices.clear(); C.data.clear();
+    C.indices.reserve(A.indices.size() + B.indices.size()); C.data.reserve(A.indices.size() + B.indices.size());
+    for (int64_t r = 0; r < n; ++r) {
+        int64_t p = A.indptr[r], pe = A.indptr[r + 1], q = B.indptr[r], qe = B.indptr[r + 1];
+        while (p < pe || q < qe) {
+            if (q >= qe || (p < pe && A.indices[p] < B.indices[q])) { C.indices.push_back(A.indices[p]); C.data.push_back(A.data[p]); ++p; }
+            else if (p >= pe || B.indices[q] < A.indices[p]) { C.indices.push_back(B.indices[q]); C.data.push_back(B.data[q]); ++q; }
+            else { C.indices.push_back(A.indices[p]); C.data.push_back(A.data[p] + B.data[q]); ++p; ++q; }
+        }
+        C.indptr[r + 1] = (int64_t)C.indices.size();
+    }
+}
+// indicator of the k largest keys (ties: the larger index wins; numpy's argpartition leaves them arbitrary)
+template <class Less>
+void top_k_indicator(int64_t m, int64_t k, Less less, double *out) {
+    std::vector<int64_t> idx(m);
+    for (int64_t i = 0; i < m; ++i) { idx[i] = i; out[i] = 0.0; }
+    if (k <= 0) return;
+    if (k < m) std::nth_element(idx.begin(), idx.begin() + (m - k), idx.end(), less);
+    for (int64_t t = (k < m ? m - k : 0); t < m; ++t) out[idx[t]] = 1.0;
+}
+}  // namespace
+
+CSLAM_API int cslam_mac_fw_subset(int64_t num_poses, int64_t n_fixed, const int64_t *fixed_i, const int64_t *fixed_j,
+                                  const double *fixed_w, int64_t n_cand, const int64_t *cand_i, const int64_t *cand_j,
+                                  const double *cand_w, const double *w_init, int64_t k, int max_iters, double duality_gap_tol,
+                                  double fiedler_tol, double *h_selected, double *h_w_unrounded, double *h_upper, int *h_iters,
+                                  void *stream) {
+    ARG_CHECK(num_poses > 4 && n_fixed >= 0 && n_cand >= 0 && k >= 0 && k <= n_cand, "bad sizes");
+    ARG_CHECK((n_fixed == 0 || (fixed_i && fixed_j && fixed_w)) && (n_cand == 0 || (cand_i && cand_j && cand_w && w_init)) && h_selected,
+              "NULL argument");
+    for (int64_t e = 0; e < n_fixed; ++e) ARG_CHECK(fixed_i[e] >= 0 && fixed_i[e] < num_poses && fixed_j[e] >= 0 && fixed_j[e] < num_poses, "fixed edge out of range");
+    for (int64_t e = 0; e < n_cand; ++e) ARG_CHECK(cand_i[e] >= 0 && cand_i[e] < num_poses && cand_j[e] >= 0 && cand_j[e] < num_poses, "candidate edge out of range");
+    Csr Lfix, Lc, L;
+    laplacian_csr(num_poses, n_fixed, fixed_i, fixed_j, fixed_w, nullptr, Lfix);
+    std::vector<double> w(w_init, w_init + n_cand), grad(n_cand), s(n_cand), prod(n_cand), v(num_poses);
+    std::vector<uint8_t> use(n_cand);
+    double u = INFINITY, f = 0.0;
+    int it = 0;
+    for (; it < max_iters; ++it) {
+        for (int64_t e = 0; e < n_cand; ++e) { use[e] = w[e] > 1e-10; prod[e] = w[e] * cand_w[e]; }      // mac.py:61-77
+        laplacian_csr(num_poses, n_cand, cand_i, cand_j, prod.data(), use.data(), Lc);
+        csr_add(Lfix, Lc, L);
+        int fi = 0;
+        const int rc = cslam_fiedler(num_poses, L.indptr.data(), L.indices.data(), L.data.data(), nullptr, 7u, fiedler_tol, 0, &f, v.data(),
+                                     &fi, stream);
+        if (rc) return rc;
+        for (int64_t e = 0; e < n_cand; ++e) {                                                          // mac.py:112-130
+            const double d = v[cand_i[e]] - v[cand_j[e]];
+            grad[e] = (cand_w[e] * d) * d;
+        }
+        top_k_indicator(n_cand, k, [&](int64_t a, int64_t b) { return grad[a] < grad[b] || (grad[a] == grad[b] && a < b); }, s.data());
+        double dot = 0.0;
+        for (int64_t e = 0; e < n_cand; ++e) dot += grad[e] * (s[e] - w[e]);
+        if (f + dot < u) u = f + dot;
+        if (u - f < duality_gap_tol) break;
+        const double alpha = 2.0 / (it + 2.0);
+        for (int64_t e = 0; e < n_cand; ++e) w[e] = w[e] + alpha * (s[e] - w[e]);
+    }
+    // rounding with the weight tie-break (mac.py:168-189): top k of (w rounded to 10 decimals, edge weight)
+    std::vector<double> wr(n_cand);
+    for (int64_t e = 0; e < n_cand; ++e) wr[e] = nearbyint(w[e] * 1e10) / 1e10;
+    top_k_indicator(n_cand, k, [&](int64_t a, int64_t b) {
+        if (wr[a] != wr[b]) return wr[a] < wr[b];
+        if (cand_w[a] != cand_w[b]) return cand_w[a] < cand_w[b];
+        return a < b;
+    }, h_selected);
+    if (h_w_unrounded) for (int64_t e = 0; e < n_cand; ++e) h_w_unrounded[e] = w[e];
+    if (h_upper) *h_upper = u;
+    if (h_iters) *h_iters = it < max_iters ? it + 1 : max_iters;
     return CSLAM_OK;
 }

@@ -6,6 +6,7 @@ top-k of the gradient, step 2/(it+2), dual bound / gap test, final rounding with
 tie-break.  The per-edge Python loops of the reference (mac.py:123-129, 178-180) are
 vectorised with the same operation order, so results are bit-identical.
 """
+import os
 from collections import namedtuple
 
 import numpy as np
@@ -25,6 +26,7 @@ class MAC:
         # 'chain_gpu'    chain-reduced inner solves and every O(n) step in HIP (large graphs)
         # 'chain_hip'    the same computation behind the C ABI's one-call `cslam_fiedler` (native host code, no torch ops)
         self.fiedler_solver = fiedler_solver
+        self._fixed = fixed_measurements          # kept for the native Frank-Wolfe loop (fw_subset, 'chain_hip')
         self.L_odom = weight_graph_lap_from_edge_list(fixed_measurements, num_poses)
         self.num_poses = num_poses
         self.weights = np.array([m.weight for m in candidate_measurements])
@@ -113,9 +115,36 @@ class MAC:
             rounded[idx] = 1.0
         return rounded
 
+    def _fw_subset_hip(self, w_init, k, max_iters, duality_gap_tol):
+        """The same loop behind the C ABI (`cslam_mac_fw_subset`, csrc/fiedler.hip): Laplacian updates, Fiedler pairs, gradient,
+        top-k and rounding in native code -- what a host without Python calls."""
+        import ctypes as C
+        from .. import _lib
+        from .utils import EdgeArrays
+        lib = _lib.load()
+        fx = EdgeArrays.from_edges(self._fixed)
+        fi, fj, fw = (np.ascontiguousarray(a) for a in (fx.i.astype(np.int64), fx.j.astype(np.int64), fx.weight.astype(np.float64)))
+        ci = np.ascontiguousarray(self.edge_list[:, 0], dtype=np.int64)
+        cj = np.ascontiguousarray(self.edge_list[:, 1], dtype=np.int64)
+        cw = np.ascontiguousarray(self.weights, dtype=np.float64)
+        w0 = np.ascontiguousarray(w_init, dtype=np.float64)
+        sel, wu, up = np.empty(len(cw)), np.empty(len(cw)), C.c_double(0.0)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        try:
+            import torch
+            st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        except ImportError:                                       # pragma: no cover
+            st = None
+        _lib.check(lib.cslam_mac_fw_subset(int(self.num_poses), len(fw), p(fi), p(fj), p(fw), len(cw), p(ci), p(cj), p(cw), p(w0),
+                                           int(k), int(max_iters), float(duality_gap_tol), 1e-8, p(sel), p(wu), C.byref(up), None, st))
+        return sel, wu, float(up.value)
+
     def fw_subset(self, w_init, k, max_iters=5, duality_gap_tol=1e-8, trace=None):
         """Frank-Wolfe on the relaxed subset selection (reference mac.py:191-233).
         Returns (rounded solution, unrounded iterate, dual upper bound)."""
+        if self.fiedler_solver == 'chain_hip' and trace is None and len(self.weights) > 0 and self.num_poses > 4 \
+                and os.environ.get('CSLAM_MAC_FW', 'hip') != 'python':
+            return self._fw_subset_hip(w_init, k, max_iters, duality_gap_tol)
         u_i = float("inf")
         w_i = w_init
         for it in range(max_iters):

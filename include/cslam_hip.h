@@ -254,6 +254,23 @@ int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h_indices, 
 int cslam_fiedler_start_block(uint32_t seed, int64_t n, double *h_x0);
 int cslam_fiedler_release(void);
 
+/* The sparsifier's Frank-Wolfe loop around cslam_fiedler, for a host without Python: replaces cslam/mac/mac.py:191-233
+ * (MAC.fw_subset) together with :61-77 (L(w) = L_fixed + sum_k w_k weight_k L_k over w_k > 1e-10), :112-130 (gradient
+ * weight_k (v_i - v_j)^2), :132-147 (linear maximisation = indicator of the k largest gradients) and :168-189 (final
+ * rounding: top k of w rounded to 10 decimals, ties towards the larger edge weight).  All arrays are HOST arrays:
+ *   fixed_* [n_fixed], cand_* [n_cand]  edges (i, j, weight) over poses 0 .. num_poses-1 (the re-keyed edges of
+ *                                       algebraic_connectivity_maximization.py:468-543; fixed includes the odometry chains)
+ *   w_init [n_cand]      start point (the greedy indicator of acm.py:380-395), k edges to choose, max_iters as mac.py (5 in cslam)
+ *   duality_gap_tol      1e-8 in the reference; fiedler_tol = the tol mac.py:33 passes on (1e-8)
+ *   h_selected [n_cand]  1.0 for the chosen edges, 0.0 otherwise; h_w_unrounded [n_cand], h_upper, h_iters optional (NULL)
+ * Exact ties in a top-k (left arbitrary by numpy's argpartition) go to the larger index.  A failing Fiedler solve (e.g. the
+ * fixed edges do not connect the graph) returns that call's error; the reference's retry policy (acm.py:436-466) is the caller's. */
+int cslam_mac_fw_subset(int64_t num_poses, int64_t n_fixed, const int64_t *fixed_i, const int64_t *fixed_j,
+                        const double *fixed_w, int64_t n_cand, const int64_t *cand_i, const int64_t *cand_j,
+                        const double *cand_w, const double *w_init, int64_t k, int max_iters, double duality_gap_tol,
+                        double fiedler_tol, double *h_selected, double *h_w_unrounded, double *h_upper, int *h_iters,
+                        void *stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Lidar place recognition: ScanContext bank.
  * Replaces cslam/lidar_pr/scancontext_matching.py:5-104 (ScanContextMatching) with its helpers

@@ -74,6 +74,16 @@ int main(void) {
             printf("fiedler: lambda_2 %.12e, expected %.12e (|v|^2 %.12f, sum %.3e, %d iterations)\n", lam, want, nrm, sum, iters);
             return 1;
         }
+        /* the sparsifier's Frank-Wolfe loop (mac.py:191-233) on the same ring as fixed edges + 8 candidate chords: 3 chosen */
+        {
+            int64_t fi[RING], fj[RING], ci[8], cj[8]; double fw[RING], cw[8], w0[8], sel[8], up = 0.0; int its = 0, chosen = 0;
+            for (int i = 0; i < RING; ++i) { fi[i] = i; fj[i] = (i + 1) % RING; fw[i] = 1.0; }
+            for (int c = 0; c < 8; ++c) { ci[c] = 7 * c; cj[c] = (7 * c + 60 + 25 * c) % RING; cw[c] = 0.3 + 0.1 * c; w0[c] = c < 3 ? 1.0 : 0.0; }
+            rc = cslam_mac_fw_subset(RING, RING, fi, fj, fw, 8, ci, cj, cw, w0, 3, 5, 1e-8, 1e-8, sel, NULL, &up, &its, NULL);
+            if (rc != CSLAM_OK) { printf("fw_subset: %s\n", cslam_last_error()); return 1; }
+            for (int c = 0; c < 8; ++c) chosen += sel[c] == 1.0;
+            if (chosen != 3 || its < 1 || !(up > 0.0)) { printf("fw_subset: %d chosen, %d iterations, bound %g\n", chosen, its, up); return 1; }
+        }
         cslam_fiedler_release();
     }
     printf("C ABI smoke ok (version %d)\n", cslam_version());

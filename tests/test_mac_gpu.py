@@ -215,3 +215,33 @@ def test_selection_with_one_call_solver_equals_reference(tag, R, K):
     sel = ac.select_candidates(K, {r: True for r in range(R)}, greedy_initialization=True)
     got = np.array([tuple(e) for e in sel], dtype=np.float64).reshape(-1, 5)
     assert np.array_equal(got, g7[tag + "/selected"])
+
+
+@pytest.mark.parametrize("R,P,C_,K", [(3, 100, 100, 10), (4, 300, 500, 40), (8, 400, 600, 60)])
+def test_native_frank_wolfe_loop_equals_the_python_loop(R, P, C_, K, monkeypatch):
+    """`cslam_mac_fw_subset` (Laplacian updates, Fiedler pairs, gradient, top-k, rounding in native host code around
+    cslam_fiedler) against MAC.fw_subset's Python loop (mac.py:191-233 restated) on the same solver: same selection, same
+    unrounded iterate and dual bound to round-off."""
+    from cslam_amd.mac.mac import MAC
+    from cslam_amd.mac.utils import Edge
+    rng = np.random.default_rng(R * 1000 + C_)
+    n = R * P
+    fixed = [Edge(r * P + t, r * P + t + 1, 1.0) for r in range(R) for t in range(P - 1)]
+    fixed += [Edge(r * P + int(rng.integers(0, P)), (r + 1) * P + int(rng.integers(0, P)), float(rng.uniform(0.5, 1.0))) for r in range(R - 1)]
+    cand = []
+    while len(cand) < C_:
+        a, b = (int(x) for x in rng.integers(0, n, 2))
+        if a // P != b // P:
+            cand.append(Edge(min(a, b), max(a, b), float(rng.uniform(0.1, 1.0))))
+    mac = MAC(fixed, cand, n, fiedler_solver="chain_hip")
+    w0 = np.zeros(len(cand))
+    w0[np.argsort([-e.weight for e in cand])[:K]] = 1.0
+    sel_c, w_c, u_c = mac.fw_subset(w0, K, max_iters=5)
+    monkeypatch.setenv("CSLAM_MAC_FW", "python")
+    sel_p, w_p, u_p = mac.fw_subset(w0, K, max_iters=5)
+    assert sel_c.sum() == K and np.array_equal(sel_c, sel_p)
+    assert np.max(np.abs(w_c - w_p)) < 1e-9 and abs(u_c - u_p) < 1e-9 * max(1.0, abs(u_p))
+    # the duality-gap exit: a tolerance no iterate can miss stops after the first Fiedler pair, w untouched
+    monkeypatch.delenv("CSLAM_MAC_FW")
+    sel1, w1, _ = mac.fw_subset(w0, K, max_iters=5, duality_gap_tol=1e30)
+    assert np.array_equal(w1, w0) and sel1.sum() == K
