@@ -3,7 +3,9 @@
 // behind one C call.  Same TraceMIN-Fiedler iteration as cslam_amd/mac/fiedler.py (start block of numpy's
 // RandomState(seed).normal(size=(4, n)).T, projection on 1-perp, Rayleigh-Ritz, stopping rule ||L v - s v||_1 / ||L||_inf < tol),
 // with the inner solves by the chain reduction of cslam_amd/mac/chain_solver.py:
-//   host (this file)   chain / junction structure from the CSR arrays, O(nnz) loops; 4 x 4 algebra (Cholesky, inverse, Jacobi)
+//   host (this file)   chain / junction structure from the CSR arrays, O(nnz) loops; connectivity check on the reduced graph
+//   device (this file) the 4 x 4 algebra of the TraceMIN loop (Cholesky, inverse, Jacobi) as one-thread kernels between the
+//                      streaming passes: one host synchronisation per iteration (the stopping rule)
 //   mac_kernels.hip    segmented scans, back substitution, L X, 4-column block products, blocked triangular solves
 //   rocBLAS/rocSOLVER  dense float64 Cholesky of the grounded junction Laplacian (diagonal blocks: potrf, panel: trsm,
 //                      trailing matrix: gemm over the stored triangle only), resolved at run time like RCCL in comm.hip
@@ -16,6 +18,9 @@
 #include <mutex>
 #include <vector>
 #include "common.h"
+
+int block4_residual_devsigma(const double *d_W, const double *d_X, int64_t n, const double *d_y4, const double *d_sigma,
+                             double *d_partial, double *d_out1, hipStream_t st);   // mac_kernels.hip
 
 // ---------------------------------------------------------------------------------------------
 // numpy RandomState(seed).normal(): MT19937 (init_genrand seeding), 53-bit doubles, polar Box-Muller with the
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(256) void fj_column0_kernel(const double *__restric
 
 // ---------------------------------------------------------------------------------------------
 // 4 x 4 host algebra (row-major)
-bool chol4_upper(const double *G, double *R) {                 // G = R^T R, R upper
+__host__ __device__ bool chol4_upper(const double *G, double *R) {                 // G = R^T R, R upper
     double L[16] = {0};
     for (int i = 0; i < 4; ++i)
         for (int j = 0; j <= i; ++j) {
@@ -220,7 +225,7 @@ bool chol4_upper(const double *G, double *R) {                 // G = R^T R, R u
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) R[i * 4 + j] = L[j * 4 + i];
     return true;
 }
-bool inv4(const double *A, double *Ai) {                       // Gauss-Jordan, partial pivoting
+__host__ __device__ bool inv4(const double *A, double *Ai) {                       // Gauss-Jordan, partial pivoting
     double a[4][8];
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { a[i][j] = A[i * 4 + j]; a[i][4 + j] = i == j ? 1.0 : 0.0; }
     for (int c = 0; c < 4; ++c) {
@@ -235,7 +240,7 @@ bool inv4(const double *A, double *Ai) {                       // Gauss-Jordan, 
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) Ai[i * 4 + j] = a[i][4 + j];
     return true;
 }
-void eigh4(const double *H, double *w, double *V) {            // cyclic Jacobi; ascending eigenvalues, eigenvectors in the columns of V
+__host__ __device__ void eigh4(const double *H, double *w, double *V) {            // cyclic Jacobi; ascending eigenvalues, eigenvectors in the columns of V
     double a[4][4], v[4][4];
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { a[i][j] = 0.5 * (H[i * 4 + j] + H[j * 4 + i]); v[i][j] = i == j ? 1.0 : 0.0; }
     for (int sweep = 0; sweep < 64; ++sweep) {
@@ -256,6 +261,31 @@ void eigh4(const double *H, double *w, double *V) {            // cyclic Jacobi;
     int order[4] = {0, 1, 2, 3};
     for (int i = 0; i < 4; ++i) for (int j = i + 1; j < 4; ++j) if (a[order[j]][order[j]] < a[order[i]][order[i]]) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
     for (int j = 0; j < 4; ++j) { w[j] = a[order[j]][order[j]]; for (int i = 0; i < 4; ++i) V[i * 4 + j] = v[i][order[j]]; }
+}
+
+// The same algebra as one-thread kernels: the TraceMIN loop then needs ONE host synchronisation per iteration (the residual of
+// the stopping rule) instead of five -- every synchronisation is a bubble of ~50 us (read-back, host arithmetic, launch latency)
+// in an iteration of 0.75-3 ms.  small[]: M16 @0, shift4 @16, Y16 @20, sig4 @36, y0 @40, res @44, fail flag (as double) @45
+__global__ void fj_cholinv_kernel(const double *__restrict__ g20, double *__restrict__ small) {
+    double R[16];
+    if (!chol4_upper(g20, R) || !inv4(R, small)) small[45] = 1.0;
+}
+__global__ void fj_eigh_kernel(const double *__restrict__ g20, double *__restrict__ small) {
+    eigh4(g20, small + 36, small + 20);
+    for (int i = 0; i < 4; ++i) small[40 + i] = small[20 + i * 4];
+}
+__global__ void fj_proj_kernel(const double *__restrict__ g20, double n, double *__restrict__ small) {
+    if (!inv4(g20, small)) small[45] = 2.0;
+    for (int j = 0; j < 4; ++j) {
+        double s = 0.0;
+        for (int i = 0; i < 4; ++i) s += g20[16 + i] * small[i * 4 + j];
+        small[16 + j] = s / n;
+    }
+}
+__global__ void fj_mean_kernel(const double *__restrict__ g20, double n, double *__restrict__ small) {
+    for (int i = 0; i < 16; ++i) small[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    for (int j = 0; j < 4; ++j) small[16 + j] = g20[16 + j] / n;
+    small[45] = 0.0;
 }
 
 struct Laps {
@@ -355,6 +385,19 @@ CSLAM_API int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h
     std::vector<int32_t> ei(nE), ej(nE); std::vector<double> ew(nE), diag(m > 0 ? m : 1, 0.0);
     for (int s = 0; s < nseg; ++s) { ei[s] = jid[sa[s]]; ej[s] = jid[sb[s]]; ew[s] = 1.0 / Rl[s]; }
     for (size_t e = 0; e < li.size(); ++e) { ei[nseg + e] = jid[li[e]]; ej[nseg + e] = jid[lj[e]]; ew[nseg + e] = lw[e]; }
+    {   // networkx raises on a graph that is not connected (fiedler_vector), and the grounded junction Laplacian of one is
+        // singular only up to round-off: decided here, on the reduced graph (connected iff the pose graph is)
+        std::vector<int> parent(nJ);
+        for (int t = 0; t < nJ; ++t) parent[t] = t;
+        auto find = [&](int x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+        int comps = nJ;
+        for (int e = 0; e < nE; ++e) {
+            if (!(ew[e] > 0.0)) continue;
+            const int a = find(ei[e]), b = find(ej[e]);
+            if (a != b) { parent[a] = b; --comps; }
+        }
+        if (comps != 1) { cslam_set_error("graph is not connected (%d components): no Fiedler pair", comps); return CSLAM_E_INVALID; }
+    }
     for (int e = 0; e < nE; ++e) if (ei[e] != g) diag[ei[e] - (ei[e] > g)] += ew[e];      // fixed order: all first ends, then all second ends
     for (int e = 0; e < nE; ++e) if (ej[e] != g) diag[ej[e] - (ej[e] > g)] += ew[e];
     laps.lap("host structure", st);
@@ -369,7 +412,7 @@ CSLAM_API int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h
     need += padded((size_t)(n + 1) * 8) + padded((size_t)nnz * 4 + 4) + padded((size_t)nnz * 8 + 8);
     need += padded((size_t)nJ * 8) + 2 * padded((size_t)nJ * 4) + 3 * padded((size_t)(nseg + 1) * 8);
     need += 3 * padded((size_t)nJ * 32) + padded((size_t)(m + 1) * 8) + 2 * padded((size_t)(nE + 1) * 4) + padded((size_t)(nE + 1) * 8);
-    need += padded((size_t)(9 * nch + 64) * 8) + padded(20 * 1024 * 8) + padded(32 * 8) + padded((size_t)bs * 32) + padded((size_t)(nb + 1) * 4) + padded((size_t)n * 8);
+    need += padded((size_t)(9 * nch + 64) * 8) + padded(20 * 1024 * 8) + padded(32 * 8) + padded((size_t)bs * 32) + padded((size_t)(nb + 1) * 4) + padded((size_t)n * 8) + padded(64 * 8);
     if ((rc = g_ws.arena.ensure(need, 1.1))) return rc;
     if (m > 0) {
         if ((rc = g_ws.dense.ensure((size_t)m * m * 8, 1.3))) return rc;
@@ -388,6 +431,7 @@ CSLAM_API int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h
     double *d_diag = bump.take<double>(m + 1); int32_t *d_ei = bump.take<int32_t>(nE + 1), *d_ej = bump.take<int32_t>(nE + 1); double *d_ew = bump.take<double>(nE + 1);
     double *d_scratch = bump.take<double>(9 * nch + 64), *d_partial = bump.take<double>(20 * 1024), *d_out20 = bump.take<double>(32);
     double *d_cs_tmp = bump.take<double>((size_t)bs * 4); int *d_info = bump.take<int>(nb + 1); double *d_v = bump.take<double>(n);
+    double *d_small = bump.take<double>(64);
     if (bump.off > g_ws.arena.cap) { cslam_set_error("internal: workspace carving exceeds its size"); return CSLAM_E_INVALID; }
 #define UP(dst, vec, count) HIP_TRY(hipMemcpyAsync(dst, (vec), (size_t)(count) * sizeof(*(dst)), hipMemcpyHostToDevice, st))
     UP(d_r, r.data(), n - 1); UP(d_Rn, Rn.data(), n); UP(d_jid, jid.data(), n); UP(d_seg_of, seg_of.data(), n); UP(d_is_j, is_j.data(), n);
@@ -523,59 +567,56 @@ CSLAM_API int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h
     }
 
     // ---- TraceMIN (fiedler.py / chain_solver_gpu.py, same order of operations) ----
-    double h20[20], h1 = 0.0, sigma[4] = {0, 0, 0, 0}, Y[16];
+    // The 4 x 4 algebra (Cholesky + inverse of X^T X, Jacobi eigen-decomposition of X^T L X, inverse of X^T A^-1 X) runs in
+    // one-thread kernels between the streaming passes; the host synchronises once per iteration, for the stopping rule.
+    double h1 = 0.0, sigma[4] = {0, 0, 0, 0};
     double *pool[2] = {P0, P1};
     int npool = 2;
-    auto gram = [&](const double *Am, const double *Bm) { return cslam_block4_gram_sync(Am, Bm, n, d_partial, d_out20, h20, st); };
-    auto affine = [&](double *&Xc, const double *M, const double *shift) {           // Xc <- Xc M - shift through a free buffer
-        double *out = pool[--npool];
-        const int r2 = cslam_block4_affine_host(Xc, n, M, shift, out, st);
-        pool[npool++] = Xc; Xc = out;
-        return r2;
-    };
-    const double eye[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
-    if ((rc = gram(X, X))) return rc;
-    double shift[4];
-    for (int j = 0; j < 4; ++j) shift[j] = h20[16 + j] / (double)n;
-    if ((rc = affine(X, eye, shift))) return rc;
     int iters = 0;
     const int cap = max_iters > 0 ? max_iters : 100000;
-    for (;;) {
-        ++iters;
-        for (int pass = 0; pass < 2; ++pass) {                                       // CholQR2
-            if ((rc = gram(X, X))) return rc;
-            double R[16], Ri[16];
-            if (!chol4_upper(h20, R) || !inv4(R, Ri)) { cslam_set_error("TraceMIN block lost rank (X^T X not positive definite)"); return CSLAM_E_INVALID; }
-            if ((rc = affine(X, Ri, nullptr))) return rc;
+    {
+        auto gram_d = [&](const double *Am, const double *Bm) { return cslam_block4_gram_dev(Am, Bm, n, d_partial, d_out20, st); };
+        auto affine_d = [&](double *&Xc, const double *dM, const double *dshift) {
+            double *out = pool[--npool];
+            const int r2 = cslam_block4_affine_dev(Xc, n, dM, dshift, out, st);
+            pool[npool++] = Xc; Xc = out;
+            return r2;
+        };
+        double hb[10];                                                               // sig4, y0, res, flag of an iteration
+        if ((rc = gram_d(X, X))) return rc;
+        hipLaunchKernelGGL(fj_mean_kernel, dim3(1), dim3(1), 0, st, d_out20, (double)n, d_small);
+        if ((rc = affine_d(X, d_small, d_small + 16))) return rc;
+        for (;;) {
+            ++iters;
+            for (int pass = 0; pass < 2; ++pass) {                                   // CholQR2
+                if ((rc = gram_d(X, X))) return rc;
+                hipLaunchKernelGGL(fj_cholinv_kernel, dim3(1), dim3(1), 0, st, d_out20, d_small);
+                if ((rc = affine_d(X, d_small, nullptr))) return rc;
+            }
+            if ((rc = cslam_csr_spmm4_dev(d_indptr, d_indices, d_data, n, X, W, st))) return rc;
+            if ((rc = gram_d(X, W))) return rc;
+            hipLaunchKernelGGL(fj_eigh_kernel, dim3(1), dim3(1), 0, st, d_out20, d_small);
+            if ((rc = affine_d(X, d_small + 20, nullptr))) return rc;
+            if ((rc = block4_residual_devsigma(W, X, n, d_small + 40, d_small + 36, d_partial, d_small + 44, st))) return rc;
+            HIP_TRY(hipMemcpyAsync(hb, d_small + 36, sizeof hb, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (hb[9] != 0.0) { cslam_set_error(hb[9] == 1.0 ? "TraceMIN block lost rank (X^T X not positive definite)" : "TraceMIN: singular X^T A^-1 X"); return CSLAM_E_INVALID; }
+            sigma[0] = hb[0]; h1 = hb[8];
+            if (h1 / Lnorm < tol) break;
+            if (!(h1 == h1) || iters >= cap) { if (h_iters) *h_iters = iters; cslam_set_error("TraceMIN did not reach tol in %d iterations (residual %.3e)", iters, h1 / Lnorm); return CSLAM_E_INVALID; }
+            double *Wi = pool[--npool];
+            if ((rc = cslam_chain_forward_dev(X, d_is_j, d_r, n, d_J, nJ, d_sso, d_seo, d_sa, d_sb, d_Rl, Bn, Qn, tmp, d_scratch, d_bt, st))) return rc;
+            if (m > 0) {
+                hipLaunchKernelGGL(fj_drop_row_kernel, dim3((m * 4 + 255) / 256), dim3(256), 0, st, d_bt, nJ, g, d_rhs, 0);
+                if ((rc = cslam_chol_solve4_dev(A, m, ld, 0, dinv, dinvT, bs, d_rhs, d_cs_tmp, st))) return rc;
+                hipLaunchKernelGGL(fj_drop_row_kernel, dim3((m * 4 + 255) / 256), dim3(256), 0, st, d_rhs, nJ, g, d_xJ, 1);
+            }
+            if ((rc = cslam_chain_backward_dev(d_xJ, Bn, Qn, d_r, d_Rn, d_jid, d_seg_of, d_sa, d_sb, d_Rl, n, Wi, st))) return rc;
+            if ((rc = gram_d(X, Wi))) return rc;
+            hipLaunchKernelGGL(fj_proj_kernel, dim3(1), dim3(1), 0, st, d_out20, (double)n, d_small);
+            if ((rc = cslam_block4_affine_dev(Wi, n, d_small, d_small + 16, X, st))) return rc;
+            pool[npool++] = Wi;
         }
-        if ((rc = cslam_csr_spmm4_dev(d_indptr, d_indices, d_data, n, X, W, st))) return rc;
-        if ((rc = gram(X, W))) return rc;
-        eigh4(h20, sigma, Y);
-        if ((rc = affine(X, Y, nullptr))) return rc;
-        const double y0[4] = {Y[0], Y[4], Y[8], Y[12]};
-        if ((rc = cslam_block4_residual_sync(W, X, n, y0, sigma[0], d_partial, d_out20, &h1, st))) return rc;
-        if (h1 / Lnorm < tol) break;
-        if (iters >= cap) { if (h_iters) *h_iters = iters; cslam_set_error("TraceMIN did not reach tol in %d iterations (residual %.3e)", iters, h1 / Lnorm); return CSLAM_E_INVALID; }
-        // Wi = A^-1 X through the chain reduction
-        double *Wi = pool[--npool];
-        if ((rc = cslam_chain_forward_dev(X, d_is_j, d_r, n, d_J, nJ, d_sso, d_seo, d_sa, d_sb, d_Rl, Bn, Qn, tmp, d_scratch, d_bt, st))) return rc;
-        if (m > 0) {
-            hipLaunchKernelGGL(fj_drop_row_kernel, dim3((m * 4 + 255) / 256), dim3(256), 0, st, d_bt, nJ, g, d_rhs, 0);
-            if ((rc = cslam_chol_solve4_dev(A, m, ld, 0, dinv, dinvT, bs, d_rhs, d_cs_tmp, st))) return rc;
-            hipLaunchKernelGGL(fj_drop_row_kernel, dim3((m * 4 + 255) / 256), dim3(256), 0, st, d_rhs, nJ, g, d_xJ, 1);
-        }
-        if ((rc = cslam_chain_backward_dev(d_xJ, Bn, Qn, d_r, d_Rn, d_jid, d_seg_of, d_sa, d_sb, d_Rl, n, Wi, st))) return rc;
-        // X <- Wi (Wi^T X)^-1 minus its column means, in one pass (chain_solver_gpu.py)
-        if ((rc = gram(X, Wi))) return rc;
-        double Mi[16];
-        if (!inv4(h20, Mi)) { cslam_set_error("TraceMIN: singular X^T A^-1 X"); return CSLAM_E_INVALID; }
-        for (int j = 0; j < 4; ++j) {
-            double s = 0.0;
-            for (int i = 0; i < 4; ++i) s += h20[16 + i] * Mi[i * 4 + j];
-            shift[j] = s / (double)n;
-        }
-        if ((rc = cslam_block4_affine_host(Wi, n, Mi, shift, X, st))) return rc;
-        pool[npool++] = Wi;
     }
     hipLaunchKernelGGL(fj_column0_kernel, dim3((unsigned)ceil_div64(n, 256)), dim3(256), 0, st, X, n, d_v);
     HIP_TRY(hipMemcpyAsync(h_v, d_v, (size_t)n * 8, hipMemcpyDeviceToHost, st));

@@ -478,6 +478,32 @@ CSLAM_API int cslam_block4_residual_dev(const double *d_W, const double *d_X, in
     return CSLAM_OK;
 }
 
+// residual with sigma read from device memory (cslam_fiedler keeps the 4 x 4 algebra on the device); internal, not exported
+__global__ __launch_bounds__(B4_BLOCK) void block4_residual_ds_kernel(const double *__restrict__ W, const double *__restrict__ X,
+                                                                      int64_t n, const double *__restrict__ y4,
+                                                                      const double *__restrict__ sigma_p, double *__restrict__ partial) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    const double y0 = y4[0], y1 = y4[1], y2 = y4[2], y3 = y4[3], sigma = sigma_p[0];
+    for (int64_t k = (int64_t)blockIdx.x * B4_BLOCK + threadIdx.x; k < n; k += (int64_t)gridDim.x * B4_BLOCK) {
+        double w = W[k * CQ] * y0 + W[k * CQ + 1] * y1 + W[k * CQ + 2] * y2 + W[k * CQ + 3] * y3;
+        acc += fabs(w - sigma * X[k * CQ]);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+int block4_residual_devsigma(const double *d_W, const double *d_X, int64_t n, const double *d_y4, const double *d_sigma,
+                             double *d_partial, double *d_out1, hipStream_t st) {
+    int grid = (int)ceil_div64(n, B4_BLOCK); if (grid > B4_GRID) grid = B4_GRID;
+    hipLaunchKernelGGL(block4_residual_ds_kernel, dim3(grid), dim3(B4_BLOCK), 0, st, d_W, d_X, n, d_y4, d_sigma, d_partial);
+    hipLaunchKernelGGL(block4_sum_finish_kernel, dim3(1), dim3(256), 0, st, d_partial, grid, d_out1);
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
 // ---- host-synchronous twins for the TraceMIN outer loop: the 4 x 4 algebra between the streaming passes runs on the host
 // (LAPACK, as in the reference), so every pass ends in a tiny read-back or starts from a tiny matrix.  Passing those through
 // torch tensors cost ~2 ms per iteration in copies, allocations and synchronisations (of ~0.3 ms of kernels at 1e6 poses): here

@@ -189,7 +189,7 @@ def test_one_call_c_abi_fiedler_argument_errors_and_disconnected_graph():
     W = sp.coo_matrix((np.ones(len(i)), (i, i + 1)), shape=(n, n))
     W = W + W.T
     L = sp.csr_matrix(sp.diags(np.asarray(W.sum(axis=1)).ravel()) - W)
-    with pytest.raises(CslamHipError):
+    with pytest.raises(CslamHipError, match="not connected"):
         fiedler_tracemin_hip(L, max_iters=50)
     # unsorted column indices are refused
     indptr = np.array([0, 2, 4, 6, 8, 10, 12], dtype=np.int64)
