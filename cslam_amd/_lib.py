@@ -20,6 +20,12 @@ class CslamHipError(RuntimeError):
     pass
 
 
+class CslamGraphError(CslamHipError):
+    """CSLAM_E_GRAPH: the graph admits no Fiedler pair (not connected, singular junction Laplacian, TraceMIN breakdown) --
+    the condition under which the reference's networkx call raises and acm.py:436-466 re-draws its start point.  Not a
+    failure of the GPU path."""
+
+
 _lib = None
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -145,6 +151,8 @@ def load():
 def check(rc):
     if rc != 0:
         msg = load().cslam_last_error()
+        if rc == -6:
+            raise CslamGraphError(f"libcslam_hip error {rc}: {msg.decode() if msg else ''}")
         raise CslamHipError(f"libcslam_hip error {rc}: {msg.decode() if msg else ''}")
 
 

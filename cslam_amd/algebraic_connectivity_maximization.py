@@ -17,7 +17,7 @@ from typing import NamedTuple
 
 import numpy as np
 
-from cslam_amd._lib import CslamHipError
+from cslam_amd._lib import CslamGraphError, CslamHipError
 from cslam_amd.mac.mac import MAC
 from cslam_amd.mac.utils import Edge, EdgeArrays
 
@@ -342,6 +342,9 @@ class AlgebraicConnectivityMaximization(object):
             try:
                 result, _, _ = mac.fw_subset(w_init, nb_candidates_to_choose, max_iters=self.max_iters)
                 break
+            except CslamGraphError:       # the native solver's "no Fiedler pair for this graph": what networkx raises on
+                trial += 1
+                w_init = self.pseudo_greedy_initialization(nb_candidates_to_choose, trial, candidate_edges)
             except CslamHipError:
                 raise                     # a failing kernel / missing GPU is not a singular Laplacian: never retried away
             except Exception:

@@ -396,7 +396,7 @@ CSLAM_API int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h
             const int a = find(ei[e]), b = find(ej[e]);
             if (a != b) { parent[a] = b; --comps; }
         }
-        if (comps != 1) { cslam_set_error("graph is not connected (%d components): no Fiedler pair", comps); return CSLAM_E_INVALID; }
+        if (comps != 1) { cslam_set_error("graph is not connected (%d components): no Fiedler pair", comps); return CSLAM_E_GRAPH; }
     }
     for (int e = 0; e < nE; ++e) if (ei[e] != g) diag[ei[e] - (ei[e] > g)] += ew[e];      // fixed order: all first ends, then all second ends
     for (int e = 0; e < nE; ++e) if (ej[e] != g) diag[ej[e] - (ej[e] > g)] += ew[e];
@@ -561,7 +561,7 @@ CSLAM_API int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h
         HIP_TRY(hipMemcpyAsync(info.data(), d_info, ib * sizeof(int), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         for (int i = 0; i < ib; ++i)
-            if (info[i] != 0) { cslam_set_error("the grounded junction Laplacian is not positive definite (graph not connected?)"); return CSLAM_E_INVALID; }
+            if (info[i] != 0) { cslam_set_error("the grounded junction Laplacian is not positive definite (graph not connected?)"); return CSLAM_E_GRAPH; }
         laps.lap("cholesky + block inverses", st);
         if (split) fprintf(stderr, " {potrf %.1f, panel trsm %.1f, trailing gemm %.1f, block inverses %.1f ms}", t_cat[0], t_cat[1], t_cat[2], t_cat[3]);
     }
@@ -600,10 +600,10 @@ CSLAM_API int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h
             if ((rc = block4_residual_devsigma(W, X, n, d_small + 40, d_small + 36, d_partial, d_small + 44, st))) return rc;
             HIP_TRY(hipMemcpyAsync(hb, d_small + 36, sizeof hb, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            if (hb[9] != 0.0) { cslam_set_error(hb[9] == 1.0 ? "TraceMIN block lost rank (X^T X not positive definite)" : "TraceMIN: singular X^T A^-1 X"); return CSLAM_E_INVALID; }
+            if (hb[9] != 0.0) { cslam_set_error(hb[9] == 1.0 ? "TraceMIN block lost rank (X^T X not positive definite)" : "TraceMIN: singular X^T A^-1 X"); return CSLAM_E_GRAPH; }
             sigma[0] = hb[0]; h1 = hb[8];
             if (h1 / Lnorm < tol) break;
-            if (!(h1 == h1) || iters >= cap) { if (h_iters) *h_iters = iters; cslam_set_error("TraceMIN did not reach tol in %d iterations (residual %.3e)", iters, h1 / Lnorm); return CSLAM_E_INVALID; }
+            if (!(h1 == h1) || iters >= cap) { if (h_iters) *h_iters = iters; cslam_set_error("TraceMIN did not reach tol in %d iterations (residual %.3e)", iters, h1 / Lnorm); return CSLAM_E_GRAPH; }
             double *Wi = pool[--npool];
             if ((rc = cslam_chain_forward_dev(X, d_is_j, d_r, n, d_J, nJ, d_sso, d_seo, d_sa, d_sb, d_Rl, Bn, Qn, tmp, d_scratch, d_bt, st))) return rc;
             if (m > 0) {

@@ -144,7 +144,13 @@ class MAC:
         Returns (rounded solution, unrounded iterate, dual upper bound)."""
         if self.fiedler_solver == 'chain_hip' and trace is None and len(self.weights) > 0 and self.num_poses > 4 \
                 and os.environ.get('CSLAM_MAC_FW', 'hip') != 'python':
-            return self._fw_subset_hip(w_init, k, max_iters, duality_gap_tol)
+            from .._lib import CslamHipError
+            try:
+                return self._fw_subset_hip(w_init, k, max_iters, duality_gap_tol)
+            except CslamHipError as e:
+                if 'junctions' not in str(e):
+                    raise                 # (CslamGraphError included: the caller's retry policy, acm.py:436-466)
+                # more junctions than the dense factor takes: the Python loop, whose Fiedler pairs fall back to the sparse-LU junction solve
         u_i = float("inf")
         w_i = w_init
         for it in range(max_iters):

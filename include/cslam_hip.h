@@ -39,6 +39,8 @@ extern "C" {
 #define CSLAM_E_NOMEM (-3)
 #define CSLAM_E_DIM (-4)      /* descriptor dimension mismatch */
 #define CSLAM_E_UNSUPPORTED (-5) /* an optional run-time dependency (RCCL) is not available on this host */
+#define CSLAM_E_GRAPH (-6)    /* cslam_fiedler / cslam_mac_fw_subset: the graph admits no Fiedler pair (not connected, singular
+                                 junction Laplacian, TraceMIN breakdown) -- where the reference's networkx call raises */
 
 #define CSLAM_F32 0
 #define CSLAM_F64 1
@@ -244,7 +246,8 @@ int cslam_chol_solve4_dev(const double *d_L, int64_t m, int64_t ld, int col_majo
  *   h_x0        start block [n][4] row-major, or NULL = numpy RandomState(seed).normal(size=(4, n)).T (bit-identical;
  *               cslam_fiedler_start_block writes that block to a host buffer)
  *   tol         stopping rule ||L v - lambda v||_1 / ||L||_inf < tol (mac.py passes 1e-8)
- *   max_iters   <= 0: no practical limit (the reference has none); otherwise CSLAM_E_INVALID when exceeded
+ *   max_iters   <= 0: no practical limit (the reference has none); otherwise CSLAM_E_GRAPH when exceeded.  A graph that is
+ *               not connected (networkx raises) or whose iteration breaks down returns CSLAM_E_GRAPH as well
  *   h_lambda2, h_v [n], h_iters (optional): results on the host.  The sign of v is arbitrary (as in the reference).
  * Work runs on the CURRENT device and `stream` (NULL: a non-blocking stream of the library's own; the blocked factorisation
  * also uses two side streams for its look-ahead, CSLAM_FIEDLER_LOOKAHEAD=0 keeps it on one); device memory is a workspace kept between calls (MAC calls this once per

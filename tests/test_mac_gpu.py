@@ -245,3 +245,41 @@ def test_native_frank_wolfe_loop_equals_the_python_loop(R, P, C_, K, monkeypatch
     monkeypatch.delenv("CSLAM_MAC_FW")
     sel1, w1, _ = mac.fw_subset(w0, K, max_iters=5, duality_gap_tol=1e30)
     assert np.array_equal(w1, w0) and sel1.sum() == K
+
+
+def test_disconnected_start_point_is_retried_like_the_reference_not_raised():
+    """Two clusters of robots that only low-weight candidates bridge: the greedy start point leaves the graph disconnected,
+    networkx raises there and acm.py:436-466 re-draws the start with one more random pick per trial.  The native solver
+    reports that condition as CSLAM_E_GRAPH (CslamGraphError) and takes the same retry path -- a failing kernel would be
+    CslamHipError and is never retried away."""
+    from cslam_amd._lib import CslamGraphError, CslamHipError
+    from cslam_amd.algebraic_connectivity_maximization import AlgebraicConnectivityMaximization, EdgeInterRobot
+    from cslam_amd.mac.chain_solver_gpu import fiedler_tracemin_hip
+    import scipy.sparse as sp
+    assert issubclass(CslamGraphError, CslamHipError)
+    n = 40
+    i = np.array([k for k in range(n - 1) if k != 19])
+    W = sp.coo_matrix((np.ones(len(i)), (i, i + 1)), shape=(n, n))
+    W = W + W.T
+    with pytest.raises(CslamGraphError, match="not connected"):
+        fiedler_tracemin_hip(sp.csr_matrix(sp.diags(np.asarray(W.sum(axis=1)).ravel()) - W))
+    rng = np.random.default_rng(3)
+    R, P, K = 4, 40, 6
+    fixed = [EdgeInterRobot(0, int(rng.integers(0, P)), 1, int(rng.integers(0, P)), 1.0),
+             EdgeInterRobot(2, int(rng.integers(0, P)), 3, int(rng.integers(0, P)), 1.0)]
+    cand = []
+    for _ in range(30):                                          # heavy candidates inside the two clusters
+        a, b = ((0, 1) if rng.random() < 0.5 else (2, 3))
+        cand.append(EdgeInterRobot(a, int(rng.integers(0, P)), b, int(rng.integers(0, P)), float(rng.uniform(0.8, 1.0))))
+    for _ in range(30):                                          # light candidates across them
+        a, b = int(rng.integers(0, 2)), int(rng.integers(2, 4))
+        cand.append(EdgeInterRobot(a, int(rng.integers(0, P)), b, int(rng.integers(0, P)), float(rng.uniform(0.05, 0.2))))
+    np.random.seed(5)
+    params = {"frontend.enable_sparsification": True, "evaluation.enable_sparsification_comparison": False,
+              "frontend.mac_fiedler_solver": "chain_hip"}
+    ac = AlgebraicConnectivityMaximization(robot_id=0, max_nb_robots=R, extra_params=params)
+    ac.set_graph(fixed, cand)
+    for r in range(R):
+        ac.nb_poses[r] = P
+    sel = ac.select_candidates(K, {r: True for r in range(R)}, greedy_initialization=True)
+    assert len(sel) == K and len({ac.edge_key(e) for e in sel}) == K
