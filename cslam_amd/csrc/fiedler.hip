@@ -314,6 +314,7 @@ CSLAM_API int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h
     ARG_CHECK(n > 4 && n < ((int64_t)1 << 31), "n must be in (4, 2^31): tiny graphs go through the host solver");
     ARG_CHECK(tol > 0.0, "tol <= 0");
     std::lock_guard<std::mutex> lock(g_mu);
+    Laps laps;
     int rc = blas_load();
     if (rc) return rc;
     int dev = 0;
@@ -323,7 +324,7 @@ CSLAM_API int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h
     hipStream_t st = stream ? (hipStream_t)stream : g_ws.stream;
     if (!g_blas.handle || g_blas.handle_dev != dev) { RB_TRY(g_blas.create(&g_blas.handle)); g_blas.handle_dev = dev; }
     RB_TRY(g_blas.set_stream(g_blas.handle, st));
-    Laps laps;
+    laps.lap("libraries + handle", st);
     const int64_t nnz = h_indptr[n];
     ARG_CHECK(h_indptr[0] == 0 && nnz >= 0, "bad indptr");
 
