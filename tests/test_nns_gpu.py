@@ -400,6 +400,37 @@ def test_multi_bank_search_equals_separate_searches(nnm):
                 assert np.all(got[i][2] == 0) and np.all(got[i][0] == -1)
 
 
+def test_multi_bank_search_is_ordered_after_the_producer_on_a_side_stream(nnm):
+    """The per-bank streams of cslam_bank_search_multi_dev fork from the CALLER's stream: queries still being written by
+    a long kernel chain on a non-blocking side stream (an extractor's output) must be complete before any bank reads them,
+    and the caller's stream must own the results afterwards."""
+    import torch
+    d, m = 512, 600
+    rng = np.random.default_rng(5)
+    banks_h = [unit_rows(np.random.default_rng(200 + i), n, d) for i, n in enumerate((4000, 2500, 900, 3100))]
+    banks = []
+    for bh in banks_h:
+        nn = nnm.NearestNeighborsMatching(dim=d)
+        nn.add_items(bh, range(len(bh)))
+        banks.append(nn)
+    base = torch.from_numpy(unit_rows(rng, m, d)).cuda()
+    mix = torch.from_numpy(np.linalg.qr(rng.standard_normal((d, d)))[0].astype(np.float32)).cuda()
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    for rep in range(3):
+        with torch.cuda.stream(side):
+            q = base
+            for _ in range(200):                                  # a few milliseconds of dependent kernels producing the queries
+                q = q @ mix
+            q = (q / q.norm(dim=1, keepdim=True)).contiguous()
+            got = nnm.search_multi_device(banks, q, [5, 1, 1, 1])
+        side.synchronize()
+        qh = q.cpu().numpy()
+        for i, bh in enumerate(banks_h):
+            oi, os_, oc = pyoracle.nns_search(bh, qh, [5, 1, 1, 1][i])
+            assert_topk_equal(got[i][0], got[i][1], got[i][2], oi, os_, oc, 1e-12)
+
+
 def test_entry_points_leave_the_callers_device_alone(nnm):
     """Every C-ABI entry point runs on the device that owns its data and restores the caller's current device (a process
     may keep its banks on one GPU and run its extractor on another).  With one visible GPU this checks the guard is
