@@ -541,8 +541,9 @@ CSLAM_API int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h
             const int e = k + cb, e2 = e + cb < m ? e + cb : m;
             if ((rc = update(k, cb, e, e2))) return rc;                             // the next panel's block row first
             if (la) HIP_TRY(hipEventRecord(g_ws.ev_row, st));
-            for (int j = e2; j < m; j += 2 * cb) {                                  // queued BEFORE the panel calls: should one of
-                const int je = j + 2 * cb < m ? j + 2 * cb : m;                     // them block the host, the GPU already has these
+            const int ub = cb;                                                      // block rows of one panel height: 289 -> 278 ms at 31.5k junctions against two (less of each diagonal block's unused triangle)
+            for (int j = e2; j < m; j += ub) {                                      // queued BEFORE the panel calls: should one of
+                const int je = j + ub < m ? j + ub : m;                             // them block the host, the GPU already has these
                 if ((rc = update(k, cb, j, je))) return rc;
             }
             if (la) {
