@@ -1,4 +1,5 @@
-"""ctypes binding of libcslam_hip.so (the C ABI declared in include/cslam_hip.h).
+"""ctypes binding of libcslam_hip.so (the C ABI declared in include/cslam_hip.h; include/cslam_hip_experimental.h for the
+A/B partners and diagnostics).
 
 There is no CPU fallback: every product entry point raises CslamHipError when the
 library is missing or no MI355X is visible.  Build with `python __graft_entry__.py`
@@ -26,6 +27,16 @@ class CslamGraphError(CslamHipError):
     failure of the GPU path."""
 
 
+class CslamUnsupportedError(CslamHipError):
+    """CSLAM_E_UNSUPPORTED: an optional run-time dependency (RCCL, rocBLAS / rocSOLVER) was not found on this host."""
+
+
+class CslamLimitError(CslamHipError):
+    """CSLAM_E_LIMIT: valid input beyond a size limit of this entry point (cslam_fiedler: junctions of the dense factor)."""
+
+
+_ERROR_CLASSES = {-5: CslamUnsupportedError, -6: CslamGraphError, -7: CslamLimitError}
+
 _lib = None
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
@@ -45,6 +56,10 @@ _SIGNATURES = {
     "cslam_bank_search_host": (_i, [_vp, _vp, _i, _i64, _i, _vp, _i, _vp, _vp, _vp]),
     "cslam_bank_search_dev": (_i, [_vp, _vp, _i, _i64, _i64, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "cslam_bank_search_multi_dev": (_i, [_vp, _i, _vp, _i, _i64, _i64, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "cslam_bank_search_enqueue_dev": (_i, [_vp, _vp, _i, _i64, _i64, _i, _vp, _i, _vp, _vp, _vp, _vp]),
+    "cslam_bank_search_finish": (_i, [_vp, C.POINTER(_i64)]),
+    "cslam_bank_search_multi_enqueue_dev": (_i, [_vp, _i, _vp, _i, _i64, _i64, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
+    "cslam_bank_search_multi_finish": (_i, [_vp, _i, C.POINTER(_i64)]),
     "cslam_bank_last_stats": (_i, [_vp, C.POINTER(_i64 * 4)]),
     "cslam_bank_last_kernel_ms": (_i, [_vp, C.POINTER(_f)]),
     "cslam_topk_merge_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp]),
@@ -109,7 +124,10 @@ _SIGNATURES = {
     "cslam_peak_mfma_dev": (_i, [_i, _i, _i, _vp, C.POINTER(C.c_double), _vp]),
 }
 
-EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+# declared in include/cslam_hip_experimental.h (A/B partners, profiling hooks, peak micro-benchmarks), not in the stable ABI
+EXPERIMENTAL_SYMBOLS = ("cslam_wino4_input_h3_dev", "cslam_wino2_fused64_dev", "cslam_wino2_fused_c64_dev",
+                        "cslam_wino4_fused_c64_dev", "cslam_debug_wfh_prof_dev", "cslam_peak_copy_dev", "cslam_peak_mfma_dev")
+EXPORTED_SYMBOLS = tuple(n for n in _SIGNATURES if n not in EXPERIMENTAL_SYMBOLS)
 
 
 def build(verbose=False):
@@ -151,9 +169,7 @@ def load():
 def check(rc):
     if rc != 0:
         msg = load().cslam_last_error()
-        if rc == -6:
-            raise CslamGraphError(f"libcslam_hip error {rc}: {msg.decode() if msg else ''}")
-        raise CslamHipError(f"libcslam_hip error {rc}: {msg.decode() if msg else ''}")
+        raise _ERROR_CLASSES.get(rc, CslamHipError)(f"libcslam_hip error {rc}: {msg.decode() if msg else ''}")
 
 
 def require_gpu():

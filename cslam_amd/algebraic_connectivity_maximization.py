@@ -315,27 +315,30 @@ class AlgebraicConnectivityMaximization(object):
     # ----------------------------------------------------------------------- solve ----
     def _fiedler_solver(self):
         """Inner solver of the Fiedler computation: 'frontend.mac_fiedler_solver' in the params
-        ('tracemin_lu' | 'chain' | 'chain_gpu' | 'chain_hip' | 'auto').  'auto' keeps the reference's sparse-LU path for
-        small graphs (bit-compatible selections) and moves graphs of >= 20000 poses to the chain-reduced
-        HIP solver when a GPU is visible ('chain_hip': the C ABI's one-call `cslam_fiedler`; 'chain_gpu' is the
-        same computation driven from torch)."""
+        ('tracemin_lu' | 'chain' | 'chain_gpu' | 'chain_hip' | 'auto').  'auto' = the chain-reduced HIP solver behind the
+        C ABI's one-call `cslam_fiedler` ('chain_hip') whenever a GPU is visible -- at every graph size, the reference's
+        normal operating regime (a few thousand poses, budget 5) included: same TraceMIN iterates, identical selections on
+        the golden graphs (tests/test_mac_gpu.py) -- and the reference's sparse-LU path on a host without one.  Where
+        rocBLAS / rocSOLVER cannot be found 'auto' falls back to the torch-driven twin ('chain_gpu'); an explicit
+        'chain_hip' does not.  Returns (solver, may_fall_back)."""
         choice = self.params.get('frontend.mac_fiedler_solver', 'auto') if hasattr(self.params, 'get') else 'auto'
         if choice != 'auto':
-            return choice
-        if self.total_nb_poses >= 20000:
-            try:
-                import torch
-                if torch.cuda.is_available():
-                    return 'chain_hip'
-            except ImportError:
-                pass
-        return 'tracemin_lu'
+            return choice, False
+        try:
+            import torch
+            if torch.cuda.is_available():
+                return 'chain_hip', True
+        except ImportError:
+            pass
+        return 'tracemin_lu', False
 
     def run_mac_solver(self, fixed_edges, candidate_edges, w_init, nb_candidates_to_choose):
         """Frank-Wolfe MAC with the reference's retry policy: any failure of the Fiedler
         solve (singular Laplacian of a disconnected selection) re-draws the initial guess with
         one more random pick, at most nb_candidates_to_choose times (reference :436-466)."""
-        mac = MAC(fixed_edges, candidate_edges, self.total_nb_poses, fiedler_solver=self._fiedler_solver())
+        solver, may_fall_back = self._fiedler_solver()
+        mac = MAC(fixed_edges, candidate_edges, self.total_nb_poses, fiedler_solver=solver)
+        mac.solver_may_fall_back = may_fall_back
         result = w_init.copy()
         trial = 0
         while trial < nb_candidates_to_choose:

@@ -30,6 +30,15 @@ struct cslam_bank {
     int *h_nflag;                     // pinned: count of uncertified queries of the last enqueued MFMA search
     int *pending_flag_list;           // device list those queries are in (bank workspace)
     int pending_dbg;
+    // a search that has been enqueued and not finished (cslam_bank_search_enqueue_dev ... cslam_bank_search_finish): its
+    // arguments, for the exact-scan fallback of the uncertified queries; ev_flag = "the uncertified-query count is on the host"
+    struct Pending {
+        bool active, deferred;
+        const void *q; int q_dtype; int64_t ldq; int k;
+        const int64_t *lim; int64_t *oi; double *os; int32_t *oc;
+        hipStream_t st;
+    } pend;
+    hipEvent_t ev_flag;
 };
 
 int bank_ws_reserve(cslam_bank *b, int slot, size_t bytes);

@@ -24,9 +24,26 @@ CSLAM_API const char *cslam_last_error(void) { return g_err; }
 CSLAM_API int cslam_version(void) { return 100; }
 
 int cslam_visible_devices() {
-    static int n = -1;                      // a benign race: every thread computes the same value
-    if (n < 0) { int c = 0; n = (hipGetDeviceCount(&c) == hipSuccess) ? c : 0; if (n == 0) (void)hipGetLastError(); }
-    return n;
+    static std::atomic<int> n{-1};          // every thread computes the same value
+    int v = n.load(std::memory_order_relaxed);
+    if (v < 0) {
+        int c = 0;
+        v = (hipGetDeviceCount(&c) == hipSuccess) ? c : 0;
+        if (v == 0) (void)hipGetLastError();
+        n.store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+
+int cslam_cu_count() {
+    static std::atomic<int> cu[64];         // zero-initialised; per device
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (dev >= 0 && dev < 64) { const int c = cu[dev].load(std::memory_order_relaxed); if (c > 0) return c; }
+    int c = 0;
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (dev >= 0 && dev < 64) cu[dev].store(c, std::memory_order_relaxed);
+    return c;
 }
 
 CSLAM_API int cslam_device_count(int *count) {
@@ -91,6 +108,7 @@ CSLAM_API int cslam_bank_create(int device, int dim, int64_t capacity_hint, csla
     b->stage = nullptr; b->stage_bytes = 0; b->last_stream = nullptr; b->ev_valid = false;
     b->side = nullptr; b->ev_fork = nullptr; b->ev_side = nullptr;
     b->h_nflag = nullptr; b->pending_flag_list = nullptr; b->pending_dbg = 0;
+    b->pend.active = false; b->pend.deferred = false; b->ev_flag = nullptr;
     for (int s = 0; s < 4; ++s) { b->stats[s] = 0; b->item_map_key[s] = -1; }
     b->num_cu = 0;
     b->device = device; b->dim = dim; b->kd = (int)round_up64(dim, 32);
@@ -119,6 +137,7 @@ CSLAM_API int cslam_bank_destroy(cslam_bank_t *b) {
     if (b->stage) (void)hipFree(b->stage);
     if (b->h_nflag) (void)hipHostFree(b->h_nflag);
     if (b->ev_valid) { (void)hipEventDestroy(b->ev0); (void)hipEventDestroy(b->ev1); }
+    if (b->ev_flag) (void)hipEventDestroy(b->ev_flag);
     if (b->side) { (void)hipStreamDestroy(b->side); (void)hipEventDestroy(b->ev_fork); (void)hipEventDestroy(b->ev_side); }
     delete b;
     return CSLAM_OK;
@@ -131,8 +150,11 @@ CSLAM_API int cslam_bank_size(const cslam_bank_t *b, int64_t *n, int *dim) {
     return CSLAM_OK;
 }
 
+#define NO_PENDING(b) ARG_CHECK(!(b)->pend.active, "a search of this bank is enqueued and not finished: call cslam_bank_search_finish first")
+
 CSLAM_API int cslam_bank_clear(cslam_bank_t *b) {
     ARG_CHECK(b, "bank is NULL");
+    NO_PENDING(b);
     b->n = 0;
     return CSLAM_OK;
 }
@@ -178,6 +200,7 @@ CSLAM_API int cslam_bank_add_host(cslam_bank_t *b, const void *vecs, int dtype, 
     ARG_CHECK(b && (vecs || n == 0), "NULL argument");
     ARG_CHECK(dtype == CSLAM_F32 || dtype == CSLAM_F64, "dtype must be CSLAM_F32 or CSLAM_F64");
     ARG_CHECK(n >= 0, "n < 0");
+    NO_PENDING(b);
     if (n == 0) return CSLAM_OK;
     BANK_DEVICE(b);
     int rc = bank_grow(b, b->n + n);
@@ -205,6 +228,7 @@ CSLAM_API int cslam_bank_add_host(cslam_bank_t *b, const void *vecs, int dtype, 
 CSLAM_API int cslam_bank_add_dev(cslam_bank_t *b, const float *d_vecs, int64_t ld, int64_t n, void *stream) {
     ARG_CHECK(b && (d_vecs || n == 0), "NULL argument");
     ARG_CHECK(n >= 0 && ld >= b->dim, "bad n / ld");
+    NO_PENDING(b);
     BANK_DEVICE(b);
     int rc = bank_grow(b, b->n + n);
     if (rc) return rc;
@@ -671,40 +695,103 @@ int scan_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, const 
 }
 
 // ------------------------------------------------------------ search entry ----
-CSLAM_API int cslam_bank_search_dev(cslam_bank_t *b, const void *d_queries, int q_dtype, int64_t ldq,
-                                    int64_t nq, int k, const int64_t *d_row_limit, int mode,
-                                    int64_t *d_out_idx, double *d_out_sim, int32_t *d_out_cnt,
-                                    void *stream) {
-    ARG_CHECK(b && (d_queries || nq == 0) && d_out_idx && d_out_sim && d_out_cnt, "NULL argument");
-    ARG_CHECK(q_dtype == CSLAM_F32 || q_dtype == CSLAM_F64, "q_dtype must be CSLAM_F32 or CSLAM_F64");
-    ARG_CHECK(nq >= 0 && k >= 1, "nq must be >= 0 and k >= 1");
-    ARG_CHECK(ldq >= b->dim, "ldq < dim");
-    ARG_CHECK(nq < (1LL << 31) && b->n < (1LL << 31), "nq / bank rows must be < 2^31");
-    BANK_DEVICE(b);
-    hipStream_t st = (hipStream_t)stream;
-    b->last_stream = st;
-    b->stats[0] = 0; b->stats[2] = 0; b->stats[3] = 0;
-    if (nq == 0) return CSLAM_OK;
+// A search = enqueue (every kernel of it, on the caller's stream, no host synchronisation) + finish (wait for the 4-byte
+// count of uncertified queries -- an EVENT recorded right behind its copy, not the stream: work the caller enqueued later,
+// the next step's extraction, keeps running -- and enqueue the exact-scan fallback for them, rare).  Results are valid in
+// stream order after finish.  One search per bank may be in flight; queries, row limits and outputs must stay alive and
+// the bank unchanged (no add / clear) until it is finished.
+static int pick_mode(const cslam_bank *b, int mode, int64_t nq, int k) {
     int use = mode;
     // the MFMA path keeps 16 merged candidates per (query, segment): k <= 16 (the reference's default
     // nb_best_matches is 10); larger k, tiny banks and single queries use the exact scan
     if (use == CSLAM_MODE_AUTO) use = (nq <= 8 || k > 16 || b->n < 256) ? CSLAM_MODE_SCAN : CSLAM_MODE_MFMA;
     if (use == CSLAM_MODE_MFMA && (k > 16 || b->n < 1)) use = CSLAM_MODE_SCAN;   // empty bank: the scan writes cnt = 0
+    return use;
+}
+
+// st_call: the stream the kernels go to; st_join: the stream the results are ordered on (= st_call unless the searches of a
+// bank list run side by side on per-bank streams that are joined back into it)
+static int bank_enqueue(cslam_bank *b, const void *d_queries, int q_dtype, int64_t ldq, int64_t nq, int k,
+                        const int64_t *d_row_limit, int mode, int64_t *d_out_idx, double *d_out_sim, int32_t *d_out_cnt,
+                        hipStream_t st_call, hipStream_t st_join) {
+    b->last_stream = st_join;
+    b->stats[0] = 0; b->stats[2] = 0; b->stats[3] = 0;
+    const int use = pick_mode(b, mode, nq, k);
     b->stats[1] = use;
-    if (use == CSLAM_MODE_SCAN)
-        return scan_search(b, d_queries, q_dtype, ldq, nullptr, nq, k, d_row_limit, d_out_idx, d_out_sim,
-                           d_out_cnt, st);
-    return mfma_search(b, d_queries, q_dtype, ldq, nq, k, d_row_limit, d_out_idx, d_out_sim, d_out_cnt, st);
+    cslam_bank::Pending &p = b->pend;
+    p.deferred = use == CSLAM_MODE_MFMA;
+    p.q = d_queries; p.q_dtype = q_dtype; p.ldq = ldq; p.k = k; p.lim = d_row_limit;
+    p.oi = d_out_idx; p.os = d_out_sim; p.oc = d_out_cnt; p.st = st_join;
+    int rc;
+    if (!p.deferred) {
+        rc = scan_search(b, d_queries, q_dtype, ldq, nullptr, nq, k, d_row_limit, d_out_idx, d_out_sim, d_out_cnt, st_call);
+    } else {
+        if (!b->ev_flag) HIP_TRY(hipEventCreateWithFlags(&b->ev_flag, hipEventDisableTiming));
+        rc = mfma_search_enqueue(b, d_queries, q_dtype, ldq, nq, k, d_row_limit, d_out_idx, d_out_sim, d_out_cnt, st_call);
+        if (rc == CSLAM_OK) HIP_TRY(hipEventRecord(b->ev_flag, st_call));
+    }
+    p.active = rc == CSLAM_OK;
+    return rc;
+}
+
+static int bank_finish(cslam_bank *b, int64_t *n_uncertified) {
+    if (n_uncertified) *n_uncertified = 0;
+    cslam_bank::Pending &p = b->pend;
+    if (!p.active) return CSLAM_OK;
+    p.active = false;
+    if (!p.deferred) return CSLAM_OK;
+    HIP_TRY(hipEventSynchronize(b->ev_flag));
+    int rc = mfma_search_finish(b, p.q, p.q_dtype, p.ldq, p.k, p.lim, p.oi, p.os, p.oc, p.st);
+    if (n_uncertified) *n_uncertified = b->stats[0];
+    return rc;
+}
+
+static int search_args_ok(const cslam_bank *b, const void *d_queries, int q_dtype, int64_t ldq, int64_t nq, int k,
+                          const int64_t *d_out_idx, const double *d_out_sim, const int32_t *d_out_cnt) {
+    ARG_CHECK(b && (d_queries || nq == 0) && d_out_idx && d_out_sim && d_out_cnt, "NULL argument");
+    ARG_CHECK(q_dtype == CSLAM_F32 || q_dtype == CSLAM_F64, "q_dtype must be CSLAM_F32 or CSLAM_F64");
+    ARG_CHECK(nq >= 0 && k >= 1, "nq must be >= 0 and k >= 1");
+    ARG_CHECK(ldq >= b->dim, "ldq < dim");
+    ARG_CHECK(nq < (1LL << 31) && b->n < (1LL << 31), "nq / bank rows must be < 2^31");
+    NO_PENDING(b);
+    return CSLAM_OK;
+}
+
+CSLAM_API int cslam_bank_search_enqueue_dev(cslam_bank_t *b, const void *d_queries, int q_dtype, int64_t ldq,
+                                            int64_t nq, int k, const int64_t *d_row_limit, int mode,
+                                            int64_t *d_out_idx, double *d_out_sim, int32_t *d_out_cnt, void *stream) {
+    int rc = search_args_ok(b, d_queries, q_dtype, ldq, nq, k, d_out_idx, d_out_sim, d_out_cnt);
+    if (rc) return rc;
+    BANK_DEVICE(b);
+    hipStream_t st = (hipStream_t)stream;
+    if (nq == 0) { b->last_stream = st; b->stats[0] = 0; b->stats[2] = 0; b->stats[3] = 0; return CSLAM_OK; }
+    return bank_enqueue(b, d_queries, q_dtype, ldq, nq, k, d_row_limit, mode, d_out_idx, d_out_sim, d_out_cnt, st, st);
+}
+
+CSLAM_API int cslam_bank_search_finish(cslam_bank_t *b, int64_t *n_uncertified) {
+    ARG_CHECK(b, "bank is NULL");
+    BANK_DEVICE(b);
+    return bank_finish(b, n_uncertified);
+}
+
+CSLAM_API int cslam_bank_search_dev(cslam_bank_t *b, const void *d_queries, int q_dtype, int64_t ldq,
+                                    int64_t nq, int k, const int64_t *d_row_limit, int mode,
+                                    int64_t *d_out_idx, double *d_out_sim, int32_t *d_out_cnt,
+                                    void *stream) {
+    int rc = cslam_bank_search_enqueue_dev(b, d_queries, q_dtype, ldq, nq, k, d_row_limit, mode, d_out_idx, d_out_sim,
+                                           d_out_cnt, stream);
+    if (rc) return rc;
+    return cslam_bank_search_finish(b, nullptr);
 }
 
 // One batch of queries against SEVERAL banks of one device (a robot's local bank and its copies of the other robots'
 // banks: lcsm.py:21-31, searched one after the other by lcsm.py:45-53 / gdlcd.py:157-160): every bank's kernels are
-// enqueued first, ONE stream synchronisation serves all the uncertified-query counts, then the (rare) exact-scan
-// fallbacks run.  Results are those of nb separate cslam_bank_search_dev calls.
-CSLAM_API int cslam_bank_search_multi_dev(cslam_bank_t *const *banks, int nb, const void *d_queries, int q_dtype,
-                                          int64_t ldq, int64_t nq, const int *k, const int64_t *const *d_row_limit,
-                                          int mode, int64_t *const *d_out_idx, double *const *d_out_sim,
-                                          int32_t *const *d_out_cnt, void *stream) {
+// enqueued first (multi_enqueue), the uncertified-query counts are waited for bank by bank and the (rare) exact-scan
+// fallbacks run (multi_finish).  Results are those of nb separate cslam_bank_search_dev calls.
+CSLAM_API int cslam_bank_search_multi_enqueue_dev(cslam_bank_t *const *banks, int nb, const void *d_queries, int q_dtype,
+                                                  int64_t ldq, int64_t nq, const int *k, const int64_t *const *d_row_limit,
+                                                  int mode, int64_t *const *d_out_idx, double *const *d_out_sim,
+                                                  int32_t *const *d_out_cnt, void *stream) {
     ARG_CHECK(banks && nb >= 1 && nb <= 64 && k && d_out_idx && d_out_sim && d_out_cnt, "bad bank list");
     ARG_CHECK((d_queries || nq == 0) && nq >= 0, "NULL queries");
     ARG_CHECK(q_dtype == CSLAM_F32 || q_dtype == CSLAM_F64, "q_dtype must be CSLAM_F32 or CSLAM_F64");
@@ -712,11 +799,14 @@ CSLAM_API int cslam_bank_search_multi_dev(cslam_bank_t *const *banks, int nb, co
         ARG_CHECK(banks[i] && d_out_idx[i] && d_out_sim[i] && d_out_cnt[i] && k[i] >= 1, "NULL bank / output or k < 1");
         ARG_CHECK(banks[i]->device == banks[0]->device && banks[i]->dim == banks[0]->dim, "banks must share device and dimension");
         ARG_CHECK(ldq >= banks[i]->dim, "ldq smaller than the descriptor dimension");
+        ARG_CHECK(nq < (1LL << 31) && banks[i]->n < (1LL << 31), "nq / bank rows must be < 2^31");
+        NO_PENDING(banks[i]);
+        // every bank has ONE workspace, side stream and pending slot: the same handle twice would race on them
+        for (int j = 0; j < i; ++j) ARG_CHECK(banks[j] != banks[i], "the same bank appears twice in the list");
     }
     if (nq == 0) return CSLAM_OK;
     BANK_DEVICE(banks[0]);
     hipStream_t st = (hipStream_t)stream;
-    bool deferred[64];
     // The searches of the list are independent and, on chunk-sized query batches against banks of a few thousand rows, far
     // too small to fill the chip one after the other (250 queries x 12 500 rows = 49 workgroups): each bank enqueues on a
     // stream of its own, forked from and joined back into the caller's stream.  CSLAM_MULTI_STREAMS=0: one after the other.
@@ -733,36 +823,54 @@ CSLAM_API int cslam_bank_search_multi_dev(cslam_bank_t *const *banks, int nb, co
         }
         HIP_TRY(hipEventRecord(banks[0]->ev_fork, st));
     }
-    for (int i = 0; i < nb; ++i) {
+    int rc = CSLAM_OK;
+    for (int i = 0; i < nb && rc == CSLAM_OK; ++i) {
         cslam_bank *b = banks[i];
-        const int64_t *lim = d_row_limit ? d_row_limit[i] : nullptr;
         hipStream_t st_call = st;
         if (fork) { HIP_TRY(hipStreamWaitEvent(b->side, banks[0]->ev_fork, 0)); st_call = b->side; }
-        b->last_stream = st;
-        b->stats[0] = 0; b->stats[2] = 0; b->stats[3] = 0;
-        int use = mode;
-        if (use == CSLAM_MODE_AUTO) use = (nq <= 8 || k[i] > 16 || b->n < 256) ? CSLAM_MODE_SCAN : CSLAM_MODE_MFMA;
-        if (use == CSLAM_MODE_MFMA && (k[i] > 16 || b->n < 1)) use = CSLAM_MODE_SCAN;
-        b->stats[1] = use;
-        deferred[i] = use == CSLAM_MODE_MFMA;
-        int rc = deferred[i] ? mfma_search_enqueue(b, d_queries, q_dtype, ldq, nq, k[i], lim, d_out_idx[i], d_out_sim[i], d_out_cnt[i], st_call)
-                             : scan_search(b, d_queries, q_dtype, ldq, nullptr, nq, k[i], lim, d_out_idx[i], d_out_sim[i], d_out_cnt[i], st_call);
+        rc = bank_enqueue(b, d_queries, q_dtype, ldq, nq, k[i], d_row_limit ? d_row_limit[i] : nullptr, mode, d_out_idx[i],
+                          d_out_sim[i], d_out_cnt[i], st_call, st);
         if (fork) {                                                 // joined even when the enqueue failed: the caller's stream stays ordered
             (void)hipEventRecord(b->ev_side, b->side);
             (void)hipStreamWaitEvent(st, b->ev_side, 0);
         }
-        if (rc) return rc;
     }
-    bool any = false;
-    for (int i = 0; i < nb; ++i) any |= deferred[i];
-    if (any) HIP_TRY(hipStreamSynchronize(st));
-    for (int i = 0; i < nb; ++i) {
-        if (!deferred[i]) continue;
-        int rc = mfma_search_finish(banks[i], d_queries, q_dtype, ldq, k[i], d_row_limit ? d_row_limit[i] : nullptr,
-                                    d_out_idx[i], d_out_sim[i], d_out_cnt[i], st);
-        if (rc) return rc;
+    if (rc != CSLAM_OK) {
+        // a bank in the middle failed: nothing of this call stays pending (the earlier banks' kernels run to completion, their
+        // results are not used)
+        char keep[512];
+        snprintf(keep, sizeof keep, "%s", g_err);
+        (void)hipStreamSynchronize(st);
+        for (int i = 0; i < nb; ++i) banks[i]->pend.active = false;
+        cslam_set_error("%s", keep);
     }
-    return CSLAM_OK;
+    return rc;
+}
+
+CSLAM_API int cslam_bank_search_multi_finish(cslam_bank_t *const *banks, int nb, int64_t *n_uncertified) {
+    ARG_CHECK(banks && nb >= 1 && nb <= 64, "bad bank list");
+    for (int i = 0; i < nb; ++i) ARG_CHECK(banks[i], "NULL bank");
+    BANK_DEVICE(banks[0]);
+    int first = CSLAM_OK;
+    int64_t total = 0;
+    for (int i = 0; i < nb; ++i) {                                  // every bank is finished even when one fallback fails
+        int64_t n = 0;
+        const int rc = bank_finish(banks[i], &n);
+        total += n;
+        if (rc != CSLAM_OK && first == CSLAM_OK) first = rc;
+    }
+    if (n_uncertified) *n_uncertified = total;
+    return first;
+}
+
+CSLAM_API int cslam_bank_search_multi_dev(cslam_bank_t *const *banks, int nb, const void *d_queries, int q_dtype,
+                                          int64_t ldq, int64_t nq, const int *k, const int64_t *const *d_row_limit,
+                                          int mode, int64_t *const *d_out_idx, double *const *d_out_sim,
+                                          int32_t *const *d_out_cnt, void *stream) {
+    int rc = cslam_bank_search_multi_enqueue_dev(banks, nb, d_queries, q_dtype, ldq, nq, k, d_row_limit, mode, d_out_idx,
+                                                 d_out_sim, d_out_cnt, stream);
+    if (rc || nq == 0) return rc;
+    return cslam_bank_search_multi_finish(banks, nb, nullptr);
 }
 
 CSLAM_API int cslam_bank_search_host(cslam_bank_t *b, const void *queries, int q_dtype, int64_t nq,

@@ -5,7 +5,9 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <atomic>
 #include "../../include/cslam_hip.h"
+#include "../../include/cslam_hip_experimental.h"
 
 #define CSLAM_API extern "C" __attribute__((visibility("default")))
 
@@ -64,6 +66,24 @@ static inline int device_of_ptr(const void *p) {
 #define PTR_DEVICE(p)                                               \
     DeviceGuard _dev_guard(device_of_ptr(p));                       \
     if (!_dev_guard.ok) { cslam_set_error("hipSetDevice failed for the device owning %s", #p); return CSLAM_E_HIP; }
+
+// ---- once-per-device set-up (thread-safe) ---------------------------------------------
+// hipFuncSetAttribute is per device, and entry points may be called from several host threads: a plain
+// `static bool done` is a data race and a per-process latch.  Bit d of the mask = device d configured; two threads
+// racing through the same set-up both perform it (idempotent) before either sets the bit.
+//     static DeviceOnce once;  int dev;
+//     if (once.todo(&dev)) { HIP_TRY(hipFuncSetAttribute(...)); once.done(dev); }
+struct DeviceOnce {
+    std::atomic<uint64_t> mask{0};
+    bool todo(int *dev) {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess) d = 0;
+        *dev = d;
+        return d < 0 || d >= 64 || !((mask.load(std::memory_order_acquire) >> d) & 1ull);
+    }
+    void done(int dev) { if (dev >= 0 && dev < 64) mask.fetch_or(1ull << dev, std::memory_order_release); }
+};
+int cslam_cu_count();          // compute units of the CURRENT device, cached per device (bank.hip); 0 on error
 
 static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int64_t ceil_div64(int64_t x, int64_t m) { return (x + m - 1) / m; }

@@ -361,7 +361,10 @@ CSLAM_API int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h
     for (int64_t i = 0; i + 1 < n; ++i) { r[i] = c[i] > 0.0 ? 1.0 / c[i] : 0.0; rcum[i + 1] = rcum[i] + r[i]; }
     for (int64_t k = 0; k < n; ++k) if (is_j[k]) J.push_back(k);
     const int64_t nJ64 = (int64_t)J.size();
-    ARG_CHECK(nJ64 - 1 <= 64000, "more than 64000 junctions: the dense junction factor does not apply (use the host sparse LU)");
+    if (nJ64 - 1 > 64000) {
+        cslam_set_error("more than 64000 junctions (%lld): the dense junction factor does not apply (use the host sparse LU)", (long long)(nJ64 - 1));
+        return CSLAM_E_LIMIT;
+    }
     const int nJ = (int)nJ64, m = nJ - 1;
     std::vector<int64_t> sa, sb; std::vector<double> Rl;
     std::vector<int32_t> seg_start_of(nJ, -1), seg_end_of(nJ, -1);

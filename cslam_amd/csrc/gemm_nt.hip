@@ -299,11 +299,12 @@ CSLAM_API int cslam_pca_project_dev(const float *d_x, int64_t ldx, const float *
         HIP_TRY(hipGetLastError());
         return CSLAM_OK;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;
+    int once_dev;
+    if (once.todo(&once_dev)) {
         HIP_TRY(hipFuncSetAttribute((const void *)gemm_nt_splitk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     2 * STAGE_BYTES));
-        attr_set = true;
+        once.done(once_dev);
     }
     hipLaunchKernelGGL(gemm_nt_splitk_kernel, dim3(mt * nt * S), dim3(256), 2 * STAGE_BYTES, st, d_comp, ldc, Dout, d_x,
                        ldx, B, Din, mt, nt, kps, g_part);

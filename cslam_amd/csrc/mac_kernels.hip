@@ -754,13 +754,14 @@ CSLAM_API int cslam_chol_solve4_dev(const double *d_L, int64_t m, int64_t ld, in
     ARG_CHECK(bs >= 64 && bs <= 4096 && (bs % 64) == 0, "block size must be a multiple of 64 in [64, 4096]");
     hipStream_t st = (hipStream_t)stream;
     const int lds_rows = bs * 4 * 8, lds_cols = (bs * 4 * 8 > (CS4_CT / 64) * 64 * 4 * 8) ? bs * 4 * 8 : (CS4_CT / 64) * 64 * 4 * 8;
-    static bool attr = false;
-    if (!attr) {
+    static DeviceOnce once;                                             // function attributes are per device
+    int once_dev;
+    if (once.todo(&once_dev)) {
         HIP_TRY(hipFuncSetAttribute((const void *)cs4_tri_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
         HIP_TRY(hipFuncSetAttribute((const void *)cs4_tri_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
         HIP_TRY(hipFuncSetAttribute((const void *)cs4_rows_kernel<true, CS4_RPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
         HIP_TRY(hipFuncSetAttribute((const void *)cs4_cols_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32));
-        attr = true;
+        once.done(once_dev);
     }
     const int64_t nb = ceil_div64(m, bs);
     auto row_grid = [](int64_t rows, int rpw) { int64_t g = ceil_div64(rows, (CS4_THREADS / 64) * rpw); return (unsigned)(g > CS4_ROWS_GRID ? CS4_ROWS_GRID : (g < 1 ? 1 : g)); };

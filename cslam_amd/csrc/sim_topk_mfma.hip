@@ -477,8 +477,9 @@ __global__ __launch_bounds__(256) void rescore_kernel(
 template <int T_, int MT, int KPL>
 static int launch_stage1(const MfmaArgs &a, int dbg, int ilv, hipStream_t st) {
     constexpr int lds = 2 * 2 * T_ * TK * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static DeviceOnce once;                                             // one latch per template instance and device
+    int once_dev;
+    if (once.todo(&once_dev)) {
         HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 0, 0>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 0, 1>,
@@ -489,7 +490,7 @@ static int launch_stage1(const MfmaArgs &a, int dbg, int ilv, hipStream_t st) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 2, 0>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr_set = true;
+        once.done(once_dev);
     }
     const dim3 grid(a.nqt * a.nseg), blk(T_ * 2);
     if (dbg == 1) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 1, 0>), grid, blk, lds, st, a);

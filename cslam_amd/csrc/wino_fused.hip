@@ -406,12 +406,8 @@ __global__ __launch_bounds__(512, 1) void wino2_fused_c64_pipe_kernel(const floa
 template <int COUT>
 static int launch_fused_pipe(const float *d_x, const float *d_Up, const float *d_bias, const float *d_res, int B, int H,
                              int W, int relu, int pool, float *d_y, hipStream_t st) {
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    const int n_cu = cslam_cu_count();
+    ARG_CHECK(n_cu > 0, "no HIP device");
     const int gxb = (int)ceil_div64(W, 2 * WF_TBW), gyb = (int)ceil_div64(H, 2 * WF_TBH);
     const int64_t nvb = (int64_t)B * gxb * gyb * (COUT / 64);
     ARG_CHECK(nvb < (1ll << 30), "too many tile blocks for one launch");
@@ -665,12 +661,8 @@ __global__ __launch_bounds__(512, 1) void wino4_fused_c64_pipe_kernel(const floa
 template <int COUT>
 static int launch_fused4_pipe(const float *d_x, const float *d_Up, const float *d_bias, const float *d_res, int B, int H,
                               int W, int relu, int pool, float *d_y, hipStream_t st) {
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    const int n_cu = cslam_cu_count();
+    ARG_CHECK(n_cu > 0, "no HIP device");
     const int gxb = (int)ceil_div64(W, 4 * W4_T), gyb = (int)ceil_div64(H, 4 * W4_T);
     const int64_t nvb = (int64_t)B * gxb * gyb * (COUT / 64);
     ARG_CHECK(nvb < (1ll << 30), "too many tile blocks for one launch");

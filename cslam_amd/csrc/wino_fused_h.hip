@@ -535,12 +535,8 @@ template <int COUT>
 static int launch_fused_h(const float *d_x, const unsigned *d_Uh, const float *d_bias, const float *d_res, int B, int H, int W,
                           int relu, int pool, const unsigned *d_amax, float inv_su, unsigned *d_amax_out, float *d_y,
                           hipStream_t st) {
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    const int n_cu = cslam_cu_count();
+    ARG_CHECK(n_cu > 0, "no HIP device");
     constexpr int NB = 8 / (COUT / 16);
     const int gxs = (int)ceil_div64(W, 16 * NB), gyb = (int)ceil_div64(H, 16);
     const int64_t nsb = (int64_t)B * gxs * gyb;

@@ -389,13 +389,9 @@ CSLAM_API int cslam_wino4_input_h2_dev(const float *d_x, int B, int H, int W, in
 
 template <int TM, int TN, int NS>
 static int wino_gemm_launch(WinoGemmArgs a, int dbg, hipStream_t st) {
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        HIP_TRY(hipGetDevice(&dev));
-        HIP_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        if (n_cu < 8) n_cu = 8;
-    }
+    int n_cu = cslam_cu_count();
+    ARG_CHECK(n_cu > 0, "no HIP device");
+    if (n_cu < 8) n_cu = 8;
     a.n_mt = (int)ceil_div64(a.T, TM);
     a.n_nt = a.Cout / TN;
     const int64_t items = (int64_t)a.nxi * a.n_mt * a.n_nt;
@@ -404,12 +400,13 @@ static int wino_gemm_launch(WinoGemmArgs a, int dbg, hipStream_t st) {
     constexpr int lds = NS * (TM + TN) * WG_ROWB;
     int grid = n_cu - n_cu % 8;                                      // one persistent workgroup per CU, 8 | grid
     if ((int64_t)grid > round_up64(a.n_items, 8)) grid = (int)round_up64(a.n_items, 8);
-    static bool attr = false;
-    if (!attr) {
+    static DeviceOnce once;
+    int once_dev;
+    if (once.todo(&once_dev)) {
         HIP_TRY(hipFuncSetAttribute((const void *)wino_gemm_h2_kernel<TM, TN, NS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void *)wino_gemm_h2_kernel<TM, TN, NS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void *)wino_gemm_h2_kernel<TM, TN, NS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        attr = true;
+        once.done(once_dev);
     }
     if (dbg == 1) hipLaunchKernelGGL((wino_gemm_h2_kernel<TM, TN, NS, 1>), dim3(grid), dim3(512), lds, st, a);
     else if (dbg == 2) hipLaunchKernelGGL((wino_gemm_h2_kernel<TM, TN, NS, 2>), dim3(grid), dim3(512), lds, st, a);

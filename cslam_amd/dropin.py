@@ -48,10 +48,18 @@ class _DropinFinder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
         return None
 
     def create_module(self, spec):
-        return importlib.import_module(_MAP[spec.name])
+        # The import machinery stamps the module it gets back with the 'cslam.<name>' spec (module.__spec__ = spec).  The
+        # module is the real cslam_amd one, so its own spec is put back in exec_module: importlib.reload, pkgutil, inspect
+        # and pickling-by-spec keep seeing where it came from.
+        module = importlib.import_module(_MAP[spec.name])
+        self._own_spec = getattr(self, "_own_spec", {})
+        self._own_spec[id(module)] = (module, module.__spec__)
+        return module
 
     def exec_module(self, module):
-        pass
+        saved = getattr(self, "_own_spec", {}).pop(id(module), None)
+        if saved is not None and saved[0] is module:
+            module.__spec__ = saved[1]
 
 
 def install_lazy():

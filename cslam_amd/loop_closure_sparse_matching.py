@@ -182,19 +182,27 @@ class LoopClosureSparseMatching(object):
         `embeddings`: [m, d] numpy array or torch tensor (a CUDA tensor is used in place).
         Returns (intra_matches list of (kf_id, matched_kf or None), inter_matches list of
         EdgeInterRobot in the order the sequential calls would produce them)."""
+        return self.process_local_keyframes_begin(embeddings, keyframe_ids, intra).finish()
+
+    def process_local_keyframes_begin(self, embeddings, keyframe_ids, intra=True):
+        """`process_local_keyframes` in two halves for a host that pipelines steps: this half adds the rows and ENQUEUES the
+        searches (local top-k + best-1 per other robot, `cslam_bank_search_multi_enqueue_dev`) without a host
+        synchronisation; the returned handle's `finish()` waits for the searches' certificate counts only -- work enqueued in
+        between, the next chunk's extraction, keeps running -- and does the host bookkeeping (thresholds, candidate edges).
+        Nothing may be added to this robot's banks between the two halves."""
+        return _LocalKeyframesStep(self, embeddings, keyframe_ids, intra)
+
+    def _local_keyframes_enqueue(self, embeddings, keyframe_ids, intra):
         host, dev, m = self._stage(embeddings)
         ids = [int(i) for i in keyframe_ids]
         assert len(ids) == m
-        ids_arr = np.asarray(ids, dtype=np.int64)
-        intra_out = []
         n0 = self.local_nnsm.n
         self._add(self.local_nnsm, host, dev, ids)
-        thr = self.params['frontend.similarity_threshold']
         me = self.params['robot_id']
         others = [i for i in range(self.params['max_nb_robots']) if i != me and self.other_robots_nnsm[i].n > 0]
         # device banks: the local top-k and the best-1 of every other robot's bank in ONE library call (all kernels
-        # enqueued before the single host synchronisation, three result copies for the whole chunk)
-        results = None
+        # enqueued before the host waits for anything, three result copies for the whole chunk)
+        pending = None
         if dev is not None and m > 0 and (intra or others):
             import torch
             from cslam_amd.nns_matching import search_multi_device
@@ -205,7 +213,16 @@ class LoopClosureSparseMatching(object):
                 banks.append(self.local_nnsm); ks.append(k); lims.append(lim)
             for i in others:
                 banks.append(self.other_robots_nnsm[i]); ks.append(1); lims.append(None)
-            results = search_multi_device(banks, dev, ks, lims)
+            pending = search_multi_device(banks, dev, ks, lims, defer=True)
+        return host, dev, m, ids, n0, others, pending
+
+    def _local_keyframes_finish(self, state, intra):
+        host, dev, m, ids, n0, others, pending = state
+        results = pending.finish() if pending is not None else None
+        ids_arr = np.asarray(ids, dtype=np.int64)
+        intra_out = []
+        thr = self.params['frontend.similarity_threshold']
+        me = self.params['robot_id']
         if intra and m > 0:
             k = int(self.params['frontend.nb_best_matches'])
             if results is not None:
@@ -268,6 +285,8 @@ class LoopClosureSparseMatching(object):
                     inter_out.append(match)
         return intra_out, inter_out
 
+    # (class _LocalKeyframesStep below)
+
     def process_remote_descriptors(self, robot_id, descriptors, keyframe_ids):
         """Batch equivalent of add_other_robot_global_descriptor for consecutive messages of
         one robot (descriptors as float64 [m, d], like np.asarray(msg.descriptor))."""
@@ -321,15 +340,31 @@ class LoopClosureSparseMatching(object):
         received from that robot), ...] -> [(matches, updated last-received id), ...] in message order.  Same result as
         `process_remote_chunk` message by message (gdlcd.py:407-422 each): every sender's rows go to that sender's bank,
         but the matching against the LOCAL bank -- the same bank for all of them, and untouched by those adds -- is ONE search
-        over the concatenated rows instead of one launch + one read-back per message."""
+        over the concatenated rows instead of one launch + one read-back per message.
+
+        Two messages of the SAME robot in one call behave like two callbacks in a row: the second one is filtered with the
+        last id the first one left (neighbors_manager.py:147-169 keeps that state per robot between callbacks), whatever
+        `last received` the caller supplied for it -- re-sent or overlapping rows are added and matched once."""
+        running = {}                                             # robot id -> last id left by its earlier messages of this call
+
+        def _last_for(chunk, supplied):
+            prev = running.get(int(chunk.robot_id))
+            return supplied if prev is None else max(int(supplied), prev)
+
         if not hasattr(self.local_nnsm, "search_device"):
-            return [self.process_remote_chunk(c, l) for c, l in messages]
+            res = []
+            for c, l in messages:
+                m, last = self.process_remote_chunk(c, _last_for(c, l))
+                running[int(c.robot_id)] = int(last)
+                res.append((m, last))
+            return res
         import torch
         from cslam_amd.wire import unknown_rows
         devname = "cuda:%d" % self.local_nnsm.device
         staged, out = [], []
         for chunk, last_received in messages:
-            rows, last = unknown_rows(chunk, last_received)
+            rows, last = unknown_rows(chunk, _last_for(chunk, last_received))
+            running[int(chunk.robot_id)] = int(last)
             out.append(([], last))
             if len(rows) == 0:
                 continue
@@ -362,3 +397,18 @@ class LoopClosureSparseMatching(object):
                     matches.append(match)
             out[slot] = (matches, out[slot][1])
         return out
+
+
+class _LocalKeyframesStep(object):
+    """Handle of `LoopClosureSparseMatching.process_local_keyframes_begin`."""
+
+    def __init__(self, lcsm, embeddings, keyframe_ids, intra):
+        self._lcsm, self._intra = lcsm, intra
+        self._state = lcsm._local_keyframes_enqueue(embeddings, keyframe_ids, intra)
+        self._result = None
+
+    def finish(self):
+        if self._result is None:
+            self._result = self._lcsm._local_keyframes_finish(self._state, self._intra)
+            self._state = None
+        return self._result

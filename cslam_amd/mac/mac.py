@@ -26,6 +26,7 @@ class MAC:
         # 'chain_gpu'    chain-reduced inner solves and every O(n) step in HIP (large graphs)
         # 'chain_hip'    the same computation behind the C ABI's one-call `cslam_fiedler` (native host code, no torch ops)
         self.fiedler_solver = fiedler_solver
+        self.solver_may_fall_back = False         # set by the 'auto' policy (acm.py): chain_hip -> chain_gpu without rocSOLVER
         self._fixed = fixed_measurements          # kept for the native Frank-Wolfe loop (fw_subset, 'chain_hip')
         self.L_odom = weight_graph_lap_from_edge_list(fixed_measurements, num_poses)
         self.num_poses = num_poses
@@ -49,15 +50,19 @@ class MAC:
             return fiedler_tracemin_chain_gpu(L, tol=tol, seed=np.random.RandomState(7))
         if self.fiedler_solver == 'chain_hip':
             import os
-            from .._lib import CslamHipError
+            from .._lib import CslamLimitError, CslamUnsupportedError
             from .chain_solver_gpu import fiedler_tracemin_chain_gpu, fiedler_tracemin_hip
             st = {} if os.environ.get('CSLAM_MAC_TIMING') else None
             try:
                 out = fiedler_tracemin_hip(L, tol=tol, seed=7, stats=st)
-            except CslamHipError as e:
-                if 'junctions' not in str(e):
+            except CslamLimitError:
+                # CSLAM_E_LIMIT: more junctions than the dense factor takes -> the torch-driven solver's sparse-LU junction solve
+                return fiedler_tracemin_chain_gpu(L, tol=tol, seed=np.random.RandomState(7))
+            except CslamUnsupportedError:
+                # CSLAM_E_UNSUPPORTED: rocBLAS / rocSOLVER not found on this host.  Only the 'auto' policy may change solver
+                if not self.solver_may_fall_back:
                     raise
-                # more junctions than the dense factor takes: the torch-driven solver's sparse-LU junction solve
+                self.fiedler_solver = 'chain_gpu'
                 return fiedler_tracemin_chain_gpu(L, tol=tol, seed=np.random.RandomState(7))
             if st is not None:
                 print('      [fiedler (cslam_fiedler): %d TraceMIN iterations, %.0f ms in all]' % (st['iters'], st['total_s'] * 1e3), flush=True)
@@ -144,13 +149,17 @@ class MAC:
         Returns (rounded solution, unrounded iterate, dual upper bound)."""
         if self.fiedler_solver == 'chain_hip' and trace is None and len(self.weights) > 0 and self.num_poses > 4 \
                 and os.environ.get('CSLAM_MAC_FW', 'hip') != 'python':
-            from .._lib import CslamHipError
+            from .._lib import CslamLimitError, CslamUnsupportedError
             try:
                 return self._fw_subset_hip(w_init, k, max_iters, duality_gap_tol)
-            except CslamHipError as e:
-                if 'junctions' not in str(e):
-                    raise                 # (CslamGraphError included: the caller's retry policy, acm.py:436-466)
-                # more junctions than the dense factor takes: the Python loop, whose Fiedler pairs fall back to the sparse-LU junction solve
+            except CslamLimitError:
+                pass                      # more junctions than the dense factor takes: the Python loop, whose Fiedler pairs
+                                          # fall back to the sparse-LU junction solve (find_fiedler_pair)
+            except CslamUnsupportedError:
+                if not self.solver_may_fall_back:
+                    raise                 # an explicitly requested 'chain_hip' without its libraries stays an error
+                self.fiedler_solver = 'chain_gpu'
+            # (every other CslamHipError propagates; CslamGraphError is the caller's retry policy, acm.py:436-466)
         u_i = float("inf")
         w_i = w_init
         for it in range(max_iters):

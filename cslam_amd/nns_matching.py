@@ -228,6 +228,33 @@ class NearestNeighborsMatching(object):
             C.c_void_p(out[2].data_ptr()), C.c_void_p(st)))
         return out
 
+    def search_device_async(self, queries, k, row_limit=None, mode=MODE_AUTO, out=None):
+        """`search_device` in two halves (C ABI: cslam_bank_search_enqueue_dev / cslam_bank_search_finish): every kernel of
+        the search is enqueued on the current stream and the call returns WITHOUT a host synchronisation; the returned
+        handle's `finish()` waits only for the event behind the uncertified-query count (work enqueued since -- the next
+        step's extraction -- keeps running), enqueues the exact-scan fallback when that count is not zero, and returns the
+        same device tensors `search_device` returns (valid in stream order).  One search per bank may be in flight; the
+        bank must not change until `finish()`."""
+        import torch
+        assert queries.is_cuda and queries.dim() == 2 and queries.stride(1) == 1
+        assert queries.dtype in (torch.float32, torch.float64)
+        dt = _lib.F32 if queries.dtype == torch.float32 else _lib.F64
+        nq = queries.shape[0]
+        if out is None:
+            out = (torch.empty((nq, k), dtype=torch.int64, device=queries.device),
+                   torch.empty((nq, k), dtype=torch.float64, device=queries.device),
+                   torch.empty((nq,), dtype=torch.int32, device=queries.device))
+        lim_p = None
+        if row_limit is not None:
+            assert row_limit.is_cuda and row_limit.dtype == torch.int64 and row_limit.is_contiguous()
+            lim_p = C.c_void_p(row_limit.data_ptr())
+        st = torch.cuda.current_stream(queries.device).cuda_stream
+        _lib.check(self._lib.cslam_bank_search_enqueue_dev(
+            self._bank, C.c_void_p(queries.data_ptr()), dt, queries.stride(0), nq, int(k), lim_p,
+            int(mode), C.c_void_p(out[0].data_ptr()), C.c_void_p(out[1].data_ptr()),
+            C.c_void_p(out[2].data_ptr()), C.c_void_p(st)))
+        return PendingSearch([self], out, keep=(queries, row_limit))
+
     def item_array(self):
         """items of rows [0, n) as an int64 array when every item is an int (keyframe ids), else None: lets the
         batched callers map result rows to keyframe ids with one gather instead of a dict lookup per row."""
@@ -255,10 +282,42 @@ class NearestNeighborsMatching(object):
         return float(ms.value)
 
 
-def search_multi_device(banks, queries, ks, row_limits=None, mode=MODE_AUTO):
+class PendingSearch(object):
+    """An enqueued search (one bank, or a list of banks sharing one query batch).  `finish()` -> the device output tensors;
+    `uncertified` afterwards = queries the exact scan had to re-do (summed over the banks).  Holds the queries / row limits
+    alive until then."""
+
+    def __init__(self, banks, out, keep=None, host_copy=None):
+        self._banks, self._out, self._keep, self._host_copy = banks, out, keep, host_copy
+        self.uncertified = None
+
+    def finish(self):
+        if self._banks is None:
+            return self._out
+        banks, self._banks = self._banks, None
+        lib = banks[0]._lib
+        n = C.c_int64(0)
+        if len(banks) == 1:
+            _lib.check(lib.cslam_bank_search_finish(banks[0]._bank, C.byref(n)))
+        else:
+            handles = (C.c_void_p * len(banks))(*[b._bank for b in banks])
+            _lib.check(lib.cslam_bank_search_multi_finish(handles, len(banks), C.byref(n)))
+        self.uncertified = int(n.value)
+        self._keep = None
+        return self._out
+
+    def __del__(self):                       # a dropped handle must not leave the bank locked
+        try:
+            self.finish()
+        except Exception:
+            pass
+
+
+def search_multi_device(banks, queries, ks, row_limits=None, mode=MODE_AUTO, defer=False):
     """One batch of device-resident queries against several banks of the same GPU in ONE library call
-    (`cslam_bank_search_multi_dev`): the kernels of every bank are enqueued before the single host synchronisation,
-    and the results come back in three copies.  banks: NearestNeighborsMatching objects (populated, same dim and
+    (`cslam_bank_search_multi_enqueue_dev` + `_finish`): the kernels of every bank are enqueued before the host waits for
+    the uncertified-query counts, and the results come back in three copies.  defer=True returns a handle right after the
+    enqueue; its `finish()` does the rest (a batch host runs the next step's extraction in between).  banks: NearestNeighborsMatching objects (populated, same dim and
     device); ks: k per bank; row_limits: per bank None or an int64 CUDA tensor [nq].
     Returns a list of (rows [nq,k] int64, sims [nq,k] float64, cnt [nq] int32) NUMPY arrays, one per bank -- what
     `search_device` of each bank would give, downloaded."""
@@ -286,8 +345,56 @@ def search_multi_device(banks, queries, ks, row_limits=None, mode=MODE_AUTO):
     p_sim = (C.c_void_p * nb)(*[sims.data_ptr() + 8 * offs[i] for i in range(nb)])
     p_cnt = (C.c_void_p * nb)(*[cnt.data_ptr() + 4 * nq * i for i in range(nb)])
     st = torch.cuda.current_stream(dev).cuda_stream
-    _lib.check(lib.cslam_bank_search_multi_dev(handles, nb, C.c_void_p(queries.data_ptr()), dt, queries.stride(0), nq, kk,
-                                               lims, int(mode), p_idx, p_sim, p_cnt, C.c_void_p(st)))
-    h_idx, h_sims, h_cnt = idx.cpu().numpy(), sims.cpu().numpy(), cnt.cpu().numpy()
-    return [(h_idx[offs[i]:offs[i + 1]].reshape(nq, ks[i]), h_sims[offs[i]:offs[i + 1]].reshape(nq, ks[i]),
-             h_cnt[i * nq:(i + 1) * nq]) for i in range(nb)]
+    _lib.check(lib.cslam_bank_search_multi_enqueue_dev(handles, nb, C.c_void_p(queries.data_ptr()), dt, queries.stride(0), nq,
+                                                       kk, lims, int(mode), p_idx, p_sim, p_cnt, C.c_void_p(st)))
+    pend = PendingSearch(list(banks), (idx, sims, cnt), keep=(queries, row_limits))
+    if not defer:
+        return PendingMultiSearch(pend, offs, nq, ks).finish()
+    # deferred: the result copies are put on the stream NOW, behind the search and ahead of whatever the caller enqueues
+    # next, into pinned memory; finish() then waits for this event only.  (They are final unless a query failed its
+    # certificate -- finish() re-copies in that case.)
+    host = tuple(_pinned(t.shape, t.dtype, slot) for slot, t in enumerate((idx, sims, cnt)))
+    for h, t in zip(host, (idx, sims, cnt)):
+        h.copy_(t, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    return PendingMultiSearch(pend, offs, nq, ks, host=host, event=ev)
+
+
+_PINNED = {}
+
+
+def _pinned(shape, dtype, slot):
+    """Grow-only pinned staging buffers, one per result slot (rows / scores / counts): hipHostMalloc is too slow to sit on
+    the per-chunk path.  One deferred multi-search is outstanding at a time per process (the callers alternate enqueue /
+    finish), so the buffers are not shared between live handles."""
+    import torch
+    n = int(np.prod(shape))
+    buf = _PINNED.get((slot, dtype))
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(max(n, 1), dtype=dtype, pin_memory=True)
+        _PINNED[(slot, dtype)] = buf
+    return buf[:n].view(shape)
+
+
+class PendingMultiSearch(object):
+    """`search_multi_device(..., defer=True)`: `finish()` -> the list of per-bank NUMPY results."""
+
+    def __init__(self, pend, offs, nq, ks, host=None, event=None):
+        self._pend, self._offs, self._nq, self._ks = pend, offs, nq, ks
+        self._host, self._event = host, event
+        self._result = None
+
+    def finish(self):
+        if self._result is None:
+            idx, sims, cnt = self._pend.finish()
+            if self._host is not None and self._pend.uncertified == 0:
+                self._event.synchronize()                      # the copies issued right behind the search: nothing later
+                h_idx, h_sims, h_cnt = (h.numpy().copy() for h in self._host)
+            else:
+                h_idx, h_sims, h_cnt = idx.cpu().numpy(), sims.cpu().numpy(), cnt.cpu().numpy()
+            offs, nq, ks = self._offs, self._nq, self._ks
+            self._result = [(h_idx[offs[i]:offs[i + 1]].reshape(nq, ks[i]), h_sims[offs[i]:offs[i + 1]].reshape(nq, ks[i]),
+                             h_cnt[i * nq:(i + 1) * nq]) for i in range(len(ks))]
+            self._pend = None
+        return self._result

@@ -83,6 +83,11 @@ class ShardedInterRobotMatcher(object):
         m = local_desc.shape[0]
         if self.world == 1:
             return self.search_fn(local_desc, self.k_intra), None
+        if m == 0:                                                   # an empty step (m is equal on all ranks): no collective
+            dev, k = local_desc.device, self.k_intra
+            e = lambda dt, *shape: torch.empty(shape, dtype=dt, device=dev)
+            return ((e(torch.int64, 0, k), e(torch.float64, 0, k), e(torch.int32, 0)),
+                    (e(torch.int64, 0, 1), e(torch.float64, 0, 1), e(torch.int32, 0), e(torch.int64, 0)))
         bounds = _chunk_bounds(m, self.chunks)
         inflight = self._gather(local_desc[bounds[0][0]:bounds[0][1]])
         parts = []
@@ -95,7 +100,8 @@ class ShardedInterRobotMatcher(object):
             # list the local rows need in full (same scores, same order), so nothing is computed twice
             rows, sims, cnt = self.search_fn(allq, self.k_intra)
             c = b - a
-            parts.append((rows.view(self.world, c, -1), sims.view(self.world, c, -1), cnt.view(self.world, c)))
+            # explicit sizes: view(..., -1) cannot infer a dimension of an empty step (m == 0 is equal on all ranks)
+            parts.append((rows.view(self.world, c, rows.shape[1]), sims.view(self.world, c, sims.shape[1]), cnt.view(self.world, c)))
         rows = torch.cat([p[0] for p in parts], dim=1)               # [world, m, k], robot-major like one big gather
         sims = torch.cat([p[1] for p in parts], dim=1)
         cnt = torch.cat([p[2] for p in parts], dim=1)
@@ -190,6 +196,10 @@ class RowShardedBankMatcher(object):
             rows, sims, cnt = self.search_fn(local_desc, k)
             return self.merge_fn(rows[None], sims[None], cnt[None], self.row_offsets) if self.row_offsets[0] else \
                 (rows, sims, cnt)
+        if m == 0:                                                       # an empty step (m is equal on all ranks): no collective
+            dev = local_desc.device
+            return (torch.empty((0, k), dtype=torch.int64, device=dev), torch.empty((0, k), dtype=torch.float64, device=dev),
+                    torch.empty((0,), dtype=torch.int32, device=dev))
         bounds = _chunk_bounds(m, self.chunks)
         inflight = self._gather(local_desc[bounds[0][0]:bounds[0][1]])
         lists, out = None, []

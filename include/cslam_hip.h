@@ -41,6 +41,8 @@ extern "C" {
 #define CSLAM_E_UNSUPPORTED (-5) /* an optional run-time dependency (RCCL) is not available on this host */
 #define CSLAM_E_GRAPH (-6)    /* cslam_fiedler / cslam_mac_fw_subset: the graph admits no Fiedler pair (not connected, singular
                                  junction Laplacian, TraceMIN breakdown) -- where the reference's networkx call raises */
+#define CSLAM_E_LIMIT (-7)    /* the input exceeds a size limit of this entry point (cslam_fiedler: junction count of the dense
+                                 factor); the arguments are valid and another path serves them */
 
 #define CSLAM_F32 0
 #define CSLAM_F64 1
@@ -101,11 +103,30 @@ int cslam_bank_search_dev(cslam_bank_t *bank, const void *d_queries, int q_dtype
  * cslam_bank_search_dev with (k[i], d_row_limit[i], d_out_*[i]); all kernels are enqueued before the single host
  * synchronisation the uncertified-query counts need, each bank's on a stream of its own forked from and joined back into
  * `stream` (chunk-sized searches do not fill the chip one after the other; CSLAM_MULTI_STREAMS=0 keeps them on `stream`).
- * d_row_limit may be NULL (no limits) or hold NULL entries. */
+ * d_row_limit may be NULL (no limits) or hold NULL entries.  A bank may appear only once in the list. */
 int cslam_bank_search_multi_dev(cslam_bank_t *const *banks, int nb, const void *d_queries, int q_dtype, int64_t ldq,
                                 int64_t nq, const int *k, const int64_t *const *d_row_limit, int mode,
                                 int64_t *const *d_out_idx, double *const *d_out_sim, int32_t *const *d_out_cnt,
                                 void *stream);
+/* The two halves of cslam_bank_search_dev / cslam_bank_search_multi_dev, for a host that pipelines steps (the reference's
+ * callbacks are serialised, cslam/loop_closure_detection_node.py:109; a batch host overlaps step i's read-back with step
+ * i + 1's extraction):
+ *   *_enqueue_dev  puts every kernel of the search on `stream` and returns without a host synchronisation;
+ *   *_finish       waits for ONE event -- the 4-byte count of queries whose float32 candidate stage could not be
+ *                  certified (see cslam_bank_last_stats), recorded right behind its copy, NOT for the stream: work enqueued
+ *                  after the search keeps running -- and enqueues the exact float64 scan for those queries (normally none).
+ * Results are valid in `stream` order after finish.  One search per bank may be in flight: queries, row limits and outputs
+ * must stay alive and the bank unchanged until it is finished (add / clear / another search return CSLAM_E_INVALID).
+ * n_uncertified (or NULL) receives that count.  finish without a pending search is a no-op. */
+int cslam_bank_search_enqueue_dev(cslam_bank_t *bank, const void *d_queries, int q_dtype, int64_t ldq, int64_t nq, int k,
+                                  const int64_t *d_row_limit, int mode, int64_t *d_out_idx, double *d_out_sim,
+                                  int32_t *d_out_cnt, void *stream);
+int cslam_bank_search_finish(cslam_bank_t *bank, int64_t *n_uncertified);
+int cslam_bank_search_multi_enqueue_dev(cslam_bank_t *const *banks, int nb, const void *d_queries, int q_dtype, int64_t ldq,
+                                        int64_t nq, const int *k, const int64_t *const *d_row_limit, int mode,
+                                        int64_t *const *d_out_idx, double *const *d_out_sim, int32_t *const *d_out_cnt,
+                                        void *stream);
+int cslam_bank_search_multi_finish(cslam_bank_t *const *banks, int nb, int64_t *n_uncertified /* summed over the banks, or NULL */);
 /* statistics of the last search on this bank (for tests / bench):
  * stats[0] = queries that failed the fp32 certificate and were re-done by the scan,
  * stats[1] = mode actually used (CSLAM_MODE_*), stats[2] = bank segments,
@@ -356,29 +377,9 @@ int cslam_wino4_output_dev(const float *d_M, const float *d_bias, const float *d
  * (d_amax NULL: M unscaled, inv_su ignored); d_amax_out (or NULL): atomic max of the bits of max |y| before pooling --
  * the next layer's d_amax without another pass over y; the caller zeroes it beforehand. */
 int cslam_absmax_dev(const float *d_x, int64_t n, unsigned *d_slot, void *stream);
-int cslam_wino4_input_h3_dev(const float *d_x, int B, int H, int W, int C, const unsigned *d_amax, void *d_V3, void *stream);
 int cslam_wino4_output_scaled_dev(const float *d_M, const float *d_bias, const float *d_residual, int B, int H, int W,
                                   int C, int relu, int pool, const unsigned *d_amax, float inv_su, unsigned *d_amax_out,
                                   float *d_y, void *stream);
-/* The same 3x3 / stride 1 / pad 1 convolution for 64 -> 64 channels (VGG-16 conv1_2, netvlad.py:163-171 +
- * the call at :227) as ONE kernel: F(2x2,3x3) input transform, the 16 per-frequency products on the fp32 MFMA pipe
- * and output transform + bias + ReLU (+ MaxPool2d(2,2)) with V and M kept on the compute unit (csrc/wino_fused.hip).
- * x [B,H,W,64] NHWC; Up = U [16,64,64] of the F(2x2) form permuted to [kq 4][xi 16][w 4][g 4][c 16][s 4] with
- * Up[kq][xi][w][g][c][s] = U[xi][16 kq + 4 g + s][16 w + c]; y [B,H,W,64] or [B,H/2,W/2,64] (pool). */
-int cslam_wino2_fused64_dev(const float *d_x, const float *d_Up, const float *d_bias, int B, int H, int W,
-                            int relu, int pool, float *d_y, void *stream);
-/* The same kernel for 64 -> Cout channels, Cout = 64 or 128 (VGG-16 conv1_2 and conv2_1; the BasicBlock convolutions
- * of ResNet-18/34 layer1, cosplace_utils/network.py:38-68, with d_residual [B,H,W,Cout] = the block's shortcut, added
- * before the ReLU, or NULL): Up = U [16,64,Cout] permuted to [kq 4][xi 16][w Cout/16][g 4][c 16][s 4];
- * y [B,H,W,Cout] or [B,H/2,W/2,Cout] (pool; not together with d_residual). */
-int cslam_wino2_fused_c64_dev(const float *d_x, const float *d_Up, const float *d_bias, const float *d_residual, int B,
-                              int H, int W, int Cout, int relu, int pool, float *d_y, void *stream);
-/* The F(4x4,3x3) form of the same one-kernel convolution (36 frequencies, 4 x 4 blocks of 4 x 4-pixel tiles per
- * workgroup step; 1.78x fewer MFMAs per output pixel): Up = U [36,64,Cout] of the F(4x4) form permuted to
- * [kq 4][xi 36][w Cout/16][g 4][c 16][s 4]; everything else as cslam_wino2_fused_c64_dev. */
-int cslam_wino4_fused_c64_dev(const float *d_x, const float *d_Up, const float *d_bias, const float *d_residual, int B,
-                              int H, int W, int Cout, int relu, int pool, float *d_y, void *stream);
-
 /* ---- split-fp16 Winograd GEMM of this library (csrc/wino_gemm.hip) ------------------------------------------------
  * The 36 per-frequency products M[xi] = V[xi] U[xi] of the F(4x4,3x3) form of the trunk's wide 3x3 convolutions
  * (the Conv2d layers of cslam/vpr/netvlad.py:163-171 / cosplace_utils/network.py:38-68) on the fp16 matrix pipe with
@@ -387,14 +388,17 @@ int cslam_wino4_fused_c64_dev(const float *d_x, const float *d_Up, const float *
  * block kb = [hi of channels 32 kb .. 32 kb + 31 | lo of the same] as fp16; V2 [36][T][Cin/32][64] (rows = tiles),
  * U2 [36][Cout][Cin/32][64] (rows = OUTPUT channels, i.e. U transposed).
  * cslam_wino4_input_h2_dev: x [B,H,W,C] NHWC float32 -> V2 (scaled by the power of two derived from *d_amax, the bits
- *   of a bound of max |x|, as cslam_wino4_input_h3_dev); C a multiple of 32.
+ *   of a bound of max |x|, see cslam_absmax_dev above); C a multiple of 32.
  * cslam_wino_gemm_h2_dev: M [36][T][Cout] float32 = (sV V)(sU U); Cin a multiple of 32, Cout of 128.  The result carries
  *   the two scales; cslam_wino4_output_scaled_dev removes them. */
 int cslam_wino4_input_h2_dev(const float *d_x, int B, int H, int W, int C, const unsigned *d_amax, void *d_V2,
                              void *stream);
 int cslam_wino_gemm_h2_dev(const void *d_V2, const void *d_U2, int64_t T, int Cin, int Cout, float *d_M, void *stream);
 
-/* The one-kernel F(4x4,3x3) convolution of the 64-input-channel layers (cslam_wino4_fused_c64_dev above) on the fp16
+/* The one-kernel F(4x4,3x3) convolution of the 64-input-channel layers (64 -> 64 / 128: VGG-16 conv1_2 and conv2_1,
+ * netvlad.py:163-171 + the call at :227; the BasicBlock convolutions of ResNet-18/34 layer1, cosplace_utils/network.py:38-68,
+ * with d_residual = the block's shortcut) -- input transform, the 36 products and output transform + bias + ReLU
+ * (+ MaxPool2d(2,2)) with V and M kept on the compute unit; x [B,H,W,64] NHWC, y [B,H,W,Cout] or pooled -- on the fp16
  * matrix pipe with fp32-grade results (csrc/wino_fused_h.hip): V and U as exact fp16 pairs packed [hi | lo << 16] per
  * value, two v_mfma_f32_16x16x32_f16 per frequency and 16-channel quarter.  d_Uh = U [36,64,Cout] of the F(4x4) form,
  * scaled by the power of two sU, split and permuted to [kq 4][xi 36][w Cout/16][g 4][c 16][s 4] uint32 with
@@ -418,11 +422,6 @@ int cslam_wino4_stem_c64_h_dev(const float *d_x0, const void *d_w1, const float 
                                const void *d_Uh, const float *d_bias, int B, int H, int W, int pool,
                                const unsigned *d_amax_x0, float inv_su, unsigned *d_amax_out, float *d_y, void *stream);
 
-/* diagnostics of the kernel above: with CSLAM_WFH_PROF=1 in the environment its conv1_2-shaped launches (ReLU + pool, 64
- * output channels; stem or not) add up, for waves 0 and 4 of workgroup 0, the shader cycles spent per phase of a quarter into
- * d_buf16 [2][8] uint64 = (transform, barrier, matrix loop, prefetch + stem work, output transform, barrier, quarters, -). */
-int cslam_debug_wfh_prof_dev(void *d_buf16);
-
 /* ---- multi-GPU exchange (csrc/comm.hip): RCCL over xGMI, one process per GPU ---------------------------------------
  * Replaces, inside one node, the ROS 2 transport of descriptors between robots
  * (cslam/global_descriptor_loop_closure_detection.py:198-227 publish GlobalDescriptors, :407-422 receive): rank g owns
@@ -442,17 +441,6 @@ int cslam_comm_info(const cslam_comm_t *comm, int *world, int *rank);
 int cslam_allgather_queries_dev(cslam_comm_t *comm, const void *d_local, int64_t rows, int64_t row_bytes, void *d_all,
                                 void *stream);
 int cslam_exchange_lists_dev(cslam_comm_t *comm, const void *d_send, void *d_recv, int64_t bytes_per_rank, void *stream);
-
-/* ---- diagnostics: in-run re-measurement of the peaks rooflines are priced against (csrc/peaks.hip) ---------------
- * Not on the extract / match path and without a reference counterpart: bench.py reports every roofline fraction against
- * the nominal MI355X peaks and against what these two kernels sustain on the box in the same run.
- * cslam_peak_copy_dev: 16-byte-per-lane streaming copy of `bytes` (multiple of 16) bytes; variant 0 = one element per
- *   thread, 1 / 2 = grid-stride with plain / non-temporal accesses (the caller keeps the fastest).
- * cslam_peak_mfma_dev: register-resident MFMA loop; kind 0 = f32 inputs (v_mfma_f32_32x32x2_f32), 1 = fp16 inputs
- * (v_mfma_f32_32x32x16_f16); `blocks` workgroups of 4 waves, `iters` x 4 independent MFMAs per wave; *flop_out = flop
- * of the launch.  The caller times both with HIP events on `stream`. */
-int cslam_peak_copy_dev(const void *d_src, void *d_dst, int64_t bytes, int variant, void *stream);
-int cslam_peak_mfma_dev(int kind, int iters, int blocks, float *d_scratch, double *flop_out, void *stream);
 
 #ifdef __cplusplus
 }

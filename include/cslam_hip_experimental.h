@@ -1,0 +1,56 @@
+/* cslam_hip_experimental.h -- entry points of libcslam_hip.so that are NOT part of the stable C ABI (include/cslam_hip.h):
+ * A/B partners of the product kernels (the f32-MFMA one-kernel convolutions, round 1's library-GEMM operand layout),
+ * profiling hooks and the bench's peak micro-benchmarks.  They may change or disappear between rounds; nothing of the
+ * product path (cslam_amd/*.py defaults) calls them except where stated. */
+#ifndef CSLAM_HIP_EXPERIMENTAL_H
+#define CSLAM_HIP_EXPERIMENTAL_H
+#include "cslam_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Round 1's operand layout of the split-fp16 Winograd products (one library GEMM over K' = 3 C: V3 [36, T, 3 C] fp16 rows
+ * = [vh | vl | vh]); `frontend.winograd_gemm: library` in vpr/winograd.py.  Superseded by cslam_wino4_input_h2_dev +
+ * cslam_wino_gemm_h2_dev (V stored once, at its fp32 size). */
+int cslam_wino4_input_h3_dev(const float *d_x, int B, int H, int W, int C, const unsigned *d_amax, void *d_V3, void *stream);
+
+/* The same 3x3 / stride 1 / pad 1 convolution for 64 -> 64 channels (VGG-16 conv1_2, netvlad.py:163-171 +
+ * the call at :227) as ONE kernel: F(2x2,3x3) input transform, the 16 per-frequency products on the fp32 MFMA pipe
+ * and output transform + bias + ReLU (+ MaxPool2d(2,2)) with V and M kept on the compute unit (csrc/wino_fused.hip).
+ * x [B,H,W,64] NHWC; Up = U [16,64,64] of the F(2x2) form permuted to [kq 4][xi 16][w 4][g 4][c 16][s 4] with
+ * Up[kq][xi][w][g][c][s] = U[xi][16 kq + 4 g + s][16 w + c]; y [B,H,W,64] or [B,H/2,W/2,64] (pool). */
+int cslam_wino2_fused64_dev(const float *d_x, const float *d_Up, const float *d_bias, int B, int H, int W,
+                            int relu, int pool, float *d_y, void *stream);
+/* The same kernel for 64 -> Cout channels, Cout = 64 or 128 (VGG-16 conv1_2 and conv2_1; the BasicBlock convolutions
+ * of ResNet-18/34 layer1, cosplace_utils/network.py:38-68, with d_residual [B,H,W,Cout] = the block's shortcut, added
+ * before the ReLU, or NULL): Up = U [16,64,Cout] permuted to [kq 4][xi 16][w Cout/16][g 4][c 16][s 4];
+ * y [B,H,W,Cout] or [B,H/2,W/2,Cout] (pool; not together with d_residual). */
+int cslam_wino2_fused_c64_dev(const float *d_x, const float *d_Up, const float *d_bias, const float *d_residual, int B,
+                              int H, int W, int Cout, int relu, int pool, float *d_y, void *stream);
+/* The F(4x4,3x3) form of the same one-kernel convolution (36 frequencies, 4 x 4 blocks of 4 x 4-pixel tiles per
+ * workgroup step; 1.78x fewer MFMAs per output pixel): Up = U [36,64,Cout] of the F(4x4) form permuted to
+ * [kq 4][xi 36][w Cout/16][g 4][c 16][s 4]; everything else as cslam_wino2_fused_c64_dev. */
+int cslam_wino4_fused_c64_dev(const float *d_x, const float *d_Up, const float *d_bias, const float *d_residual, int B,
+                              int H, int W, int Cout, int relu, int pool, float *d_y, void *stream);
+
+/* diagnostics of the kernel above: with CSLAM_WFH_PROF=1 in the environment its conv1_2-shaped launches (ReLU + pool, 64
+ * output channels; stem or not) add up, for waves 0 and 4 of workgroup 0, the shader cycles spent per phase of a quarter into
+ * d_buf16 [2][8] uint64 = (transform, barrier, matrix loop, prefetch + stem work, output transform, barrier, quarters, -). */
+int cslam_debug_wfh_prof_dev(void *d_buf16);
+
+/* ---- diagnostics: in-run re-measurement of the peaks rooflines are priced against (csrc/peaks.hip) ---------------
+ * Not on the extract / match path and without a reference counterpart: bench.py reports every roofline fraction against
+ * the nominal MI355X peaks and against what these two kernels sustain on the box in the same run.
+ * cslam_peak_copy_dev: 16-byte-per-lane streaming copy of `bytes` (multiple of 16) bytes; variant 0 = one element per
+ *   thread, 1 / 2 = grid-stride with plain / non-temporal accesses (the caller keeps the fastest).
+ * cslam_peak_mfma_dev: register-resident MFMA loop; kind 0 = f32 inputs (v_mfma_f32_32x32x2_f32), 1 = fp16 inputs
+ * (v_mfma_f32_32x32x16_f16); `blocks` workgroups of 4 waves, `iters` x 4 independent MFMAs per wave; *flop_out = flop
+ * of the launch.  The caller times both with HIP events on `stream`. */
+int cslam_peak_copy_dev(const void *d_src, void *d_dst, int64_t bytes, int variant, void *stream);
+int cslam_peak_mfma_dev(int kind, int iters, int blocks, float *d_scratch, double *flop_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSLAM_HIP_EXPERIMENTAL_H */

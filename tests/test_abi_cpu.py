@@ -11,8 +11,8 @@ from conftest import ROOT
 from cslam_amd import _lib
 
 
-def declared_symbols():
-    src = open(os.path.join(ROOT, "include", "cslam_hip.h")).read()
+def declared_symbols(header="cslam_hip.h"):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(cslam_[a-z0-9_]+)\s*\(", src)))
 
@@ -26,6 +26,12 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/cslam_hip.h but not exported"
     assert set(names) == set(_lib.EXPORTED_SYMBOLS), "ctypes signature table out of sync with the header"
+    # the experimental header (A/B partners, profiling hooks, peak micro-benchmarks) is kept apart from the stable ABI
+    exp = declared_symbols("cslam_hip_experimental.h")
+    assert set(exp) == set(_lib.EXPERIMENTAL_SYMBOLS) and not (set(exp) & set(names))
+    for n in exp:
+        assert hasattr(lib, n), f"{n} declared in include/cslam_hip_experimental.h but not exported"
+    assert not any(("debug" in n or "peak" in n) for n in names), "diagnostics belong in the experimental header"
     assert _lib.load().cslam_version() >= 100
 
 

@@ -167,7 +167,7 @@ def test_select_candidates_1000_of_100k_poses_chain_gpu(c5, monkeypatch):
     before = {sel.edge_key(e) for e in sel.candidate_edges.values()}
     second = sel.select_candidates(K, in_range)                      # MAC: Frank-Wolfe over > 10^5 poses
     monkeypatch.undo()
-    assert sel._fiedler_solver() == "chain_gpu" and sel.total_nb_poses >= 100_000
+    assert sel._fiedler_solver() == ("chain_gpu", False) and sel.total_nb_poses >= 100_000
     assert len(seen) >= 2, "the Frank-Wolfe loop did not run (fell back to greedy?)"
     assert all(m.fiedler_solver == "chain_gpu" and m.num_poses == sel.total_nb_poses for m, _, _, _ in seen)
     keys2 = {sel.edge_key(e) for e in second}

@@ -26,6 +26,10 @@ assert len(d._MAP) == 10
 for ref_name, our_name in d._MAP.items():
     m = importlib.import_module(ref_name)
     assert m.__name__ == our_name and m is sys.modules[our_name], (ref_name, m)
+    # the module keeps its OWN import spec (importlib.reload / pkgutil / inspect see where it came from)
+    assert m.__spec__ is not None and m.__spec__.name == our_name, (ref_name, m.__spec__)
+before = sys.modules["cslam_amd.broker"].Broker
+assert importlib.reload(sys.modules["cslam_amd.broker"]).Broker is not before      # reload re-executes the module
 from cslam.nns_matching import NearestNeighborsMatching
 from cslam.loop_closure_sparse_matching import LoopClosureSparseMatching
 from cslam.algebraic_connectivity_maximization import AlgebraicConnectivityMaximization, EdgeInterRobot

@@ -73,3 +73,32 @@ def test_intra_decision_arrays_equal_the_reference_loop():
             kfs, s = kfs[1:], s[1:]
         want = lc._first_valid(kfs, s, int(ids[j]), gap, thr) if kfs else None
         assert got[j] == (int(ids[j]), want), (j, got[j], want)
+
+
+def test_drained_queue_filters_a_robots_second_message_with_the_id_its_first_one_left():
+    """process_remote_chunks with two messages of one robot in a call == two callbacks in a row
+    (neighbors_manager.py:147-169 keeps the last id per robot between callbacks): the stale id supplied with the
+    second message must not let re-sent rows through.  Host-only form (a bank without `search_device`)."""
+    from cslam_amd.wire import DescriptorChunk
+
+    class _Bank(object):                         # no search_device: the per-message path
+        n = 0
+
+    lcsm = LoopClosureSparseMatching.__new__(LoopClosureSparseMatching)
+    lcsm.params = _params(0)
+    lcsm.local_nnsm = _Bank()
+    seen = []
+
+    def fake_chunk(chunk, last):
+        from cslam_amd.wire import unknown_rows
+        rows, new_last = unknown_rows(chunk, last)
+        seen.append((int(chunk.robot_id), int(last), [int(chunk.keyframe_ids[r]) for r in rows]))
+        return [], new_last
+    lcsm.process_remote_chunk = fake_chunk
+    d = np.zeros((4, 8), dtype=np.float32)
+    m1 = DescriptorChunk(1, np.array([0, 1, 2, 3], dtype=np.int32), d)
+    m2 = DescriptorChunk(1, np.array([2, 3, 4, 5], dtype=np.int32), d)       # overlaps m1
+    m3 = DescriptorChunk(2, np.array([0, 1, 2, 3], dtype=np.int32), d)
+    res = lcsm.process_remote_chunks([(m1, -1), (m3, 1), (m2, -1)])
+    assert [r[1] for r in res] == [3, 3, 5]
+    assert seen == [(1, -1, [0, 1, 2, 3]), (2, 1, [2, 3]), (1, 3, [4, 5])]

@@ -283,3 +283,64 @@ def test_disconnected_start_point_is_retried_like_the_reference_not_raised():
         ac.nb_poses[r] = P
     sel = ac.select_candidates(K, {r: True for r in range(R)}, greedy_initialization=True)
     assert len(sel) == K and len({ac.edge_key(e) for e in sel}) == K
+
+
+@pytest.mark.parametrize("tag,R,K", [("mac_R1_P100_C50_K10", 1, 10), ("mac_R3_P100_C100_K10", 3, 10),
+                                     ("mac_R5_P100_C200_K100", 5, 100), ("mac_R8_P400_C600_K60", 8, 60)])
+def test_default_solver_on_a_gpu_host_is_the_hip_solver_and_selects_the_reference_edges(tag, R, K):
+    """The reference's normal operating regime (a few hundred to a few thousand poses, acm.py:468-543 with default
+    parameters): with a GPU visible 'auto' runs `cslam_fiedler` / `cslam_mac_fw_subset`, and the selection is the one the
+    reference recorded (G7), edge for edge and in the same order."""
+    from helpers import GOLDEN
+    from cslam_amd.algebraic_connectivity_maximization import AlgebraicConnectivityMaximization, EdgeInterRobot
+    from cslam_amd.mac import mac as mac_mod
+    g7 = np.load(GOLDEN + "/mac_g7.npz")
+    ed = lambda arr: [EdgeInterRobot(int(a), int(b), int(c), int(d), float(w)) for a, b, c, d, w in arr]
+    ac = AlgebraicConnectivityMaximization(robot_id=0, max_nb_robots=R)            # no solver parameter: 'auto'
+    assert ac._fiedler_solver() == ("chain_hip", True)
+    used = []
+    real = mac_mod.MAC._fw_subset_hip
+
+    def spy(self, *a, **kw):
+        used.append(self.fiedler_solver)
+        return real(self, *a, **kw)
+    mac_mod.MAC._fw_subset_hip = spy
+    try:
+        ac.set_graph(ed(g7[tag + "/fixed"]), ed(g7[tag + "/cand"]))
+        sel = ac.select_candidates(K, {r: True for r in range(R)}, greedy_initialization=True)
+    finally:
+        mac_mod.MAC._fw_subset_hip = real
+    got = np.array([tuple(e) for e in sel], dtype=np.float64).reshape(-1, 5)
+    assert np.array_equal(got, g7[tag + "/selected"])
+    if R > 1:                                        # a single robot never reaches MAC (no fixed inter-robot link)
+        assert used and all(u == "chain_hip" for u in used)
+
+
+def test_auto_falls_back_to_the_torch_driven_solver_without_rocsolver_and_explicit_chain_hip_does_not(monkeypatch):
+    """CSLAM_E_UNSUPPORTED (-5: librocblas / librocsolver not found by dlopen) under 'auto' -> 'chain_gpu', same selection;
+    an explicitly requested 'chain_hip' keeps raising.  The junction limit has its own code (CSLAM_E_LIMIT, -7)."""
+    from helpers import GOLDEN
+    from cslam_amd import _lib
+    from cslam_amd.algebraic_connectivity_maximization import AlgebraicConnectivityMaximization, EdgeInterRobot
+    from cslam_amd.mac import mac as mac_mod
+    from cslam_amd.mac import chain_solver_gpu
+    assert issubclass(_lib.CslamUnsupportedError, _lib.CslamHipError) and issubclass(_lib.CslamLimitError, _lib.CslamHipError)
+    assert _lib._ERROR_CLASSES[-5] is _lib.CslamUnsupportedError and _lib._ERROR_CLASSES[-7] is _lib.CslamLimitError
+
+    def no_lib(*a, **kw):
+        raise _lib.CslamUnsupportedError("libcslam_hip error -5: rocBLAS / rocSOLVER not found")
+    monkeypatch.setattr(mac_mod.MAC, "_fw_subset_hip", no_lib)
+    monkeypatch.setattr(chain_solver_gpu, "fiedler_tracemin_hip", no_lib)
+    g7 = np.load(GOLDEN + "/mac_g7.npz")
+    tag, R, K = "mac_R3_P100_C100_K10", 3, 10
+    ed = lambda arr: [EdgeInterRobot(int(a), int(b), int(c), int(d), float(w)) for a, b, c, d, w in arr]
+    ac = AlgebraicConnectivityMaximization(robot_id=0, max_nb_robots=R)
+    ac.set_graph(ed(g7[tag + "/fixed"]), ed(g7[tag + "/cand"]))
+    sel = ac.select_candidates(K, {r: True for r in range(R)}, greedy_initialization=True)
+    assert np.array_equal(np.array([tuple(e) for e in sel], dtype=np.float64).reshape(-1, 5), g7[tag + "/selected"])
+    params = {"frontend.enable_sparsification": True, "evaluation.enable_sparsification_comparison": False,
+              "frontend.mac_fiedler_solver": "chain_hip"}
+    ac = AlgebraicConnectivityMaximization(robot_id=0, max_nb_robots=R, extra_params=params)
+    ac.set_graph(ed(g7[tag + "/fixed"]), ed(g7[tag + "/cand"]))
+    with pytest.raises(_lib.CslamUnsupportedError):
+        ac.select_candidates(K, {r: True for r in range(R)}, greedy_initialization=True)

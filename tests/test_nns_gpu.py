@@ -459,3 +459,72 @@ def test_entry_points_leave_the_callers_device_alone(nnm):
     assert nn.data.shape[1] == 128 and torch.cuda.current_device() == 0
     if n_dev < 2:
         pytest.skip("cross-device half needs 2 GPUs (the transparent half passed)")
+
+
+def test_enqueue_finish_halves_equal_the_synchronous_search(nnm):
+    """cslam_bank_search_enqueue_dev / _finish (one bank and a bank list): same results as the synchronous calls -- with a
+    long-running kernel enqueued BETWEEN the two halves (the next step's extraction of a pipelining host: finish must not
+    wait for it), with queries that fail the certificate (fallback enqueued by finish), and with the bank locked in between
+    (add / a second search are refused, nothing is lost)."""
+    import time
+    import torch
+    from cslam_amd._lib import CslamHipError
+    rng = np.random.default_rng(91)
+    d = 256
+    bank_h = unit_rows(rng, 5000, d)
+    nn = make_bank(nnm, bank_h)
+    base = unit_rows(rng, 1, d)[0]
+    dup = np.tile(base, (700, 1)).astype(np.float32)
+    for i in range(700):
+        dup[i, i % d] = np.nextafter(dup[i, i % d], np.float32(1.0)) if i % 3 else dup[i, i % d]
+    nn_dup = make_bank(nnm, dup)
+    q = unit_rows(rng, 400, d)
+    qd = torch.from_numpy(q).cuda()
+    want = [t.cpu().numpy() for t in nn.search_device(qd, 5, mode=nnm.MODE_MFMA)]
+    filler = torch.randn(8192, 8192, device="cuda")
+    torch.cuda.synchronize()
+    pend = nn.search_device_async(qd, 5, mode=nnm.MODE_MFMA)
+    with pytest.raises(CslamHipError, match="not finished"):
+        nn.add_items(bank_h[:3], range(3))
+    with pytest.raises(CslamHipError, match="not finished"):
+        nn.search_device(qd, 5)
+    for _ in range(20):                                       # ~0.3 s of GPU work behind the search
+        filler = filler @ filler
+        filler /= filler.abs().max()
+    t0 = time.perf_counter()
+    got = pend.finish()
+    waited = time.perf_counter() - t0
+    busy = not torch.cuda.current_stream().query()            # the filler is still running: finish did not drain the stream
+    assert pend.uncertified == 0 and pend.finish() is got     # idempotent
+    got = [t.cpu().numpy() for t in got]
+    assert all(np.array_equal(g, w) for g, w in zip(got, want))
+    assert busy and waited < 0.15, (busy, waited)
+    nn.add_items(bank_h[:3], range(5000, 5003))               # unlocked again
+    assert nn.n == 5003
+    # certificate failures: the fallback is enqueued by finish
+    pend = nn_dup.search_device_async(qd, 5, mode=nnm.MODE_MFMA)
+    r, s, c = (t.cpu().numpy() for t in pend.finish())
+    assert pend.uncertified > 0
+    oi, os_, oc = pyoracle.nns_search(dup, q, 5)
+    assert_topk_equal(r, s, c, oi, os_, oc, 1e-12)
+    # scan mode: nothing deferred, finish is a no-op
+    pend = nn.search_device_async(qd[:4], 5)
+    r, s, c = (t.cpu().numpy() for t in pend.finish())
+    oi, os_, oc = pyoracle.nns_search(np.concatenate((bank_h, bank_h[:3])), q[:4], 5)
+    assert_topk_equal(r, s, c, oi, os_, oc, 1e-12)
+    # bank list, deferred: pinned result copies issued behind the search
+    banks = [nn, nn_dup, make_bank(nnm, unit_rows(rng, 900, d))]
+    ref = nnm.search_multi_device(banks, qd, [5, 1, 1])
+    h = nnm.search_multi_device(banks, qd, [5, 1, 1], defer=True)
+    for _ in range(5):
+        filler = filler @ filler
+        filler /= filler.abs().max()
+    got = h.finish()
+    for (a0, a1, a2), (b0, b1, b2) in zip(got, ref):
+        assert np.array_equal(a0, b0) and np.array_equal(a1, b1, equal_nan=True) and np.array_equal(a2, b2)
+    torch.cuda.synchronize()
+    # the same bank twice in one list: refused (one workspace / side stream / pending slot per bank)
+    with pytest.raises(CslamHipError, match="twice"):
+        nnm.search_multi_device([nn, nn], qd, [5, 1])
+    r, s, c = (t.cpu().numpy() for t in nn.search_device(qd, 5))      # and the bank is not left locked
+    assert np.array_equal(r[:, 0], want[0][:, 0])

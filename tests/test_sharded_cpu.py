@@ -139,3 +139,21 @@ def test_host_merge_stand_in_order():
     r, s, c = _host_merge(rows, sims, np.array([[2], [2]]), [0, 10])
     assert r.tolist() == [[11, 10, 2]] and c.tolist() == [3]            # NaN first, tie 0.5 -> larger global row
     assert np.isnan(s[0, 0]) and s[0, 1:].tolist() == [0.5, 0.5]
+
+
+def test_empty_step_returns_empty_results_without_a_collective():
+    """m == 0 (equal on all ranks): both matchers return empty results; no gather / search / exchange is issued
+    (the one-gather code did, the chunked code raised on view(world, 0, -1))."""
+    from cslam_amd.sharded import RowShardedBankMatcher, ShardedInterRobotMatcher
+
+    def never(*a, **kw):
+        raise AssertionError("an empty step must not reach the search / the collectives")
+    m = ShardedInterRobotMatcher(1, 2, never, k_intra=5, gather_fn=never, chunks=2)
+    intra, inter = m.step(torch.zeros(0, 16))
+    assert intra[0].shape == (0, 5) and intra[1].shape == (0, 5) and intra[2].shape == (0,)
+    assert inter[0].shape == (0, 1) and inter[1].shape == (0, 1) and inter[2].shape == (0,) and inter[3].shape == (0,)
+    assert intra[0].dtype == torch.int64 and intra[1].dtype == torch.float64 and intra[2].dtype == torch.int32
+    r = RowShardedBankMatcher(0, 2, never, [0, 50], k=5, gather_fn=never, exchange_fn=never, merge_fn=never, chunks=3)
+    rows, sims, cnt = r.step(torch.zeros(0, 16))
+    assert rows.shape == (0, 5) and sims.shape == (0, 5) and cnt.shape == (0,)
+    assert rows.dtype == torch.int64 and sims.dtype == torch.float64 and cnt.dtype == torch.int32

@@ -125,7 +125,7 @@ def main():
           f"{t_loc:.1f} s | exchange to {R - 1} peers {t_rem:.1f} s]; intra closures {n_intra}, inter-robot matches {n_inter}")
     print(f"  broker: {n_cand} candidate edges on robot 0; select_candidates(K={K}) first call {t_sel1:.2f} s "
           f"({len(chosen)} edges, biased greedy until every robot has a fixed link), second call {t_sel2:.2f} s "
-          f"({len(chosen2)} edges, MAC over {n} poses, solver {sel._fiedler_solver() if hasattr(sel, '_fiedler_solver') else '?'})")
+          f"({len(chosen2)} edges, MAC over {n} poses, solver {sel._fiedler_solver()[0] if hasattr(sel, '_fiedler_solver') else '?'})")
     print(f"  whole loop {t_front + t_sel1 + t_sel2:.1f} s -> {n / (t_front + t_sel1 + t_sel2):.0f} keyframes/s")
 
 
