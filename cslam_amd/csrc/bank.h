@@ -13,6 +13,13 @@ struct cslam_bank {
     float *rows;    // [cap, ld]  float32 descriptors (reference: nns_matching.py:21)
     double *vv;     // [cap]      sum of squares of each row, float64
     float *invn;    // [cap]      (float)(1/sqrt(vv)); used by the fp32 candidate stage only
+    // the same rows as exact fp16 pairs for the candidate stage on the fp16 matrix pipe (sim_topk_pair.hip): row r times
+    // the power of two s_r (max |v| s_r in [2^14, 2^15)) split into hi + lo halfs, 32-channel blocks [hi 32 | lo 32] of
+    // 128 bytes; pitch ld2 BYTES (one extra 128-byte line when a multiple of 1 KiB, as ld)
+    char *rows2;    // [cap, ld2]
+    float *invs;    // [cap]      invn / s_r: key = (pair dot) * invs[row] * (1 / s_query); NaN for a row whose largest
+                    //            magnitude is outside [2^-100, 2^100] (such a row is always a contender, rescored exactly)
+    int64_t ld2;
     // grow-on-demand workspace
     char *ws[3];          // [0] MFMA path, [1] scan path (also the MFMA fallback), [2] host-API staging
     size_t ws_bytes[3];
@@ -39,6 +46,8 @@ struct cslam_bank {
         hipStream_t st;
     } pend;
     hipEvent_t ev_flag;
+    // diagnostics: where the last MFMA-mode search left its stage-1 candidate lists (cslam_debug_last_candidates)
+    const float *dbg_part_key; const int *dbg_part_idx; int dbg_nseg, dbg_nq; double dbg_err_bound;
 };
 
 int bank_ws_reserve(cslam_bank *b, int slot, size_t bytes);

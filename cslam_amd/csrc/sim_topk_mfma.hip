@@ -21,12 +21,13 @@
 //          random data) are re-done by the exact scan kernel (bank.hip).
 #include <stdlib.h>
 #include "bank.h"
+#include "sim_topk.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define TK 32           // floats per K step
-#define KP 16           // merged candidate list length per (query, segment)
+#define KP SIM_KP       // merged candidate list length per (query, segment)
 
 __device__ __forceinline__ void glds16(const float *g, char *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
@@ -506,6 +507,10 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
                         const int64_t *d_row_limit, int64_t *d_out_idx, double *d_out_sim,
                         int32_t *d_out_cnt, hipStream_t st) {
     static int dbg = -1, tile_env = -1, ilv_env = -1;
+    // read on every call (tests and A/B runs switch it inside one process): "f32" = the f32-input MFMA candidate stage
+    // (round 1-2's kernel, the A/B partner); default = fp16 pairs on the fp16 matrix pipe (sim_topk_pair.hip)
+    const char *s1 = getenv("CSLAM_MFMA_STAGE1");
+    const int stage1_pair = !(s1 && s1[0] == 'f');
     if (dbg < 0) {
         const char *v = getenv("CSLAM_MFMA_DBG");       // timing-only ablations, see the kernel
         dbg = v ? atoi(v) : 0;
@@ -552,11 +557,13 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     }
 
     // queries are used in place only when their pitch is not L2-set-aliasing (see bank.hip)
-    const bool direct = q_dtype == CSLAM_F32 && b->dim == kd && (ldq % 4 == 0) && (ldq % 256 != 0) &&
+    const bool pair = stage1_pair != 0;
+    const bool direct = !pair && q_dtype == CSLAM_F32 && b->dim == kd && (ldq % 4 == 0) && (ldq % 256 != 0) &&
                         (((uintptr_t)d_q) % 16 == 0);
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = (size_t)round_up64((int64_t)(off + bytes), 256); return o; };
-    size_t o_q32 = carve(direct ? 0 : (size_t)nq_pad * ld * 4);
+    size_t o_q32 = carve(direct ? 0 : (pair ? (size_t)nq_pad * b->ld2 : (size_t)nq_pad * ld * 4));
+    size_t o_qs = carve(pair ? (size_t)nq_pad * 4 : 0);
     size_t o_lim = carve((size_t)nq_pad * 4);
     size_t o_qtm = carve((size_t)nqt * 4);
     size_t o_pk = carve((size_t)nq_pad * nseg * KP * 4);
@@ -602,13 +609,17 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
 
     HIP_TRY(hipMemsetAsync(qtm, 0, (size_t)nqt * 4, st));
     HIP_TRY(hipMemsetAsync(flag_count, 0, 4, st));
-    if (q_dtype == CSLAM_F32)
+    if (pair) {
+        rc = pair_prep_launch(d_q, q_dtype, ldq, (int)nq, b->dim, kd, ws + o_q32, b->ld2, (float *)(ws + o_qs), d_row_limit,
+                              (int)b->n, lim, qtm, nq_pad, tile, st);
+        if (rc) return rc;
+    } else if (q_dtype == CSLAM_F32)
         hipLaunchKernelGGL(mfma_prep_kernel<float>, dim3(nq_pad), dim3(256), 0, st, (const float *)d_q, ldq,
                            (int)nq, b->dim, kd, ld, q32, d_row_limit, (int)b->n, lim, qtm, nq_pad, tile);
     else
         hipLaunchKernelGGL(mfma_prep_kernel<double>, dim3(nq_pad), dim3(256), 0, st, (const double *)d_q, ldq,
                            (int)nq, b->dim, kd, ld, q32, d_row_limit, (int)b->n, lim, qtm, nq_pad, tile);
-    HIP_TRY(hipGetLastError());
+    if (!pair) HIP_TRY(hipGetLastError());
 
     MfmaArgs a;
     a.bank = b->rows; a.ldb = ld; a.invn = b->invn; a.n_rows = (int)b->n;
@@ -621,14 +632,24 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     // a SIMD used to issue their 8 loads together right after the barrier); -0.5 on the 128 tile, whose
     // two independent workgroups per CU already overlap each other's issue slots
     const int ilv = ilv_env >= 0 ? ilv_env : (tile == 256 ? 1 : 0);
-    rc = tile == 256 ? launch_stage1<256, 4, 8>(a, dbg, ilv, st) : launch_stage1<128, 2, 16>(a, dbg, ilv, st);
+    if (pair) {
+        PairArgs pa;
+        pa.bank2 = b->rows2; pa.ldb2 = b->ld2; pa.invs = b->invs; pa.n_rows = (int)b->n;
+        pa.q2 = ws + o_q32; pa.ldq2 = b->ld2; pa.qinvs = (const float *)(ws + o_qs);
+        pa.lim = lim; pa.qt_maxlim = qtm; pa.nkt = kd / 32;
+        pa.nqt = nqt; pa.nseg = nseg; pa.tps = tps; pa.n_btiles = n_btiles;
+        pa.part_key = part_key; pa.part_idx = part_idx; pa.part_bound = part_bound; pa.item_map = item_map;
+        rc = pair_stage1_launch(pa, tile, dbg, st);
+    } else {
+        rc = tile == 256 ? launch_stage1<256, 4, 8>(a, dbg, ilv, st) : launch_stage1<128, 2, 16>(a, dbg, ilv, st);
+    }
     if (rc) return rc;
     if (b->ev_valid) HIP_TRY(hipEventRecord(b->ev1, st));
 
     // rigorous bound on |f32 key - exact| / ||q||: kd-term fma chain (gamma_kd), inv-norm
     // rounding, key multiply rounding, query f64->f32 rounding; 2^-24 unit roundoff.
     const double u = 5.9604644775390625e-08;
-    const double err_bound = 1.0625 * ((double)kd + 8.0) * u;
+    const double err_bound = pair ? pair_err_bound(kd) : 1.0625 * ((double)kd + 8.0) * u;
     const unsigned rgrid = (unsigned)ceil_div64(nq, 4);
     if (q_dtype == CSLAM_F32)
         hipLaunchKernelGGL(rescore_kernel<float>, dim3(rgrid), dim3(256), 0, st, b->rows, (int64_t)ld, kd, b->vv,
@@ -648,6 +669,7 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     b->stats[2] = nseg; b->stats[3] = nqt;
     b->pending_flag_list = flag_list;
     b->pending_dbg = dbg;
+    b->dbg_part_key = part_key; b->dbg_part_idx = part_idx; b->dbg_nseg = nseg; b->dbg_nq = (int)nq; b->dbg_err_bound = err_bound;
     return CSLAM_OK;
 }
 
@@ -668,6 +690,22 @@ int mfma_search(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(st));
     return mfma_search_finish(b, d_q, q_dtype, ldq, k, d_row_limit, d_out_idx, d_out_sim, d_out_cnt, st);
+}
+
+/* diagnostics (include/cslam_hip_experimental.h): the candidate lists stage 1 of the last MFMA-mode search left in the bank's
+ * workspace -- keys [nq][nseg][16] (float32, in units of q.b / ||b||), rows [nq][nseg][16] (-1 = empty) -- and the bound on
+ * |key - exact| / ||q|| handed to the certificate.  Valid until the next search of the bank. */
+CSLAM_API int cslam_debug_last_candidates(cslam_bank_t *b, int64_t nq, int *nseg, float *keys, int *rows, double *err_bound) {
+    ARG_CHECK(b && nseg, "NULL argument");
+    ARG_CHECK(b->dbg_part_key && nq >= 0 && nq <= b->dbg_nq, "no MFMA-mode search to report, or nq larger than its batch");
+    BANK_DEVICE(b);
+    *nseg = b->dbg_nseg;
+    if (err_bound) *err_bound = b->dbg_err_bound;
+    HIP_TRY(hipStreamSynchronize(b->last_stream));
+    const size_t cnt = (size_t)nq * b->dbg_nseg * KP;
+    if (keys) HIP_TRY(hipMemcpy(keys, b->dbg_part_key, cnt * 4, hipMemcpyDeviceToHost));
+    if (rows) HIP_TRY(hipMemcpy(rows, b->dbg_part_idx, cnt * 4, hipMemcpyDeviceToHost));
+    return CSLAM_OK;
 }
 
 CSLAM_API int cslam_bank_last_kernel_ms(cslam_bank_t *b, float *ms) {

@@ -1,7 +1,7 @@
 /* cslam_hip_experimental.h -- entry points of libcslam_hip.so that are NOT part of the stable C ABI (include/cslam_hip.h):
  * A/B partners of the product kernels (the f32-MFMA one-kernel convolutions, round 1's library-GEMM operand layout),
  * profiling hooks and the bench's peak micro-benchmarks.  They may change or disappear between rounds; nothing of the
- * product path (cslam_amd/*.py defaults) calls them except where stated. */
+ * product path (the defaults of the Python layer) calls them except where stated. */
 #ifndef CSLAM_HIP_EXPERIMENTAL_H
 #define CSLAM_HIP_EXPERIMENTAL_H
 #include "cslam_hip.h"
@@ -49,6 +49,12 @@ int cslam_debug_wfh_prof_dev(void *d_buf16);
  * of the launch.  The caller times both with HIP events on `stream`. */
 int cslam_peak_copy_dev(const void *d_src, void *d_dst, int64_t bytes, int variant, void *stream);
 int cslam_peak_mfma_dev(int kind, int iters, int blocks, float *d_scratch, double *flop_out, void *stream);
+
+/* The candidate lists stage 1 of the last MFMA-mode search of `bank` left in its workspace (valid until the bank's next
+ * search): keys [nq][*nseg][16] float32 in units of q.b / ||b|| (sorted per segment, -inf = empty), rows [nq][*nseg][16]
+ * (-1 = empty), and the bound on |key - exact| / ||q|| handed to the float64 certificate.  tests/test_nns_gpu.py checks the
+ * measured error of the fp16-pair stage against that bound. */
+int cslam_debug_last_candidates(cslam_bank_t *bank, int64_t nq, int *nseg, float *keys, int *rows, double *err_bound);
 
 #ifdef __cplusplus
 }

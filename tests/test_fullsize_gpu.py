@@ -1,0 +1,153 @@
+"""GPU parity at the sizes BASELINE.json's configs name (-m gpu) -- not reduced stand-ins:
+
+  C3  the full 100k-query x 100k-row x 4096-D launch the roofline is quoted on: 512 sampled queries against the CPU oracle
+      (indices identical, float64 scores within 1e-12), no query left to the exact-scan fallback;
+  C4  8 robots x 50 000 x 4096 banks, every robot's 50 000 keyframes scored against every OTHER robot's bank (best-1 per
+      (keyframe, bank) pair: cslam/loop_closure_sparse_matching.py:45-53), 224 sampled pairs against the oracle;
+  C5  candidate selection over 10^6 poses, K = 1000 (cslam/algebraic_connectivity_maximization.py:468-543 ->
+      mac/mac.py:191-233): lambda_2 of the first and of the last Frank-Wolfe iterate from `cslam_fiedler` against the reference's
+      algorithm (TraceMIN + SuperLU restated in cslam_amd/mac/fiedler.py) on the same Laplacians, K distinct edges, none
+      re-selected.
+
+The oracle (oracle/nns_oracle.c) is a scalar C restatement: sampled queries run on a thread pool (ctypes releases the GIL)."""
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_parallel(bank, queries, k, threads=16):
+    chunks = np.array_split(np.arange(queries.shape[0]), min(threads, queries.shape[0]))
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        parts = list(ex.map(lambda c: pyoracle.nns_search(bank, queries[c], k), chunks))
+    return tuple(np.concatenate([p[i] for p in parts]) for i in range(3))
+
+
+def test_c3_full_batch_100k_queries_against_100k_rows():
+    import torch
+    from cslam_amd import nns_matching as nnm
+    n = nq = 100_000
+    d, k = 4096, 5
+    gen = torch.Generator(device="cuda").manual_seed(1234)
+    bank = torch.randn((n, d), generator=gen, device="cuda")
+    bank /= bank.norm(dim=1, keepdim=True)
+    qgen = torch.Generator(device="cuda").manual_seed(4321)
+    q = torch.randn((nq, d), generator=qgen, device="cuda")
+    q /= q.norm(dim=1, keepdim=True)
+    nn = nnm.NearestNeighborsMatching()
+    nn.add_items_device(bank)
+    rows, sims, cnt = nn.search_device(q, k, mode=nnm.MODE_MFMA)
+    torch.cuda.synchronize()
+    st = nn.last_stats()
+    assert st[1] == nnm.MODE_MFMA and st[0] == 0, "uncertified queries on the C3 batch: %s" % (st,)
+    assert int(cnt.min()) == k and bool(torch.all(sims[:, :-1] >= sims[:, 1:]))
+    sel = np.random.default_rng(5).choice(nq, size=512, replace=False)
+    hb = bank.cpu().numpy()
+    hq = q[torch.from_numpy(sel).cuda()].cpu().numpy()
+    t0 = time.perf_counter()
+    oi, os_, oc = _oracle_parallel(hb, hq, k)
+    print("C3: oracle on 512 sampled queries: %.1f s" % (time.perf_counter() - t0))
+    assert np.array_equal(rows.cpu().numpy()[sel], oi) and np.array_equal(cnt.cpu().numpy()[sel], oc)
+    assert np.max(np.abs(sims.cpu().numpy()[sel] - os_)) < 1e-12
+
+
+def test_c4_eight_banks_of_50k_every_keyframe_against_every_other_bank():
+    import torch
+    from cslam_amd import nns_matching as nnm
+    R, N, D = 8, 50_000, 4096
+    banks, nns = [], []
+    for r in range(R):
+        gen = torch.Generator(device="cuda").manual_seed(1234 + r)
+        b = torch.randn((N, D), generator=gen, device="cuda")
+        b /= b.norm(dim=1, keepdim=True)
+        nn = nnm.NearestNeighborsMatching()
+        nn.add_items_device(b)
+        banks.append(b); nns.append(nn)
+    rng = np.random.default_rng(11)
+    checks = []                                                  # (query robot, bank robot, sampled keyframes, rows, sims)
+    t0 = time.perf_counter()
+    for o in range(R):                                           # bank-major: what rank o does after the all-gather
+        for r in range(R):
+            if r == o:
+                continue
+            rows, sims, cnt = nns[o].search_device(banks[r], 1, mode=nnm.MODE_MFMA)     # robot r's 50k keyframes vs bank o
+            assert nns[o].last_stats()[0] == 0
+            assert int(cnt.min()) == 1
+            if (o + r) % 2 == 0:                                 # 28 of the 56 (bank, robot) pairs, 8 keyframes each
+                sel = rng.choice(N, size=8, replace=False)
+                ts = torch.from_numpy(sel).cuda()
+                checks.append((r, o, sel, rows[ts, 0].cpu().numpy(), sims[ts, 0].cpu().numpy()))
+    torch.cuda.synchronize()
+    print("C4: 56 searches of 50k x 50k x 4096: %.1f s" % (time.perf_counter() - t0))
+    assert sum(len(c[2]) for c in checks) >= 200
+    host = {}
+    for r, o, sel, got_rows, got_sims in checks:
+        for x in (r, o):
+            if x not in host:
+                host[x] = banks[x].cpu().numpy()
+        oi, os_, _ = _oracle_parallel(host[o], host[r][sel], 1, threads=8)
+        assert np.array_equal(got_rows, oi[:, 0]), (r, o)
+        assert np.max(np.abs(got_sims - os_[:, 0])) < 1e-12
+
+
+def test_c5_selection_over_one_million_poses():
+    import random
+    from cslam_amd.algebraic_connectivity_maximization import AlgebraicConnectivityMaximization, EdgeInterRobot
+    from cslam_amd.mac import mac as mac_mod
+    from cslam_amd.mac.chain_solver_gpu import fiedler_tracemin_hip
+    from cslam_amd.mac.fiedler import fiedler_tracemin_lu
+    R, P, C_, K = 8, 125_000, 20_000, 1000
+    rnd = random.Random(0)
+    fixed = [EdgeInterRobot(r, P - 1, r + 1, P - 1, 1.0) for r in range(R - 1)]
+    cand = {}
+    while len(cand) < C_:
+        a = rnd.randrange(R)
+        b = rnd.choice([x for x in range(R) if x != a])
+        e = EdgeInterRobot(a, rnd.randrange(P), b, rnd.randrange(P), round(0.1 + 0.9 * rnd.random(), 6))
+        cand[(min(a, b), e.robot0_keyframe_id if a < b else e.robot1_keyframe_id, max(a, b),
+              e.robot1_keyframe_id if a < b else e.robot0_keyframe_id)] = e
+    ac = AlgebraicConnectivityMaximization(robot_id=0, max_nb_robots=R)        # default parameters: 'auto' solver
+    assert ac._fiedler_solver()[0] == "chain_hip"
+    ac.set_graph(list(fixed), list(cand.values()))
+    seen = []
+    real = mac_mod.MAC.fw_subset
+
+    def spy(self, w_init, k, **kw):
+        out = real(self, w_init, k, **kw)
+        seen.append((self, np.array(w_init, copy=True), np.array(out[1], copy=True), np.array(out[0], copy=True)))
+        return out
+    mac_mod.MAC.fw_subset = spy
+    try:
+        t0 = time.perf_counter()
+        before = {ac.edge_key(e) for e in ac.candidate_edges.values()}
+        first = ac.select_candidates(K, {r: True for r in range(R)})
+        print("C5: select_candidates(K = 1000) over 10^6 poses: %.1f s" % (time.perf_counter() - t0))
+    finally:
+        mac_mod.MAC.fw_subset = real
+    keys = {ac.edge_key(e) for e in first}
+    assert len(first) == K and len(keys) == K and keys <= before
+    assert not (keys & {ac.edge_key(e) for e in ac.candidate_edges.values()})
+    assert len(seen) == 1 and seen[0][0].num_poses == R * P and seen[0][0].fiedler_solver == "chain_hip"
+    m, w_first, w_last, picked = seen[0]
+    assert picked.sum() == K and abs(w_first.sum() - K) < 1e-9 and abs(w_last.sum() - K) < 1e-6
+    assert np.count_nonzero(w_last > 1e-10) > K, "the Frank-Wolfe loop did not move off its start point"
+    for tag, w in (("first", w_first), ("last", w_last)):
+        L = m.combined_laplacian(w)
+        t0 = time.perf_counter()
+        f_hip, v_hip = fiedler_tracemin_hip(L)
+        t1 = time.perf_counter()
+        f_ref, v_ref = fiedler_tracemin_lu(L, tol=1e-8, seed=np.random.RandomState(7))
+        t2 = time.perf_counter()
+        print("C5: lambda_2 of the %s iterate (%d weighted candidates): cslam_fiedler %.3e in %.2f s, reference algorithm %.3e in %.1f s"
+              % (tag, int(np.count_nonzero(w > 1e-10)), f_hip, t1 - t0, f_ref, t2 - t1))
+        assert f_ref > 0 and abs(f_hip - f_ref) <= 1e-9 * abs(f_ref), (tag, f_hip, f_ref)
+        assert min(np.abs(v_hip - v_ref).max(), np.abs(v_hip + v_ref).max()) <= 1e-6
+    # nothing is selected twice once the first selection has become fixed edges
+    ac.candidate_edges_to_fixed(list(first))
+    second = ac.select_candidates(100, {r: True for r in range(R)})
+    assert len(second) == 100 and not ({ac.edge_key(e) for e in second} & keys)

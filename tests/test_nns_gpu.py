@@ -528,3 +528,81 @@ def test_enqueue_finish_halves_equal_the_synchronous_search(nnm):
         nnm.search_multi_device([nn, nn], qd, [5, 1])
     r, s, c = (t.cpu().numpy() for t in nn.search_device(qd, 5))      # and the bank is not left locked
     assert np.array_equal(r[:, 0], want[0][:, 0])
+
+
+def _stage1_candidates(nnm, nn, nq):
+    import ctypes as C
+    nseg, eb = C.c_int(0), C.c_double(0.0)
+    lib = nn._lib
+    from cslam_amd import _lib
+    _lib.check(lib.cslam_debug_last_candidates(nn._bank, nq, C.byref(nseg), None, None, C.byref(eb)))
+    keys = np.empty((nq, nseg.value, 16), dtype=np.float32)
+    rows = np.empty((nq, nseg.value, 16), dtype=np.int32)
+    _lib.check(lib.cslam_debug_last_candidates(nn._bank, nq, C.byref(nseg), keys.ctypes.data_as(C.c_void_p),
+                                               rows.ctypes.data_as(C.c_void_p), C.byref(eb)))
+    return keys, rows, eb.value
+
+
+@pytest.mark.parametrize("d,f64", [(4096, False), (4096, True), (512, False), (96, True)])
+def test_fp16_pair_candidate_stage_error_is_inside_the_certificates_bound(nnm, monkeypatch, d, f64):
+    """The candidate stage on fp16 pairs (csrc/sim_topk_pair.hip) is a filter whose keys must stay within the bound handed to
+    the float64 certificate: |key - q.b/||b||| <= bound * ||q||.  Measured here on every candidate the stage kept (rows of
+    very different magnitudes, values spread over twelve binades inside a row), against float64 -- and against the f32-input
+    MFMA stage it replaces, whose bound is 5x tighter and whose results must be the same (both are exact after stage 2)."""
+    rng = np.random.default_rng(1000 + d)
+    n, nq = 3000, 300
+    bank = rng.standard_normal((n, d)).astype(np.float32)
+    bank *= np.exp2(rng.integers(-12, 1, size=(n, d))).astype(np.float32)          # wide dynamic range inside a row
+    bank *= np.exp2(rng.integers(-40, 40, size=(n, 1))).astype(np.float32)         # rows of very different norms
+    q = rng.standard_normal((nq, d)) * np.exp2(rng.integers(-30, 30, size=(nq, 1)))
+    q = q.astype(np.float64 if f64 else np.float32)
+    nn = make_bank(nnm, bank)
+    out = {}
+    for stage in ("pair", "f32"):
+        monkeypatch.setenv("CSLAM_MFMA_STAGE1", stage)
+        idx, sims, cnt = nn.search_batch(q, 5, mode=nnm.MODE_MFMA)
+        assert nn.last_stats()[1] == nnm.MODE_MFMA
+        keys, rows, bound = _stage1_candidates(nnm, nn, nq)
+        out[stage] = (idx, sims, cnt, bound)
+        b64, q64 = bank.astype(np.float64), q.astype(np.float64)
+        bn = np.sqrt((b64 * b64).sum(axis=1))
+        qn = np.sqrt((q64 * q64).sum(axis=1))
+        worst = 0.0
+        for j in range(nq):
+            r = rows[j].ravel()
+            ok = r >= 0
+            exact = (b64[r[ok]] @ q64[j]) / bn[r[ok]]
+            worst = max(worst, float(np.max(np.abs(keys[j].ravel()[ok].astype(np.float64) - exact)) / qn[j]))
+        assert worst <= bound, (stage, worst, bound)
+        if stage == "pair":
+            kd = (d + 31) // 32 * 32
+            assert 3 * kd * 2.0 ** -23 < bound < 1.2 * (3 * kd + 64) * 2.0 ** -23 + 3e-6      # the pair bound: ~ 3 kd 2^-23
+            assert worst < 2e-5, worst                          # and what the arithmetic really does: fp32-grade
+    oi, os_, oc = pyoracle.nns_search(bank, q, 5)
+    for stage in ("pair", "f32"):
+        assert_topk_equal(out[stage][0], out[stage][1], out[stage][2], oi, os_, oc, 1e-12)
+    assert out["pair"][3] > out["f32"][3]
+
+
+def test_fp16_pair_stage_rows_and_queries_it_cannot_scale_are_still_exact(nnm):
+    """Rows / queries whose magnitudes the power-of-two scale of the pair split cannot serve (beyond 2^+-100, non-finite
+    entries) and zero rows: the candidate stage marks them (NaN key -> always a contender / query uncertified) and the
+    float64 stages give them the score the reference gives them."""
+    rng = np.random.default_rng(2024)
+    n, d, nq = 2500, 256, 280
+    bank = unit_rows(rng, n, d)
+    bank[7] *= np.float32(1e-35)          # tiny row: cosine is scale-free, the reference ranks it like any other
+    bank[8] *= np.float32(3e35)           # huge row
+    bank[9] = 0.0                         # zero row: NaN similarity, ranks first (reference: argsort()[::-1])
+    bank[10, 3] = np.inf                  # non-finite row: NaN similarity
+    q = unit_rows(rng, nq, d)
+    q[0] = bank[7] * np.float32(1e30)     # best match of q[0] is the tiny row
+    q[1] = bank[8] * np.float32(1e-36)
+    q[2] *= np.float32(1e-38)             # query below the servable range
+    q[3] *= np.float32(1e37)
+    nn = make_bank(nnm, bank)
+    idx, sims, cnt = nn.search_batch(q, 5, mode=nnm.MODE_MFMA)
+    assert nn.last_stats()[1] == nnm.MODE_MFMA
+    oi, os_, oc = pyoracle.nns_search(bank, q, 5)
+    assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
+    assert 7 in idx[0] and 8 in idx[1]
