@@ -409,13 +409,16 @@ __global__ __launch_bounds__(256) void rescore_kernel(
     }
     unsigned long long cmask = __ballot(cand.idx >= 0);
     const int ncand = __popcll(cmask);
-    // contenders: the first KP candidates whose f32 key is within 2e of the k-th f32 key
+    // contenders: the candidates (at most the 64 the merged list holds) whose f32 key is within 2e of the k-th f32 key.
+    // (Round 2 capped them at KP = 16: enough for the f32-input stage's bound, 2e = 5e-4 at 4096-D; with the fp16-pair stage's
+    // 2e = 3e-3 a 100k-row random bank has ~4 rows in that window on average and 0.06 % of the queries had more than 11 --
+    // each of them a needless trip through the exact-scan fallback.)
     const double e_abs = err_bound * qnorm;                 // error bound in key units (dot / ||b||)
     const int kth = (k - 1 < ncand - 1) ? k - 1 : ncand - 1;
     const double ck_k = ncand > 0 ? cand.key_at(kth > 0 ? kth : 0) : -INFINITY;
     int nres = 0;
     {
-        bool want = cand.idx >= 0 && lane < KP && (cand.key >= ck_k - 2.0 * e_abs || !(e_abs == e_abs));
+        bool want = cand.idx >= 0 && (cand.key >= ck_k - 2.0 * e_abs || !(e_abs == e_abs));
         unsigned long long wm_ = __ballot(want);
         nres = __popcll(wm_);            // candidates are sorted, so `want` lanes are a prefix
         if (nres < ncand) {              // everything after the prefix is treated as "not kept"

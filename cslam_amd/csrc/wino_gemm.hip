@@ -279,6 +279,208 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_h2_kernel(WinoGemmArgs p) {
     }
 }
 
+// ---- the same products with the COLUMN half of the output transform folded in ("Z form") ------------------------------
+// Y = A^T M A per tile and channel; Z_i[q] = sum_j M[6 i + j] A^T[q][j] (q = 0..3) needs the six frequencies of ONE row i of
+// the 6 x 6 frequency grid only.  A work item here = (row i, 128-tile row block, 128-channel column block): the K loops of
+// its six frequencies run back to back, each finished 128 x 128 product is folded into four register-resident Z planes
+// (a few hundred v_fma per wave next to thousands of MFMA cycles) and only those leave the chip:
+//     Z [24][T][Cout] float32 (plane 4 i + q)  =  2/3 of M's bytes, written here and read by wino4_output_z_kernel,
+// which finishes with Y[p][q] = sum_i A^T[p][i] Z_i[q].  Same operands, same loader, same LDS image and fragment addressing
+// as wino_gemm_h2_kernel; 128 x 128 tiles (8 waves as 2 x 4, wave tile 64 x 32: 32 accumulator + 128 Z registers), ring of
+// three 32 KB stages.  Used where the product is HBM-bound (Cin <= 256: V2 in + M out), DESIGN.md section 3.6.
+__constant__ float WZ_AT[6][4] = {{1.f, 0.f, 0.f, 0.f}, {1.f, 1.f, 1.f, 1.f}, {1.f, -1.f, 1.f, -1.f},
+                                  {1.f, 2.f, 4.f, 8.f}, {1.f, -2.f, 4.f, -8.f}, {0.f, 0.f, 0.f, 1.f}};
+
+template <int NS>
+__global__ __launch_bounds__(512, 2) void wino_zgemm_h2_kernel(WinoGemmArgs p) {
+    constexpr int TM = 128, TN = 128, MT = 2;
+    constexpr int OPA = TM * WG_ROWB, OPB = TN * WG_ROWB;
+    constexpr int STAGE = OPA + OPB;
+    constexpr int NLA = TM * 8 / 512, NLB = TN * 8 / 512;   // 2 + 2 sixteen-byte chunks per thread per stage
+    constexpr int L = NLA + NLB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    const int xcd = blockIdx.x & 7, j8 = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int q8 = p.n_items >> 3, r8 = p.n_items & 7;
+    const int x_beg = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int x_cnt = q8 + (xcd < r8 ? 1 : 0);
+    const int n_mine = j8 < x_cnt ? (x_cnt - j8 + per_xcd - 1) / per_xcd : 0;
+    if (n_mine == 0) return;
+
+    const int64_t pitch = (int64_t)p.nk * WG_ROWB;
+    int rowA[NLA], offA[NLA], rowB[NLB], offB[NLB];
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+        const int pch = i * 512 + tid, r = pch >> 3, slot = pch & 7;
+        rowA[i] = r; offA[i] = (slot ^ ((r >> 1) & 7)) << 4;
+    }
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+        const int pch = i * 512 + tid, r = pch >> 3, slot = pch & 7;
+        rowB[i] = r; offB[i] = (slot ^ ((r >> 1) & 7)) << 4;
+    }
+    const int wave_chunk = wave * 1024;
+
+    struct Item { int gi, mt, nt; };                         // gi = row of the frequency grid (0..5)
+    auto decode = [&](int k) {
+        const int it = x_beg + j8 + k * per_xcd;
+        Item c;
+        c.nt = it % p.n_nt;
+        const int rest = it / p.n_nt;
+        c.mt = rest % p.n_mt;
+        c.gi = rest / p.n_mt;
+        return c;
+    };
+    const char *gA[NLA], *gB[NLB];
+    auto point_at = [&](const Item &c, int j) {              // K block 0 of frequency 6 gi + j of the item
+        const int xi = 6 * c.gi + j;
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            int64_t row = (int64_t)c.mt * TM + rowA[i];
+            if (row > p.T - 1) row = p.T - 1;
+            gA[i] = p.V2 + ((int64_t)xi * p.T + row) * pitch + offA[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NLB; ++i)
+            gB[i] = p.U2 + ((int64_t)xi * p.Cout + (int64_t)c.nt * TN + rowB[i]) * pitch + offB[i];
+    };
+    auto load_part_a = [&](int stage, int kt, int i) {
+        wg_glds16(gA[i] + kt * WG_ROWB, smem + stage * STAGE + i * (512 * 16) + wave_chunk);
+    };
+    auto load_part_b = [&](int stage, int kt, int i) {
+        wg_glds16(gB[i] + kt * WG_ROWB, smem + stage * STAGE + OPA + i * (512 * 16) + wave_chunk);
+    };
+
+    const int swz = (lane >> 1) & 7;
+    int foff[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int lo = 0; lo < 2; ++lo) foff[s][lo] = ((4 * lo + 2 * s + h) ^ swz) << 4;
+    const int arow0 = (wm * (TM / 2) + l31) * WG_ROWB;
+    const int brow0 = (wn * 32 + l31) * WG_ROWB;
+
+    f32x16 acc[MT], Z[4][MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            acc[m][r] = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Z[q][m][r] = 0.0f;
+        }
+
+    // the loader runs NS - 1 stages ahead: (l_item, l_j, l_kt) = the next stage to fetch; a stage = one K block of one of the
+    // item's six frequencies
+    const int total = n_mine * 6 * p.nk;
+    int l_item = 0, l_j = 0, l_kt = 0, l_stage = 0, fetched = 0;
+    Item l_cur = decode(0);
+    Item cur_item = l_cur;
+    point_at(l_cur, 0);
+    auto advance_loader = [&]() {
+        ++fetched;
+        l_stage = l_stage + 1 == NS ? 0 : l_stage + 1;
+        if (++l_kt == p.nk) {
+            l_kt = 0;
+            if (++l_j == 6) { l_j = 0; ++l_item; if (fetched < total) l_cur = decode(l_item); }
+            if (fetched < total) point_at(l_cur, l_j);
+        }
+    };
+#pragma unroll 1
+    for (int pre = 0; pre < NS - 1; ++pre) {
+        if (fetched < total) {
+#pragma unroll
+            for (int i = 0; i < NLA; ++i) load_part_a(l_stage, l_kt, i);
+#pragma unroll
+            for (int i = 0; i < NLB; ++i) load_part_b(l_stage, l_kt, i);
+            advance_loader();
+        }
+    }
+    if (NS == 2 || total == 1) __builtin_amdgcn_s_waitcnt(0); else WG_VMCNT(L);
+    __syncthreads();
+
+    int k_item = 0, jf = 0, kt = 0, cur = 0;
+    bool store_pending = false;
+    Item st_item = cur_item;
+    auto store_z = [&](const Item &c) {
+        // lane = column, 128-byte runs per row (as wino_gemm_h2_kernel); four planes 4 gi + q
+        const int row_base = c.mt * TM + wm * (TM / 2) + 4 * h;
+        const int col = c.nt * TN + wn * 32 + l31;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float *zo = p.M + ((int64_t)(4 * c.gi + q) * p.T + row_base) * p.Cout + col;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = m * 32 + (r & 3) + 8 * (r >> 2);
+                    if (row_base + ro < p.T) __builtin_nontemporal_store(Z[q][m][r], zo + (int64_t)ro * p.Cout);
+                    Z[q][m][r] = 0.0f;
+                }
+        }
+    };
+    for (int it = 0; it < total; ++it) {
+        if (store_pending) { store_z(st_item); store_pending = false; }
+        const bool fetch = fetched < total;
+        const char *sA = smem + cur * STAGE;
+        const char *sB = sA + OPA;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 ah[MT], al[MT], bh, bl;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                ah[m] = *(const f16x8 *)(sA + arow0 + m * 32 * WG_ROWB + foff[s][0]);
+                al[m] = *(const f16x8 *)(sA + arow0 + m * 32 * WG_ROWB + foff[s][1]);
+            }
+            bh = *(const f16x8 *)(sB + brow0 + foff[s][0]);
+            bl = *(const f16x8 *)(sB + brow0 + foff[s][1]);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh, acc[m], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl, acc[m], 0, 0, 0);
+            if (fetch) {
+#pragma unroll
+                for (int i = s * (NLA / 2); i < (s + 1) * (NLA / 2); ++i) load_part_a(l_stage, l_kt, i);
+#pragma unroll
+                for (int i = s * (NLB / 2); i < (s + 1) * (NLB / 2); ++i) load_part_b(l_stage, l_kt, i);
+            }
+        }
+        if (fetch) advance_loader();
+
+        if (kt == p.nk - 1) {
+            // frequency 6 gi + jf is complete: fold it into the four Z planes (coefficients A^T[q][jf], wave-uniform)
+            const float c0 = WZ_AT[jf][0], c1 = WZ_AT[jf][1], c2 = WZ_AT[jf][2], c3 = WZ_AT[jf][3];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float a = acc[m][r];
+                    Z[0][m][r] = fmaf(c0, a, Z[0][m][r]);
+                    Z[1][m][r] = fmaf(c1, a, Z[1][m][r]);
+                    Z[2][m][r] = fmaf(c2, a, Z[2][m][r]);
+                    Z[3][m][r] = fmaf(c3, a, Z[3][m][r]);
+                    acc[m][r] = 0.0f;
+                }
+            if (jf == 5) { store_pending = true; st_item = cur_item; }
+        }
+        if (NS == 2 || !fetch) __builtin_amdgcn_s_waitcnt(0); else WG_VMCNT(L);
+        __builtin_amdgcn_s_barrier();
+        cur = cur + 1 == NS ? 0 : cur + 1;
+        if (++kt == p.nk) {
+            kt = 0;
+            if (++jf == 6) { jf = 0; ++k_item; if (it + 1 < total) cur_item = decode(k_item); }
+        }
+    }
+    if (store_pending) store_z(st_item);
+}
+
 // ---- input transform into the pair layout ------------------------------------------------------------------------------
 __device__ __forceinline__ float wg_h_scale(unsigned amax_bits) {       // = wino_h3_scale (winograd.hip)
     const float a = fminf(fmaxf(__uint_as_float(amax_bits), 1e-30f), 1e30f);
@@ -459,4 +661,39 @@ int cslam_pair_gemm_launch(const void *d_A2, const void *d_B2, int nxi, int64_t 
     a.n_mt = a.n_nt = a.n_items = 0;
     a.nxi = nxi;
     return wino_gemm_launch<256, 128, 3>(a, 0, st);
+}
+
+/* The Z form (wino_zgemm_h2_kernel above): d_Z [24][T][Cout] float32, plane 4 i + q = sum_j (V U)[6 i + j] A^T[q][j]; finished by
+ * cslam_wino4_output_z_dev (winograd.hip).  Cin a multiple of 32, Cout of 128. */
+CSLAM_API int cslam_wino_zgemm_h2_dev(const void *d_V2, const void *d_U2, int64_t T, int Cin, int Cout, float *d_Z, void *stream) {
+    PTR_DEVICE(d_V2);
+    ARG_CHECK(d_V2 && d_U2 && d_Z, "NULL argument");
+    ARG_CHECK(T >= 1 && T < (1LL << 31), "T out of range");
+    ARG_CHECK(Cin >= 32 && (Cin % 32) == 0, "Cin must be a multiple of 32");
+    ARG_CHECK(Cout >= 128 && (Cout % 128) == 0, "Cout must be a multiple of 128");
+    WinoGemmArgs a;
+    a.V2 = (const char *)d_V2; a.U2 = (const char *)d_U2; a.M = d_Z;
+    a.T = (int)T; a.Cin = Cin; a.Cout = Cout; a.nk = Cin / 32;
+    a.nxi = 6;
+    a.n_mt = (int)ceil_div64(T, 128);
+    a.n_nt = Cout / 128;
+    const int64_t items = (int64_t)6 * a.n_mt * a.n_nt;
+    ARG_CHECK(items < (1LL << 31), "too many work items");
+    a.n_items = (int)items;
+    int n_cu = cslam_cu_count();
+    ARG_CHECK(n_cu > 0, "no HIP device");
+    if (n_cu < 8) n_cu = 8;
+    constexpr int NS = 3;
+    constexpr int lds = NS * (128 + 128) * WG_ROWB;
+    int grid = n_cu - n_cu % 8;
+    if ((int64_t)grid > round_up64(a.n_items, 8)) grid = (int)round_up64(a.n_items, 8);
+    static DeviceOnce once;
+    int once_dev;
+    if (once.todo(&once_dev)) {
+        HIP_TRY(hipFuncSetAttribute((const void *)wino_zgemm_h2_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        once.done(once_dev);
+    }
+    hipLaunchKernelGGL((wino_zgemm_h2_kernel<NS>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
 }

@@ -660,6 +660,100 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const float *__restri
     }
 }
 
+// The second half of the output transform for the Z form of the products (wino_zgemm_h2_kernel, wino_gemm.hip):
+// Z [24][T][C], plane 4 i + q = sum_j M[6 i + j] A^T[q][j]  ->  Y[p][q] = sum_i A^T[p][i] Z_i[q], then exactly the epilogue of
+// wino4_output_kernel (rescale, bias, ReLU, max |y|, MaxPool2d).  24 loads per tile and channel pair instead of 36.
+template <bool RELU, bool POOL>
+__global__ __launch_bounds__(256) void wino4_output_z_kernel(const float *__restrict__ Zp, const float *__restrict__ bias,
+                                                             int B, int H, int W, int C, float *__restrict__ y,
+                                                             const unsigned *__restrict__ amax, float inv_su,
+                                                             unsigned *__restrict__ amax_out) {
+    __shared__ unsigned wg_amax;
+    if (amax_out) {
+        if (threadIdx.x == 0) wg_amax = 0u;
+        __syncthreads();
+    }
+    const int c2n = C >> 1;
+    const int64_t gid0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int TH = (H + 3) >> 2, TW = (W + 3) >> 2;
+    const int64_t T = (int64_t)B * TH * TW;
+    const bool live = gid0 < T * c2n;
+    const int64_t gid = live ? gid0 : 0;
+    const int c2 = (int)(gid % c2n);
+    const int64_t t = gid / c2n;
+    const int64_t plane = T * C;
+    const float *p = Zp + t * C + 2 * c2;
+    const float inv = amax ? inv_su / wino_h3_scale(*amax) : 1.0f;
+    const f2 bv = bias ? *((const f2 *)bias + c2) : (f2)(0.0f);
+    const int tj = (int)(t % TW);
+    const int ti = (int)((t / TW) % TH);
+    const int b = (int)(t / ((int64_t)TW * TH));
+    f2 o[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f2 m[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) m[i] = __builtin_nontemporal_load((const f2 *)(p + (int64_t)(4 * i + q) * plane));
+        wino4_at(m[0], m[1], m[2], m[3], m[4], m[5], o[0][q], o[1][q], o[2][q], o[3][q]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            o[i][j] = amax ? o[i][j] * inv + bv : o[i][j] + bv;
+            if (RELU) o[i][j] = __builtin_elementwise_max(o[i][j], (f2)(0.0f));
+        }
+    if (amax_out) {
+        float m = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (live && 4 * ti + i < H && 4 * tj + j < W) m = fmaxf(m, fmaxf(fabsf(o[i][j].x), fabsf(o[i][j].y)));
+        atomicMax(&wg_amax, __float_as_uint(m));
+        __syncthreads();
+        if (threadIdx.x == 0 && wg_amax > *(volatile unsigned *)amax_out) atomicMax(amax_out, wg_amax);
+    }
+    if (POOL) {
+        const int Ho = H >> 1, Wo = W >> 1;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                f2 v = __builtin_elementwise_max(__builtin_elementwise_max(o[2 * i][2 * j], o[2 * i][2 * j + 1]),
+                                                 __builtin_elementwise_max(o[2 * i + 1][2 * j], o[2 * i + 1][2 * j + 1]));
+                if (live && 2 * ti + i < Ho && 2 * tj + j < Wo)
+                    *((f2 *)(y + (((int64_t)b * Ho + 2 * ti + i) * Wo + 2 * tj + j) * C) + c2) = v;
+            }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (live && 4 * ti + i < H && 4 * tj + j < W)
+                    *((f2 *)(y + (((int64_t)b * H + 4 * ti + i) * W + 4 * tj + j) * C) + c2) = o[i][j];
+    }
+}
+
+/* Output transform of the Z form (cslam_wino_zgemm_h2_dev): arguments as cslam_wino4_output_scaled_dev without the residual. */
+CSLAM_API int cslam_wino4_output_z_dev(const float *d_Z, const float *d_bias, int B, int H, int W, int C, int relu, int pool,
+                                       const unsigned *d_amax, float inv_su, unsigned *d_amax_out, float *d_y, void *stream) {
+    PTR_DEVICE(d_Z);
+    ARG_CHECK(d_Z && d_y, "NULL argument");
+    ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
+    ARG_CHECK(C >= 2 && (C % 2) == 0, "C must be even");
+    const int64_t n = (int64_t)B * ((H + 3) / 4) * ((W + 3) / 4) * (C / 2);
+    ARG_CHECK(ceil_div64(n, 256) < (1LL << 31), "too many tiles for one launch");
+    dim3 grid((unsigned)ceil_div64(n, 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (relu && pool) hipLaunchKernelGGL((wino4_output_z_kernel<true, true>), grid, block, 0, st, d_Z, d_bias, B, H, W, C, d_y, d_amax, inv_su, d_amax_out);
+    else if (relu) hipLaunchKernelGGL((wino4_output_z_kernel<true, false>), grid, block, 0, st, d_Z, d_bias, B, H, W, C, d_y, d_amax, inv_su, d_amax_out);
+    else if (pool) hipLaunchKernelGGL((wino4_output_z_kernel<false, true>), grid, block, 0, st, d_Z, d_bias, B, H, W, C, d_y, d_amax, inv_su, d_amax_out);
+    else hipLaunchKernelGGL((wino4_output_z_kernel<false, false>), grid, block, 0, st, d_Z, d_bias, B, H, W, C, d_y, d_amax, inv_su, d_amax_out);
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
 // Measured and rejected: evaluating the first layer (3 -> 64 + ReLU) inside this layer's input transform for
 // conv1_2, so that the 12.8 MB-per-frame activation between them never touches HBM.  The fused kernel (6x6 window
 // of first-layer outputs recomputed per tile from an 8x8x3 LDS patch, 972 packed FMAs per thread, 256 VGPRs) ran

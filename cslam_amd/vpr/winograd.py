@@ -194,6 +194,12 @@ def use_tuned_gemms():
         warnings.warn("cslam_amd: tuned GEMM table not loaded (%s)" % e)
 
 
+def _z_form(cin):
+    """Z form of the pair products (GEMM + column half of the output transform) for layers with at most CSLAM_WINO_Z input
+    channels (default 256: where the product is HBM-bound; 0 switches it off, 512 = every layer)."""
+    return cin <= int(os.environ.get("CSLAM_WINO_Z", "256"))
+
+
 def wino_conv3x3(ws, x, U, U4, bias, relu, pool=False, residual=None, U3=None, amax_in=None, amax_out=None, U2=None):
     """3x3 / stride 1 / pad 1 convolution of x [B,Cin,H,W] (channels_last storage, any H and W) through the
     Winograd pipeline; U / U4 from `wino_weights` (U4 None = F(2x2,3x3) only).  bias [Cout] or None, residual
@@ -225,9 +231,18 @@ def wino_conv3x3(ws, x, U, U4, bias, relu, pool=False, residual=None, U3=None, a
         V2 = ws._buf("V", 36 * T * Cin, x.device)                      # 36 x T x 2 Cin halfs
         M = ws._buf("M", 36 * T * Cout, x.device)
         _lib.check(lib.cslam_wino4_input_h2_dev(_p(x), B, H, W, Cin, _p(slot), _p(V2), s))
-        _lib.check(lib.cslam_wino_gemm_h2_dev(_p(V2), _p(U2[0]), T, Cin, Cout, _p(M), s))
         Ho, Wo = (H // 2, W // 2) if pool else (H, W)
         y = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        if residual is None and _z_form(Cin):
+            # HBM-bound products (Cin <= 256): the column half of the output transform is folded into the GEMM, which then
+            # writes -- and the output kernel reads -- 24 instead of 36 planes (csrc/wino_gemm.hip `wino_zgemm_h2_kernel`)
+            _lib.check(lib.cslam_wino_zgemm_h2_dev(_p(V2), _p(U2[0]), T, Cin, Cout, _p(M), s))
+            _lib.check(lib.cslam_wino4_output_z_dev(
+                _p(M), _p(bias) if bias is not None else None, B, H, W, Cout, int(relu), int(pool), _p(slot), float(U2[1]),
+                _p(amax_out) if amax_out is not None else None, _p(y), s))
+            ws.amax_written = amax_out is not None
+            return y
+        _lib.check(lib.cslam_wino_gemm_h2_dev(_p(V2), _p(U2[0]), T, Cin, Cout, _p(M), s))
         if residual is not None:
             residual = residual.contiguous(memory_format=torch.channels_last)
             assert residual.shape == y.shape and not pool

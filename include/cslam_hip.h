@@ -394,6 +394,13 @@ int cslam_wino4_output_scaled_dev(const float *d_M, const float *d_bias, const f
 int cslam_wino4_input_h2_dev(const float *d_x, int B, int H, int W, int C, const unsigned *d_amax, void *d_V2,
                              void *stream);
 int cslam_wino_gemm_h2_dev(const void *d_V2, const void *d_U2, int64_t T, int Cin, int Cout, float *d_M, void *stream);
+/* The same products with the column half of the output transform Y = A^T M A folded in (the "Z form", for the layers whose
+ * product is HBM-bound, Cin <= 256): d_Z [24][T][Cout] float32, plane 4 i + q = sum_j M[6 i + j] A^T[q][j] -- 2/3 of M's bytes
+ * written and read.  cslam_wino4_output_z_dev finishes: Y[p][q] = sum_i A^T[p][i] Z_i[q], then the epilogue of
+ * cslam_wino4_output_scaled_dev (no residual input). */
+int cslam_wino_zgemm_h2_dev(const void *d_V2, const void *d_U2, int64_t T, int Cin, int Cout, float *d_Z, void *stream);
+int cslam_wino4_output_z_dev(const float *d_Z, const float *d_bias, int B, int H, int W, int C, int relu, int pool,
+                             const unsigned *d_amax, float inv_su, unsigned *d_amax_out, float *d_y, void *stream);
 
 /* The one-kernel F(4x4,3x3) convolution of the 64-input-channel layers (64 -> 64 / 128: VGG-16 conv1_2 and conv2_1,
  * netvlad.py:163-171 + the call at :227; the BasicBlock convolutions of ResNet-18/34 layer1, cosplace_utils/network.py:38-68,

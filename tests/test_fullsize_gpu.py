@@ -3,7 +3,7 @@
   C3  the full 100k-query x 100k-row x 4096-D launch the roofline is quoted on: 512 sampled queries against the CPU oracle
       (indices identical, float64 scores within 1e-12), no query left to the exact-scan fallback;
   C4  8 robots x 50 000 x 4096 banks, every robot's 50 000 keyframes scored against every OTHER robot's bank (best-1 per
-      (keyframe, bank) pair: cslam/loop_closure_sparse_matching.py:45-53), 224 sampled pairs against the oracle;
+      (keyframe, bank) pair: cslam/loop_closure_sparse_matching.py:45-53), 240 sampled pairs against the oracle;
   C5  candidate selection over 10^6 poses, K = 1000 (cslam/algebraic_connectivity_maximization.py:468-543 ->
       mac/mac.py:191-233): lambda_2 of the first and of the last Frank-Wolfe iterate from `cslam_fiedler` against the reference's
       algorithm (TraceMIN + SuperLU restated in cslam_amd/mac/fiedler.py) on the same Laplacians, K distinct edges, none
@@ -78,8 +78,8 @@ def test_c4_eight_banks_of_50k_every_keyframe_against_every_other_bank():
             rows, sims, cnt = nns[o].search_device(banks[r], 1, mode=nnm.MODE_MFMA)     # robot r's 50k keyframes vs bank o
             assert nns[o].last_stats()[0] == 0
             assert int(cnt.min()) == 1
-            if (o + r) % 2 == 0:                                 # 28 of the 56 (bank, robot) pairs, 8 keyframes each
-                sel = rng.choice(N, size=8, replace=False)
+            if (o + r) % 2 == 0:                                 # 24 of the 56 (bank, robot) pairs, 10 keyframes each
+                sel = rng.choice(N, size=10, replace=False)
                 ts = torch.from_numpy(sel).cuda()
                 checks.append((r, o, sel, rows[ts, 0].cpu().numpy(), sims[ts, 0].cpu().numpy()))
     torch.cuda.synchronize()
