@@ -179,9 +179,18 @@ def main():
     rows_mode = world > 1 and a.shard_mode == "rows"
     offs = [g * a.bank_rows // world for g in range(world + 1)] if rows_mode else [0, a.bank_rows]
     local_rows = offs[rank + 1] - offs[rank] if rows_mode else a.bank_rows     # rows resident on this GPU
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    bank = torch.randn((local_rows, a.dim), generator=gen, device=dev, dtype=torch.float32)
-    bank /= bank.norm(dim=1, keepdim=True)
+    if rows_mode:
+        # ONE seeded bank at every N: rank g holds rows [offs[g], offs[g + 1]) of the bank the N = 1 run builds (same seed,
+        # same generator stream, sliced), so an N-rank result is checkable against the unsharded bank (`sharded_check` below)
+        gen = torch.Generator(device=dev).manual_seed(1234)
+        whole = torch.randn((a.bank_rows, a.dim), generator=gen, device=dev, dtype=torch.float32)
+        whole /= whole.norm(dim=1, keepdim=True)
+        bank = whole[offs[rank]:offs[rank + 1]].clone()
+        del whole
+    else:
+        gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+        bank = torch.randn((local_rows, a.dim), generator=gen, device=dev, dtype=torch.float32)
+        bank /= bank.norm(dim=1, keepdim=True)
     nn = nnm.NearestNeighborsMatching(device=local_rank)
     nn.add_items_device(bank)
     extractor = None
@@ -230,8 +239,26 @@ def main():
                 for s in range(0, a.batch, a.extract_chunk)]
         return torch.cat(outs)
 
+    # N = 1: the search of step i is ENQUEUED behind its extraction (cslam_bank_search_enqueue_dev) and FINISHED -- one event
+    # wait for the certificate count, no stream synchronisation -- after step i + 1 has been enqueued: no host
+    # synchronisation between extract chunks and search, the GPU queue never drains inside the timed region.
+    pending = []
+
+    def retire():
+        while pending:
+            pending.pop(0).finish()
+            kernel_ms.append(nn.last_kernel_ms())      # events of a search that has finished: no wait
+
     def step():
-        return matcher.step(extract())
+        if world > 1:
+            return matcher.step(extract())
+        d = extract()                                  # enqueued; the host runs ahead of the GPU
+        retire()                                       # step i - 1's search: done long ago, its count is on the host
+        pending.append(nn.search_device_async(d, a.k, mode=nnm.MODE_MFMA))
+        return pending[-1]
+
+    def flush():
+        retire()
 
     def barrier():
         if world > 1:
@@ -243,6 +270,7 @@ def main():
         t0 = time.perf_counter()
         for _ in range(n):
             fn()
+        flush()
         barrier()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -251,12 +279,45 @@ def main():
             dt = float(t.item())
         return dt
 
+    from cslam_amd import _lib as _clib
+    import ctypes as _C
     for _ in range(a.warmup):
         step()
+    flush()
     kernel_ms.clear()
+    trunk_times = None
+    if extractor is not None:
+        _clib.check(_clib.load().cslam_trunk_timing(1))       # two HIP events per product launch, on the launch stream
     dt = timed(step, a.steps)
+    if extractor is not None:
+        tt = (_C.c_double * 8)()
+        _clib.check(_clib.load().cslam_trunk_timing_read(_C.byref(tt)))
+        _clib.check(_clib.load().cslam_trunk_timing(0))
+        trunk_times = [float(x) for x in tt]
     step_kernel_ms = [m for m in kernel_ms if m > 0]
     value = world * a.batch * a.steps / dt
+
+    # ---- N > 1, rows mode: the sharded step's answer against the UNSHARDED bank (outside the timed region): every rank rebuilds
+    # the whole seeded bank, searches its own step's descriptors in it on its own GPU and compares rows / float64 scores / counts
+    sharded_check = None
+    if rows_mode and extractor is not None:
+        d_chk = extract()
+        got = matcher.step(d_chk)
+        gen = torch.Generator(device=dev).manual_seed(1234)
+        whole = torch.randn((a.bank_rows, a.dim), generator=gen, device=dev, dtype=torch.float32)
+        whole /= whole.norm(dim=1, keepdim=True)
+        nn_whole = nnm.NearestNeighborsMatching(device=local_rank)
+        nn_whole.add_items_device(whole)
+        want = nn_whole.search_device(d_chk, a.k, mode=nnm.MODE_MFMA)
+        ok = bool(torch.equal(got[0], want[0]) and torch.equal(got[2], want[2]) and
+                  float((got[1] - want[1]).abs().max()) <= 1e-12)
+        flag = torch.tensor([1 if ok else 0], device="cpu" if a.debug_shared_gpu else dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        sharded_check = {"equal_to_unsharded_bank_on_every_rank": bool(int(flag.item()) == 1),
+                         "what": "top-%d rows, counts and float64 scores (<= 1e-12) of one step's %d descriptors per rank: "
+                                 "row-sharded path over %d ranks vs a single-GPU search of the whole %d-row bank" % (a.k, a.batch, world, a.bank_rows)}
+        del whole, nn_whole
+        torch.cuda.empty_cache()
 
     # ---- the two legs separately (rank-local work, same barriers) ----
     extract_only = None
@@ -307,28 +368,55 @@ def main():
     match_kernel_ms = float(np.mean(kernel_ms))
     uncertified = nn.last_stats()[0]
 
-    # roofline of the dominant hand-written kernel, from the launches inside the timed steps
-    # (algorithmic work: 2*D flop per (query, bank row) pair)
+    # ---- rooflines.  `roofline` describes the TIMED STEP: the kernel north_star names (the D.D^T similarity + top-k
+    # candidate stage), from its launches inside the timed steps (HIP events on the launch stream).  The separate 100k-query
+    # C3 batch is `roofline_c3_batch`; the step's largest consumer (the trunk's pair products) is `roofline_step_largest`.
+    # Algorithmic work of the match: 2*D flop per (query, bank row) pair.  The candidate stage runs on the
+    # fp16 matrix pipe with THREE fp16 products per fp32-grade product (exact hi/lo pairs, csrc/sim_topk_pair.hip), so its
+    # roofline is the dense fp16 MFMA peak / 3, in fp32-equivalent TFLOP/s; CSLAM_MFMA_STAGE1=f32 selects the f32-input
+    # MFMA stage of rounds 1-2, priced against the f32 MFMA peak.
     nq_step = world * a.batch if world > 1 else a.batch
-    # primary: the full C3 batch launch (100k queries) of the timed match leg; the smaller
-    # launches inside the extract+match steps are reported alongside
-    ach = 2.0 * nqm * local_rows * a.dim / (match_kernel_ms * 1e-3) / 1e12
-    src = "match-leg launches (%d queries), HIP events on the launch stream" % nqm
-    in_step = None
-    if step_kernel_ms and world == 1:
-        in_step = round(2.0 * nq_step * local_rows * a.dim / (np.mean(step_kernel_ms) * 1e-3) / 1e12, 2)
-    # HBM-side traffic per launch: the committed rocprofv3 PMC passes of this same launch (profiles/pmc_by_kernel.json,
-    # looked up by kernel name and launch shape; FETCH_SIZE x2 correction per the MI355X guide) -- it cannot be
-    # collected inside an unprofiled run
+    pair_stage = not os.environ.get("CSLAM_MFMA_STAGE1", "pair").startswith("f")
+    mm_peak = FP16_MFMA_PEAK_TFLOPS / 3.0 if pair_stage else FP32_MFMA_PEAK_TFLOPS
+    mm_unit = ("TFLOP/s fp32-equivalent (3 fp16 MFMA products per product: peak = 2500 / 3)" if pair_stage else "TFLOP/s")
+    mm_kernel = "sim_topk_pair_kernel" if pair_stage else "sim_topk_mfma_kernel"
     peaks = measure_peaks(torch, dev) if rank == 0 else None
-    pm = pmc_entry("sim_topk_mfma_kernel", queries=nqm, bank_rows=local_rows, dim=a.dim)
-    roofline = {"bound": "mfma", "kernel": "sim_topk_mfma_kernel", "achieved": round(ach, 2),
-                "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TFLOPS, 4),
+
+    def match_roofline(nq_launch, ms, source, pmc_queries):
+        ach = 2.0 * nq_launch * local_rows * a.dim / (ms * 1e-3) / 1e12
+        pm = pmc_entry(mm_kernel, queries=pmc_queries, bank_rows=local_rows, dim=a.dim)
+        return {"bound": "mfma", "kernel": mm_kernel, "achieved": round(ach, 2), "peak": round(mm_peak, 1), "unit": mm_unit,
+                "frac": round(ach / mm_peak, 4), "kernel_ms": round(ms, 3), "queries_per_launch": nq_launch,
+                "fp16_TFLOPs_issued": round(3 * ach, 1) if pair_stage else None,
                 "traffic": pm["traffic_bytes"] if pm else None,
                 "traffic_source": (pm["source"] + "; L2 hit rate %.2f" % pm.get("l2_hit_rate", float("nan"))) if pm else None,
-                "source": src, "kernel_ms": round(match_kernel_ms, 3), "in_step_achieved": in_step,
-                "peak_measured": peaks and peaks["mfma_f32_TFLOPs"],
-                "frac_of_measured": round(ach / peaks["mfma_f32_TFLOPs"], 4) if peaks and peaks["mfma_f32_TFLOPs"] else None}
+                "source": source}
+    roofline_c3 = match_roofline(nqm, match_kernel_ms, "match-only leg (%d queries per launch), HIP events on the launch stream" % nqm, nqm)
+    if step_kernel_ms and world == 1:
+        roofline = match_roofline(nq_step, float(np.mean(step_kernel_ms)),
+                                  "the %d launches inside the timed steps, HIP events on the launch stream" % len(step_kernel_ms), nq_step)
+    else:
+        roofline = dict(roofline_c3, note="N > 1: per-launch events of the in-step searches are not collected; this is the match-only leg")
+    roofline["peaks_measured_note"] = ("in-run micro-benchmarks (peaks_measured) are reported beside the nominal peaks, not used "
+                                       "as denominators: under load the chip clocks to its power budget")
+    roofline_step_largest = None
+    if trunk_times is not None and rank == 0 and trunk_times[0] + trunk_times[4] > 0:
+        lh, msh, flh, byh, lm, msm, flm, bym = trunk_times
+        per_step = (msh + msm) / a.steps
+        roofline_step_largest = {
+            "kernel": "wino_zgemm_h2_kernel / wino_gemm_h2_kernel (the trunk's 36-frequency pair products)",
+            "launches_per_step": round((lh + lm) / a.steps, 1), "ms_per_step": round(per_step, 3),
+            "share_of_step": round(per_step / (dt / a.steps * 1e3), 4),
+            "source": "every product launch of the timed steps bracketed by HIP events on its stream (cslam_trunk_timing)",
+            "hbm_bound_layers": None if lh == 0 else {
+                "what": "Cin <= 256 (conv2_2 ... conv4_1): V2 in + M / Z out", "bound": "hbm", "launches": int(lh),
+                "kernel_ms": round(msh / lh, 4), "achieved": round(byh / msh / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(byh / msh / 1e6 / HBM_PEAK_GBS, 4), "fp16_TFLOPs": round(flh / msh / 1e9, 1)},
+            "mfma_bound_layers": None if lm == 0 else {
+                "what": "Cin = 512 (conv4_2 ... conv5_3)", "bound": "mfma", "launches": int(lm),
+                "kernel_ms": round(msm / lm, 4), "achieved": round(flm / msm / 1e9, 1), "peak": FP16_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s (fp16, 3 products)", "frac": round(flm / msm / 1e9 / FP16_MFMA_PEAK_TFLOPS, 4),
+                "GBs": round(bym / msm / 1e6, 1)}}
 
     # the hand-written kernels of the extract leg are the Winograd transforms (HBM-bound streaming): time the
     # largest one on its real shape with HIP events on the launch stream.  Algorithmic bytes per launch:
@@ -563,6 +651,7 @@ def main():
                                        "one %d-row bank split by rows over %d GPUs: RCCL all-gather of the new descriptors, "
                                        "local top-k, all-to-all of the lists, HIP merge" % (a.bank_rows, world) if rows_mode
                                        else "1 robot bank per GPU, RCCL all-gather of new descriptors")},
+            "sharded_check": sharded_check,
             "ranks": world, "collective_backend": None if world == 1 else ("gloo via host (debug)" if a.debug_shared_gpu else "nccl (RCCL)"),
             "value_fp32_gemms": None if value_fp32_gemms is None else round(value_fp32_gemms, 2),
             "peaks_measured": peaks,
@@ -580,6 +669,8 @@ def main():
             "match_only_queries": nqm,
             "uncertified_queries": int(uncertified),
             "roofline": roofline,
+            "roofline_c3_batch": roofline_c3,
+            "roofline_step_largest": roofline_step_largest,
             "roofline_extract": extract_roofline,
             "cpu_baseline": cpu,
         }

@@ -361,8 +361,13 @@ CSLAM_API int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h
     for (int64_t i = 0; i + 1 < n; ++i) { r[i] = c[i] > 0.0 ? 1.0 / c[i] : 0.0; rcum[i + 1] = rcum[i] + r[i]; }
     for (int64_t k = 0; k < n; ++k) if (is_j[k]) J.push_back(k);
     const int64_t nJ64 = (int64_t)J.size();
-    if (nJ64 - 1 > 64000) {
-        cslam_set_error("more than 64000 junctions (%lld): the dense junction factor does not apply (use the host sparse LU)", (long long)(nJ64 - 1));
+    // the dense float64 junction factor: 64000 junctions = 33 GB.  CSLAM_FIEDLER_MAX_JUNCTIONS moves the limit (tests exercise the
+    // callers' fallback with a small one; a host with the memory to spare may raise it up to 150000 = 180 GB)
+    int64_t max_j = 64000;
+    if (const char *e = getenv("CSLAM_FIEDLER_MAX_JUNCTIONS")) { const long long v = atoll(e); if (v >= 2 && v <= 150000) max_j = v; }
+    if (nJ64 - 1 > max_j) {
+        cslam_set_error("more than %lld junctions (%lld): the dense junction factor does not apply (use the host sparse LU)",
+                        (long long)max_j, (long long)(nJ64 - 1));
         return CSLAM_E_LIMIT;
     }
     const int nJ = (int)nJ64, m = nJ - 1;

@@ -589,6 +589,58 @@ CSLAM_API int cslam_wino4_input_h2_dev(const float *d_x, int B, int H, int W, in
     return CSLAM_OK;
 }
 
+// ---- diagnostics: per-launch timing of the trunk's products inside a run (include/cslam_hip_experimental.h) -----------------
+// bench.py prices the step's largest consumer from the launches of the timed steps themselves: while enabled, every product
+// launch is bracketed by two HIP events ON ITS OWN STREAM and its algorithmic flop / bytes are noted; cslam_trunk_timing_read
+// waits for the recorded events, adds everything up and clears the log.  Off (the default) it costs one relaxed load.
+namespace {
+struct TimedLaunch { hipEvent_t e0, e1; double flop16, bytes; int cin; };
+struct TrunkTiming {
+    std::atomic<int> on{0};
+    int n = 0;
+    TimedLaunch log[512];
+    bool made[512] = {};
+} g_tt;
+}
+static void tt_begin(hipStream_t st, int &slot) {
+    slot = -1;
+    if (!g_tt.on.load(std::memory_order_relaxed) || g_tt.n >= 512) return;
+    slot = g_tt.n;
+    if (!g_tt.made[slot]) {
+        if (hipEventCreate(&g_tt.log[slot].e0) != hipSuccess || hipEventCreate(&g_tt.log[slot].e1) != hipSuccess) { slot = -1; return; }
+        g_tt.made[slot] = true;
+    }
+    (void)hipEventRecord(g_tt.log[slot].e0, st);
+}
+static void tt_end(hipStream_t st, int slot, const WinoGemmArgs &a, int planes_out) {
+    if (slot < 0) return;
+    (void)hipEventRecord(g_tt.log[slot].e1, st);
+    g_tt.log[slot].flop16 = 3.0 * 2.0 * 36.0 * a.T * (double)a.Cin * a.Cout * (a.nxi == 36 || a.nxi == 6 ? 1.0 : a.nxi / 36.0);
+    g_tt.log[slot].bytes = 36.0 * a.T * a.Cin * 4.0 + (double)planes_out * a.T * a.Cout * 4.0 + 36.0 * a.Cin * (double)a.Cout * 4.0;
+    g_tt.log[slot].cin = a.Cin;
+    g_tt.n = slot + 1;
+}
+CSLAM_API int cslam_trunk_timing(int enable) {
+    g_tt.n = 0;
+    g_tt.on.store(enable ? 1 : 0, std::memory_order_relaxed);
+    return CSLAM_OK;
+}
+/* out[0..3] = launches / ms / fp16 flop / algorithmic HBM bytes of the products with Cin <= 256 (HBM-bound), out[4..7] = the
+ * same for Cin > 256 (matrix-pipe-bound), since the last read; clears the log. */
+CSLAM_API int cslam_trunk_timing_read(double out[8]) {
+    ARG_CHECK(out, "NULL argument");
+    for (int i = 0; i < 8; ++i) out[i] = 0.0;
+    for (int i = 0; i < g_tt.n; ++i) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventSynchronize(g_tt.log[i].e1));
+        HIP_TRY(hipEventElapsedTime(&ms, g_tt.log[i].e0, g_tt.log[i].e1));
+        const int o = g_tt.log[i].cin <= 256 ? 0 : 4;
+        out[o] += 1.0; out[o + 1] += ms; out[o + 2] += g_tt.log[i].flop16; out[o + 3] += g_tt.log[i].bytes;
+    }
+    g_tt.n = 0;
+    return CSLAM_OK;
+}
+
 template <int TM, int TN, int NS>
 static int wino_gemm_launch(WinoGemmArgs a, int dbg, hipStream_t st) {
     int n_cu = cslam_cu_count();
@@ -610,9 +662,12 @@ static int wino_gemm_launch(WinoGemmArgs a, int dbg, hipStream_t st) {
         HIP_TRY(hipFuncSetAttribute((const void *)wino_gemm_h2_kernel<TM, TN, NS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         once.done(once_dev);
     }
+    int tslot;
+    tt_begin(st, tslot);
     if (dbg == 1) hipLaunchKernelGGL((wino_gemm_h2_kernel<TM, TN, NS, 1>), dim3(grid), dim3(512), lds, st, a);
     else if (dbg == 2) hipLaunchKernelGGL((wino_gemm_h2_kernel<TM, TN, NS, 2>), dim3(grid), dim3(512), lds, st, a);
     else hipLaunchKernelGGL((wino_gemm_h2_kernel<TM, TN, NS, 0>), dim3(grid), dim3(512), lds, st, a);
+    if (a.nxi == 36) tt_end(st, tslot, a, 36);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }
@@ -693,7 +748,10 @@ CSLAM_API int cslam_wino_zgemm_h2_dev(const void *d_V2, const void *d_U2, int64_
         HIP_TRY(hipFuncSetAttribute((const void *)wino_zgemm_h2_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         once.done(once_dev);
     }
+    int tslot;
+    tt_begin((hipStream_t)stream, tslot);
     hipLaunchKernelGGL((wino_zgemm_h2_kernel<NS>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    tt_end((hipStream_t)stream, tslot, a, 24);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }

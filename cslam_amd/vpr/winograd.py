@@ -194,10 +194,13 @@ def use_tuned_gemms():
         warnings.warn("cslam_amd: tuned GEMM table not loaded (%s)" % e)
 
 
-def _z_form(cin):
-    """Z form of the pair products (GEMM + column half of the output transform) for layers with at most CSLAM_WINO_Z input
-    channels (default 256: where the product is HBM-bound; 0 switches it off, 512 = every layer)."""
-    return cin <= int(os.environ.get("CSLAM_WINO_Z", "256"))
+def _z_form(cin, cout):
+    """Z form of the pair products (GEMM + column half of the output transform, 24 planes instead of 36) where it pays:
+    measured per layer at the 256-frame chunk (profiles/r03_v4_perf_zform.log) the output kernel gains ~30 % everywhere, but
+    the GEMM's 128 x 128 tiles (all the 128 Z registers per lane leave room for) lose more than that wherever the product is
+    not purely HBM-bound -- only conv2_2 (128 -> 128 channels at 112 x 112: 2.08 -> 1.78 ms) comes out ahead.
+    CSLAM_WINO_Z = largest Cin * Cout that takes it (default 128 * 128; 0 = off, 262144 = every layer)."""
+    return cin * cout <= int(os.environ.get("CSLAM_WINO_Z", str(128 * 128)))
 
 
 def wino_conv3x3(ws, x, U, U4, bias, relu, pool=False, residual=None, U3=None, amax_in=None, amax_out=None, U2=None):
@@ -233,8 +236,8 @@ def wino_conv3x3(ws, x, U, U4, bias, relu, pool=False, residual=None, U3=None, a
         _lib.check(lib.cslam_wino4_input_h2_dev(_p(x), B, H, W, Cin, _p(slot), _p(V2), s))
         Ho, Wo = (H // 2, W // 2) if pool else (H, W)
         y = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
-        if residual is None and _z_form(Cin):
-            # HBM-bound products (Cin <= 256): the column half of the output transform is folded into the GEMM, which then
+        if residual is None and _z_form(Cin, Cout):
+            # the purely HBM-bound product (conv2_2): the column half of the output transform is folded into the GEMM, which then
             # writes -- and the output kernel reads -- 24 instead of 36 planes (csrc/wino_gemm.hip `wino_zgemm_h2_kernel`)
             _lib.check(lib.cslam_wino_zgemm_h2_dev(_p(V2), _p(U2[0]), T, Cin, Cout, _p(M), s))
             _lib.check(lib.cslam_wino4_output_z_dev(

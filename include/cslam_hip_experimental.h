@@ -50,6 +50,14 @@ int cslam_debug_wfh_prof_dev(void *d_buf16);
 int cslam_peak_copy_dev(const void *d_src, void *d_dst, int64_t bytes, int variant, void *stream);
 int cslam_peak_mfma_dev(int kind, int iters, int blocks, float *d_scratch, double *flop_out, void *stream);
 
+/* Per-launch timing of the trunk's pair products (cslam_wino_gemm_h2_dev / cslam_wino_zgemm_h2_dev) inside a run: while enabled
+ * every launch is bracketed by two HIP events on its own stream.  cslam_trunk_timing_read: out[0..3] = launches, ms, fp16 flop
+ * (3 products), algorithmic HBM bytes (V2 in + M or Z out + U2) of the launches with Cin <= 256, out[4..7] the same for
+ * Cin > 256, since the last read (waits for the events, clears the log; at most 512 launches are kept).  bench.py's
+ * `roofline_step_largest` is computed from these over the timed steps. */
+int cslam_trunk_timing(int enable);
+int cslam_trunk_timing_read(double out[8]);
+
 /* The candidate lists stage 1 of the last MFMA-mode search of `bank` left in its workspace (valid until the bank's next
  * search): keys [nq][*nseg][16] float32 in units of q.b / ||b|| (sorted per segment, -inf = empty), rows [nq][*nseg][16]
  * (-1 = empty), and the bound on |key - exact| / ||q|| handed to the float64 certificate.  tests/test_nns_gpu.py checks the

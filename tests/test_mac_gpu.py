@@ -344,3 +344,40 @@ def test_auto_falls_back_to_the_torch_driven_solver_without_rocsolver_and_explic
     ac.set_graph(ed(g7[tag + "/fixed"]), ed(g7[tag + "/cand"]))
     with pytest.raises(_lib.CslamUnsupportedError):
         ac.select_candidates(K, {r: True for r in range(R)}, greedy_initialization=True)
+
+
+def test_more_junctions_than_the_dense_factor_takes_falls_back_and_still_selects_the_reference_edges(monkeypatch):
+    """CSLAM_E_LIMIT (-7): `cslam_fiedler` / `cslam_mac_fw_subset` refuse a graph with more junctions than the dense factor
+    takes (64 000 by default: 33 GB); the Python layer then runs the Frank-Wolfe loop itself with the torch-driven solver, whose
+    junction system goes through a host sparse LU.  Exercised here with the limit lowered to 50 junctions on a golden graph
+    (G7, 8 robots x 400 poses, 600 candidates): the selection must still be the reference's, edge for edge."""
+    import ctypes as C
+    from helpers import GOLDEN
+    from cslam_amd import _lib
+    from cslam_amd.algebraic_connectivity_maximization import AlgebraicConnectivityMaximization, EdgeInterRobot
+    from cslam_amd.mac import mac as mac_mod
+    from cslam_amd.mac import chain_solver_gpu
+    monkeypatch.setenv("CSLAM_FIEDLER_MAX_JUNCTIONS", "50")
+    g7 = np.load(GOLDEN + "/mac_g7.npz")
+    tag, R, K = "mac_R8_P400_C600_K60", 8, 60
+    ed = lambda arr: [EdgeInterRobot(int(a), int(b), int(c), int(d), float(w)) for a, b, c, d, w in arr]
+    fell_back = []
+    real = chain_solver_gpu.fiedler_tracemin_chain_gpu
+
+    def spy(*a, **kw):
+        fell_back.append(1)
+        return real(*a, **kw)
+    monkeypatch.setattr(chain_solver_gpu, "fiedler_tracemin_chain_gpu", spy)
+    ac = AlgebraicConnectivityMaximization(robot_id=0, max_nb_robots=R)            # 'auto' -> chain_hip
+    ac.set_graph(ed(g7[tag + "/fixed"]), ed(g7[tag + "/cand"]))
+    sel = ac.select_candidates(K, {r: True for r in range(R)}, greedy_initialization=True)
+    assert np.array_equal(np.array([tuple(e) for e in sel], dtype=np.float64).reshape(-1, 5), g7[tag + "/selected"])
+    assert len(fell_back) >= 2, "the junction limit was not hit: the fallback did not run"
+    # and the C entry point reports the limit with its own code, not as an invalid argument
+    from cslam_amd.mac.mac import MAC
+    from cslam_amd.mac.utils import Edge
+    n = 2000
+    fixed = [Edge(t, t + 1, 1.0) for t in range(n - 1)] + [Edge(7 * t, n - 1 - 5 * t, 0.5) for t in range(1, 150)]
+    mac = MAC(fixed, [Edge(3, 1500, 0.7)], n, fiedler_solver="chain_hip")
+    with pytest.raises(_lib.CslamLimitError, match="junctions"):
+        chain_solver_gpu.fiedler_tracemin_hip(mac.combined_laplacian(np.zeros(1)))

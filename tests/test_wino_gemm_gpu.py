@@ -99,3 +99,63 @@ def test_input_transform_pair_layout(T, B, H, W, C):
     tol = 2.0 ** -22 * V.double().abs() + 2.0 ** -25           # fp16 subnormal spacing 2^-24 at the bottom of lo's range
     assert ((rec - V.double()).abs() <= tol).all()
 
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(300, 128, 128), (1000, 256, 256), (129, 32, 128), (5000, 128, 256), (70000, 64, 128)])
+def test_z_form_gemm_equals_the_column_transform_of_the_plain_products(T, rows, cin, cout):
+    """cslam_wino_zgemm_h2_dev: Z[4 i + q] = sum_j M[6 i + j] A^T[q][j] with M from cslam_wino_gemm_h2_dev on the same operands --
+    the same fp32 products, folded with four exact small-integer coefficients per plane: equal to a float64 fold of M within
+    fp32 rounding of the fold (<= 4e-7 of sum |terms|).  Ragged row counts (partial 128-row blocks), one and two column blocks."""
+    torch, _lib = T
+    from cslam_amd.vpr import winograd as wg
+    lib = _lib.load()
+    g = torch.Generator(device="cuda").manual_seed(rows + cin)
+    v = (torch.randn((36, rows, cin), generator=g, device="cuda") * 3000.0).clamp_(-30000, 30000)
+    U4 = torch.randn((36, cin, cout), generator=g, device="cuda") / cin ** 0.5
+    V2, _, _ = _pairs_rows(v)
+    U2, _ = wg.split16_pair_weights(U4)
+    M = torch.empty((36, rows, cout), device="cuda")
+    Z = torch.full((24, rows, cout), float("nan"), device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.cslam_wino_gemm_h2_dev(_p(V2), _p(U2), rows, cin, cout, _p(M), st))
+    _lib.check(lib.cslam_wino_zgemm_h2_dev(_p(V2), _p(U2), rows, cin, cout, _p(Z), st))
+    torch.cuda.synchronize()
+    assert torch.isfinite(Z).all()
+    At = torch.tensor([[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]], dtype=torch.float64, device="cuda")
+    Md = M.double().view(6, 6, rows, cout)
+    want = torch.einsum("qj,ijrc->iqrc", At, Md).reshape(24, rows, cout)
+    mag = torch.einsum("qj,ijrc->iqrc", At.abs(), Md.abs()).reshape(24, rows, cout)
+    err = (Z.double() - want).abs()
+    assert (err <= 4e-7 * mag + 1e-30).all(), float((err / (mag + 1e-30)).max())
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,pool", [(3, 28, 28, 128, 128, True), (2, 13, 15, 256, 256, False), (5, 56, 56, 128, 256, False)])
+def test_z_form_layer_equals_plain_form_layer_and_float64(T, B, H, W, cin, cout, pool, monkeypatch):
+    """A whole layer (input transform, products, output transform + bias + ReLU (+ MaxPool2d)) through the Z form against the
+    36-plane form and a float64 convolution: the two forms agree to fp32 rounding, both inside the layer tolerance of
+    tests/test_heads_gpu.py (2e-5 of the largest activation); max |y| delivered for the next layer is identical in kind."""
+    torch, _lib = T
+    from cslam_amd.vpr import winograd as wg
+    torch.manual_seed(B * H + cin)
+    x = torch.relu(torch.randn((B, cin, H, W), device="cuda")).contiguous(memory_format=torch.channels_last)
+    w = torch.randn((cout, cin, 3, 3), device="cuda") / (3 * cin ** 0.5)
+    bias = torch.randn(cout, device="cuda") * 0.1
+    U, U4 = wg.wino_weights(w, 2).cuda(), wg.wino_weights(w, 4).cuda()
+    U2 = wg.split16_pair_weights(U4)
+    ws = wg._Workspace()
+    outs, slots = {}, {}
+    for tag, z in (("z", "262144"), ("plain", "0")):
+        monkeypatch.setenv("CSLAM_WINO_Z", z)
+        slot = torch.zeros(1, dtype=torch.float32, device="cuda")
+        big = x.repeat(-(-512 // (B * -(-H // 4) * -(-W // 4))), 1, 1, 1) if B * -(-H // 4) * -(-W // 4) < 512 else x
+        y = wg.wino_conv3x3(ws, big.contiguous(memory_format=torch.channels_last), U, U4, bias, True, pool=pool, U2=U2, amax_out=slot)
+        torch.cuda.synchronize()
+        outs[tag], slots[tag] = y[:B].clone(), slot.item()
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), bias.double(), padding=1).relu()
+    if pool:
+        ref = torch.nn.functional.max_pool2d(ref, 2)
+    scale = ref.abs().max().item()
+    for tag in ("z", "plain"):
+        assert (outs[tag].double() - ref).abs().max().item() <= 2e-5 * scale, tag
+    assert (outs["z"] - outs["plain"]).abs().max().item() <= 2e-6 * scale
+    assert abs(slots["z"] - slots["plain"]) <= 2e-6 * scale and slots["z"] > 0
