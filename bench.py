@@ -43,7 +43,10 @@ def pmc_entry(kernel, **match):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_by_kernel.json,
     keyed by kernel name -- no globbing), only if the entry was collected on exactly the launch timed here."""
     try:
-        e = json.load(open(PMC_FILE)).get(kernel)
+        table = json.load(open(PMC_FILE))
+        e = table.get(kernel)
+        if "queries" in match and (not e or e.get("match", {}).get("queries") != match["queries"]):
+            e = table.get("%s/q%d" % (kernel, match["queries"]))      # one entry per profiled launch shape of the matcher
     except Exception:
         return None
     if not e or any(e.get("match", {}).get(k) != v for k, v in match.items()):
