@@ -75,8 +75,12 @@ def main():
             if v is not None:
                 e[k] = v
         if e.get("GRBM_GUI_ACTIVE") and mf:
-            # SQ_VALU_MFMA_BUSY_CYCLES sums over the SIMDs (4 per CU, 256 CUs) in cycles; GRBM_GUI_ACTIVE = chip-active cycles
-            e["mfma_busy_frac"] = mf / (e["GRBM_GUI_ACTIVE"] * 256 * 4)
+            # SQ_VALU_MFMA_BUSY_CYCLES sums cycles over the 1024 SIMDs (4 per CU, 256 CUs); rocprofv3 reports GRBM_GUI_ACTIVE summed
+            # over the 8 XCDs (its value / 8 / kernel time = the effective shader clock, 1.8 GHz under this load)
+            active = e["GRBM_GUI_ACTIVE"] / 8.0
+            e["mfma_busy_frac"] = mf / (active * 256 * 4)
+            if times.get(nq):
+                e["effective_clock_GHz"] = active / (times[nq] * 1e-3) / 1e9
         if e.get("SQ_LDS_IDX_ACTIVE"):
             e["lds_bank_conflict_frac"] = e.get("SQ_LDS_BANK_CONFLICT", 0.0) / e["SQ_LDS_IDX_ACTIVE"]
         if times.get(nq):
