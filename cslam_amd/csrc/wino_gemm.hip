@@ -738,19 +738,24 @@ CSLAM_API int cslam_wino_zgemm_h2_dev(const void *d_V2, const void *d_U2, int64_
     int n_cu = cslam_cu_count();
     ARG_CHECK(n_cu > 0, "no HIP device");
     if (n_cu < 8) n_cu = 8;
-    constexpr int NS = 3;
-    constexpr int lds = NS * (128 + 128) * WG_ROWB;
+    // ring of three 32 KB stages (default); CSLAM_ZGEMM_NS=2: double buffer (A/B runs)
+    const char *nse = getenv("CSLAM_ZGEMM_NS");
+    const int ns = (nse && atoi(nse) == 2) ? 2 : 3;
+    const int lds = ns * (128 + 128) * WG_ROWB;
     int grid = n_cu - n_cu % 8;
+    if (const char *ge = getenv("CSLAM_ZGEMM_WGS")) { const int v = atoi(ge); if (v >= 1 && v <= 4 && ns * 32 * v <= 160) grid *= v; }   // workgroups per CU (A/B runs)
     if ((int64_t)grid > round_up64(a.n_items, 8)) grid = (int)round_up64(a.n_items, 8);
     static DeviceOnce once;
     int once_dev;
     if (once.todo(&once_dev)) {
-        HIP_TRY(hipFuncSetAttribute((const void *)wino_zgemm_h2_kernel<NS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)wino_zgemm_h2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * WG_ROWB));
+        HIP_TRY(hipFuncSetAttribute((const void *)wino_zgemm_h2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * WG_ROWB));
         once.done(once_dev);
     }
     int tslot;
     tt_begin((hipStream_t)stream, tslot);
-    hipLaunchKernelGGL((wino_zgemm_h2_kernel<NS>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    if (ns == 2) hipLaunchKernelGGL((wino_zgemm_h2_kernel<2>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((wino_zgemm_h2_kernel<3>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
     tt_end((hipStream_t)stream, tslot, a, 24);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
