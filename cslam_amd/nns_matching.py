@@ -353,46 +353,59 @@ def search_multi_device(banks, queries, ks, row_limits=None, mode=MODE_AUTO, def
     # deferred: the result copies are put on the stream NOW, behind the search and ahead of whatever the caller enqueues
     # next, into pinned memory; finish() then waits for this event only.  (They are final unless a query failed its
     # certificate -- finish() re-copies in that case.)
-    host = tuple(_pinned(t.shape, t.dtype, slot) for slot, t in enumerate((idx, sims, cnt)))
+    owned = []
+    host = tuple(_pinned(t.shape, t.dtype, owned) for t in (idx, sims, cnt))
     for h, t in zip(host, (idx, sims, cnt)):
         h.copy_(t, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(dev))
-    return PendingMultiSearch(pend, offs, nq, ks, host=host, event=ev)
+    return PendingMultiSearch(pend, offs, nq, ks, host=host, event=ev, owned=owned)
 
 
-_PINNED = {}
+_PINNED_POOL = []       # free pinned staging buffers (uint8); a live deferred search owns the ones it took
 
 
-def _pinned(shape, dtype, slot):
-    """Grow-only pinned staging buffers, one per result slot (rows / scores / counts): hipHostMalloc is too slow to sit on
-    the per-chunk path.  One deferred multi-search is outstanding at a time per process (the callers alternate enqueue /
-    finish), so the buffers are not shared between live handles."""
+def _pinned_take(nbytes):
+    """A pinned host buffer of at least nbytes from the pool (hipHostMalloc is too slow to sit on the per-chunk path); the
+    handle that takes it gives it back in finish(), so several deferred searches may be outstanding at once."""
     import torch
-    n = int(np.prod(shape))
-    buf = _PINNED.get((slot, dtype))
-    if buf is None or buf.numel() < n:
-        buf = torch.empty(max(n, 1), dtype=dtype, pin_memory=True)
-        _PINNED[(slot, dtype)] = buf
-    return buf[:n].view(shape)
+    best = None
+    for i, b in enumerate(_PINNED_POOL):
+        if b.numel() >= nbytes and (best is None or b.numel() < _PINNED_POOL[best].numel()):
+            best = i
+    if best is not None:
+        return _PINNED_POOL.pop(best)
+    return torch.empty(max(int(nbytes * 1.25), 4096), dtype=torch.uint8, pin_memory=True)
+
+
+def _pinned(shape, dtype, owner):
+    import torch
+    n = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+    buf = _pinned_take(n)
+    owner.append(buf)
+    return buf[:n].view(dtype).view(shape)
 
 
 class PendingMultiSearch(object):
     """`search_multi_device(..., defer=True)`: `finish()` -> the list of per-bank NUMPY results."""
 
-    def __init__(self, pend, offs, nq, ks, host=None, event=None):
+    def __init__(self, pend, offs, nq, ks, host=None, event=None, owned=None):
         self._pend, self._offs, self._nq, self._ks = pend, offs, nq, ks
-        self._host, self._event = host, event
+        self._host, self._event, self._owned = host, event, owned
         self._result = None
 
     def finish(self):
         if self._result is None:
             idx, sims, cnt = self._pend.finish()
-            if self._host is not None and self._pend.uncertified == 0:
+            if self._host is not None:
                 self._event.synchronize()                      # the copies issued right behind the search: nothing later
+            if self._host is not None and self._pend.uncertified == 0:
                 h_idx, h_sims, h_cnt = (h.numpy().copy() for h in self._host)
-            else:
+            else:                                              # a fallback rewrote some rows after the early copies
                 h_idx, h_sims, h_cnt = idx.cpu().numpy(), sims.cpu().numpy(), cnt.cpu().numpy()
+            if self._owned:
+                _PINNED_POOL.extend(self._owned)               # copies are done (event waited for): back to the pool
+                self._owned = self._host = None
             offs, nq, ks = self._offs, self._nq, self._ks
             self._result = [(h_idx[offs[i]:offs[i + 1]].reshape(nq, ks[i]), h_sims[offs[i]:offs[i + 1]].reshape(nq, ks[i]),
                              h_cnt[i * nq:(i + 1) * nq]) for i in range(len(ks))]

@@ -5,7 +5,11 @@ the reference's causal order through the batched LoopClosureSparseMatching calls
 between the robots, and the budgeted candidate selection (algebraic connectivity maximisation) on the broker.
 In the 8-GPU configuration every robot owns a GPU; here the eight robots take turns on one.
 
-    python tools/perf_c5.py [keyframes_per_robot=12500] [robots=8] [budget=1000] [chunk=250] [drain]
+    python tools/perf_c5.py [keyframes_per_robot=12500] [robots=8] [budget=1000] [chunk=250] [drain | drain-async]
+
+drain: every receiver takes a step's remote messages in one call; drain-async: additionally robot r's matching is only ENQUEUED
+(LoopClosureSparseMatching.process_local_keyframes_begin) and finished -- read-back, thresholds, candidate edges, wire copy -- after
+robot r + 1's extraction has been enqueued, so the host's share of the matching hides under the next extraction on the GPU.
 """
 import os
 import sys
@@ -21,7 +25,8 @@ def main():
     R = int(sys.argv[2]) if len(sys.argv) > 2 else 8
     K = int(sys.argv[3]) if len(sys.argv) > 3 else 1000
     CH = int(sys.argv[4]) if len(sys.argv) > 4 else 250
-    DRAIN = len(sys.argv) > 5 and sys.argv[5] == "drain"     # receivers take a step's remote messages in one call
+    DRAIN = len(sys.argv) > 5 and sys.argv[5].startswith("drain")     # receivers take a step's remote messages in one call
+    ASYNC = len(sys.argv) > 5 and sys.argv[5] == "drain-async"
     import torch
     from cslam_amd.loop_closure_sparse_matching import LoopClosureSparseMatching
     from cslam_amd.vpr.netvlad import NetVLAD
@@ -80,10 +85,32 @@ def main():
     for s in range(0, P, CH):
         m = min(CH, P - s)
         ids = list(range(s, s + m))
+        prev = None
+
+        def retire(p):
+            nonlocal n_intra, n_inter
+            rr, handle, ev, pinned = p
+            intra, inter = handle.finish()
+            n_intra += sum(k is not None for _, k in intra)
+            n_inter += len(inter)
+            ev.synchronize()
+            bufs[rr].extend(ids, pinned.numpy())
         for r in range(R):
             t0 = time.perf_counter()
             frames = views(torch.from_numpy(walk[r][s:s + m]).to(dev))
             ddev = nv.compute_embeddings_device(frames)
+            if ASYNC:
+                t1 = time.perf_counter()
+                handle = lc[r].process_local_keyframes_begin(ddev, ids)      # add + searches enqueued, no host synchronisation
+                pinned = torch.empty(ddev.shape, dtype=ddev.dtype, pin_memory=True)
+                pinned.copy_(ddev, non_blocking=True)                        # the copy that goes on the wire
+                ev = torch.cuda.Event(); ev.record()
+                if prev is not None:
+                    retire(prev)                                             # robot r - 1: under robot r's extraction
+                prev = (r, handle, ev, pinned)
+                t2 = time.perf_counter()
+                t_ext += t1 - t0; t_loc += t2 - t1
+                continue
             desc = ddev.cpu().numpy()                              # the copy that goes on the wire
             t1 = time.perf_counter()
             intra, inter = lc[r].process_local_keyframes(ddev, ids)    # matching reads the device tensor in place
@@ -99,6 +126,10 @@ def main():
                 bufs[r].delete_below(s + m)
             t3 = time.perf_counter()
             t_ext += t1 - t0; t_loc += t2 - t1; t_rem += t3 - t2
+        if prev is not None:
+            t2 = time.perf_counter()
+            retire(prev)
+            t_loc += time.perf_counter() - t2
         if DRAIN:
             # every receiver drains its queue once per step: the step's messages of its 7 peers in one call (one search)
             t2 = time.perf_counter()
