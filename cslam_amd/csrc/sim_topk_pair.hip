@@ -35,10 +35,118 @@ __device__ __forceinline__ void pk_glds16(const char *g, char *lds_wave_base) {
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
 
+
+// ---- tile epilogue: lane-local candidate update from the finished 32 MT x 64 wave tile, then clear the accumulators
+// (a lane's 16 accumulator registers of a tile belong to ONE query column: no cross-lane traffic)
+template <int MT, int KPL>
+__device__ __forceinline__ void pair_tile_epilogue(f32x16 (&acc)[MT][2], float (&lk)[2][KPL], int (&li)[2][KPL], const int (&lim)[2],
+                                                   const float (&qmul)[2], const float *__restrict__ invs, int n_rows, int row_base) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+        float inv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int row = row_base + m * 32 + (r & 3) + 8 * (r >> 2);
+            inv[r] = invs[row < n_rows ? row : n_rows - 1];
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            f32x16 keys;
+            bool any = false;
+            const float thr = lk[n][KPL - 1];
+            const int rel_lim = lim[n] - (row_base + m * 32);   // row < lim  <=>  rowoff < rel_lim
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float kx = (acc[m][n][r] * inv[r]) * qmul[n];
+                keys[r] = kx;
+                bool ok = ((r & 3) + 8 * (r >> 2)) < rel_lim;
+                any |= ok && !(kx <= thr);     // NaN passes (ranks first)
+                acc[m][n][r] = 0.0f;
+            }
+            if (__any(any)) {
+#pragma unroll 1
+                for (int r = 0; r < 16; ++r) {
+                    float ck = keys[r];        // uniform dynamic index
+                    int roff = (r & 3) + 8 * (r >> 2);
+                    ck = (ck != ck) ? INFINITY : ck;
+                    bool ins = (roff < rel_lim) && (ck > lk[n][KPL - 1]);
+                    if (__any(ins)) {
+                        ck = ins ? ck : -INFINITY;
+                        int ci = row_base + m * 32 + roff;
+#pragma unroll
+                        for (int j = 0; j < KPL; ++j) {
+                            bool sw = ck > lk[n][j];
+                            float tk = sw ? lk[n][j] : ck;
+                            int ti = sw ? li[n][j] : ci;
+                            lk[n][j] = sw ? ck : lk[n][j];
+                            li[n][j] = sw ? ci : li[n][j];
+                            ck = tk; ci = ti;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- block merge: 4 lists per query (2 row-halves of the wave x 2 waves along the bank axis) -> the best KP of them, plus the
+// bound on everything dropped (see sim_topk_mfma_kernel); the LDS of the K loop is reused
+template <int T_, int KPL>
+__device__ __forceinline__ void pair_block_merge(char *smem, float (&lk)[2][KPL], int (&li)[2][KPL], int wn, int wm, int h, int l31,
+                                                 int tid, int qt, int seg, const PairArgs &p) {
+    __syncthreads();
+    float *mk = (float *)smem;                       // [T_][4][KPL]
+    int *mi = (int *)(smem + T_ * 4 * KPL * 4);      // [T_][4][KPL]
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        int qcol = wn * 64 + n * 32 + l31;
+        int src = wm * 2 + h;
+#pragma unroll
+        for (int j = 0; j < KPL; ++j) {
+            mk[(qcol * 4 + src) * KPL + j] = lk[n][j];
+            mi[(qcol * 4 + src) * KPL + j] = li[n][j];
+        }
+    }
+    __syncthreads();
+    if (tid < T_) {
+        const float *k0 = mk + (tid * 4) * KPL;
+        const int *i0 = mi + (tid * 4) * KPL;
+        int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+        size_t o = ((size_t)(qt * T_ + tid) * p.nseg + seg) * SIM_KP;
+        float bound = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+            if (i0[s * KPL + KPL - 1] >= 0) bound = fmaxf(bound, k0[s * KPL + KPL - 1]);   // full lane list
+        for (int j = 0; j < SIM_KP; ++j) {
+            float c0 = p0 < KPL ? k0[p0] : -INFINITY;
+            float c1 = p1 < KPL ? k0[KPL + p1] : -INFINITY;
+            float c2 = p2 < KPL ? k0[2 * KPL + p2] : -INFINITY;
+            float c3 = p3 < KPL ? k0[3 * KPL + p3] : -INFINITY;
+            int best = 0; float bk = c0;
+            if (c1 > bk) { bk = c1; best = 1; }
+            if (c2 > bk) { bk = c2; best = 2; }
+            if (c3 > bk) { bk = c3; best = 3; }
+            int bi;
+            if (best == 0) { bi = p0 < KPL ? i0[p0] : -1; ++p0; }
+            else if (best == 1) { bi = i0[KPL + p1]; ++p1; }
+            else if (best == 2) { bi = i0[2 * KPL + p2]; ++p2; }
+            else { bi = i0[3 * KPL + p3]; ++p3; }
+            p.part_key[o + j] = bk;
+            p.part_idx[o + j] = (bk == -INFINITY) ? -1 : bi;
+        }
+        float c0 = p0 < KPL ? k0[p0] : -INFINITY, c1 = p1 < KPL ? k0[KPL + p1] : -INFINITY;
+        float c2 = p2 < KPL ? k0[2 * KPL + p2] : -INFINITY, c3 = p3 < KPL ? k0[3 * KPL + p3] : -INFINITY;
+        bound = fmaxf(fmaxf(bound, fmaxf(c0, c1)), fmaxf(c2, c3));
+        p.part_bound[(size_t)(qt * T_ + tid) * p.nseg + seg] = bound;
+    }
+}
+
 // T_ = tile edge (bank rows = queries per tile), MT = 32-row MFMA tiles per wave along the bank axis (wave tile =
 // 32 MT x 64), KPL = per-lane candidate list length.  Waves: 2 along the bank axis x (T_/64) along the query axis.
 // DBG != 0: TIMING-ONLY ablations (wrong results): 1 = no global loads after the first stage.
-template <int T_, int MT, int KPL, int DBG>
+// LDM: placement of the next stage's LDS-DMA requests: 1 = all of them among the MFMAs of the first K step (default),
+// 0 = half behind each K step's MFMAs (round 3's first form; CSLAM_PAIR_LDM=0 for A/B runs)
+template <int T_, int MT, int KPL, int DBG, int LDM>
 __global__ __launch_bounds__(T_ * 2, 2) void sim_topk_pair_kernel(PairArgs p) {
     constexpr int NTHR = T_ * 2;
     constexpr int NWN = T_ / 64;
@@ -167,64 +275,35 @@ __global__ __launch_bounds__(T_ * 2, 2) void sim_topk_pair_kernel(PairArgs p) {
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
                     for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[n], acc[m][n], 0, 0, 0);
-                // half of the next stage's LDS-DMA per K step, behind this step's MFMAs (a global_load_lds costs 60-180 issue
-                // cycles; back to back after the barrier they idle the matrix pipe: sim_topk_mfma.hip, wino_gemm.hip)
-                if (DBG != 1) {
+                // The whole next stage's LDS-DMA is issued during the FIRST K step, one request between every few of its MFMAs
+                // (a global_load_lds costs 60-180 issue cycles: back to back after the barrier they idle the matrix pipe,
+                // sim_topk_mfma.hip), so that the second K step's MFMAs cover the L2 round trip.  Round 3's first form issued half
+                // of them behind the LAST MFMAs of the stage and waited for them at once: a third of the wave cycles parked at
+                // that s_waitcnt (SQ_WAIT_ANY / SQ_WAVE_CYCLES = 0.33, profiles/r03_v6_pmc_match_summary.json).
+                if (LDM == 0) {
+                    if (DBG != 1) {
 #pragma unroll
-                    for (int i = s * (NLD / 2); i < (s + 1) * (NLD / 2); ++i) stage_load_part(cur ^ 1, ltile, lkt, i);
+                        for (int i = s * (NLD / 2); i < (s + 1) * (NLD / 2); ++i) stage_load_part(cur ^ 1, ltile, lkt, i);
+                    }
+                } else if (s == 0) {
+                    if (DBG != 1) {
+#pragma unroll
+                        for (int i = 0; i < NLD; ++i) stage_load_part(cur ^ 1, ltile, lkt, i);
+                    }
+                    constexpr int G = MT * 2 * 3;                    // MFMAs of a K step: 24 | 12
+                    constexpr int NL = 2 * NLD;                      // LDS-DMA requests of a stage: 8
+                    constexpr int PER = G / NL > 0 ? G / NL : 1;
+#pragma unroll
+                    for (int i = 0; i < NL; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);      // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // VMEM read (LDS-DMA)
+                    }
+                    if (G - PER * NL > 0) __builtin_amdgcn_sched_group_barrier(0x008, G - PER * NL > 0 ? G - PER * NL : 1, 0);
                 }
             }
 
-            if (kt == p.nkt - 1) {
-                // ---- tile epilogue: lane-local candidate update, then clear the accumulators
-                const int row_base = tile * T_ + wm * 32 * MT + 4 * h;
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    float inv[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int row = row_base + m * 32 + (r & 3) + 8 * (r >> 2);
-                        inv[r] = p.invs[row < p.n_rows ? row : p.n_rows - 1];
-                    }
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        f32x16 keys;
-                        bool any = false;
-                        const float thr = lk[n][KPL - 1];
-                        const int rel_lim = lim[n] - (row_base + m * 32);   // row < lim  <=>  rowoff < rel_lim
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            float kx = (acc[m][n][r] * inv[r]) * qmul[n];
-                            keys[r] = kx;
-                            bool ok = ((r & 3) + 8 * (r >> 2)) < rel_lim;
-                            any |= ok && !(kx <= thr);     // NaN passes (ranks first)
-                            acc[m][n][r] = 0.0f;
-                        }
-                        if (__any(any)) {
-#pragma unroll 1
-                            for (int r = 0; r < 16; ++r) {
-                                float ck = keys[r];        // uniform dynamic index
-                                int roff = (r & 3) + 8 * (r >> 2);
-                                ck = (ck != ck) ? INFINITY : ck;
-                                bool ins = (roff < rel_lim) && (ck > lk[n][KPL - 1]);
-                                if (__any(ins)) {
-                                    ck = ins ? ck : -INFINITY;
-                                    int ci = row_base + m * 32 + roff;
-#pragma unroll
-                                    for (int j = 0; j < KPL; ++j) {
-                                        bool sw = ck > lk[n][j];
-                                        float tk = sw ? lk[n][j] : ck;
-                                        int ti = sw ? li[n][j] : ci;
-                                        lk[n][j] = sw ? ck : lk[n][j];
-                                        li[n][j] = sw ? ci : li[n][j];
-                                        ck = tk; ci = ti;
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-            }
+            if (kt == p.nkt - 1)
+                pair_tile_epilogue<MT, KPL>(acc, lk, li, lim, qmul, p.invs, p.n_rows, tile * T_ + wm * 32 * MT + 4 * h);
 
             __builtin_amdgcn_s_waitcnt(0);       // next stage landed (vmcnt(0)), this stage's fragment reads done
             __syncthreads();
@@ -233,54 +312,16 @@ __global__ __launch_bounds__(T_ * 2, 2) void sim_topk_pair_kernel(PairArgs p) {
         }
     }
 
-    // ---- block merge: 4 lists per query (2 row-halves of the wave x 2 waves along the bank axis) -> the best KP of them,
-    // plus the bound on everything dropped (see sim_topk_mfma_kernel)
-    __syncthreads();
-    float *mk = (float *)smem;                       // [T_][4][KPL]
-    int *mi = (int *)(smem + T_ * 4 * KPL * 4);      // [T_][4][KPL]
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        int qcol = wn * 64 + n * 32 + l31;
-        int src = wm * 2 + h;
-#pragma unroll
-        for (int j = 0; j < KPL; ++j) {
-            mk[(qcol * 4 + src) * KPL + j] = lk[n][j];
-            mi[(qcol * 4 + src) * KPL + j] = li[n][j];
-        }
-    }
-    __syncthreads();
-    if (tid < T_) {
-        const float *k0 = mk + (tid * 4) * KPL;
-        const int *i0 = mi + (tid * 4) * KPL;
-        int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-        size_t o = ((size_t)(qt * T_ + tid) * p.nseg + seg) * SIM_KP;
-        float bound = -INFINITY;
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-            if (i0[s * KPL + KPL - 1] >= 0) bound = fmaxf(bound, k0[s * KPL + KPL - 1]);   // full lane list
-        for (int j = 0; j < SIM_KP; ++j) {
-            float c0 = p0 < KPL ? k0[p0] : -INFINITY;
-            float c1 = p1 < KPL ? k0[KPL + p1] : -INFINITY;
-            float c2 = p2 < KPL ? k0[2 * KPL + p2] : -INFINITY;
-            float c3 = p3 < KPL ? k0[3 * KPL + p3] : -INFINITY;
-            int best = 0; float bk = c0;
-            if (c1 > bk) { bk = c1; best = 1; }
-            if (c2 > bk) { bk = c2; best = 2; }
-            if (c3 > bk) { bk = c3; best = 3; }
-            int bi;
-            if (best == 0) { bi = p0 < KPL ? i0[p0] : -1; ++p0; }
-            else if (best == 1) { bi = i0[KPL + p1]; ++p1; }
-            else if (best == 2) { bi = i0[2 * KPL + p2]; ++p2; }
-            else { bi = i0[3 * KPL + p3]; ++p3; }
-            p.part_key[o + j] = bk;
-            p.part_idx[o + j] = (bk == -INFINITY) ? -1 : bi;
-        }
-        float c0 = p0 < KPL ? k0[p0] : -INFINITY, c1 = p1 < KPL ? k0[KPL + p1] : -INFINITY;
-        float c2 = p2 < KPL ? k0[2 * KPL + p2] : -INFINITY, c3 = p3 < KPL ? k0[3 * KPL + p3] : -INFINITY;
-        bound = fmaxf(fmaxf(bound, fmaxf(c0, c1)), fmaxf(c2, c3));
-        p.part_bound[(size_t)(qt * T_ + tid) * p.nseg + seg] = bound;
-    }
+    pair_block_merge<T_, KPL>(smem, lk, li, wn, wm, h, l31, tid, qt, seg, p);
 }
+
+// Measured and rejected (round 3, profiles/r03_v13_pair_pingpong_rejected.log; code removed): a "ping-pong" form of the 256 x 256
+// kernel -- a K step as two phases per wave (R: its 12 fragment reads; C: its 24 MFMAs with the LDS-DMA requests of the step after
+// next but one between them), raw s_barriers between phases, waves 4..7 one barrier behind waves 0..3 for the whole K loop so that on
+// every SIMD one wave reads while the other feeds the matrix pipe, ring of four 32 KB half-stages with counted vmcnt(4).  Correct
+// (bit-identical results, three runs of the suite), but 269 ms against 223 ms on the 100k x 100k launch: with two barriers per
+// 768 MFMA cycles and ONE wave issuing into the pipe, every LDS-DMA issue slot and barrier latency is exposed, where the lockstep
+// form's two waves fill each other's issue gaps at instruction granularity.
 
 // ---- query preparation: exact fp16 pairs of every query (times its own power-of-two scale), the factor that removes that
 // scale from the keys, per-query row limits, per-tile max limit.  One workgroup per (padded) query row.
@@ -363,13 +404,17 @@ static int launch_pair(const PairArgs &a, int dbg, hipStream_t st) {
     static DeviceOnce once;
     int once_dev;
     if (once.todo(&once_dev)) {
-        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_pair_kernel<T_, MT, KPL, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_pair_kernel<T_, MT, KPL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_pair_kernel<T_, MT, KPL, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_pair_kernel<T_, MT, KPL, 0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_pair_kernel<T_, MT, KPL, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         once.done(once_dev);
     }
+    const char *le = getenv("CSLAM_PAIR_LDM");
+    const int ldm = (le && le[0] == '0') ? 0 : 1;
     const dim3 grid(a.nqt * a.nseg), blk(T_ * 2);
-    if (dbg == 1) hipLaunchKernelGGL((sim_topk_pair_kernel<T_, MT, KPL, 1>), grid, blk, lds, st, a);
-    else hipLaunchKernelGGL((sim_topk_pair_kernel<T_, MT, KPL, 0>), grid, blk, lds, st, a);
+    if (dbg == 1) hipLaunchKernelGGL((sim_topk_pair_kernel<T_, MT, KPL, 1, 1>), grid, blk, lds, st, a);
+    else if (ldm == 0) hipLaunchKernelGGL((sim_topk_pair_kernel<T_, MT, KPL, 0, 0>), grid, blk, lds, st, a);
+    else hipLaunchKernelGGL((sim_topk_pair_kernel<T_, MT, KPL, 0, 1>), grid, blk, lds, st, a);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }
