@@ -14,6 +14,7 @@
 #   chunks       bench value by frames per backbone pass (256 / 512 / 1024)
 #   acm_small    select_candidates on 2k-16k-pose graphs, default solver vs the reference's path (tools/perf_acm_small.py)
 #   c5           C5 rehearsal on one GPU, drain and drain-async (tools/perf_c5.py)
+#   two_rank     bench.py --gpus 2 --debug-shared-gpu in both shard modes (two ranks sharing the box's GPU, collectives through gloo)
 tag=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}; out=gpurun_out/$tag; mkdir -p $R/$out; cd $R; export TMPDIR=/tmp
 note() { echo "$1 rc=$2" >> $out/summary.txt; }
@@ -37,6 +38,8 @@ for w in "$@"; do
     acm_small) timeout 900 python tools/perf_acm_small.py > $out/perf_acm_small.log 2>&1; note acm_small $?;;
     c5) timeout 1200 python tools/perf_c5.py 12500 8 1000 250 drain > $out/perf_c5_drain.log 2>&1; note c5_drain $?
         timeout 1200 python tools/perf_c5.py 12500 8 1000 250 drain-async > $out/perf_c5_drain_async.log 2>&1; note c5_drain_async $?;;
+    two_rank) timeout 900 python bench.py --gpus 2 --debug-shared-gpu --steps 2 --warmup 1 --no-cpu-baseline > $out/two_rank_rows.json 2> $out/two_rank_rows.err; note two_rank_rows $?
+              timeout 900 python bench.py --gpus 2 --debug-shared-gpu --shard-mode robots --steps 2 --warmup 1 --no-cpu-baseline > $out/two_rank_robots.json 2> $out/two_rank_robots.err; note two_rank_robots $?;;
     *) echo "unknown item $w" >> $out/summary.txt;;
   esac
 done
