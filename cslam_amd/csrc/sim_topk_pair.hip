@@ -316,12 +316,14 @@ __global__ __launch_bounds__(T_ * 2, 2) void sim_topk_pair_kernel(PairArgs p) {
 }
 
 // Measured and rejected (round 3, profiles/r03_v13_pair_pingpong_rejected.log; code removed): a "ping-pong" form of the 256 x 256
-// kernel -- a K step as two phases per wave (R: its 12 fragment reads; C: its 24 MFMAs with the LDS-DMA requests of the step after
-// next but one between them), raw s_barriers between phases, waves 4..7 one barrier behind waves 0..3 for the whole K loop so that on
-// every SIMD one wave reads while the other feeds the matrix pipe, ring of four 32 KB half-stages with counted vmcnt(4).  Correct
-// (bit-identical results, three runs of the suite), but 269 ms against 223 ms on the 100k x 100k launch: with two barriers per
-// 768 MFMA cycles and ONE wave issuing into the pipe, every LDS-DMA issue slot and barrier latency is exposed, where the lockstep
-// form's two waves fill each other's issue gaps at instruction granularity.
+// kernel -- a K step as two phases per wave (R: its 12 fragment reads; C: its 24 MFMAs), raw s_barriers between phases, waves 4..7
+// one barrier behind waves 0..3 for the whole K loop so that on every SIMD one wave reads while the other feeds the matrix pipe,
+// ring of four 32 KB half-stages with counted vmcnt(4).  Correct both times (bit-identical results in every round, the suite green
+// with it), and slower both times: with the LDS-DMA requests between the MFMAs of C 269 ms against 223 ms on the 100k x 100k launch
+// (ONE wave issuing into the pipe: every request's 60-180-cycle issue slot idles it); with the requests in R 237 ms against 225 ms --
+// a wave's non-MFMA issue work per K step (12 ds_read_b128, 4 LDS-DMA requests, waits, two barriers: ~1000 cycles) is longer than
+// its partner's 768 cycles of MFMAs, so R bounds the phase, where the lockstep form's two waves fill each other's issue gaps at
+// instruction granularity (matrix pipe busy 0.60).
 
 // ---- query preparation: exact fp16 pairs of every query (times its own power-of-two scale), the factor that removes that
 // scale from the keys, per-query row limits, per-tile max limit.  One workgroup per (padded) query row.
