@@ -7,19 +7,22 @@
 
 One step (BASELINE config 3, per rank = per robot):
     B synthetic 640x480 RGB keyframes already in HBM (uint8, seeded on device)
-      -> NetVLAD extract: crop/bicubic-resize/normalise [HIP] -> VGG-16 conv5_3 [PyTorch-ROCm, fp32]
-         -> VLAD aggregation [HIP] -> PCA 32768->4096 + L2 [HIP fp32 MFMA]
+      -> NetVLAD extract: crop/bicubic-resize/normalise [HIP] -> VGG-16 conv5_3 [every layer a HIP kernel of this library, fp32-grade]
+         -> VLAD aggregation [HIP] -> PCA 32768->4096 + L2 [HIP, fp16-pair GEMM]
       -> (N > 1) RCCL all-gather of the new descriptors: every rank sees every query
-      -> top-5 against the resident 100k x 4096 bank [HIP: sim_topk_mfma + float64 re-score].
-         N > 1, --shard-mode rows (default): the bank of the metric is split by rows over the ranks, every
-         rank scores all N*B new descriptors against its 100k/N rows, one all-to-all returns the lists to the
-         keyframes' owners and cslam_topk_merge_dev picks the exact whole-bank top-5 (SURVEY 8e);
-         --shard-mode robots: BASELINE config 4's shape, one full bank per rank (= per robot), top-5 for
-         its own keyframes and best-1 for the other robots' keyframes
+      -> top-5 against the resident 100k x 4096 bank [HIP: sim_topk_pair (fp16-pair candidate stage) + float64 re-score + certificate].
+         N = 1: the search is ENQUEUED behind the extraction (cslam_bank_search_enqueue_dev) and finished after the next step has
+         been enqueued -- no host synchronisation inside the timed region.
+         N > 1, --shard-mode rows (default): the bank of the metric (ONE seeded bank at every N) is split by rows over the ranks, every
+         rank scores all N*B new descriptors against its 100k/N rows, one all-to-all returns the lists to the keyframes' owners and
+         cslam_topk_merge_dev picks the exact whole-bank top-5; `sharded_check` compares one step with a single-GPU search
+         of the whole bank.  --shard-mode robots: BASELINE config 4's shape, one full bank per rank (= per robot), top-5 for its own
+         keyframes and best-1 for the other robots' keyframes
 value = keyframes processed by all ranks / max-over-ranks time of exactly K steps.
-The JSON line also carries: match_only / extract_only throughputs (the two legs timed
-separately), `roofline` of the dominant hand-written kernel (sim_topk_mfma, HIP-event timed on
-its launch stream inside the timed steps) and `cpu_baseline` (the C oracle on a bounded sample).
+The JSON line also carries: match_only / extract_only throughputs (the two legs timed separately), `roofline` (the candidate-stage
+kernel's launches INSIDE the timed steps, HIP events on the launch stream), `roofline_c3_batch` (the separate 100k-query launch),
+`roofline_step_largest` (the trunk's pair products, from per-launch events of the timed steps), `roofline_extract` (the other
+kernels of the extract leg on their real shapes) and `cpu_baseline` (the oracle restatements on a bounded sample).
 """
 import argparse
 import glob
