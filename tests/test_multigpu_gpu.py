@@ -149,3 +149,23 @@ def test_c_abi_exchange_two_ranks_over_rccl(tmp_path):
     world = 2
     mp.spawn(_cabi_worker, args=(world, str(tmp_path)), nprocs=world, join=True)
     assert all(os.path.exists(tmp_path / ("ok%d" % r)) for r in range(world))
+
+
+@pytest.mark.parametrize("mode", ["rows", "robots"])
+def test_bench_self_launch_over_rccl(mode):
+    """`python bench.py --gpus N` on a multi-GPU box: launches its own N ranks over RCCL, prints ONE JSON line with n_gpus = N, and in
+    rows mode the sharded step equals a single-GPU search of the whole (one, seeded) bank on every rank (`sharded_check`)."""
+    import json
+    import subprocess
+    n = min(N_GPUS, 8)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--bank-rows", "40000", "--batch", "512", "--match-queries", "4096", "--shard-mode", mode],
+                       capture_output=True, text=True, env=env, timeout=1500, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == n and d["ranks"] == n and d["collective_backend"] == "nccl (RCCL)" and d["value"] > 0
+    if mode == "rows":
+        assert d["sharded_check"]["equal_to_unsharded_bank_on_every_rank"] is True
