@@ -11,6 +11,7 @@
 // All of these are HBM-bandwidth bound: one workgroup per image / row,
 // coalesced reads along the contiguous (pixel) axis, wave64 shuffle reductions, LDS for the
 // per-image intermediates.  float32 arithmetic like the reference's torch float32 modules.
+#include <stdlib.h>
 #include "common.h"
 #include <mutex>
 #include <vector>
@@ -369,6 +370,295 @@ __global__ __launch_bounds__(512) void vlad_fast_kernel(const float *__restrict_
     }
 }
 
+// ---- the batch form on the f32 matrix pipe (round 3) -------------------------------------------------------------------
+// vlad_fast_kernel does the two small contractions of NetVLADLayer.forward (netvlad.py:109: logits = W x; :115-124:
+// V = a x^T - (sum a) cent) with one v_fma per LDS read or two: 1.2 us per frame, LDS-instruction-bound, a tenth of what the
+// 0.53 MB a frame moves would cost at HBM speed.  Here both run on v_mfma_f32_32x32x2_f32 (exact f32 products and f32
+// accumulation: an fmaf chain, so the result is as good as the VALU form's, in another summation order):
+//   sweep 1  logits [pixel][cluster] = x [pixel][channel] W^T:  wave w = pixels 32 w .. 32 w + 31, two 32-cluster tiles,
+//            K = the 128 channels of a slab;  sum x^2 per pixel on the VALU beside it
+//   softmax  per pixel (thread = pixel), a' = softmax / ||x_p||, asum[k] = sum_p softmax
+//   sweep 2  V [cluster][channel] = a'^T x:  wave w = cluster tile w >> 2, channel tile w & 3 of the slab, K = the pixels
+//   then V - asum cent, intra-normalisation over the channels of a cluster, global L2, stores in 128-byte runs.
+// x [P][C] channels-last (what the trunk writes), streamed twice in slabs of 128 channels through LDS rows of 132 floats
+// (16-byte stores and reads; lanes along pixels -- sweep 1's A operand, one ds_read_b128 per four K-steps -- spread over all
+// banks, lanes along channels -- sweep 2's B operand -- are consecutive); the next slab (and its 128 x 64 block of W) is
+// prefetched into registers under the current slab's MFMAs.  C a multiple of 128 up to 512, 32 <= P <= 200 (14 x 14 = 196).
+typedef float vf32x16 __attribute__((ext_vector_type(16)));
+#define VM_CS 128
+#define VM_XS 132                      // LDS row pitch of a slab of x in floats
+#define VM_AP 65                       // LDS row pitch of the assignment (and of the W block) in floats
+#define VM_PP 200                      // padded pixel count (even, >= P): LDS rows
+#define VM_LDS_FLOATS (VM_PP * VM_XS + VM_PP * VM_AP + 256 + VK + 8 * VK + 16)
+__global__ __launch_bounds__(512) void vlad_mfma_kernel(const float *__restrict__ feat, const float *__restrict__ W,
+                                                        const float *__restrict__ bias, const float *__restrict__ cent,
+                                                        int C, int P, float *__restrict__ out, int64_t ldo, int dbg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *xs = (float *)smem;                        // [VM_PP][VM_XS]
+    float *a_lds = xs + VM_PP * VM_XS;                // [VM_PP][VM_AP] logits -> softmax -> a'; sweep 1: ws [VM_CS][VM_AP] lives here
+    float *invn = a_lds + VM_PP * VM_AP;              // [256]
+    float *asum = invn + 256;                         // [VK]
+    float *red = asum + VK;                           // [8][VK] + 16
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, l31 = lane & 31;
+    const float *x = feat + (size_t)blockIdx.x * C * P;
+    const int nslab = C / VM_CS;
+    constexpr int NPF = (VM_PP * VM_CS / 4 + 511) / 512;          // float4 prefetch registers per thread (13)
+    constexpr int NWF = VM_CS * VK / 512;                          // W prefetch registers per thread (16)
+
+    float4 pf[NPF];
+    float wpf[NWF];
+    // addresses as (uniform base) + (one 32-bit per-thread offset): the thirteen + sixteen loads share two offset registers
+    const unsigned xoff = (unsigned)(tid >> 5) * (unsigned)C + 4u * (tid & 31);      // pixel tid >> 5 (+ 16 i), float4 tid & 31
+    const unsigned woff = (unsigned)(tid >> 7) * (unsigned)C + (tid & 127);          // W row tid >> 7 (+ 4 i), channel tid & 127
+    auto prefetch = [&](int sl, bool with_w) {
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const float *base = x + (size_t)(i * 16) * C + sl * VM_CS;                 // 32 float4 per pixel row of the slab
+            pf[i] = i * 16 + (tid >> 5) < P && !(dbg & 8) ? *(const float4 *)(base + xoff) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (with_w) {
+#pragma unroll
+            for (int i = 0; i < NWF; ++i) wpf[i] = (W + (size_t)(i * 4) * C + sl * VM_CS)[woff];   // lanes along the channels of a row
+        }
+    };
+    auto commit = [&](bool with_w) {                                   // rows P .. VM_PP - 1 are written as zeros
+#pragma unroll
+        for (int i = 0; i < NPF; ++i) {
+            const int e = i * 512 + tid, pp = e >> 5, c4 = e & 31;
+            if (pp < VM_PP) *(float4 *)(xs + pp * VM_XS + 4 * c4) = pf[i];
+        }
+        if (with_w) {
+#pragma unroll
+            for (int i = 0; i < NWF; ++i) {
+                const int e = i * 512 + tid, k = e >> 7, cc = e & 127;
+                a_lds[cc * VM_AP + k] = wpf[i];                          // ws[cc][k] = W[k][c0 + cc]
+            }
+        }
+    };
+
+    // ---------------- sweep 1
+    const float *ws = a_lds;
+    const int px = tid & 255, half = tid >> 8;                         // sum of squares: thread = (pixel, half of the slab)
+    float ss = 0.0f;
+    vf32x16 lg[2];                                                     // running totals; every slab sums in four chains of its own
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lg[n][r] = 0.0f;
+    const int prow = (32 * wave + l31 < VM_PP ? 32 * wave + l31 : VM_PP - 1) * VM_XS;    // wave 6 reaches past the padded rows
+    const bool mm1 = 32 * wave < P && !(dbg & 1);                      // this wave's pixel tile holds real pixels
+    prefetch(0, true);
+    for (int sl = 0; sl < nslab; ++sl) {
+        __syncthreads();                                               // previous slab consumed (xs and ws)
+        commit(true);
+        if (sl + 1 < nslab) prefetch(sl + 1, true);
+        __syncthreads();
+        if (px < P) {
+            const float4 *xr = (const float4 *)(xs + px * VM_XS + half * (VM_CS / 2));
+#pragma unroll 4
+            for (int c4 = 0; c4 < VM_CS / 8; ++c4) {
+                const float4 v = xr[c4];
+                ss = fmaf(v.x, v.x, ss); ss = fmaf(v.y, v.y, ss); ss = fmaf(v.z, v.z, ss); ss = fmaf(v.w, v.w, ss);
+            }
+        }
+        if (mm1) {
+            // K order: step 4 j + i takes channel 8 j + 4 h + i from the lanes of half h (both operands agree; any order of
+            // the channels is a valid sum) -- one 16-byte read of x feeds four K-steps
+            // (short chains: the error of a 512-term sum stays that of a blocked sum; and four independent MFMA chains).
+            // The operands of group j + 1 are read from LDS while group j's eight MFMAs run.
+            vf32x16 acc[2][2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[q][n][r] = 0.0f;
+            float4 xa[2];
+            float wv[2][8];
+            auto fetch = [&](int j, int q) {
+                xa[q] = *(const float4 *)(xs + prow + 8 * j + 4 * h);
+                const float *wr = ws + (8 * j + 4 * h) * VM_AP + l31;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { wv[q][2 * i] = wr[i * VM_AP]; wv[q][2 * i + 1] = wr[i * VM_AP + 32]; }
+            };
+            auto mm = [&](int q) {
+                const float av[4] = {xa[q].x, xa[q].y, xa[q].z, xa[q].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], wv[q][2 * i], acc[q][0], 0, 0, 0);
+                    acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], wv[q][2 * i + 1], acc[q][1], 0, 0, 0);
+                }
+            };
+            fetch(0, 0);
+#pragma unroll 1
+            for (int j = 0; j < VM_CS / 8; j += 2) {
+                fetch(j + 1, 1);
+                __builtin_amdgcn_sched_barrier(0);                     // keep the reads ahead of the MFMAs they hide under
+                mm(0);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(j + 2 < VM_CS / 8 ? j + 2 : j, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                mm(1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) lg[n][r] += acc[0][n][r] + acc[1][n][r];
+        }
+    }
+    if (nslab > 1) prefetch(nslab - 2, false);                         // sweep 2 walks the slabs backwards: the last one is in LDS
+    __syncthreads();                                                   // ws (in a_lds) no longer needed
+    if (half == 1 && px < P) invn[px] = ss;
+    if (mm1) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int p_ = 32 * wave + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (p_ < VM_PP) a_lds[p_ * VM_AP + 32 * n + l31] = lg[n][r];
+            }
+    }
+    __syncthreads();
+    if (half == 0 && px < P && !(dbg & 4)) {
+        ss += invn[px];
+        const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);             // F.normalize(dim=1), netvlad.py:105-106
+        float v[VK];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < VK; ++k) {
+            v[k] = a_lds[px * VM_AP + k] * inv + (bias ? bias[k] : 0.0f);
+            mx = fmaxf(mx, v[k]);
+        }
+        float se = 0.0f;
+#pragma unroll
+        for (int k = 0; k < VK; ++k) { v[k] = expf(v[k] - mx); se += v[k]; }
+        const float rs = 1.0f / se;
+#pragma unroll
+        for (int k = 0; k < VK; ++k) a_lds[px * VM_AP + k] = v[k] * rs;  // softmax, netvlad.py:109-110
+        invn[px] = inv;
+    }
+    __syncthreads();
+    {                                                                  // asum[k] = sum_p a[p][k]  (unscaled): 8 partial sums
+        const int k = tid & 63, part = tid >> 6;
+        float s = 0.0f;
+        for (int pp = part; pp < P; pp += 8) s += a_lds[pp * VM_AP + k];
+        red[part * VK + k] = s;
+    }
+    __syncthreads();
+    if (tid < VK) {
+        float s = 0.0f;
+#pragma unroll
+        for (int part = 0; part < 8; ++part) s += red[part * VK + tid];
+        asum[tid] = s;
+    }
+    for (int e = tid; e < VM_PP * VK; e += 512) {                       // a' = a / ||x_p||; padded pixels: 0
+        const int pp = e >> 6, k = e & 63;
+        a_lds[pp * VM_AP + k] = pp < P ? a_lds[pp * VM_AP + k] * invn[pp] : 0.0f;
+    }
+
+    // ---------------- sweep 2: wave = (cluster tile ct, channel tile nt of the slab), K = pixels
+    const int ct = wave >> 2, nt = wave & 3;
+    vf32x16 vo[4];
+    const int kp2 = (P + 1) >> 1;                                      // pixel pairs (rows P .. VM_PP - 1 are zero on both sides)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {                                      // vo[t] = slab nslab - 1 - t
+        const int sl = nslab - 1 - t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vo[t][r] = 0.0f;
+        if (sl >= 0) {
+            __syncthreads();                                           // a' and asum complete (first pass) / previous slab consumed
+            if (t > 0) {
+                commit(false);
+                if (sl > 0) prefetch(sl - 1, false);
+                __syncthreads();
+            }
+            const float *ar = a_lds + h * VM_AP + 32 * ct + l31, *xr = xs + h * VM_XS + 32 * nt + l31;
+            const int c = sl * VM_CS + 32 * nt + l31;
+            float cv[16];                                              // this wave's centroid entries: in flight under the MFMAs
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cv[r] = cent[(size_t)(32 * ct + (r & 3) + 8 * (r >> 2) + 4 * h) * C + c];
+            vf32x16 v1;                                                // two chains over the pixel pairs (even / odd)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v1[r] = 0.0f;
+            // groups of four pixel pairs (the rows up to VM_PP are zero on both sides: the last group may run past P);
+            // group g + 1's operands are read from LDS while group g's MFMAs run
+            const int ng = (dbg & 2) ? 0 : (kp2 + 3) >> 2;
+            float na[4], nb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { na[i] = ar[2 * i * VM_AP]; nb[i] = xr[2 * i * VM_XS]; }
+#pragma unroll 1
+            for (int g = 0; g < ng; ++g) {
+                float ca[4], cb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { ca[i] = na[i]; cb[i] = nb[i]; }
+                const int gn = g + 1 < ng ? g + 1 : g;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { na[i] = ar[(8 * gn + 2 * i) * VM_AP]; nb[i] = xr[(8 * gn + 2 * i) * VM_XS]; }
+                __builtin_amdgcn_sched_barrier(0);                     // reads first, then the MFMAs they hide under
+                vo[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[0], cb[0], vo[t], 0, 0, 0);
+                v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[1], cb[1], v1, 0, 0, 0);
+                vo[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[2], cb[2], vo[t], 0, 0, 0);
+                v1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ca[3], cb[3], v1, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) vo[t][r] += v1[r];
+            // V[k,c] = sum_p a[k,p] (x[c,p]/||x_p|| - cent[k,c])   (netvlad.py:115-124)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) vo[t][r] -= asum[32 * ct + (r & 3) + 8 * (r >> 2) + 4 * h] * cv[r];
+        }
+    }
+    // intra-normalisation over c for every k (netvlad.py:126): a cluster's channels sit in the 32 lanes of a half-wave, the
+    // slabs (registers) and the four channel-tile waves of the cluster tile
+    float part[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float s = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s = fmaf(vo[t][r], vo[t][r], s);
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+        part[r] = s;
+    }
+    __syncthreads();
+    if (l31 == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[nt * VK + 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * h] = part[r];
+    }
+    __syncthreads();
+    float sc[16], gpart = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float s = (red[k] + red[VK + k]) + (red[2 * VK + k] + red[3 * VK + k]);
+        const float nk = sqrtf(s);
+        sc[r] = 1.0f / fmaxf(nk, 1e-12f);
+        const float nn = nk * sc[r];
+        gpart += nn * nn;                                              // the same in the four nt waves: taken from nt == 0 below
+    }
+    // global L2 over all K*C (netvlad.py:127-128): the 64 clusters' squared norms; lanes l31 == 0 of the nt == 0 waves hold them
+    if (nt == 0 && l31 == 0) red[4 * VK + 2 * ct + h] = gpart;
+    __syncthreads();
+    const float gsum = (red[4 * VK] + red[4 * VK + 1]) + (red[4 * VK + 2] + red[4 * VK + 3]);
+    const float gs = 1.0f / fmaxf(sqrtf(gsum), 1e-12f);
+    float *o = out + (size_t)blockIdx.x * ldo;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int sl = nslab - 1 - t;
+        if (sl >= 0) {
+            const int c = sl * VM_CS + 32 * nt + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = 32 * ct + (r & 3) + 8 * (r >> 2) + 4 * h;
+                o[(size_t)k * C + c] = vo[t][r] * sc[r] * gs;
+            }
+        }
+    }
+}
+
 // ---- small batches (the online path: one keyframe per call) ----------------------------------------------
 // vlad_fast_kernel keeps one image in one workgroup, which is the right shape for a batch (256 images fill the chip)
 // but leaves 255 CUs idle for a single keyframe (272 us, latency of 32 dependent slab steps).  For B <= 8 the same
@@ -534,6 +824,21 @@ static int vlad_aggregate(const float *d_feat, const float *d_assign_w, const fl
     if (B == 0) return CSLAM_OK;
     if (nhwc) {
         ARG_CHECK(P <= VL_PMAX && B > 8, "the channels-last form is the batch kernel's (B > 8, P <= 256)");
+        // NetVLAD's own shape (512 channels, 14 x 14): the two contractions on the f32 matrix pipe; CSLAM_VLAD_MFMA=0: the VALU form
+        static const bool use_mfma = [] { const char *e = getenv("CSLAM_VLAD_MFMA"); return !(e && e[0] == '0'); }();
+        if (use_mfma && C % VM_CS == 0 && C <= 4 * VM_CS && P <= VM_PP && P >= 32) {
+            const size_t lds_m = (size_t)VM_LDS_FLOATS * 4;
+            static DeviceOnce once;
+            int once_dev;
+            if (once.todo(&once_dev)) {
+                HIP_TRY(hipFuncSetAttribute((const void *)vlad_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_m));
+                once.done(once_dev);
+            }
+            hipLaunchKernelGGL(vlad_mfma_kernel, dim3(B), dim3(512), lds_m, (hipStream_t)stream, d_feat, d_assign_w, d_assign_b,
+                               d_centroids, C, P, d_out, ldo, getenv("CSLAM_VLAD_DBG") ? atoi(getenv("CSLAM_VLAD_DBG")) : 0);
+            HIP_TRY(hipGetLastError());
+            return CSLAM_OK;
+        }
         size_t lds = (size_t)(VL_PMAX * VK + VL_CC * VL_PPAD + VL_CC * VK + VL_PMAX + VK + VK + 16) * 4;
         HIP_TRY(hipFuncSetAttribute((const void *)vlad_fast_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(vlad_fast_kernel<true>, dim3(B), dim3(512), lds, (hipStream_t)stream, d_feat, d_assign_w,

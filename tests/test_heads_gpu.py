@@ -716,11 +716,15 @@ def test_pca_project_on_fp16_pairs_is_fp32_grade(T, B, din, dout, whiten):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,C,H,W", [(12, 512, 14, 14), (9, 96, 16, 16), (40, 500, 5, 3), (33, 64, 1, 1)])
+@pytest.mark.parametrize("B,C,H,W", [(12, 512, 14, 14), (9, 96, 16, 16), (40, 500, 5, 3), (33, 64, 1, 1), (11, 512, 7, 5),
+                                     (10, 256, 14, 14), (9, 128, 8, 4), (17, 384, 10, 20), (9, 512, 15, 14)])
 def test_vlad_channels_last_feature_map_equals_nchw(T, B, C, H, W):
-    """cslam_vlad_aggregate_nhwc_dev: the batch kernel on the channels_last map the Winograd trunk writes, against the same
-    kernel on the converted NCHW map (same arithmetic in the same order: bit-identical) and the numpy restatement of
-    NetVLADLayer.forward (netvlad.py:94-130); ragged last slab (C not a multiple of 32), bias, P = 1."""
+    """cslam_vlad_aggregate_nhwc_dev: the batch kernels on the channels_last map the Winograd trunk writes, against the NCHW
+    kernel on the converted map and the numpy restatement of NetVLADLayer.forward (netvlad.py:94-130).  C a multiple of 128 (up
+    to 512) with 32 <= P <= 200 -- NetVLAD's own 512 x 14 x 14 among them -- runs the two contractions on the f32 matrix pipe
+    (vlad_mfma_kernel: another summation order, so a tolerance; P odd, P = 200, one to four slabs); the other shapes run the VALU
+    kernel in both layouts (same arithmetic in the same order: bit-identical): ragged last slab (C not a multiple of 32), P = 1,
+    P above the matrix form's limit."""
     torch, heads = T
     rng = np.random.default_rng(B + C)
     x = rng.standard_normal((B, C, H, W)).astype(np.float32)
@@ -732,8 +736,49 @@ def test_vlad_channels_last_feature_map_equals_nchw(T, B, C, H, W):
     assert not xl.is_contiguous() or H * W == 1
     y_nchw = heads.vlad_aggregate(xd, dev(T, w), dev(T, b), dev(T, c))
     y_nhwc = heads.vlad_aggregate(xl, dev(T, w), dev(T, b), dev(T, c))
-    assert torch.equal(y_nchw, y_nhwc)
+    matrix_form = C % 128 == 0 and C <= 512 and 32 <= H * W <= 200
+    if matrix_form:
+        assert float((y_nchw - y_nhwc).abs().max()) < 2e-7
+    else:
+        assert torch.equal(y_nchw, y_nhwc)
     assert np.max(np.abs(y_nhwc.cpu().numpy() - ho.vlad_forward(x, w, b, c))) < 1e-6
+
+
+@pytest.mark.gpu
+def test_vlad_matrix_form_against_float64_and_its_valu_partner(T, monkeypatch):
+    """vlad_mfma_kernel on trunk-like input (non-negative, a few dead channels, one all-zero pixel, one all-zero frame) with the
+    trained layer's scales (assignment weights 2 alpha centroids, netvlad.py:62-71): no further from the float64 restatement than
+    the VALU kernel is, unit norm, finite on the zero frame."""
+    torch, heads = T
+    rng = np.random.default_rng(3)
+    B, C, H, W = 64, 512, 14, 14
+    x = np.maximum(rng.standard_normal((B, C, H, W)), 0).astype(np.float32) * rng.random((1, C, 1, 1)).astype(np.float32) * 30
+    x[:, ::37] = 0
+    x[3, :, 5, 5] = 0
+    x[7] = 0
+    cent = rng.random((64, C)).astype(np.float32)
+    cent /= np.linalg.norm(cent, axis=1, keepdims=True)
+    w = (2.0 * 100.0 * cent).astype(np.float32)
+    b = (-100.0 * np.linalg.norm(cent, axis=1)).astype(np.float32)
+    xl = dev(T, x).contiguous(memory_format=torch.channels_last)
+    y = heads.vlad_aggregate(xl, dev(T, w), dev(T, b), dev(T, cent)).cpu().numpy()
+    y_valu = heads.vlad_aggregate(dev(T, x), dev(T, w), dev(T, b), dev(T, cent)).cpu().numpy()
+    # NetVLADLayer.forward (netvlad.py:94-130) in float64
+    xf = x.astype(np.float64).reshape(B, C, -1)
+    xf = xf / np.maximum(np.linalg.norm(xf, axis=1, keepdims=True), 1e-12)
+    sa = np.einsum("kc,ncp->nkp", w.astype(np.float64), xf) + b.astype(np.float64)[None, :, None]
+    a = np.exp(sa - sa.max(axis=1, keepdims=True))
+    a /= a.sum(axis=1, keepdims=True)
+    v = np.einsum("nkp,ncp->nkc", a, xf) - a.sum(axis=2)[:, :, None] * cent.astype(np.float64)[None]
+    v = v / np.maximum(np.linalg.norm(v, axis=2, keepdims=True), 1e-12)
+    v = v.reshape(B, -1)
+    ref = v / np.maximum(np.linalg.norm(v, axis=1, keepdims=True), 1e-12)
+    assert np.all(np.isfinite(y))
+    e, ev = np.max(np.abs(y - ref)), np.max(np.abs(y_valu - ref))
+    print("vlad matrix form: max error against float64 %.2e (VALU kernel %.2e)" % (e, ev))
+    assert e < 1e-5 and e <= max(2.0 * ev, 2e-7), (e, ev)
+    keep = [i for i in range(B) if i != 7]
+    assert np.max(np.abs(np.linalg.norm(y[keep], axis=1) - 1.0)) < 1e-6
 
 
 @pytest.mark.gpu

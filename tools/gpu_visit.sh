@@ -21,6 +21,7 @@ note() { echo "$1 rc=$2" >> $out/summary.txt; }
 for w in "$@"; do
   case $w in
     tests) timeout 2400 python -m pytest tests -m gpu -x -q > $out/tests_gpu.log 2>&1; note tests $?; tail -3 $out/tests_gpu.log >> $out/summary.txt;;
+    heads) timeout 900 python -m pytest tests/test_heads_gpu.py -x -q -s > $out/tests_heads.log 2>&1; note heads $?; tail -3 $out/tests_heads.log >> $out/summary.txt; grep 'vlad matrix' $out/tests_heads.log >> $out/summary.txt;;
     smoke) timeout 600 python __graft_entry__.py smoke > $out/smoke.log 2>&1; note smoke $?;;
     bench) timeout 900 python bench.py --steps 20 --warmup 2 > $out/bench.json 2> $out/bench.err; note bench $?;;
     trace) (cd /tmp; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/bench_trace -o b -- python $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $R/$out/bench_traced.json 2> $R/$out/bench_traced.err); note trace $?
