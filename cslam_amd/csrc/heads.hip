@@ -392,7 +392,7 @@ typedef float vf32x16 __attribute__((ext_vector_type(16)));
 #define VM_LDS_FLOATS (VM_PP * VM_XS + VM_PP * VM_AP + 256 + VK + 8 * VK + 16)
 __global__ __launch_bounds__(512) void vlad_mfma_kernel(const float *__restrict__ feat, const float *__restrict__ W,
                                                         const float *__restrict__ bias, const float *__restrict__ cent,
-                                                        int C, int P, float *__restrict__ out, int64_t ldo, int dbg) {
+                                                        int C, int P, float *__restrict__ out, int64_t ldo) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *xs = (float *)smem;                        // [VM_PP][VM_XS]
     float *a_lds = xs + VM_PP * VM_XS;                // [VM_PP][VM_AP] logits -> softmax -> a'; sweep 1: ws [VM_CS][VM_AP] lives here
@@ -416,7 +416,7 @@ __global__ __launch_bounds__(512) void vlad_mfma_kernel(const float *__restrict_
 #pragma unroll
         for (int i = 0; i < NPF; ++i) {
             const float *base = x + (size_t)(i * 16) * C + sl * VM_CS;                 // 32 float4 per pixel row of the slab
-            pf[i] = i * 16 + (tid >> 5) < P && !(dbg & 8) ? *(const float4 *)(base + xoff) : make_float4(0.f, 0.f, 0.f, 0.f);
+            pf[i] = i * 16 + (tid >> 5) < P ? *(const float4 *)(base + xoff) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (with_w) {
 #pragma unroll
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(512) void vlad_mfma_kernel(const float *__restrict_
 #pragma unroll
         for (int r = 0; r < 16; ++r) lg[n][r] = 0.0f;
     const int prow = (32 * wave + l31 < VM_PP ? 32 * wave + l31 : VM_PP - 1) * VM_XS;    // wave 6 reaches past the padded rows
-    const bool mm1 = 32 * wave < P && !(dbg & 1);                      // this wave's pixel tile holds real pixels
+    const bool mm1 = 32 * wave < P;                                    // this wave's pixel tile holds real pixels
     prefetch(0, true);
     for (int sl = 0; sl < nslab; ++sl) {
         __syncthreads();                                               // previous slab consumed (xs and ws)
@@ -522,7 +522,7 @@ __global__ __launch_bounds__(512) void vlad_mfma_kernel(const float *__restrict_
             }
     }
     __syncthreads();
-    if (half == 0 && px < P && !(dbg & 4)) {
+    if (half == 0 && px < P) {
         ss += invn[px];
         const float inv = 1.0f / fmaxf(sqrtf(ss), 1e-12f);             // F.normalize(dim=1), netvlad.py:105-106
         float v[VK];
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(512) void vlad_mfma_kernel(const float *__restrict_
             for (int r = 0; r < 16; ++r) v1[r] = 0.0f;
             // groups of four pixel pairs (the rows up to VM_PP are zero on both sides: the last group may run past P);
             // group g + 1's operands are read from LDS while group g's MFMAs run
-            const int ng = (dbg & 2) ? 0 : (kp2 + 3) >> 2;
+            const int ng = (kp2 + 3) >> 2;
             float na[4], nb[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) { na[i] = ar[2 * i * VM_AP]; nb[i] = xr[2 * i * VM_XS]; }
@@ -835,7 +835,7 @@ static int vlad_aggregate(const float *d_feat, const float *d_assign_w, const fl
                 once.done(once_dev);
             }
             hipLaunchKernelGGL(vlad_mfma_kernel, dim3(B), dim3(512), lds_m, (hipStream_t)stream, d_feat, d_assign_w, d_assign_b,
-                               d_centroids, C, P, d_out, ldo, getenv("CSLAM_VLAD_DBG") ? atoi(getenv("CSLAM_VLAD_DBG")) : 0);
+                               d_centroids, C, P, d_out, ldo);
             HIP_TRY(hipGetLastError());
             return CSLAM_OK;
         }
@@ -1013,38 +1013,11 @@ __device__ __forceinline__ int clip8(int v) {
     return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
 
-// Fused crop + horizontal pass + vertical pass + ToTensor + Normalize.  One workgroup = one image x
-// PP_TY output rows: the input rows those outputs need (about 1.7*PP_TY + 8 at 376 -> 224) are
-// read from HBM once with 4-byte loads into LDS, resized horizontally to uint8 in LDS (Pillow
-// rounds and clips to 8 bits between the passes), then vertically, and stored as float32 CHW with
-// consecutive lanes on consecutive x.  HBM traffic per frame ~ crop*crop*3 (x1.3 row overlap between
-// tiles, absorbed by L2) + 3*out*out*4 bytes; the old two-kernel version moved the uint8
-// intermediate through memory and read single bytes.
-// `ty` (PP_TY_MAX = 16 at the reference's 376 -> 224; smaller when a larger crop would not fit the 160 KiB of LDS) is a
-// launch parameter.  A frame smaller than the crop is zero-padded like torchvision's CenterCrop (`ptop`, `pleft` rows /
-// pixels of padding before the frame; `top`, `left` then address the padded frame).
-#define PP_TY_MAX 16
-__global__ __launch_bounds__(256) void preprocess_fused_kernel(
-    const uint8_t *__restrict__ img, int H, int W, int crop, int top, int left, int ptop, int pleft, int ty,
-    int out_hw, int ksize, int max_rows, const int *__restrict__ bounds, const int *__restrict__ kk,
-    float m0, float m1, float m2, float s0, float s1, float s2, float *__restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int in_row_bytes = (crop * 3 + 3) & ~3;        // padded to dwords
-    const int tmp_row_bytes = out_hw * 3;
-    int *s_bounds = (int *)smem;                                     // [out_hw][2]
-    int *s_kk = s_bounds + out_hw * 2;                               // [out_hw][ksize]
-    uint8_t *s_in = (uint8_t *)(s_kk + out_hw * ksize);              // [max_rows][in_row_bytes]
-    uint8_t *s_tmp = s_in + (size_t)max_rows * in_row_bytes;         // [max_rows][tmp_row_bytes]
+// Rows rlo .. rlo + nrows - 1 of frame b's crop window into LDS (`in_row_bytes` per row), zero-filled where the window
+// hangs over a frame smaller than the crop (torchvision pads, then crops).
+__device__ __forceinline__ void pp_load_rows(const uint8_t *__restrict__ img, uint8_t *s_in, int b, int H, int W, int crop, int top,
+                                             int left, int ptop, int pleft, int rlo, int nrows, int in_row_bytes) {
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int b = blockIdx.y, y0 = blockIdx.x * ty;
-    const int ny = out_hw - y0 < ty ? out_hw - y0 : ty;
-    for (int e = tid; e < out_hw * 2; e += nt) s_bounds[e] = bounds[e];
-    for (int e = tid; e < out_hw * ksize; e += nt) s_kk[e] = kk[e];
-    const int rlo = bounds[y0 * 2];
-    const int ylast = y0 + ny - 1;
-    const int rhi = bounds[ylast * 2] + bounds[ylast * 2 + 1];
-    const int nrows = rhi - rlo;
-    // ---- load the input rows (crop window) into LDS
     const bool padded = (ptop | pleft) != 0 || H < crop || W < crop;
     const size_t row0 = padded ? 0 : ((size_t)b * H + top + rlo) * W * 3 + (size_t)left * 3;
     const int row_bytes = crop * 3;
@@ -1087,6 +1060,42 @@ __global__ __launch_bounds__(256) void preprocess_fused_kernel(
             }
         }
     }
+}
+
+// Fused crop + horizontal pass + vertical pass + ToTensor + Normalize.  One workgroup = one image x
+// PP_TY output rows: the input rows those outputs need (about 1.7*PP_TY + 8 at 376 -> 224) are
+// read from HBM once with 4-byte loads into LDS, resized horizontally to uint8 in LDS (Pillow
+// rounds and clips to 8 bits between the passes), then vertically, and stored as float32 CHW with
+// consecutive lanes on consecutive x.  HBM traffic per frame ~ crop*crop*3 (x1.3 row overlap between
+// tiles, absorbed by L2) + 3*out*out*4 bytes; the old two-kernel version moved the uint8
+// intermediate through memory and read single bytes.
+// `ty` (PP_TY_MAX = 16 at the reference's 376 -> 224; smaller when a larger crop would not fit the 160 KiB of LDS) is a
+// launch parameter.  A frame smaller than the crop is zero-padded like torchvision's CenterCrop (`ptop`, `pleft` rows /
+// pixels of padding before the frame; `top`, `left` then address the padded frame).
+#define PP_TY_MAX 16
+__global__ __launch_bounds__(256) void preprocess_fused_kernel(
+    const uint8_t *__restrict__ img, int H, int W, int crop, int top, int left, int ptop, int pleft, int ty,
+    int out_hw, int ksize, int max_rows, const int *__restrict__ bounds, const int *__restrict__ kk,
+    float m0, float m1, float m2, float s0, float s1, float s2, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int in_row_bytes = (crop * 3 + 3) & ~3;        // padded to dwords
+    const int tmp_row_bytes = out_hw * 3;
+    int *s_bounds = (int *)smem;                                     // [out_hw][2]
+    int *s_kk = s_bounds + out_hw * 2;                               // [out_hw][ksize]
+    uint8_t *s_in = (uint8_t *)(s_kk + out_hw * ksize);              // [max_rows][in_row_bytes]
+    uint8_t *s_tmp = s_in + (size_t)max_rows * in_row_bytes;         // [max_rows][tmp_row_bytes]
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int b = blockIdx.y, y0 = blockIdx.x * ty;
+    const int ny = out_hw - y0 < ty ? out_hw - y0 : ty;
+    for (int e = tid; e < out_hw * 2; e += nt) s_bounds[e] = bounds[e];
+    for (int e = tid; e < out_hw * ksize; e += nt) s_kk[e] = kk[e];
+    const int rlo = bounds[y0 * 2];
+    const int ylast = y0 + ny - 1;
+    const int rhi = bounds[ylast * 2] + bounds[ylast * 2 + 1];
+    const int nrows = rhi - rlo;
+    // ---- load the input rows (crop window) into LDS
+    pp_load_rows(img, s_in, b, H, W, crop, top, left, ptop, pleft, rlo, nrows, in_row_bytes);
+    const int lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
     __syncthreads();
     // ---- horizontal pass (uint8 result, rounded + clipped like ImagingResampleHorizontal_8bpc);
     //      a lane owns one output x and produces its three channels with one read of the taps
@@ -1130,8 +1139,111 @@ __global__ __launch_bounds__(256) void preprocess_fused_kernel(
     }
 }
 
+// The same transform with far fewer LDS instructions (the form above spends one per byte and per tap: 72 a pixel, and is
+// bound by them at 1.1 us a frame), for the tap counts that occur in practice (KS = 5 .. 13: scale factors up to 3):
+//   horizontal  a lane owns output columns xo, xo + 64, ..: their KS taps sit in registers; per input row the 3 KS bytes
+//               under the taps arrive as (3 KS + 3) / 4 + 1 aligned dwords, shifted into place with v_alignbyte
+//   vertical    a lane owns FOUR consecutive bytes (a dword column) of the interleaved uint8 rows; the row's taps are
+//               wave-uniform (scalar loads); one dword read per tap feeds four accumulators
+//   store       the uint8 results of a row go through LDS once more so that the three float planes are written with
+//               consecutive lanes on consecutive x.
+// Integer arithmetic as above (sums of the same products: the order is immaterial), so the result is the same bit for bit.
+// Taps past a window's end are zero in `kk` (precompute_coeffs pads them): what the extra reads hit does not matter, they stay
+// inside the workgroup's LDS.
+template <int KS>
+__global__ __launch_bounds__(512) void preprocess_tile_kernel(
+    const uint8_t *__restrict__ img, int H, int W, int crop, int top, int left, int ptop, int pleft, int ty,
+    int out_hw, int max_rows, const int *__restrict__ bounds, const int *__restrict__ kk,
+    float m0, float m1, float m2, float s0, float s1, float s2, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int in_row_bytes = (crop * 3 + 3) & ~3;
+    const int tmp_pitch = (out_hw * 3 + 3) & ~3;
+    uint8_t *s_in = (uint8_t *)smem;                                 // [max_rows][in_row_bytes]
+    uint8_t *s_tmp = s_in + (size_t)max_rows * in_row_bytes;         // [max_rows][tmp_pitch]   horizontal pass, uint8
+    uint8_t *s_out = s_tmp + (size_t)max_rows * tmp_pitch;           // [ty][tmp_pitch]         vertical pass, uint8
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
+    const int b = blockIdx.y, y0 = blockIdx.x * ty;
+    const int ny = out_hw - y0 < ty ? out_hw - y0 : ty;
+    const int rlo = bounds[y0 * 2];
+    const int ylast = y0 + ny - 1;
+    const int nrows = bounds[ylast * 2] + bounds[ylast * 2 + 1] - rlo;
+    pp_load_rows(img, s_in, b, H, W, crop, top, left, ptop, pleft, rlo, nrows, in_row_bytes);
+    __syncthreads();
+    // ---- horizontal pass (uint8 result, rounded + clipped like ImagingResampleHorizontal_8bpc)
+    constexpr int NE = (3 * KS + 3) / 4;                             // dwords holding the 3 KS bytes once aligned
+    const int in_pitch4 = in_row_bytes >> 2;
+    for (int xo = lane; xo < out_hw; xo += 64) {
+        int k[KS];
+#pragma unroll
+        for (int j = 0; j < KS; ++j) k[j] = kk[xo * KS + j];
+        const int boff = bounds[xo * 2] * 3, sh = boff & 3;
+        const uint32_t *src = (const uint32_t *)(s_in + (boff & ~3)) + wave * in_pitch4;
+        uint8_t *dst = s_tmp + (size_t)wave * tmp_pitch + xo * 3;
+        for (int r = wave; r < nrows; r += nw, src += nw * in_pitch4, dst += nw * tmp_pitch) {
+            uint32_t d[NE + 1], e[NE];
+#pragma unroll
+            for (int i = 0; i <= NE; ++i) d[i] = src[i];
+#pragma unroll
+            for (int i = 0; i < NE; ++i) e[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
+            int a[3] = {1 << (PREC_BITS - 1), 1 << (PREC_BITS - 1), 1 << (PREC_BITS - 1)};
+#pragma unroll
+            for (int x = 0; x < KS; ++x)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int idx = 3 * x + c;
+                    a[c] += __mul24((int)((e[idx >> 2] >> (8 * (idx & 3))) & 0xffu), k[x]);    // |k| < 2^23 (checked on the host)
+                }
+            dst[0] = (uint8_t)clip8(a[0]); dst[1] = (uint8_t)clip8(a[1]); dst[2] = (uint8_t)clip8(a[2]);
+        }
+    }
+    __syncthreads();
+    // ---- vertical pass + ToTensor + Normalize: one wave per output row
+    const int pitch4 = tmp_pitch >> 2;
+    for (int yo = wave; yo < ny; yo += nw) {
+        const int y = y0 + yo;
+        const int r0 = bounds[y * 2] - rlo;
+        int kj[KS], rj[KS];
+#pragma unroll
+        for (int j = 0; j < KS; ++j) {
+            kj[j] = kk[y * KS + j];
+            rj[j] = (r0 + j < nrows ? r0 + j : nrows - 1) * pitch4;   // zero taps past the window: any row will do
+        }
+        uint32_t *orow = (uint32_t *)(s_out + (size_t)yo * tmp_pitch);
+        for (int dc = lane; dc < pitch4; dc += 64) {
+            int a[4] = {1 << (PREC_BITS - 1), 1 << (PREC_BITS - 1), 1 << (PREC_BITS - 1), 1 << (PREC_BITS - 1)};
+#pragma unroll
+            for (int j = 0; j < KS; ++j) {
+                const uint32_t v = ((const uint32_t *)s_tmp)[rj[j] + dc];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) a[q] += __mul24((int)((v >> (8 * q)) & 0xffu), kj[j]);
+            }
+            // (the four clipped values are made opaque before packing: left to itself the compiler turns the low pair into
+            //  gfx950's v_ashr_pk_u8_i32 and ORs the other two onto a register whose upper half that instruction does not clear --
+            //  measured: bytes 2 and 3 of every dword wrong)
+            int c4[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { c4[q] = clip8(a[q]); asm volatile("" : "+v"(c4[q])); }
+            orow[dc] = (uint32_t)c4[0] | ((uint32_t)c4[1] << 8) | ((uint32_t)c4[2] << 16) | ((uint32_t)c4[3] << 24);
+        }
+        // the row was written by this wave and is read by this wave: LDS operations of a wave complete in order
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint8_t *q = s_out + (size_t)yo * tmp_pitch;
+        float *o0 = out + (((size_t)b * 3 + 0) * out_hw + y) * out_hw;
+        float *o1 = o0 + (size_t)out_hw * out_hw, *o2 = o1 + (size_t)out_hw * out_hw;
+        for (int xo = lane; xo < out_hw; xo += 64) {
+            o0[xo] = ((float)q[xo * 3] / 255.0f - m0) / s0;          // ToTensor, Normalize
+            o1[xo] = ((float)q[xo * 3 + 1] / 255.0f - m1) / s1;
+            o2[xo] = ((float)q[xo * 3 + 2] / 255.0f - m2) / s2;
+        }
+    }
+}
+
 struct PreprocCache {
     int device, crop, out_hw, ksize, max_rows, ty;
+    int max_rows2, ty2;                 // preprocess_tile_kernel's tile (its LDS holds no tables, but the output rows); ty2 = 0: not usable
     int *d_bounds, *d_kk;
 };
 static std::mutex g_pp_mutex;          // extractors on several threads share the tables
@@ -1172,7 +1284,27 @@ CSLAM_API int cslam_preprocess_dev(const uint8_t *d_img, int B, int H, int W, in
                               (size_t)max_rows * (in_row_bytes + (size_t)out_hw * 3);
                 if (need <= 160 * 1024 || ty == 1) break;
             }
-            pp = new PreprocCache{dev, crop, out_hw, ksize, max_rows, ty, nullptr, nullptr};
+            // preprocess_tile_kernel: the largest row tile that leaves room for two workgroups per CU (80 KiB), else for one
+            const size_t tmp_pitch = ((size_t)out_hw * 3 + 3) & ~(size_t)3;
+            int ty2 = PP_TY_MAX, max_rows2 = 0;
+            for (int pass = 0; pass < 2; ++pass) {
+                const size_t limit = pass == 0 ? 80 * 1024 : 160 * 1024;
+                bool ok = false;
+                for (ty2 = PP_TY_MAX; ty2 >= (pass == 0 ? 4 : 1); ty2 >>= 1) {
+                    max_rows2 = 0;
+                    for (int y0 = 0; y0 < out_hw; y0 += ty2) {
+                        int yl = y0 + ty2 - 1 < out_hw - 1 ? y0 + ty2 - 1 : out_hw - 1;
+                        int span = bounds[yl * 2] + bounds[yl * 2 + 1] - bounds[y0 * 2];
+                        if (span > max_rows2) max_rows2 = span;
+                    }
+                    if ((size_t)max_rows2 * (in_row_bytes + tmp_pitch) + (size_t)ty2 * tmp_pitch <= limit) { ok = true; break; }
+                }
+                if (ok) break;
+                if (pass == 1) ty2 = 0;                                  // does not fit: the table form decides
+            }
+            for (int v : kk)
+                if (v >= (1 << 23) || v <= -(1 << 23)) ty2 = 0;          // its 24-bit multiplies need |tap| < 2^23 (a tap is <= ~1.1 x 2^22)
+            pp = new PreprocCache{dev, crop, out_hw, ksize, max_rows, ty, max_rows2, ty2, nullptr, nullptr};
             HIP_TRY(hipMalloc((void **)&pp->d_bounds, bounds.size() * 4));
             HIP_TRY(hipMalloc((void **)&pp->d_kk, kk.size() * 4));
             HIP_TRY(hipMemcpy(pp->d_bounds, bounds.data(), bounds.size() * 4, hipMemcpyHostToDevice));
@@ -1181,16 +1313,36 @@ CSLAM_API int cslam_preprocess_dev(const uint8_t *d_img, int B, int H, int W, in
         }
     }
     const PreprocCache &g_pp = *pp;
-    const size_t lds = (size_t)out_hw * 2 * 4 + (size_t)out_hw * g_pp.ksize * 4 +
-                       (size_t)g_pp.max_rows * (in_row_bytes + (size_t)out_hw * 3);
-    ARG_CHECK(lds <= 160 * 1024, "crop too large for the fused transform: one output row's input rows exceed the LDS");
-    HIP_TRY(hipFuncSetAttribute((const void *)preprocess_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds));
     // torchvision CenterCrop: a frame smaller than the crop is zero-padded first ((crop - H) / 2 rows on top, the
     // odd row at the bottom), then top = round((H' - crop) / 2), left = round((W' - crop) / 2) on the padded frame
     const int ptop = H < crop ? (crop - H) / 2 : 0, pleft = W < crop ? (crop - W) / 2 : 0;
     const int Hp = H < crop ? crop : H, Wp = W < crop ? crop : W;
     const int top = (int)lrint((Hp - crop) / 2.0), left = (int)lrint((Wp - crop) / 2.0);
+    static const bool tile_form = [] { const char *e = getenv("CSLAM_PREPROCESS_TILE"); return !(e && e[0] == '0'); }();
+    if (tile_form && g_pp.ty2 > 0 && g_pp.ksize >= 5 && g_pp.ksize <= 13 && (g_pp.ksize & 1)) {
+        const size_t tmp_pitch = ((size_t)out_hw * 3 + 3) & ~(size_t)3;
+        const size_t lds2 = (size_t)g_pp.max_rows2 * (in_row_bytes + tmp_pitch) + (size_t)g_pp.ty2 * tmp_pitch;
+        const dim3 grid((out_hw + g_pp.ty2 - 1) / g_pp.ty2, B);
+#define PP_TILE(KS_)                                                                                                          \
+    case KS_:                                                                                                                 \
+        HIP_TRY(hipFuncSetAttribute((const void *)preprocess_tile_kernel<KS_>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                    (int)lds2));                                                                              \
+        hipLaunchKernelGGL(preprocess_tile_kernel<KS_>, grid, dim3(512), lds2, st, d_img, H, W, crop, top, left, ptop, pleft, \
+                           g_pp.ty2, out_hw, g_pp.max_rows2, g_pp.d_bounds, g_pp.d_kk, mean[0], mean[1], mean[2], std_[0],    \
+                           std_[1], std_[2], d_out);                                                                          \
+        break;
+        switch (g_pp.ksize) {
+            PP_TILE(5) PP_TILE(7) PP_TILE(9) PP_TILE(11) PP_TILE(13)
+        }
+#undef PP_TILE
+        HIP_TRY(hipGetLastError());
+        return CSLAM_OK;
+    }
+    const size_t lds = (size_t)out_hw * 2 * 4 + (size_t)out_hw * g_pp.ksize * 4 +
+                       (size_t)g_pp.max_rows * (in_row_bytes + (size_t)out_hw * 3);
+    ARG_CHECK(lds <= 160 * 1024, "crop too large for the fused transform: one output row's input rows exceed the LDS");
+    HIP_TRY(hipFuncSetAttribute((const void *)preprocess_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds));
     hipLaunchKernelGGL(preprocess_fused_kernel, dim3((out_hw + g_pp.ty - 1) / g_pp.ty, B), dim3(256), lds, st, d_img, H,
                        W, crop, top, left, ptop, pleft, g_pp.ty, out_hw, g_pp.ksize, g_pp.max_rows, g_pp.d_bounds,
                        g_pp.d_kk, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], d_out);

@@ -194,21 +194,6 @@ def use_tuned_gemms():
         warnings.warn("cslam_amd: tuned GEMM table not loaded (%s)" % e)
 
 
-def _sub_frames(B, tiles_per_frame, floats_per_tile):
-    """Frames per pass of one layer's three kernels (input transform -> 36 products -> output transform).  V and M are
-    written by one kernel and read once by the next; CSLAM_WINO_SUB_MB (0 = off: the whole batch in one pass) bounds their
-    size so that they are still in the memory-side cache (256 MB on MI355X) when they are read.  Never fewer frames than
-    give the products 1024 tiles."""
-    mb = float(os.environ.get("CSLAM_WINO_SUB_MB", "0"))
-    if mb <= 0:
-        return B
-    sb = int(mb * 2 ** 20 // (4 * tiles_per_frame * floats_per_tile))
-    sb = max(sb, -(-1024 // tiles_per_frame), 1)
-    if sb >= B:
-        return B
-    return -(-B // -(-B // sb))                                          # equal passes
-
-
 def _z_form(cin, cout):
     """Z form of the pair products (GEMM + column half of the output transform, 24 planes instead of 36) where it pays:
     measured per layer at the 256-frame chunk (profiles/r03_v4_perf_zform.log) the output kernel gains ~30 % everywhere, but
@@ -246,36 +231,28 @@ def wino_conv3x3(ws, x, U, U4, bias, relu, pool=False, residual=None, U3=None, a
         if slot is None:
             slot = ws._buf("amax", 1, x.device)
             _lib.check(lib.cslam_absmax_dev(_p(x), x.numel(), _p(slot), s))
+        V2 = ws._buf("V", 36 * T * Cin, x.device)                      # 36 x T x 2 Cin halfs
+        M = ws._buf("M", 36 * T * Cout, x.device)
+        _lib.check(lib.cslam_wino4_input_h2_dev(_p(x), B, H, W, Cin, _p(slot), _p(V2), s))
         Ho, Wo = (H // 2, W // 2) if pool else (H, W)
         y = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        if residual is None and _z_form(Cin, Cout):
+            # the purely HBM-bound product (conv2_2): the column half of the output transform is folded into the GEMM, which then
+            # writes -- and the output kernel reads -- 24 instead of 36 planes (csrc/wino_gemm.hip `wino_zgemm_h2_kernel`)
+            _lib.check(lib.cslam_wino_zgemm_h2_dev(_p(V2), _p(U2[0]), T, Cin, Cout, _p(M), s))
+            _lib.check(lib.cslam_wino4_output_z_dev(
+                _p(M), _p(bias) if bias is not None else None, B, H, W, Cout, int(relu), int(pool), _p(slot), float(U2[1]),
+                _p(amax_out) if amax_out is not None else None, _p(y), s))
+            ws.amax_written = amax_out is not None
+            return y
+        _lib.check(lib.cslam_wino_gemm_h2_dev(_p(V2), _p(U2[0]), T, Cin, Cout, _p(M), s))
         if residual is not None:
             residual = residual.contiguous(memory_format=torch.channels_last)
             assert residual.shape == y.shape and not pool
-        z = residual is None and _z_form(Cin, Cout)
-        # sub-batches whose V and M planes (36 (Cin + Cout) floats per tile; 36 Cin + 24 Cout in the Z form) stay in the
-        # memory-side cache between the three kernels: see `_sub_frames`.  The scale slot (a bound on max |x| of the whole
-        # batch) and amax_out (an atomic max) are shared, so the result does not depend on the split.
-        sb = _sub_frames(B, t4h * t4w, 36 * Cin + (24 if z else 36) * Cout)
-        V2 = ws._buf("V", 36 * sb * t4h * t4w * Cin, x.device)           # 36 x T x 2 Cin halfs
-        M = ws._buf("M", 36 * sb * t4h * t4w * Cout, x.device)
-        pb, pr, pa = (_p(bias) if bias is not None else None), None, (_p(amax_out) if amax_out is not None else None)
-        for b0 in range(0, B, sb):
-            nb = min(sb, B - b0)
-            Ts = nb * t4h * t4w
-            xs, ys = x[b0:b0 + nb], y[b0:b0 + nb]
-            _lib.check(lib.cslam_wino4_input_h2_dev(_p(xs), nb, H, W, Cin, _p(slot), _p(V2), s))
-            if z:
-                # the purely HBM-bound product (conv2_2): the column half of the output transform is folded into the GEMM, which
-                # then writes -- and the output kernel reads -- 24 instead of 36 planes (csrc/wino_gemm.hip `wino_zgemm_h2_kernel`)
-                _lib.check(lib.cslam_wino_zgemm_h2_dev(_p(V2), _p(U2[0]), Ts, Cin, Cout, _p(M), s))
-                _lib.check(lib.cslam_wino4_output_z_dev(_p(M), pb, nb, H, W, Cout, int(relu), int(pool), _p(slot), float(U2[1]), pa,
-                                                        _p(ys), s))
-            else:
-                _lib.check(lib.cslam_wino_gemm_h2_dev(_p(V2), _p(U2[0]), Ts, Cin, Cout, _p(M), s))
-                if residual is not None:
-                    pr = _p(residual[b0:b0 + nb])
-                _lib.check(lib.cslam_wino4_output_scaled_dev(_p(M), pb, pr, nb, H, W, Cout, int(relu), int(pool), _p(slot),
-                                                             float(U2[1]), pa, _p(ys), s))
+        _lib.check(lib.cslam_wino4_output_scaled_dev(
+            _p(M), _p(bias) if bias is not None else None, _p(residual) if residual is not None else None,
+            B, H, W, Cout, int(relu), int(pool), _p(slot), float(U2[1]), _p(amax_out) if amax_out is not None else None,
+            _p(y), s))
         ws.amax_written = amax_out is not None
         return y
     if four and U3 is not None:

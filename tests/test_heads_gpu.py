@@ -154,6 +154,26 @@ def test_preprocess_bit_exact_vs_pillow(g, T):
         assert np.max(np.abs(out[b] - o)) <= 2.4e-7
 
 
+@pytest.mark.parametrize("H,W,crop,out", [(120, 160, 100, 224), (301, 403, 300, 224), (480, 640, 600, 224), (301, 403, 301, 111),
+                                          (480, 640, 700, 224), (64, 48, 376, 224), (480, 640, 376, 225), (480, 641, 224, 224)])
+def test_preprocess_other_geometries_bit_exact(T, H, W, crop, out):
+    """cslam_preprocess_dev over the tap counts and layouts its two kernels meet: 5 taps (upsampling), 7, 9, 13, 15 taps (the
+    last beyond preprocess_tile_kernel's instantiations: the table kernel), frames smaller than the crop (zero padding like
+    torchvision's CenterCrop), rows that are not dword-aligned, an output width that is not a multiple of four, crop == output
+    (5 taps, a copy) -- against the numpy restatement of Pillow's two-pass 8-bit resize (oracle/heads_oracle.py, pinned to
+    Pillow's own output by tests/golden): the uint8 result identical, the floats within an ulp."""
+    torch, heads = T
+    imgs = np.random.default_rng(H + W + crop).integers(0, 256, size=(2, H, W, 3), dtype=np.uint8)
+    got = heads.preprocess(dev(T, imgs), crop, out).cpu().numpy()
+    mean = np.array(heads.IMAGENET_DEFAULT_MEAN, dtype=np.float32)[:, None, None]
+    std = np.array(heads.IMAGENET_DEFAULT_STD, dtype=np.float32)[:, None, None]
+    for b in range(2):
+        want = ho.preprocess(imgs[b], crop, out, heads.IMAGENET_DEFAULT_MEAN, heads.IMAGENET_DEFAULT_STD)
+        assert got[b].shape == want.shape == (3, out, out)
+        assert np.array_equal(np.rint((got[b] * std + mean) * 255.0), np.rint((want * std + mean) * 255.0))
+        assert np.max(np.abs(got[b] - want)) <= 2.4e-7
+
+
 def test_extractors_end_to_end_structure(T):
     """NetVLAD / CosPlace drop-in classes with seeded random weights (no checkpoints ship with
     the reference): HIP pipeline == the same pipeline restated with torch + the numpy oracle."""

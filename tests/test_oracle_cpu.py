@@ -117,3 +117,37 @@ def test_extract_oracle_vgg16_is_the_reference_layer_list():
         a, b = extract_oracle.vgg16_encoder(x, params), trunk(x)
     assert a.shape == (1, 512, 4, 4) and torch.equal(a, b)
     assert (a < 0).any()                                   # no ReLU after conv5_3
+
+
+def _prep_image(i):
+    img = np.random.default_rng(7 + i).integers(0, 256, size=(480, 640, 3), dtype=np.uint8)
+    if i == 1:
+        yy, xx = np.mgrid[0:480, 0:640]
+        img = np.stack([(xx * 255 // 639), (yy * 255 // 479), ((xx // 40 + yy // 40) % 2) * 255], axis=2).astype(np.uint8)
+    return img
+
+
+def test_preprocess_oracle_matches_the_pillow_golden():
+    """oracle/heads_oracle.py `preprocess` (the checker of cslam_preprocess_dev) against tests/golden/heads_g.npz `prep_*`: Pillow's own
+    crop + bicubic resize of the two 480 x 640 frames oracle/gen_golden_heads.py fed it (netvlad.py:202-208,223-226)."""
+    from oracle import heads_oracle as ho
+    g = np.load(GOLDEN + "/heads_g.npz")
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    for i in range(2):
+        img = _prep_image(i)
+        top, left = int(round((480 - 376) / 2.0)), int(round((640 - 376) / 2.0))
+        assert np.array_equal(ho.pil_bicubic_resize_u8(img[top:top + 376, left:left + 376], 224), g["prep_%d/resized_u8" % i])
+        assert np.max(np.abs(ho.preprocess(img, 376, 224, mean, std) - g["prep_%d/out" % i])) <= 2.4e-7
+
+
+@pytest.mark.parametrize("size,out", [(100, 224), (300, 224), (600, 224), (301, 111), (700, 224), (376, 225), (224, 224), (256, 112)])
+def test_preprocess_oracle_resize_equals_pillow_at_other_geometries(size, out):
+    """The geometries tests/test_heads_gpu.py::test_preprocess_other_geometries_bit_exact checks the kernels on (5 .. 15 taps,
+    upsampling, odd sizes): the numpy restatement of ImagingResample's two 8-bit passes against Pillow itself, where Pillow is
+    installed (it is in the build container; nothing here travels)."""
+    Image = pytest.importorskip("PIL.Image")
+    from oracle import heads_oracle as ho
+    img = np.random.default_rng(size + out).integers(0, 256, size=(size, size, 3), dtype=np.uint8)
+    img[: size // 2, : size // 3] //= 8                                 # flat dark region + edges: negative lobes, clipping
+    want = np.asarray(Image.fromarray(img).resize((out, out), Image.BICUBIC))
+    assert np.array_equal(ho.pil_bicubic_resize_u8(img, out), want)

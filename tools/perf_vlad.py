@@ -27,11 +27,5 @@ def run(tag, B=256, reps=30):
 
 
 if __name__ == "__main__":
-    for env, tag in (("0", "full"), ("1", "no sweep-1 MFMA"), ("2", "no sweep-2 MFMA"), ("3", "no MFMA"), ("7", "no MFMA, no softmax"),
-                     ("15", "no MFMA/softmax/loads"), ("8", "no global x loads")):
-        os.environ["CSLAM_VLAD_DBG"] = env
-        run(tag)
-    os.environ["CSLAM_VLAD_DBG"] = "0"
-    run("full", B=512)
-    run("full", B=1024)
-    os.environ["CSLAM_VLAD_MFMA"] = "0"
+    for B in (256, 512, 1024):
+        run("matrix form (vlad_mfma_kernel)", B=B)
