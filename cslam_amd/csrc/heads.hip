@@ -1161,6 +1161,7 @@ __global__ __launch_bounds__(512) void preprocess_tile_kernel(
     uint8_t *s_in = (uint8_t *)smem;                                 // [max_rows][in_row_bytes]
     uint8_t *s_tmp = s_in + (size_t)max_rows * in_row_bytes;         // [max_rows][tmp_pitch]   horizontal pass, uint8
     uint8_t *s_out = s_tmp + (size_t)max_rows * tmp_pitch;           // [ty][tmp_pitch]         vertical pass, uint8
+    float *s_lut = (float *)(s_out + (size_t)ty * tmp_pitch);        // [3][256]                ToTensor + Normalize of every uint8 value
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nw = blockDim.x >> 6;
     const int b = blockIdx.y, y0 = blockIdx.x * ty;
@@ -1169,6 +1170,11 @@ __global__ __launch_bounds__(512) void preprocess_tile_kernel(
     const int ylast = y0 + ny - 1;
     const int nrows = bounds[ylast * 2] + bounds[ylast * 2 + 1] - rlo;
     pp_load_rows(img, s_in, b, H, W, crop, top, left, ptop, pleft, rlo, nrows, in_row_bytes);
+    // the two IEEE divisions of ToTensor + Normalize, once per (channel, uint8 value) instead of once per output element
+    for (int e = tid; e < 768; e += blockDim.x) {
+        const int c = e >> 8;
+        s_lut[e] = ((float)(e & 255) / 255.0f - (c == 0 ? m0 : c == 1 ? m1 : m2)) / (c == 0 ? s0 : c == 1 ? s1 : s2);
+    }
     __syncthreads();
     // ---- horizontal pass (uint8 result, rounded + clipped like ImagingResampleHorizontal_8bpc)
     constexpr int NE = (3 * KS + 3) / 4;                             // dwords holding the 3 KS bytes once aligned
@@ -1234,9 +1240,9 @@ __global__ __launch_bounds__(512) void preprocess_tile_kernel(
         float *o0 = out + (((size_t)b * 3 + 0) * out_hw + y) * out_hw;
         float *o1 = o0 + (size_t)out_hw * out_hw, *o2 = o1 + (size_t)out_hw * out_hw;
         for (int xo = lane; xo < out_hw; xo += 64) {
-            o0[xo] = ((float)q[xo * 3] / 255.0f - m0) / s0;          // ToTensor, Normalize
-            o1[xo] = ((float)q[xo * 3 + 1] / 255.0f - m1) / s1;
-            o2[xo] = ((float)q[xo * 3 + 2] / 255.0f - m2) / s2;
+            o0[xo] = s_lut[q[xo * 3]];                                // ToTensor, Normalize
+            o1[xo] = s_lut[256 + q[xo * 3 + 1]];
+            o2[xo] = s_lut[512 + q[xo * 3 + 2]];
         }
     }
 }
@@ -1297,7 +1303,7 @@ CSLAM_API int cslam_preprocess_dev(const uint8_t *d_img, int B, int H, int W, in
                         int span = bounds[yl * 2] + bounds[yl * 2 + 1] - bounds[y0 * 2];
                         if (span > max_rows2) max_rows2 = span;
                     }
-                    if ((size_t)max_rows2 * (in_row_bytes + tmp_pitch) + (size_t)ty2 * tmp_pitch <= limit) { ok = true; break; }
+                    if ((size_t)max_rows2 * (in_row_bytes + tmp_pitch) + (size_t)ty2 * tmp_pitch + 3072 <= limit) { ok = true; break; }
                 }
                 if (ok) break;
                 if (pass == 1) ty2 = 0;                                  // does not fit: the table form decides
@@ -1321,7 +1327,7 @@ CSLAM_API int cslam_preprocess_dev(const uint8_t *d_img, int B, int H, int W, in
     static const bool tile_form = [] { const char *e = getenv("CSLAM_PREPROCESS_TILE"); return !(e && e[0] == '0'); }();
     if (tile_form && g_pp.ty2 > 0 && g_pp.ksize >= 5 && g_pp.ksize <= 13 && (g_pp.ksize & 1)) {
         const size_t tmp_pitch = ((size_t)out_hw * 3 + 3) & ~(size_t)3;
-        const size_t lds2 = (size_t)g_pp.max_rows2 * (in_row_bytes + tmp_pitch) + (size_t)g_pp.ty2 * tmp_pitch;
+        const size_t lds2 = (size_t)g_pp.max_rows2 * (in_row_bytes + tmp_pitch) + (size_t)g_pp.ty2 * tmp_pitch + 3072;   // + the [3][256] table
         const dim3 grid((out_hw + g_pp.ty2 - 1) / g_pp.ty2, B);
 #define PP_TILE(KS_)                                                                                                          \
     case KS_:                                                                                                                 \
