@@ -115,6 +115,8 @@ def parse():
     ap.add_argument("--extract-chunk", type=int, default=512,
                     help="frames per backbone forward (512: +2-3 %% over 256, profiles/r02_v23_extract_chunk.log; the per-kernel "
                          "rooflines below are priced on 256-frame launches, the shapes of the committed PMC passes)")
+    ap.add_argument("--extract-lanes", type=int, default=2,
+                    help="HIP streams the step's extract chunks alternate over (NetVLAD.compute_embeddings_batch_device; 1 = one stream)")
     ap.add_argument("--backbone-conv", default="winograd", choices=["winograd", "winograd2", "direct"],
                     help="execution of the wide 3x3 backbone convolutions (vpr/winograd.py)")
     ap.add_argument("--cpu-queries", type=int, default=48, help="cpu_baseline sample size of the match leg (queries)")
@@ -241,6 +243,8 @@ def main():
         if extractor is None:
             d = torch.randn((a.batch, a.dim), generator=qgen, device=dev)
             return d / d.norm(dim=1, keepdim=True)
+        if bdt is None:
+            return extractor.compute_embeddings_batch_device(frames, a.extract_chunk, a.extract_lanes)
         outs = [extractor.compute_embeddings_device(frames[s:s + a.extract_chunk], bdt)
                 for s in range(0, a.batch, a.extract_chunk)]
         return torch.cat(outs)
@@ -292,16 +296,38 @@ def main():
     flush()
     kernel_ms.clear()
     trunk_times = None
-    if extractor is not None:
-        _clib.check(_clib.load().cslam_trunk_timing(1))       # two HIP events per product launch, on the launch stream
-    dt = timed(step, a.steps)
-    if extractor is not None:
+    trunk_steps, trunk_step_ms = a.steps, None
+    trunk_src = "every product launch of the timed steps bracketed by HIP events on its stream (cslam_trunk_timing)"
+
+    def read_trunk_times():
         tt = (_C.c_double * 8)()
         _clib.check(_clib.load().cslam_trunk_timing_read(_C.byref(tt)))
         _clib.check(_clib.load().cslam_trunk_timing(0))
-        trunk_times = [float(x) for x in tt]
+        return [float(x) for x in tt]
+    one_lane = extractor is None or a.extract_lanes <= 1 or bdt is not None
+    if extractor is not None and one_lane:
+        _clib.check(_clib.load().cslam_trunk_timing(1))       # two HIP events per product launch, on the launch stream
+    dt = timed(step, a.steps)
+    if extractor is not None and one_lane:
+        trunk_times = read_trunk_times()
     step_kernel_ms = [m for m in kernel_ms if m > 0]
     value = world * a.batch * a.steps / dt
+    if extractor is not None and not one_lane:
+        # with two lanes a product launch shares the chip with the other lane's kernels and its duration is not its own: the
+        # per-launch figures of the trunk's products come from two one-lane steps run after the timed region
+        keep_lanes, keep_ms = a.extract_lanes, list(kernel_ms)
+        a.extract_lanes = 1
+        step()
+        flush()
+        _clib.check(_clib.load().cslam_trunk_timing(1))
+        trunk_steps = 2
+        trunk_step_ms = timed(step, trunk_steps) / trunk_steps * 1e3
+        trunk_times = read_trunk_times()
+        a.extract_lanes = keep_lanes
+        kernel_ms[:] = keep_ms
+        trunk_src = ("every product launch of %d one-lane steps run after the timed region, bracketed by HIP events on its stream "
+                     "(cslam_trunk_timing); in the timed steps the extract chunks alternate over %d lanes and a launch shares the chip "
+                     "with the other lane's kernels" % (trunk_steps, keep_lanes))
 
     # ---- N > 1, rows mode: the sharded step's answer against the UNSHARDED bank (outside the timed region): every rank rebuilds
     # the whole seeded bank, searches its own step's descriptors in it on its own GPU and compares rows / float64 scores / counts
@@ -408,12 +434,13 @@ def main():
     roofline_step_largest = None
     if trunk_times is not None and rank == 0 and trunk_times[0] + trunk_times[4] > 0:
         lh, msh, flh, byh, lm, msm, flm, bym = trunk_times
-        per_step = (msh + msm) / a.steps
+        per_step = (msh + msm) / trunk_steps
         roofline_step_largest = {
             "kernel": "wino_zgemm_h2_kernel / wino_gemm_h2_kernel (the trunk's 36-frequency pair products)",
-            "launches_per_step": round((lh + lm) / a.steps, 1), "ms_per_step": round(per_step, 3),
-            "share_of_step": round(per_step / (dt / a.steps * 1e3), 4),
-            "source": "every product launch of the timed steps bracketed by HIP events on its stream (cslam_trunk_timing)",
+            "launches_per_step": round((lh + lm) / trunk_steps, 1), "ms_per_step": round(per_step, 3),
+            "share_of_step": round(per_step / (trunk_step_ms if trunk_step_ms is not None else dt / a.steps * 1e3), 4),
+            "one_lane_step_ms": None if trunk_step_ms is None else round(trunk_step_ms, 3),
+            "source": trunk_src,
             "hbm_bound_layers": None if lh == 0 else {
                 "what": "Cin <= 256 (conv2_2 ... conv4_1): V2 in + M / Z out", "bound": "hbm", "launches": int(lh),
                 "kernel_ms": round(msh / lh, 4), "achieved": round(byh / msh / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -652,6 +679,7 @@ def main():
                                    f"{a.bank_rows}-row bank" + (" per GPU" if not rows_mode else "") + ("" if extractor else " [match leg only]"),
                        "bank_rows": a.bank_rows, "dim": a.dim, "keyframes_per_rank_per_step": a.batch, "k": a.k,
                        "queries_per_rank_per_step": nq_step,
+                       "extract_chunk": a.extract_chunk, "extract_lanes": a.extract_lanes if extractor is not None else None,
                        "bank_rows_per_gpu": local_rows,
                        "parallelism": ("single GPU" if world == 1 else
                                        "one %d-row bank split by rows over %d GPUs: RCCL all-gather of the new descriptors, "

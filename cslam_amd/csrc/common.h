@@ -6,6 +6,8 @@
 #include <string.h>
 #include <math.h>
 #include <atomic>
+#include <mutex>
+#include <vector>
 #include "../../include/cslam_hip.h"
 #include "../../include/cslam_hip_experimental.h"
 
@@ -84,6 +86,35 @@ struct DeviceOnce {
     void done(int dev) { if (dev >= 0 && dev < 64) mask.fetch_or(1ull << dev, std::memory_order_release); }
 };
 int cslam_cu_count();          // compute units of the CURRENT device, cached per device (bank.hip); 0 on error
+
+// Scratch of an entry point that needs device memory between its own kernels (split-K partial sums, operand pairs): one
+// grow-only buffer per (device, stream).  Launches on ONE stream run in order, so they can share a buffer; two streams -- two
+// extraction lanes, two host threads -- must not.  A superseded buffer stays allocated: a pointer captured in a hipGraph (the
+// online path replays one) has to remain valid when a later, larger batch needs more room.  `floor_bytes` = smallest allocation.
+// Returns nullptr when the allocation fails or the stream is being captured into a graph and has no buffer of that size yet.
+struct StreamScratch {
+    struct Entry { int dev; void *stream; char *ptr; size_t bytes; };
+    std::mutex mu;
+    std::vector<Entry> entries;
+    char *get(int dev, void *stream, size_t need, size_t floor_bytes) {
+        std::lock_guard<std::mutex> lock(mu);
+        Entry *e = nullptr;
+        for (Entry &x : entries)
+            if (x.dev == dev && x.stream == stream) e = &x;
+        if (e && e->bytes >= need) return e->ptr;
+        size_t want = e && need < 2 * e->bytes ? 2 * e->bytes : need;
+        if (want < floor_bytes) want = floor_bytes;
+        // a capturing stream cannot allocate (and the attempt would invalidate the capture): the caller has to have run the entry
+        // point once, at this size, on the stream it captures on -- cslam_amd.vpr.heads.OnlineGraph warms up on its capture stream
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return nullptr;
+        char *fresh = nullptr;
+        if (hipMalloc((void **)&fresh, want) != hipSuccess) return nullptr;
+        if (e) { e->ptr = fresh; e->bytes = want; }                // the previous buffer is left alive on purpose (see above)
+        else entries.push_back(Entry{dev, stream, fresh, want});
+        return fresh;
+    }
+};
 
 static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int64_t ceil_div64(int64_t x, int64_t m) { return (x + m - 1) / m; }

@@ -255,11 +255,8 @@ __global__ __launch_bounds__(256) void pca_gemv_kernel(const float *__restrict__
     }
 }
 
-// Split-K / GEMV partial sums.  Buffers only ever grow and superseded ones stay allocated, so a pointer captured in
-// a hipGraph (the online path replays one) stays valid when a later, larger batch needs more room.
-static float *g_part = nullptr;
-static size_t g_part_bytes = 0;
-static int g_part_dev = -1;
+// Split-K / GEMV partial sums, operand pairs of the pair form: per (device, stream), grow-only (common.h).
+static StreamScratch g_part_scratch;
 
 CSLAM_API int cslam_pca_project_dev(const float *d_x, int64_t ldx, const float *d_comp, int64_t ldc,
                                     const float *d_mean_proj, const float *d_inv_scale, int B, int Din, int Dout,
@@ -280,13 +277,9 @@ CSLAM_API int cslam_pca_project_dev(const float *d_x, int64_t ldx, const float *
     const int kps = (int)ceil_div64(nkt, S);
     S = (int)ceil_div64(nkt, kps);
     size_t need = (size_t)S * B * Dout * 4;
-    if (need > g_part_bytes || g_part_dev != dev) {
-        size_t want = need > 2 * g_part_bytes ? need : 2 * g_part_bytes;
-        if (want < ((size_t)64 << 20)) want = (size_t)64 << 20;
-        float *fresh = nullptr;
-        HIP_TRY(hipMalloc((void **)&fresh, want));      // the previous buffer is left alive on purpose (see above)
-        g_part = fresh; g_part_bytes = want; g_part_dev = dev;
-    }
+    char *g_part_c = g_part_scratch.get(dev, stream, need, (size_t)64 << 20);
+    ARG_CHECK(g_part_c, "no scratch for this stream: out of device memory, or the stream is capturing and the call was not run on it before");
+    float *g_part = (float *)g_part_c;
     if (B <= 4 && Din % 4 == 0) {
         dim3 grid((unsigned)ceil_div64(ceil_div64(Dout, 2), 4)), block(256);
         if (B == 1) hipLaunchKernelGGL(pca_gemv_kernel<1>, grid, block, 0, st, d_comp, ldc, d_x, ldx, Din, Dout, g_part);
@@ -377,13 +370,9 @@ CSLAM_API int cslam_pca_project_pairs_dev(const float *d_x, int64_t ldx, float x
     int dev = 0; HIP_TRY(hipGetDevice(&dev));
     const size_t a2_bytes = (size_t)B * Din * 4, part_bytes = (size_t)S * B * Dout * 4;
     const size_t need = a2_bytes + part_bytes + 256;
-    if (need > g_part_bytes || g_part_dev != dev) {
-        size_t want = need > 2 * g_part_bytes ? need : 2 * g_part_bytes;
-        if (want < ((size_t)64 << 20)) want = (size_t)64 << 20;
-        float *fresh = nullptr;
-        HIP_TRY(hipMalloc((void **)&fresh, want));      // the previous buffer is left alive on purpose (see above)
-        g_part = fresh; g_part_bytes = want; g_part_dev = dev;
-    }
+    char *g_part_c = g_part_scratch.get(dev, stream, need, (size_t)64 << 20);
+    ARG_CHECK(g_part_c, "no scratch for this stream: out of device memory, or the stream is capturing and the call was not run on it before");
+    float *g_part = (float *)g_part_c;
     unsigned *slot = (unsigned *)g_part;
     unsigned short *A2 = (unsigned short *)((char *)g_part + 256);
     float *part = (float *)((char *)g_part + 256 + a2_bytes);

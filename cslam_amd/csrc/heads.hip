@@ -808,10 +808,8 @@ __global__ __launch_bounds__(256) void vlad_norm_kernel(float *__restrict__ out,
     for (int c = tid; c < C; c += 256) o[c] *= f;
 }
 
-// scratch of the small-batch path; grows only, superseded buffers stay allocated (hipGraph-safe, like g_part)
-static float *g_vs = nullptr;
-static size_t g_vs_floats = 0;
-static int g_vs_dev = -1;
+// scratch of the small-batch path: per (device, stream), grow-only (common.h)
+static StreamScratch g_vs_scratch;
 
 static int vlad_aggregate(const float *d_feat, const float *d_assign_w, const float *d_assign_b,
                           const float *d_centroids, int B, int C, int P, int K,
@@ -853,13 +851,8 @@ static int vlad_aggregate(const float *d_feat, const float *d_assign_w, const fl
         const int ntile = (P + VS_PT - 1) / VS_PT, nslab = (C + VL_CC - 1) / VL_CC;
         const size_t n_wt = (size_t)C * VK, n_a = (size_t)B * P * VK, n_as = (size_t)B * ntile * VK;
         const size_t n_ss = (size_t)B * VK * nslab, need = n_wt + n_a + n_as + n_ss;
-        if (need > g_vs_floats || g_vs_dev != dev) {
-            size_t want = need > 2 * g_vs_floats ? need : 2 * g_vs_floats;
-            if (want < ((size_t)1 << 20)) want = (size_t)1 << 20;
-            float *fresh = nullptr;
-            HIP_TRY(hipMalloc((void **)&fresh, want * 4));
-            g_vs = fresh; g_vs_floats = want; g_vs_dev = dev;
-        }
+        float *g_vs = (float *)g_vs_scratch.get(dev, stream, need * 4, (size_t)4 << 20);
+        ARG_CHECK(g_vs, "no scratch for this stream: out of device memory, or the stream is capturing and the call was not run on it before");
         float *wt = g_vs, *a = wt + n_wt, *as = a + n_a, *ss = as + n_as;
         hipLaunchKernelGGL(vlad_wt_kernel, dim3((unsigned)((C * VK + 255) / 256)), dim3(256), 0, st, d_assign_w, C, wt);
         const size_t lds1 = ((size_t)C * VS_PT + 16 * VS_PT + VS_PT * VK + VS_PT) * 4;

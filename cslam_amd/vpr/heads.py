@@ -163,7 +163,9 @@ class OnlineGraph(object):
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # captured on the stream the warm-up ran on: the C side keeps its scratch per (device, stream) and cannot allocate
+        # while a stream is capturing
+        with torch.cuda.graph(graph, stream=side):
             out = self.fn(inp)
         pin_in = torch.empty(tuple(shape), dtype=torch.uint8).pin_memory()
         pin_out = torch.empty(tuple(out.shape), dtype=out.dtype).pin_memory()

@@ -19,10 +19,13 @@
  *   - row indices are int64 in the API (bank row number = order of insertion,
  *     the key of the reference's `items` dict, cslam/nns_matching.py:38);
  *   - threading: like the reference classes (one rclpy single-threaded executor per robot,
- *     loop_closure_detection_node.py:109) objects are not thread-safe, and the descriptor-head entry points
- *     share per-process scratch buffers: call them from one thread (or one stream at a time) per process;
+ *     loop_closure_detection_node.py:109) objects (banks, communicators) are not thread-safe.  The descriptor-head
+ *     entry points keep the scratch they need between their own kernels per (device, stream): calls on
+ *     different streams may be in flight together (cslam_amd's two extraction lanes are), calls on one stream
+ *     run in order anyway;
  *   - scratch buffers and coefficient tables owned by the library only grow and are released at process exit,
- *     so device pointers captured in a hipGraph stay valid.
+ *     so device pointers captured in a hipGraph stay valid.  A stream that is being captured cannot allocate:
+ *     run an entry point once, at the captured sizes, on the stream you capture on (otherwise CSLAM_E_INVALID).
  */
 #ifndef CSLAM_HIP_H
 #define CSLAM_HIP_H

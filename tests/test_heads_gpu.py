@@ -174,6 +174,50 @@ def test_preprocess_other_geometries_bit_exact(T, H, W, crop, out):
         assert np.max(np.abs(got[b] - want)) <= 2.4e-7
 
 
+@pytest.mark.parametrize("chunk", [12, 4])
+def test_netvlad_batch_extraction_over_two_lanes_equals_one_stream(T, chunk):
+    """NetVLAD.compute_embeddings_batch_device: chunks alternating over two HIP streams (each with its own trunk workspaces) give
+    the descriptors of the same chunks on one stream, bit for bit -- chunk 12: the batch kernels (stem, pair products,
+    channels-last VLAD, pair PCA); chunk 4: the small-batch kernels, whose scratch (VLAD partials, split-K sums) is per stream."""
+    torch, heads = T
+    from cslam_amd.vpr.netvlad import NetVLAD
+    nv = NetVLAD({"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376, "frontend.netvlad.pca_dim": 256}, None)
+    gen = torch.Generator(device="cuda").manual_seed(chunk)
+    frames = torch.randint(0, 256, (5 * chunk + 3, 240, 320, 3), generator=gen, device="cuda", dtype=torch.uint8)
+    one = nv.compute_embeddings_batch_device(frames, chunk, 1)
+    for _ in range(3):
+        two = nv.compute_embeddings_batch_device(frames, chunk, 2)
+        torch.cuda.synchronize()
+        assert two.shape == one.shape == (frames.shape[0], 256) and torch.equal(one, two)
+    three = nv.compute_embeddings_batch_device(frames, chunk, 3)
+    assert torch.equal(one, three)
+    assert torch.equal(one[:chunk], nv.compute_embeddings_device(frames[:chunk]))
+
+
+def test_projection_scratch_is_per_stream(T):
+    """cslam_pca_project_pairs_dev / cslam_pca_project_dev keep operand pairs and split-K sums in scratch between their kernels:
+    two streams in flight at once (two extraction lanes, two host threads) must not share it."""
+    torch, heads = T
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    comp = torch.randn((512, 4096), generator=gen, device="cuda") / 64.0
+    mp = torch.randn(512, generator=gen, device="cuda") * 0.1
+    pairs = heads.pca_pair_weights(comp)
+    xs = [torch.randn((96, 4096), generator=gen, device="cuda") for _ in range(2)]
+    small = [x[:3].contiguous() for x in xs]
+    want = [heads.pca_project(x, comp, mp, None, pairs) for x in xs] + [heads.pca_project(x, comp, mp, None) for x in small]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(2)]
+    for _ in range(10):
+        got = [None] * 4
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                for _ in range(4):
+                    got[i] = heads.pca_project(xs[i], comp, mp, None, pairs)
+                    got[2 + i] = heads.pca_project(small[i], comp, mp, None)
+        torch.cuda.synchronize()
+        assert all(torch.equal(g, w) for g, w in zip(got, want))
+
+
 def test_extractors_end_to_end_structure(T):
     """NetVLAD / CosPlace drop-in classes with seeded random weights (no checkpoints ship with
     the reference): HIP pipeline == the same pipeline restated with torch + the numpy oracle."""
