@@ -140,6 +140,37 @@ def l2_normalize_(x, eps=1e-12, zero_norm_to_one=False):
     return x
 
 
+def extract_over_lanes(lane_list, frames_u8, chunk, lanes, lane_runner, run_chunk):
+    """The batch form of an extractor: `chunk` frames per pass of its pipeline, the passes alternating over `lanes` HIP streams.
+    `lane_list` is the extractor's own list of (stream, runner) pairs, grown here with `lane_runner(i)` (a trunk runner with its
+    own V / M workspaces); `run_chunk(frames, runner)` -> [b, d] runs one pass on the CURRENT stream.  Two passes in flight fill
+    each other's tails and launch gaps (NetVLAD: 16.5 -> 15.3 ms per 256 frames with two lanes, no gain from a third, none from
+    offsetting the lanes by part of a pass: profiles/r03_v25_two_lanes.log).  The lanes start behind the caller's stream and the
+    caller's stream continues behind them: no host synchronisation.  (Not offered for CosPlace: its ResNet runner launches
+    library convolutions -- 7 x 7 stem, strided layers -- whose per-stream set-up made a second lane 16 x slower and the
+    descriptors differ in the last bit, profiles/r03_v30_c2_lanes_rejected.log.)"""
+    B = int(frames_u8.shape[0])
+    starts = list(range(0, B, chunk))
+    lanes = min(lanes, len(starts))
+    while len(lane_list) < lanes:
+        lane_list.append((torch.cuda.Stream(device=frames_u8.device), lane_runner(len(lane_list))))
+    cur = torch.cuda.current_stream(frames_u8.device)
+    out = None
+    for st, _ in lane_list[:lanes]:
+        st.wait_stream(cur)
+    for i, s in enumerate(starts):
+        st, runner = lane_list[i % lanes]
+        with torch.cuda.stream(st):
+            d = run_chunk(frames_u8[s:s + chunk], runner)
+            if out is None:
+                out = torch.empty((B, d.shape[1]), dtype=d.dtype, device=d.device)
+            out[s:s + d.shape[0]].copy_(d)
+    for st, _ in lane_list[:lanes]:
+        cur.wait_stream(st)
+    out.record_stream(cur)            # allocated on a lane's stream, handed to the caller's: tell the caching allocator
+    return out
+
+
 class OnlineGraph(object):
     """The one-keyframe pipeline (H2D of the frame excluded) captured once per frame shape in a HIP graph and
     replayed: the online path is ~45 small launches per keyframe, launch-bound when issued one by one.

@@ -229,42 +229,22 @@ class NetVLAD(object):
 
     def compute_embeddings_batch_device(self, frames_u8, chunk=512, lanes=2):
         """frames [B,H,W,3] uint8 (device) -> descriptors [B, d] float32 (device), `chunk` frames per pass of the pipeline, the
-        passes alternating over `lanes` HIP streams, each with its own trunk workspaces.  Two passes in flight fill each other's
-        tails and launch gaps (measured: 16.5 -> 15.3 ms per 256 frames with two lanes, no gain from a third, none from offsetting the
-        lanes by part of a pass: profiles/r03_v25_two_lanes.log).  The lanes start behind the caller's stream and the caller's stream
-        continues behind them: no host synchronisation.  Each chunk runs exactly the kernels of `compute_embeddings_device` on its
-        frames, so the descriptors do not depend on `lanes`."""
-        B = int(frames_u8.shape[0])
-        starts = list(range(0, B, chunk))
-        if lanes <= 1 or len(starts) <= 1 or self.backbone_conv not in ('winograd', 'winograd2'):
-            outs = [self.compute_embeddings_device(frames_u8[s:s + chunk]) for s in starts]
+        passes alternating over `lanes` HIP streams, each with its own trunk workspaces (heads.extract_over_lanes).  Each chunk
+        runs exactly the kernels of `compute_embeddings_device` on its frames, so the descriptors do not depend on `lanes`."""
+        if lanes <= 1 or frames_u8.shape[0] <= chunk or self.backbone_conv not in ('winograd', 'winograd2'):
+            outs = [self.compute_embeddings_device(frames_u8[s:s + chunk]) for s in range(0, int(frames_u8.shape[0]), chunk)]
             return outs[0] if len(outs) == 1 else torch.cat(outs)
-        lanes = min(lanes, len(starts))
-        while len(self._lanes) < lanes:
-            if not self._lanes and self.trunk is not None:
-                trunk = self.trunk                                  # lane 0 shares the single-pass trunk (and its workspaces)
-            else:
-                trunk = WinogradTrunk(self.encoder, min_in_channels=64, tile=4 if self.backbone_conv == 'winograd' else 2)
-                trunk.input_bound = heads.normalised_image_bound()
-                if not self._lanes:
-                    self.trunk = trunk
-            self._lanes.append((torch.cuda.Stream(device=frames_u8.device), trunk))
-        cur = torch.cuda.current_stream(frames_u8.device)
-        out = None
-        for st, _ in self._lanes[:lanes]:
-            st.wait_stream(cur)
-        for i, s in enumerate(starts):
-            st, trunk = self._lanes[i % lanes]
-            with torch.cuda.stream(st):
-                d = self.compute_embeddings_device(frames_u8[s:s + chunk], _trunk=trunk)
-                if out is None:
-                    out = torch.empty((B, d.shape[1]), dtype=d.dtype, device=d.device)
-                out[s:s + d.shape[0]].copy_(d)
-        for st, _ in self._lanes[:lanes]:
-            cur.wait_stream(st)
-        # `out` was allocated on a lane's stream and is handed to the caller's: tell the caching allocator
-        out.record_stream(cur)
-        return out
+
+        def lane_trunk(i):
+            if i == 0 and self.trunk is not None:
+                return self.trunk                                   # lane 0 shares the single-pass trunk (and its workspaces)
+            trunk = WinogradTrunk(self.encoder, min_in_channels=64, tile=4 if self.backbone_conv == 'winograd' else 2)
+            trunk.input_bound = heads.normalised_image_bound()
+            if i == 0:
+                self.trunk = trunk
+            return trunk
+        return heads.extract_over_lanes(self._lanes, frames_u8, chunk, lanes, lane_trunk,
+                                        lambda fr, trunk: self.compute_embeddings_device(fr, _trunk=trunk))
 
     def compute_embedding(self, keyframe):
         """Global image descriptor of one RGB keyframe (reference :212-245)."""

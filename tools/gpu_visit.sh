@@ -37,6 +37,7 @@ for w in "$@"; do
     zform) timeout 600 python tools/perf_zform.py > $out/perf_zform.log 2>&1; note zform $?; timeout 300 python tools/perf_zgemm_variants.py > $out/zgemm_variants.log 2>&1;;
     chunks) for c in 256 512 1024; do timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --extract-chunk $c > $out/bench_chunk$c.json 2> $out/bench_chunk$c.err; done; note chunks $?;;
     lanes) for cl in "256 1" "256 2" "256 4" "512 1" "512 2" "342 3" "128 2"; do set -- $cl; timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --extract-chunk $1 --extract-lanes $2 > $out/bench_c$1_l$2.json 2> $out/bench_c$1_l$2.err; python -c "import json,sys; d=json.load(open('$out/bench_c$1_l$2.json')); print('chunk $1 lanes $2', d['value'], d['ms_per_step'], d.get('extract_only'))" >> $out/summary.txt; done; note lanes $?;;
+    c2) for c in 250 500; do timeout 900 python tools/perf_c2.py 10000 $c winograd > $out/perf_c2_$c.log 2>&1; grep "^C2" $out/perf_c2_$c.log >> $out/summary.txt; done; note c2 $?;;
     acm_small) timeout 900 python tools/perf_acm_small.py > $out/perf_acm_small.log 2>&1; note acm_small $?;;
     c5) timeout 1200 python tools/perf_c5.py 12500 8 1000 250 drain > $out/perf_c5_drain.log 2>&1; note c5_drain $?
         timeout 1200 python tools/perf_c5.py 12500 8 1000 250 drain-async > $out/perf_c5_drain_async.log 2>&1; note c5_drain_async $?;;
