@@ -85,12 +85,14 @@ typedef int (*fn_dgemm)(rb_handle, int, int, int, int, int, const double *, cons
                         const double *, double *, int);
 typedef int (*fn_dtrsm)(rb_handle, int, int, int, int, int, int, const double *, const double *, int, double *, int);
 typedef int (*fn_dpotrf)(rb_handle, int, int, double *, int, int *);
+typedef int (*fn_set_atomics)(rb_handle, int);
 enum { RB_OP_N = 111, RB_OP_T = 112, RB_UPPER = 121, RB_NON_UNIT = 131, RB_LEFT = 141 };
 
 struct Blas {
     void *hb = nullptr, *hs = nullptr;
     fn_create create = nullptr; fn_set_stream set_stream = nullptr; fn_dgemm dgemm = nullptr; fn_dtrsm dtrsm = nullptr;
     fn_dpotrf dpotrf = nullptr;
+    fn_set_atomics set_atomics = nullptr;      // optional
     rb_handle handle = nullptr, handle2 = nullptr, handle3 = nullptr;
     int handle_dev = -1;
 } g_blas;
@@ -119,6 +121,7 @@ int blas_load() {
         g_blas.dgemm = (fn_dgemm)dlsym(g_blas.hb, "rocblas_dgemm");
         g_blas.dtrsm = (fn_dtrsm)dlsym(g_blas.hb, "rocblas_dtrsm");
         g_blas.dpotrf = (fn_dpotrf)dlsym(g_blas.hs, "rocsolver_dpotrf");
+        g_blas.set_atomics = (fn_set_atomics)dlsym(g_blas.hb, "rocblas_set_atomics_mode");
         if (g_blas.create && g_blas.set_stream && g_blas.dgemm && g_blas.dtrsm && g_blas.dpotrf) return CSLAM_OK;
         g_blas.dpotrf = nullptr;
     }
@@ -322,7 +325,12 @@ CSLAM_API int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h
     if (g_ws.device != dev) { if (g_ws.device >= 0) { DeviceGuard guard(g_ws.device); g_ws.release(); } g_ws.device = dev; }
     if (!stream && !g_ws.stream) HIP_TRY(hipStreamCreateWithFlags(&g_ws.stream, hipStreamNonBlocking));
     hipStream_t st = stream ? (hipStream_t)stream : g_ws.stream;
-    if (!g_blas.handle || g_blas.handle_dev != dev) { RB_TRY(g_blas.create(&g_blas.handle)); g_blas.handle_dev = dev; }
+    if (!g_blas.handle || g_blas.handle_dev != dev) {
+        RB_TRY(g_blas.create(&g_blas.handle));
+        g_blas.handle_dev = dev;
+        // the pair this call returns is promised bit for bit (tests/test_mac_gpu.py): no kernels that sum through atomics
+        if (g_blas.set_atomics) RB_TRY(g_blas.set_atomics(g_blas.handle, 0 /* rocblas_atomics_not_allowed */));
+    }
     RB_TRY(g_blas.set_stream(g_blas.handle, st));
     laps.lap("libraries + handle", st);
     const int64_t nnz = h_indptr[n];
@@ -501,7 +509,14 @@ CSLAM_API int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h
                 HIP_TRY(hipEventCreateWithFlags(&g_ws.ev_panel, hipEventDisableTiming));
                 HIP_TRY(hipEventCreateWithFlags(&g_ws.ev_inv, hipEventDisableTiming));
             }
-            if (!g_blas.handle2) { RB_TRY(g_blas.create(&g_blas.handle2)); RB_TRY(g_blas.create(&g_blas.handle3)); }
+            if (!g_blas.handle2) {
+                RB_TRY(g_blas.create(&g_blas.handle2));
+                RB_TRY(g_blas.create(&g_blas.handle3));
+                if (g_blas.set_atomics) {
+                    RB_TRY(g_blas.set_atomics(g_blas.handle2, 0));
+                    RB_TRY(g_blas.set_atomics(g_blas.handle3, 0));
+                }
+            }
             RB_TRY(g_blas.set_stream(g_blas.handle2, g_ws.stream2));
             RB_TRY(g_blas.set_stream(g_blas.handle3, g_ws.stream3));
         }
