@@ -63,9 +63,12 @@ struct WinoGemmArgs {
 // A finished item's results are stored right AFTER the barrier that ends its last stage, so the stores drain under the
 // next stage's MFMAs instead of in front of a wait.
 // DBG: timing-only ablations (1 = no stores, 2 = no loads after the prologue), CSLAM_WGEMM_DBG; never the product path.
-template <int TM, int TN, int NS, int DBG>
+template <int TM, int TN, int NS, int DBG, int WM>
 __global__ __launch_bounds__(512, 2) void wino_gemm_h2_kernel(WinoGemmArgs p) {
-    constexpr int MT = TM / 64, NT = TN / 128;
+    // the eight waves as WM x WN over the tile: wave tile 32 MT x 32 NT (WM = 2: 128 x 32 at 256 x 128 -- ten 16-byte fragment
+    // reads per twelve MFMAs; WM = 4: 64 x 64 -- eight)
+    constexpr int WN = 8 / WM;
+    constexpr int MT = TM / (32 * WM), NT = TN / (32 * WN);
     constexpr int OPA = TM * WG_ROWB, OPB = TN * WG_ROWB;
     constexpr int STAGE = OPA + OPB;
     constexpr int NLA = TM * 8 / 512, NLB = TN * 8 / 512;   // 16-byte chunks per thread per stage
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_h2_kernel(WinoGemmArgs p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int wm = wave / WN, wn = wave % WN;
     const int h = lane >> 5, l31 = lane & 31;
 
     // this workgroup's items: XCD x (= blockIdx % 8) owns the contiguous run [x I / 8, (x + 1) I / 8) of the xi-major list,
@@ -139,7 +142,7 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_h2_kernel(WinoGemmArgs p) {
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int lo = 0; lo < 2; ++lo) foff[s][lo] = ((4 * lo + 2 * s + h) ^ swz) << 4;
-    const int arow0 = (wm * (TM / 2) + l31) * WG_ROWB;
+    const int arow0 = (wm * (32 * MT) + l31) * WG_ROWB;
     const int brow0 = (wn * (32 * NT) + l31) * WG_ROWB;
 
     f32x16 acc[MT][NT];
@@ -181,12 +184,12 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_h2_kernel(WinoGemmArgs p) {
     Item st_item = cur_item;
     for (int it = 0; it < total; ++it) {
         if (store_pending) {
-            // ---- the item finished in the previous stage: store the TM/2 x TN/4 wave tile (lane = column, 128-byte runs per
+            // ---- the item finished in the previous stage: store the 32 MT x 32 NT wave tile (lane = column, 128-byte runs per
             // row) and clear; issued behind the barrier, drains under this stage's MFMAs
-            const int row_base = st_item.mt * TM + wm * (TM / 2) + 4 * h;
+            const int row_base = st_item.mt * TM + wm * (32 * MT) + 4 * h;
             const int col = st_item.nt * TN + wn * (32 * NT) + l31;
             float *mo = p.M + ((int64_t)st_item.xi * p.T + row_base) * p.Cout + col;
-            const bool full = st_item.mt * TM + wm * (TM / 2) + TM / 2 <= p.T;    // wave-uniform: no per-row test
+            const bool full = st_item.mt * TM + wm * (32 * MT) + 32 * MT <= p.T;    // wave-uniform: no per-row test
             const bool st_on = DBG != 1 || p.T < 0;                               // DBG 1: stores compiled, never executed
             if (full) {
 #pragma unroll
@@ -263,7 +266,7 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_h2_kernel(WinoGemmArgs p) {
         if (++kt == p.nk) { kt = 0; ++k_item; if (it + 1 < total) cur_item = decode(k_item); }
     }
     if (store_pending) {
-        const int row_base = st_item.mt * TM + wm * (TM / 2) + 4 * h;
+        const int row_base = st_item.mt * TM + wm * (32 * MT) + 4 * h;
         const int col = st_item.nt * TN + wn * (32 * NT) + l31;
         float *mo = p.M + ((int64_t)st_item.xi * p.T + row_base) * p.Cout + col;
         const bool st_on = DBG != 1 || p.T < 0;
@@ -641,7 +644,7 @@ CSLAM_API int cslam_trunk_timing_read(double out[8]) {
     return CSLAM_OK;
 }
 
-template <int TM, int TN, int NS>
+template <int TM, int TN, int NS, int WM = 2>
 static int wino_gemm_launch(WinoGemmArgs a, int dbg, hipStream_t st) {
     int n_cu = cslam_cu_count();
     ARG_CHECK(n_cu > 0, "no HIP device");
@@ -657,16 +660,16 @@ static int wino_gemm_launch(WinoGemmArgs a, int dbg, hipStream_t st) {
     static DeviceOnce once;
     int once_dev;
     if (once.todo(&once_dev)) {
-        HIP_TRY(hipFuncSetAttribute((const void *)wino_gemm_h2_kernel<TM, TN, NS, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_TRY(hipFuncSetAttribute((const void *)wino_gemm_h2_kernel<TM, TN, NS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_TRY(hipFuncSetAttribute((const void *)wino_gemm_h2_kernel<TM, TN, NS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)wino_gemm_h2_kernel<TM, TN, NS, 0, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)wino_gemm_h2_kernel<TM, TN, NS, 1, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)wino_gemm_h2_kernel<TM, TN, NS, 2, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         once.done(once_dev);
     }
     int tslot;
     tt_begin(st, tslot);
-    if (dbg == 1) hipLaunchKernelGGL((wino_gemm_h2_kernel<TM, TN, NS, 1>), dim3(grid), dim3(512), lds, st, a);
-    else if (dbg == 2) hipLaunchKernelGGL((wino_gemm_h2_kernel<TM, TN, NS, 2>), dim3(grid), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((wino_gemm_h2_kernel<TM, TN, NS, 0>), dim3(grid), dim3(512), lds, st, a);
+    if (dbg == 1) hipLaunchKernelGGL((wino_gemm_h2_kernel<TM, TN, NS, 1, WM>), dim3(grid), dim3(512), lds, st, a);
+    else if (dbg == 2) hipLaunchKernelGGL((wino_gemm_h2_kernel<TM, TN, NS, 2, WM>), dim3(grid), dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((wino_gemm_h2_kernel<TM, TN, NS, 0, WM>), dim3(grid), dim3(512), lds, st, a);
     if (a.nxi == 36) tt_end(st, tslot, a, 36);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
@@ -687,17 +690,20 @@ CSLAM_API int cslam_wino_gemm_h2_dev(const void *d_V2, const void *d_U2, int64_t
     // read on every call (two getenv, ~100 ns) so that tests and experiments can switch shapes inside one process
     const char *e = getenv("CSLAM_WGEMM_DBG"), *c = getenv("CSLAM_WGEMM_CFG");
     const int dbg = e ? atoi(e) : 0;            // timing-only ablations
-    const int cfg = c ? atoi(c) : 0;            // force a tile / ring shape (1..4 below); 0 = default
+    const int cfg = c ? atoi(c) : 0;            // force a tile / ring shape (1..5 below); 0 = default
     hipStream_t st = (hipStream_t)stream;
     // default: 256 x 128 tiles with the ring of three stages -- the fastest or within 4 % of the fastest shape on every
-    // layer of the VGG-16 trunk at the 256-frame chunk (interleaved medians, profiles/r02_v4_perf_wino_gemm.log)
+    // layer of the VGG-16 trunk at the 256-frame chunk (interleaved medians, profiles/r02_v4_perf_wino_gemm.log) -- with the
+    // waves as 4 x 2 (64 x 64 wave tiles: 8 instead of 10 fragment reads per 12 MFMAs; 0-3 % faster than 2 x 4 on every layer,
+    // profiles/r03_v33_perf_wino_gemm_wave_grid.log)
     const bool wide = (Cout % 256) == 0;
     int use = cfg;
-    if (use < 1 || use > 4 || ((use == 1 || use == 3) && !wide)) use = 2;
+    if (use < 1 || use > 5 || ((use == 1 || use == 3) && !wide)) use = 5;
     switch (use) {
     case 1: return wino_gemm_launch<256, 256, 2>(a, dbg, st);      // double buffer, 256 x 256
     case 2: return wino_gemm_launch<256, 128, 3>(a, dbg, st);      // ring of 3, 256 x 128
     case 3: return wino_gemm_launch<128, 256, 3>(a, dbg, st);      // ring of 3, 128 x 256
+    case 5: return wino_gemm_launch<256, 128, 3, 4>(a, dbg, st);   // ring of 3, 256 x 128, 64 x 64 wave tiles
     default: return wino_gemm_launch<256, 128, 2>(a, dbg, st);     // double buffer, 256 x 128 (round-2 first form)
     }
 }
@@ -715,7 +721,7 @@ int cslam_pair_gemm_launch(const void *d_A2, const void *d_B2, int nxi, int64_t 
     a.T = (int)T; a.Cin = K; a.Cout = N; a.nk = K / 32;
     a.n_mt = a.n_nt = a.n_items = 0;
     a.nxi = nxi;
-    return wino_gemm_launch<256, 128, 3>(a, 0, st);
+    return wino_gemm_launch<256, 128, 3, 4>(a, 0, st);
 }
 
 /* The Z form (wino_zgemm_h2_kernel above): d_Z [24][T][Cout] float32, plane 4 i + q = sum_j (V U)[6 i + j] A^T[q][j]; finished by
