@@ -9,6 +9,7 @@ One step (BASELINE config 3, per rank = per robot):
     B synthetic 640x480 RGB keyframes already in HBM (uint8, seeded on device)
       -> NetVLAD extract: crop/bicubic-resize/normalise [HIP] -> VGG-16 conv5_3 [every layer a HIP kernel of this library, fp32-grade]
          -> VLAD aggregation [HIP] -> PCA 32768->4096 + L2 [HIP, fp16-pair GEMM]
+         (the step's chunks of --extract-chunk frames alternate over --extract-lanes HIP streams: NetVLAD.compute_embeddings_batch_device)
       -> (N > 1) RCCL all-gather of the new descriptors: every rank sees every query
       -> top-5 against the resident 100k x 4096 bank [HIP: sim_topk_pair (fp16-pair candidate stage) + float64 re-score + certificate].
          N = 1: the search is ENQUEUED behind the extraction (cslam_bank_search_enqueue_dev) and finished after the next step has
@@ -21,7 +22,8 @@ One step (BASELINE config 3, per rank = per robot):
 value = keyframes processed by all ranks / max-over-ranks time of exactly K steps.
 The JSON line also carries: match_only / extract_only throughputs (the two legs timed separately), `roofline` (the candidate-stage
 kernel's launches INSIDE the timed steps, HIP events on the launch stream), `roofline_c3_batch` (the separate 100k-query launch),
-`roofline_step_largest` (the trunk's pair products, from per-launch events of the timed steps), `roofline_extract` (the other
+`roofline_step_largest` (the trunk's pair products, from per-launch events of one-lane steps run after the timed region -- with two
+lanes a launch shares the chip with the other lane's kernels), `roofline_extract` (the other
 kernels of the extract leg on their real shapes) and `cpu_baseline` (the oracle restatements on a bounded sample).
 """
 import argparse
