@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """HBM-side bytes of ONE 256-frame extract pass, by kernel: FETCH_SIZE / WRITE_SIZE of `tools/extract_leg.py --iters 2` collected in
 separate rocprofv3 --pmc runs (tools/gpu_pmc_extract.sh); bytes = FETCH_SIZE[KB] * 1024 * 2 + WRITE_SIZE[KB] * 1024 (gfx950 correction of
-the MI355X guide for wide coalesced reads).  The last pass of the run is taken (cut at preprocess_fused_kernel).
+the MI355X guide for wide coalesced reads).  The last pass of the run is taken (cut at the image transform: preprocess_tile_kernel / preprocess_fused_kernel).
     python tools/pmc_extract_pass.py <dir with fetch/ and write/> <tag>  ->  profiles/<tag>_extract_pass_bytes.json"""
 import collections
 import csv
@@ -23,7 +23,7 @@ def last_pass(d, counter):
         e = byd.setdefault(int(r["Dispatch_Id"]), [r["Kernel_Name"], 0.0])
         e[1] += float(r["Counter_Value"])
     seq = [byd[k] for k in sorted(byd)]
-    starts = [i for i, (n, _) in enumerate(seq) if "preprocess_fused_kernel" in n]
+    starts = [i for i, (n, _) in enumerate(seq) if "preprocess_fused_kernel" in n or "preprocess_tile_kernel" in n]
     return seq[starts[-1]:]
 
 
