@@ -693,12 +693,12 @@ CSLAM_API int cslam_wino_gemm_h2_dev(const void *d_V2, const void *d_U2, int64_t
     const int cfg = c ? atoi(c) : 0;            // force a tile / ring shape (1..5 below); 0 = default
     hipStream_t st = (hipStream_t)stream;
     // default: 256 x 128 tiles with the ring of three stages -- the fastest or within 4 % of the fastest shape on every
-    // layer of the VGG-16 trunk at the 256-frame chunk (interleaved medians, profiles/r02_v4_perf_wino_gemm.log) -- with the
-    // waves as 4 x 2 (64 x 64 wave tiles: 8 instead of 10 fragment reads per 12 MFMAs; 0-3 % faster than 2 x 4 on every layer,
-    // profiles/r03_v33_perf_wino_gemm_wave_grid.log)
+    // layer of the VGG-16 trunk at the 256-frame chunk (interleaved medians, profiles/r02_v4_perf_wino_gemm.log).  The waves as
+    // 4 x 2 instead of 2 x 4 (cfg 5: 64 x 64 wave tiles, 8 instead of 10 fragment reads per 12 MFMAs) is the same speed: -3 .. +5 %
+    // per layer from run to run, 16.06 against 16.02 ms on whole trunk passes (profiles/r03_v33_perf_wino_gemm_wave_grid.log)
     const bool wide = (Cout % 256) == 0;
     int use = cfg;
-    if (use < 1 || use > 5 || ((use == 1 || use == 3) && !wide)) use = 5;
+    if (use < 1 || use > 5 || ((use == 1 || use == 3) && !wide)) use = 2;
     switch (use) {
     case 1: return wino_gemm_launch<256, 256, 2>(a, dbg, st);      // double buffer, 256 x 256
     case 2: return wino_gemm_launch<256, 128, 3>(a, dbg, st);      // ring of 3, 256 x 128
@@ -721,7 +721,7 @@ int cslam_pair_gemm_launch(const void *d_A2, const void *d_B2, int nxi, int64_t 
     a.T = (int)T; a.Cin = K; a.Cout = N; a.nk = K / 32;
     a.n_mt = a.n_nt = a.n_items = 0;
     a.nxi = nxi;
-    return wino_gemm_launch<256, 128, 3, 4>(a, 0, st);
+    return wino_gemm_launch<256, 128, 3>(a, 0, st);
 }
 
 /* The Z form (wino_zgemm_h2_kernel above): d_Z [24][T][Cout] float32, plane 4 i + q = sum_j (V U)[6 i + j] A^T[q][j]; finished by
