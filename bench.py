@@ -405,14 +405,18 @@ def main():
     # ---- rooflines.  `roofline` describes the TIMED STEP: the kernel north_star names (the D.D^T similarity + top-k
     # candidate stage), from its launches inside the timed steps (HIP events on the launch stream).  The separate 100k-query
     # C3 batch is `roofline_c3_batch`; the step's largest consumer (the trunk's pair products) is `roofline_step_largest`.
-    # Algorithmic work of the match: 2*D flop per (query, bank row) pair.  The candidate stage runs on the
-    # fp16 matrix pipe with THREE fp16 products per fp32-grade product (exact hi/lo pairs, csrc/sim_topk_pair.hip), so its
-    # roofline is the dense fp16 MFMA peak / 3, in fp32-equivalent TFLOP/s; CSLAM_MFMA_STAGE1=f32 selects the f32-input
-    # MFMA stage of rounds 1-2, priced against the f32 MFMA peak.
+    # Algorithmic work of the match: 2*D flop per (query, bank row) pair.  The candidate stage (a filter: the
+    # float64 re-scoring + certificate behind it make the result exact) runs on the fp16 matrix pipe: by default ONE fp16
+    # product on the operands' hi halves (csrc/sim_topk_pair.hip NPROD = 1), whose roofline is the dense fp16 MFMA peak itself;
+    # CSLAM_MFMA_STAGE1=pair = round 3's exact hi/lo pairs (three products: peak / 3), =f32 = the f32-input MFMA stage of
+    # rounds 1-2, priced against the f32 MFMA peak.
     nq_step = world * a.batch if world > 1 else a.batch
-    pair_stage = not os.environ.get("CSLAM_MFMA_STAGE1", "pair").startswith("f")
-    mm_peak = FP16_MFMA_PEAK_TFLOPS / 3.0 if pair_stage else FP32_MFMA_PEAK_TFLOPS
-    mm_unit = ("TFLOP/s fp32-equivalent (3 fp16 MFMA products per product: peak = 2500 / 3)" if pair_stage else "TFLOP/s")
+    stage1 = os.environ.get("CSLAM_MFMA_STAGE1", "h1")
+    n_prod = 0 if stage1.startswith("f") else (3 if stage1.startswith("p") else 1)
+    pair_stage = n_prod != 0
+    mm_peak = FP16_MFMA_PEAK_TFLOPS / n_prod if pair_stage else FP32_MFMA_PEAK_TFLOPS
+    mm_unit = ("TFLOP/s (2*D flop per query-row pair; %d fp16 MFMA product%s per pair: peak = 2500 / %d)"
+               % (n_prod, "" if n_prod == 1 else "s", n_prod) if pair_stage else "TFLOP/s")
     mm_kernel = "sim_topk_pair_kernel" if pair_stage else "sim_topk_mfma_kernel"
     peaks = measure_peaks(torch, dev) if rank == 0 else None
 
@@ -421,7 +425,7 @@ def main():
         pm = pmc_entry(mm_kernel, queries=pmc_queries, bank_rows=local_rows, dim=a.dim)
         return {"bound": "mfma", "kernel": mm_kernel, "achieved": round(ach, 2), "peak": round(mm_peak, 1), "unit": mm_unit,
                 "frac": round(ach / mm_peak, 4), "kernel_ms": round(ms, 3), "queries_per_launch": nq_launch,
-                "fp16_TFLOPs_issued": round(3 * ach, 1) if pair_stage else None,
+                "fp16_TFLOPs_issued": round(n_prod * ach, 1) if pair_stage else None, "fp16_products": n_prod if pair_stage else None,
                 "traffic": pm["traffic_bytes"] if pm else None,
                 "traffic_source": (pm["source"] + "; L2 hit rate %.2f" % pm.get("l2_hit_rate", float("nan"))) if pm else None,
                 "source": source}

@@ -10,7 +10,9 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcslam_hip.so")
+# CSLAM_HIP_LIB: another build of the same library (measurement builds: `make -C cslam_amd/csrc abl` = the timing-only
+# ablation switches compiled in, libcslam_hip_abl.so; never the product default)
+LIB_PATH = os.environ.get("CSLAM_HIP_LIB") or os.path.join(_HERE, "libcslam_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 F32, F64 = 0, 1

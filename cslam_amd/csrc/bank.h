@@ -13,13 +13,19 @@ struct cslam_bank {
     float *rows;    // [cap, ld]  float32 descriptors (reference: nns_matching.py:21)
     double *vv;     // [cap]      sum of squares of each row, float64
     float *invn;    // [cap]      (float)(1/sqrt(vv)); used by the fp32 candidate stage only
-    // the same rows as exact fp16 pairs for the candidate stage on the fp16 matrix pipe (sim_topk_pair.hip): row r times
-    // the power of two s_r (max |v| s_r in [2^14, 2^15)) split into hi + lo halfs, 32-channel blocks [hi 32 | lo 32] of
-    // 128 bytes; pitch ld2 BYTES (one extra 128-byte line when a multiple of 1 KiB, as ld)
-    char *rows2;    // [cap, ld2]
-    float *invs;    // [cap]      invn / s_r: key = (pair dot) * invs[row] * (1 / s_query); NaN for a row whose largest
+    // candidate-stage copies of the rows (sim_topk_pair.hip).  Row r times the power of two s_r (max |v| s_r in [2^14, 2^15)):
+    //  rowsh: rounded to fp16, kh = dim rounded up to 64 channels (whole 128-byte K stages), 2 bytes per value -- the one-product
+    //         stage, the default; always kept up to date by bank_append_kernel;
+    //  rows2: split exactly into hi + lo halfs, 32-channel blocks [hi 32 | lo 32] of 128 bytes, 4 bytes per value -- the
+    //         three-product stage (CSLAM_MFMA_STAGE1=pair, the A/B partner); built from `rows` on the first search that asks
+    //         for it (bank_pairs_ensure) and kept up to date from then on, so a bank that never uses it never pays for it.
+    // Pitches ldh / ld2 in BYTES (one extra 128-byte line when a multiple of 1 KiB, as ld).
+    char *rowsh;    // [cap, ldh]
+    char *rows2;    // [cap, ld2] or nullptr
+    float *invs;    // [cap]      invn / s_r: key = (dot of the scaled copies) * invs[row] * (1 / s_query); NaN for a row whose largest
                     //            magnitude is outside [2^-100, 2^100] (such a row is always a contender, rescored exactly)
-    int64_t ld2;
+    int kh;
+    int64_t ldh, ld2;
     // grow-on-demand workspace
     char *ws[3];          // [0] MFMA path, [1] scan path (also the MFMA fallback), [2] host-API staging
     size_t ws_bytes[3];
@@ -51,6 +57,7 @@ struct cslam_bank {
 };
 
 int bank_ws_reserve(cslam_bank *b, int slot, size_t bytes);
+int bank_pairs_ensure(cslam_bank *b, hipStream_t st);      // rows2 exists and covers rows [0, n)
 
 // exact fp64 scan over selected queries (bank.hip)
 //  d_q: queries [nq_total, ldq] of q_dtype; qsel: [nsel] int32 query numbers or NULL (identity)

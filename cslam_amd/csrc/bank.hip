@@ -78,9 +78,10 @@ static int bank_grow(cslam_bank *b, int64_t need) {
     int64_t ncap = b->cap > 0 ? b->cap : 1000;   // reference starts at 1000 rows (nns_matching.py:21)
     while (ncap < need) ncap *= 2;               // and doubles (nns_matching.py:36)
     float *rows = nullptr; double *vv = nullptr; float *invn = nullptr, *invs = nullptr;
-    char *rows2 = nullptr;
+    char *rows2 = nullptr, *rowsh = nullptr;
     HIP_TRY(hipMalloc((void **)&rows, (size_t)ncap * b->ld * sizeof(float)));
-    HIP_TRY(hipMalloc((void **)&rows2, (size_t)ncap * b->ld2));
+    HIP_TRY(hipMalloc((void **)&rowsh, (size_t)ncap * b->ldh));
+    if (b->rows2) HIP_TRY(hipMalloc((void **)&rows2, (size_t)ncap * b->ld2));
     HIP_TRY(hipMalloc((void **)&invs, (size_t)ncap * sizeof(float)));
     HIP_TRY(hipMalloc((void **)&vv, (size_t)ncap * sizeof(double)));
     HIP_TRY(hipMalloc((void **)&invn, (size_t)ncap * sizeof(float)));
@@ -91,15 +92,17 @@ static int bank_grow(cslam_bank *b, int64_t need) {
         HIP_TRY(hipMemcpy(rows, b->rows, (size_t)b->n * b->ld * sizeof(float), hipMemcpyDeviceToDevice));
         HIP_TRY(hipMemcpy(vv, b->vv, (size_t)b->n * sizeof(double), hipMemcpyDeviceToDevice));
         HIP_TRY(hipMemcpy(invn, b->invn, (size_t)b->n * sizeof(float), hipMemcpyDeviceToDevice));
-        HIP_TRY(hipMemcpy(rows2, b->rows2, (size_t)b->n * b->ld2, hipMemcpyDeviceToDevice));
+        HIP_TRY(hipMemcpy(rowsh, b->rowsh, (size_t)b->n * b->ldh, hipMemcpyDeviceToDevice));
+        if (rows2) HIP_TRY(hipMemcpy(rows2, b->rows2, (size_t)b->n * b->ld2, hipMemcpyDeviceToDevice));
         HIP_TRY(hipMemcpy(invs, b->invs, (size_t)b->n * sizeof(float), hipMemcpyDeviceToDevice));
     }
     if (b->rows) HIP_TRY(hipFree(b->rows));
     if (b->vv) HIP_TRY(hipFree(b->vv));
     if (b->invn) HIP_TRY(hipFree(b->invn));
     if (b->rows2) HIP_TRY(hipFree(b->rows2));
+    if (b->rowsh) HIP_TRY(hipFree(b->rowsh));
     if (b->invs) HIP_TRY(hipFree(b->invs));
-    b->rows = rows; b->vv = vv; b->invn = invn; b->rows2 = rows2; b->invs = invs; b->cap = ncap;
+    b->rows = rows; b->vv = vv; b->invn = invn; b->rows2 = rows2; b->rowsh = rowsh; b->invs = invs; b->cap = ncap;
     return CSLAM_OK;
 }
 
@@ -111,7 +114,8 @@ CSLAM_API int cslam_bank_create(int device, int dim, int64_t capacity_hint, csla
     cslam_bank *b = new (std::nothrow) cslam_bank();
     if (!b) { cslam_set_error("out of host memory"); return CSLAM_E_NOMEM; }
     b->device = 0; b->dim = 0; b->kd = 0; b->ld = 0; b->n = 0; b->cap = 0;
-    b->rows = nullptr; b->vv = nullptr; b->invn = nullptr; b->rows2 = nullptr; b->invs = nullptr; b->ld2 = 0;
+    b->rows = nullptr; b->vv = nullptr; b->invn = nullptr; b->rows2 = nullptr; b->rowsh = nullptr; b->invs = nullptr; b->ld2 = 0;
+    b->kh = 0; b->ldh = 0;
     for (int s = 0; s < 3; ++s) { b->ws[s] = nullptr; b->ws_bytes[s] = 0; }
     b->stage = nullptr; b->stage_bytes = 0; b->last_stream = nullptr; b->ev_valid = false;
     b->side = nullptr; b->ev_fork = nullptr; b->ev_side = nullptr;
@@ -126,6 +130,8 @@ CSLAM_API int cslam_bank_create(int device, int dim, int64_t capacity_hint, csla
     // 128-byte line per row spreads the rows of a tile over the sets.
     b->ld = b->kd + ((b->kd % 256 == 0) ? 32 : 0);
     b->ld2 = (int64_t)b->kd * 4 + ((b->kd % 256 == 0) ? 128 : 0);     // the pair copy: same bytes per value, same padding rule
+    b->kh = (int)round_up64(dim, 64);
+    b->ldh = (int64_t)b->kh * 2 + ((b->kh % 512 == 0) ? 128 : 0);     // the fp16 copy: half the bytes, same padding rule
     hipDeviceProp_t p;
     if (hipGetDeviceProperties(&p, device) == hipSuccess) b->num_cu = p.multiProcessorCount;
     if (b->num_cu <= 0) b->num_cu = 256;
@@ -144,6 +150,7 @@ CSLAM_API int cslam_bank_destroy(cslam_bank_t *b) {
     if (b->vv) (void)hipFree(b->vv);
     if (b->invn) (void)hipFree(b->invn);
     if (b->rows2) (void)hipFree(b->rows2);
+    if (b->rowsh) (void)hipFree(b->rowsh);
     if (b->invs) (void)hipFree(b->invs);
     for (int s = 0; s < 3; ++s) if (b->ws[s]) (void)hipFree(b->ws[s]);
     if (b->stage) (void)hipFree(b->stage);
@@ -172,34 +179,44 @@ CSLAM_API int cslam_bank_clear(cslam_bank_t *b) {
 }
 
 // one wave per appended row: copy (with float64->float32 cast when SRC is double, the
-// numpy assignment cast of nns_matching.py:39), zero the padding, float64 sum of squares; then the same row once more as
-// exact fp16 pairs for the candidate stage on the fp16 matrix pipe (sim_topk_pair.hip).
-template <typename SRC>
+// numpy assignment cast of nns_matching.py:39), zero the padding, float64 sum of squares; then the same row once more, times
+// its power-of-two scale, for the candidate stages on the fp16 matrix pipe (sim_topk_pair.hip): rounded to fp16 (rowsh) and,
+// when the bank keeps the pair copy, split exactly into hi + lo (rows2).  STATS = false: rows / vv / invn / invs exist already
+// and only rows2 is (re)built from the float32 rows (bank_pairs_ensure).
+template <typename SRC, bool STATS>
 __global__ __launch_bounds__(256) void bank_append_kernel(const SRC *__restrict__ src, int64_t ld_src,
-                                                          int64_t nrows, int dim, int ld, int kd,
+                                                          int64_t nrows, int dim, int ld, int kd, int kh,
                                                           float *__restrict__ rows, double *__restrict__ vv,
-                                                          float *__restrict__ invn, char *__restrict__ rows2, int64_t ld2,
+                                                          float *__restrict__ invn, char *__restrict__ rowsh, int64_t ldh,
+                                                          char *__restrict__ rows2, int64_t ld2,
                                                           float *__restrict__ invs, int64_t row0) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= nrows) return;
     const SRC *s = src + r * ld_src;
-    float *d = rows + (row0 + r) * (int64_t)ld;
     double acc = 0.0;
     float amax = 0.0f;
     bool finite = true;
-    for (int c = lane; c < ld; c += 64) {
-        float v = c < dim ? (float)s[c] : 0.0f;
-        d[c] = v;
-        acc += (double)v * (double)v;
-        finite &= (v - v) == 0.0f;
-        amax = fmaxf(amax, fabsf(v));
+    if (STATS) {
+        float *d = rows + (row0 + r) * (int64_t)ld;
+        for (int c = lane; c < ld; c += 64) {
+            float v = c < dim ? (float)s[c] : 0.0f;
+            d[c] = v;
+            acc += (double)v * (double)v;
+            finite &= (v - v) == 0.0f;
+            amax = fmaxf(amax, fabsf(v));
+        }
+        acc = wave_allreduce_sum(acc);
+    } else {
+        for (int c = lane; c < dim; c += 64) {
+            const float v = (float)s[c];
+            finite &= (v - v) == 0.0f;
+            amax = fmaxf(amax, fabsf(v));
+        }
     }
-    acc = wave_allreduce_sum(acc);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
     finite = __all(finite);
-    const float inv_n = (float)(1.0 / sqrt(acc));         // zero row -> +inf (NaN score, like the reference)
     // power-of-two scale: max |v| s in [2^14, 2^15)  (fp16 holds 65504; the split keeps 22 bits of every value that is not
     // below 2^-39 of the row's largest).  Rows the scale cannot serve (non-finite entries, magnitudes outside
     // [2^-100, 2^100]) get invs = NaN: their key is NaN in the candidate stage, which makes them contenders of every query --
@@ -208,15 +225,16 @@ __global__ __launch_bounds__(256) void bank_append_kernel(const SRC *__restrict_
     if (amax > 0.0f) (void)frexpf(amax, &e);               // amax = m 2^e, m in [0.5, 1)
     const bool servable = finite && (amax == 0.0f || (e > -100 && e < 100));
     const float sc = (amax > 0.0f && servable) ? ldexpf(1.0f, 15 - e) : 1.0f;
-    if (lane == 0) {
+    if (STATS && lane == 0) {
+        const float inv_n = (float)(1.0 / sqrt(acc));     // zero row -> +inf (NaN score, like the reference)
         vv[row0 + r] = acc;
         invn[row0 + r] = inv_n;
         invs[row0 + r] = servable ? inv_n / sc : NAN;     // sc is a power of two: exact
     }
-    // pairs: lane = 4 consecutive channels; block kb = [hi 32 | lo 32] halfs
-    char *d2 = rows2 + (row0 + r) * ld2;
-    for (int c = 4 * lane; c < kd; c += 256) {
-        // second pass over the SOURCE row (not over the float32 copy other lanes have just stored)
+    // lane = 4 consecutive channels; second pass over the SOURCE row (not over the float32 copy other lanes have just stored)
+    char *dh = STATS ? rowsh + (row0 + r) * ldh : nullptr;
+    char *d2 = rows2 ? rows2 + (row0 + r) * ld2 : nullptr;
+    for (int c = 4 * lane; c < kh; c += 256) {
         unsigned hi[2], lo[2];
         float w[4];
 #pragma unroll
@@ -228,9 +246,12 @@ __global__ __launch_bounds__(256) void bank_append_kernel(const SRC *__restrict_
             const __half2 l = __floats2half2_rn(servable ? w[2 * t] - f.x : 0.0f, servable ? w[2 * t + 1] - f.y : 0.0f);
             hi[t] = *(const unsigned *)&h; lo[t] = *(const unsigned *)&l;
         }
-        char *blk = d2 + (c >> 5) * 128 + (c & 31) * 2;
-        *(uint2 *)blk = make_uint2(hi[0], hi[1]);
-        *(uint2 *)(blk + 64) = make_uint2(lo[0], lo[1]);
+        if (STATS) *(uint2 *)(dh + c * 2) = make_uint2(hi[0], hi[1]);
+        if (d2 && c < kd) {                                // pairs: block kb = [hi 32 | lo 32] halfs
+            char *blk = d2 + (c >> 5) * 128 + (c & 31) * 2;
+            *(uint2 *)blk = make_uint2(hi[0], hi[1]);
+            *(uint2 *)(blk + 64) = make_uint2(lo[0], lo[1]);
+        }
     }
 }
 
@@ -238,11 +259,25 @@ template <typename SRC>
 static int bank_append_launch(cslam_bank *b, const SRC *d_src, int64_t ld_src, int64_t n, hipStream_t st) {
     if (n == 0) return CSLAM_OK;
     dim3 grid((unsigned)ceil_div64(n, 4));
-    hipLaunchKernelGGL(bank_append_kernel<SRC>, grid, dim3(256), 0, st, d_src, ld_src, n, b->dim, b->ld, b->kd,
-                       b->rows, b->vv, b->invn, b->rows2, b->ld2, b->invs, b->n);
+    hipLaunchKernelGGL((bank_append_kernel<SRC, true>), grid, dim3(256), 0, st, d_src, ld_src, n, b->dim, b->ld, b->kd, b->kh,
+                       b->rows, b->vv, b->invn, b->rowsh, b->ldh, b->rows2, b->ld2, b->invs, b->n);
     HIP_TRY(hipGetLastError());
     b->n += n;
     b->last_stream = st;
+    return CSLAM_OK;
+}
+
+// The pair copy on demand (CSLAM_MFMA_STAGE1=pair): allocate it at the bank's capacity and fill rows [0, n) from the float32
+// rows, on the caller's stream (ordered behind the appends the caller has ordered its search behind).
+int bank_pairs_ensure(cslam_bank *b, hipStream_t st) {
+    if (b->rows2) return CSLAM_OK;
+    HIP_TRY(hipMalloc((void **)&b->rows2, (size_t)b->cap * b->ld2));
+    if (b->n > 0) {
+        hipLaunchKernelGGL((bank_append_kernel<float, false>), dim3((unsigned)ceil_div64(b->n, 4)), dim3(256), 0, st,
+                           (const float *)b->rows, (int64_t)b->ld, b->n, b->dim, b->ld, b->kd, b->kh, b->rows, b->vv, b->invn,
+                           b->rowsh, b->ldh, b->rows2, b->ld2, b->invs, (int64_t)0);
+        HIP_TRY(hipGetLastError());
+    }
     return CSLAM_OK;
 }
 

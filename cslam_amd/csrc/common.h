@@ -91,12 +91,14 @@ int cslam_cu_count();          // compute units of the CURRENT device, cached pe
 // grow-only buffer per (device, stream).  Launches on ONE stream run in order, so they can share a buffer; two streams -- two
 // extraction lanes, two host threads -- must not.  A superseded buffer stays allocated: a pointer captured in a hipGraph (the
 // online path replays one) has to remain valid when a later, larger batch needs more room.  `floor_bytes` = smallest allocation.
-// Returns nullptr when the allocation fails or the stream is being captured into a graph and has no buffer of that size yet.
+// Returns nullptr with *status = CSLAM_E_NOMEM when the allocation fails, CSLAM_E_HIP when the stream is being captured into a graph
+// and has no buffer of that size yet (the message says which); SCRATCH_GET turns that into the entry point's return value.
 struct StreamScratch {
     struct Entry { int dev; void *stream; char *ptr; size_t bytes; };
     std::mutex mu;
     std::vector<Entry> entries;
-    char *get(int dev, void *stream, size_t need, size_t floor_bytes) {
+    char *get(int dev, void *stream, size_t need, size_t floor_bytes, int *status) {
+        *status = CSLAM_OK;
         std::lock_guard<std::mutex> lock(mu);
         Entry *e = nullptr;
         for (Entry &x : entries)
@@ -107,14 +109,27 @@ struct StreamScratch {
         // a capturing stream cannot allocate (and the attempt would invalidate the capture): the caller has to have run the entry
         // point once, at this size, on the stream it captures on -- cslam_amd.vpr.heads.OnlineGraph warms up on its capture stream
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return nullptr;
+        if (hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+            cslam_set_error("scratch of %zu bytes needed on a stream that is being captured: run the call once on that stream first", need);
+            *status = CSLAM_E_HIP;
+            return nullptr;
+        }
         char *fresh = nullptr;
-        if (hipMalloc((void **)&fresh, want) != hipSuccess) return nullptr;
+        if (hipMalloc((void **)&fresh, want) != hipSuccess) {
+            (void)hipGetLastError();
+            cslam_set_error("out of device memory: %zu bytes of scratch", want);
+            *status = CSLAM_E_NOMEM;
+            return nullptr;
+        }
         if (e) { e->ptr = fresh; e->bytes = want; }                // the previous buffer is left alive on purpose (see above)
         else entries.push_back(Entry{dev, stream, fresh, want});
         return fresh;
     }
 };
+
+#define SCRATCH_GET(var, type, scratch, dev, stream, need, floor_bytes)                         \
+    type var;                                                                                  \
+    { int _st; var = (type)(scratch).get((dev), (stream), (need), (floor_bytes), &_st); if (!var) return _st; }
 
 static inline int64_t round_up64(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int64_t ceil_div64(int64_t x, int64_t m) { return (x + m - 1) / m; }

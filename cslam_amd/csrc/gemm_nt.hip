@@ -277,8 +277,7 @@ CSLAM_API int cslam_pca_project_dev(const float *d_x, int64_t ldx, const float *
     const int kps = (int)ceil_div64(nkt, S);
     S = (int)ceil_div64(nkt, kps);
     size_t need = (size_t)S * B * Dout * 4;
-    char *g_part_c = g_part_scratch.get(dev, stream, need, (size_t)64 << 20);
-    ARG_CHECK(g_part_c, "no scratch for this stream: out of device memory, or the stream is capturing and the call was not run on it before");
+    SCRATCH_GET(g_part_c, char *, g_part_scratch, dev, stream, need, (size_t)64 << 20);
     float *g_part = (float *)g_part_c;
     if (B <= 4 && Din % 4 == 0) {
         dim3 grid((unsigned)ceil_div64(ceil_div64(Dout, 2), 4)), block(256);
@@ -370,8 +369,7 @@ CSLAM_API int cslam_pca_project_pairs_dev(const float *d_x, int64_t ldx, float x
     int dev = 0; HIP_TRY(hipGetDevice(&dev));
     const size_t a2_bytes = (size_t)B * Din * 4, part_bytes = (size_t)S * B * Dout * 4;
     const size_t need = a2_bytes + part_bytes + 256;
-    char *g_part_c = g_part_scratch.get(dev, stream, need, (size_t)64 << 20);
-    ARG_CHECK(g_part_c, "no scratch for this stream: out of device memory, or the stream is capturing and the call was not run on it before");
+    SCRATCH_GET(g_part_c, char *, g_part_scratch, dev, stream, need, (size_t)64 << 20);
     float *g_part = (float *)g_part_c;
     unsigned *slot = (unsigned *)g_part;
     unsigned short *A2 = (unsigned short *)((char *)g_part + 256);

@@ -851,8 +851,7 @@ static int vlad_aggregate(const float *d_feat, const float *d_assign_w, const fl
         const int ntile = (P + VS_PT - 1) / VS_PT, nslab = (C + VL_CC - 1) / VL_CC;
         const size_t n_wt = (size_t)C * VK, n_a = (size_t)B * P * VK, n_as = (size_t)B * ntile * VK;
         const size_t n_ss = (size_t)B * VK * nslab, need = n_wt + n_a + n_as + n_ss;
-        float *g_vs = (float *)g_vs_scratch.get(dev, stream, need * 4, (size_t)4 << 20);
-        ARG_CHECK(g_vs, "no scratch for this stream: out of device memory, or the stream is capturing and the call was not run on it before");
+        SCRATCH_GET(g_vs, float *, g_vs_scratch, dev, stream, need * 4, (size_t)4 << 20);
         float *wt = g_vs, *a = wt + n_wt, *as = a + n_a, *ss = as + n_as;
         hipLaunchKernelGGL(vlad_wt_kernel, dim3((unsigned)((C * VK + 255) / 256)), dim3(256), 0, st, d_assign_w, C, wt);
         const size_t lds1 = ((size_t)C * VS_PT + 16 * VS_PT + VS_PT * VK + VS_PT) * 4;

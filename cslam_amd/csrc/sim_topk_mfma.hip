@@ -490,16 +490,21 @@ static int launch_stage1(const MfmaArgs &a, int dbg, int ilv, hipStream_t st) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 0, 2>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+#ifdef CSLAM_ABLATIONS
         HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 1, 0>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 2, 0>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+#endif
         once.done(once_dev);
     }
     const dim3 grid(a.nqt * a.nseg), blk(T_ * 2);
+#ifdef CSLAM_ABLATIONS
     if (dbg == 1) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 1, 0>), grid, blk, lds, st, a);
     else if (dbg == 2) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 2, 0>), grid, blk, lds, st, a);
-    else if (ilv == 2) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 0, 2>), grid, blk, lds, st, a);
+    else
+#endif
+    if (ilv == 2) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 0, 2>), grid, blk, lds, st, a);
     else if (ilv) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 0, 1>), grid, blk, lds, st, a);
     else hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 0, 0>), grid, blk, lds, st, a);
     HIP_TRY(hipGetLastError());
@@ -511,13 +516,18 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
                         int32_t *d_out_cnt, hipStream_t st) {
     static int dbg = -1, tile_env = -1, ilv_env = -1;
     // read on every call (tests and A/B runs switch it inside one process): "f32" = the f32-input MFMA candidate stage
-    // (round 1-2's kernel, the A/B partner); default = fp16 pairs on the fp16 matrix pipe (sim_topk_pair.hip)
+    // (round 1-2's kernel), "pair" = exact fp16 pairs, three products (round 3's); default ("h1") = ONE fp16 product on the hi
+    // halves (round 4, sim_topk_pair.hip NPROD = 1: same rigorous bound as the pair stage at a third of the matrix work)
     const char *s1 = getenv("CSLAM_MFMA_STAGE1");
-    const int stage1_pair = !(s1 && s1[0] == 'f');
+    const int nprod = (s1 && s1[0] == 'f') ? 0 : ((s1 && s1[0] == 'p') ? 3 : 1);
+    const int stage1_pair = nprod != 0;
     if (dbg < 0) {
-        const char *v = getenv("CSLAM_MFMA_DBG");       // timing-only ablations, see the kernel
+        dbg = 0;
+#ifdef CSLAM_ABLATIONS
+        const char *v = getenv("CSLAM_MFMA_DBG");       // timing-only ablations (wrong results), see the kernel: never in the default build
         dbg = v ? atoi(v) : 0;
         if (dbg < 0 || dbg > 2) dbg = 0;
+#endif
         const char *t = getenv("CSLAM_MFMA_TILE");      // 128 | 256 (default chosen below)
         tile_env = t ? atoi(t) : 0;
         const char *iv = getenv("CSLAM_MFMA_ILV");     // 0: all LDS-DMA at the top of the K step (A/B switch)
@@ -561,11 +571,14 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
 
     // queries are used in place only when their pitch is not L2-set-aliasing (see bank.hip)
     const bool pair = stage1_pair != 0;
+    if (nprod == 3) { int rcp = bank_pairs_ensure(b, st); if (rcp) return rcp; }
+    const int64_t ldq2 = nprod == 1 ? b->ldh : b->ld2;          // the query copy has the layout (and pitch) of the bank copy
+    const int kq2 = nprod == 1 ? b->kh : kd;
     const bool direct = !pair && q_dtype == CSLAM_F32 && b->dim == kd && (ldq % 4 == 0) && (ldq % 256 != 0) &&
                         (((uintptr_t)d_q) % 16 == 0);
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = (size_t)round_up64((int64_t)(off + bytes), 256); return o; };
-    size_t o_q32 = carve(direct ? 0 : (pair ? (size_t)nq_pad * b->ld2 : (size_t)nq_pad * ld * 4));
+    size_t o_q32 = carve(direct ? 0 : (pair ? (size_t)nq_pad * ldq2 : (size_t)nq_pad * ld * 4));
     size_t o_qs = carve(pair ? (size_t)nq_pad * 4 : 0);
     size_t o_lim = carve((size_t)nq_pad * 4);
     size_t o_qtm = carve((size_t)nqt * 4);
@@ -617,7 +630,7 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     HIP_TRY(hipMemsetAsync(qtm, 0, (size_t)nqt * 4, st));
     HIP_TRY(hipMemsetAsync(flag_count, 0, 4, st));
     if (pair) {
-        rc = pair_prep_launch(d_q, q_dtype, ldq, (int)nq, b->dim, kd, ws + o_q32, b->ld2, (float *)(ws + o_qs), d_row_limit,
+        rc = pair_prep_launch(d_q, q_dtype, ldq, (int)nq, b->dim, kq2, nprod, ws + o_q32, ldq2, (float *)(ws + o_qs), d_row_limit,
                               (int)b->n, lim, qtm, nq_pad, tile, st);
         if (rc) return rc;
     } else if (q_dtype == CSLAM_F32)
@@ -641,12 +654,12 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     const int ilv = ilv_env >= 0 ? ilv_env : (tile == 256 ? 1 : 0);
     if (pair) {
         PairArgs pa;
-        pa.bank2 = b->rows2; pa.ldb2 = b->ld2; pa.invs = b->invs; pa.n_rows = (int)b->n;
-        pa.q2 = ws + o_q32; pa.ldq2 = b->ld2; pa.qinvs = (const float *)(ws + o_qs);
-        pa.lim = lim; pa.qt_maxlim = qtm; pa.nkt = kd / 32;
+        pa.bank2 = nprod == 1 ? b->rowsh : b->rows2; pa.ldb2 = ldq2; pa.invs = b->invs; pa.n_rows = (int)b->n;
+        pa.q2 = ws + o_q32; pa.ldq2 = ldq2; pa.qinvs = (const float *)(ws + o_qs);
+        pa.lim = lim; pa.qt_maxlim = qtm; pa.nkt = nprod == 1 ? b->kh / 64 : kd / 32;
         pa.nqt = nqt; pa.nseg = nseg; pa.tps = tps; pa.n_btiles = n_btiles;
         pa.part_key = part_key; pa.part_idx = part_idx; pa.part_bound = part_bound; pa.item_map = item_map;
-        rc = pair_stage1_launch(pa, tile, dbg, st);
+        rc = pair_stage1_launch(pa, tile, nprod, dbg, st);
     } else {
         rc = tile == 256 ? launch_stage1<256, 4, 8>(a, dbg, ilv, st) : launch_stage1<128, 2, 16>(a, dbg, ilv, st);
     }
@@ -656,7 +669,7 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     // rigorous bound on |f32 key - exact| / ||q||: kd-term fma chain (gamma_kd), inv-norm
     // rounding, key multiply rounding, query f64->f32 rounding; 2^-24 unit roundoff.
     const double u = 5.9604644775390625e-08;
-    const double err_bound = pair ? pair_err_bound(kd) : 1.0625 * ((double)kd + 8.0) * u;
+    const double err_bound = pair ? pair_err_bound(nprod == 1 ? b->kh : kd, nprod) : 1.0625 * ((double)kd + 8.0) * u;
     const unsigned rgrid = (unsigned)ceil_div64(nq, 4);
     if (q_dtype == CSLAM_F32)
         hipLaunchKernelGGL(rescore_kernel<float>, dim3(rgrid), dim3(256), 0, st, b->rows, (int64_t)ld, kd, b->vv,

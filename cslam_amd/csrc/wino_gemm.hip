@@ -600,6 +600,7 @@ namespace {
 struct TimedLaunch { hipEvent_t e0, e1; double flop16, bytes; int cin; };
 struct TrunkTiming {
     std::atomic<int> on{0};
+    std::mutex mu;                      // entry points are called from several host threads (extraction lanes): the log is shared
     int n = 0;
     TimedLaunch log[512];
     bool made[512] = {};
@@ -607,8 +608,14 @@ struct TrunkTiming {
 }
 static void tt_begin(hipStream_t st, int &slot) {
     slot = -1;
-    if (!g_tt.on.load(std::memory_order_relaxed) || g_tt.n >= 512) return;
-    slot = g_tt.n;
+    if (!g_tt.on.load(std::memory_order_relaxed)) return;
+    // an event recorded on a capturing stream becomes a graph node: the later hipEventSynchronize would fail
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return; }
+    std::lock_guard<std::mutex> lock(g_tt.mu);
+    if (g_tt.n >= 512) return;
+    slot = g_tt.n++;                    // the slot is this launch's from here on
+    g_tt.log[slot].cin = -1;            // not complete yet (cslam_trunk_timing_read skips it)
     if (!g_tt.made[slot]) {
         if (hipEventCreate(&g_tt.log[slot].e0) != hipSuccess || hipEventCreate(&g_tt.log[slot].e1) != hipSuccess) { slot = -1; return; }
         g_tt.made[slot] = true;
@@ -617,13 +624,14 @@ static void tt_begin(hipStream_t st, int &slot) {
 }
 static void tt_end(hipStream_t st, int slot, const WinoGemmArgs &a, int planes_out) {
     if (slot < 0) return;
+    std::lock_guard<std::mutex> lock(g_tt.mu);
     (void)hipEventRecord(g_tt.log[slot].e1, st);
     g_tt.log[slot].flop16 = 3.0 * 2.0 * 36.0 * a.T * (double)a.Cin * a.Cout * (a.nxi == 36 || a.nxi == 6 ? 1.0 : a.nxi / 36.0);
     g_tt.log[slot].bytes = 36.0 * a.T * a.Cin * 4.0 + (double)planes_out * a.T * a.Cout * 4.0 + 36.0 * a.Cin * (double)a.Cout * 4.0;
     g_tt.log[slot].cin = a.Cin;
-    g_tt.n = slot + 1;
 }
 CSLAM_API int cslam_trunk_timing(int enable) {
+    std::lock_guard<std::mutex> lock(g_tt.mu);
     g_tt.n = 0;
     g_tt.on.store(enable ? 1 : 0, std::memory_order_relaxed);
     return CSLAM_OK;
@@ -633,8 +641,10 @@ CSLAM_API int cslam_trunk_timing(int enable) {
 CSLAM_API int cslam_trunk_timing_read(double out[8]) {
     ARG_CHECK(out, "NULL argument");
     for (int i = 0; i < 8; ++i) out[i] = 0.0;
+    std::lock_guard<std::mutex> lock(g_tt.mu);
     for (int i = 0; i < g_tt.n; ++i) {
         float ms = 0.0f;
+        if (g_tt.log[i].cin < 0) continue;           // begun, never ended (its launch failed)
         HIP_TRY(hipEventSynchronize(g_tt.log[i].e1));
         HIP_TRY(hipEventElapsedTime(&ms, g_tt.log[i].e0, g_tt.log[i].e1));
         const int o = g_tt.log[i].cin <= 256 ? 0 : 4;

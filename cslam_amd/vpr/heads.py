@@ -163,11 +163,18 @@ def extract_over_lanes(lane_list, frames_u8, chunk, lanes, lane_runner, run_chun
         with torch.cuda.stream(st):
             d = run_chunk(frames_u8[s:s + chunk], runner)
             if out is None:
-                out = torch.empty((B, d.shape[1]), dtype=d.dtype, device=d.device)
+                # The shared result lives on the CALLER's stream: allocated inside a lane's context the caching allocator would
+                # carve it from a block that lane has just freed (chunk 0's intermediates, whose kernels are still queued),
+                # and the other lanes' copies into it are not ordered against that lane's queue.  A block of the caller's
+                # stream was last used by work the lanes already wait for (the fork above); every lane that writes it is
+                # recorded, so it is not handed out again before the lanes are done with it.
+                with torch.cuda.stream(cur):
+                    out = torch.empty((B, d.shape[1]), dtype=d.dtype, device=d.device)
+                for ls, _ in lane_list[:lanes]:
+                    out.record_stream(ls)
             out[s:s + d.shape[0]].copy_(d)
     for st, _ in lane_list[:lanes]:
         cur.wait_stream(st)
-    out.record_stream(cur)            # allocated on a lane's stream, handed to the caller's: tell the caching allocator
     return out
 
 

@@ -545,10 +545,11 @@ def _stage1_candidates(nnm, nn, nq):
 
 @pytest.mark.parametrize("d,f64", [(4096, False), (4096, True), (512, False), (96, True)])
 def test_fp16_pair_candidate_stage_error_is_inside_the_certificates_bound(nnm, monkeypatch, d, f64):
-    """The candidate stage on fp16 pairs (csrc/sim_topk_pair.hip) is a filter whose keys must stay within the bound handed to
-    the float64 certificate: |key - q.b/||b||| <= bound * ||q||.  Measured here on every candidate the stage kept (rows of
-    very different magnitudes, values spread over twelve binades inside a row), against float64 -- and against the f32-input
-    MFMA stage it replaces, whose bound is 5x tighter and whose results must be the same (both are exact after stage 2)."""
+    """The candidate stages on the fp16 matrix pipe (csrc/sim_topk_pair.hip: "h1" = ONE product on the hi halves, the default;
+    "pair" = exact hi / lo pairs, three products) are filters whose keys must stay within the bound handed to the float64
+    certificate: |key - q.b/||b||| <= bound * ||q||.  Measured here on every candidate each stage kept (rows of very
+    different magnitudes, values spread over twelve binades inside a row), against float64 -- and against the f32-input MFMA
+    stage, whose bound is 5x tighter and whose results must be the same (all three are exact after stage 2)."""
     rng = np.random.default_rng(1000 + d)
     n, nq = 3000, 300
     bank = rng.standard_normal((n, d)).astype(np.float32)
@@ -558,15 +559,15 @@ def test_fp16_pair_candidate_stage_error_is_inside_the_certificates_bound(nnm, m
     q = q.astype(np.float64 if f64 else np.float32)
     nn = make_bank(nnm, bank)
     out = {}
-    for stage in ("pair", "f32"):
+    b64, q64 = bank.astype(np.float64), q.astype(np.float64)
+    bn = np.sqrt((b64 * b64).sum(axis=1))
+    qn = np.sqrt((q64 * q64).sum(axis=1))
+    for stage in ("h1", "pair", "f32"):
         monkeypatch.setenv("CSLAM_MFMA_STAGE1", stage)
         idx, sims, cnt = nn.search_batch(q, 5, mode=nnm.MODE_MFMA)
         assert nn.last_stats()[1] == nnm.MODE_MFMA
         keys, rows, bound = _stage1_candidates(nnm, nn, nq)
         out[stage] = (idx, sims, cnt, bound)
-        b64, q64 = bank.astype(np.float64), q.astype(np.float64)
-        bn = np.sqrt((b64 * b64).sum(axis=1))
-        qn = np.sqrt((q64 * q64).sum(axis=1))
         worst = 0.0
         for j in range(nq):
             r = rows[j].ravel()
@@ -578,10 +579,17 @@ def test_fp16_pair_candidate_stage_error_is_inside_the_certificates_bound(nnm, m
             kd = (d + 31) // 32 * 32
             assert 3 * kd * 2.0 ** -23 < bound < 1.2 * (3 * kd + 64) * 2.0 ** -23 + 3e-6      # the pair bound: ~ 3 kd 2^-23
             assert worst < 2e-5, worst                          # and what the arithmetic really does: fp32-grade
+        if stage == "h1":
+            kh = (d + 63) // 64 * 64
+            # the one-product bound: two fp16 roundings (2^-10, Cauchy-Schwarz) + kh fp32 additions
+            assert 2.0 ** -10 + kh * 2.0 ** -23 < bound < 1.07 * (2.0 ** -10 + 1.01 * (kh + 64) * 2.0 ** -23) + 3e-6
+            assert worst < 2.0 ** -11, worst                    # what the arithmetic really does: random-sign fp16 roundings
     oi, os_, oc = pyoracle.nns_search(bank, q, 5)
-    for stage in ("pair", "f32"):
+    for stage in ("h1", "pair", "f32"):
         assert_topk_equal(out[stage][0], out[stage][1], out[stage][2], oi, os_, oc, 1e-12)
-    assert out["pair"][3] > out["f32"][3]
+    assert out["pair"][3] > out["f32"][3] and out["h1"][3] > out["f32"][3]
+    if d == 4096:
+        assert abs(out["h1"][3] / out["pair"][3] - 1.0) < 0.01  # same window for stage 2: 1.566e-3 against 1.570e-3
 
 
 def test_fp16_pair_stage_rows_and_queries_it_cannot_scale_are_still_exact(nnm):

@@ -4,7 +4,8 @@ import os, sys, time, statistics
 import torch
 sys.path.insert(0, ".")
 from cslam_amd import nns_matching as nnm
-n = nq = 100_000; d = 4096
+n = nq = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000; d = 4096
+nq = int(sys.argv[2]) if len(sys.argv) > 2 else nq
 gen = torch.Generator(device="cuda").manual_seed(1234)
 bank = torch.randn((n, d), generator=gen, device="cuda"); bank /= bank.norm(dim=1, keepdim=True)
 nn = nnm.NearestNeighborsMatching(); nn.add_items_device(bank)
@@ -20,4 +21,4 @@ for rnd in range(3):
 fl = 2.0 * n * nq * d
 for s in shapes:
     km = statistics.median(res[s])
-    print(f"patch {s:8s}: stage-1 kernel {km:7.2f} ms = {fl/km/1e9:6.1f} TFLOP/s fp32-equivalent ({3*fl/km/1e9:.0f} fp16)", flush=True)
+    print(f"n={n} nq={nq} stage1={os.environ.get('CSLAM_MFMA_STAGE1', 'h1')} patch {s:8s}: stage-1 kernel {km:7.3f} ms = {fl/km/1e9:6.1f} TFLOP/s (2 D flop per pair)", flush=True)
