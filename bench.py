@@ -189,18 +189,20 @@ def main():
     rows_mode = world > 1 and a.shard_mode == "rows"
     offs = [g * a.bank_rows // world for g in range(world + 1)] if rows_mode else [0, a.bank_rows]
     local_rows = offs[rank + 1] - offs[rank] if rows_mode else a.bank_rows     # rows resident on this GPU
+    # Inputs are BASELINE.md section 3's, bit for bit (cslam_amd/synthetic.py: numpy default_rng(1234 + robot) / (4321 + robot) /
+    # (7 + frame), generated on the host in two threads while the model is set up, uploaded once: resident in HBM before any timed region).
+    from concurrent.futures import ThreadPoolExecutor
+    from cslam_amd import synthetic
+    pool = ThreadPoolExecutor(max_workers=2)
     if rows_mode:
-        # ONE seeded bank at every N: rank g holds rows [offs[g], offs[g + 1]) of the bank the N = 1 run builds (same seed,
-        # same generator stream, sliced), so an N-rank result is checkable against the unsharded bank (`sharded_check` below)
-        gen = torch.Generator(device=dev).manual_seed(1234)
-        whole = torch.randn((a.bank_rows, a.dim), generator=gen, device=dev, dtype=torch.float32)
-        whole /= whole.norm(dim=1, keepdim=True)
-        bank = whole[offs[rank]:offs[rank + 1]].clone()
-        del whole
+        # ONE seeded bank at every N: rank g holds rows [offs[g], offs[g + 1]) of robot 0's bank, the bank the N = 1 run builds
+        # (same generator stream, sliced), so an N-rank result is checkable against the unsharded bank (`sharded_check` below)
+        whole_np = pool.submit(synthetic.bank, 0, a.bank_rows, a.dim)
+        bank_f = pool.submit(lambda: whole_np.result()[offs[rank]:offs[rank + 1]])
     else:
-        gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-        bank = torch.randn((local_rows, a.dim), generator=gen, device=dev, dtype=torch.float32)
-        bank /= bank.norm(dim=1, keepdim=True)
+        bank_f = pool.submit(synthetic.bank, rank, local_rows, a.dim)
+    mq_f = pool.submit(synthetic.queries, rank, a.match_queries, a.dim)      # the match-only leg's queries (and --no-extract's)
+    bank = torch.from_numpy(bank_f.result()).to(dev)
     nn = nnm.NearestNeighborsMatching(device=local_rank)
     nn.add_items_device(bank)
     extractor = None
@@ -209,9 +211,10 @@ def main():
                              "frontend.netvlad.pca_dim": a.dim, "frontend.random_seed": 0,
                              "frontend.backbone_conv": a.backbone_conv}, None)
     bdt = None if a.backbone_dtype == "fp32" else torch.bfloat16
-    fgen = torch.Generator(device=dev).manual_seed(7 + rank)
-    frames = torch.randint(0, 256, (a.batch, 480, 640, 3), generator=fgen, device=dev, dtype=torch.uint8)
-    qgen = torch.Generator(device=dev).manual_seed(4321 + rank)
+    frames = torch.from_numpy(synthetic.frames(rank * a.batch, a.batch)).to(dev)     # frame i of the job = default_rng(7 + i)
+    mq_all = torch.from_numpy(mq_f.result()).to(dev)
+    pool.shutdown()
+    noext_pos = [0]
     if extractor is not None:
         # model set-up, not a step: builds the transformed weights, the V / M workspaces and loads the GEMM table
         extractor.compute_embeddings_device(frames[:a.extract_chunk], bdt)
@@ -238,22 +241,27 @@ def main():
         hooks = {"gather_fn": gather_fn}
         if rows_mode:
             hooks["exchange_fn"] = exchange_fn
-    matcher = (RowShardedBankMatcher(rank, world, search, offs, k=a.k, **hooks) if rows_mode
-               else ShardedInterRobotMatcher(rank, world, search, k_intra=a.k, **hooks))
+    def search_async(q, k):
+        return nn.search_device_async(q, k, mode=nnm.MODE_MFMA)
+    matcher = (RowShardedBankMatcher(rank, world, search, offs, k=a.k, search_async_fn=search_async, **hooks) if rows_mode
+               else ShardedInterRobotMatcher(rank, world, search, k_intra=a.k, search_async_fn=search_async, **hooks))
 
     def extract():
         if extractor is None:
-            d = torch.randn((a.batch, a.dim), generator=qgen, device=dev)
-            return d / d.norm(dim=1, keepdim=True)
+            p0 = noext_pos[0] % max(1, mq_all.shape[0] - a.batch + 1)     # --no-extract: walk through the query recipe's rows
+            noext_pos[0] = p0 + a.batch
+            return mq_all[p0:p0 + a.batch]
         if bdt is None:
             return extractor.compute_embeddings_batch_device(frames, a.extract_chunk, a.extract_lanes)
         outs = [extractor.compute_embeddings_device(frames[s:s + a.extract_chunk], bdt)
                 for s in range(0, a.batch, a.extract_chunk)]
         return torch.cat(outs)
 
-    # N = 1: the search of step i is ENQUEUED behind its extraction (cslam_bank_search_enqueue_dev) and FINISHED -- one event
+    # The search of step i is ENQUEUED behind its extraction (cslam_bank_search_enqueue_dev) and FINISHED -- one event
     # wait for the certificate count, no stream synchronisation -- after step i + 1 has been enqueued: no host
-    # synchronisation between extract chunks and search, the GPU queue never drains inside the timed region.
+    # synchronisation between extract chunks and search, the GPU queue never drains inside the timed region.  N > 1 runs
+    # the same two halves through the sharded matchers (all-gather, search, all-to-all and merge enqueued by step_begin;
+    # sharded.py), so a rank's step differs from the N = 1 step by its collectives only.
     pending = []
 
     def retire():
@@ -262,11 +270,9 @@ def main():
             kernel_ms.append(nn.last_kernel_ms())      # events of a search that has finished: no wait
 
     def step():
-        if world > 1:
-            return matcher.step(extract())
         d = extract()                                  # enqueued; the host runs ahead of the GPU
         retire()                                       # step i - 1's search: done long ago, its count is on the host
-        pending.append(nn.search_device_async(d, a.k, mode=nnm.MODE_MFMA))
+        pending.append(matcher.step_begin(d) if world > 1 else nn.search_device_async(d, a.k, mode=nnm.MODE_MFMA))
         return pending[-1]
 
     def flush():
@@ -336,10 +342,8 @@ def main():
     sharded_check = None
     if rows_mode and extractor is not None:
         d_chk = extract()
-        got = matcher.step(d_chk)
-        gen = torch.Generator(device=dev).manual_seed(1234)
-        whole = torch.randn((a.bank_rows, a.dim), generator=gen, device=dev, dtype=torch.float32)
-        whole /= whole.norm(dim=1, keepdim=True)
+        got = matcher.step_begin(d_chk).finish()               # the two halves the timed steps ran on
+        whole = torch.from_numpy(whole_np.result()).to(dev)
         nn_whole = nnm.NearestNeighborsMatching(device=local_rank)
         nn_whole.add_items_device(whole)
         want = nn_whole.search_device(d_chk, a.k, mode=nnm.MODE_MFMA)
@@ -390,8 +394,7 @@ def main():
         torch.cuda.empty_cache()
     kernel_ms.clear()
     nqm = a.match_queries
-    mq = torch.randn((nqm, a.dim), generator=qgen, device=dev)
-    mq /= mq.norm(dim=1, keepdim=True)
+    mq = mq_all[:nqm]
     mout = nn.search_device(mq, a.k, mode=nnm.MODE_MFMA)
     kernel_ms.clear()
     dm = timed(lambda: search(mq, a.k), max(1, min(a.steps, 2)))

@@ -60,6 +60,7 @@ _SIGNATURES = {
     "cslam_bank_search_multi_dev": (_i, [_vp, _i, _vp, _i, _i64, _i64, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "cslam_bank_search_enqueue_dev": (_i, [_vp, _vp, _i, _i64, _i64, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "cslam_bank_search_finish": (_i, [_vp, C.POINTER(_i64)]),
+    "cslam_bank_search_flag_copy_dev": (_i, [_vp, _vp, _vp]),
     "cslam_bank_search_multi_enqueue_dev": (_i, [_vp, _i, _vp, _i, _i64, _i64, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "cslam_bank_search_multi_finish": (_i, [_vp, _i, C.POINTER(_i64)]),
     "cslam_bank_last_stats": (_i, [_vp, C.POINTER(_i64 * 4)]),

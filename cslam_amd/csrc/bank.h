@@ -42,6 +42,7 @@ struct cslam_bank {
     int item_map_key[4];
     int *h_nflag;                     // pinned: count of uncertified queries of the last enqueued MFMA search
     int *pending_flag_list;           // device list those queries are in (bank workspace)
+    int *pending_flag_count;          // device count of that list (bank workspace)
     int pending_dbg;
     // a search that has been enqueued and not finished (cslam_bank_search_enqueue_dev ... cslam_bank_search_finish): its
     // arguments, for the exact-scan fallback of the uncertified queries; ev_flag = "the uncertified-query count is on the host"

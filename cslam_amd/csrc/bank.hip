@@ -119,7 +119,7 @@ CSLAM_API int cslam_bank_create(int device, int dim, int64_t capacity_hint, csla
     for (int s = 0; s < 3; ++s) { b->ws[s] = nullptr; b->ws_bytes[s] = 0; }
     b->stage = nullptr; b->stage_bytes = 0; b->last_stream = nullptr; b->ev_valid = false;
     b->side = nullptr; b->ev_fork = nullptr; b->ev_side = nullptr;
-    b->h_nflag = nullptr; b->pending_flag_list = nullptr; b->pending_dbg = 0;
+    b->h_nflag = nullptr; b->pending_flag_list = nullptr; b->pending_flag_count = nullptr; b->pending_dbg = 0;
     b->pend.active = false; b->pend.deferred = false; b->ev_flag = nullptr;
     b->dbg_part_key = nullptr; b->dbg_part_idx = nullptr; b->dbg_nseg = 0; b->dbg_nq = 0; b->dbg_err_bound = 0.0;
     for (int s = 0; s < 4; ++s) { b->stats[s] = 0; b->item_map_key[s] = -1; }
@@ -853,6 +853,21 @@ CSLAM_API int cslam_bank_search_enqueue_dev(cslam_bank_t *b, const void *d_queri
     return bank_enqueue(b, d_queries, q_dtype, ldq, nq, k, d_row_limit, mode, d_out_idx, d_out_sim, d_out_cnt, st, st);
 }
 
+/* The uncertified-query count of the enqueued search, handed on INSIDE the stream: a 4-byte device-to-device copy enqueued on
+ * `stream` (the stream of the enqueue) into d_count -- 0 for a search that needs no certificate (exact scan).  A sharded step
+ * sends it along with its provisional lists, so that every rank learns in stream order, without a host round trip, whether some
+ * shard still owes an exact re-scan (cslam_amd/sharded.py: step_begin / finish). */
+CSLAM_API int cslam_bank_search_flag_copy_dev(cslam_bank_t *b, int32_t *d_count, void *stream) {
+    ARG_CHECK(b && d_count, "NULL argument");
+    BANK_DEVICE(b);
+    hipStream_t st = (hipStream_t)stream;
+    if (b->pend.active && b->pend.deferred && b->pending_flag_count)
+        HIP_TRY(hipMemcpyAsync(d_count, b->pending_flag_count, 4, hipMemcpyDeviceToDevice, st));
+    else
+        HIP_TRY(hipMemsetAsync(d_count, 0, 4, st));
+    return CSLAM_OK;
+}
+
 CSLAM_API int cslam_bank_search_finish(cslam_bank_t *b, int64_t *n_uncertified) {
     ARG_CHECK(b, "bank is NULL");
     BANK_DEVICE(b);
@@ -894,9 +909,9 @@ CSLAM_API int cslam_bank_search_multi_enqueue_dev(cslam_bank_t *const *banks, in
     hipStream_t st = (hipStream_t)stream;
     // The searches of the list are independent and, on chunk-sized query batches against banks of a few thousand rows, far
     // too small to fill the chip one after the other (250 queries x 12 500 rows = 49 workgroups): each bank enqueues on a
-    // stream of its own, forked from and joined back into the caller's stream.  CSLAM_MULTI_STREAMS=0: one after the other.
-    static const bool side_by_side = [] { const char *e = getenv("CSLAM_MULTI_STREAMS"); return !(e && e[0] == '0'); }();
-    const bool fork = side_by_side && nb > 1;
+    // stream of its own, forked from and joined back into the caller's stream (one after the other: C5 rehearsal's local
+    // matching 2.5 instead of 2.0 s, profiles/r02_v50_perf_c5_drain_multistream.log).
+    const bool fork = nb > 1;
     if (fork) {
         for (int i = 0; i < nb; ++i) {
             cslam_bank *b = banks[i];

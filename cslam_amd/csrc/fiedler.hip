@@ -489,9 +489,9 @@ CSLAM_API int cslam_fiedler(int64_t n, const int64_t *h_indptr, const int32_t *h
         // the trailing matrix; the inversions of the diagonal blocks (needed only by the solves afterwards) on a third.
         const double one = 1.0, minus = -1.0;
         const int cb = m > 4096 ? bs : m;                                           // small systems: one potrf
-        const char *lenv = getenv("CSLAM_FIEDLER_LOOKAHEAD"), *tenv = getenv("CSLAM_MAC_TIMING");
+        const char *tenv = getenv("CSLAM_MAC_TIMING");
         const bool split = tenv && tenv[0] == '2';                                 // per-category times: one stream, a sync after every call
-        const bool la = m > cb && !(lenv && lenv[0] == '0') && !split;
+        const bool la = m > cb && !split;                                           // look-ahead: 308 -> 278 ms at 31.5k junctions (round 2)
         double t_cat[4] = {0, 0, 0, 0};                                             // potrf, panel trsm, trailing gemm, block inverses
         auto tick = [&](int cat, std::chrono::steady_clock::time_point t0) {
             if (!split) return;

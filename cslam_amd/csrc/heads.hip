@@ -822,9 +822,8 @@ static int vlad_aggregate(const float *d_feat, const float *d_assign_w, const fl
     if (B == 0) return CSLAM_OK;
     if (nhwc) {
         ARG_CHECK(P <= VL_PMAX && B > 8, "the channels-last form is the batch kernel's (B > 8, P <= 256)");
-        // NetVLAD's own shape (512 channels, 14 x 14): the two contractions on the f32 matrix pipe; CSLAM_VLAD_MFMA=0: the VALU form
-        static const bool use_mfma = [] { const char *e = getenv("CSLAM_VLAD_MFMA"); return !(e && e[0] == '0'); }();
-        if (use_mfma && C % VM_CS == 0 && C <= 4 * VM_CS && P <= VM_PP && P >= 32) {
+        // NetVLAD's own shape (512 channels, 14 x 14): the two contractions on the f32 matrix pipe; other shapes: the VALU form
+        if (C % VM_CS == 0 && C <= 4 * VM_CS && P <= VM_PP && P >= 32) {
             const size_t lds_m = (size_t)VM_LDS_FLOATS * 4;
             static DeviceOnce once;
             int once_dev;
@@ -1316,8 +1315,7 @@ CSLAM_API int cslam_preprocess_dev(const uint8_t *d_img, int B, int H, int W, in
     const int ptop = H < crop ? (crop - H) / 2 : 0, pleft = W < crop ? (crop - W) / 2 : 0;
     const int Hp = H < crop ? crop : H, Wp = W < crop ? crop : W;
     const int top = (int)lrint((Hp - crop) / 2.0), left = (int)lrint((Wp - crop) / 2.0);
-    static const bool tile_form = [] { const char *e = getenv("CSLAM_PREPROCESS_TILE"); return !(e && e[0] == '0'); }();
-    if (tile_form && g_pp.ty2 > 0 && g_pp.ksize >= 5 && g_pp.ksize <= 13 && (g_pp.ksize & 1)) {
+    if (g_pp.ty2 > 0 && g_pp.ksize >= 5 && g_pp.ksize <= 13 && (g_pp.ksize & 1)) {
         const size_t tmp_pitch = ((size_t)out_hw * 3 + 3) & ~(size_t)3;
         const size_t lds2 = (size_t)g_pp.max_rows2 * (in_row_bytes + tmp_pitch) + (size_t)g_pp.ty2 * tmp_pitch + 3072;   // + the [3][256] table
         const dim3 grid((out_hw + g_pp.ty2 - 1) / g_pp.ty2, B);

@@ -191,22 +191,6 @@ __global__ __launch_bounds__(T_ * 2, 2) void sim_topk_mfma_kernel(MfmaArgs p) {
                     __builtin_amdgcn_sched_group_barrier(0x008, G / 4, 0);
                     __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, G / 2, 0);
-                } else if (ILV == 2) {
-                    // same, but everything is issued during the first two K groups so that the last loads
-                    // have two groups of MFMAs (not a quarter of one) to land before the end-of-step wait
-                    constexpr int G = MT * 2 * 4;
-                    if (j < 2) {
-                        if (DBG != 1) { stage_load_part(cur ^ 1, ltile, lkt, 2 * j); stage_load_part(cur ^ 1, ltile, lkt, 2 * j + 1); }
-                        __builtin_amdgcn_sched_group_barrier(0x008, G / 8, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, G / 4, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, G / 4, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, G / 4, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x008, G / 8, 0);
-                    }
                 }
             }
 
@@ -488,8 +472,6 @@ static int launch_stage1(const MfmaArgs &a, int dbg, int ilv, hipStream_t st) {
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 0, 1>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 0, 2>,
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
 #ifdef CSLAM_ABLATIONS
         HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_mfma_kernel<T_, MT, KPL, 1, 0>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -504,8 +486,7 @@ static int launch_stage1(const MfmaArgs &a, int dbg, int ilv, hipStream_t st) {
     else if (dbg == 2) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 2, 0>), grid, blk, lds, st, a);
     else
 #endif
-    if (ilv == 2) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 0, 2>), grid, blk, lds, st, a);
-    else if (ilv) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 0, 1>), grid, blk, lds, st, a);
+    if (ilv) hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 0, 1>), grid, blk, lds, st, a);
     else hipLaunchKernelGGL((sim_topk_mfma_kernel<T_, MT, KPL, 0, 0>), grid, blk, lds, st, a);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
@@ -514,7 +495,7 @@ static int launch_stage1(const MfmaArgs &a, int dbg, int ilv, hipStream_t st) {
 int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq, int64_t nq, int k,
                         const int64_t *d_row_limit, int64_t *d_out_idx, double *d_out_sim,
                         int32_t *d_out_cnt, hipStream_t st) {
-    static int dbg = -1, tile_env = -1, ilv_env = -1;
+    static int dbg = -1, tile_env = -1;
     // read on every call (tests and A/B runs switch it inside one process): "f32" = the f32-input MFMA candidate stage
     // (round 1-2's kernel), "pair" = exact fp16 pairs, three products (round 3's); default ("h1") = ONE fp16 product on the hi
     // halves (round 4, sim_topk_pair.hip NPROD = 1: same rigorous bound as the pair stage at a third of the matrix work)
@@ -530,8 +511,6 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
 #endif
         const char *t = getenv("CSLAM_MFMA_TILE");      // 128 | 256 (default chosen below)
         tile_env = t ? atoi(t) : 0;
-        const char *iv = getenv("CSLAM_MFMA_ILV");     // 0: all LDS-DMA at the top of the K step (A/B switch)
-        if (iv) ilv_env = atoi(iv);
     }
     const int ld = b->ld, kd = b->kd;
     // tile shape: 256x256 halves the operand traffic per flop and is faster from nq = 512 upwards
@@ -609,10 +588,12 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
         if (bseg < 1) bseg = 1;
         int aq = (int)ceil_div64(per_xcd, bseg);
         if (aq < 1) aq = 1;
-        if (const char *pe = getenv("CSLAM_MFMA_PATCH")) {       // experiments: "aq,bseg" = query tiles x segments per XCD patch
-            int a_ = 0, b_ = 0;
+#ifdef CSLAM_ABLATIONS
+        if (const char *pe = getenv("CSLAM_MFMA_PATCH")) {       // measurement build: "aq,bseg" = query tiles x segments per XCD patch
+            int a_ = 0, b_ = 0;                                  // (1 x 32 ... 32 x 1 move the stage by <= 3 %: profiles/r04_v2_h1_patch_shapes.log)
             if (sscanf(pe, "%d,%d", &a_, &b_) == 2 && a_ >= 1 && b_ >= 1) { aq = a_; bseg = b_ > nseg ? nseg : b_; }
         }
+#endif
         if (b->item_map_host.size() != (size_t)nqt * nseg || b->item_map_key[0] != nqt || b->item_map_key[1] != nseg ||
             b->item_map_key[2] != aq || b->item_map_key[3] != bseg) {
             b->item_map_host.clear();
@@ -651,7 +632,7 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     // interleaved LDS-DMA issue: +3.4 points of peak on the 256 tile (one workgroup per CU: both waves of
     // a SIMD used to issue their 8 loads together right after the barrier); -0.5 on the 128 tile, whose
     // two independent workgroups per CU already overlap each other's issue slots
-    const int ilv = ilv_env >= 0 ? ilv_env : (tile == 256 ? 1 : 0);
+    const int ilv = tile == 256 ? 1 : 0;
     if (pair) {
         PairArgs pa;
         pa.bank2 = nprod == 1 ? b->rowsh : b->rows2; pa.ldb2 = ldq2; pa.invs = b->invs; pa.n_rows = (int)b->n;
@@ -688,6 +669,7 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     HIP_TRY(hipMemcpyAsync(b->h_nflag, flag_count, 4, hipMemcpyDeviceToHost, st));
     b->stats[2] = nseg; b->stats[3] = nqt;
     b->pending_flag_list = flag_list;
+    b->pending_flag_count = flag_count;
     b->pending_dbg = dbg;
     b->dbg_part_key = part_key; b->dbg_part_idx = part_idx; b->dbg_nseg = nseg; b->dbg_nq = (int)nq; b->dbg_err_bound = err_bound;
     return CSLAM_OK;

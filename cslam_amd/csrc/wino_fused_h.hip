@@ -35,8 +35,8 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
                                        // transform's ds_read_b32 of two tiles of a 32-lane group then collide 2-way)
 #define WH_VS 16                       // V row = 16 dwords (16 channels x [hi | lo]), 16-byte groups rotated by (tile & 15) >> 1
 #define WH_VSW(tile, grp) (4 * (((((tile) & 15) >> 1) + (grp)) & 3))
-#define WH_BR_DEFAULT 2                // weight fragments in flight, in pairs of frequencies (template parameter WH_BR;
-                                       // CSLAM_WFH_BR = 2 | 4 selects the other instantiations for experiments)
+#define WH_BR_DEFAULT 2                // weight fragments in flight, in pairs of frequencies (template parameter WH_BR; a ring of 3
+                                       // or 4 pairs spills more than its depth gains: 2.39 / 2.47 / 2.63 ms at 2 / 3 / 4, round 2)
 
 __device__ __forceinline__ void wh_glds16(const float *g, float *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
@@ -555,16 +555,15 @@ static int launch_fused_h(const float *d_x, const unsigned *d_Uh, const float *d
         HIP_TRY(hipMemset(zero16, 0, 256));
         zero_dev = dev;
     }
-    const char *dbg_env = getenv("CSLAM_WFH_DBG");                  // timing-only ablations, relu + pool form only
-    const int dbg = dbg_env ? atoi(dbg_env) : 0;
 #define WH_LAUNCH_DB(R, P, D, BR) do { \
         HIP_TRY(hipFuncSetAttribute((const void *)wino4_fused_c64_h_kernel<COUT, R, P, D, BR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
         hipLaunchKernelGGL((wino4_fused_c64_h_kernel<COUT, R, P, D, BR>), grid, block, lds, st, d_x, d_Uh, d_bias, d_res, \
                            H, W, gxs, gyb, (int)nsb, d_amax, inv_su, d_amax_out, zero16, d_y, (const unsigned *)nullptr, (const float *)nullptr, (const float *)nullptr, 0.0f); } while (0)
 #define WH_LAUNCH_D(R, P, D) WH_LAUNCH_DB(R, P, D, WH_BR_DEFAULT)
-    const char *br_env = getenv("CSLAM_WFH_BR");
-    const int br = br_env ? atoi(br_env) : WH_BR_DEFAULT;
-#define WH_LAUNCH(R, P) do { if (br == 2) WH_LAUNCH_DB(R, P, 0, 2); else if (br == 4) WH_LAUNCH_DB(R, P, 0, 4); else WH_LAUNCH_DB(R, P, 0, WH_BR_DEFAULT); } while (0)
+#define WH_LAUNCH(R, P) WH_LAUNCH_DB(R, P, 0, WH_BR_DEFAULT)
+#ifdef CSLAM_ABLATIONS
+    const char *dbg_env = getenv("CSLAM_WFH_DBG");                  // timing-only ablations (wrong results), relu + pool form only: measurement build
+    const int dbg = dbg_env ? atoi(dbg_env) : 0;
     if (dbg && relu) {
         if (pool) { switch (dbg) { case 1: WH_LAUNCH_D(true, true, 1); break; case 2: WH_LAUNCH_D(true, true, 2); break; case 4: WH_LAUNCH_D(true, true, 4); break;
                                    case 5: WH_LAUNCH_D(true, true, 5); break; case 8: WH_LAUNCH_D(true, true, 8); break; case 16: WH_LAUNCH_D(true, true, 16); break;
@@ -574,6 +573,7 @@ static int launch_fused_h(const float *d_x, const unsigned *d_Uh, const float *d
                               case 6: WH_LAUNCH_D(true, false, 6); break; default: WH_LAUNCH_D(true, false, 31); } }
         return CSLAM_OK;
     }
+#endif
     if (d_res) {                                                    // shortcut add (never pooled): its own instantiation
         const void *fr = relu ? (const void *)wino4_fused_c64_h_kernel<COUT, true, false, 0, WH_BR_DEFAULT, true>
                               : (const void *)wino4_fused_c64_h_kernel<COUT, false, false, 0, WH_BR_DEFAULT, true>;
@@ -584,11 +584,13 @@ static int launch_fused_h(const float *d_x, const unsigned *d_Uh, const float *d
                                 d_bias, d_res, H, W, gxs, gyb, (int)nsb, d_amax, inv_su, d_amax_out, zero16, d_y, (const unsigned *)nullptr, (const float *)nullptr, (const float *)nullptr, 0.0f);
         return CSLAM_OK;
     }
+#ifdef CSLAM_ABLATIONS
     const char *prof_env = getenv("CSLAM_WFH_PROF");
     if (prof_env && atoi(prof_env) && relu && !d_res) {             // per-phase cycle counts of workgroup 0 (conv1_2's / conv2_1's forms)
         if (COUT == 64 && pool) { WH_LAUNCH_DB(true, true, 32, WH_BR_DEFAULT); return CSLAM_OK; }
         if (COUT == 128 && !pool) { WH_LAUNCH_DB(true, false, 32, WH_BR_DEFAULT); return CSLAM_OK; }
     }
+#endif
     if (relu && pool) WH_LAUNCH(true, true);
     else if (relu) WH_LAUNCH(true, false);
     else if (pool) WH_LAUNCH(false, true);
@@ -643,9 +645,11 @@ static int launch_stem_h(const float *d_x0, const unsigned *d_w1, const float *d
         HIP_TRY(hipFuncSetAttribute((const void *)wino4_fused_c64_h_kernel<64, true, P, D, WH_BR_DEFAULT, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
         hipLaunchKernelGGL((wino4_fused_c64_h_kernel<64, true, P, D, WH_BR_DEFAULT, false, true>), grid, block, lds, st, d_x0, d_Uh, d_bias, \
                            (const float *)nullptr, H, W, gxs, gyb, (int)nsb, d_amax, inv_su, d_amax_out, zero16[dev], d_y, d_w1, d_b1, d_sumw, inv_sw); } while (0)
+#ifdef CSLAM_ABLATIONS
     const char *prof_env = getenv("CSLAM_WFH_PROF");
-    if (prof_env && atoi(prof_env) && pool) ST_LAUNCH(true, 32);
-    else if (pool) ST_LAUNCH(true, 0);
+    if (prof_env && atoi(prof_env) && pool) { ST_LAUNCH(true, 32); return CSLAM_OK; }
+#endif
+    if (pool) ST_LAUNCH(true, 0);
     else ST_LAUNCH(false, 0);
 #undef ST_LAUNCH
     return CSLAM_OK;

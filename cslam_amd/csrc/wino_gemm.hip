@@ -579,15 +579,10 @@ CSLAM_API int cslam_wino4_input_h2_dev(const float *d_x, int B, int H, int W, in
     ARG_CHECK(C >= 32 && (C % 32) == 0, "C must be a multiple of 32");
     const int64_t n4 = (int64_t)B * ((H + 3) / 4) * ((W + 3) / 4) * (C / 4);
     ARG_CHECK(ceil_div64(n4, 256) < (1LL << 31), "too many tiles for one launch");
-    // 16-byte stores through a lane-pair exchange (default; CSLAM_WIN_PAIR16=0: two 8-byte stores per thread and frequency):
-    // 5.0 -> 5.3 TB/s on the trunk's shapes, profiles/r02_v28_input_transform_pair16_ab.log
-    const char *pe = getenv("CSLAM_WIN_PAIR16");
-    if (!(pe && atoi(pe) == 0))
-        hipLaunchKernelGGL(wino4_input_h2_kernel<true>, dim3((unsigned)round_up64(ceil_div64(n4, 256), 8)), dim3(256), 0,
-                           (hipStream_t)stream, d_x, B, H, W, C, d_amax, (__half *)d_V2);
-    else
-        hipLaunchKernelGGL(wino4_input_h2_kernel<false>, dim3((unsigned)round_up64(ceil_div64(n4, 256), 8)), dim3(256), 0,
-                           (hipStream_t)stream, d_x, B, H, W, C, d_amax, (__half *)d_V2);
+    // 16-byte stores through a lane-pair exchange (two 8-byte stores per thread and frequency: 5.0 -> 5.3 TB/s on the trunk's
+    // shapes, profiles/r02_v28_input_transform_pair16_ab.log)
+    hipLaunchKernelGGL(wino4_input_h2_kernel<true>, dim3((unsigned)round_up64(ceil_div64(n4, 256), 8)), dim3(256), 0,
+                       (hipStream_t)stream, d_x, B, H, W, C, d_amax, (__half *)d_V2);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }
@@ -671,15 +666,20 @@ static int wino_gemm_launch(WinoGemmArgs a, int dbg, hipStream_t st) {
     int once_dev;
     if (once.todo(&once_dev)) {
         HIP_TRY(hipFuncSetAttribute((const void *)wino_gemm_h2_kernel<TM, TN, NS, 0, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+#ifdef CSLAM_ABLATIONS
         HIP_TRY(hipFuncSetAttribute((const void *)wino_gemm_h2_kernel<TM, TN, NS, 1, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
         HIP_TRY(hipFuncSetAttribute((const void *)wino_gemm_h2_kernel<TM, TN, NS, 2, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+#endif
         once.done(once_dev);
     }
     int tslot;
     tt_begin(st, tslot);
+#ifdef CSLAM_ABLATIONS
     if (dbg == 1) hipLaunchKernelGGL((wino_gemm_h2_kernel<TM, TN, NS, 1, WM>), dim3(grid), dim3(512), lds, st, a);
     else if (dbg == 2) hipLaunchKernelGGL((wino_gemm_h2_kernel<TM, TN, NS, 2, WM>), dim3(grid), dim3(512), lds, st, a);
-    else hipLaunchKernelGGL((wino_gemm_h2_kernel<TM, TN, NS, 0, WM>), dim3(grid), dim3(512), lds, st, a);
+    else
+#endif
+    hipLaunchKernelGGL((wino_gemm_h2_kernel<TM, TN, NS, 0, WM>), dim3(grid), dim3(512), lds, st, a);
     if (a.nxi == 36) tt_end(st, tslot, a, 36);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
@@ -697,9 +697,12 @@ CSLAM_API int cslam_wino_gemm_h2_dev(const void *d_V2, const void *d_U2, int64_t
     a.T = (int)T; a.Cin = Cin; a.Cout = Cout; a.nk = Cin / 32;
     a.n_mt = a.n_nt = a.n_items = 0;
     a.nxi = 36;
-    // read on every call (two getenv, ~100 ns) so that tests and experiments can switch shapes inside one process
-    const char *e = getenv("CSLAM_WGEMM_DBG"), *c = getenv("CSLAM_WGEMM_CFG");
-    const int dbg = e ? atoi(e) : 0;            // timing-only ablations
+    // read on every call (~100 ns) so that tests can switch shapes inside one process
+    const char *c = getenv("CSLAM_WGEMM_CFG");
+    int dbg = 0;
+#ifdef CSLAM_ABLATIONS
+    if (const char *e = getenv("CSLAM_WGEMM_DBG")) dbg = atoi(e);   // timing-only ablations (wrong results): measurement build only
+#endif
     const int cfg = c ? atoi(c) : 0;            // force a tile / ring shape (1..5 below); 0 = default
     hipStream_t st = (hipStream_t)stream;
     // default: 256 x 128 tiles with the ring of three stages -- the fastest or within 4 % of the fastest shape on every
@@ -754,24 +757,20 @@ CSLAM_API int cslam_wino_zgemm_h2_dev(const void *d_V2, const void *d_U2, int64_
     int n_cu = cslam_cu_count();
     ARG_CHECK(n_cu > 0, "no HIP device");
     if (n_cu < 8) n_cu = 8;
-    // ring of three 32 KB stages (default); CSLAM_ZGEMM_NS=2: double buffer (A/B runs)
-    const char *nse = getenv("CSLAM_ZGEMM_NS");
-    const int ns = (nse && atoi(nse) == 2) ? 2 : 3;
-    const int lds = ns * (128 + 128) * WG_ROWB;
+    // ring of three 32 KB stages, one workgroup per CU (a double buffer, two workgroups per CU: 1.50-1.54 ms against 1.30 on
+    // conv2_2, profiles/r03_v9_zgemm_variants.log)
+    const int lds = 3 * (128 + 128) * WG_ROWB;
     int grid = n_cu - n_cu % 8;
-    if (const char *ge = getenv("CSLAM_ZGEMM_WGS")) { const int v = atoi(ge); if (v >= 1 && v <= 4 && ns * 32 * v <= 160) grid *= v; }   // workgroups per CU (A/B runs)
     if ((int64_t)grid > round_up64(a.n_items, 8)) grid = (int)round_up64(a.n_items, 8);
     static DeviceOnce once;
     int once_dev;
     if (once.todo(&once_dev)) {
         HIP_TRY(hipFuncSetAttribute((const void *)wino_zgemm_h2_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * (128 + 128) * WG_ROWB));
-        HIP_TRY(hipFuncSetAttribute((const void *)wino_zgemm_h2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * WG_ROWB));
         once.done(once_dev);
     }
     int tslot;
     tt_begin((hipStream_t)stream, tslot);
-    if (ns == 2) hipLaunchKernelGGL((wino_zgemm_h2_kernel<2>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((wino_zgemm_h2_kernel<3>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL((wino_zgemm_h2_kernel<3>), dim3(grid), dim3(512), lds, (hipStream_t)stream, a);
     tt_end((hipStream_t)stream, tslot, a, 24);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;

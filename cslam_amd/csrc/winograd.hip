@@ -819,7 +819,7 @@ CSLAM_API int cslam_wino4_input_h3_dev(const float *d_x, int B, int H, int W, in
     ARG_CHECK(C >= 2 && (C % 2) == 0, "C must be even");
     const int64_t n = (int64_t)B * ((H + 3) / 4) * ((W + 3) / 4) * (C / 2);
     ARG_CHECK(ceil_div64(n, 256) < (1LL << 31), "too many tiles for one launch");
-    if ((C % 4) == 0 && !getenv("CSLAM_H3_C2")) {
+    if ((C % 4) == 0) {
         const int64_t n4 = n / 2;
         hipLaunchKernelGGL(wino4_input_h3x4_kernel, dim3((unsigned)round_up64(ceil_div64(n4, 256), 8)), dim3(256), 0,
                            (hipStream_t)stream, d_x, B, H, W, C, d_amax, (__half *)d_V3);

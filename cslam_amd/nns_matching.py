@@ -306,6 +306,22 @@ class PendingSearch(object):
         self._keep = None
         return self._out
 
+    @property
+    def out(self):
+        """The output tensors as enqueued: valid in stream order, PROVISIONAL for queries the certificate could not settle
+        until `finish()` has re-done them."""
+        return self._out
+
+    def uncertified_to(self, count):
+        """Enqueue (current stream) a copy of this search's uncertified-query count into `count`, an int32 CUDA tensor of one
+        element: the device-side twin of `finish()`'s return, for a caller that ships it with the provisional lists."""
+        import torch
+        assert self._banks is not None and len(self._banks) == 1, "one pending single-bank search"
+        assert count.is_cuda and count.dtype == torch.int32 and count.numel() == 1
+        b = self._banks[0]
+        st = torch.cuda.current_stream(count.device).cuda_stream
+        _lib.check(b._lib.cslam_bank_search_flag_copy_dev(b._bank, C.c_void_p(count.data_ptr()), C.c_void_p(st)))
+
     def __del__(self):                       # a dropped handle must not leave the bank locked
         try:
             self.finish()

@@ -53,6 +53,34 @@ def exchange_lists_async(packed, world_size, group=None):
     return out, dist.all_to_all_single(out, packed.contiguous(), group=group, async_op=True)
 
 
+class PendingStep(object):
+    """A sharded step whose kernels and collectives are enqueued (`step_begin`); `finish()` -> what `step()` returns.
+    Between the two the host is free -- it enqueues the NEXT step's extraction, so the GPU queue never drains on a host
+    wait (the N = 1 step's `search_device_async` pipelining carried over to N > 1)."""
+
+    def __init__(self, finish_fn):
+        self._finish, self._result = finish_fn, None
+
+    def finish(self):
+        if self._finish is not None:
+            self._result = self._finish()
+            self._finish = None
+        return self._result
+
+
+class _SyncPending(object):
+    """A search that has already run (a synchronous `search_fn` behind the asynchronous interface)."""
+
+    def __init__(self, out):
+        self.out, self.uncertified = out, 0
+
+    def uncertified_to(self, count):
+        count.zero_()
+
+    def finish(self):
+        return self.out
+
+
 def _chunk_bounds(m, chunks):
     """[0, m) cut into at most `chunks` equal pieces (the same cut on every rank: m is equal on all ranks)."""
     c = max(1, min(int(chunks), m)) if m > 0 else 1
@@ -61,20 +89,57 @@ def _chunk_bounds(m, chunks):
 
 
 class ShardedInterRobotMatcher(object):
-    def __init__(self, rank, world_size, search_fn, k_intra=5, gather_fn=None, chunks=2):
+    def __init__(self, rank, world_size, search_fn, k_intra=5, gather_fn=None, chunks=2, search_async_fn=None):
         """search_fn(queries [nq,d], k) -> (rows [nq,k], sims [nq,k], cnt [nq]) against THIS
         rank's bank (e.g. NearestNeighborsMatching.search_device).
+        search_async_fn(queries, k) -> handle with `.finish()` -> the same triple (NearestNeighborsMatching.
+        search_device_async): what `step_begin` enqueues; None = `search_fn` behind the same interface.
         chunks: the step's descriptors are exchanged and scored in this many pieces, the all-gather of piece
         t+1 in flight while piece t is scored (SURVEY 8e "double-buffer query chunks"); 1 = one gather, one launch.
         gather_fn: injected synchronous all-gather (tests, host-staged debug runs); None = RCCL, asynchronous."""
         self.rank, self.world = rank, world_size
         self.search_fn, self.gather_fn, self.k_intra = search_fn, gather_fn, k_intra
+        self.search_async_fn = search_async_fn
         self.chunks = int(chunks) if world_size > 1 else 1
 
     def _gather(self, x):
         if self.gather_fn is not None:
             return self.gather_fn(x, self.world), _Done()
         return all_gather_rows_async(x, self.world)
+
+    def _search_async(self, q, k):
+        if self.search_async_fn is not None:
+            return self.search_async_fn(q, k)
+        return _SyncPending(self.search_fn(q, k))
+
+    def _split(self, rows, sims, cnt, m):
+        """[world*m, k] robot-major results -> (intra, inter) as `step` documents."""
+        k = rows.shape[1]
+        rows, sims, cnt = rows.view(self.world, m, k), sims.view(self.world, m, k), cnt.view(self.world, m)
+        intra = (rows[self.rank], sims[self.rank], cnt[self.rank])
+        keep = [g for g in range(self.world) if g != self.rank]
+        robot = torch.tensor(keep, device=rows.device).repeat_interleave(m)
+        inter = (rows[keep].reshape(-1, k)[:, :1], sims[keep].reshape(-1, k)[:, :1],
+                 cnt[keep].reshape(-1).clamp(max=1), robot)
+        return intra, inter
+
+    def step_begin(self, local_desc):
+        """`step` in two halves: the all-gather and ONE search over every robot's descriptors are enqueued here (no host
+        wait: the bank takes one search at a time, so the step is one piece and the gather is not hidden under a previous
+        piece's search -- 17 MB per rank against the extraction the caller enqueues next); `finish()` of the returned
+        PendingStep waits for the search's certificate count only (cslam_bank_search_finish) and returns `step`'s result.
+        Results stay with the bank owner: no second collective, so nothing provisional ever leaves the rank."""
+        m = local_desc.shape[0]
+        if self.world == 1:
+            pend = self._search_async(local_desc, self.k_intra)
+            return PendingStep(lambda: (pend.finish(), None))
+        if m == 0:
+            empty = self.step(local_desc)
+            return PendingStep(lambda: empty)
+        allq, handle = self._gather(local_desc)
+        handle.wait()
+        pend = self._search_async(allq, self.k_intra)
+        return PendingStep(lambda: self._split(*pend.finish(), m))
 
     def step(self, local_desc):
         """local_desc [m, d]: this robot's new descriptors.  Returns
@@ -162,7 +227,7 @@ class RowShardedBankMatcher(object):
     `search_fn`, `gather_fn`, `exchange_fn`, `merge_fn` are injectable (CPU control-flow tests with gloo)."""
 
     def __init__(self, rank, world_size, search_fn, row_offsets, k=5, gather_fn=None, exchange_fn=None,
-                 merge_fn=merge_topk_device, chunks=2):
+                 merge_fn=merge_topk_device, chunks=2, search_async_fn=None):
         """chunks: pieces per step.  The all-gather of piece t+1 and the all-to-all of piece t-1's lists are in
         flight while piece t is scored; both collectives of a piece are issued in the same order on every rank.
         gather_fn / exchange_fn: injected synchronous collectives (tests, host-staged debug runs); None = RCCL,
@@ -171,6 +236,7 @@ class RowShardedBankMatcher(object):
         self.rank, self.world, self.k = rank, world_size, int(k)
         self.row_offsets = [int(o) for o in row_offsets[:world_size]]
         self.search_fn, self.gather_fn, self.exchange_fn, self.merge_fn = search_fn, gather_fn, exchange_fn, merge_fn
+        self.search_async_fn = search_async_fn
         self.chunks = int(chunks) if world_size > 1 else 1
 
     def _gather(self, x):
@@ -182,6 +248,67 @@ class RowShardedBankMatcher(object):
         if self.exchange_fn is not None:
             return self.exchange_fn(packed, self.world), _Done()
         return exchange_lists_async(packed, self.world)
+
+    def _search_async(self, q, k):
+        if self.search_async_fn is not None:
+            return self.search_async_fn(q, k)
+        return _SyncPending(self.search_fn(q, k))
+
+    @staticmethod
+    def _pack(rows, sims, cnt):
+        """one int64 buffer per query: k rows | k score bit patterns | count"""
+        return torch.cat((rows, sims.contiguous().view(torch.int64), cnt.to(torch.int64)[:, None]), dim=1)
+
+    def step_begin(self, local_desc):
+        """`step` in two halves (ONE piece: the bank takes one search at a time).  Enqueued here, without a host wait:
+        all-gather, the shard's search, the all-to-all of its lists, the merge.  The lists are PROVISIONAL for queries the
+        candidate stage's certificate could not settle (normally none); the shard's count of them travels with the lists as
+        one extra row, so after the all-to-all every rank holds every shard's count -- in stream order, and the same numbers
+        on every rank.  `finish()`: one event wait for those counts (behind the merge), the banks' own `finish`; only if some
+        shard's count is not zero, ALL ranks redo exchange and merge with the re-scanned lists (a collective every rank
+        enters, because every rank saw the same counts)."""
+        m, k, G = local_desc.shape[0], self.k, self.world
+        if G == 1:
+            pend = self._search_async(local_desc, k)
+
+            def fin1():
+                rows, sims, cnt = pend.finish()
+                return self.merge_fn(rows[None], sims[None], cnt[None], self.row_offsets) if self.row_offsets[0] else \
+                    (rows, sims, cnt)
+            return PendingStep(fin1)
+        if m == 0:
+            empty = self.step(local_desc)
+            return PendingStep(lambda: empty)
+        dev = local_desc.device
+        allq, handle = self._gather(local_desc)
+        handle.wait()
+        pend = self._search_async(allq, k)
+        flag = torch.zeros((1,), dtype=torch.int32, device=dev)
+        pend.uncertified_to(flag)
+        w = 2 * k + 1
+        packed = torch.empty((G, m + 1, w), dtype=torch.int64, device=dev)
+        packed[:, :m] = self._pack(*pend.out).view(G, m, w)
+        packed[:, m] = flag.to(torch.int64)                              # the same count to every destination rank
+        got, h2 = self._exchange(packed)
+        merged = self._merge_piece(got[:, :m], h2)
+        owed = got[:, m, 0].max().reshape(1)                             # some shard still owes a re-scan?
+        host = torch.empty((1,), dtype=torch.int64, pin_memory=True) if dev.type == "cuda" else torch.empty((1,), dtype=torch.int64)
+        host.copy_(owed, non_blocking=True)
+        ev = None
+        if dev.type == "cuda":
+            ev = torch.cuda.Event()
+            ev.record()
+
+        def fin():
+            if ev is not None:
+                ev.synchronize()
+            rows, sims, cnt = pend.finish()                              # unlocks the bank; re-scans what it flagged
+            if int(host.item()) == 0:
+                return merged
+            packed2 = self._pack(rows, sims, cnt).view(G, m, w)
+            got2, h3 = self._exchange(packed2.contiguous())
+            return self._merge_piece(got2, h3)
+        return PendingStep(fin)
 
     def _merge_piece(self, got, handle):
         handle.wait()
@@ -211,8 +338,7 @@ class RowShardedBankMatcher(object):
             rows, sims, cnt = self.search_fn(allq, k)                    # shard-local rows, [G*(b-a), k]
             if lists is not None:                                        # previous piece's lists arrived meanwhile
                 out.append(self._merge_piece(*lists))
-            # one int64 buffer per query: k rows | k score bit patterns | count  -> ONE collective per piece
-            packed = torch.cat((rows, sims.contiguous().view(torch.int64), cnt.to(torch.int64)[:, None]), dim=1)
+            packed = self._pack(rows, sims, cnt)                         # ONE collective per piece
             lists = self._exchange(packed.view(G, b - a, 2 * k + 1))     # -> [G shards, own queries of the piece, 2k+1]
         out.append(self._merge_piece(*lists))
         if len(out) == 1:

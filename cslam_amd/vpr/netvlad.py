@@ -163,7 +163,7 @@ class NetVLAD(object):
         mean = np.asarray(mean, dtype=np.float32)
         self.pca_components = heads.padded_rows(comp.shape[0], comp.shape[1], self.device)
         self.pca_components.copy_(torch.from_numpy(comp))
-        self.pca_pairs = heads.pca_pair_weights(self.pca_components) if os.environ.get("CSLAM_PCA_PAIRS", "1") != "0" else None
+        self.pca_pairs = heads.pca_pair_weights(self.pca_components)
         self.pca_mean_proj = torch.from_numpy((mean.reshape(1, -1) @ comp.T).reshape(-1).astype(np.float32)).to(self.device)
         self.pca_inv_scale = None
         if whiten:
@@ -196,7 +196,7 @@ class NetVLAD(object):
         comp = torch.randn((pca_dim, din), generator=g, dtype=torch.float32) / din ** 0.5
         self.pca_components = heads.padded_rows(pca_dim, din, self.device)
         self.pca_components.copy_(comp)
-        self.pca_pairs = heads.pca_pair_weights(self.pca_components) if os.environ.get("CSLAM_PCA_PAIRS", "1") != "0" else None
+        self.pca_pairs = heads.pca_pair_weights(self.pca_components)
         self.pca_mean_proj = torch.zeros(pca_dim, dtype=torch.float32, device=self.device)
         self.pca_inv_scale = None
 

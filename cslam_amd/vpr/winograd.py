@@ -331,22 +331,17 @@ class _FoldedConv(object):
     def __init__(self, conv, bn, tile, min_in_channels):
         self.weight, self.bias = fold_bn(conv, bn)
         self.stride, self.padding = conv.stride, conv.padding
-        self.U = self.U4 = self.Up = None
+        self.U = self.U4 = None
         if (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
                 and conv.groups == 1 and conv.in_channels >= min_in_channels and conv.in_channels % 4 == 0
                 and conv.out_channels % 4 == 0 and conv.weight.is_cuda):
             self.U = wino_weights(self.weight).to(self.weight.device)
             self.U4 = wino_weights(self.weight, 4).to(self.weight.device) if tile == 4 else None
-            # layer1 of ResNet-18/34 CAN run through the one-kernel form (csrc/wino_fused.hip, shortcut fused), but on
-            # its 56 x 56 maps V and M of a 250-frame chunk (0.45 GB each) largely stay in the 256 MB Infinity Cache and
-            # the F(4x4) pipeline wins: 31.8k vs 30.9k frames/s (profiles/r01_perf_c2.log) -- opt-in only
-            if (conv.in_channels == 64 and conv.out_channels in (64, 128)
-                    and os.environ.get("CSLAM_WINO_FUSED_RESNET", "0") == "1"):
-                self.Up = fused64_weights(self.U)
+            # (layer1 of ResNet-18/34 can run through the one-kernel form of csrc/wino_fused.hip, shortcut fused, but on its
+            # 56 x 56 maps V and M of a 250-frame chunk -- 0.45 GB each -- largely stay in the 256 MB Infinity Cache and the
+            # F(4x4) pipeline wins: 31.8k vs 30.9k frames/s, profiles/r01_perf_c2.log.  Not wired in.)
 
     def __call__(self, ws, x, relu, residual=None):
-        if self.Up is not None:
-            return wino_fused64(x.contiguous(memory_format=torch.channels_last), self.Up, self.bias, relu, False, residual)
         if self.U is not None:
             return wino_conv3x3(ws, x.contiguous(memory_format=torch.channels_last), self.U, self.U4, self.bias, relu,
                                 False, residual)
@@ -419,8 +414,8 @@ class WinogradTrunk(_Workspace):
         self.min_in_channels = int(min_in_channels)
         self.tile = int(tile)
         self.fused64 = (os.environ.get("CSLAM_WINO_FUSED64", "1") != "0") if fused64 is None else bool(fused64)
-        self.fused_min_blocks = int(os.environ.get("CSLAM_WINO_FUSED_MIN_BLOCKS", "256"))
-        self.fused_couts = tuple(int(c) for c in os.environ.get("CSLAM_WINO_FUSED_COUTS", "64,128").split(","))
+        self.fused_min_blocks = 256                  # fewer tile blocks than this (single frames): the three-kernel form
+        self.fused_couts = (64, 128)
         # split-fp16 GEMMs on the F(4x4) layers from this many input channels on (0 = off: plain fp32 library GEMMs).
         # Default: this library's pair GEMM (`split16_pair_weights`, csrc/wino_gemm.hip) from 128 channels on -- V is no
         # larger than its fp32 form, so every layer the three-kernel form runs gains.  CSLAM_WINO_H3=1 selects round 1's
@@ -454,8 +449,8 @@ class WinogradTrunk(_Workspace):
                     else:
                         st.U3 = split16_weights(st.U4)
                 if self.fused64 and m.in_channels == 64 and m.out_channels in self.fused_couts:
-                    # F(4x4) one-kernel form on the F(4x4) trunk (CSLAM_WINO_FUSED_TILE=2 keeps the F(2x2) one)
-                    t4 = self.tile == 4 and os.environ.get("CSLAM_WINO_FUSED_TILE", "4") == "4"
+                    # F(4x4) one-kernel form on the F(4x4) trunk, the F(2x2) one on an F(2x2) trunk
+                    t4 = self.tile == 4
                     st.Up = fused64_weights(st.U4 if t4 else st.U)
                     # the fp16-pair form of the one-kernel convolution (csrc/wino_fused_h.hip); CSLAM_WINO_FUSED_H=0 keeps
                     # the f32-MFMA kernel

@@ -105,7 +105,7 @@ int cslam_bank_search_dev(cslam_bank_t *bank, const void *d_queries, int q_dtype
  * (lcsm.py:45-53 best-1 per other robot, lcsm.py:74-76 top-k in the local bank).  Same results as nb calls of
  * cslam_bank_search_dev with (k[i], d_row_limit[i], d_out_*[i]); all kernels are enqueued before the single host
  * synchronisation the uncertified-query counts need, each bank's on a stream of its own forked from and joined back into
- * `stream` (chunk-sized searches do not fill the chip one after the other; CSLAM_MULTI_STREAMS=0 keeps them on `stream`).
+ * `stream` (chunk-sized searches do not fill the chip one after the other).
  * d_row_limit may be NULL (no limits) or hold NULL entries.  A bank may appear only once in the list. */
 int cslam_bank_search_multi_dev(cslam_bank_t *const *banks, int nb, const void *d_queries, int q_dtype, int64_t ldq,
                                 int64_t nq, const int *k, const int64_t *const *d_row_limit, int mode,
@@ -125,6 +125,11 @@ int cslam_bank_search_enqueue_dev(cslam_bank_t *bank, const void *d_queries, int
                                   const int64_t *d_row_limit, int mode, int64_t *d_out_idx, double *d_out_sim,
                                   int32_t *d_out_cnt, void *stream);
 int cslam_bank_search_finish(cslam_bank_t *bank, int64_t *n_uncertified);
+/* Between the halves: the uncertified-query count of the enqueued search as a 4-byte device-to-device copy on `stream` (the
+ * enqueue's stream) into d_count; 0 when the search needs no certificate (exact-scan modes) or none is pending.  Lets a sharded
+ * step (one robot bank, or one row shard, per GPU: loop_closure_sparse_matching.py:45-53 across ranks) ship the count WITH its
+ * provisional lists, so that every rank knows in stream order -- no host round trip -- whether a shard still owes a re-scan. */
+int cslam_bank_search_flag_copy_dev(cslam_bank_t *bank, int32_t *d_count, void *stream);
 int cslam_bank_search_multi_enqueue_dev(cslam_bank_t *const *banks, int nb, const void *d_queries, int q_dtype, int64_t ldq,
                                         int64_t nq, const int *k, const int64_t *const *d_row_limit, int mode,
                                         int64_t *const *d_out_idx, double *const *d_out_sim, int32_t *const *d_out_cnt,

@@ -1,5 +1,6 @@
 """GPU parity at the sizes BASELINE.json's configs name (-m gpu) -- not reduced stand-ins:
 
+  (banks and queries are BASELINE.md section 3's numpy recipe, cslam_amd/synthetic.py)
   C3  the full 100k-query x 100k-row x 4096-D launch the roofline is quoted on: 512 sampled queries against the CPU oracle
       (indices identical, float64 scores within 1e-12), no query left to the exact-scan fallback;
   C4  8 robots x 50 000 x 4096 banks, every robot's 50 000 keyframes scored against every OTHER robot's bank (best-1 per
@@ -31,14 +32,13 @@ def _oracle_parallel(bank, queries, k, threads=16):
 def test_c3_full_batch_100k_queries_against_100k_rows():
     import torch
     from cslam_amd import nns_matching as nnm
+    from cslam_amd import synthetic
     n = nq = 100_000
     d, k = 4096, 5
-    gen = torch.Generator(device="cuda").manual_seed(1234)
-    bank = torch.randn((n, d), generator=gen, device="cuda")
-    bank /= bank.norm(dim=1, keepdim=True)
-    qgen = torch.Generator(device="cuda").manual_seed(4321)
-    q = torch.randn((nq, d), generator=qgen, device="cuda")
-    q /= q.norm(dim=1, keepdim=True)
+    with ThreadPoolExecutor(max_workers=2) as ex:                 # BASELINE.md section 3's inputs, bit for bit
+        fb, fq = ex.submit(synthetic.bank, 0, n, d), ex.submit(synthetic.queries, 0, nq, d)
+        hb, hq_all = fb.result(), fq.result()
+    bank, q = torch.from_numpy(hb).cuda(), torch.from_numpy(hq_all).cuda()
     nn = nnm.NearestNeighborsMatching()
     nn.add_items_device(bank)
     rows, sims, cnt = nn.search_device(q, k, mode=nnm.MODE_MFMA)
@@ -47,8 +47,7 @@ def test_c3_full_batch_100k_queries_against_100k_rows():
     assert st[1] == nnm.MODE_MFMA and st[0] == 0, "uncertified queries on the C3 batch: %s" % (st,)
     assert int(cnt.min()) == k and bool(torch.all(sims[:, :-1] >= sims[:, 1:]))
     sel = np.random.default_rng(5).choice(nq, size=512, replace=False)
-    hb = bank.cpu().numpy()
-    hq = q[torch.from_numpy(sel).cuda()].cpu().numpy()
+    hq = hq_all[sel]
     t0 = time.perf_counter()
     oi, os_, oc = _oracle_parallel(hb, hq, k)
     print("C3: oracle on 512 sampled queries: %.1f s" % (time.perf_counter() - t0))
@@ -59,12 +58,13 @@ def test_c3_full_batch_100k_queries_against_100k_rows():
 def test_c4_eight_banks_of_50k_every_keyframe_against_every_other_bank():
     import torch
     from cslam_amd import nns_matching as nnm
+    from cslam_amd import synthetic
     R, N, D = 8, 50_000, 4096
     banks, nns = [], []
+    with ThreadPoolExecutor(max_workers=R) as ex:                 # robot r's bank = default_rng(1234 + r)
+        host_banks = list(ex.map(lambda r: synthetic.bank(r, N, D), range(R)))
     for r in range(R):
-        gen = torch.Generator(device="cuda").manual_seed(1234 + r)
-        b = torch.randn((N, D), generator=gen, device="cuda")
-        b /= b.norm(dim=1, keepdim=True)
+        b = torch.from_numpy(host_banks[r]).cuda()
         nn = nnm.NearestNeighborsMatching()
         nn.add_items_device(b)
         banks.append(b); nns.append(nn)
@@ -85,11 +85,8 @@ def test_c4_eight_banks_of_50k_every_keyframe_against_every_other_bank():
     torch.cuda.synchronize()
     print("C4: 56 searches of 50k x 50k x 4096: %.1f s" % (time.perf_counter() - t0))
     assert sum(len(c[2]) for c in checks) >= 200
-    host = {}
+    host = host_banks
     for r, o, sel, got_rows, got_sims in checks:
-        for x in (r, o):
-            if x not in host:
-                host[x] = banks[x].cpu().numpy()
         oi, os_, _ = _oracle_parallel(host[o], host[r][sel], 1, threads=8)
         assert np.array_equal(got_rows, oi[:, 0]), (r, o)
         assert np.max(np.abs(got_sims - os_[:, 0])) < 1e-12

@@ -133,6 +133,88 @@ def test_gloo_row_sharded_bank(tmp_path, shard_rows, chunks):
         assert np.array_equal(got["rows"], i) and np.array_equal(got["sims"], s) and np.array_equal(got["cnt"], c)
 
 
+class _FakePending(object):
+    """A pending search as NearestNeighborsMatching.search_device_async hands out: `.out` is valid in stream order but
+    PROVISIONAL for `n_bad` queries (here: deliberately wrong rows and scores) until `.finish()` has re-done them."""
+
+    def __init__(self, exact, n_bad):
+        self._exact, self.n_bad, self.finished = exact, n_bad, False
+        rows, sims, cnt = (t.clone() for t in exact)
+        rows[:n_bad] = 0
+        sims[:n_bad] = 0.999                   # would win every merge if it were believed
+        self.out = (rows, sims, cnt)
+
+    def uncertified_to(self, count):
+        count.fill_(self.n_bad)
+
+    def finish(self):
+        self.finished = True
+        return self._exact
+
+
+def _row_worker_async(rank, world, port, outdir, shard_rows, bad_rank):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cslam_amd.sharded import RowShardedBankMatcher, ShardedInterRobotMatcher
+    from oracle import pyoracle
+    from helpers import unit_rows
+    offs = np.concatenate(([0], np.cumsum(shard_rows)))
+    whole = unit_rows(np.random.default_rng(99), int(offs[-1]), 64)
+    shard = whole[offs[rank]:offs[rank + 1]]
+    pends = []
+
+    def search_async(q, k):
+        i, s, c = pyoracle.nns_search(shard, q.numpy(), k)
+        pends.append(_FakePending((torch.from_numpy(i), torch.from_numpy(s), torch.from_numpy(c)), 7 if rank == bad_rank else 0))
+        return pends[-1]
+
+    merge = lambda r, s, c, o: _host_merge(r.numpy(), s.numpy(), c.numpy(), o)      # noqa: E731
+    m = RowShardedBankMatcher(rank, world, None, offs[:world], k=5, merge_fn=merge, search_async_fn=search_async)
+    local = [torch.from_numpy(unit_rows(np.random.default_rng(4321 + 10 * t + rank), 40, 64)) for t in range(2)]
+    h0 = m.step_begin(local[0])
+    h1 = m.step_begin(local[1])                 # the next step is enqueued before the first is finished
+    out = [h0.finish(), h1.finish()]
+    assert all(p.finished for p in pends)
+    # one robot bank per rank through the same two halves
+    r = ShardedInterRobotMatcher(rank, world, None, k_intra=5, search_async_fn=search_async)
+    intra, inter = r.step_begin(local[0]).finish()
+    np.savez(os.path.join(outdir, f"a{rank}.npz"), rows0=out[0][0].numpy(), sims0=out[0][1].numpy(), cnt0=out[0][2].numpy(),
+             rows1=out[1][0].numpy(), sims1=out[1][1].numpy(), intra_rows=intra[0].numpy(), inter_rows=inter[0].numpy(),
+             inter_sims=inter[1].numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shard_rows,bad_rank", [((300, 300), -1), ((150, 150, 200, 100), 2)])
+def test_gloo_sharded_steps_in_two_halves(tmp_path, shard_rows, bad_rank):
+    """`step_begin` / `finish` of both matchers (what bench.py's N > 1 step runs on): two steps enqueued back to back, finished
+    afterwards, equal to the oracle on the unsharded bank.  With `bad_rank` one shard's lists are PROVISIONAL for 7 queries
+    (wrong rows, winning scores) until its search is finished: its count travels with the lists, every rank sees it and all
+    of them redo exchange and merge with the re-scanned lists -- nothing provisional survives."""
+    from helpers import unit_rows
+    from oracle import pyoracle
+    world, port = len(shard_rows), 31500 + (os.getpid() % 1000) + 13 * len(shard_rows) + bad_rank
+    mp.spawn(_row_worker_async, args=(world, port, str(tmp_path), shard_rows, bad_rank), nprocs=world, join=True)
+    offs = np.concatenate(([0], np.cumsum(shard_rows)))
+    whole = unit_rows(np.random.default_rng(99), sum(shard_rows), 64)
+    for r in range(world):
+        got = np.load(tmp_path / f"a{r}.npz")
+        for t in range(2):
+            q = unit_rows(np.random.default_rng(4321 + 10 * t + r), 40, 64)
+            i, s, c = pyoracle.nns_search(whole, q, 5)
+            assert np.array_equal(got[f"rows{t}"], i) and np.array_equal(got[f"sims{t}"], s)
+        assert np.array_equal(got["cnt0"], c * 0 + 5)
+        shard = whole[offs[r]:offs[r + 1]]
+        q = unit_rows(np.random.default_rng(4321 + r), 40, 64)
+        assert np.array_equal(got["intra_rows"], pyoracle.nns_search(shard, q, 5)[0])
+        oq = np.concatenate([unit_rows(np.random.default_rng(4321 + o), 40, 64) for o in range(world) if o != r])
+        i, s, _ = pyoracle.nns_search(shard, oq, 1)
+        assert np.array_equal(got["inter_rows"], i) and np.array_equal(got["inter_sims"], s)
+
+
 def test_host_merge_stand_in_order():
     rows = np.array([[[2, 0, -1]], [[1, 0, -1]]])                      # shard 0: rows 2,0 ; shard 1: rows 1,0
     sims = np.array([[[0.5, 0.25, np.nan]], [[np.nan, 0.5, np.nan]]])   # shard 1 starts with a NaN score
