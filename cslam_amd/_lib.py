@@ -112,6 +112,7 @@ _SIGNATURES = {
     "cslam_wino4_fused_c64_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "cslam_scancontext_from_cloud_dev": (_i, [_vp, _vp, _i, _i, _i, C.c_double, _vp, _vp, _vp]),
     "cslam_wino4_fused_c64_h_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, C.c_float, _vp, _vp, _vp]),
+    "cslam_conv3x3_direct_h_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _f, _vp, _vp, _vp]),
     "cslam_wino4_stem_c64_h_dev": (_i, [_vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _i, _i, _i, _i, _vp, C.c_float, _vp, _vp, _vp]),
     "cslam_debug_wfh_prof_dev": (_i, [_vp]),
     "cslam_conv3x3_c3_amax_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
@@ -126,7 +127,7 @@ _SIGNATURES = {
     "cslam_allgather_queries_dev": (_i, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "cslam_exchange_lists_dev": (_i, [_vp, _vp, _vp, _i64, _vp]),
     "cslam_peak_copy_dev": (_i, [_vp, _vp, _i64, _i, _vp]),
-    "cslam_peak_mfma_dev": (_i, [_i, _i, _i, _vp, C.POINTER(C.c_double), _vp]),
+    "cslam_peak_mfma_dev": (_i, [_i, _i, _i, _i, _vp, C.POINTER(C.c_double), _vp]),
     "cslam_debug_last_candidates": (_i, [_vp, _i64, C.POINTER(_i), _vp, _vp, C.POINTER(C.c_double)]),
     "cslam_trunk_timing": (_i, [_i]),
     "cslam_trunk_timing_read": (_i, [C.POINTER(C.c_double * 8)]),

@@ -65,6 +65,31 @@ def split16_pair_weights(U4):
     return pair.contiguous(), 1.0 / su
 
 
+def direct_pair_weights(weight):
+    """conv weight [Cout, Cin, 3, 3] float32 -> (W2 [9, Cout, Cin/32, 2, 32] float16, inv_sw): the weight operand of the direct
+    one-kernel convolution (csrc/conv_direct_h.hip): tap ky * 3 + kx major, rows = output channels, every 32-channel block of a row
+    its hi halves then its lo halves (`split16_pair_weights` with the 9 taps in the place of the 36 Winograd frequencies)."""
+    cout, cin = weight.shape[:2]
+    return split16_pair_weights(weight.detach().to(torch.float32).permute(2, 3, 1, 0).reshape(9, cin, cout))
+
+
+def conv3x3_direct_h(x, Wd, bias, relu, pool, amax_in, amax_out=None):
+    """y = [pool](relu(conv3x3(x) + bias)) through `cslam_conv3x3_direct_h_dev` (csrc/conv_direct_h.hip): x [B,Cin,H,W]
+    channels_last float32 (Cin a multiple of 32), 128 output channels; Wd = `direct_pair_weights(weight)`; amax_in = 4-byte device
+    slot with (a bound of) max |x|; amax_out (optional): zeroed slot that receives max |y|."""
+    lib = _lib.load()
+    x = x.contiguous(memory_format=torch.channels_last)
+    B, Cin, H, W = x.shape
+    W2, inv_sw = Wd
+    Cout = W2.shape[1]
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    y = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    _lib.check(lib.cslam_conv3x3_direct_h_dev(_p(x), _p(W2), _p(bias) if bias is not None else None, B, H, W, Cin, Cout,
+                                              int(relu), int(pool), _p(amax_in), float(inv_sw),
+                                              _p(amax_out) if amax_out is not None else None, _p(y), _stream(x)))
+    return y
+
+
 def fused64_weights(U):
     """U [16 | 36, 64, Cout] (`wino_weights(w, 2 | 4)`; Cout 64 or 128) -> the operand order of
     `cslam_wino2_fused_c64_dev` / `cslam_wino4_fused_c64_dev`: Up[kq][xi][w][g][c][s] = U[xi][16 kq + 4 g + s][16 w + c]
@@ -394,11 +419,12 @@ class WinogradResNet(_Workspace):
 
 
 class _Step(object):
-    __slots__ = ("kind", "module", "conv", "relu", "pool", "U", "U4", "U3", "U2", "Up", "Uph", "bias", "stem")
+    __slots__ = ("kind", "module", "conv", "relu", "pool", "U", "U4", "U3", "U2", "Up", "Uph", "bias", "stem", "Wd")
 
     def __init__(self):
         self.kind, self.module, self.conv, self.relu, self.pool = "torch", None, None, False, False
         self.U, self.U4, self.U3, self.U2, self.Up, self.Uph, self.bias, self.stem = None, None, None, None, None, None, None, None
+        self.Wd = None
 
 
 class WinogradTrunk(_Workspace):
@@ -423,6 +449,9 @@ class WinogradTrunk(_Workspace):
         # a known bound of max |input| (e.g. a normalised 8-bit image: heads.normalised_image_bound()) spares the stem kernel
         # its pass over the input; None = measured per call
         self.input_bound = None
+        # CSLAM_CONV_DIRECT=0: conv2_1 / conv2_2 through the F(4x4) forms of round 3 (the A/B partner)
+        self.direct128 = os.environ.get("CSLAM_CONV_DIRECT", "1") != "0"
+        self.direct_cins = (128,)                    # input widths that take the direct kernel (tests set (64, 128))
         self.split16_h3 = os.environ.get("CSLAM_WINO_H3", "0") == "1"
         self.split16_min_cin = int(os.environ.get("CSLAM_WINO_SPLIT16", "256" if self.split16_h3 else "128"))
         use_tuned_gemms()
@@ -456,6 +485,13 @@ class WinogradTrunk(_Workspace):
                     # the f32-MFMA kernel
                     if t4 and os.environ.get("CSLAM_WINO_FUSED_H", "1") != "0":
                         st.Uph = fused64_pair_weights(st.U4)
+                if (self.direct128 and self.tile == 4 and m.out_channels == 128 and m.in_channels in self.direct_cins):
+                    # VGG-16 conv2_2 (128 -> 128 on 112 x 112 maps, + MaxPool2d): the direct one-kernel form on fp16 pairs
+                    # (csrc/conv_direct_h.hip) -- HBM sees the activation in and out, nothing else; the F(4x4) pipeline moved 10 x
+                    # the activation there (17 of the pass's 63 GB) and was bound by it: 2.6-2.7 ms against 2.8, -14 GB.  conv2_1
+                    # (64 -> 128) stays on the one-kernel F(4x4) form: 1.47 ms against the direct kernel's 1.62 (a quarter of the
+                    # multiplications; measured, profiles/r04_v9_direct_conv.log)
+                    st.Wd = direct_pair_weights(m.weight)
                 st.bias = None if m.bias is None else m.bias.detach().to(torch.float32).contiguous()
                 i += 1
                 if i < len(mods) and isinstance(mods[i], nn.ReLU):
@@ -510,7 +546,7 @@ class WinogradTrunk(_Workspace):
         # step k|, written by the step before it when that step can (first-layer kernel, fused fp16 kernel, F(4x4) output
         # transform); otherwise the consumer makes its own pass over x
         slots = amax_ready = None
-        wants = lambda st_: st_ is not None and (st_.U3 is not None or st_.U2 is not None or st_.Uph is not None)   # noqa: E731
+        wants = lambda st_: st_ is not None and (st_.U3 is not None or st_.U2 is not None or st_.Uph is not None or st_.Wd is not None)   # noqa: E731
         if any(wants(st) for st in self.steps):
             slots = self._buf("amax_slots", len(self.steps) + 1, x.device)
             slots.zero_()
@@ -564,6 +600,15 @@ class WinogradTrunk(_Workspace):
                 x = y if not (st.pool and not pool) else torch.nn.functional.max_pool2d(y, 2, 2)
                 continue
             x = x.contiguous(memory_format=torch.channels_last)
+            if (st.Wd is not None and not (st.pool and (x.shape[2] % 2 or x.shape[3] % 2))
+                    and x.shape[0] * -(-x.shape[2] // 16) * -(-x.shape[3] // 16) >= self.fused_min_blocks and x.numel() % 4 == 0):
+                slot = slots[k:k + 1]
+                if not have:
+                    _lib.check(lib.cslam_absmax_dev(_p(x), x.numel(), _p(slot), _stream(x)))
+                want = slots[k + 1:k + 2] if wants(nxt) else None
+                x = conv3x3_direct_h(x, st.Wd, st.bias, st.relu, st.pool, slot, want)
+                amax_ready = want is not None
+                continue
             if st.Up is not None and not (st.pool and (x.shape[2] % 2 or x.shape[3] % 2)):
                 # one persistent workgroup per compute unit: worth it from one tile block per CU on (a single 224 x 224
                 # frame has 196: VGG-16 at B = 1 502 us through it, 459 us through the three-kernel form)

@@ -423,6 +423,15 @@ int cslam_wino4_output_z_dev(const float *d_Z, const float *d_bias, int B, int H
 int cslam_wino4_fused_c64_h_dev(const float *d_x, const void *d_Uh, const float *d_bias, const float *d_residual, int B,
                                 int H, int W, int Cout, int relu, int pool, const unsigned *d_amax, float inv_su,
                                 unsigned *d_amax_out, float *d_y, void *stream);
+/* The direct (non-Winograd) one-kernel form of the same convolution for 128 output channels (csrc/conv_direct_h.hip; VGG-16
+ * conv2_1, conv2_2 of cslam/vpr/netvlad.py:163-171,227): an implicit GEMM over the 9 taps on exact fp16 pairs (three products,
+ * fp32 accumulate: fp32-grade), the 18 x 18 input patch of a 16 x 16-pixel block read once into LDS, the output written once --
+ * HBM sees activation in + out only.  x [B][H][W][Cin] float32 (Cin a multiple of 32), y [B][H | H/2][W | W/2][128];
+ * d_w2 = [9 taps][128][Cin/32][hi 32 | lo 32] halfs of s_w w (cslam_amd/vpr/winograd.py `direct_pair_weights`), inv_sw = 1 / s_w;
+ * d_amax: 4-byte slot with (a bound of) max |x|; d_amax_out (or NULL): zeroed slot receiving max |y|. */
+int cslam_conv3x3_direct_h_dev(const float *d_x, const void *d_w2, const float *d_bias, int B, int H, int W, int Cin, int Cout,
+                               int relu, int pool, const unsigned *d_amax, float inv_sw, unsigned *d_amax_out, float *d_y,
+                               void *stream);
 /* cslam_conv3x3_c3_dev that also delivers max |y| (float bits, into the zeroed 4-byte slot d_amax_out; NULL = off):
  * the first trunk layer feeds the scale of the fused fp16 layer behind it without a separate pass over its output. */
 int cslam_conv3x3_c3_amax_dev(const float *d_x, const float *d_wt, const float *d_bias, int B, int H, int W, int Cout,

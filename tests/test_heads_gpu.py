@@ -556,6 +556,71 @@ def test_fused_winograd_f4_equals_float64(T, form, cout, B, H, W, relu, pool, bi
     assert ef <= 2e-5 and rf <= 5e-6, (ef, rf)
 
 
+@pytest.mark.parametrize("cin", [64, 128])
+@pytest.mark.parametrize("B,H,W,relu,pool,bias,amp", [(2, 112, 112, True, True, True, 1.0), (3, 37, 50, True, False, True, 1e3),
+                                                      (300, 16, 16, False, False, False, 1.0), (1, 8, 90, True, True, False, 1e-3),
+                                                      (5, 20, 34, False, True, True, 1.0)])
+def test_direct_conv_on_fp16_pairs_equals_float64(T, cin, B, H, W, relu, pool, bias, amp):
+    """The direct one-kernel convolution of the 128-output-channel layers (csrc/conv_direct_h.hip: VGG-16 conv2_1, conv2_2) against
+    a float64 conv2d (+ ReLU + MaxPool2d): fp32-grade -- no Winograd transform in it, so the bar is that of an fp32 convolution,
+    3 x tighter than the F(4x4) forms' -- on ragged 16 x 16 blocks, block counts below and above the compute-unit count,
+    activations six decades apart (power-of-two scale from the max |x| slot), with the max |y| it leaves for the next layer."""
+    torch, _ = T
+    from cslam_amd import _lib
+    from cslam_amd.vpr import winograd as wg
+    lib = _lib.load()
+    torch.manual_seed(101 + cin)
+    x = (torch.randn(B, cin, H, W, device="cuda") * amp).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(128, cin, 3, 3, device="cuda") / (3.0 * cin ** 0.5)
+    b = torch.randn(128, device="cuda") * amp if bias else None
+    Wd = wg.direct_pair_weights(w)
+    assert tuple(Wd[0].shape) == (9, 128, cin // 32, 2, 32) and Wd[0].dtype == torch.float16
+    slot = torch.zeros(1, dtype=torch.float32, device="cuda")
+    _lib.check(lib.cslam_absmax_dev(x.data_ptr(), x.numel(), slot.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    out_slot = torch.zeros(1, dtype=torch.float32, device="cuda")
+    y = wg.conv3x3_direct_h(x, Wd, b, relu, pool, slot, out_slot)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), None if b is None else b.double(), padding=1)
+    if pool:
+        ref = torch.nn.functional.max_pool2d(ref, 2)             # max and ReLU commute
+    if relu:
+        ref = torch.relu(ref)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    ef = (y.double() - ref).abs().max().item() / ref.abs().max().item()
+    rf = float(((y.double() - ref) ** 2).sum().sqrt() / (ref ** 2).sum().sqrt())
+    assert ef <= 5e-6 and rf <= 2e-6, (ef, rf)
+    assert out_slot.item() == y.abs().max().item()
+
+
+def test_trunk_runs_conv2_1_and_conv2_2_through_the_direct_kernel_and_matches_the_winograd_forms(T, monkeypatch):
+    """VGG-16's first two blocks through the trunk runner: by default conv2_2 takes the direct kernel (here conv2_1 as well:
+    `direct_cins`); CSLAM_CONV_DIRECT=0 keeps round 3's F(4x4) forms.  Both against float64, and against each other at the F(4x4)
+    forms' tolerance."""
+    torch, _ = T
+    from torch import nn
+    from cslam_amd.vpr.winograd import WinogradTrunk
+    torch.manual_seed(7)
+    seq = nn.Sequential(nn.Conv2d(3, 64, 3, padding=1), nn.ReLU(), nn.Conv2d(64, 64, 3, padding=1), nn.ReLU(), nn.MaxPool2d(2, 2),
+                        nn.Conv2d(64, 128, 3, padding=1), nn.ReLU(), nn.Conv2d(128, 128, 3, padding=1), nn.ReLU(),
+                        nn.MaxPool2d(2, 2)).cuda().eval()
+    x = torch.randn((36, 3, 64, 80), device="cuda")
+    outs = {}
+    for tag, env in (("direct", "1"), ("wino", "0")):
+        monkeypatch.setenv("CSLAM_CONV_DIRECT", env)
+        t = WinogradTrunk(seq, 64, 4, fused64=True)
+        assert t.steps[2].Wd is None and (t.steps[3].Wd is not None) == (tag == "direct")       # the default: conv2_2 only
+        if tag == "direct":
+            t.direct_cins = (64, 128)
+            t.refresh()
+            assert t.steps[2].Wd is not None and t.steps[3].Wd is not None
+        outs[tag] = t(x)
+    with torch.no_grad():
+        ref = seq.double()(x.double())
+    seq.float()
+    for tag in outs:
+        assert _rel_rms(outs[tag], ref) <= 1e-5, tag
+    assert (outs["direct"] - outs["wino"]).abs().max().item() <= 2e-5 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("cout,B,H,W,pool,amp", [(64, 4, 64, 48, True, 1.0), (128, 3, 40, 56, False, 1e3), (64, 2, 30, 22, False, 1e-3)])
 def test_fused_winograd_h_scales_shortcut_and_amax(T, cout, B, H, W, pool, amp):
     """cslam_wino4_fused_c64_h_dev called directly: activations six decades apart (the power-of-two scale from the max |x|

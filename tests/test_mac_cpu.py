@@ -239,7 +239,7 @@ def test_chain_reduced_solver_is_exact(R, P, m, overlap):
     import scipy.sparse as sp
     import scipy.sparse.linalg as spla
     from cslam_amd.mac.chain_solver import ChainReducedSolver, fiedler_tracemin_chain
-    from cslam_amd.mac.fiedler import fiedler_tracemin_lu
+    from oracle.fiedler_oracle import fiedler_tracemin_lu
     L = _random_pose_graph(R, P, m, R + P, overlap)
     n = L.shape[0]
     g = int((L.indptr[1:] - L.indptr[:-1]).argmax())
@@ -254,6 +254,20 @@ def test_chain_reduced_solver_is_exact(R, P, m, overlap):
     l2, v2 = fiedler_tracemin_chain(L)
     assert abs(l1 - l2) < 1e-12 * max(1.0, abs(l1)) + 1e-14
     assert min(np.max(np.abs(v1 - v2)), np.max(np.abs(v1 + v2))) < 1e-9
+
+
+def test_tracemin_restatement_and_product_solver_equal_the_reference_dependency():
+    """oracle/fiedler_oracle.py restates networkx's private TraceMIN (the function cslam/mac/mac.py:35-59 calls); the product's
+    'tracemin_lu' solver CALLS it.  Same start block, same iterates: lambda_2 and the Fiedler vector agree to round-off."""
+    pytest.importorskip("networkx")
+    from cslam_amd.mac.fiedler import fiedler_tracemin_lu as product
+    from oracle.fiedler_oracle import fiedler_tracemin_lu as restated
+    for R, P, m in ((3, 50, 12), (8, 400, 600)):
+        L = _random_pose_graph(R, P, m, R + P, False)
+        l1, v1 = product(L)
+        l2, v2 = restated(L)
+        assert abs(l1 - l2) <= 1e-13 * max(1.0, abs(l1))
+        assert min(np.max(np.abs(v1 - v2)), np.max(np.abs(v1 + v2))) < 1e-10
 
 
 def test_chain_solver_handles_missing_chain_edges_and_ragged_ids():

@@ -90,7 +90,7 @@ def test_chain_solver_gpu_matches_host(R, P, m):
 
 def test_fiedler_gpu_matches_reference_algorithm():
     from cslam_amd.mac.chain_solver_gpu import fiedler_tracemin_chain_gpu
-    from cslam_amd.mac.fiedler import fiedler_tracemin_lu
+    from oracle.fiedler_oracle import fiedler_tracemin_lu
     for (R, P, m) in [(3, 100, 30), (8, 400, 600), (8, 2000, 2000)]:
         L = _pose_graph(R, P, m, 7)
         l1, v1 = fiedler_tracemin_lu(L)
@@ -154,7 +154,7 @@ def test_one_call_c_abi_fiedler_matches_reference_algorithm(R, P, m):
     all behind ONE C call) against the sparse-LU restatement of the reference's networkx call (mac.py:35-59) and against
     the torch-driven device solver.  (4, 6000, 5200): > 4096 junctions, the blocked factorisation with 2048 blocks."""
     from cslam_amd.mac.chain_solver_gpu import fiedler_tracemin_chain_gpu, fiedler_tracemin_hip
-    from cslam_amd.mac.fiedler import fiedler_tracemin_lu
+    from oracle.fiedler_oracle import fiedler_tracemin_lu
     L = _pose_graph(R, P, m, 7)
     l1, v1 = fiedler_tracemin_lu(L)
     st = {}

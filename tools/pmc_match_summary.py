@@ -39,7 +39,10 @@ def med(g, key):
 
 def main():
     src, tag = sys.argv[1], sys.argv[2]
-    kern = "sim_topk_pair_kernel" if os.environ.get("CSLAM_MFMA_STAGE1", "pair")[0] != "f" else "sim_topk_mfma_kernel"
+    stage = os.environ.get("CSLAM_MFMA_STAGE1", "h1")
+    prod = 0 if stage[0] == "f" else (3 if stage[0] == "p" else 1)        # fp16 products per pair (0: the f32-input stage)
+    kern = "sim_topk_pair_kernel" if prod else "sim_topk_mfma_kernel"
+    bpv = {0: 4, 1: 2, 3: 4}[prod]                                        # bytes per value of the operand copies the stage reads
     fetch = per_dispatch(os.path.join(src, "fetch"), ("FETCH_SIZE",))
     write = per_dispatch(os.path.join(src, "write"), ("WRITE_SIZE",))
     tcc = per_dispatch(os.path.join(src, "tcc"), ("TCC_HIT_sum", "TCC_MISS_sum"))
@@ -51,7 +54,9 @@ def main():
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
         d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows]
         times = {100000: statistics.median(d[:REPS]) if len(d) >= REPS else None, 1024: statistics.median(d[REPS:2 * REPS]) if len(d) >= 2 * REPS else None}
-    out = {"kernel": kern, "tag": tag, "bank": "100000 x 4096 float32 (+ its fp16-pair copy)", "launches": {}}
+    out = {"kernel": kern, "tag": tag, "fp16_products": prod, "bank": "100000 x 4096 float32 (+ the candidate stage's copy, %d bytes per value)" % bpv,
+           "traffic_is": "L2-miss (fabric-side) bytes: FETCH_SIZE x 2 + WRITE_SIZE; Infinity-Cache hits are included (MI355X guide, HBM section)",
+           "launches": {}}
     path = os.path.join(ROOT, "profiles", "pmc_by_kernel.json")
     table = json.load(open(path)) if os.path.exists(path) else {}
     for gi, nq in enumerate((100000, 1024)):
@@ -62,8 +67,8 @@ def main():
         if fk is not None and wk is not None:
             e["FETCH_SIZE_KB"], e["WRITE_SIZE_KB"] = fk, wk
             e["traffic_bytes"] = fk * 1024 * 2 + wk * 1024
-        # algorithmic minimum: the bank's pair copy once + the queries' pair copy once + the candidate lists out
-        e["algorithmic_min_bytes"] = 100000 * 4096 * 4 + nq * 4096 * 4
+        # algorithmic minimum: the bank's candidate-stage copy once + the queries' copy once
+        e["algorithmic_min_bytes"] = 100000 * 4096 * bpv + nq * 4096 * bpv
         if e.get("traffic_bytes"):
             e["traffic_over_algorithmic"] = e["traffic_bytes"] / e["algorithmic_min_bytes"]
         if hit is not None and miss is not None and hit + miss > 0:
@@ -85,15 +90,15 @@ def main():
             e["lds_bank_conflict_frac"] = e.get("SQ_LDS_BANK_CONFLICT", 0.0) / e["SQ_LDS_IDX_ACTIVE"]
         if times.get(nq):
             e["kernel_ms_traced"] = times[nq]
-            e["TFLOPs_fp32_equivalent_traced"] = 2.0 * nq * 100000 * 4096 / (times[nq] * 1e-3) / 1e12
+            e["TFLOPs_traced"] = 2.0 * nq * 100000 * 4096 / (times[nq] * 1e-3) / 1e12      # 2 D flop per (query, row) pair
         out["launches"][str(nq)] = e
         if e.get("traffic_bytes"):
             key = kern if nq == 100000 else kern + "/q%d" % nq
             table[key] = {"traffic_bytes": e["traffic_bytes"], "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk,
                           "algorithmic_min_bytes": e["algorithmic_min_bytes"], "l2_hit_rate": e.get("l2_hit_rate"),
                           "mfma_busy_frac": e.get("mfma_busy_frac"),
-                          "match": {"queries": nq, "bank_rows": 100000, "dim": 4096},
-                          "source": "profiles/%s_pmc_match_summary.json (round 3: separate rocprofv3 --pmc passes of tools/pmc_match_target.py, tools/gpu_pmc_match.sh)" % tag}
+                          "match": {"queries": nq, "bank_rows": 100000, "dim": 4096, "products": prod},
+                          "source": "profiles/%s_pmc_match_summary.json (separate rocprofv3 --pmc passes of tools/pmc_match_target.py, tools/gpu_pmc_match.sh): L2-miss (fabric-side) bytes, Infinity-Cache hits included" % tag}
     json.dump(table, open(path, "w"), indent=1)
     print(json.dumps(out, indent=1))
 

@@ -1,6 +1,6 @@
 """Launch target for the rocprofv3 --pmc passes of the matcher's candidate stage (tools/gpu_pmc_match.sh): a 100k x 4096 bank and, in
-order, REPS searches of 100 000 queries (BASELINE config 3's batch) and REPS of 1024 (the bench's in-step launch), top-5, fp16-pair
-candidate stage (the default); CSLAM_MFMA_STAGE1=f32 profiles the f32-input stage instead."""
+order, REPS searches of 100 000 queries (BASELINE config 3's batch) and REPS of 1024 (the bench's in-step launch), top-5, the default
+candidate stage (one fp16 product); CSLAM_MFMA_STAGE1=pair / f32 profile the other stages instead."""
 import sys
 import torch
 sys.path.insert(0, ".")
