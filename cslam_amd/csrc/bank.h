@@ -43,6 +43,8 @@ struct cslam_bank {
     int *h_nflag;                     // pinned: count of uncertified queries of the last enqueued MFMA search
     int *pending_flag_list;           // device list those queries are in (bank workspace)
     int *pending_flag_count;          // device count of that list (bank workspace)
+    int last_nprod;                   // candidate stage of the last MFMA-mode search: fp16 products per pair (0: the f32-input stage)
+    int f32_backoff;                  // searches left on the f32-input stage after an fp16 stage left too many queries uncertified
     int pending_dbg;
     // a search that has been enqueued and not finished (cslam_bank_search_enqueue_dev ... cslam_bank_search_finish): its
     // arguments, for the exact-scan fallback of the uncertified queries; ev_flag = "the uncertified-query count is on the host"

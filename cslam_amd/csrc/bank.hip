@@ -120,6 +120,7 @@ CSLAM_API int cslam_bank_create(int device, int dim, int64_t capacity_hint, csla
     b->stage = nullptr; b->stage_bytes = 0; b->last_stream = nullptr; b->ev_valid = false;
     b->side = nullptr; b->ev_fork = nullptr; b->ev_side = nullptr;
     b->h_nflag = nullptr; b->pending_flag_list = nullptr; b->pending_flag_count = nullptr; b->pending_dbg = 0;
+    b->last_nprod = 1; b->f32_backoff = 0;
     b->pend.active = false; b->pend.deferred = false; b->ev_flag = nullptr;
     b->dbg_part_key = nullptr; b->dbg_part_idx = nullptr; b->dbg_nseg = 0; b->dbg_nq = 0; b->dbg_err_bound = 0.0;
     for (int s = 0; s < 4; ++s) { b->stats[s] = 0; b->item_map_key[s] = -1; }

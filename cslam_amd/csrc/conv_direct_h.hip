@@ -122,7 +122,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_h_kernel(ConvDirectArgs
             elem(half * (NPL / 2) + j, dst, pr, pc);
             const int gy = by * 16 - 1 + pr, gx = bx * 16 - 1 + pc;
             const bool in = (dst >= 0) & (gy >= 0) & (gy < p.H) & (gx >= 0) & (gx < p.W);
-            stg[j] = in ? *(const float4 *)(xs + (gy * p.W + gx) * p.Cin) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            // EVERY lane of EVERY wave issues this load (a clamped address, the value dropped): the stage barriers count the
+            // outstanding requests (vmcnt(NV)), and a load under `if (in)` is skipped by waves whose lanes are all outside
+            // (s_cbranch_execz) -- such a wave then waited for fewer of its OLDER requests than it had to, and with the weights
+            // slow to arrive (another stream thrashing the L2) multiplied a ring slot that had not landed
+            const int cy = gy < 0 ? 0 : gy >= p.H ? p.H - 1 : gy, cx = gx < 0 ? 0 : gx >= p.W ? p.W - 1 : gx;
+            const float4 v = *(const float4 *)(xs + (cy * p.W + cx) * p.Cin);
+            stg[j].x = in ? v.x : 0.0f; stg[j].y = in ? v.y : 0.0f; stg[j].z = in ? v.z : 0.0f; stg[j].w = in ? v.w : 0.0f;
         }
     };
     auto patch_store = [&](int buf, int half) {                // registers -> exact fp16 pairs of s_x x -> LDS

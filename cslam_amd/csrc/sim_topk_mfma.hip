@@ -500,7 +500,14 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     // (round 1-2's kernel), "pair" = exact fp16 pairs, three products (round 3's); default ("h1") = ONE fp16 product on the hi
     // halves (round 4, sim_topk_pair.hip NPROD = 1: same rigorous bound as the pair stage at a third of the matrix work)
     const char *s1 = getenv("CSLAM_MFMA_STAGE1");
-    const int nprod = (s1 && s1[0] == 'f') ? 0 : ((s1 && s1[0] == 'p') ? 3 : 1);
+    int nprod = (s1 && s1[0] == 'f') ? 0 : ((s1 && s1[0] == 'p') ? 3 : 1);
+    // Clustered banks (many near-duplicates inside the fp16 stages' re-scoring window, 2 x 1.57e-3 at 4096-D) overflow the 64
+    // contenders stage 2 re-scores and send their queries through the exact scan: results stay exact, throughput does not.  When
+    // the last search left more than 1/32 of its queries uncertified, the next eight searches of this bank take the f32-input
+    // stage (window 2 x 2.6e-4: six times fewer contenders), then the fp16 stage is tried again.  An explicit CSLAM_MFMA_STAGE1
+    // switches this off.
+    if (!s1 && b->f32_backoff > 0) { nprod = 0; --b->f32_backoff; }
+    b->last_nprod = nprod;
     const int stage1_pair = nprod != 0;
     if (dbg < 0) {
         dbg = 0;
@@ -679,6 +686,7 @@ int mfma_search_finish(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq,
                        int64_t *d_out_idx, double *d_out_sim, int32_t *d_out_cnt, hipStream_t st) {
     const int nflag = b->h_nflag ? *b->h_nflag : 0;        // valid once `st` has been synchronised
     b->stats[0] = nflag;
+    if (b->last_nprod != 0 && (int64_t)nflag * 32 > (int64_t)b->dbg_nq) b->f32_backoff = 8;
     if (nflag > 0 && b->pending_dbg == 0)
         return scan_search(b, d_q, q_dtype, ldq, b->pending_flag_list, nflag, k, d_row_limit, d_out_idx, d_out_sim,
                            d_out_cnt, st);

@@ -451,7 +451,8 @@ class WinogradTrunk(_Workspace):
         self.input_bound = None
         # CSLAM_CONV_DIRECT=0: conv2_1 / conv2_2 through the F(4x4) forms of round 3 (the A/B partner)
         self.direct128 = os.environ.get("CSLAM_CONV_DIRECT", "1") != "0"
-        self.direct_cins = (128,)                    # input widths that take the direct kernel (tests set (64, 128))
+        # input widths that take the direct kernel (CSLAM_CONV_DIRECT=2: conv2_2 only, conv2_1 on the one-kernel F(4x4) form)
+        self.direct_cins = (128,) if os.environ.get("CSLAM_CONV_DIRECT", "1") == "2" else (64, 128)
         self.split16_h3 = os.environ.get("CSLAM_WINO_H3", "0") == "1"
         self.split16_min_cin = int(os.environ.get("CSLAM_WINO_SPLIT16", "256" if self.split16_h3 else "128"))
         use_tuned_gemms()

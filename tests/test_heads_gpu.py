@@ -591,10 +591,63 @@ def test_direct_conv_on_fp16_pairs_equals_float64(T, cin, B, H, W, relu, pool, b
     assert out_slot.item() == y.abs().max().item()
 
 
+@pytest.mark.parametrize("cin,pool", [(128, True), (64, False)])
+def test_direct_conv_beside_a_stream_that_thrashes_the_l2_is_bit_identical(T, cin, pool):
+    """The direct kernel's stage barriers count outstanding requests (`s_waitcnt vmcnt(N)`), which is only right if every wave
+    issues the same requests per stage.  Round 4's first form loaded the patch under `if (inside)`: waves whose lanes were all
+    outside skipped the load, waited for one request too few, and -- once the weights were slow to arrive because another stream
+    streamed 256 MB through the L2 -- multiplied a ring slot that had not landed (errors up to 0.7 in whole channel groups; alone on
+    the GPU the weights are L2 hits and the race never showed).  Same launch alone and beside such a stream: bit-identical."""
+    torch, _ = T
+    from cslam_amd.vpr import winograd as wg
+    torch.manual_seed(0)
+    B, H, W = 12, 188, 188                                        # a 12-frame chunk at conv2's resolution: 1728 blocks, ragged edges
+    x = torch.relu(torch.randn(B, cin, H, W, device="cuda")).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(128, cin, 3, 3, device="cuda") / (3 * cin ** 0.5)
+    b = torch.randn(128, device="cuda")
+    Wd = wg.direct_pair_weights(w)
+    slot = x.abs().max().reshape(1).clone()
+    ref = wg.conv3x3_direct_h(x, Wd, b, True, pool, slot)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    big = torch.zeros(64 << 20, device="cuda")
+    for _ in range(6):
+        with torch.cuda.stream(s2):
+            for _ in range(4):
+                big.add_(1.0)
+        with torch.cuda.stream(s1):
+            ys = [wg.conv3x3_direct_h(x, Wd, b, True, pool, slot) for _ in range(3)]
+        torch.cuda.synchronize()
+        for y in ys:
+            assert torch.equal(y, ref)
+
+
+def test_netvlad_extraction_beside_a_stream_that_thrashes_the_l2_is_bit_identical(T):
+    """The whole extract pass (stem kernel, direct kernels, pair products, transforms, heads: every kernel with counted waits or
+    LDS-DMA rings) beside a stream that keeps HBM and the L2 busy: the descriptors of the pass alone, bit for bit."""
+    torch, heads = T
+    from cslam_amd.vpr.netvlad import NetVLAD
+    nv = NetVLAD({"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376, "frontend.netvlad.pca_dim": 256}, None)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    frames = torch.randint(0, 256, (24, 240, 320, 3), generator=gen, device="cuda", dtype=torch.uint8)
+    ref = nv.compute_embeddings_device(frames)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    big = torch.zeros(64 << 20, device="cuda")
+    for _ in range(4):
+        with torch.cuda.stream(s2):
+            for _ in range(12):
+                big.add_(1.0)
+        with torch.cuda.stream(s1):
+            got = nv.compute_embeddings_device(frames)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref)
+
+
 def test_trunk_runs_conv2_1_and_conv2_2_through_the_direct_kernel_and_matches_the_winograd_forms(T, monkeypatch):
-    """VGG-16's first two blocks through the trunk runner: by default conv2_2 takes the direct kernel (here conv2_1 as well:
-    `direct_cins`); CSLAM_CONV_DIRECT=0 keeps round 3's F(4x4) forms.  Both against float64, and against each other at the F(4x4)
-    forms' tolerance."""
+    """VGG-16's first two blocks through the trunk runner: by default conv2_1 and conv2_2 take the direct kernel;
+    CSLAM_CONV_DIRECT=2 leaves conv2_1 on the one-kernel F(4x4) form, =0 keeps round 3's F(4x4) forms for both.  All against float64,
+    and against each other at the F(4x4) forms' tolerance."""
     torch, _ = T
     from torch import nn
     from cslam_amd.vpr.winograd import WinogradTrunk
@@ -604,21 +657,21 @@ def test_trunk_runs_conv2_1_and_conv2_2_through_the_direct_kernel_and_matches_th
                         nn.MaxPool2d(2, 2)).cuda().eval()
     x = torch.randn((36, 3, 64, 80), device="cuda")
     outs = {}
-    for tag, env in (("direct", "1"), ("wino", "0")):
-        monkeypatch.setenv("CSLAM_CONV_DIRECT", env)
+    for tag, env, direct in (("direct", None, (True, True)), ("conv2_2", "2", (False, True)), ("wino", "0", (False, False))):
+        if env is None:
+            monkeypatch.delenv("CSLAM_CONV_DIRECT", raising=False)
+        else:
+            monkeypatch.setenv("CSLAM_CONV_DIRECT", env)
         t = WinogradTrunk(seq, 64, 4, fused64=True)
-        assert t.steps[2].Wd is None and (t.steps[3].Wd is not None) == (tag == "direct")       # the default: conv2_2 only
-        if tag == "direct":
-            t.direct_cins = (64, 128)
-            t.refresh()
-            assert t.steps[2].Wd is not None and t.steps[3].Wd is not None
+        assert ((t.steps[2].Wd is not None), (t.steps[3].Wd is not None)) == direct, tag
         outs[tag] = t(x)
     with torch.no_grad():
         ref = seq.double()(x.double())
     seq.float()
     for tag in outs:
         assert _rel_rms(outs[tag], ref) <= 1e-5, tag
-    assert (outs["direct"] - outs["wino"]).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    for tag in ("direct", "conv2_2"):
+        assert (outs[tag] - outs["wino"]).abs().max().item() <= 2e-5 * ref.abs().max().item(), tag
 
 
 @pytest.mark.parametrize("cout,B,H,W,pool,amp", [(64, 4, 64, 48, True, 1.0), (128, 3, 40, 56, False, 1e3), (64, 2, 30, 22, False, 1e-3)])

@@ -592,6 +592,66 @@ def test_fp16_pair_candidate_stage_error_is_inside_the_certificates_bound(nnm, m
         assert abs(out["h1"][3] / out["pair"][3] - 1.0) < 0.01  # same window for stage 2: 1.566e-3 against 1.570e-3
 
 
+def test_clustered_near_duplicates_stay_exact_and_back_off_to_the_f32_stage(nnm, monkeypatch):
+    """Real place-recognition banks are clustered: revisits of a place are near-duplicates.  With hundreds of rows inside the fp16
+    candidate stage's re-scoring window (2 x 1.57e-3 at 4096-D: more than the 64 contenders stage 2 re-scores) the certificate
+    refuses and those queries go through the exact scan -- the results stay those of the oracle, bit for bit.  The bank notices
+    (more than 1/32 of a search's queries uncertified) and runs its next searches on the f32-input stage, whose window is six
+    times narrower; the fraction each stage leaves uncertified is what this test reports."""
+    monkeypatch.delenv("CSLAM_MFMA_STAGE1", raising=False)
+    rng = np.random.default_rng(77)
+    d, n_c, per = 4096, 24, 150
+    centres = unit_rows(rng, n_c, d)
+    # rows of a cluster: centre + noise of norm a_r, a_r^2 uniform in [0, 5e-3]: cosine to the centre 1 - a_r^2 / 2, i.e. the 150 rows
+    # spread evenly over 2.5e-3 -- all of them inside the fp16 stages' window (3.1e-3), about 30 inside the f32 stage's (5.2e-4)
+    a = np.sqrt(rng.uniform(0.0, 5e-3, size=(n_c * per, 1))).astype(np.float32)
+    bank = np.repeat(centres, per, axis=0) + a / np.sqrt(d) * rng.standard_normal((n_c * per, d)).astype(np.float32)
+    bank = np.concatenate([bank.astype(np.float32), unit_rows(rng, 2000, d)])           # and unrelated rows around them
+    q = (centres[rng.integers(0, n_c, size=400)] + (0.01 / np.sqrt(d)) * rng.standard_normal((400, d))).astype(np.float32)
+    oi, os_, oc = pyoracle.nns_search(bank, q, 5)
+    nn = make_bank(nnm, bank)
+    frac = {}
+    for tag in ("h1 (first search)", "after the back-off"):
+        idx, sims, cnt = nn.search_batch(q, 5, mode=nnm.MODE_MFMA)
+        assert nn.last_stats()[1] == nnm.MODE_MFMA
+        assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
+        _, _, bound = _stage1_candidates(nnm, nn, 4)
+        frac[tag] = (nn.last_stats()[0] / 400.0, bound)
+    print("uncertified fraction / certificate bound per search:", frac)
+    assert frac["h1 (first search)"][1] > 1e-3 and frac["h1 (first search)"][0] > 1.0 / 32      # the fp16 stage ran and gave up on many
+    assert frac["after the back-off"][1] < 5e-4                                                 # the f32-input stage ran instead
+    assert frac["after the back-off"][0] <= frac["h1 (first search)"][0]
+    # an explicit choice of stage is never overridden
+    monkeypatch.setenv("CSLAM_MFMA_STAGE1", "h1")
+    idx, sims, cnt = nn.search_batch(q, 5, mode=nnm.MODE_MFMA)
+    assert _stage1_candidates(nnm, nn, 4)[2] > 1e-3
+    assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
+
+
+@pytest.mark.parametrize("stage", ["h1", "pair", "f32"])
+def test_search_beside_a_stream_that_thrashes_the_l2_is_bit_identical(nnm, monkeypatch, stage):
+    """Every candidate stage stages its operands through LDS-DMA rings whose barriers wait on request counters: latency-dependent
+    by construction.  The same search alone and beside a stream that streams 256 MB through the L2 over and over (operands that
+    are L2 hits alone become HBM misses): rows, float64 scores and counts bit for bit."""
+    import torch
+    monkeypatch.setenv("CSLAM_MFMA_STAGE1", stage)
+    rng = np.random.default_rng(31)
+    bank = unit_rows(rng, 20000, 1024)
+    q = unit_rows(rng, 3000, 1024)
+    nn = make_bank(nnm, bank)
+    ref = nn.search_batch(q, 5, mode=nnm.MODE_MFMA)
+    big = torch.zeros(64 << 20, device="cuda")
+    side = torch.cuda.Stream()
+    for _ in range(4):
+        with torch.cuda.stream(side):
+            for _ in range(8):
+                big.add_(1.0)
+        got = nn.search_batch(q, 5, mode=nnm.MODE_MFMA)
+        torch.cuda.synchronize()
+        for a, b in zip(got, ref):
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
 def test_fp16_pair_stage_rows_and_queries_it_cannot_scale_are_still_exact(nnm):
     """Rows / queries whose magnitudes the power-of-two scale of the pair split cannot serve (beyond 2^+-100, non-finite
     entries) and zero rows: the candidate stage marks them (NaN key -> always a contender / query uncertified) and the

@@ -38,7 +38,7 @@ def main():
             d = byd.setdefault(int(r["Dispatch_Id"]), [r["Kernel_Name"], 0.0])
             d[1] += float(r["Counter_Value"])
         seq = [byd[k] for k in sorted(byd)]
-        idx = [i for i, (n, _) in enumerate(seq) if n.startswith("preprocess_fused")]
+        idx = [i for i, (n, _) in enumerate(seq) if ("preprocess_fused" in n or "preprocess_tile" in n)]
         sel = seq[idx[-a.iters]:]
         agg = collections.defaultdict(lambda: [0.0, 0])
         for n, v in sel:
@@ -49,7 +49,7 @@ def main():
             print(f"  {v / a.iters:16.0f} per pass  x{c / a.iters:5.1f}  {k}")
         return
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("preprocess_fused")]
+    idx = [i for i, r in enumerate(rows) if ("preprocess_fused" in r["Kernel_Name"] or "preprocess_tile" in r["Kernel_Name"])]
     sel = rows[idx[-a.iters]:]
     t0 = int(sel[0]["Start_Timestamp"])
     t1 = max(int(r["End_Timestamp"]) for r in sel)
