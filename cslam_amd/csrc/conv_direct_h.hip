@@ -32,6 +32,7 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define CD_PIXB 144                    // bytes per patch pixel: 64 hi + 64 lo + 16 pad
@@ -40,7 +41,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define CD_WROWB 128                   // bytes per weight row of a stage: [hi 32 | lo 32]
 #define CD_WSTAGE (128 * CD_WROWB)     // 16 KB: 128 output channels
 #define CD_NW 3                        // weight stages in the ring: requests run two stages ahead
-#define CD_LDS (2 * CD_PATCHB + CD_NW * CD_WSTAGE + 512)  // + the 128 bias values
+#define CD_LDS (2 * CD_PATCHB + CD_NW * CD_WSTAGE + 512 + 256)  // + the 128 bias values + a sink for the patch elements that do not exist
 
 struct ConvDirectArgs {
     const float *x; const char *w2; const float *bias; float *y;
@@ -51,13 +52,21 @@ struct ConvDirectArgs {
     int stagger_cycles;                // start-up offset per phase (workgroup >> 3 & 3), 0 = none
 };
 
-__device__ __forceinline__ void cd_glds16(const char *g, char *lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+// LDS-DMA in the MUBUF encoding (`buffer_load_dwordx4 ... lds`; sim_topk_pair.hip has the why: hipcc counts LDS reads again -- behind
+// a pending `global_load_lds` every lgkmcnt(N) became lgkmcnt(0) --, the stage's offset travels in an SGPR, the lane's in one register)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cd_rsrc(const char *base, int64_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    const uint64_t u = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a);
+    const int n = __builtin_amdgcn_readfirstlane((int)(bytes > 0x7fffffff ? 0x7fffffff : bytes));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)u, 0, n, 0x00020000);
+}
+__device__ __forceinline__ void cd_blds16(__amdgpu_buffer_rsrc_t rs, int voff, int soff, char *lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
 // DBG (builds with -DCSLAM_ABLATIONS only; WRONG results): 1 = no weight requests after the prologue, 2 = no patch staging after the
-// prologue, 3 = both; + 4 = no stage barrier / wait; + 8 = fragments read once per workgroup only
+// prologue, 3 = both; + 4 = no stage barrier / wait; + 8 = fragments read once per workgroup only; 32 = patch loaded but not split into
+// LDS; 64 = patch split into LDS but not loaded
 #ifdef CSLAM_ABLATIONS
 __device__ unsigned long long *cd_prof = nullptr;             // measurement build: [stage loops, epilogues, blocks] ticks of wave 0 / workgroup 0
 extern "C" __attribute__((visibility("default"))) int cslam_debug_cd_prof_dev(void *d_buf) {
@@ -109,55 +118,94 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_h_kernel(ConvDirectArgs
         dst = e < 2592 ? pr * CD_ROWB + pc * CD_PIXB + f4 * 8 : -1;
     };
     float4 stg[NPL / 2];                                       // the patch goes through the registers in two halves (12 registers, not 24)
-    auto patch_load = [&](int gslab, int half) {               // global slab counter -> (block, slab): loads into registers
-        const int bi = gslab / p.nslab, sl = gslab - bi * p.nslab;
+    unsigned inmask = 0;                                       // bit half * 3 + j: element j of the half lies inside the image
+    // what a patch LOAD needs of the geometry stays in seven registers: the element's byte offset from the patch's first pixel and its
+    // column (5 bits each), so that a load is one add and sits at the very top of its stage -- the stage waits give a request until
+    // the end of the NEXT stage to land, and these come from HBM
+    int inv_off[NPL];
+    unsigned pcpack = 0, validpack = 0;
+#pragma unroll
+    for (int i = 0; i < NPL; ++i) {
+        const int e = i * 512 + tid, px = e >> 3;
+        const int pr = (px * 3641) >> 16, pc = px - pr * 18;
+        const bool valid = e < 2592;
+        inv_off[i] = valid ? (pr * p.W + pc) * p.Cin * 4 + (e & 7) * 16 : 0;
+        pcpack |= (unsigned)(valid ? pc : 0) << (5 * i);
+        validpack |= (valid ? 1u : 0u) << i;
+    }
+    char *const s_sink = cd_smem + 2 * CD_PATCHB + CD_NW * CD_WSTAGE + 512 + (tid & 15) * 8;
+    // block coordinates are decoded ONCE per block on the scalar unit (three run-time divisions: ~90 dependent scalar instructions,
+    // which sat at the top of two stages per slab): `cb` = the block being multiplied, `nb` = the next one (the last block again
+    // behind the workgroup's last)
+    struct Blk { int by, bx; const char *xb; };               // xb = the block's image
+    auto decode_blk = [&](int bi) {
         const int blk = (int)blockIdx.x + bi * (int)gridDim.x;
         const int per_img = p.gxb * p.gyb;
         const int img = blk / per_img, rem = blk - img * per_img;
-        const int by = rem / p.gxb, bx = rem - by * p.gxb;
-        const float *xs = p.x + ((int64_t)img * p.H * p.W) * p.Cin + sl * 32 + (tid & 7) * 4;
+        Blk b;
+        b.by = rem / p.gxb; b.bx = rem - b.by * p.gxb;
+        b.xb = (const char *)p.x + (int64_t)img * p.H * p.W * p.Cin * 4;
+        return b;
+    };
+    Blk cb = decode_blk(0), nb = decode_blk(n_mine > 1 ? 1 : 0);
+    const int img_bytes = p.H * p.W * p.Cin * 4;
+    const int lane_ch = (tid & 7) * 16;                        // the lane's float4 inside a pixel's 32-channel slab
+    // float32 patch of (block b, slab sl), half `half`, into registers: buffer loads (the lane's offset is one register, the slab's
+    // an SGPR)
+    auto patch_load = [&](const Blk &b, int sl, int half) {
+        // the image is the buffer: rows above and below it are out of its range and read as zero; the columns left and right of it
+        // would read the neighbouring row's pixels and are masked when the registers are split into LDS (a select right here would
+        // wait for the load).  EVERY lane of EVERY wave issues every load: the stage barriers count the outstanding requests
+        // (vmcnt(NV)), and a load under `if (inside)` is skipped by waves whose lanes are all outside (s_cbranch_execz) -- such a
+        // wave then waited for fewer of its OLDER requests than it had to, and with the weights slow to arrive (another stream
+        // thrashing the L2) multiplied a ring slot that had not landed (round 4's first form)
+        const __amdgpu_buffer_rsrc_t rsX = cd_rsrc(b.xb, img_bytes);
+        const int blk_off = ((b.by * 16 - 1) * p.W + (b.bx * 16 - 1)) * p.Cin * 4;
+        const int gx0 = b.bx * 16 - 1;
+        unsigned m = inmask & ~(7u << (3 * half));
 #pragma unroll
         for (int j = 0; j < NPL / 2; ++j) {
-            int dst, pr, pc;
-            elem(half * (NPL / 2) + j, dst, pr, pc);
-            const int gy = by * 16 - 1 + pr, gx = bx * 16 - 1 + pc;
-            const bool in = (dst >= 0) & (gy >= 0) & (gy < p.H) & (gx >= 0) & (gx < p.W);
-            // EVERY lane of EVERY wave issues this load (a clamped address, the value dropped): the stage barriers count the
-            // outstanding requests (vmcnt(NV)), and a load under `if (in)` is skipped by waves whose lanes are all outside
-            // (s_cbranch_execz) -- such a wave then waited for fewer of its OLDER requests than it had to, and with the weights
-            // slow to arrive (another stream thrashing the L2) multiplied a ring slot that had not landed
-            const int cy = gy < 0 ? 0 : gy >= p.H ? p.H - 1 : gy, cx = gx < 0 ? 0 : gx >= p.W ? p.W - 1 : gx;
-            const float4 v = *(const float4 *)(xs + (cy * p.W + cx) * p.Cin);
-            stg[j].x = in ? v.x : 0.0f; stg[j].y = in ? v.y : 0.0f; stg[j].z = in ? v.z : 0.0f; stg[j].w = in ? v.w : 0.0f;
+            const int i = half * (NPL / 2) + j;
+            const int gx = gx0 + (int)((pcpack >> (5 * i)) & 31u);
+            const bool in = ((validpack >> i) & 1u) & (gx >= 0) & (gx < p.W);
+            const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsX, inv_off[i] + blk_off, sl * 128, 0);
+            stg[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            m |= (in ? 1u : 0u) << (3 * half + j);
         }
+        inmask = m;
     };
-    auto patch_store = [&](int buf, int half) {                // registers -> exact fp16 pairs of s_x x -> LDS
+    // registers -> exact fp16 pairs of s_x x -> LDS, elements [j0, j1) of the half.  Branch-free (an element that does not exist --
+    // the last 480 of 6 x 512 -- goes to a sink): the stage must stay ONE basic block for its instruction order to be set
+    auto patch_store = [&](int buf, int half, int j0, int j1) {
         char *dst = s_patch + buf * CD_PATCHB;
 #pragma unroll
         for (int j = 0; j < NPL / 2; ++j) {
+            if (j < j0 || j >= j1) continue;
             int pd, pr, pc;
             elem(half * (NPL / 2) + j, pd, pr, pc);
-            if (pd >= 0) {
-                const float w0 = stg[j].x * sx, w1 = stg[j].y * sx, w2 = stg[j].z * sx, w3 = stg[j].w * sx;
-                const __half2 h01 = __floats2half2_rn(w0, w1), h23 = __floats2half2_rn(w2, w3);
-                const float2 f01 = __half22float2(h01), f23 = __half22float2(h23);
-                const __half2 l01 = __floats2half2_rn(w0 - f01.x, w1 - f01.y), l23 = __floats2half2_rn(w2 - f23.x, w3 - f23.y);
-                *(uint2 *)(dst + pd) = make_uint2(*(const unsigned *)&h01, *(const unsigned *)&h23);
-                *(uint2 *)(dst + pd + 64) = make_uint2(*(const unsigned *)&l01, *(const unsigned *)&l23);
-            }
+            const bool in = (inmask >> (3 * half + j)) & 1u;
+            const float w0 = in ? stg[j].x * sx : 0.0f, w1 = in ? stg[j].y * sx : 0.0f, w2 = in ? stg[j].z * sx : 0.0f, w3 = in ? stg[j].w * sx : 0.0f;
+            const __half2 h01 = __floats2half2_rn(w0, w1), h23 = __floats2half2_rn(w2, w3);
+            const float2 f01 = __half22float2(h01), f23 = __half22float2(h23);
+            const __half2 l01 = __floats2half2_rn(w0 - f01.x, w1 - f01.y), l23 = __floats2half2_rn(w2 - f23.x, w3 - f23.y);
+            char *d = pd >= 0 ? dst + pd : s_sink;
+            *(uint2 *)d = make_uint2(*(const unsigned *)&h01, *(const unsigned *)&h23);
+            *(uint2 *)(d + 64) = make_uint2(*(const unsigned *)&l01, *(const unsigned *)&l23);
         }
     };
 
     // ---- weight loader: chunk pch = i * 512 + tid -> row pch >> 3 (output channel), physical 16-byte slot pch & 7 holding
     // logical chunk slot ^ ((row >> 1) & 7) of the row's 128-byte block (wino_gemm.hip's image: conflict-free ds_read_b128)
-    const int64_t tap_stride = (int64_t)128 * p.nslab * CD_WROWB;
-    const char *wp[2];                                         // running pointers: the weights of the stage after the current one
+    const int tap_stride = 128 * p.nslab * CD_WROWB;
+    const __amdgpu_buffer_rsrc_t rsW = cd_rsrc(p.w2, (int64_t)9 * tap_stride);
+    int voffW[2];                                              // the lane's two chunks inside a (tap, slab)'s 128 rows
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int pch = i * 512 + tid;
         const int r = pch >> 3, c = (pch & 7) ^ ((r >> 1) & 7);
-        wp[i] = p.w2 + (int64_t)r * p.nslab * CD_WROWB + (c << 4);
+        voffW[i] = r * p.nslab * CD_WROWB + (c << 4);
     }
+    int woff = 0;                                              // running scalar offset: the weights of the stage after the current one
 
     // ---- fragment addressing
     // A (patch): lane (l31, h) = pixel (row l31 >> 4, column l31 & 15) of an MFMA tile of 2 rows x 16 pixels; tile t of the wave =
@@ -220,16 +268,27 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_h_kernel(ConvDirectArgs
                                                          : __builtin_amdgcn_mfma_f32_32x32x16_f16(fb[u][1][n], fa[u][0][t], acc[t][n], 0, 0, 0);
     };
 
+    // MFMAs 3 k .. 3 k + 2 of multiply(u)'s twelve, in its order (the sums do not change)
+    auto multiply3 = [&](int u, int k) {
+#pragma unroll
+        for (int idx = 3 * k; idx < 3 * k + 3; ++idx) {
+            const int prod = idx >> 2, t = (idx >> 1) & 1, n = idx & 1;
+            const f16x8 a = prod == 2 ? fb[u][1][n] : fb[u][0][n];
+            const f16x8 b = prod == 1 ? fa[u][1][t] : fa[u][0][t];
+            acc[t][n] = PIXA ? __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, acc[t][n], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[t][n], 0, 0, 0);
+        }
+    };
+
     // ---- prologue: patch of slab 0, weights of stage 0
 #pragma unroll
-    for (int b = 0; b < 2; ++b)                                // stages 0 and 1: (tap 0 | 1, slab 0); the pointers move on to (tap 2, slab 0)
+    for (int b = 0; b < 2; ++b) {                              // stages 0 and 1: (tap 0 | 1, slab 0); the offset moves on to (tap 2, slab 0)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            cd_glds16(wp[i], s_w + b * CD_WSTAGE + wave * 1024 + i * (512 * 16));
-            wp[i] += tap_stride;
-        }
-    patch_load(0, 0); patch_store(0, 0);
-    patch_load(0, 1); patch_store(0, 1);
+        for (int i = 0; i < 2; ++i) cd_blds16(rsW, voffW[i], woff, s_w + b * CD_WSTAGE + wave * 1024 + i * (512 * 16));
+        woff += tap_stride;
+    }
+    patch_load(cb, 0, 0); patch_store(0, 0, 0, NPL / 2);
+    patch_load(cb, 0, 1); patch_store(0, 1, 0, NPL / 2);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
 
@@ -243,54 +302,103 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_h_kernel(ConvDirectArgs
         constexpr bool FIRST = decltype(first_tag)::value;     // first stage of a block: nothing is carried in
         constexpr int DY = TAP / 3, DX = TAP - 3 * DY;
         // next slab's patch in two halves: loaded (float32 -> registers) at taps 0 / 4, split into the idle buffer at taps 3 / 7
-        // (branch-free: behind the workgroup's very last slab its own patch is staged once more, into the idle buffer)
-        if (!(DBG & 2)) {
-            const int nx = gslab + 1 < nslabs_total ? gslab + 1 : gslab;
-            if (TAP == 0) patch_load(nx, 0);
-            if (TAP == 3) patch_store((gslab + 1) & 1, 0);
-            if (TAP == 4) patch_load(nx, 1);
-            if (TAP == 7) patch_store((gslab + 1) & 1, 1);
-        }
+        // (branch-free: behind the workgroup's very last slab its own patch is staged once more, into the idle buffer).  Their ~200 /
+        // ~120 VALU instructions per wave are INTERLEAVED with the stage's MFMAs (sched_group_barrier pipelines below): at the top of
+        // the stage, where program order puts them, both waves of a SIMD executed them at the same time right behind the barrier with
+        // the matrix pipe idle -- 20 % of the kernel (profiles/r04_v24_direct_conv_ablations.log: 2.84 ms, without patch staging 2.25).
+        // Schedule over a slab's nine taps: 0 load half 0 | 2, 3 split its three elements into LDS | 4 load half 1 | 6, 7, 8 split
+        // (a load has landed two stages later: the stage waits leave only the newest requests in flight).
+        constexpr bool PL = (TAP == 0 || TAP == 4) && !(DBG & 2) && !(DBG & 64);
+        constexpr int HALF = TAP >= 4 ? 1 : 0;
+        constexpr int ST1 = (DBG & (2 | 32)) ? -1 : TAP == 2 ? 0 : TAP == 3 ? 1 : TAP == 6 ? 0 : TAP == 7 ? 1 : TAP == 8 ? 2 : -1;   // element split under K step 1
+        constexpr int ST2 = (DBG & (2 | 32)) ? -1 : TAP == 3 ? 2 : -1;                                                         // ... under K step 0
+        constexpr bool PS = ST1 >= 0;
+        if ((DBG & 32) && TAP == 8) { asm volatile("" :: "v"(stg[0].x), "v"(stg[1].y), "v"(stg[2].z), "v"(stg[0].w), "v"(stg[1].x), "v"(stg[2].y)); }
+        // the slab whose patch is staged during this one: the next slab of this block, or slab 0 of the next block
+        const bool same_blk = sl + 1 < p.nslab;
+        Blk tb;
+        tb.by = same_blk ? cb.by : nb.by; tb.bx = same_blk ? cb.bx : nb.bx; tb.xb = same_blk ? cb.xb : nb.xb;
         const char *sA = s_patch + (gslab & 1) * CD_PATCHB + a_base + DY * CD_ROWB + DX * CD_PIXB;
         const char *sB = s_w + wb * CD_WSTAGE + b_base;
-        // ---- behind the barrier: this stage's first reads, the next stage's weights, the previous stage's second K step
-        if (!(DBG & 8) || g == 0) read_frags(0, sA, sB, 0);
-        if (!(DBG & 1)) {
-            // (the very last stage of the workgroup requests the weights of a stage nobody will run: harmless)
+        auto request_weights = [&]() {
             // the weights of stage g + 2 into the buffer stage g - 1 was read from (every wave finished that before the last barrier)
+            // (the very last stage of the workgroup requests the weights of a stage nobody will run: harmless)
             const int wb2 = wb == 0 ? 2 : wb - 1;
             char *d = s_w + wb2 * CD_WSTAGE + wave * 1024;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                cd_glds16(wp[i], d + i * (512 * 16));
-                // a RUNNING pointer: written as gW[i] + (TAP + 1) * tap_stride the nine taps' addresses are loop invariants, and the
-                // compiler keeps all eighteen of them in registers across the K loop (36 VGPRs: the kernel spilled)
-                // (behind tap 6's request -- tap 8 of this slab -- comes tap 0 of the next slab: a relative step, so that the base
-                // pointers need not stay in registers)
-                wp[i] += TAP == 6 ? (int64_t)(sl_next - sl) * CD_WROWB - 8 * tap_stride : tap_stride;
-            }
-        }
+            for (int i = 0; i < 2; ++i) cd_blds16(rsW, voffW[i], woff, d + i * (512 * 16));
+            // a RUNNING offset (scalar): written as (TAP + 1) * tap_stride + ... the nine taps' addresses are loop invariants that the
+            // compiler keeps in registers across the K loop (as 64-bit per-lane pointers, round 4's first form: 36 VGPRs, the kernel
+            // spilled).  Behind tap 6's request -- tap 8 of this slab -- comes tap 0 of the next slab: a relative step.
+            woff += TAP == 6 ? (sl_next - sl) * CD_WROWB - 8 * tap_stride : tap_stride;
+        };
+        // ---- behind the barrier: this stage's first reads, the next stage's weights, the previous stage's second K step
+        if (!(DBG & 8) || g == 0) read_frags(0, sA, sB, 0);
+        // (a stage that writes the patch requests its weights BEHIND its last LDS write: while an LDS-DMA is pending hipcc puts
+        // vmcnt(0) in front of every LDS write that may alias its destination -- behind this stage's own requests that would be
+        // their full latency)
+        // a stage that loads issues its three requests FIRST
+        if (PL) patch_load(tb, sl_next, HALF);
+        if (!(DBG & 1) && !PS) request_weights();
         if constexpr (!FIRST) {
+            if (PS) patch_store((gslab + 1) & 1, HALF, ST1, ST1 + 1);
             multiply(1);
             __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);      // DS read
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      // MFMA
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read (LDS-DMA)
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            if (PS) {
+                // the groups are upper bounds, filled from the stage's end: what does not fit is left at its top
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);              // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 9, 0);              // VALU
+                    __builtin_amdgcn_sched_group_barrier(0x004, 3, 0);              // SALU
+                }
+                __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                  // DS write (hi, lo)
+            } else {
+                if (PL) {
+                    __builtin_amdgcn_sched_group_barrier(0x004, 16, 0);     // the patch loads and what they need
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x020, 3, 0);
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);      // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read (LDS-DMA)
+                if (PL) __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (PL) __builtin_amdgcn_sched_group_barrier(0x002, 12, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- K step 0 over the reads of K step 1
         if (!(DBG & 8) || g == 0) read_frags(1, sA, sB, 1);
+        if (ST2 >= 0) patch_store((gslab + 1) & 1, HALF, ST2, ST2 + 1);
         multiply(0);
+        if (!(DBG & 1) && PS) request_weights();
         __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
         __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
+        if (ST2 >= 0) {
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+                __builtin_amdgcn_sched_group_barrier(0x004, 4, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        } else if (PS) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        } else {
+            __builtin_amdgcn_sched_group_barrier(0x008, 10, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         // my requests for stage g + 1 (issued a stage ago) have landed -- the two of this stage, and the patch loads issued with
         // them at taps 0 / 4, stay in flight: a counted vmcnt --, my reads of stage g and my patch stores are done: raw barrier
         if (!(DBG & 4)) {
-            constexpr int NV = (DBG & 1 ? 0 : 2) + ((TAP == 0 || TAP == 4) && !(DBG & 2) ? NPL / 2 : 0);
+            constexpr int NV = (DBG & 1 ? 0 : 2) + (PL ? NPL / 2 : 0);
             __builtin_amdgcn_s_waitcnt(NV | 0x70);             // vmcnt(NV) lgkmcnt(0)
             __builtin_amdgcn_s_barrier();
         }
@@ -322,9 +430,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_h_kernel(ConvDirectArgs
         if (CD_PROF) { t1 = __builtin_amdgcn_s_memtime(); t_loop += t1 - t0; }
         // ---- block epilogue
         const int blk = (int)blockIdx.x + bi * (int)gridDim.x;
-        const int per_img = p.gxb * p.gyb;
-        const int img = blk / per_img, rem = blk - img * per_img;
-        const int by = rem / p.gxb, bx = rem - by * p.gxb;
+        const int img = blk / (p.gxb * p.gyb);
+        const int by = cb.by, bx = cb.bx;
+        cb = nb;
+        nb = decode_blk(bi + 2 < n_mine ? bi + 2 : n_mine - 1);
         if constexpr (PIXA) {
             // pixels as the A operand: lane (l31, h) holds, for tile (t, n), channel 64 wn + 32 n + l31 of the 16 pixels
             // m = (r & 3) + 8 (r >> 2) + 4 h of the tile (row m >> 4, column m & 15): a store instruction writes 128 contiguous bytes
@@ -374,6 +483,17 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_h_kernel(ConvDirectArgs
             int ln = tid;
             asm volatile("" : "+v"(ln));
             const int el = ln & 31, eh = (ln >> 5) & 1;
+            // the lane's 32 bias values, read BEFORE the first store: behind a pending LDS-DMA the compiler puts `vmcnt(0)` in front of
+            // an LDS read that may alias its destination -- in between the stores that is an HBM round trip per read
+            float4 bvs[2][4];
+            {
+                const float *bb = s_bias + wn * 64 + 4 * eh;
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bvs[n][q] = *(const float4 *)(bb + n * 32 + 8 * q);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 const int oy = by * 16 + 4 * wm + 2 * t + (el >> 4), ox = bx * 16 + (el & 15);      // this lane's pixel
@@ -386,7 +506,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_h_kernel(ConvDirectArgs
                     store = oy < p.H && ox < p.W;
                     yb = p.y + (((int64_t)img * p.H + oy) * p.W + ox) * 128 + wn * 64 + 4 * eh;
                 }
-                const float *bb = s_bias + wn * 64 + 4 * eh;
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
 #pragma unroll
@@ -400,7 +519,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_h_kernel(ConvDirectArgs
                             v.x = fmaxf(v.x, __shfl_xor(v.x, 16, 64)); v.y = fmaxf(v.y, __shfl_xor(v.y, 16, 64));
                             v.z = fmaxf(v.z, __shfl_xor(v.z, 16, 64)); v.w = fmaxf(v.w, __shfl_xor(v.w, 16, 64));
                         }
-                        const float4 bv = *(const float4 *)(bb + n * 32 + 8 * q);
+                        const float4 bv = bvs[n][q];
                         v.x = v.x * inv + bv.x; v.y = v.y * inv + bv.y; v.z = v.z * inv + bv.z; v.w = v.w * inv + bv.w;
                         if (RELU) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
                         if (store) {
@@ -468,16 +587,20 @@ CSLAM_API int cslam_conv3x3_direct_h_dev(const float *d_x, const void *d_w2, con
 #ifdef CSLAM_ABLATIONS
     if (const char *e = getenv("CSLAM_CD_DBG")) {              // timing-only ablations (wrong results): measurement build
         const int d = atoi(e);
-#define CD_LAUNCH_D(D) do { HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_direct_h_kernel<true, false, D>, hipFuncAttributeMaxDynamicSharedMemorySize, CD_LDS)); \
-        hipLaunchKernelGGL((conv3x3_direct_h_kernel<true, false, D>), dim3(grid), dim3(512), CD_LDS, st, a); HIP_TRY(hipGetLastError()); return CSLAM_OK; } while (0)
+#define CD_LAUNCH_D1(D, P) do { HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_direct_h_kernel<true, P, D>, hipFuncAttributeMaxDynamicSharedMemorySize, CD_LDS)); \
+        hipLaunchKernelGGL((conv3x3_direct_h_kernel<true, P, D>), dim3(grid), dim3(512), CD_LDS, st, a); HIP_TRY(hipGetLastError()); return CSLAM_OK; } while (0)
+#define CD_LAUNCH_D(D) do { if (pool) CD_LAUNCH_D1(D, true); else CD_LAUNCH_D1(D, false); } while (0)
         if (d == 1) CD_LAUNCH_D(1);
         if (d == 2) CD_LAUNCH_D(2);
         if (d == 3) CD_LAUNCH_D(3);
         if (d == 7) CD_LAUNCH_D(7);
         if (d == 11) CD_LAUNCH_D(11);
         if (d == 15) CD_LAUNCH_D(15);
-        if (d == 16) { HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_direct_h_kernel<true, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CD_LDS));
+        if (d == 32) CD_LAUNCH_D(32);
+        if (d == 64) CD_LAUNCH_D(64);
+        if (d == 16 && !pool) { HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_direct_h_kernel<true, false, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CD_LDS));
                        hipLaunchKernelGGL((conv3x3_direct_h_kernel<true, false, 0, true>), dim3(grid), dim3(512), CD_LDS, st, a); HIP_TRY(hipGetLastError()); return CSLAM_OK; }
+#undef CD_LAUNCH_D1
 #undef CD_LAUNCH_D
     }
 #endif

@@ -41,9 +41,19 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define PK_ROWB 128     // bytes of one 32-channel block of one row
 
-__device__ __forceinline__ void pk_glds16(const char *g, char *lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
-                                     (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
+// LDS-DMA in the MUBUF encoding (`buffer_load_dwordx4 ... lds`), round 4.  `global_load_lds` is FLAT-encoded with an LDS operand:
+// hipcc's waitcnt pass marks it "pending flat" and from then on turns every `lgkmcnt(N)` into `lgkmcnt(0)` -- a K step's MFMAs then
+// wait for ALL fragment reads issued before them.  The buffer form carries no such mark (LDS reads are counted again), takes the
+// stage's K offset in an SGPR and the lane's row offset in ONE register (a 64-bit address per request before), and clamps in
+// hardware: rows beyond `num_records` read as zero.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pk_rsrc(const char *base, int64_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    const uint64_t u = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a);
+    const int n = __builtin_amdgcn_readfirstlane((int)(bytes > 0x7fffffff ? 0x7fffffff : bytes));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)u, 0, n, 0x00020000);
+}
+__device__ __forceinline__ void pk_blds16(__amdgpu_buffer_rsrc_t rs, int voff, int soff, char *lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
 
@@ -210,34 +220,32 @@ __global__ __launch_bounds__(T_ * 2, 2) void sim_topk_pair_kernel(PairArgs p) {
     if (ntiles > 0) {
         // ---- loader: chunk pch = i*NTHR + tid -> tile row pch >> 3, physical 16-byte slot pch & 7 holding logical chunk
         // slot ^ ((row >> 1) & 7) of the row's 128-byte block
-        const char *gB[NLD];
-        int rowA[NLD], offA[NLD];
+        int voffA[NLD], voffB[NLD];                              // byte offset of the lane's chunk i inside the bank / query tile
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
             const int pch = i * NTHR + tid;
             const int r = pch >> 3, slot = pch & 7;
             const int c = slot ^ ((r >> 1) & 7);
-            rowA[i] = r; offA[i] = c << 4;
-            gB[i] = p.q2 + ((int64_t)qt * T_ + r) * p.ldq2 + (c << 4);      // the query copy is padded to whole tiles
+            voffA[i] = r * (int)p.ldb2 + (c << 4);
+            voffB[i] = r * (int)p.ldq2 + (c << 4);
         }
         const int wave_chunk = wave * 1024;
-
-        // bank rows of the tile the loader points at: clamped row offsets, recomputed when the loader moves to another tile
-        // (once per nkt stages), so that a request is one 64-bit add (per request they were 10 VALU instructions)
-        const char *gA[NLD];
+        // the query copy is padded to whole tiles
+        const __amdgpu_buffer_rsrc_t rsB = pk_rsrc(p.q2 + (int64_t)(DBG == 2 ? 0 : qt) * T_ * p.ldq2, (int64_t)T_ * p.ldq2);
+        // the bank tile the loader points at: a buffer resource over its rows (rows beyond the bank read as zero; the epilogue
+        // masks them), rebuilt when the loader moves to another tile (once per nkt stages, on the scalar unit)
+        __amdgpu_buffer_rsrc_t rsA;
         auto point_at_tile = [&](int tile) {
-#pragma unroll
-            for (int i = 0; i < NLD; ++i) {
-                int64_t brow = (int64_t)(DBG == 2 ? 0 : tile) * T_ + rowA[i];
-                if (brow > p.n_rows - 1) brow = p.n_rows - 1;
-                gA[i] = p.bank2 + brow * p.ldb2 + offA[i];
-            }
+            const int t0 = DBG == 2 ? 0 : tile;
+            int64_t rows = (int64_t)p.n_rows - (int64_t)t0 * T_;
+            if (rows > T_) rows = T_;
+            rsA = pk_rsrc(p.bank2 + (int64_t)t0 * T_ * p.ldb2, rows * p.ldb2);
         };
         auto stage_load_part = [&](int stage, int kt, int i) {
             char *sA = smem + stage * STAGE;
             char *sB = sA + OPB;
-            pk_glds16(gA[i] + kt * PK_ROWB, sA + i * (NTHR * 16) + wave_chunk);
-            pk_glds16(gB[i] + kt * PK_ROWB - (DBG == 2 ? (int64_t)qt * T_ * p.ldq2 : 0), sB + i * (NTHR * 16) + wave_chunk);
+            pk_blds16(rsA, voffA[i], kt * PK_ROWB, sA + i * (NTHR * 16) + wave_chunk);
+            pk_blds16(rsB, voffB[i], kt * PK_ROWB, sB + i * (NTHR * 16) + wave_chunk);
         };
 
         // fragment read offsets: row * 128 + (chunk ^ swz) * 16, chunk = 4 lo + 2 s + h for K step s (16 channels) of the stage

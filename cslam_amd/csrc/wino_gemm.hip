@@ -41,6 +41,17 @@ __device__ __forceinline__ void wg_glds16(const char *g, char *lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)g,
                                      (__attribute__((address_space(3))) void *)lds_wave_base, 16, 0, 0);
 }
+// LDS-DMA in the MUBUF encoding (round 4; sim_topk_pair.hip has the why: hipcc counts LDS reads again, the K offset travels in an
+// SGPR, the lane's offset is one register, rows beyond `bytes` read as zero)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wg_rsrc(const char *base, int64_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    const uint64_t u = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a);
+    const int n = __builtin_amdgcn_readfirstlane((int)(bytes > 0x7fffffff ? 0x7fffffff : bytes));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)u, 0, n, 0x00020000);
+}
+__device__ __forceinline__ void wg_blds16(__amdgpu_buffer_rsrc_t rs, int voff, int soff, char *lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voff, soff, 0, 0);
+}
 
 struct WinoGemmArgs {
     const char *V2;        // [36][T][Cin/32][128 B]
@@ -90,18 +101,19 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_h2_kernel(WinoGemmArgs p) {
     const int n_mine = j8 < x_cnt ? (x_cnt - j8 + per_xcd - 1) / per_xcd : 0;
     if (n_mine == 0) return;
 
-    const int64_t pitch = (int64_t)p.nk * WG_ROWB;     // bytes per row (both operands)
-    // loader geometry: chunk pch = i * 512 + tid -> row pch >> 3, physical slot pch & 7 holding logical chunk slot ^ swz(row)
-    int rowA[NLA], offA[NLA], rowB[NLB], offB[NLB];
+    const int pitch = p.nk * WG_ROWB;                  // bytes per row (both operands)
+    // loader geometry: chunk pch = i * 512 + tid -> row pch >> 3, physical slot pch & 7 holding logical chunk slot ^ swz(row):
+    // the lane's byte offset inside the item's row block of either operand
+    int voffA[NLA], voffB[NLB];
 #pragma unroll
     for (int i = 0; i < NLA; ++i) {
         const int pch = i * 512 + tid, r = pch >> 3, slot = pch & 7;
-        rowA[i] = r; offA[i] = (slot ^ ((r >> 1) & 7)) << 4;
+        voffA[i] = r * pitch + ((slot ^ ((r >> 1) & 7)) << 4);
     }
 #pragma unroll
     for (int i = 0; i < NLB; ++i) {
         const int pch = i * 512 + tid, r = pch >> 3, slot = pch & 7;
-        rowB[i] = r; offB[i] = (slot ^ ((r >> 1) & 7)) << 4;
+        voffB[i] = r * pitch + ((slot ^ ((r >> 1) & 7)) << 4);
     }
     const int wave_chunk = wave * 1024;
 
@@ -115,24 +127,20 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_h2_kernel(WinoGemmArgs p) {
         c.xi = rest / p.n_mt;
         return c;
     };
-    // per-lane source addresses of K block 0 of the item the loader is in (recomputed only at item boundaries)
-    const char *gA[NLA], *gB[NLB];
+    // buffer resources over the row blocks of the item the loader is in (rebuilt only at item boundaries, on the scalar unit);
+    // tile rows beyond T read as zero and are never stored
+    __amdgpu_buffer_rsrc_t rsA, rsB;
     auto point_at = [&](const Item &c) {
-#pragma unroll
-        for (int i = 0; i < NLA; ++i) {
-            int64_t row = (int64_t)c.mt * TM + rowA[i];
-            if (row > p.T - 1) row = p.T - 1;
-            gA[i] = p.V2 + ((int64_t)c.xi * p.T + row) * pitch + offA[i];
-        }
-#pragma unroll
-        for (int i = 0; i < NLB; ++i)
-            gB[i] = p.U2 + ((int64_t)c.xi * p.Cout + (int64_t)c.nt * TN + rowB[i]) * pitch + offB[i];
+        int64_t rows = (int64_t)p.T - (int64_t)c.mt * TM;
+        if (rows > TM) rows = TM;
+        rsA = wg_rsrc(p.V2 + ((int64_t)c.xi * p.T + (int64_t)c.mt * TM) * pitch, rows * pitch);
+        rsB = wg_rsrc(p.U2 + ((int64_t)c.xi * p.Cout + (int64_t)c.nt * TN) * pitch, (int64_t)TN * pitch);
     };
     auto load_part_a = [&](int stage, int kt, int i) {
-        wg_glds16(gA[i] + kt * WG_ROWB, smem + stage * STAGE + i * (512 * 16) + wave_chunk);
+        wg_blds16(rsA, voffA[i], kt * WG_ROWB, smem + stage * STAGE + i * (512 * 16) + wave_chunk);
     };
     auto load_part_b = [&](int stage, int kt, int i) {
-        wg_glds16(gB[i] + kt * WG_ROWB, smem + stage * STAGE + OPA + i * (512 * 16) + wave_chunk);
+        wg_blds16(rsB, voffB[i], kt * WG_ROWB, smem + stage * STAGE + OPA + i * (512 * 16) + wave_chunk);
     };
 
     // fragment read offsets: row * 128 + ((chunk) ^ swz) * 16, chunk = 4 * lo + 2 * s + h for K step s of the stage
@@ -705,13 +713,14 @@ CSLAM_API int cslam_wino_gemm_h2_dev(const void *d_V2, const void *d_U2, int64_t
 #endif
     const int cfg = c ? atoi(c) : 0;            // force a tile / ring shape (1..5 below); 0 = default
     hipStream_t st = (hipStream_t)stream;
-    // default: 256 x 128 tiles with the ring of three stages -- the fastest or within 4 % of the fastest shape on every
-    // layer of the VGG-16 trunk at the 256-frame chunk (interleaved medians, profiles/r02_v4_perf_wino_gemm.log).  The waves as
-    // 4 x 2 instead of 2 x 4 (cfg 5: 64 x 64 wave tiles, 8 instead of 10 fragment reads per 12 MFMAs) is the same speed: -3 .. +5 %
-    // per layer from run to run, 16.06 against 16.02 ms on whole trunk passes (profiles/r03_v33_perf_wino_gemm_wave_grid.log)
+    // default (cfg 5): 256 x 128 tiles, ring of three stages, the eight waves as 4 x 2 = 64 x 64 wave tiles: 8 fragment reads per 12
+    // MFMAs (2 x 4 waves = 128 x 32 wave tiles, cfg 2, the default until round 4: 10).  With `global_load_lds` the two were the same
+    // speed (profiles/r03_v33_perf_wino_gemm_wave_grid.log); with the buffer form of the LDS-DMA, under which hipcc counts LDS reads
+    // instead of draining them, cfg 5 is 4-6 % faster on every layer (profiles/r04_v22_perf_wino_gemm_shapes_mubuf.log): what is left
+    // is LDS bandwidth -- per stage and CU 128 KB of fragment reads + 48 KB of DMA writes = 1400 LDS cycles under 1536 matrix cycles.
     const bool wide = (Cout % 256) == 0;
     int use = cfg;
-    if (use < 1 || use > 5 || ((use == 1 || use == 3) && !wide)) use = 2;
+    if (use < 1 || use > 5 || ((use == 1 || use == 3) && !wide)) use = 5;
     switch (use) {
     case 1: return wino_gemm_launch<256, 256, 2>(a, dbg, st);      // double buffer, 256 x 256
     case 2: return wino_gemm_launch<256, 128, 3>(a, dbg, st);      // ring of 3, 256 x 128
@@ -734,7 +743,7 @@ int cslam_pair_gemm_launch(const void *d_A2, const void *d_B2, int nxi, int64_t 
     a.T = (int)T; a.Cin = K; a.Cout = N; a.nk = K / 32;
     a.n_mt = a.n_nt = a.n_items = 0;
     a.nxi = nxi;
-    return wino_gemm_launch<256, 128, 3>(a, 0, st);
+    return wino_gemm_launch<256, 128, 3, 4>(a, 0, st);
 }
 
 /* The Z form (wino_zgemm_h2_kernel above): d_Z [24][T][Cout] float32, plane 4 i + q = sum_j (V U)[6 i + j] A^T[q][j]; finished by
