@@ -478,13 +478,13 @@ def main():
         lh, msh, flh, byh, lm, msm, flm, bym = trunk_times
         per_step = (msh + msm) / trunk_steps
         roofline_step_largest = {
-            "kernel": "wino_zgemm_h2_kernel / wino_gemm_h2_kernel (the trunk's 36-frequency pair products)",
+            "kernel": "wino_gemm_h2_kernel (the 36-frequency pair products of conv3_1 ... conv5_3)",
             "launches_per_step": round((lh + lm) / trunk_steps, 1), "ms_per_step": round(per_step, 3),
             "share_of_step": round(per_step / (trunk_step_ms if trunk_step_ms is not None else dt / a.steps * 1e3), 4),
             "one_lane_step_ms": None if trunk_step_ms is None else round(trunk_step_ms, 3),
             "source": trunk_src,
             "hbm_bound_layers": None if lh == 0 else {
-                "what": "Cin <= 256 (conv2_2 ... conv4_1): V2 in + M / Z out", "bound": "hbm", "launches": int(lh),
+                "what": "Cin <= 256 (conv3_1 ... conv4_1): V2 in + M out", "bound": "hbm", "launches": int(lh),
                 "kernel_ms": round(msh / lh, 4), "achieved": round(byh / msh / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(byh / msh / 1e6 / HBM_PEAK_GBS, 4), "fp16_TFLOPs": round(flh / msh / 1e9, 1)},
             "mfma_bound_layers": None if lm == 0 else {
@@ -551,12 +551,14 @@ def main():
                             "frac_of_measured": round(gbs2 / peaks["hbm_copy_GBs"], 4) if peaks["hbm_copy_GBs"] else None,
                             "traffic": ph["traffic_bytes"] if ph else None, "traffic_source": ph["source"] if ph else None,
                             "algorithmic_bytes": nbytes, "kernel_ms": round(ms2, 3), "shape": shape_h2,
-                            "note": "the trunk's input transform (fp16-pair V) on conv2_2's shape; the other kernels of the "
-                                    "extract pass follow: pair_gemm, fused_conv, stem_conv",
+                            "note": "the trunk's input transform (fp16-pair V) on the shape its PMC passes were collected on (conv2_2's: "
+                                    "that layer runs through the direct kernel since round 4; the transform's largest launch in a pass "
+                                    "is conv3_1's, a quarter of this one); the other kernels of the extract pass follow: pair_gemm, "
+                                    "direct_conv, stem_conv",
                             "fp32_input_transform": legacy}
         del xt, vt, xh
         # this library's split-fp16 GEMM between the transforms (csrc/wino_gemm.hip), on the two regimes of the trunk:
-        # conv2_2 (128 -> 128 channels, 200704 tile rows: HBM-bound, V2 in + M out) and conv4_2 (512 -> 512, 12544 rows:
+        # conv3_2 (256 -> 256 channels, 50176 tile rows: HBM-bound, V2 in + M out) and conv4_2 (512 -> 512, 12544 rows:
         # the matrix pipe matters; 3 fp16 MFMA products per fp32-grade product)
         def time_ms(fn, n=5):
             fn()
@@ -567,7 +569,7 @@ def main():
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / n
         gem = {}
-        for tag, hw, cin, cout in (("conv2_2", 112, 128, 128), ("conv4_2", 28, 512, 512)):
+        for tag, hw, cin, cout in (("conv3_2", 56, 256, 256), ("conv4_2", 28, 512, 512)):
             T_ = eb * (hw // 4) * (hw // 4)
             v2 = (torch.randn((36 * T_ * 2 * cin,), device=dev) * 100.0).to(torch.float16)
             u2 = (torch.randn((36 * cout * 2 * cin,), device=dev) * 100.0).to(torch.float16)
@@ -586,37 +588,44 @@ def main():
                         "mfma": {"achieved": round(fl16 / gms / 1e9, 1), "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (fp16, 3 products)",
                                  "frac": round(fl16 / gms / 1e9 / FP16_MFMA_PEAK_TFLOPS, 4),
                                  "fp32_equivalent_TFLOPs": round(fl16 / 3 / gms / 1e9, 1)},
-                        "bound": "hbm" if tag == "conv2_2" else "mfma"}
+                        "bound": "hbm" if tag == "conv3_2" else "mfma"}
             del v2, u2, mo
         extract_roofline["pair_gemm"] = gem
-        # the largest single kernel of the extract leg: the one-kernel Winograd convolution conv1_2 in its fp16-pair form
-        # (csrc/wino_fused_h.hip).  Its floor is what it moves: activation in + pooled activation out (HBM); the matrix
-        # work is 3 fp16 products' worth folded into 2 MFMAs per frequency and quarter
-        fh = 224
-        xf = torch.relu(torch.randn((eb, 64, fh, fh), device=dev)).contiguous(memory_format=torch.channels_last)
+        # conv2_1 / conv2_2: the direct one-kernel convolution on fp16 pairs (csrc/conv_direct_h.hip, round 4): implicit GEMM over the
+        # nine taps, 3 fp16 MFMA products per fp32-grade product; HBM sees the activation in (x 1.27 halo) and out
         from cslam_amd.vpr import winograd as wg
+        dconv = {}
+        for tag, cin, pool in (("conv2_2", 128, True), ("conv2_1", 64, False)):
+            xd = torch.relu(torch.randn((eb, cin, 112, 112), device=dev)).contiguous(memory_format=torch.channels_last)
+            wd = torch.randn((128, cin, 3, 3), device=dev) / (3.0 * cin ** 0.5)
+            bd = torch.randn(128, device=dev)
+            Wd = wg.direct_pair_weights(wd)
+            sd = torch.zeros(1, dtype=torch.float32, device=dev)
+            _lib.check(lib.cslam_absmax_dev(xd.data_ptr(), xd.numel(), sd.data_ptr(), st))
+            dms = time_ms(lambda: wg.conv3x3_direct_h(xd, Wd, bd, True, pool, sd, None))
+            dfl = 3 * 2.0 * eb * 112 * 112 * 9 * cin * 128
+            dby = (xd.numel() + eb * 128 * 112 * 112 // (4 if pool else 1)) * 4
+            shape_d = f"x [{eb},112,112,{cin}] -> conv {cin}->128 + bias + ReLU" + (" + MaxPool2d" if pool else "")
+            pd_ = pmc_entry("conv3x3_direct_h_kernel/" + tag, shape=shape_d)
+            dconv[tag] = {"bound": "mfma", "kernel": "conv3x3_direct_h_kernel", "shape": shape_d, "kernel_ms": round(dms, 3),
+                          "achieved": round(dfl / dms / 1e9, 1), "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (fp16, 3 products)",
+                          "frac": round(dfl / dms / 1e9 / FP16_MFMA_PEAK_TFLOPS, 4),
+                          "fp32_equivalent_TFLOPs": round(dfl / 3 / dms / 1e9, 1),
+                          "hbm_algorithmic_bytes": dby, "hbm_GBs": round(dby / dms / 1e6, 1),
+                          "traffic": pd_["traffic_bytes"] if pd_ else None, "traffic_source": pd_["source"] if pd_ else None,
+                          "matrix_pipe_busy_pmc": pd_.get("mfma_busy_frac") if pd_ else None}
+            del xd
+        extract_roofline["direct_conv"] = dconv
+        fh = 224
         wf = torch.randn((64, 64, 3, 3), device=dev) / 24.0
         U4f = wg.wino_weights(wf, 4).to(dev)
-        Uhf, Upf = wg.fused64_pair_weights(U4f), wg.fused64_weights(U4f)
+        Uhf = wg.fused64_pair_weights(U4f)
         bf = torch.randn(64, device=dev)
+        # conv1_2 alone (fp16-pair one-kernel Winograd form, csrc/wino_fused_h.hip): the stem kernel's A/B partner
+        xf = torch.relu(torch.randn((eb, 64, fh, fh), device=dev)).contiguous(memory_format=torch.channels_last)
         slot = torch.zeros(1, dtype=torch.float32, device=dev)
         _lib.check(lib.cslam_absmax_dev(xf.data_ptr(), xf.numel(), slot.data_ptr(), st))
         fms = time_ms(lambda: wg.wino_fused64_h(xf, Uhf, bf, True, True, slot, None))
-        fms32 = time_ms(lambda: wg.wino_fused64(xf, Upf, bf, True, True))
-        fflop = eb * (fh // 4) * (fh // 4) * 36 * 2 * 64 * 64
-        fbytes = (xf.numel() + xf.numel() // 4) * 4
-        shape_f = f"x [{eb},{fh},{fh},64] -> conv 64->64 + bias + ReLU + MaxPool2d"
-        pf = pmc_entry("wino4_fused_c64_h_kernel/conv1_2", shape=shape_f)
-        extract_roofline["fused_conv"] = {
-            "bound": "hbm", "kernel": "wino4_fused_c64_h_kernel", "achieved": round(fbytes / fms / 1e6, 1),
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(fbytes / fms / 1e6 / HBM_PEAK_GBS, 4),
-            "peak_measured": peaks["hbm_copy_GBs"], "frac_of_measured": round(fbytes / fms / 1e6 / peaks["hbm_copy_GBs"], 4),
-            "kernel_ms": round(fms, 3), "algorithmic_bytes": fbytes, "traffic": pf["traffic_bytes"] if pf else None,
-            "traffic_source": pf["source"] if pf else None,
-            "fp32_equivalent_TFLOPs": round(fflop / fms / 1e9, 1),
-            "f32_mfma_form_ms": round(fms32, 3),
-            "f32_mfma_form_frac_of_f32_mfma_peak": round(fflop / fms32 / 1e9 / FP32_MFMA_PEAK_TFLOPS, 4),
-            "shape": shape_f + f" -> [{eb},{fh // 2},{fh // 2},64]"}
         del xf
         # the trunk's first TWO convolutions as one launch (conv1_1 folded into the kernel above, csrc/wino_fused_h.hip STEM):
         # the 64-channel map between them (3.3 GB per 256 frames, written and read back) never exists in HBM.  Its floor is the
@@ -733,11 +742,11 @@ def main():
             "backbone_conv": None if extractor is None else extractor.backbone_conv,
             "trunk_gemm": None if extractor is None or extractor.backbone_conv != "winograd" else (
                 "plain fp32 (rocBLAS sgemm)" if split16 == "0" else
-                "conv2_2 ... conv5_3 (from 128 input channels on): this library's GEMM (csrc/wino_gemm.hip) over exact fp16 hi/lo "
+                "conv3_1 ... conv5_3: F(4x4) Winograd with this library's GEMM (csrc/wino_gemm.hip) over exact fp16 hi/lo "
                 "pairs of both operands, 3 of the 4 partial products on the fp16 MFMA pipe with fp32 accumulation (error vs "
                 "float64 = that of the fp32 GEMM, tests/test_heads_gpu.py::test_split16_*, tests/test_wino_gemm_gpu.py); "
-                "conv1_1 + conv1_2: ONE kernel (first layer folded into the one-kernel Winograd convolution, fp16 pairs), conv2_1: "
-                "one-kernel Winograd convolution on fp16 pairs (csrc/wino_fused_h.hip)"),
+                "conv1_1 + conv1_2: ONE kernel (first layer folded into the one-kernel Winograd convolution, fp16 pairs, "
+                "csrc/wino_fused_h.hip); conv2_1, conv2_2: the direct one-kernel convolution on fp16 pairs (csrc/conv_direct_h.hip)"),
             "extract_only_fp32_gemms": None if extract_fp32_gemms is None else round(extract_fp32_gemms, 2),
             "match_only": round(match_only, 2),
             "match_only_queries": nqm,
