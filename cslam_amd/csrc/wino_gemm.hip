@@ -27,6 +27,7 @@
 // Bound: HBM for Cin <= 256 (V2 in + M out = 4 (Cin + Cout) bytes per tile row and frequency against 6 Cin Cout flop),
 // about balanced at 512 x 512.
 #include "common.h"
+#include <type_traits>
 #include <hip/hip_fp16.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -287,6 +288,200 @@ __global__ __launch_bounds__(512, 2) void wino_gemm_h2_kernel(WinoGemmArgs p) {
                 for (int n = 0; n < NT; ++n)
                     if (st_on && row_base + ro < p.T) __builtin_nontemporal_store(acc[m][n][r], mo + (int64_t)ro * p.Cout + 32 * n);
             }
+    }
+}
+
+// ---- the same products on FOUR waves of 512 registers ("big" form, round 4; CSLAM_WGEMM_CFG=6; the default for Cin >= 512) -------
+// What bounds the eight-wave kernel above is LDS volume: with 64 accumulator registers per lane a wave reads 8 fragments (8 KB) per
+// 12 MFMAs -- per stage and CU 128 KB of reads + 48 KB of DMA writes = 1400 LDS cycles under 1536 matrix cycles, and the counters
+// show the two units busy one after the other.  One wave per SIMD may use the whole register file: wave tile 128 x 128 = 256
+// accumulators (AGPRs), 16 fragments per 48 MFMAs -- half the LDS bytes per MFMA (PMC: SQ_LDS_IDX_ACTIVE halves, matrix pipe busy
+// 0.53 -> 0.62 of its cycles on conv4_2).  With nobody else on the SIMD to cover a wave's waits everything is software-pipelined
+// inside the wave: fragments in two register sets (K step 1 read under the MFMAs of K step 0, the stage's last K step multiplied
+// BEHIND the barrier), the next stage's 16 LDS-DMA requests spread over the first half of the stage, an item's first K step starts
+// its accumulators from the constant 0.  256 x 256 tiles, double-buffered 64 KB stages; Cout a multiple of 256.
+// Measured and not kept: stages of ONE K step in a ring of four (requests three stages ahead): the 256 stores of a tile cannot be
+// counted in a 6-bit vmcnt, requests return in order, so whatever is requested behind the stores is confirmed only when they have
+// drained -- with twice the barriers it came out 7 % slower than this form (profiles/r04_v37_perf_wino_gemm_big.log).
+template <int DBG>
+__global__ __launch_bounds__(256, 1) void wino_gemm_h2_big_kernel(WinoGemmArgs p) {
+    constexpr int TM = 256, TN = 256, MT = 4, NT = 4;
+    constexpr int OPA = TM * WG_ROWB, OPB = TN * WG_ROWB;
+    constexpr int STAGE = OPA + OPB;
+    constexpr int NLA = TM * 8 / 256, NLB = TN * 8 / 256;   // 8 + 8 sixteen-byte chunks per thread per stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+
+    const int xcd = blockIdx.x & 7, j8 = blockIdx.x >> 3, per_xcd = gridDim.x >> 3;
+    const int q8 = p.n_items >> 3, r8 = p.n_items & 7;
+    const int x_beg = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+    const int x_cnt = q8 + (xcd < r8 ? 1 : 0);
+    const int n_mine = j8 < x_cnt ? (x_cnt - j8 + per_xcd - 1) / per_xcd : 0;
+    if (n_mine == 0) return;
+
+    const int pitch = p.nk * WG_ROWB;
+    // chunk pch = i * 256 + tid -> row pch >> 3, physical slot pch & 7 holding logical chunk slot ^ swz(row); both operands alike
+    int voff[NLA];
+#pragma unroll
+    for (int i = 0; i < NLA; ++i) {
+        const int pch = i * 256 + tid, r = pch >> 3, slot = pch & 7;
+        voff[i] = r * pitch + ((slot ^ ((r >> 1) & 7)) << 4);
+    }
+    const int wave_chunk = wave * 1024;
+
+    struct Item { int xi, mt, nt; };
+    auto decode = [&](int k) {
+        const int it = x_beg + j8 + k * per_xcd;
+        Item c;
+        c.nt = it % p.n_nt;
+        const int rest = it / p.n_nt;
+        c.mt = rest % p.n_mt;
+        c.xi = rest / p.n_mt;
+        return c;
+    };
+    __amdgpu_buffer_rsrc_t rsA, rsB;
+    auto point_at = [&](const Item &c) {
+        int64_t rows = (int64_t)p.T - (int64_t)c.mt * TM;
+        if (rows > TM) rows = TM;
+        rsA = wg_rsrc(p.V2 + ((int64_t)c.xi * p.T + (int64_t)c.mt * TM) * pitch, rows * pitch);
+        rsB = wg_rsrc(p.U2 + ((int64_t)c.xi * p.Cout + (int64_t)c.nt * TN) * pitch, (int64_t)TN * pitch);
+    };
+    auto load_part = [&](int stage, int kt, int i) {          // parts 0..7: A, 8..15: B
+        if (i < NLA) wg_blds16(rsA, voff[i], kt * WG_ROWB, smem + stage * STAGE + i * (256 * 16) + wave_chunk);
+        else wg_blds16(rsB, voff[i - NLA], kt * WG_ROWB, smem + stage * STAGE + OPA + (i - NLA) * (256 * 16) + wave_chunk);
+    };
+
+    const int swz = (lane >> 1) & 7;
+    int foff[2][2];                                    // [s][lo]
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int lo = 0; lo < 2; ++lo) foff[s][lo] = ((4 * lo + 2 * s + h) ^ swz) << 4;
+    const int arow0 = (wm * 128 + l31) * WG_ROWB;
+    const int brow0 = (wn * 128 + l31) * WG_ROWB;
+
+    f32x16 acc[MT][NT];
+    f16x8 fa[2][2][MT], fb[2][2][NT];                         // [register set][hi | lo][tile]
+    auto read_frags = [&](int u, const char *sA, const char *sB, int s) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            fa[u][0][m] = *(const f16x8 *)(sA + arow0 + m * 32 * WG_ROWB + foff[s][0]);
+            fa[u][1][m] = *(const f16x8 *)(sA + arow0 + m * 32 * WG_ROWB + foff[s][1]);
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            fb[u][0][n] = *(const f16x8 *)(sB + brow0 + n * 32 * WG_ROWB + foff[s][0]);
+            fb[u][1][n] = *(const f16x8 *)(sB + brow0 + n * 32 * WG_ROWB + foff[s][1]);
+        }
+    };
+    // 48 MFMAs: hi.hi, lo.hi, hi.lo over the 16 tiles; ZERO = an item's first K step: the accumulators start from the constant 0 (no
+    // 256 register writes per item to clear them)
+    auto multiply = [&](int u, auto zero_tag) {
+        constexpr bool ZERO = decltype(zero_tag)::value;
+        const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u][0][m], fb[u][0][n], ZERO ? z : acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u][1][m], fb[u][0][n], acc[m][n], 0, 0, 0);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u][0][m], fb[u][1][n], acc[m][n], 0, 0, 0);
+    };
+
+    // loader: one stage ahead (double buffer).  Which stage that is follows from the K loop's position: the same item's next K block,
+    // or -- in an item's last stage -- the next item's first (behind the workgroup's last item: its own last block once more, into the
+    // idle buffer).  The resources move to the next item right before an item's last stage.
+    point_at(decode(0));
+#pragma unroll
+    for (int i = 0; i < NLA + NLB; ++i) load_part(0, 0, i);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+
+    int cur = 0;
+    auto stage = [&](auto first_tag, auto last_tag, int kt_load) {
+        constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
+        const char *sA = smem + cur * STAGE;
+        const char *sB = sA + OPA;
+        // ---- behind the barrier: K step 0's fragments, ALL of the next stage's requests (they have the rest of this stage to land: the
+        // wait at its end is vmcnt(0)), the previous stage's K step 1
+        read_frags(0, sA, sB, 0);
+        if (DBG != 2) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) load_part(cur ^ 1, kt_load, i);
+        }
+        if constexpr (!FIRST) {
+            multiply(1, std::false_type{});
+            __builtin_amdgcn_sched_group_barrier(0x100, 16, 0);      // DS read
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);   // MFMA
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);   // VMEM read (LDS-DMA)
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- K step 0 under the reads of K step 1
+        read_frags(1, sA, sB, 1);
+        multiply(0, first_tag);
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 5, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (LAST) multiply(1, std::false_type{});
+        __builtin_amdgcn_s_waitcnt(0);                               // the next stage has landed, my reads of this one are done
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        cur ^= 1;
+    };
+    for (int k_item = 0; k_item < n_mine; ++k_item) {
+        const Item c = decode(k_item);
+        const bool more = k_item + 1 < n_mine;
+        const int kt_after = more ? 0 : p.nk - 1;                    // what an item's last stage requests
+        if (p.nk == 1) {
+            if (more) point_at(decode(k_item + 1));
+            stage(std::true_type{}, std::true_type{}, kt_after);
+        } else {
+            stage(std::true_type{}, std::false_type{}, 1);
+            for (int kt = 1; kt + 1 < p.nk; ++kt) stage(std::false_type{}, std::false_type{}, kt + 1);
+            if (more) point_at(decode(k_item + 1));
+            stage(std::false_type{}, std::true_type{}, kt_after);
+        }
+        // ---- the finished item: lane = column, 128-byte runs per row; issued behind the barrier, drains under the next item's first stage
+        const int row_base = c.mt * TM + wm * 128 + 4 * h;
+        float *mo = p.M + ((int64_t)c.xi * p.T + row_base) * p.Cout + c.nt * TN + wn * 128 + l31;
+        const bool full = c.mt * TM + wm * 128 + 128 <= p.T;        // wave-uniform: no per-row test
+        const bool st_on = DBG != 1 || p.T < 0;
+        if (full) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        if (st_on) __builtin_nontemporal_store(acc[m][n][r], mo + (int64_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * p.Cout + 32 * n);
+        } else {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ro = m * 32 + (r & 3) + 8 * (r >> 2);
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        if (st_on && row_base + ro < p.T) __builtin_nontemporal_store(acc[m][n][r], mo + (int64_t)ro * p.Cout + 32 * n);
+                }
+        }
     }
 }
 
@@ -693,6 +888,33 @@ static int wino_gemm_launch(WinoGemmArgs a, int dbg, hipStream_t st) {
     return CSLAM_OK;
 }
 
+static int wino_gemm_big_launch(WinoGemmArgs a, int dbg, hipStream_t st) {
+    int n_cu = cslam_cu_count();
+    ARG_CHECK(n_cu > 0, "no HIP device");
+    if (n_cu < 8) n_cu = 8;
+    a.n_mt = (int)ceil_div64(a.T, 256);
+    a.n_nt = a.Cout / 256;
+    const int64_t items = (int64_t)a.nxi * a.n_mt * a.n_nt;
+    ARG_CHECK(items < (1LL << 31), "too many work items");
+    a.n_items = (int)items;
+    constexpr int lds = 2 * (256 + 256) * WG_ROWB;                    // two 64 KB stages
+    int grid = n_cu - n_cu % 8;
+    if ((int64_t)grid > round_up64(a.n_items, 8)) grid = (int)round_up64(a.n_items, 8);
+    static DeviceOnce once;
+    int once_dev;
+    if (once.todo(&once_dev)) {
+        HIP_TRY(hipFuncSetAttribute((const void *)wino_gemm_h2_big_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        once.done(once_dev);
+    }
+    int tslot;
+    tt_begin(st, tslot);
+    hipLaunchKernelGGL((wino_gemm_h2_big_kernel<0>), dim3(grid), dim3(256), lds, st, a);
+    if (a.nxi == 36) tt_end(st, tslot, a, 36);
+    HIP_TRY(hipGetLastError());
+    (void)dbg;
+    return CSLAM_OK;
+}
+
 CSLAM_API int cslam_wino_gemm_h2_dev(const void *d_V2, const void *d_U2, int64_t T, int Cin, int Cout, float *d_M,
                                      void *stream) {
     PTR_DEVICE(d_V2);
@@ -720,7 +942,11 @@ CSLAM_API int cslam_wino_gemm_h2_dev(const void *d_V2, const void *d_U2, int64_t
     // is LDS bandwidth -- per stage and CU 128 KB of fragment reads + 48 KB of DMA writes = 1400 LDS cycles under 1536 matrix cycles.
     const bool wide = (Cout % 256) == 0;
     int use = cfg;
-    if (use < 1 || use > 5 || ((use == 1 || use == 3) && !wide)) use = 5;
+    // 0 / invalid: the default -- the four-wave form from 256 input channels on (conv3_2 ... conv5_3: 3-7 % per layer at Cin = 512, a
+    // tie at 256 -> 256, slower at 128 -> 256), 64 x 64 wave tiles on eight waves elsewhere.  Whole trunk passes, interleaved:
+    // 15.25 ms against 15.47 with the eight-wave form everywhere (profiles/r04_v33_perf_wino_gemm_big.log, r04_v39_trunk_gemm_cfg_ab.log)
+    if (use < 1 || use > 6 || ((use == 1 || use == 3 || use == 6) && !wide)) use = (wide && Cin >= 256) ? 6 : 5;
+    if (use == 6) return wino_gemm_big_launch(a, dbg, st);          // four waves of 512 registers, 256 x 256 tiles
     switch (use) {
     case 1: return wino_gemm_launch<256, 256, 2>(a, dbg, st);      // double buffer, 256 x 256
     case 2: return wino_gemm_launch<256, 128, 3>(a, dbg, st);      // ring of 3, 256 x 128

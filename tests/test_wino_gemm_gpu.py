@@ -31,7 +31,7 @@ def _pairs_rows(v):
     return torch.stack((hi.view(n, r, k // 32, 32), lo.view(n, r, k // 32, 32)), dim=3).contiguous(), hi, lo
 
 
-@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("rows,cin,cout", [(300, 128, 128), (1024, 256, 256), (257, 512, 512), (5000, 128, 256),
                                            (2049, 256, 512), (64, 32, 128), (70000, 64, 256)])
 def test_pair_gemm_equals_float64(T, rows, cin, cout, cfg, monkeypatch):

@@ -42,7 +42,7 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     tot = {"pair": 0.0, "h3": 0.0, "f32": 0.0}
     print(f"B = {B} frames; CSLAM_WGEMM_DBG = {os.environ.get('CSLAM_WGEMM_DBG', '0')}; pair GEMM shapes CSLAM_WGEMM_CFG: "
-          f"1 = 256x256 double buffer, 2 = 256x128 ring of 3, 3 = 128x256 ring of 3, 4 = 256x128 double buffer, 5 = 256x128 ring of 3 with 64x64 wave tiles")
+          f"1 = 256x256 double buffer, 2 = 256x128 ring of 3, 3 = 128x256 ring of 3, 4 = 256x128 double buffer, 5 = 256x128 ring of 3 with 64x64 wave tiles, 6 = 256x256 on four waves of 512 registers (128x128 wave tiles)")
     for name, hw, cin, cout in LAYERS:
         torch.manual_seed(1)
         x = torch.relu(torch.randn((B, cin, hw, hw), device="cuda")).contiguous(memory_format=torch.channels_last)
@@ -60,7 +60,7 @@ def main():
         t_in2 = timed(lambda: _lib.check(lib.cslam_wino4_input_h2_dev(p(x), B, hw, hw, cin, p(slot), p(V2), st)))
         # shapes of the pair GEMM: interleaved rounds (the chip's clock drifts over a run), median per shape
         import statistics
-        cfgs = [c for c in (1, 2, 3, 4, 5) if not (c in (1, 3) and cout % 256)]
+        cfgs = [c for c in (1, 2, 3, 4, 5, 6) if not (c in (1, 3, 6) and cout % 256)]
         samples = {c: [] for c in cfgs}
         for _ in range(4):
             for c in cfgs:
