@@ -59,9 +59,9 @@ __device__ __forceinline__ void pk_blds16(__amdgpu_buffer_rsrc_t rs, int voff, i
 
 // ---- tile epilogue: lane-local candidate update from the finished 32 MT x 64 wave tile, then clear the accumulators
 // (a lane's 16 accumulator registers of a tile belong to ONE query column: no cross-lane traffic)
-template <int MT, int KPL>
-__device__ __forceinline__ void pair_tile_epilogue(f32x16 (&acc)[MT][2], float (&lk)[2][KPL], int (&li)[2][KPL], const int (&lim)[2],
-                                                   const float (&qmul)[2], const float *__restrict__ invs, int n_rows, int row_base) {
+template <int MT, int KPL, int NTW>
+__device__ __forceinline__ void pair_tile_epilogue(f32x16 (&acc)[MT][NTW], float (&lk)[NTW][KPL], int (&li)[NTW][KPL], const int (&lim)[NTW],
+                                                   const float (&qmul)[NTW], const float *__restrict__ invs, int n_rows, int row_base) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         float inv[16];
@@ -71,7 +71,7 @@ __device__ __forceinline__ void pair_tile_epilogue(f32x16 (&acc)[MT][2], float (
             inv[r] = invs[row < n_rows ? row : n_rows - 1];
         }
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
+        for (int n = 0; n < NTW; ++n) {
             f32x16 keys;
             bool any = false;
             const float thr = lk[n][KPL - 1];
@@ -112,15 +112,15 @@ __device__ __forceinline__ void pair_tile_epilogue(f32x16 (&acc)[MT][2], float (
 
 // ---- block merge: 4 lists per query (2 row-halves of the wave x 2 waves along the bank axis) -> the best KP of them, plus the
 // bound on everything dropped (see sim_topk_mfma_kernel); the LDS of the K loop is reused
-template <int T_, int KPL>
-__device__ __forceinline__ void pair_block_merge(char *smem, float (&lk)[2][KPL], int (&li)[2][KPL], int wn, int wm, int h, int l31,
+template <int T_, int KPL, int NTW>
+__device__ __forceinline__ void pair_block_merge(char *smem, float (&lk)[NTW][KPL], int (&li)[NTW][KPL], int wn, int wm, int h, int l31,
                                                  int tid, int qt, int seg, const PairArgs &p) {
     __syncthreads();
     float *mk = (float *)smem;                       // [T_][4][KPL]
     int *mi = (int *)(smem + T_ * 4 * KPL * 4);      // [T_][4][KPL]
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        int qcol = wn * 64 + n * 32 + l31;
+    for (int n = 0; n < NTW; ++n) {
+        int qcol = wn * (32 * NTW) + n * 32 + l31;
         int src = wm * 2 + h;
 #pragma unroll
         for (int j = 0; j < KPL; ++j) {
@@ -168,10 +168,13 @@ __device__ __forceinline__ void pair_block_merge(char *smem, float (&lk)[2][KPL]
 // NPROD = 1: operands are fp16 rows, a stage = 64 channels = four K steps of one MFMA per tile.
 // DBG != 0 (builds with -DCSLAM_ABLATIONS only): TIMING-ONLY ablations (wrong results): 1 = no global loads after the first stage,
 // 2 = every workgroup loads bank tile 0 / query tile 0 over and over (every request an L2 hit: the structure at L2 latency).
-template <int T_, int MT, int KPL, int NPROD, int DBG>
-__global__ __launch_bounds__(T_ * 2, 2) void sim_topk_pair_kernel(PairArgs p) {
-    constexpr int NTHR = T_ * 2;
-    constexpr int NWN = T_ / 64;
+// NTW = 32-query MFMA tiles per wave along the query axis: 2 = eight waves of 256 registers (wave tile 128 x 64), 4 = FOUR waves of 512
+// registers (wave tile 128 x 128: 256 accumulators in AGPRs, 8 fragment reads per 16 MFMAs instead of 6 per 8 -- a third fewer LDS
+// bytes per MFMA; round 4, after csrc/wino_gemm.hip's four-wave kernel: measured slower here, instantiated in the measurement build only).
+template <int T_, int MT, int KPL, int NPROD, int DBG, int NTW>
+__global__ __launch_bounds__(T_ * 64 / (16 * NTW), NTW == 4 ? 1 : 2) void sim_topk_pair_kernel(PairArgs p) {
+    constexpr int NWN = T_ / (32 * NTW);
+    constexpr int NTHR = 2 * NWN * 64;
     constexpr int OPB = T_ * PK_ROWB;            // bytes of one operand tile (one 32-channel block of T_ rows) in LDS
     constexpr int STAGE = 2 * OPB;
     constexpr int NLD = T_ * 8 / NTHR;           // 16-byte chunks per thread per operand (= 4)
@@ -203,17 +206,17 @@ __global__ __launch_bounds__(T_ * 2, 2) void sim_topk_pair_kernel(PairArgs p) {
         if (t_end > te) t_end = te;
     }
 
-    float lk[2][KPL]; int li[2][KPL];
+    float lk[NTW][KPL]; int li[NTW][KPL];
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < NTW; ++n)
 #pragma unroll
         for (int j = 0; j < KPL; ++j) { lk[n][j] = -INFINITY; li[n][j] = -1; }
-    int lim[2];
-    float qmul[2];
+    int lim[NTW];
+    float qmul[NTW];
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        lim[n] = p.lim[qt * T_ + wn * 64 + n * 32 + l31];
-        qmul[n] = p.qinvs[qt * T_ + wn * 64 + n * 32 + l31];
+    for (int n = 0; n < NTW; ++n) {
+        lim[n] = p.lim[qt * T_ + wn * (32 * NTW) + n * 32 + l31];
+        qmul[n] = p.qinvs[qt * T_ + wn * (32 * NTW) + n * 32 + l31];
     }
 
     const int ntiles = t_end - t_beg;
@@ -257,13 +260,13 @@ __global__ __launch_bounds__(T_ * 2, 2) void sim_topk_pair_kernel(PairArgs p) {
 #pragma unroll
             for (int lo = 0; lo < 2; ++lo) foff[s][lo] = ((4 * lo * (NPROD == 3) + 2 * s + h) ^ swz) << 4;
         const int arow0 = (wm * 32 * MT + l31) * PK_ROWB;
-        const int brow0 = (wn * 64 + l31) * PK_ROWB;
+        const int brow0 = (wn * (32 * NTW) + l31) * PK_ROWB;
 
-        f32x16 acc[MT][2];
+        f32x16 acc[MT][NTW];
 #pragma unroll
         for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+            for (int n = 0; n < NTW; ++n)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
@@ -283,7 +286,7 @@ __global__ __launch_bounds__(T_ * 2, 2) void sim_topk_pair_kernel(PairArgs p) {
         // K step cover most of the read latency, and two fragment sets of hi AND lo halves do not fit beside the accumulators.)
         constexpr int NF = NPROD == 3 ? 2 : 1;           // fragment kinds per operand: hi (| lo)
         constexpr int NBUF = NPROD == 3 ? 1 : 2;         // fragment register sets
-        f16x8 fa[NBUF][NF][MT], fb[NBUF][NF][2];
+        f16x8 fa[NBUF][NF][MT], fb[NBUF][NF][NTW];
 #pragma unroll
         for (int u = 0; u < NBUF; ++u)
 #pragma unroll
@@ -291,7 +294,7 @@ __global__ __launch_bounds__(T_ * 2, 2) void sim_topk_pair_kernel(PairArgs p) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) fa[u][f][m] = (f16x8)(_Float16)0.0f;
 #pragma unroll
-                for (int n = 0; n < 2; ++n) fb[u][f][n] = (f16x8)(_Float16)0.0f;
+                for (int n = 0; n < NTW; ++n) fb[u][f][n] = (f16x8)(_Float16)0.0f;
             }
         auto read_frags = [&](int u, const char *sA, const char *sB, int s) {       // u, s: compile-time after unrolling
 #pragma unroll
@@ -299,27 +302,27 @@ __global__ __launch_bounds__(T_ * 2, 2) void sim_topk_pair_kernel(PairArgs p) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m) fa[u][f][m] = *(const f16x8 *)(sA + arow0 + m * 32 * PK_ROWB + foff[s][f]);
 #pragma unroll
-                for (int n = 0; n < 2; ++n) fb[u][f][n] = *(const f16x8 *)(sB + brow0 + n * 32 * PK_ROWB + foff[s][f]);
+                for (int n = 0; n < NTW; ++n) fb[u][f][n] = *(const f16x8 *)(sB + brow0 + n * 32 * PK_ROWB + foff[s][f]);
             }
         };
         auto multiply = [&](int u) {
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u][0][m], fb[u][0][n], acc[m][n], 0, 0, 0);
+                for (int n = 0; n < NTW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u][0][m], fb[u][0][n], acc[m][n], 0, 0, 0);
             if (NPROD == 3) {
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u][NF - 1][m], fb[u][0][n], acc[m][n], 0, 0, 0);
+                    for (int n = 0; n < NTW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u][NF - 1][m], fb[u][0][n], acc[m][n], 0, 0, 0);
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u][0][m], fb[u][NF - 1][n], acc[m][n], 0, 0, 0);
+                    for (int n = 0; n < NTW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u][0][m], fb[u][NF - 1][n], acc[m][n], 0, 0, 0);
             }
         };
-        constexpr int G = MT * 2 * NPROD;                // MFMAs of a K step: 24 | 12 | 8 | 4
-        constexpr int NRD = NF * (MT + 2);               // fragment reads of a K step: 12 | 8 | 6 | 4
+        constexpr int G = MT * NTW * NPROD;                // MFMAs of a K step: 24 | 12 | 8 | 4
+        constexpr int NRD = NF * (MT + NTW);               // fragment reads of a K step: 12 | 8 | 6 | 4
 
         const int total = ntiles * p.nkt;
         point_at_tile(t_beg);
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(T_ * 2, 2) void sim_topk_pair_kernel(PairArgs p) {
                     }
                 }
                 if (kt == p.nkt - 1)
-                    pair_tile_epilogue<MT, KPL>(acc, lk, li, lim, qmul, p.invs, p.n_rows, tile * T_ + wm * 32 * MT + 4 * h);
+                    pair_tile_epilogue<MT, KPL, NTW>(acc, lk, li, lim, qmul, p.invs, p.n_rows, tile * T_ + wm * 32 * MT + 4 * h);
                 __builtin_amdgcn_s_waitcnt(0);       // next stage landed (vmcnt(0)), this stage's fragment reads done
                 __builtin_amdgcn_s_barrier();
                 kt = nkt_; tile = ntile;
@@ -444,12 +447,12 @@ __global__ __launch_bounds__(T_ * 2, 2) void sim_topk_pair_kernel(PairArgs p) {
                 stage_body(std::true_type{}, tile, 0);
                 for (int kt = 1; kt < p.nkt; ++kt) stage_body(std::false_type{}, tile, kt);
                 multiply((NS - 1) & 1);                                  // the tile's last K step, then its candidates
-                pair_tile_epilogue<MT, KPL>(acc, lk, li, lim, qmul, p.invs, p.n_rows, tile * T_ + wm * 32 * MT + 4 * h);
+                pair_tile_epilogue<MT, KPL, NTW>(acc, lk, li, lim, qmul, p.invs, p.n_rows, tile * T_ + wm * 32 * MT + 4 * h);
             }
         }
     }
 
-    pair_block_merge<T_, KPL>(smem, lk, li, wn, wm, h, l31, tid, qt, seg, p);
+    pair_block_merge<T_, KPL, NTW>(smem, lk, li, wn, wm, h, l31, tid, qt, seg, p);
 }
 
 // Measured and rejected (round 3, profiles/r03_v13_pair_pingpong_rejected.log; code removed): a "ping-pong" form of the 256 x 256
@@ -549,32 +552,42 @@ double pair_err_bound(int kd, int nprod) {
     return 1.0625 * (rep + dropped + accum + keyr + floor_);
 }
 
-template <int T_, int MT, int KPL, int NPROD>
+template <int T_, int MT, int KPL, int NPROD, int NTW = 2>
 static int launch_pair(const PairArgs &a, int dbg, hipStream_t st) {
     constexpr int lds = 2 * 2 * T_ * PK_ROWB;
     static DeviceOnce once;
     int once_dev;
     if (once.todo(&once_dev)) {
-        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_pair_kernel<T_, MT, KPL, NPROD, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_pair_kernel<T_, MT, KPL, NPROD, 0, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
 #ifdef CSLAM_ABLATIONS
-        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_pair_kernel<T_, MT, KPL, NPROD, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_pair_kernel<T_, MT, KPL, NPROD, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_pair_kernel<T_, MT, KPL, NPROD, 1, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_pair_kernel<T_, MT, KPL, NPROD, 2, NTW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
 #endif
         once.done(once_dev);
     }
-    const dim3 grid(a.nqt * a.nseg), blk(T_ * 2);
+    const dim3 grid(a.nqt * a.nseg), blk(T_ * 64 / (16 * NTW));
 #ifdef CSLAM_ABLATIONS
-    if (dbg == 1) { hipLaunchKernelGGL((sim_topk_pair_kernel<T_, MT, KPL, NPROD, 1>), grid, blk, lds, st, a); HIP_TRY(hipGetLastError()); return CSLAM_OK; }
-    if (dbg == 2) { hipLaunchKernelGGL((sim_topk_pair_kernel<T_, MT, KPL, NPROD, 2>), grid, blk, lds, st, a); HIP_TRY(hipGetLastError()); return CSLAM_OK; }
+    if (dbg == 1) { hipLaunchKernelGGL((sim_topk_pair_kernel<T_, MT, KPL, NPROD, 1, NTW>), grid, blk, lds, st, a); HIP_TRY(hipGetLastError()); return CSLAM_OK; }
+    if (dbg == 2) { hipLaunchKernelGGL((sim_topk_pair_kernel<T_, MT, KPL, NPROD, 2, NTW>), grid, blk, lds, st, a); HIP_TRY(hipGetLastError()); return CSLAM_OK; }
 #endif
     (void)dbg;
-    hipLaunchKernelGGL((sim_topk_pair_kernel<T_, MT, KPL, NPROD, 0>), grid, blk, lds, st, a);
+    hipLaunchKernelGGL((sim_topk_pair_kernel<T_, MT, KPL, NPROD, 0, NTW>), grid, blk, lds, st, a);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }
 
 int pair_stage1_launch(const PairArgs &a, int tile, int nprod, int dbg, hipStream_t st) {
-    if (nprod == 1) return tile == 256 ? launch_pair<256, 4, 8, 1>(a, dbg, st) : launch_pair<128, 2, 16, 1>(a, dbg, st);
+    if (nprod == 1) {
+        if (tile != 256) return launch_pair<128, 2, 16, 1>(a, dbg, st);
+#ifdef CSLAM_ABLATIONS
+        // the four-wave form (NTW = 4: 128 x 128 wave tiles, 256 accumulators in AGPRs) is correct -- the suite passes with it -- and
+        // 8 % slower than the eight-wave form on this kernel (94.5 against 85.6-88.2 ms on 100k x 100k, 1.34 against 1.20 ms on the
+        // in-step launch: profiles/r04_v41_match_four_waves_ab.log): with ONE product per fragment pair a K step is 16 MFMAs per 8
+        // reads, and a single wave per SIMD has no partner to fill its waits.  Measurement build only.
+        if (const char *e = getenv("CSLAM_PAIR_WAVES")) if (atoi(e) == 4) return launch_pair<256, 4, 8, 1, 4>(a, dbg, st);
+#endif
+        return launch_pair<256, 4, 8, 1>(a, dbg, st);
+    }
     return tile == 256 ? launch_pair<256, 4, 8, 3>(a, dbg, st) : launch_pair<128, 2, 16, 3>(a, dbg, st);
 }
 
