@@ -464,6 +464,10 @@ def main():
                 "fp16_TFLOPs_issued": round(n_prod * ach, 1) if pair_stage else None, "fp16_products": n_prod if pair_stage else None,
                 "traffic": pm["traffic_bytes"] if pm else None,
                 "traffic_source": (pm["source"] + "; L2 hit rate %.2f" % pm.get("l2_hit_rate", float("nan"))) if pm else None,
+                "traffic_kind": "L2-miss (fabric-side) bytes: Infinity-Cache hits are included, so this is an upper bound of the HBM bytes",
+                "algorithmic_min_bytes": pm.get("algorithmic_min_bytes") if pm else None,
+                "matrix_pipe_busy_pmc": round(pm["mfma_busy_frac"], 3) if pm and pm.get("mfma_busy_frac") else None,
+                "effective_clock_GHz_pmc": round(pm["effective_clock_GHz"], 2) if pm and pm.get("effective_clock_GHz") else None,
                 "source": source}
     roofline_c3 = match_roofline(nqm, match_kernel_ms, "match-only leg (%d queries per launch), HIP events on the launch stream" % nqm, nqm)
     if step_kernel_ms and world == 1:
@@ -478,7 +482,7 @@ def main():
         lh, msh, flh, byh, lm, msm, flm, bym = trunk_times
         per_step = (msh + msm) / trunk_steps
         roofline_step_largest = {
-            "kernel": "wino_gemm_h2_kernel (the 36-frequency pair products of conv3_1 ... conv5_3)",
+            "kernel": "wino_gemm_h2_big_kernel / wino_gemm_h2_kernel (the 36-frequency pair products of conv3_1 ... conv5_3)",
             "launches_per_step": round((lh + lm) / trunk_steps, 1), "ms_per_step": round(per_step, 3),
             "share_of_step": round(per_step / (trunk_step_ms if trunk_step_ms is not None else dt / a.steps * 1e3), 4),
             "one_lane_step_ms": None if trunk_step_ms is None else round(trunk_step_ms, 3),
