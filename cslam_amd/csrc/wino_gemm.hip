@@ -485,6 +485,14 @@ __global__ __launch_bounds__(256, 1) void wino_gemm_h2_big_kernel(WinoGemmArgs p
     }
 }
 
+// Measured and removed (round 4, profiles/r04_v43_perf_wino_gemm_big2.log): the four-wave kernel with TWO accumulator sets of 128
+// (256 x 128 tiles, ring of three) -- item k accumulates in set k & 1 while the tile of item k - 1 leaves 8-32 buffer stores per stage,
+// counted in the stage wait, so that no stage waits for a whole tile to drain.  0.745 against 0.659 ms on conv4_2, 0.871 against 0.828
+// on conv3_2: its 12 fragment reads per 24 MFMAs (8 per 48 above) cost more than the smoother stores gave.  (Found on the way: a
+// run-time choice between the two sets in ONE merged block -- the compiler's tail merging of the two final-tile stores -- turns the
+// accumulators into stack objects; buffer stores with the row offset in an SGPR need no per-store address registers and drop rows
+// beyond the resource's range in hardware.)
+
 // ---- the same products with the COLUMN half of the output transform folded in ("Z form") ------------------------------
 // Y = A^T M A per tile and channel; Z_i[q] = sum_j M[6 i + j] A^T[q][j] (q = 0..3) needs the six frequencies of ONE row i of
 // the 6 x 6 frequency grid only.  A work item here = (row i, 128-tile row block, 128-channel column block): the K loops of
