@@ -458,29 +458,28 @@ __global__ __launch_bounds__(256, 1) void wino_gemm_h2_big_kernel(WinoGemmArgs p
             if (more) point_at(decode(k_item + 1));
             stage(std::false_type{}, std::true_type{}, kt_after);
         }
-        // ---- the finished item: lane = column, 128-byte runs per row; issued behind the barrier, drains under the next item's first stage
-        const int row_base = c.mt * TM + wm * 128 + 4 * h;
-        float *mo = p.M + ((int64_t)c.xi * p.T + row_base) * p.Cout + c.nt * TN + wn * 128 + l31;
-        const bool full = c.mt * TM + wm * 128 + 128 <= p.T;        // wave-uniform: no per-row test
-        const bool st_on = DBG != 1 || p.T < 0;
-        if (full) {
+        // ---- the finished item: lane = column, 128-byte runs per row; issued behind the barrier, drains under the next item's first
+        // stage.  Buffer stores: the resource spans the wave tile's rows that exist (a store to a row beyond T is out of range and
+        // dropped by the hardware: no predicate, no second code path), the lane's offset is one register, a row's offset a scalar
+        // (as 64-bit per-lane addresses the 256 stores of a tile cost two VALU instructions each and spilled)
+        {
+            const int row0 = c.mt * TM + wm * 128;
+            int64_t rows = (int64_t)p.T - row0;
+            if (rows < 0) rows = 0;
+            const int col0 = c.nt * TN + wn * 128;
+            const __amdgpu_buffer_rsrc_t rsM = wg_rsrc((const char *)(p.M + ((int64_t)c.xi * p.T + row0) * p.Cout + col0),
+                                                       rows > 0 ? rows * p.Cout * 4 - (int64_t)col0 * 4 : 0);   // a wave tile beyond T: nothing is in range
+            const int st_voff = (4 * h * p.Cout + l31) * 4;
+            const bool st_on = DBG != 1 || p.T < 0;
+            int row_bytes = p.Cout * 4;
+            asm volatile("" : "+s"(row_bytes));                  // opaque per item: the 256 row offsets are loop invariants otherwise, hoisted and spilled
 #pragma unroll
             for (int m = 0; m < MT; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
 #pragma unroll
                     for (int n = 0; n < NT; ++n)
-                        if (st_on) __builtin_nontemporal_store(acc[m][n][r], mo + (int64_t)(m * 32 + (r & 3) + 8 * (r >> 2)) * p.Cout + 32 * n);
-        } else {
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ro = m * 32 + (r & 3) + 8 * (r >> 2);
-#pragma unroll
-                    for (int n = 0; n < NT; ++n)
-                        if (st_on && row_base + ro < p.T) __builtin_nontemporal_store(acc[m][n][r], mo + (int64_t)ro * p.Cout + 32 * n);
-                }
+                        if (st_on) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[m][n][r]), rsM, st_voff, (m * 32 + (r & 3) + 8 * (r >> 2)) * row_bytes + 128 * n, 2);
         }
     }
 }
