@@ -915,6 +915,14 @@ static int wino_gemm_big_launch(WinoGemmArgs a, int dbg, hipStream_t st) {
     }
     int tslot;
     tt_begin(st, tslot);
+#ifdef CSLAM_ABLATIONS
+    if (dbg == 1 || dbg == 2) {                                     // timing-only: 1 = no stores, 2 = no requests after the prologue
+        if (dbg == 1) { HIP_TRY(hipFuncSetAttribute((const void *)wino_gemm_h2_big_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+                        hipLaunchKernelGGL((wino_gemm_h2_big_kernel<1>), dim3(grid), dim3(256), lds, st, a); }
+        else { HIP_TRY(hipFuncSetAttribute((const void *)wino_gemm_h2_big_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+               hipLaunchKernelGGL((wino_gemm_h2_big_kernel<2>), dim3(grid), dim3(256), lds, st, a); }
+    } else
+#endif
     hipLaunchKernelGGL((wino_gemm_h2_big_kernel<0>), dim3(grid), dim3(256), lds, st, a);
     if (a.nxi == 36) tt_end(st, tslot, a, 36);
     HIP_TRY(hipGetLastError());
