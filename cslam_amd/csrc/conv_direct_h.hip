@@ -563,6 +563,7 @@ CSLAM_API int cslam_conv3x3_direct_h_dev(const float *d_x, const void *d_w2, con
     ARG_CHECK(Cin >= 32 && (Cin % 32) == 0, "Cin must be a multiple of 32");
     ARG_CHECK(!pool || ((H % 2) == 0 && (W % 2) == 0), "pooling needs even H and W");
     ARG_CHECK(inv_sw > 0.0f, "inv_sw must be positive");
+    ARG_CHECK((int64_t)H * W * Cin * 4 < (1ll << 31), "one image must stay below 2 GiB (32-bit buffer offsets)");
     ConvDirectArgs a;
     a.x = d_x; a.w2 = (const char *)d_w2; a.bias = d_bias; a.y = d_y;
     a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.nslab = Cin / 32;
