@@ -77,6 +77,20 @@ extern "C" __attribute__((visibility("default"))) int cslam_debug_cd_prof_dev(vo
 #else
 #define CD_PROF 0
 #endif
+// max over lanes l, l ^ 1, l ^ 16, l ^ 17 (the four pixels of a 2 x 2 pooling window) without going through LDS: a DPP quad
+// permutation and gfx950's v_permlane16_swap (of two copies of v one ends up holding the even 16-lane rows twice, the other the odd
+// rows); as `__shfl_xor` each step was a ds_bpermute_b32 with an LDS round trip behind it (conv_stem_direct_h.hip has the numbers)
+__device__ __forceinline__ float cd_pool4(float v) {
+    const float a = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1, 0, 3, 2]
+    asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(a));   // (fmaxf would first canonicalise both operands: two more instructions per maximum)
+    // (as inline assembly: hipcc 7.2 folds the two results of __builtin_amdgcn_permlane16_swap(v, v) into ONE value and drops the maximum
+    // that follows; the s_nop covers the VALU-write -> permlane-read hazard the compiler cannot see in here)
+    float b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v), "+v"(b));
+    asm("v_max_f32 %0, %1, %2" : "=v"(v) : "v"(v), "v"(b));
+    return v;
+}
+
 template <bool RELU, bool POOL, int DBG = 0, bool PIXA = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_direct_h_kernel(ConvDirectArgs p) {
     extern __shared__ __attribute__((aligned(16))) char cd_smem[];
@@ -514,10 +528,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_h_kernel(ConvDirectArgs
                         if (POOL) {
                             // 2 x 2 maximum FIRST (lanes l ^ 1: the column neighbour, l ^ 16: the row below), then the exact
                             // power-of-two rescale, bias and ReLU on the survivor: all monotone, so the result is the same bit for bit
-                            v.x = fmaxf(v.x, __shfl_xor(v.x, 1, 64)); v.y = fmaxf(v.y, __shfl_xor(v.y, 1, 64));
-                            v.z = fmaxf(v.z, __shfl_xor(v.z, 1, 64)); v.w = fmaxf(v.w, __shfl_xor(v.w, 1, 64));
-                            v.x = fmaxf(v.x, __shfl_xor(v.x, 16, 64)); v.y = fmaxf(v.y, __shfl_xor(v.y, 16, 64));
-                            v.z = fmaxf(v.z, __shfl_xor(v.z, 16, 64)); v.w = fmaxf(v.w, __shfl_xor(v.w, 16, 64));
+                            v.x = cd_pool4(v.x); v.y = cd_pool4(v.y); v.z = cd_pool4(v.z); v.w = cd_pool4(v.w);
                         }
                         const float4 bv = bvs[n][q];
                         v.x = v.x * inv + bv.x; v.y = v.y * inv + bv.y; v.z = v.z * inv + bv.z; v.w = v.w * inv + bv.w;

@@ -143,6 +143,40 @@ def stem_pair_weights(weight):
     return W1.to(weight.device), 1.0 / sw, sumw.to(weight.device).contiguous()
 
 
+def stem_direct_pair_weights(weight):
+    """Second-layer weights [64, 64, 3, 3] float32 -> (W2r float16 [4, 9, 2, 2, 64, 8], inv_sw): the register-resident operand of
+    `cslam_conv_stem_direct_h_dev` (csrc/conv_stem_direct_h.hip).  sW w (sW the power of two that brings max |w| into
+    [2^14, 2^15)) is split into exact fp16 pairs; W2r[kq][tap][n][hi | lo][lane][e] = the pair half of
+    w[32 n + lane % 32][16 kq + 8 (lane // 32) + e][tap // 3][tap % 3]: one v_mfma_f32_32x32x16_f16 A fragment per (kq, tap, n, half),
+    wave kq of a workgroup holding [kq] for the whole kernel."""
+    assert tuple(weight.shape) == (64, 64, 3, 3)
+    w = weight.detach().to(torch.float64)
+    amax = float(w.abs().max())
+    sw = 2.0 ** (14 - math.floor(math.log2(amax))) if amax > 0 else 1.0
+    ws = (w * sw).to(torch.float32)
+    wh = ws.to(torch.float16)
+    wl = (ws - wh.to(torch.float32)).to(torch.float16)
+    pair = torch.stack((wh, wl), dim=0).reshape(2, 2, 32, 4, 2, 8, 9)       # [hl][n][l31][kq][h][e][tap]
+    W2r = pair.permute(3, 6, 1, 0, 4, 2, 5).reshape(4, 9, 2, 2, 64, 8)      # [kq][tap][n][hl][lane = 32 h + l31][e]
+    return W2r.contiguous(), 1.0 / sw
+
+
+def conv_stem_direct_h(x0, stem, bias1, Wr, bias, pool, amax_x0, amax_out=None):
+    """VGG-16's first two convolutions as ONE direct kernel (`cslam_conv_stem_direct_h_dev`): x0 planar [B,3,H,W] float32,
+    stem = `stem_pair_weights(conv1_1.weight)`, Wr = `stem_direct_pair_weights(conv1_2.weight)`; amax_x0 = 4-byte device slot with
+    the bits of max |x0|.  Returns ReLU(conv(ReLU(conv(x0) + bias1)) + bias) (+ MaxPool2d), channels_last."""
+    lib = _lib.load()
+    B, C3, H, W = x0.shape
+    assert C3 == 3 and x0.is_contiguous()
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    y = torch.empty((B, 64, Ho, Wo), dtype=torch.float32, device=x0.device, memory_format=torch.channels_last)
+    _lib.check(lib.cslam_conv_stem_direct_h_dev(
+        _p(x0), _p(stem[0]), _p(bias1) if bias1 is not None else None, _p(stem[2]), float(stem[1]), _p(Wr[0]),
+        _p(bias) if bias is not None else None, float(Wr[1]), B, H, W, int(pool), _p(amax_x0),
+        _p(amax_out) if amax_out is not None else None, _p(y), _stream(x0)))
+    return y
+
+
 def wino_stem64_h(x0, stem, bias1, Uh, bias, pool, amax_x0, amax_out=None):
     """VGG-16's first two convolutions as ONE kernel (`cslam_wino4_stem_c64_h_dev`): x0 planar [B,3,H,W] float32,
     stem = `stem_pair_weights(conv1_1.weight)`, Uh = `fused64_pair_weights` of the 64 -> 64 layer; amax_x0 = 4-byte device
@@ -419,12 +453,13 @@ class WinogradResNet(_Workspace):
 
 
 class _Step(object):
-    __slots__ = ("kind", "module", "conv", "relu", "pool", "U", "U4", "U3", "U2", "Up", "Uph", "bias", "stem", "Wd")
+    __slots__ = ("kind", "module", "conv", "relu", "pool", "U", "U4", "U3", "U2", "Up", "Uph", "bias", "stem", "Wd", "Wr")
 
     def __init__(self):
         self.kind, self.module, self.conv, self.relu, self.pool = "torch", None, None, False, False
         self.U, self.U4, self.U3, self.U2, self.Up, self.Uph, self.bias, self.stem = None, None, None, None, None, None, None, None
         self.Wd = None
+        self.Wr = None
 
 
 class WinogradTrunk(_Workspace):
@@ -537,6 +572,9 @@ class WinogradTrunk(_Workspace):
                 if (a.kind == "c3" and a.relu and a.conv.out_channels == 64 and b.kind == "wino" and b.Uph is not None
                         and b.relu and b.conv.out_channels == 64):
                     a.stem = stem_pair_weights(a.conv.weight)
+                    # the direct one-kernel form of the pair (csrc/conv_stem_direct_h.hip); CSLAM_STEM_DIRECT=0 keeps the F(4x4) one
+                    if os.environ.get("CSLAM_STEM_DIRECT", "1") != "0":
+                        a.Wr = stem_direct_pair_weights(b.conv.weight)
         return self
 
     @torch.no_grad()
@@ -572,7 +610,10 @@ class WinogradTrunk(_Workspace):
                         slot.copy_(x.abs().max().reshape(1))
                     nn2 = self.steps[k + 2] if k + 2 < len(self.steps) else None
                     want = slots[k + 2:k + 3] if wants(nn2) else None
-                    x = wino_stem64_h(x, st.stem, st.bias, nxt.Uph, nxt.bias, nxt.pool, slot, want)
+                    if st.Wr is not None:
+                        x = conv_stem_direct_h(x, st.stem, st.bias, st.Wr, nxt.bias, nxt.pool, slot, want)
+                    else:
+                        x = wino_stem64_h(x, st.stem, st.bias, nxt.Uph, nxt.bias, nxt.pool, slot, want)
                     amax_ready = want is not None
                     skip = True
                     continue

@@ -446,6 +446,15 @@ int cslam_wino4_stem_c64_h_dev(const float *d_x0, const void *d_w1, const float 
                                const void *d_Uh, const float *d_bias, int B, int H, int W, int pool,
                                const unsigned *d_amax_x0, float inv_su, unsigned *d_amax_out, float *d_y, void *stream);
 
+/* The same pair of layers (cslam/vpr/netvlad.py:163-171,227: VGG-16 conv1_1 + ReLU + conv1_2 + ReLU (+ MaxPool2d)) as ONE DIRECT
+ * convolution kernel (csrc/conv_stem_direct_h.hip): the 147 KB of second-layer weights (exact fp16 pairs) stay in the registers of the
+ * four waves of a workgroup, each wave owning 16 of the 64 intermediate channels; no Winograd transforms, no weight stream.
+ * d_w1 / inv_sw1 / d_sumw as above; d_w2r / inv_sw2: the second layer's weights in MFMA-fragment order
+ * [4 channel quarters][9 taps][2 x 32 output channels][hi | lo][64 lanes][8 halfs] (`stem_direct_pair_weights`). */
+int cslam_conv_stem_direct_h_dev(const float *d_x0, const void *d_w1, const float *d_b1, const float *d_sumw, float inv_sw1,
+                                 const void *d_w2r, const float *d_bias, float inv_sw2, int B, int H, int W, int pool,
+                                 const unsigned *d_amax_x0, unsigned *d_amax_out, float *d_y, void *stream);
+
 /* ---- multi-GPU exchange (csrc/comm.hip): RCCL over xGMI, one process per GPU ---------------------------------------
  * Replaces, inside one node, the ROS 2 transport of descriptors between robots
  * (cslam/global_descriptor_loop_closure_detection.py:198-227 publish GlobalDescriptors, :407-422 receive): rank g owns

@@ -830,13 +830,18 @@ def test_split16_trunk_equals_fp32_gemm_trunk(T):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("direct", [True, False])
 @pytest.mark.parametrize("B,H,W,pool,amp", [(2, 224, 224, True, 1.0), (3, 37, 50, False, 1.0), (5, 64, 96, True, 1e-3),
-                                            (300, 16, 32, True, 1.0), (2, 30, 22, False, 40.0), (1, 18, 34, True, 1.0)])
-def test_stem_kernel_first_two_convolutions_equal_float64_and_separate_kernels(T, B, H, W, pool, amp, monkeypatch):
-    """cslam_wino4_stem_c64_h_dev (conv 3 -> 64 + ReLU folded into the one-kernel 64 -> 64 convolution + ReLU (+ MaxPool2d);
-    VGG-16 conv1_1 / conv1_2, cslam/vpr/netvlad.py:163-171) against a float64 evaluation of the two layers at the tolerance
-    of the one-kernel form, and against the two separate kernels (fp32-grade: within 2e-6 of the largest activation).
-    Ragged blocks, maps narrower than one block pair, block counts below / above the compute-unit count, image scales."""
+                                            (300, 16, 32, True, 1.0), (2, 30, 22, False, 40.0), (1, 18, 34, True, 1.0),
+                                            (7, 8, 16, True, 1.0), (1, 2, 2, True, 1.0), (40, 226, 230, True, 0.05)])
+def test_stem_kernel_first_two_convolutions_equal_float64_and_separate_kernels(T, B, H, W, pool, amp, direct, monkeypatch):
+    """cslam_conv_stem_direct_h_dev (direct = True: conv 3 -> 64 + ReLU + conv 64 -> 64 + ReLU (+ MaxPool2d) as one DIRECT kernel
+    whose second-layer weights stay in registers, csrc/conv_stem_direct_h.hip) and cslam_wino4_stem_c64_h_dev (the one-kernel
+    F(4x4) form of the same pair); VGG-16 conv1_1 / conv1_2, cslam/vpr/netvlad.py:163-171: against a float64 evaluation of the
+    two layers at the tolerance of the one-kernel form, and against the two separate kernels (fp32-grade: within 2e-6 of the
+    largest activation).  Ragged blocks, maps narrower / lower than one block, single-block maps, block counts below / above the
+    compute-unit count (several blocks per persistent workgroup), image scales."""
+    monkeypatch.setenv("CSLAM_STEM_DIRECT", "1" if direct else "0")
     torch, _ = T
     from torch import nn
     from cslam_amd.vpr.winograd import WinogradTrunk
@@ -848,7 +853,7 @@ def test_stem_kernel_first_two_convolutions_equal_float64_and_separate_kernels(T
     monkeypatch.setenv("CSLAM_WINO_STEM", "1")
     stem = WinogradTrunk(seq, 64, 4, fused64=True)
     stem.fused_min_blocks = 0
-    assert stem.steps[0].stem is not None and stem.steps[1].Uph is not None
+    assert stem.steps[0].stem is not None and stem.steps[1].Uph is not None and (stem.steps[0].Wr is not None) == direct
     ys = stem(x)
     monkeypatch.setenv("CSLAM_WINO_STEM", "0")
     apart = WinogradTrunk(seq, 64, 4, fused64=True)

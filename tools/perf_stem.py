@@ -1,6 +1,7 @@
 #!/usr/bin/env python
-"""VGG-16 conv1_1 + conv1_2 (+ pool) at the 256-frame chunk: the stem kernel (first layer folded into the one-kernel
-convolution, csrc/wino_fused_h.hip STEM) against the two separate kernels, interleaved rounds, median / minimum.
+"""VGG-16 conv1_1 + conv1_2 (+ pool) at the 256-frame chunk: the direct stem kernel (csrc/conv_stem_direct_h.hip) against the
+F(4x4) stem kernel (first layer folded into the one-kernel convolution, csrc/wino_fused_h.hip STEM) and the two separate kernels,
+interleaved rounds, median / minimum.
     python tools/perf_stem.py [frames=256] [rounds=5]"""
 import os
 import statistics
@@ -21,7 +22,12 @@ def main():
                         nn.MaxPool2d(2, 2)).cuda().eval()
     x = torch.rand((B, 3, 224, 224), device="cuda") * 4.8 - 2.2
     os.environ["CSLAM_WINO_STEM"] = "1"
+    os.environ["CSLAM_STEM_DIRECT"] = "1"
+    direct = WinogradTrunk(seq, 64, 4, fused64=True)
+    assert direct.steps[0].Wr is not None
+    os.environ["CSLAM_STEM_DIRECT"] = "0"
     stem = WinogradTrunk(seq, 64, 4, fused64=True)
+    assert stem.steps[0].Wr is None
     os.environ["CSLAM_WINO_STEM"] = "0"
     apart = WinogradTrunk(seq, 64, 4, fused64=True)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -33,12 +39,13 @@ def main():
         e1.record()
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n
-    ys, ya = stem(x), apart(x)
+    ys, ya, yd = stem(x), apart(x), direct(x)
     print("stem vs separate kernels: max |diff| / max |y| = %.1e" % float((ys - ya).abs().max() / ya.abs().max()))
-    ts, ta = [], []
+    print("direct stem vs separate kernels: max |diff| / max |y| = %.1e" % float((yd - ya).abs().max() / ya.abs().max()))
+    ts, ta, td = [], [], []
     for _ in range(rounds):
-        ta.append(t(apart)); ts.append(t(stem))
-    for tag, v in (("conv1_1 + conv1_2 as two kernels", ta), ("stem kernel", ts)):
+        ta.append(t(apart)); ts.append(t(stem)); td.append(t(direct))
+    for tag, v in (("conv1_1 + conv1_2 as two kernels", ta), ("F(4x4) stem kernel", ts), ("direct stem kernel", td)):
         print(f"{tag:34s}: median {statistics.median(v):.3f} ms, min {min(v):.3f} ms per {B} frames")
 
 
