@@ -146,9 +146,9 @@ def stem_pair_weights(weight):
 def stem_direct_pair_weights(weight):
     """Second-layer weights [64, 64, 3, 3] float32 -> (W2r float16 [4, 9, 2, 2, 64, 8], inv_sw): the register-resident operand of
     `cslam_conv_stem_direct_h_dev` (csrc/conv_stem_direct_h.hip).  sW w (sW the power of two that brings max |w| into
-    [2^14, 2^15)) is split into exact fp16 pairs; W2r[kq][tap][n][hi | lo][lane][e] = the pair half of
-    w[32 n + lane % 32][16 kq + 8 (lane // 32) + e][tap // 3][tap % 3]: one v_mfma_f32_32x32x16_f16 A fragment per (kq, tap, n, half),
-    wave kq of a workgroup holding [kq] for the whole kernel."""
+    [2^14, 2^15)) is split into exact fp16 pairs; W2r[q][tap][ks][hi | lo][lane][e] = the pair half of
+    w[16 q + lane % 16][32 ks + 8 (lane // 16) + e][tap // 3][tap % 3]: one v_mfma_f32_16x16x32_f16 A fragment per (q, tap, ks, half),
+    wave q of a workgroup -- the owner of output channels 16 q .. 16 q + 15 -- holding [q] for the whole kernel."""
     assert tuple(weight.shape) == (64, 64, 3, 3)
     w = weight.detach().to(torch.float64)
     amax = float(w.abs().max())
@@ -156,8 +156,8 @@ def stem_direct_pair_weights(weight):
     ws = (w * sw).to(torch.float32)
     wh = ws.to(torch.float16)
     wl = (ws - wh.to(torch.float32)).to(torch.float16)
-    pair = torch.stack((wh, wl), dim=0).reshape(2, 2, 32, 4, 2, 8, 9)       # [hl][n][l31][kq][h][e][tap]
-    W2r = pair.permute(3, 6, 1, 0, 4, 2, 5).reshape(4, 9, 2, 2, 64, 8)      # [kq][tap][n][hl][lane = 32 h + l31][e]
+    pair = torch.stack((wh, wl), dim=0).reshape(2, 4, 16, 2, 4, 8, 9)       # [hl][q][i][ks][kg][e][tap]
+    W2r = pair.permute(1, 6, 3, 0, 4, 2, 5).reshape(4, 9, 2, 2, 64, 8)      # [q][tap][ks][hl][lane = 16 kg + i][e]
     return W2r.contiguous(), 1.0 / sw
 
 

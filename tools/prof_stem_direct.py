@@ -38,9 +38,8 @@ def main():
         torch.cuda.synchronize()
         h = [int(v) for v in buf.cpu().numpy()]
         n = max(h[4], 1)
-        print(f"{e0.elapsed_time(e1):.3f} ms per launch (absmax pass included); wave 0 of workgroup 0: {n} blocks, per block: main loop + next first "
-              f"layer {h[0] / n:.0f}, exchange writes + barrier {h[1] / n:.0f}, image + exchange reads {h[2] / n:.0f}, epilogue {h[3] / n:.0f}, "
-              f"sum {sum(h[:4]) / n:.0f} cycles")
+        print(f"{e0.elapsed_time(e1):.3f} ms per launch (absmax pass included); wave 0 of workgroup 0: {n} blocks, per block: six columns + next "
+              f"first layer {h[0] / n:.0f}, image + epilogue {h[1] / n:.0f}, barrier {h[2] / n:.0f}, sum {sum(h[:3]) / n:.0f} cycles")
     lib.cslam_debug_sd_prof_dev(None)
 
 

@@ -1,0 +1,56 @@
+import itertools
+G128 = [[0,1,2,3,12,13,14,15,20,21,22,23,24,25,26,27],[4,5,6,7,8,9,10,11,16,17,18,19,28,29,30,31]]
+G128 = G128 + [[l+32 for l in g] for g in G128]
+def read_conf(P, f):
+    worst = 1
+    for dx in range(3):
+        for ks in range(2):
+            for half in range(2):
+                for g in G128:
+                    slots = {}
+                    for l in g:
+                        l15, kg = l & 15, l >> 4
+                        pc = l15 + dx
+                        a = pc * P + half * 8 + ((4*ks + kg) ^ f(pc))
+                        slots.setdefault(a % 16, set()).add(a)
+                    worst = max(worst, max(len(v) for v in slots.values()))
+    return worst
+def write_conf(P, f, nb=32):
+    worst = 1; tot = 0; n = 0
+    for w in range(4):
+        for t in range(12):
+            for gq in range(4):
+                for half in range(2):
+                    banks = {}
+                    for l15 in range(16):
+                        pp = min(16*t + l15, 179)
+                        pc = pp % 18
+                        a = pp * P * 4 + half*32 + ((2*w + (gq >> 1)) ^ f(pc)) * 4 + (gq & 1) * 2
+                        for d in range(2):
+                            banks.setdefault((a + d) % nb, set()).add(a + d)
+                    m = max(len(v) for v in banks.values())
+                    worst = max(worst, m); tot += m; n += 1
+    return worst, tot / n
+fs = {"0": lambda pc: 0, "pc&7": lambda pc: pc & 7, "pc>>1&7": lambda pc: (pc >> 1) & 7, "pc>>2&3": lambda pc: (pc >> 2) & 3,
+      "pc>>2&7": lambda pc: (pc >> 2) & 7, "pc&3": lambda pc: pc & 3, "(pc&3)*2": lambda pc: (pc & 3) * 2, "(pc>>1&3)": lambda pc: (pc >> 1) & 3,
+      "(pc>>1&3)*2": lambda pc: ((pc >> 1) & 3) * 2, "pc&1": lambda pc: pc & 1, "(pc&1)*4": lambda pc: (pc & 1) * 4, "(pc>>2&1)*4": lambda pc: ((pc>>2)&1)*4,
+      "(pc>>3&1)*4": lambda pc: ((pc>>3)&1)*4, "(pc>>2&3)*2": lambda pc: ((pc>>2)&3)*2, "(pc>>1&1)*4": lambda pc: ((pc>>1)&1)*4}
+for P in range(16, 26):
+    for name, f in fs.items():
+        r = read_conf(P, f)
+        if r == 1:
+            w = write_conf(P, f)
+            print(P, name, "read", r, "write worst/avg", w)
+import random
+random.seed(1)
+best = {}
+for P in range(17, 25):
+    bestP = None
+    for trial in range(3000):
+        tab = [random.randrange(8) for _ in range(18)]
+        f = lambda pc, tab=tab: tab[pc]
+        if read_conf(P, f) != 1: continue
+        w = write_conf(P, f)
+        if bestP is None or w[1] < bestP[0][1]:
+            bestP = (w, tab)
+    print("P", P, bestP)
