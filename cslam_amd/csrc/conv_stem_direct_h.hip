@@ -92,6 +92,11 @@ __device__ __forceinline__ float sd_sub_half(float v, __half2 h) {
     else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hb), "v"(v));
     return d;
 }
+__device__ __forceinline__ float sd_max(float a, float b) {   // (fmaxf first canonicalises both operands: two more instructions per maximum)
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 // max(v, v of lane ^ 1): a DPP quad permutation (as `__shfl_xor` it is a ds_bpermute_b32 with an LDS round trip behind it)
 __device__ __forceinline__ float sd_max_xor1(float v) {
     const float a = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1, 0, 3, 2]
@@ -280,6 +285,51 @@ __global__ __launch_bounds__(256, 1) void conv_stem_direct_h_kernel(StemDirectAr
         }
     };
 
+    // ---- epilogue of a finished block, in FOUR pieces (two output rows = one pooled row each) that ride in the NEXT block's first two
+    // columns: the accumulators are copied out (`eacc`) when a block's columns are through and the next block starts at once -- with one
+    // wave per SIMD the matrix pipe would otherwise idle through the epilogue's ~150 vector instructions and stores (1.2k of a block's
+    // 12.6k cycles).  Lane = (pixel column l15, channels 16 wave + 4 gq .. + 3).  Buffer stores, the image's output map = the buffer: a
+    // lane that does not store (the odd column of a pooling window, pixels beyond a ragged edge, the pieces in front of the first block)
+    // gets an offset out of its range and is dropped by the hardware -- no branch around the stores, so the compiler can count them
+    float my_amax = 0.0f;
+    const int Ho = POOL ? p.H >> 1 : p.H, Wo = POOL ? p.W >> 1 : p.W;
+    f32x4 eacc[8];
+    Blk ecb = {0, 0, 0};
+    bool e_ok = false;
+    auto epi_piece = [&](int k) {
+        const __amdgpu_buffer_rsrc_t rsY = sd_rsrc((const char *)(p.y + (int64_t)ecb.img * Ho * Wo * 64), (int64_t)Ho * Wo * 256);
+        const int ox = ecb.bx * 16 + l15;
+        const int ch_off = (16 * wave + 4 * gq) * 4;
+        if (POOL) {
+            const int py = ecb.by * 4 + k;
+            float4 v;
+            // 2 x 2 maximum first (the two rows sit in one lane, the two columns in lanes l, l ^ 1), then the exact rescale, bias and ReLU
+            // on the survivor: all monotone
+            v.x = sd_max_xor1(sd_max(eacc[2 * k][0], eacc[2 * k + 1][0])); v.y = sd_max_xor1(sd_max(eacc[2 * k][1], eacc[2 * k + 1][1]));
+            v.z = sd_max_xor1(sd_max(eacc[2 * k][2], eacc[2 * k + 1][2])); v.w = sd_max_xor1(sd_max(eacc[2 * k][3], eacc[2 * k + 1][3]));
+            v.x = fmaxf(v.x * inv2 + bv2.x, 0.0f); v.y = fmaxf(v.y * inv2 + bv2.y, 0.0f);
+            v.z = fmaxf(v.z * inv2 + bv2.z, 0.0f); v.w = fmaxf(v.w * inv2 + bv2.w, 0.0f);
+            const bool store = e_ok & ((l15 & 1) == 0) & ((ox >> 1) < Wo) & (py < Ho);          // (bitwise: `&&` became branches on exec)
+            my_amax = sd_max(my_amax, store ? sd_max(sd_max(v.x, v.y), sd_max(v.z, v.w)) : 0.0f);
+            u32x4 bits;
+            bits.x = __float_as_uint(v.x); bits.y = __float_as_uint(v.y); bits.z = __float_as_uint(v.z); bits.w = __float_as_uint(v.w);
+            if (!(DBG & 4)) __builtin_amdgcn_raw_buffer_store_b128(bits, rsY, store ? (py * Wo + (ox >> 1)) * 256 + ch_off : 0x7fffffff, 0, 0);
+        } else {
+#pragma unroll
+            for (int r = 2 * k; r < 2 * k + 2; ++r) {
+                const int oy = ecb.by * 8 + r;
+                float4 v;
+                v.x = fmaxf(eacc[r][0] * inv2 + bv2.x, 0.0f); v.y = fmaxf(eacc[r][1] * inv2 + bv2.y, 0.0f);
+                v.z = fmaxf(eacc[r][2] * inv2 + bv2.z, 0.0f); v.w = fmaxf(eacc[r][3] * inv2 + bv2.w, 0.0f);
+                const bool store = e_ok & (ox < p.W) & (oy < p.H);
+                my_amax = sd_max(my_amax, store ? sd_max(sd_max(v.x, v.y), sd_max(v.z, v.w)) : 0.0f);
+                u32x4 bits;
+                bits.x = __float_as_uint(v.x); bits.y = __float_as_uint(v.y); bits.z = __float_as_uint(v.z); bits.w = __float_as_uint(v.w);
+                __builtin_amdgcn_raw_buffer_store_b128(bits, rsY, store ? (oy * p.W + ox) * 256 + ch_off : 0x7fffffff, 0, 0);
+            }
+        }
+    };
+
     // ---- second layer.  acc[r]: output row r of the block, lane (l15, gq) = pixel column l15, channels 16 wave + 4 gq .. + 3.
     // Column (dx, ks): for the ten patch rows R the fragment (row R, columns l15 + dx, channels 32 ks + 8 gq .. + 7; hi and lo) is read
     // once and multiplied into the up to three output rows r = R - dy with the weights of tap (dy, dx).
@@ -317,6 +367,7 @@ __global__ __launch_bounds__(256, 1) void conv_stem_direct_h_kernel(StemDirectAr
                 acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, (COL == 0 && prod == 0 && dy == 0) ? (f32x4)(0.0f) : acc[r], 0, 0, 0);
             }
         if constexpr (R >= 2 && R <= 7 && !(DBG & 1)) conv1_piece(COL, R - 2, nblk, npatch);
+        if constexpr (COL < 2 && (R == 1 || R == 8)) epi_piece(2 * COL + (R == 8 ? 1 : 0));    // the previous block's epilogue
         // inside the region: the reads first, then a few vector instructions behind every MFMA (hipcc otherwise runs a piece's ~25
         // vector instructions in one block with the matrix pipe idle)
         __builtin_amdgcn_sched_group_barrier(0x100, R == 0 ? 18 : 2, 0);
@@ -324,22 +375,46 @@ __global__ __launch_bounds__(256, 1) void conv_stem_direct_h_kernel(StemDirectAr
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, (COL < 2 && (R == 1 || R == 8)) ? 6 : 3, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
+    // The last patch row of a column multiplies into ONE accumulator (output row 7), the first row of the next column into one as well
+    // (row 0): as regions of their own each was a chain of three dependent MFMAs.  Together, alternating, no MFMA waits for its predecessor.
+    auto edge = [&](auto col_tag, const char *patch, const unsigned *s_img) {
+        constexpr int COL = decltype(col_tag)::value;           // row 9 of column COL + row 0 of column COL + 1
+        constexpr int DX = COL >> 1, KS = COL & 1, SLOT = (9 + COL) % 3;
+        constexpr int DX2 = (COL + 1) >> 1, KS2 = (COL + 1) & 1, SLOT2 = (COL + 1) % 3;
+        if constexpr (!(DBG & 2)) frag_read(std::integral_constant<int, COL + 1>{}, std::integral_constant<int, 1>{}, patch);
+        if constexpr (!(DBG & 1) && !(DBG & 8)) conv1_read(COL + 1, s_img);
+#pragma unroll
+        for (int prod = 0; prod < 3; ++prod) {
+            acc[7] = __builtin_amdgcn_mfma_f32_16x16x32_f16(prod == 2 ? wr[6 + DX][KS][1] : wr[6 + DX][KS][0], prod == 1 ? fl[SLOT] : fh[SLOT], acc[7], 0, 0, 0);
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(prod == 2 ? wr[DX2][KS2][1] : wr[DX2][KS2][0], prod == 1 ? fl[SLOT2] : fh[SLOT2], acc[0], 0, 0, 0);
+        }
+        // (row 2 of the next column lands in the ring slot row 9 was just multiplied from: behind its MFMAs)
+        if constexpr (!(DBG & 2)) frag_read(std::integral_constant<int, COL + 1>{}, std::integral_constant<int, 2>{}, patch);
+        __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
     auto column = [&](auto col_tag, const char *patch, const unsigned *s_img, const Blk &nblk, char *npatch) {
-        rstep(col_tag, std::integral_constant<int, 0>{}, patch, s_img, nblk, npatch); rstep(col_tag, std::integral_constant<int, 1>{}, patch, s_img, nblk, npatch);
+        constexpr int COL_ = decltype(col_tag)::value;
+        if constexpr (COL_ == 0) rstep(col_tag, std::integral_constant<int, 0>{}, patch, s_img, nblk, npatch);      // (the other columns' row 0: `edge`)
+        rstep(col_tag, std::integral_constant<int, 1>{}, patch, s_img, nblk, npatch);
         rstep(col_tag, std::integral_constant<int, 2>{}, patch, s_img, nblk, npatch); rstep(col_tag, std::integral_constant<int, 3>{}, patch, s_img, nblk, npatch);
         rstep(col_tag, std::integral_constant<int, 4>{}, patch, s_img, nblk, npatch); rstep(col_tag, std::integral_constant<int, 5>{}, patch, s_img, nblk, npatch);
         rstep(col_tag, std::integral_constant<int, 6>{}, patch, s_img, nblk, npatch); rstep(col_tag, std::integral_constant<int, 7>{}, patch, s_img, nblk, npatch);
-        rstep(col_tag, std::integral_constant<int, 8>{}, patch, s_img, nblk, npatch); rstep(col_tag, std::integral_constant<int, 9>{}, patch, s_img, nblk, npatch);
+        rstep(col_tag, std::integral_constant<int, 8>{}, patch, s_img, nblk, npatch);
+        if constexpr (COL_ == 5) rstep(col_tag, std::integral_constant<int, 9>{}, patch, s_img, nblk, npatch);
+        else edge(col_tag, patch, s_img);
     };
 #define SD_C(T) std::integral_constant<int, T>{}
-
-    float my_amax = 0.0f;
-    const int Ho = POOL ? p.H >> 1 : p.H, Wo = POOL ? p.W >> 1 : p.W;
 
     [[maybe_unused]] unsigned long long t_main = 0, t_epi = 0, t_bar = 0, t1 = 0, t2 = 0, t3 = 0;
     // ---- prologue: block 0's first layer, block 1's image
@@ -376,48 +451,11 @@ __global__ __launch_bounds__(256, 1) void conv_stem_direct_h_kernel(StemDirectAr
         // the image of block bi + 2 into the buffer block bi's came from (read during iteration bi - 1), consumed HERE, in front of this
         // block's stores: loads and stores share vmcnt and return out of order, so a load consumed behind a store waits for the store
         img_store(s_img_all + cur * SD_IMGB);
-        // ---- epilogue: lane = (pixel column l15, channels 16 wave + 4 gq .. + 3) of the eight output rows.  Buffer stores, the image's
-        // output map = the buffer: a lane that does not store (the odd column of a pooling window, pixels beyond a ragged edge) gets an
-        // offset out of its range and is dropped by the hardware -- no branch around the stores, so the compiler can count them
-        {
+        // the finished block's accumulators out of the way: its epilogue rides in the next block's first two columns
 #pragma unroll
-            for (int r = 0; r < 8; ++r) asm volatile("" : "+v"(acc[r]));
-            const __amdgpu_buffer_rsrc_t rsY = sd_rsrc((const char *)(p.y + (int64_t)cb.img * Ho * Wo * 64), (int64_t)Ho * Wo * 256);
-            const int ox = cb.bx * 16 + l15;
-            const int ch_off = (16 * wave + 4 * gq) * 4;
-            if (POOL) {
-                const bool colok = ((l15 & 1) == 0) && (ox >> 1) < Wo;
-#pragma unroll
-                for (int rp = 0; rp < 4; ++rp) {
-                    const int py = cb.by * 4 + rp;
-                    float4 v;
-                    // 2 x 2 maximum first (the two rows sit in one lane, the two columns in lanes l, l ^ 1), then the exact rescale, bias and
-                    // ReLU on the survivor: all monotone
-                    v.x = sd_max_xor1(fmaxf(acc[2 * rp][0], acc[2 * rp + 1][0])); v.y = sd_max_xor1(fmaxf(acc[2 * rp][1], acc[2 * rp + 1][1]));
-                    v.z = sd_max_xor1(fmaxf(acc[2 * rp][2], acc[2 * rp + 1][2])); v.w = sd_max_xor1(fmaxf(acc[2 * rp][3], acc[2 * rp + 1][3]));
-                    v.x = fmaxf(v.x * inv2 + bv2.x, 0.0f); v.y = fmaxf(v.y * inv2 + bv2.y, 0.0f);
-                    v.z = fmaxf(v.z * inv2 + bv2.z, 0.0f); v.w = fmaxf(v.w * inv2 + bv2.w, 0.0f);
-                    const bool store = colok && py < Ho;
-                    my_amax = fmaxf(my_amax, store ? fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)) : 0.0f);
-                    u32x4 bits;
-                    bits.x = __float_as_uint(v.x); bits.y = __float_as_uint(v.y); bits.z = __float_as_uint(v.z); bits.w = __float_as_uint(v.w);
-                    if (!(DBG & 4)) __builtin_amdgcn_raw_buffer_store_b128(bits, rsY, store ? (py * Wo + (ox >> 1)) * 256 + ch_off : 0x7fffffff, 0, 0);
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 8; ++r) {
-                    const int oy = cb.by * 8 + r;
-                    float4 v;
-                    v.x = fmaxf(acc[r][0] * inv2 + bv2.x, 0.0f); v.y = fmaxf(acc[r][1] * inv2 + bv2.y, 0.0f);
-                    v.z = fmaxf(acc[r][2] * inv2 + bv2.z, 0.0f); v.w = fmaxf(acc[r][3] * inv2 + bv2.w, 0.0f);
-                    const bool store = ox < p.W && oy < p.H;
-                    my_amax = fmaxf(my_amax, store ? fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)) : 0.0f);
-                    u32x4 bits;
-                    bits.x = __float_as_uint(v.x); bits.y = __float_as_uint(v.y); bits.z = __float_as_uint(v.z); bits.w = __float_as_uint(v.w);
-                    __builtin_amdgcn_raw_buffer_store_b128(bits, rsY, store ? (oy * p.W + ox) * 256 + ch_off : 0x7fffffff, 0, 0);
-                }
-            }
-        }
+        for (int r = 0; r < 8; ++r) eacc[r] = acc[r];
+        ecb = cb;
+        e_ok = true;
         if (SD_PROF) { t3 = __builtin_amdgcn_s_memtime(); t_epi += t3 - t2; }
         // ONE barrier per block: the next block's patch and the image after it are whole, everybody is through this block's patch
         __syncthreads();
@@ -425,6 +463,8 @@ __global__ __launch_bounds__(256, 1) void conv_stem_direct_h_kernel(StemDirectAr
         cb = nb;
         nb = nnb;
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) epi_piece(k);                  // the last block's
 #ifdef CSLAM_ABLATIONS
     if (sd_prof && blockIdx.x == 0 && tid == 0) { sd_prof[0] = t_main; sd_prof[1] = t_epi; sd_prof[2] = t_bar; sd_prof[3] = 0; sd_prof[4] = (unsigned long long)n_mine; }
 #endif
