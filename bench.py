@@ -645,23 +645,32 @@ def main():
         stemw = wg.stem_pair_weights(w1)
         s0 = torch.zeros(1, dtype=torch.float32, device=dev)
         _lib.check(lib.cslam_absmax_dev(x0.data_ptr(), x0.numel(), s0.data_ptr(), st))
-        sms = time_ms(lambda: wg.wino_stem64_h(x0, stemw, b1, Uhf, bf, True, s0, None))
+        # (the default since round 4: the DIRECT form of the pair, csrc/conv_stem_direct_h.hip -- the second layer's 147 KB of fp16-pair
+        # weights stay in the registers of four waves, each the owner of 16 output channels; the F(4x4) stem kernel is its A/B partner)
+        Wrf = wg.stem_direct_pair_weights(wf)
+        sms = time_ms(lambda: wg.conv_stem_direct_h(x0, stemw, b1, Wrf, bf, True, s0, None))
+        wms = time_ms(lambda: wg.wino_stem64_h(x0, stemw, b1, Uhf, bf, True, s0, None))
         y1 = torch.empty((eb, 64, fh, fh), device=dev, memory_format=torch.channels_last)
         w1k = w1.permute(1, 2, 3, 0).reshape(27, 64).contiguous()
         c1ms = time_ms(lambda: _lib.check(lib.cslam_conv3x3_c3_amax_dev(x0.data_ptr(), w1k.data_ptr(), b1.data_ptr(), eb, fh, fh, 64,
                                                                        1, y1.data_ptr(), None, st)))
         sbytes = (x0.numel() + eb * 64 * (fh // 2) * (fh // 2)) * 4
-        ps = pmc_entry("wino4_fused_c64_h_kernel/stem", shape=f"x0 [{eb},3,{fh},{fh}] -> conv 3->64 + ReLU -> conv 64->64 + ReLU + MaxPool2d")
-        sflop16 = eb * (fh // 4) * (fh // 4) * 36 * 2 * 64 * 64 * 4 + eb * fh * fh * 1.2 * 2 * 32 * 64 * 3
+        ps = pmc_entry("conv_stem_direct_h_kernel", shape=f"x0 [{eb},3,{fh},{fh}] -> conv 3->64 + ReLU -> conv 64->64 + ReLU + MaxPool2d")
+        # fp16 MFMA flop issued: the second layer direct (9 taps x 64 x 64, 3 products) + the first layer on the 10 x 18 patch of every
+        # 8 x 16 block (K = 27 padded to 32, 3 products)
+        sflop16 = eb * fh * fh * (3 * 2.0 * 9 * 64 * 64 + (180.0 / 128.0) * 3 * 2.0 * 32 * 64)
         extract_roofline["stem_conv"] = {
-            "bound": "mfma", "kernel": "wino4_fused_c64_h_kernel<STEM>", "kernel_ms": round(sms, 3),
+            "bound": "mfma", "kernel": "conv_stem_direct_h_kernel", "kernel_ms": round(sms, 3),
+            "wino_f4x4_stem_kernel_ms": round(wms, 3),
             "separate_kernels_ms": round(c1ms + fms, 3), "first_layer_kernel_ms": round(c1ms, 3),
-            "achieved": round(sflop16 / sms / 1e9, 1), "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (fp16 MFMA issued)",
+            "achieved": round(sflop16 / sms / 1e9, 1), "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (fp16, 3 products)",
             "frac": round(sflop16 / sms / 1e9 / FP16_MFMA_PEAK_TFLOPS, 4),
+            "fp32_equivalent_TFLOPs": round(sflop16 / 3 / sms / 1e9, 1),
             "hbm_algorithmic_bytes": sbytes, "hbm_GBs": round(sbytes / sms / 1e6, 1),
             "traffic": ps["traffic_bytes"] if ps else None, "traffic_source": ps["source"] if ps else None,
-            "note": "latency-bound (per-phase cycle counts: profiles/r02_v18_fused_h_phases.log): the matrix pipe is busy 15 % of "
-                    "the kernel; fp16 flops = 4 products per frequency (2 MFMAs on duplicated weights) + 3 per first-layer tap",
+            "matrix_pipe_busy_pmc": ps.get("mfma_busy_frac") if ps else None,
+            "note": "one wave per SIMD with the weights register-resident (no weight stream, no scratch); the first layer of block i + 1 and "
+                    "the epilogue of block i - 1 ride in block i's MFMA stream; per-phase cycle counts: profiles/r04_v56_stem_direct_phases.log",
             "shape": f"x0 [{eb},3,{fh},{fh}] -> conv 3->64 + ReLU -> conv 64->64 + ReLU + MaxPool2d -> [{eb},{fh // 2},{fh // 2},64]"}
         del x0, y1
 
