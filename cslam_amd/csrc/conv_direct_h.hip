@@ -113,7 +113,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_h_kernel(ConvDirectArgs
     const float sx = ldexpf(1.0f, e_ - 1);
     const float inv = p.inv_sw / sx;
 
-    const int n_mine = (p.nblk - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    // Blocks to workgroups, XCD-aware (as conv_stem_direct_h.hip): workgroup w runs on XCD w % 8, every XCD has its own L2; each XCD
+    // takes one contiguous eighth of the blocks and its workgroups walk it side by side, so that the halo a block shares with its
+    // neighbours is read through ONE L2 at about the same time (block b -> workgroup b % grid: the halo came through two or three)
+    const bool by_xcd = (gridDim.x & 7) == 0;
+    const int wg_xcd = by_xcd ? (int)blockIdx.x & 7 : 0, wg_j = by_xcd ? (int)blockIdx.x >> 3 : (int)blockIdx.x;
+    const int wg_per = by_xcd ? (int)gridDim.x >> 3 : (int)gridDim.x;
+    const int per_xcd = by_xcd ? (p.nblk + 7) >> 3 : p.nblk;
+    const int blk_beg = wg_xcd * per_xcd;
+    const int blk_cnt = min(per_xcd, p.nblk - blk_beg);
+    const int n_mine = blk_cnt > wg_j ? (blk_cnt - wg_j + wg_per - 1) / wg_per : 0;
     if (n_mine <= 0) return;
     const int nslabs_total = n_mine * p.nslab;
 
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_h_kernel(ConvDirectArgs
     // behind the workgroup's last)
     struct Blk { int by, bx; const char *xb; };               // xb = the block's image
     auto decode_blk = [&](int bi) {
-        const int blk = (int)blockIdx.x + bi * (int)gridDim.x;
+        const int blk = blk_beg + wg_j + bi * wg_per;
         const int per_img = p.gxb * p.gyb;
         const int img = blk / per_img, rem = blk - img * per_img;
         Blk b;
@@ -443,7 +452,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_h_kernel(ConvDirectArgs
         multiply(1);                                           // the block's last K step, then its outputs
         if (CD_PROF) { t1 = __builtin_amdgcn_s_memtime(); t_loop += t1 - t0; }
         // ---- block epilogue
-        const int blk = (int)blockIdx.x + bi * (int)gridDim.x;
+        const int blk = blk_beg + wg_j + bi * wg_per;
         const int img = blk / (p.gxb * p.gyb);
         const int by = cb.by, bx = cb.bx;
         cb = nb;
