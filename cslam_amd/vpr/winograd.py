@@ -90,6 +90,37 @@ def conv3x3_direct_h(x, Wd, bias, relu, pool, amax_in, amax_out=None):
     return y
 
 
+def direct_r_pair_weights(weight):
+    """conv weight [128, 64, 3, 3] float32 -> (W2r float16 [4, 9, 2, 2, 2, 64, 8], inv_sw): the register-resident operand of
+    `cslam_conv3x3_direct_r_dev` (csrc/conv_direct_r.hip).  sW w split into exact fp16 pairs;
+    W2r[q][tap][ks][mt][hi | lo][lane][e] = the pair half of w[32 q + 16 mt + lane % 16][32 ks + 8 (lane // 16) + e][tap // 3][tap % 3]:
+    one v_mfma_f32_16x16x32_f16 A fragment per (q, tap, ks, mt, half), wave q of a workgroup holding [q] for the whole kernel."""
+    assert tuple(weight.shape) == (128, 64, 3, 3)
+    w = weight.detach().to(torch.float64)
+    amax = float(w.abs().max())
+    sw = 2.0 ** (14 - math.floor(math.log2(amax))) if amax > 0 else 1.0
+    ws = (w * sw).to(torch.float32)
+    wh = ws.to(torch.float16)
+    wl = (ws - wh.to(torch.float32)).to(torch.float16)
+    pair = torch.stack((wh, wl), dim=0).reshape(2, 4, 2, 16, 2, 4, 8, 9)    # [hl][q][mt][i][ks][kg][e][tap]
+    W2r = pair.permute(1, 7, 4, 2, 0, 5, 3, 6).reshape(4, 9, 2, 2, 2, 64, 8)  # [q][tap][ks][mt][hl][lane = 16 kg + i][e]
+    return W2r.contiguous(), 1.0 / sw
+
+
+def conv3x3_direct_r(x, Wr, bias, relu, pool, amax_in, amax_out=None):
+    """y = [pool](relu(conv3x3(x) + bias)) through `cslam_conv3x3_direct_r_dev` (csrc/conv_direct_r.hip): x [B,64,H,W] channels_last
+    float32, 128 output channels; Wr = `direct_r_pair_weights(weight)`; amax_in / amax_out as `conv3x3_direct_h`."""
+    lib = _lib.load()
+    x = x.contiguous(memory_format=torch.channels_last)
+    B, Cin, H, W = x.shape
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    y = torch.empty((B, 128, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    _lib.check(lib.cslam_conv3x3_direct_r_dev(_p(x), _p(Wr[0]), _p(bias) if bias is not None else None, B, H, W, Cin, 128,
+                                              int(relu), int(pool), _p(amax_in), float(Wr[1]),
+                                              _p(amax_out) if amax_out is not None else None, _p(y), _stream(x)))
+    return y
+
+
 def fused64_weights(U):
     """U [16 | 36, 64, Cout] (`wino_weights(w, 2 | 4)`; Cout 64 or 128) -> the operand order of
     `cslam_wino2_fused_c64_dev` / `cslam_wino4_fused_c64_dev`: Up[kq][xi][w][g][c][s] = U[xi][16 kq + 4 g + s][16 w + c]
@@ -453,13 +484,14 @@ class WinogradResNet(_Workspace):
 
 
 class _Step(object):
-    __slots__ = ("kind", "module", "conv", "relu", "pool", "U", "U4", "U3", "U2", "Up", "Uph", "bias", "stem", "Wd", "Wr")
+    __slots__ = ("kind", "module", "conv", "relu", "pool", "U", "U4", "U3", "U2", "Up", "Uph", "bias", "stem", "Wd", "Wr", "Wdr")
 
     def __init__(self):
         self.kind, self.module, self.conv, self.relu, self.pool = "torch", None, None, False, False
         self.U, self.U4, self.U3, self.U2, self.Up, self.Uph, self.bias, self.stem = None, None, None, None, None, None, None, None
         self.Wd = None
         self.Wr = None
+        self.Wdr = None
 
 
 class WinogradTrunk(_Workspace):
@@ -528,6 +560,9 @@ class WinogradTrunk(_Workspace):
                     # (64 -> 128) stays on the one-kernel F(4x4) form: 1.47 ms against the direct kernel's 1.62 (a quarter of the
                     # multiplications; measured, profiles/r04_v9_direct_conv.log)
                     st.Wd = direct_pair_weights(m.weight)
+                    # 64 -> 128 (conv2_1): the register-resident form (csrc/conv_direct_r.hip); CSLAM_CONV_DIRECT_R=0 keeps the one above
+                    if m.in_channels == 64 and os.environ.get("CSLAM_CONV_DIRECT_R", "1") != "0":
+                        st.Wdr = direct_r_pair_weights(m.weight)
                 st.bias = None if m.bias is None else m.bias.detach().to(torch.float32).contiguous()
                 i += 1
                 if i < len(mods) and isinstance(mods[i], nn.ReLU):
@@ -648,7 +683,10 @@ class WinogradTrunk(_Workspace):
                 if not have:
                     _lib.check(lib.cslam_absmax_dev(_p(x), x.numel(), _p(slot), _stream(x)))
                 want = slots[k + 1:k + 2] if wants(nxt) else None
-                x = conv3x3_direct_h(x, st.Wd, st.bias, st.relu, st.pool, slot, want)
+                if st.Wdr is not None and x.shape[2] * x.shape[3] * 512 < 2 ** 31 - 16:
+                    x = conv3x3_direct_r(x, st.Wdr, st.bias, st.relu, st.pool, slot, want)
+                else:
+                    x = conv3x3_direct_h(x, st.Wd, st.bias, st.relu, st.pool, slot, want)
                 amax_ready = want is not None
                 continue
             if st.Up is not None and not (st.pool and (x.shape[2] % 2 or x.shape[3] % 2)):

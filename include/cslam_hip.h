@@ -446,6 +446,14 @@ int cslam_wino4_stem_c64_h_dev(const float *d_x0, const void *d_w1, const float 
                                const void *d_Uh, const float *d_bias, int B, int H, int W, int pool,
                                const unsigned *d_amax_x0, float inv_su, unsigned *d_amax_out, float *d_y, void *stream);
 
+/* 3x3 / stride 1 / pad 1 convolution 64 -> 128 channels (cslam/vpr/netvlad.py:163-171,227: VGG-16 conv2_1) as ONE direct kernel whose
+ * weights (295 KB of exact fp16 pairs) stay in the registers of the four waves of a workgroup, 32 output channels each
+ * (csrc/conv_direct_r.hip).  Arguments as cslam_conv3x3_direct_h_dev with Cin = 64, Cout = 128; d_w2r = `direct_r_pair_weights`:
+ * [4 output-channel quarters][9 taps][2 K steps][2 channel tiles][hi | lo][64 lanes][8 halfs]. */
+int cslam_conv3x3_direct_r_dev(const float *d_x, const void *d_w2r, const float *d_bias, int B, int H, int W, int Cin, int Cout,
+                               int relu, int pool, const unsigned *d_amax, float inv_sw, unsigned *d_amax_out, float *d_y,
+                               void *stream);
+
 /* The same pair of layers (cslam/vpr/netvlad.py:163-171,227: VGG-16 conv1_1 + ReLU + conv1_2 + ReLU (+ MaxPool2d)) as ONE DIRECT
  * convolution kernel (csrc/conv_stem_direct_h.hip): the 147 KB of second-layer weights (exact fp16 pairs) stay in the registers of the
  * four waves of a workgroup, each wave owning 16 of the 64 intermediate channels; no Winograd transforms, no weight stream.

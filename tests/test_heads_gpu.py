@@ -1045,4 +1045,44 @@ def test_netvlad_batch_path_descriptors_against_float64_model_on_distinct_frames
     assert float((1.0 - cos).max()) <= 2e-7
     assert rel <= 2e-2, rel
     assert int(prefix_clear.sum()) >= 150 and bool(same[prefix_clear].all())
-    assert float((g_got - g_ref)[~eye].abs().max()) <= 1e-6                  # similarities themselves: well inside the 1e-5 gate
+    assert float((g_got - g_ref)[~eye].abs().max()) <= 1e-6                  # similarities themselves: well inside the 1e-5 gate@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,relu,pool,bias,amp", [(2, 112, 112, True, False, True, 1.0), (3, 37, 50, True, False, True, 1e3),
+                                                      (300, 16, 16, False, False, False, 1.0), (1, 8, 90, True, True, False, 1e-3),
+                                                      (5, 20, 34, False, True, True, 1.0), (1, 2, 2, True, True, True, 1.0),
+                                                      (40, 114, 118, True, False, True, 0.05)])
+def test_register_resident_direct_conv_equals_float64(T, B, H, W, relu, pool, bias, amp):
+    """cslam_conv3x3_direct_r_dev (csrc/conv_direct_r.hip: VGG-16 conv2_1, 64 -> 128 channels, the weights register-resident, four waves
+    of 32 output channels each) against a float64 conv2d (+ ReLU + MaxPool2d) at the direct kernel's fp32-grade bar, and against the
+    streaming direct kernel; ragged 8 x 16 blocks, single-block maps, block counts below / above the compute-unit count (several blocks
+    per persistent workgroup: the double-buffered patch), activations six decades apart, the max |y| slot."""
+    torch, _ = T
+    from cslam_amd import _lib
+    from cslam_amd.vpr import winograd as wg
+    lib = _lib.load()
+    torch.manual_seed(211)
+    x = (torch.randn(B, 64, H, W, device="cuda") * amp).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(128, 64, 3, 3, device="cuda") / 24.0
+    b = torch.randn(128, device="cuda") * amp if bias else None
+    Wr = wg.direct_r_pair_weights(w)
+    assert tuple(Wr[0].shape) == (4, 9, 2, 2, 2, 64, 8) and Wr[0].dtype == torch.float16
+    slot = torch.zeros(1, dtype=torch.float32, device="cuda")
+    _lib.check(lib.cslam_absmax_dev(x.data_ptr(), x.numel(), slot.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    out_slot = torch.zeros(1, dtype=torch.float32, device="cuda")
+    y = wg.conv3x3_direct_r(x, Wr, b, relu, pool, slot, out_slot)
+    yh = wg.conv3x3_direct_h(x, wg.direct_pair_weights(w), b, relu, pool, slot, None)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), None if b is None else b.double(), padding=1)
+    if pool:
+        ref = torch.nn.functional.max_pool2d(ref, 2)             # max and ReLU commute
+    if relu:
+        ref = torch.relu(ref)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    top = ref.abs().max().item()
+    ef = (y.double() - ref).abs().max().item() / top
+    rf = float(((y.double() - ref) ** 2).sum().sqrt() / (ref ** 2).sum().sqrt())
+    assert ef <= 5e-6 and rf <= 2e-6, (ef, rf)
+    assert (y - yh).abs().max().item() <= 5e-6 * top
+    assert out_slot.item() == y.abs().max().item()
+    assert torch.equal(y, wg.conv3x3_direct_r(x, Wr, b, relu, pool, slot, None))      # run to run bit-identical
+
+
+
