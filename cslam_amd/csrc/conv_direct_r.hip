@@ -72,7 +72,8 @@ __device__ __forceinline__ float dr_max_xor1(float v) {                   // max
     return dr_max(v, a);
 }
 
-template <bool POOL, bool RELU>
+// DBG (builds with -DCSLAM_ABLATIONS only; WRONG results, timing): 1 = no patch staging inside the loop, 4 = no stores
+template <bool POOL, bool RELU, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void conv3x3_direct_r_kernel(ConvDirectRArgs p) {
     extern __shared__ __attribute__((aligned(16))) char dr_smem[];
     const int tid = threadIdx.x;
@@ -157,7 +158,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_r_kernel(ConvDirectRArg
         asm volatile("" : "+v"(t));                            // opaque: the twelve offsets are loop invariants otherwise, hoisted and spilled
         const int e = i * 256 + t, px = e >> 4;
         const int pr = (px * 3641) >> 16, pc = px - 18 * pr;
-        stg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, px < DR_NPIX ? ((pr * p.W + pc) * 64 + (e & 15) * 4) * 4 + blk_off : 0x7fffffff, 0, 0);
+        int off = ((pr * p.W + pc) * 64 + (e & 15) * 4) * 4 + blk_off;
+        asm volatile("" : "+v"(off));                          // computed by every lane: written as one select hipcc turns the "expensive" arm
+        stg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, px < DR_NPIX ? off : 0x7fffffff, 0, 0);     // into a branch, and a branch ends the region
     };
     auto patch_split = [&](const Blk &b, int i, char *patch) {
         const int pc = (int)(((i < 6 ? st_pc : st_pc2) >> (5 * (i < 6 ? i : i - 6))) & 31u);
@@ -215,10 +218,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_r_kernel(ConvDirectRArg
             }
             v.x = v.x * inv + bv[mt].x; v.y = v.y * inv + bv[mt].y; v.z = v.z * inv + bv[mt].z; v.w = v.w * inv + bv[mt].w;
             if (RELU) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
-            my_amax = dr_max(my_amax, store ? dr_max(dr_max(fabsf(v.x), fabsf(v.y)), dr_max(fabsf(v.z), fabsf(v.w))) : 0.0f);
+            float m = dr_max(dr_max(fabsf(v.x), fabsf(v.y)), dr_max(fabsf(v.z), fabsf(v.w)));
+            asm volatile("" : "+v"(m), "+v"(off));             // (both computed by every lane: no branch around them)
+            my_amax = dr_max(my_amax, store ? m : 0.0f);
             u32x4 bits;
             bits.x = __float_as_uint(v.x); bits.y = __float_as_uint(v.y); bits.z = __float_as_uint(v.z); bits.w = __float_as_uint(v.w);
-            __builtin_amdgcn_raw_buffer_store_b128(bits, rsY, store ? off : 0x7fffffff, 0, 0);
+            if (!(DBG & 4)) __builtin_amdgcn_raw_buffer_store_b128(bits, rsY, store ? off : 0x7fffffff, 0, 0);
+            else asm volatile("" :: "v"(bits));
         }
     };
 
@@ -229,7 +235,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_r_kernel(ConvDirectRArg
         constexpr int DX = COL >> 1, KS = COL & 1, SLOT = (R + COL) % 3;
         if constexpr (R + 2 < 10) frag_read(col_tag, std::integral_constant<int, (R + 2) % 10>{}, patch);
         else if constexpr (COL < 5) frag_read(std::integral_constant<int, (COL + 1) % 6>{}, std::integral_constant<int, (R + 2) % 10>{}, patch);
-        if constexpr (COL == 0 && R >= 1 && R <= 6) { patch_load(nblk, 2 * (R - 1)); patch_load(nblk, 2 * (R - 1) + 1); }
+        if constexpr (COL == 0 && R >= 1 && R <= 6 && !(DBG & 1)) { patch_load(nblk, 2 * (R - 1)); patch_load(nblk, 2 * (R - 1) + 1); }
 #pragma unroll
         for (int prod = 0; prod < 3; ++prod)
 #pragma unroll
@@ -242,7 +248,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_r_kernel(ConvDirectRArg
                     const f16x8 b = prod == 1 ? fl[SLOT] : fh[SLOT];
                     acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, (COL == 0 && prod == 0 && dy == 0) ? (f32x4)(0.0f) : acc[r][mt], 0, 0, 0);
                 }
-        if constexpr (COL >= 2 && (R == 2 || R == 4 || R == 6)) patch_split(nblk, 3 * (COL - 2) + (R - 2) / 2, npatch);
+        if constexpr (COL >= 2 && (R == 2 || R == 4 || R == 6) && !(DBG & 1)) patch_split(nblk, 3 * (COL - 2) + (R - 2) / 2, npatch);
         if constexpr (COL == 5 && !POOL && R >= 3) epi_rows(R - 3);                                 // output row R - 3 was finished by the last region
         if constexpr (COL == 5 && POOL && (R == 4 || R == 6 || R == 8)) epi_rows((R - 4) / 2);
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
@@ -339,6 +345,17 @@ CSLAM_API int cslam_conv3x3_direct_r_dev(const float *d_x, const void *d_w2r, co
             HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_direct_r_kernel<P, R>, hipFuncAttributeMaxDynamicSharedMemorySize, DR_LDS)); \
             once.done(once_dev); } \
         hipLaunchKernelGGL((conv3x3_direct_r_kernel<P, R>), dim3(grid), dim3(256), DR_LDS, st, a); } while (0)
+#ifdef CSLAM_ABLATIONS
+    if (const char *e = getenv("CSLAM_DR_DBG")) {
+        const int d = atoi(e);
+#define DR_LAUNCH_D(D) do { HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_direct_r_kernel<false, true, D>, hipFuncAttributeMaxDynamicSharedMemorySize, DR_LDS)); \
+        hipLaunchKernelGGL((conv3x3_direct_r_kernel<false, true, D>), dim3(grid), dim3(256), DR_LDS, st, a); HIP_TRY(hipGetLastError()); return CSLAM_OK; } while (0)
+        if (d == 1) DR_LAUNCH_D(1);
+        if (d == 4) DR_LAUNCH_D(4);
+        if (d == 5) DR_LAUNCH_D(5);
+#undef DR_LAUNCH_D
+    }
+#endif
     if (pool && relu) DR_LAUNCH(true, true);
     else if (pool) DR_LAUNCH(true, false);
     else if (relu) DR_LAUNCH(false, true);

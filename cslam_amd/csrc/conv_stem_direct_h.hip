@@ -320,10 +320,13 @@ __global__ __launch_bounds__(256, 1) void conv_stem_direct_h_kernel(StemDirectAr
             v.x = fmaxf(v.x * inv2 + bv2.x, 0.0f); v.y = fmaxf(v.y * inv2 + bv2.y, 0.0f);
             v.z = fmaxf(v.z * inv2 + bv2.z, 0.0f); v.w = fmaxf(v.w * inv2 + bv2.w, 0.0f);
             const bool store = e_ok & ((l15 & 1) == 0) & ((ox >> 1) < Wo) & (py < Ho);          // (bitwise: `&&` became branches on exec)
-            my_amax = sd_max(my_amax, store ? sd_max(sd_max(v.x, v.y), sd_max(v.z, v.w)) : 0.0f);
+            float m = sd_max(sd_max(v.x, v.y), sd_max(v.z, v.w));
+            int off = (py * Wo + (ox >> 1)) * 256 + ch_off;
+            asm volatile("" : "+v"(m), "+v"(off));             // computed by every lane: inside a select hipcc turns them into a branch, and a branch ends the region
+            my_amax = sd_max(my_amax, store ? m : 0.0f);
             u32x4 bits;
             bits.x = __float_as_uint(v.x); bits.y = __float_as_uint(v.y); bits.z = __float_as_uint(v.z); bits.w = __float_as_uint(v.w);
-            if (!(DBG & 4)) __builtin_amdgcn_raw_buffer_store_b128(bits, rsY, store ? (py * Wo + (ox >> 1)) * 256 + ch_off : 0x7fffffff, 0, 0);
+            if (!(DBG & 4)) __builtin_amdgcn_raw_buffer_store_b128(bits, rsY, store ? off : 0x7fffffff, 0, 0);
         } else {
 #pragma unroll
             for (int r = 2 * k; r < 2 * k + 2; ++r) {
@@ -332,10 +335,13 @@ __global__ __launch_bounds__(256, 1) void conv_stem_direct_h_kernel(StemDirectAr
                 v.x = fmaxf(eacc[r][0] * inv2 + bv2.x, 0.0f); v.y = fmaxf(eacc[r][1] * inv2 + bv2.y, 0.0f);
                 v.z = fmaxf(eacc[r][2] * inv2 + bv2.z, 0.0f); v.w = fmaxf(eacc[r][3] * inv2 + bv2.w, 0.0f);
                 const bool store = e_ok & (ox < p.W) & (oy < p.H);
-                my_amax = sd_max(my_amax, store ? sd_max(sd_max(v.x, v.y), sd_max(v.z, v.w)) : 0.0f);
+                float m = sd_max(sd_max(v.x, v.y), sd_max(v.z, v.w));
+                int off = (oy * p.W + ox) * 256 + ch_off;
+                asm volatile("" : "+v"(m), "+v"(off));
+                my_amax = sd_max(my_amax, store ? m : 0.0f);
                 u32x4 bits;
                 bits.x = __float_as_uint(v.x); bits.y = __float_as_uint(v.y); bits.z = __float_as_uint(v.z); bits.w = __float_as_uint(v.w);
-                __builtin_amdgcn_raw_buffer_store_b128(bits, rsY, store ? (oy * p.W + ox) * 256 + ch_off : 0x7fffffff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(bits, rsY, store ? off : 0x7fffffff, 0, 0);
             }
         }
     };
