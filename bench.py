@@ -611,12 +611,17 @@ def main():
             Wd = wg.direct_pair_weights(wd)
             sd = torch.zeros(1, dtype=torch.float32, device=dev)
             _lib.check(lib.cslam_absmax_dev(xd.data_ptr(), xd.numel(), sd.data_ptr(), st))
-            dms = time_ms(lambda: wg.conv3x3_direct_h(xd, Wd, bd, True, pool, sd, None))
+            hms = time_ms(lambda: wg.conv3x3_direct_h(xd, Wd, bd, True, pool, sd, None))
+            dms, kname = hms, "conv3x3_direct_h_kernel"
+            if cin == 64:                                    # conv2_1: the register-resident form (csrc/conv_direct_r.hip), the trunk's default
+                Wdr = wg.direct_r_pair_weights(wd)
+                dms, kname = time_ms(lambda: wg.conv3x3_direct_r(xd, Wdr, bd, True, pool, sd, None)), "conv3x3_direct_r_kernel"
             dfl = 3 * 2.0 * eb * 112 * 112 * 9 * cin * 128
             dby = (xd.numel() + eb * 128 * 112 * 112 // (4 if pool else 1)) * 4
             shape_d = f"x [{eb},112,112,{cin}] -> conv {cin}->128 + bias + ReLU" + (" + MaxPool2d" if pool else "")
-            pd_ = pmc_entry("conv3x3_direct_h_kernel/" + tag, shape=shape_d)
-            dconv[tag] = {"bound": "mfma", "kernel": "conv3x3_direct_h_kernel", "shape": shape_d, "kernel_ms": round(dms, 3),
+            pd_ = pmc_entry(kname + "/" + tag, shape=shape_d)
+            dconv[tag] = {"bound": "mfma", "kernel": kname, "shape": shape_d, "kernel_ms": round(dms, 3),
+                          "streaming_direct_kernel_ms": round(hms, 3),
                           "achieved": round(dfl / dms / 1e9, 1), "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (fp16, 3 products)",
                           "frac": round(dfl / dms / 1e9 / FP16_MFMA_PEAK_TFLOPS, 4),
                           "fp32_equivalent_TFLOPs": round(dfl / 3 / dms / 1e9, 1),
