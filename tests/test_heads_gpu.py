@@ -645,9 +645,10 @@ def test_netvlad_extraction_beside_a_stream_that_thrashes_the_l2_is_bit_identica
 
 
 def test_trunk_runs_conv2_1_and_conv2_2_through_the_direct_kernel_and_matches_the_winograd_forms(T, monkeypatch):
-    """VGG-16's first two blocks through the trunk runner: by default conv2_1 and conv2_2 take the direct kernel;
-    CSLAM_CONV_DIRECT=2 leaves conv2_1 on the one-kernel F(4x4) form, =0 keeps round 3's F(4x4) forms for both.  All against float64,
-    and against each other at the F(4x4) forms' tolerance."""
+    """VGG-16's first two blocks through the trunk runner: by default the stem and conv2_1 take the register-resident direct kernels
+    and conv2_2 the streaming direct kernel; CSLAM_CONV_DIRECT=2 leaves conv2_1 on the one-kernel F(4x4) form, =0 keeps round 3's
+    F(4x4) forms for both; CSLAM_CONV_DIRECT_R=0 / CSLAM_STEM_DIRECT=0 select the A/B partners of the register-resident kernels.  All
+    against float64, and against each other at the F(4x4) forms' tolerance."""
     torch, _ = T
     from torch import nn
     from cslam_amd.vpr.winograd import WinogradTrunk
@@ -664,13 +665,23 @@ def test_trunk_runs_conv2_1_and_conv2_2_through_the_direct_kernel_and_matches_th
             monkeypatch.setenv("CSLAM_CONV_DIRECT", env)
         t = WinogradTrunk(seq, 64, 4, fused64=True)
         assert ((t.steps[2].Wd is not None), (t.steps[3].Wd is not None)) == direct, tag
+        assert (t.steps[2].Wdr is not None) == direct[0] and t.steps[3].Wdr is None and t.steps[0].Wr is not None
         outs[tag] = t(x)
+    # the A/B partners of the register-resident kernels: conv2_1 on the streaming direct kernel, the F(4x4) stem kernel
+    monkeypatch.delenv("CSLAM_CONV_DIRECT", raising=False)
+    for tag, env in (("conv2_1 streaming", "CSLAM_CONV_DIRECT_R"), ("wino stem", "CSLAM_STEM_DIRECT")):
+        monkeypatch.setenv(env, "0")
+        t = WinogradTrunk(seq, 64, 4, fused64=True)
+        assert (t.steps[2].Wdr is None) == (env == "CSLAM_CONV_DIRECT_R") and (t.steps[0].Wr is None) == (env == "CSLAM_STEM_DIRECT"), tag
+        assert t.steps[2].Wd is not None and t.steps[0].stem is not None
+        outs[tag] = t(x)
+        monkeypatch.delenv(env)
     with torch.no_grad():
         ref = seq.double()(x.double())
     seq.float()
     for tag in outs:
         assert _rel_rms(outs[tag], ref) <= 1e-5, tag
-    for tag in ("direct", "conv2_2"):
+    for tag in ("direct", "conv2_2", "conv2_1 streaming", "wino stem"):
         assert (outs[tag] - outs["wino"]).abs().max().item() <= 2e-5 * ref.abs().max().item(), tag
 
 
