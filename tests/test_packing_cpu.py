@@ -57,6 +57,26 @@ def test_stem_pair_weights_slots_taps_and_bound():
     assert float(sw) == 2.0 ** round(np.log2(sw))
 
 
+def test_register_resident_weight_fragments_are_in_mfma_lane_order():
+    """`stem_direct_pair_weights` / `direct_r_pair_weights` (csrc/conv_stem_direct_h.hip, conv_direct_r.hip): every (wave, tap, K step
+    [, channel tile], half) is one v_mfma_f32_16x16x32_f16 A fragment -- lane l holds output channel l % 16 of the tile, input channels
+    8 (l // 16) .. + 7 of the K step --, hi + lo reproduce the power-of-two-scaled weight to 22 bits."""
+    torch.manual_seed(5)
+    w = torch.randn(64, 64, 3, 3) / 24.0
+    W, inv = wg.stem_direct_pair_weights(w)
+    assert W.shape == (4, 9, 2, 2, 64, 8) and W.dtype == torch.float16 and float(1.0 / inv) == 2.0 ** round(np.log2(1.0 / inv))
+    rec = (W[:, :, :, 0].double() + W[:, :, :, 1].double()) * inv                              # [q][tap][ks][lane][e]
+    want = w.double().reshape(4, 16, 2, 4, 8, 9).permute(0, 5, 2, 3, 1, 4).reshape(4, 9, 2, 64, 8)   # [q][i][ks][kg][e][tap] -> lane = 16 kg + i
+    assert float((rec - want).abs().max()) <= 2.0 ** -21 * float(w.abs().max())
+    assert float(W.abs().max()) < 2.0 ** 15 and float(W[:, :, :, 0].abs().max()) >= 2.0 ** 13
+    w2 = torch.randn(128, 64, 3, 3) / 24.0
+    W2, inv2 = wg.direct_r_pair_weights(w2)
+    assert W2.shape == (4, 9, 2, 2, 2, 64, 8) and W2.dtype == torch.float16
+    rec2 = (W2[:, :, :, :, 0].double() + W2[:, :, :, :, 1].double()) * inv2                    # [q][tap][ks][mt][lane][e]
+    want2 = w2.double().reshape(4, 2, 16, 2, 4, 8, 9).permute(0, 6, 3, 1, 4, 2, 5).reshape(4, 9, 2, 2, 64, 8)
+    assert float((rec2 - want2).abs().max()) <= 2.0 ** -21 * float(w2.abs().max())
+
+
 def test_split16_pair_weights_layout():
     torch.manual_seed(2)
     U4 = torch.randn(36, 64, 128) / 8.0
