@@ -1056,7 +1056,10 @@ def test_netvlad_batch_path_descriptors_against_float64_model_on_distinct_frames
     assert float((1.0 - cos).max()) <= 2e-7
     assert rel <= 2e-2, rel
     assert int(prefix_clear.sum()) >= 150 and bool(same[prefix_clear].all())
-    assert float((g_got - g_ref)[~eye].abs().max()) <= 1e-6                  # similarities themselves: well inside the 1e-5 gate@pytest.mark.gpu
+    assert float((g_got - g_ref)[~eye].abs().max()) <= 1e-6                  # similarities themselves: well inside the 1e-5 gate
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,H,W,relu,pool,bias,amp", [(2, 112, 112, True, False, True, 1.0), (3, 37, 50, True, False, True, 1e3),
                                                       (300, 16, 16, False, False, False, 1.0), (1, 8, 90, True, True, False, 1e-3),
                                                       (5, 20, 34, False, True, True, 1.0), (1, 2, 2, True, True, True, 1.0),
@@ -1094,6 +1097,3 @@ def test_register_resident_direct_conv_equals_float64(T, B, H, W, relu, pool, bi
     assert (y - yh).abs().max().item() <= 5e-6 * top
     assert out_slot.item() == y.abs().max().item()
     assert torch.equal(y, wg.conv3x3_direct_r(x, Wr, b, relu, pool, slot, None))      # run to run bit-identical
-
-
-
