@@ -1097,3 +1097,75 @@ def test_register_resident_direct_conv_equals_float64(T, B, H, W, relu, pool, bi
     assert (y - yh).abs().max().item() <= 5e-6 * top
     assert out_slot.item() == y.abs().max().item()
     assert torch.equal(y, wg.conv3x3_direct_r(x, Wr, b, relu, pool, slot, None))      # run to run bit-identical
+
+
+@pytest.mark.gpu
+def test_netvlad_batch_path_descriptors_with_heavy_tailed_weights(T):
+    """The same descriptor-level gate with weights that are NOT He-initialised Gaussians (no trained checkpoint ships; this is the nearest
+    stand-in): every convolution's output channels rescaled log-normally (sigma 0.7: a factor 16 between the 2.5 % tails), 0.5 % of the
+    weights blown up 8 x, biases spread -- activations whose channels differ by orders of magnitude, which is what the power-of-two
+    scales of the fp16-pair operands (one scale per layer, from max |x|) have to survive.  Batch path (direct stem, register-resident
+    conv2_1, direct conv2_2, pair GEMMs, pair PCA) against the SAME weights in float64, with torch's fp32 convolutions as yardstick."""
+    torch, _ = T
+    import copy
+    import torch.nn.functional as Fn
+    from cslam_amd.vpr import heads
+    from cslam_amd.vpr.netvlad import NetVLAD
+    rng = np.random.default_rng(23)
+    imgs = []
+    for i in range(48):
+        bsz = (6, 10, 16, 24, 40, 64, 96, 160)[i % 8]
+        low = rng.random((-(-480 // bsz), -(-640 // bsz), 3)).astype(np.float32)
+        img = np.kron(low, np.ones((bsz, bsz, 1), dtype=np.float32))[:480, :640]
+        contrast, bright, sigma = rng.uniform(0.05, 1.0), rng.uniform(20.0, 230.0), rng.uniform(0.0, 40.0) * (i % 3 == 0)
+        img = bright + contrast * (img - 0.5) * 255.0 * rng.uniform(0.3, 1.0, size=(1, 1, 3)) + rng.normal(0.0, 1.0, size=img.shape) * sigma
+        imgs.append(np.clip(img, 0, 255).astype(np.uint8))
+    frames = torch.from_numpy(np.stack(imgs)).cuda()
+    cfg = {"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376, "frontend.netvlad.pca_dim": 4096, "frontend.random_seed": 5}
+    nv = NetVLAD(cfg, None)
+    gen = torch.Generator(device="cpu").manual_seed(77)
+    with torch.no_grad():
+        for m in nv.encoder.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                co = m.weight.shape[0]
+                scale = torch.exp(0.7 * torch.randn(co, generator=gen))
+                scale = scale / scale.pow(2).mean().sqrt()                      # the layer's overall gain stays He's
+                spikes = 1.0 + 7.0 * (torch.rand(m.weight.shape, generator=gen) < 0.005).float()
+                m.weight.mul_((scale.reshape(-1, 1, 1, 1) * spikes).to(m.weight.device))
+                if m.bias is not None:
+                    m.bias.copy_((0.3 * torch.randn(co, generator=gen) * m.weight.detach().abs().mean().cpu() * 27.0).to(m.bias.device))
+    nv.trunk = None                                            # transformed weights are rebuilt on the next forward
+    got = nv.compute_embeddings_device(frames).double()
+    assert nv.trunk is not None and nv.trunk.steps[0].Wr is not None and any(st.Wdr is not None for st in nv.trunk.steps), "the register-resident kernels did not run"
+    x = heads.preprocess(frames.contiguous(), nv.crop)
+    enc = copy.deepcopy(nv.encoder).double()
+    W, b, cent = nv.pool.conv_weight.double(), nv.pool.conv_bias, nv.pool.centroids.double()
+    comp = nv.pca_components[:4096].double()
+
+    def head(f):
+        xf = Fn.normalize(f, p=2.0, dim=1).flatten(2)
+        sa = torch.einsum("kc,ncp->nkp", W.reshape(W.shape[0], -1), xf)
+        if b is not None:
+            sa = sa + b.double().reshape(1, -1, 1)
+        a = torch.softmax(sa, dim=1)
+        v = torch.einsum("nkp,ncp->nkc", a, xf) - a.sum(2)[:, :, None] * cent[None]
+        v = Fn.normalize(Fn.normalize(v, p=2.0, dim=2).flatten(1), p=2.0, dim=1)
+        return Fn.normalize(v @ comp.T - nv.pca_mean_proj.double()[None], p=2.0, dim=1)
+    ref, ref32, act = [], [], []
+    with torch.no_grad():
+        for s in range(0, x.shape[0], 16):
+            f = enc(x[s:s + 16].double())
+            act.append(f.abs().amax(dim=(0, 2, 3)))
+            ref.append(head(f))
+            ref32.append(head(nv.encoder(x[s:s + 16]).double()))                # torch's own fp32 convolutions (MIOpen), float64 head
+    ref, ref32 = torch.cat(ref), torch.cat(ref32)
+    chan = torch.stack(act).amax(0)
+    worst = (got - ref).abs().max().item()
+    e_direct = (ref32 - ref).abs().max().item()
+    cos = (got * ref).sum(1)
+    print("heavy-tailed weights: channel maxima of the last map span %.1e .. %.1e; descriptor error vs float64 %.2e (torch fp32 convolutions "
+          "%.2e), max 1-cos %.1e" % (chan[chan > 0].min().item(), chan.max().item(), worst, e_direct, float((1.0 - cos).max())), flush=True)
+    assert torch.isfinite(got).all()
+    assert worst <= 1e-5, worst
+    assert worst <= 2.0 * e_direct + 1e-6, (worst, e_direct)
+    assert float((1.0 - cos).max()) <= 2e-7
