@@ -59,6 +59,73 @@ def pmc_entry(kernel, **match):
     return e
 
 
+class BoardSensors:
+    """Board power and shader clock of the bench's GPU over the timed steps, from the amdgpu hwmon files of its card (power1_average or
+    power1_input in microwatts, power1_cap, freq1_input = sclk in Hz), sampled back to back by a thread of rank 0 (a read of the power file takes tens of milliseconds).  A reported context
+    figure, not part of the metric: the fp16-pair kernels of the trunk run the board at its power cap, and the clock the chip then
+    sustains -- not the nominal 2.4 GHz the roofline peaks are quoted at -- is what their matrix pipe runs at (DESIGN.md section 5;
+    tools/power_trace.py, profiles/r04_v65_power_trace.jsonl for one kernel at a time)."""
+
+    def __init__(self, torch, dev_index):
+        import glob
+        self.files, self.card, self.samples, self.thread, self.stop = {}, None, [], None, None
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(dev_index)
+            want = "%04x:%02x:%02x." % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
+        cands = []
+        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            f = {k: os.path.join(d, k) for k in ("power1_average", "power1_input", "power1_cap", "freq1_input") if os.path.exists(os.path.join(d, k))}
+            if "power1_average" in f or "power1_input" in f:
+                cands.append((os.path.realpath(os.path.join(d, "..", "..")), f))
+        hit = [c for c in cands if want and want in c[0]]
+        self.matched = bool(hit)
+        if hit or cands:
+            self.card, self.files = (hit or cands)[0]
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return int(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def start(self):
+        import threading
+        pf = self.files.get("power1_average") or self.files.get("power1_input")
+        if not pf:
+            return
+        self.samples, self.stop, self.t0 = [], threading.Event(), time.perf_counter()
+
+        def run():
+            while not self.stop.is_set():
+                self.samples.append((self._read(pf), self._read(self.files["freq1_input"]) if "freq1_input" in self.files else None))
+                self.stop.wait(0.01)
+        self.thread = threading.Thread(target=run, daemon=True)
+        self.thread.start()
+
+    def finish(self):
+        if self.thread is None:
+            return None
+        self.stop.set()
+        self.thread.join(timeout=5)
+        span = time.perf_counter() - self.t0
+        w = [p / 1e6 for p, _ in self.samples if p is not None]
+        f = [c / 1e6 for _, c in self.samples if c is not None]
+        cap = self._read(self.files["power1_cap"]) if "power1_cap" in self.files else None
+        if not w:
+            return None
+        return {"power_W_mean": round(sum(w) / len(w), 1), "power_W_max": round(max(w), 1), "power_cap_W": None if cap is None else cap / 1e6,
+                "sclk_MHz_mean": round(sum(f) / len(f), 1) if f else None, "sclk_MHz_min": round(min(f), 1) if f else None,
+                "sclk_MHz_max": round(max(f), 1) if f else None, "samples": len(w), "period_ms": round(1e3 * span / len(w), 1),
+                "source": self.card + (" (PCI address matched to the torch device)" if self.matched else " (first card with a power sensor)"),
+                "note": "sampled over the timed steps only; the roofline peaks are nominal (2.4 GHz) figures, the chip sustains the clock "
+                        "reported here under this load"}
+
+
 def measure_peaks(torch, dev):
     """What THIS box sustains, in the same run: a streaming copy (HBM) and register-resident MFMA loops
     (csrc/peaks.hip), HIP-event timed.  BASELINE.md section 4: fractions are printed against nominal AND measured."""
@@ -353,7 +420,11 @@ def main():
     one_lane = extractor is None or a.extract_lanes <= 1 or bdt is not None
     if extractor is not None and one_lane:
         _clib.check(_clib.load().cslam_trunk_timing(1))       # two HIP events per product launch, on the launch stream
+    sensors = BoardSensors(torch, dev.index or 0) if rank == 0 else None
+    if sensors is not None:
+        sensors.start()
     dt = timed(step, a.steps)
+    board = sensors.finish() if sensors is not None else None
     if extractor is not None and one_lane:
         trunk_times = read_trunk_times()
     step_kernel_ms = [m for m in kernel_ms if m > 0]
@@ -768,8 +839,9 @@ def main():
                 "conv3_1 ... conv5_3: F(4x4) Winograd with this library's GEMM (csrc/wino_gemm.hip) over exact fp16 hi/lo "
                 "pairs of both operands, 3 of the 4 partial products on the fp16 MFMA pipe with fp32 accumulation (error vs "
                 "float64 = that of the fp32 GEMM, tests/test_heads_gpu.py::test_split16_*, tests/test_wino_gemm_gpu.py); "
-                "conv1_1 + conv1_2: ONE kernel (first layer folded into the one-kernel Winograd convolution, fp16 pairs, "
-                "csrc/wino_fused_h.hip); conv2_1, conv2_2: the direct one-kernel convolution on fp16 pairs (csrc/conv_direct_h.hip)"),
+                "conv1_1 + conv1_2: ONE direct kernel on fp16 pairs, the second layer's weights register-resident "
+                "(csrc/conv_stem_direct_h.hip); conv2_1: the same form (csrc/conv_direct_r.hip); conv2_2: the direct one-kernel "
+                "convolution on fp16 pairs, weights through LDS (csrc/conv_direct_h.hip)"),
             "extract_only_fp32_gemms": None if extract_fp32_gemms is None else round(extract_fp32_gemms, 2),
             "match_only": round(match_only, 2),
             "match_only_queries": nqm,
@@ -779,6 +851,7 @@ def main():
             "roofline_step_largest": roofline_step_largest,
             "roofline_extract": extract_roofline,
             "cpu_baseline": cpu,
+            "board": board,
         }
         print(json.dumps(line))
     if world > 1:
