@@ -91,6 +91,16 @@ __device__ __forceinline__ float cd_pool4(float v) {
     return v;
 }
 
+// v - (float)half HI of the packed pair h: one v_fma_mix_f32, the fp16 operand read in place (conv_stem_direct_h.hip's sd_sub_half)
+template <int HI>
+__device__ __forceinline__ float cd_sub_half(float v, __half2 h) {
+    float d;
+    const unsigned hb = *(const unsigned *)&h;
+    if (HI) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hb), "v"(v));
+    else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hb), "v"(v));
+    return d;
+}
+
 template <bool RELU, bool POOL, int DBG = 0, bool PIXA = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_direct_h_kernel(ConvDirectArgs p) {
     extern __shared__ __attribute__((aligned(16))) char cd_smem[];
@@ -209,8 +219,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_h_kernel(ConvDirectArgs
             const bool in = (inmask >> (3 * half + j)) & 1u;
             const float w0 = in ? stg[j].x * sx : 0.0f, w1 = in ? stg[j].y * sx : 0.0f, w2 = in ? stg[j].z * sx : 0.0f, w3 = in ? stg[j].w * sx : 0.0f;
             const __half2 h01 = __floats2half2_rn(w0, w1), h23 = __floats2half2_rn(w2, w3);
-            const float2 f01 = __half22float2(h01), f23 = __half22float2(h23);
-            const __half2 l01 = __floats2half2_rn(w0 - f01.x, w1 - f01.y), l23 = __floats2half2_rn(w2 - f23.x, w3 - f23.y);
+            // w - (float)hi straight out of the packed register (v_fma_mix_f32; through __half22float2 hipcc rounds every value a second
+            // time with a scalar v_cvt_f16_f32, converts that back and subtracts: three instructions per value instead of one)
+            const __half2 l01 = __floats2half2_rn(cd_sub_half<0>(w0, h01), cd_sub_half<1>(w1, h01));
+            const __half2 l23 = __floats2half2_rn(cd_sub_half<0>(w2, h23), cd_sub_half<1>(w3, h23));
             char *d = pd >= 0 ? dst + pd : s_sink;
             *(uint2 *)d = make_uint2(*(const unsigned *)&h01, *(const unsigned *)&h23);
             *(uint2 *)(d + 64) = make_uint2(*(const unsigned *)&l01, *(const unsigned *)&l23);

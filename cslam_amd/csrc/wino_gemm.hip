@@ -711,6 +711,15 @@ __device__ __forceinline__ void wg_bt4(wf4 &d0, wf4 &d1, wf4 &d2, wf4 &d3, wf4 &
     d0 = r0; d1 = r1; d2 = r2; d3 = r3; d4 = r4; d5 = r5;
 }
 
+template <int HI>
+__device__ __forceinline__ float wg_sub_half(float v, __half2 h) {       // v - (float)half HI of the packed pair h: one v_fma_mix_f32
+    float d;
+    const unsigned hb = *(const unsigned *)&h;
+    if (HI) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hb), "v"(v));
+    else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hb), "v"(v));
+    return d;
+}
+
 // V = B^T d B of every 6 x 6 input tile of x [B,H,W,C] (NHWC, times the power-of-two scale derived from *amax), split into
 // fp16 pairs and stored as V2 [36][T][C/32][hi 32 | lo 32].  One thread = one tile x 4 consecutive channels: 16-byte
 // loads; per frequency the hi and the lo halves of its 4 channels (8 bytes each) -- lanes 2k / 2k + 1 trade them (DPP) so that
@@ -756,8 +765,10 @@ __global__ __launch_bounds__(256) void wino4_input_h2_kernel(const float *__rest
         for (int j = 0; j < 6; ++j) {
             const wf4 v = d[i][j];
             const __half2 h0v = __floats2half2_rn(v.x, v.y), h1v = __floats2half2_rn(v.z, v.w);
-            const float2 f0 = __half22float2(h0v), f1 = __half22float2(h1v);
-            const __half2 l0v = __floats2half2_rn(v.x - f0.x, v.y - f0.y), l1v = __floats2half2_rn(v.z - f1.x, v.w - f1.y);
+            // v - (float)hi read in place out of the packed register (one v_fma_mix_f32 per value; through __half22float2 hipcc rounds
+            // the value once more with a scalar conversion, converts back and subtracts)
+            const __half2 l0v = __floats2half2_rn(wg_sub_half<0>(v.x, h0v), wg_sub_half<1>(v.y, h0v));
+            const __half2 l1v = __floats2half2_rn(wg_sub_half<0>(v.z, h1v), wg_sub_half<1>(v.w, h1v));
             wu2 hi, lo;
             hi.x = *(const unsigned *)&h0v; hi.y = *(const unsigned *)&h1v;
             lo.x = *(const unsigned *)&l0v; lo.y = *(const unsigned *)&l1v;
