@@ -551,6 +551,18 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
             // peak with 15 x 27-tile segments over 391 tiles vs 87.5 % with even splits
             double balance = (double)n_btiles / ((double)se * t);
             double eff = T / (rounds * slots) * balance * balance * ((double)t / (t + 0.3)) - 0.0005 * se;
+            if (nprod == 1 && tile == 256) {
+                // The one-product stage on 256 x 256 tiles, refitted on forced segment counts (profiles/r04_v71_match_nseg_sweep.log:
+                // 100k rows x 16 384 / 49 152 / 100 000 queries, 1 ... 23 segments): a launch takes rounds x (t + R) tile-times with
+                // R = min(8, 0.3 t) (at least 4 over several rounds) -- every round of work items costs several tile-times beyond its tiles (49 152 queries: 4
+                // segments = 3 rounds of 98 tiles 35.8 ms, 8 = 6 rounds of 49 tiles 38.5, 17 = 13 rounds of 23 tiles 41.9), which the
+                // 0.3 above (fitted on the f32 stage, whose tile-time is 16 x longer) does not see.  At least 4 segments once the
+                // chip is full: fewer leave too few candidates per query for the certificate (2 segments: uncertified queries).
+                double R = fmin(8.0, 0.3 * t);
+                if (rounds > 1.0 && R < 4.0) R = 4.0;          // short items over many rounds were not measured: kept out of reach
+                const double cost = rounds * (t + R) / (balance * balance) * (1.0 + 0.0005 * se);
+                eff = (se < 4 && T >= slots) ? -1.0 : 1.0e6 / cost;
+            }
             if (eff > best) { best = eff; nseg = se; tps = t; }
         }
     }
