@@ -19,13 +19,37 @@ import threading
 import time
 
 
-def find_hwmon():
+def all_hwmon():
+    out = []
     for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
         files = {f: os.path.join(d, f) for f in ("power1_average", "power1_input", "power1_cap", "freq1_input")
                  if os.path.exists(os.path.join(d, f))}
         if "power1_average" in files or "power1_input" in files:
-            return d, files
-    return None, {}
+            out.append((d, files))
+    return out
+
+
+def find_hwmon():
+    """The card under load: a box shows the sensors of all eight GPUs of its node but runs on one -- the one whose power rises when a
+    short matrix load runs on the visible device (first card with a power sensor if torch is not there)."""
+    cards = all_hwmon()
+    if len(cards) <= 1:
+        return cards[0] if cards else (None, {})
+    try:
+        import torch
+        pf = [c[1].get("power1_average") or c[1].get("power1_input") for c in cards]
+        a = torch.randn((8192, 8192), device="cuda", dtype=torch.float16)
+        peak = [0] * len(cards)
+        t_end = time.time() + 2.0
+        while time.time() < t_end:
+            for _ in range(20):
+                a @ a
+            for i, f in enumerate(pf):
+                peak[i] = max(peak[i], read_int(f) or 0)
+        torch.cuda.synchronize()
+        return cards[max(range(len(cards)), key=lambda i: peak[i])]
+    except Exception:  # noqa: BLE001
+        return cards[0]
 
 
 def read_int(path):

@@ -3,6 +3,7 @@
     python tools/steady_loop.py gemm [seconds=12] [hw=28] [cin=512] [cout=512]    the trunk's pair GEMM (csrc/wino_gemm.hip), 256 frames
     python tools/steady_loop.py match [seconds=12] [nq=16384]                     the candidate stage + re-scoring on a 100k x 4096 bank
     python tools/steady_loop.py stem [seconds=12]                                 the direct stem kernel, 256 frames
+    python tools/steady_loop.py conv21 | conv22 | input [seconds=12]              conv2_1 / conv2_2 (direct kernels), the input transform of conv3_2
     python tools/steady_loop.py peak16 [seconds=12]                               csrc/peaks.hip's register-resident fp16 MFMA loop, non-zero operands
 Prints ms per launch over the whole loop (HIP events) and the launches done."""
 import ctypes as C
@@ -52,6 +53,27 @@ elif what == "stem":
     trunk = wg.WinogradTrunk(seq, 64, 4, fused64=True)
     flop = 3 * 2.0 * 256 * 224 * 224 * 9 * 64 * 64
     fn = lambda: trunk(x)  # noqa: E731
+elif what in ("conv21", "conv22"):
+    from torch import nn as tnn
+    cin, pool = (64, False) if what == "conv21" else (128, True)
+    seq = tnn.Sequential(*([tnn.Conv2d(cin, 128, 3, padding=1), tnn.ReLU()] + ([tnn.MaxPool2d(2, 2)] if pool else []))).cuda().eval()
+    x = torch.relu(torch.randn((256, cin, 112, 112), device="cuda")).contiguous(memory_format=torch.channels_last)
+    trunk = wg.WinogradTrunk(seq, 64, 4, fused64=True)
+    flop = 3 * 2.0 * 256 * 112 * 112 * 9 * cin * 128
+    fn = lambda: trunk(x)  # noqa: E731
+elif what in ("input", "output"):
+    hw, c = 56, 256
+    B = 256
+    x = torch.relu(torch.randn((B, c, hw, hw), device="cuda")).contiguous(memory_format=torch.channels_last)
+    T = B * (hw // 4) * (hw // 4)
+    slot = torch.zeros(1, dtype=torch.float32, device="cuda")
+    _lib.check(lib.cslam_absmax_dev(p(x), x.numel(), p(slot), st))
+    V2 = torch.empty((36, T, c), device="cuda")
+    flop = 0.0
+    nbytes = B * hw * hw * c * 4 + 36 * T * c * 4
+    fn = lambda: _lib.check(lib.cslam_wino4_input_h2_dev(p(x), B, hw, hw, c, p(slot), p(V2), st))  # noqa: E731
+    if what == "output":
+        raise SystemExit("output transform: not wired here")
 elif what == "peak16":
     scratch = torch.zeros(16, dtype=torch.float32, device="cuda")
     fl = C.c_double(0.0)
@@ -74,4 +96,5 @@ while time.time() < t_end:
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / n
-print(f"{what}: {n} launches, {ms:.3f} ms each = {flop / ms / 1e9:.0f} TFLOP/s (fp16 flop issued; match: 2 D flop per pair)")
+extra = f", {nbytes / ms / 1e6:.0f} GB/s algorithmic" if what == "input" else ""
+print(f"{what}: {n} launches, {ms:.3f} ms each = {flop / ms / 1e9:.0f} TFLOP/s (fp16 flop issued; match: 2 D flop per pair){extra}")
