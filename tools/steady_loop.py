@@ -3,7 +3,7 @@
     python tools/steady_loop.py gemm [seconds=12] [hw=28] [cin=512] [cout=512]    the trunk's pair GEMM (csrc/wino_gemm.hip), 256 frames
     python tools/steady_loop.py match [seconds=12] [nq=16384]                     the candidate stage + re-scoring on a 100k x 4096 bank
     python tools/steady_loop.py stem [seconds=12]                                 the direct stem kernel, 256 frames
-    python tools/steady_loop.py conv21 | conv22 | input [seconds=12]              conv2_1 / conv2_2 (direct kernels), the input transform of conv3_2
+    python tools/steady_loop.py conv21 | conv22 | input | copy [seconds=12]       conv2_1 / conv2_2 (direct kernels), the input transform of conv3_2, a 1 GiB copy
     python tools/steady_loop.py peak16 [seconds=12]                               csrc/peaks.hip's register-resident fp16 MFMA loop, non-zero operands
 Prints ms per launch over the whole loop (HIP events) and the launches done."""
 import ctypes as C
@@ -74,6 +74,13 @@ elif what in ("input", "output"):
     fn = lambda: _lib.check(lib.cslam_wino4_input_h2_dev(p(x), B, hw, hw, c, p(slot), p(V2), st))  # noqa: E731
     if what == "output":
         raise SystemExit("output transform: not wired here")
+elif what == "copy":
+    nb = 1 << 30
+    src = torch.empty(nb // 4, dtype=torch.float32, device="cuda").normal_()
+    dst = torch.empty_like(src)
+    flop = 0.0
+    nbytes = 2 * nb
+    fn = lambda: _lib.check(lib.cslam_peak_copy_dev(p(src), p(dst), C.c_int64(nb), 2, st))  # noqa: E731
 elif what == "peak16":
     scratch = torch.zeros(16, dtype=torch.float32, device="cuda")
     fl = C.c_double(0.0)
@@ -96,5 +103,5 @@ while time.time() < t_end:
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / n
-extra = f", {nbytes / ms / 1e6:.0f} GB/s algorithmic" if what == "input" else ""
+extra = f", {nbytes / ms / 1e6:.0f} GB/s algorithmic" if what in ("input", "copy") else ""
 print(f"{what}: {n} launches, {ms:.3f} ms each = {flop / ms / 1e9:.0f} TFLOP/s (fp16 flop issued; match: 2 D flop per pair){extra}")
