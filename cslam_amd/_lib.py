@@ -131,6 +131,7 @@ _SIGNATURES = {
     "cslam_peak_copy_dev": (_i, [_vp, _vp, _i64, _i, _vp]),
     "cslam_peak_mfma_dev": (_i, [_i, _i, _i, _i, _vp, C.POINTER(C.c_double), _vp]),
     "cslam_debug_last_candidates": (_i, [_vp, _i64, C.POINTER(_i), _vp, _vp, C.POINTER(C.c_double)]),
+    "cslam_ring_schedule_describe": (_i, [_i, _i, _i, _i, C.POINTER(C.c_int32 * 6), _vp, _i64, _vp, _vp, _vp]),
     "cslam_trunk_timing": (_i, [_i]),
     "cslam_trunk_timing_read": (_i, [C.POINTER(C.c_double * 8)]),
 }
@@ -138,7 +139,7 @@ _SIGNATURES = {
 # declared in include/cslam_hip_experimental.h (A/B partners, profiling hooks, peak micro-benchmarks), not in the stable ABI
 EXPERIMENTAL_SYMBOLS = ("cslam_wino4_input_h3_dev", "cslam_wino2_fused64_dev", "cslam_wino2_fused_c64_dev",
                         "cslam_wino4_fused_c64_dev", "cslam_debug_wfh_prof_dev", "cslam_peak_copy_dev", "cslam_peak_mfma_dev",
-                        "cslam_debug_last_candidates", "cslam_trunk_timing", "cslam_trunk_timing_read")
+                        "cslam_debug_last_candidates", "cslam_ring_schedule_describe", "cslam_trunk_timing", "cslam_trunk_timing_read")
 EXPORTED_SYMBOLS = tuple(n for n in _SIGNATURES if n not in EXPERIMENTAL_SYMBOLS)
 
 

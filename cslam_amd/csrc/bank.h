@@ -2,6 +2,7 @@
 #pragma once
 #include "common.h"
 #include <vector>
+#include "sim_topk.h"
 
 struct cslam_bank {
     int device;
@@ -40,6 +41,8 @@ struct cslam_bank {
     int num_cu;
     std::vector<int> item_map_host;   // cached work-item order of the MFMA path (see sim_topk_mfma.hip)
     int item_map_key[4];
+    RingSchedule ring_sched;          // cached static schedule of the persistent candidate stage (sim_topk_ring.hip)
+    bool dbg_ring;                    // the last MFMA-mode search used it: its lists have the per-query-tile layout
     int *h_nflag;                     // pinned: count of uncertified queries of the last enqueued MFMA search
     int *pending_flag_list;           // device list those queries are in (bank workspace)
     int *pending_flag_count;          // device count of that list (bank workspace)

@@ -19,6 +19,48 @@ struct PairArgs {
     float *part_bound;                   // [nqt * T][nseg] upper bound of the key of every row of the segment NOT in the list
 };
 
+// ---- the persistent form of the one-product stage (sim_topk_ring.hip) ------------------------------------------------------
+// One workgroup per CU for the whole launch; the workgroups of an XCD form an Sq x Sb patch (query tiles x bank tiles) that
+// walks the bank Sb tiles at a time, all of them at the same K position, so every operand stream of the patch is fetched into
+// the XCD's L2 once and read Sq (bank) or Sb (queries) times.  A task = one query tile against the strided bank tiles
+// t_beg, t_beg + t_stride, ... (t_cnt of them); its merged candidate list is "segment" `seg` of that query tile.
+struct RingTask {
+    int qt, t_beg, t_cnt, seg;
+    int sync_base, sync_n, sync_expect, pad;    // tile-start rendezvous of the patch: counters sync_base + i, i < sync_n
+};
+struct RingArgs {
+    const char *bank2; int64_t ldb2;     // bank rows as fp16 (hi halves), pitch in bytes
+    const float *invs; int n_rows;
+    const char *q2; int64_t ldq2;        // queries as fp16 [nqt * 256][ldq2]
+    const float *qinvs;
+    const int *lim;
+    const int *qt_maxlim;
+    int nkt;                             // K stages of 128 bytes per row
+    int nqt, n_btiles, t_stride;
+    int n_xcd, wpx;                      // workgroup b = slot b / n_xcd of XCD b % n_xcd
+    const RingTask *tasks;               // tasks of workgroup w: [task_off[w], task_off[w + 1])
+    const int *task_off;
+    const int *qt_nseg, *qt_segoff;      // per query tile: lists per query, lists before this tile's (in units of 256 queries' lists)
+    float *part_key; int *part_idx;      // list l of query j of tile qt at ((qt_segoff[qt] * 256 + j * qt_nseg[qt] + l) * SIM_KP
+    float *part_bound;
+    int *sync;                           // rendezvous counters (zeroed per launch) or nullptr
+    int *xcc_out;                        // diagnostics: [workgroups] HW_REG_XCC_ID of the CU each workgroup ran on, or nullptr
+    long long *trace_out;                // diagnostics: [workgroups][64] wall clock (100 MHz) at the top of the first 62 tiles of the first task,
+                                         //              [62] = timed-out rendezvous waits, [63] = wall clock at kernel exit; or nullptr
+    int stagger_cycles;                  // measurement build: a workgroup starts its first task tasks[].pad x this many cycles late
+};
+struct RingSchedule {                    // host side, cached per bank
+    int nqt, n_btiles, n_xcd, wpx;       // key
+    int stag_q, stag_b;
+    int sq, sb, total_lists;             // total_lists = sum of qt_nseg (lists per query, summed over query tiles)
+    int n_sync;
+    std::vector<RingTask> tasks;
+    std::vector<int> task_off, qt_nseg, qt_segoff;
+};
+// stag_q / stag_b (measurement build): start offset of patch slot (qi, bi), in units of RingArgs::stagger_cycles
+void ring_schedule_build(RingSchedule &s, int nqt, int n_btiles, int n_xcd, int wpx, int stag_q = 0, int stag_b = 0);
+int ring_stage1_launch(const RingArgs &a, int variant, int dbg, hipStream_t st);
+
 double pair_err_bound(int kd, int nprod);
 int pair_stage1_launch(const PairArgs &a, int tile, int nprod, int dbg, hipStream_t st);
 // kd = the K extent the query copy is padded to with zeros (whole stages: a multiple of 32 for pairs, of 64 for hi halves)

@@ -339,11 +339,20 @@ __global__ __launch_bounds__(256) void rescore_kernel(
     const float *__restrict__ part_bound, int nseg,
     int k, double err_bound,
     int64_t *__restrict__ out_idx, double *__restrict__ out_sim, int32_t *__restrict__ out_cnt,
-    int *__restrict__ flag_list, int *__restrict__ flag_count) {
+    int *__restrict__ flag_list, int *__restrict__ flag_count,
+    const int *__restrict__ qt_nseg, const int *__restrict__ qt_segoff, int seg_tile) {
     const int lane = threadIdx.x & 63;
     const int qn = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (qn >= nq) return;
     const QS *qp = q + (size_t)qn * ldq;
+    // lists of this query: `nseg` of them from list number `l0` on.  Uniform layout [nq][nseg] (one workgroup per work item), or
+    // the persistent stage's per-query-tile counts (sim_topk_ring.hip: a tile's walk may be cut into several runs)
+    size_t l0 = (size_t)qn * nseg;
+    if (qt_nseg) {
+        const int qt = qn / seg_tile;
+        nseg = qt_nseg[qt];
+        l0 = (size_t)qt_segoff[qt] * seg_tile + (size_t)(qn - qt * seg_tile) * nseg;
+    }
 
     // uu = q.q (float64)
     double uu = 0.0;
@@ -354,15 +363,15 @@ __global__ __launch_bounds__(256) void rescore_kernel(
     // 1. t32 = upper bound on the f32 key of every row NOT kept: the per-segment bounds of stage 1 ...
     double t32 = -INFINITY;
     for (int s = lane; s < nseg; s += 64) {
-        double bnd = (double)part_bound[(size_t)qn * nseg + s];
+        double bnd = (double)part_bound[l0 + s];
         t32 = bnd > t32 ? bnd : t32;
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { double o = __shfl_xor(t32, off, 64); t32 = o > t32 ? o : t32; }
     //    ... and whatever the merge of the per-segment lists below drops.
     WaveList cand; cand.init();
-    const float *pk = part_key + (size_t)qn * nseg * KP;
-    const int *pi = part_idx + (size_t)qn * nseg * KP;
+    const float *pk = part_key + l0 * KP;
+    const int *pi = part_idx + l0 * KP;
     const int total = nseg * KP;
     for (int base = 0; base < total; base += 64) {
         int e = base + lane;
@@ -514,7 +523,7 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
 #ifdef CSLAM_ABLATIONS
         const char *v = getenv("CSLAM_MFMA_DBG");       // timing-only ablations (wrong results), see the kernel: never in the default build
         dbg = v ? atoi(v) : 0;
-        if (dbg < 0 || dbg > 2) dbg = 0;
+        if (dbg < 0 || dbg > 7) dbg = 0;          // 3..5: the persistent stage only (sim_topk_ring.hip)
 #endif
         const char *t = getenv("CSLAM_MFMA_TILE");      // 128 | 256 (default chosen below)
         tile_env = t ? atoi(t) : 0;
@@ -535,7 +544,33 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     // (shorter candidate merge in rescore_kernel).
     const int slots = (tile == 256 ? 1 : 2) * b->num_cu;
     int nseg = 1, tps = n_btiles;
-    {
+    // The one-product stage on 256 x 256 tiles runs as a persistent kernel on a static XCD-aligned schedule (sim_topk_ring.hip);
+    // variant bit 0 = tile-start rendezvous of a patch, bit 1 = static priority for the younger waves.
+    bool ring = nprod == 1 && tile == 256 && b->num_cu >= 8;
+    int ring_variant = 0;
+#ifdef CSLAM_ABLATIONS
+    if (const char *r = getenv("CSLAM_MFMA_RING")) {     // measurement build: -1 = the one-workgroup-per-item kernel, 0..3 = variant
+        const int v = atoi(r);
+        if (v < 0) ring = false; else ring_variant = v & 3;
+    }
+#endif
+    RingSchedule *rs = nullptr;
+    int stag_q = 0, stag_b = 0, stag_cycles = 0;
+    bool want_xcc = false;
+#ifdef CSLAM_ABLATIONS
+    if (const char *e = getenv("CSLAM_RING_STAGGER")) (void)sscanf(e, "%d,%d,%d", &stag_q, &stag_b, &stag_cycles);
+    want_xcc = getenv("CSLAM_RING_XCC") != nullptr;
+#endif
+    if (ring) {
+        const int n_xcd = b->num_cu % 8 == 0 ? 8 : 1;
+        const int wpx = b->num_cu / n_xcd;
+        rs = &b->ring_sched;
+        if (rs->nqt != nqt || rs->n_btiles != n_btiles || rs->n_xcd != n_xcd || rs->wpx != wpx || rs->stag_q != stag_q || rs->stag_b != stag_b)
+            ring_schedule_build(*rs, nqt, n_btiles, n_xcd, wpx, stag_q, stag_b);
+        nseg = 0;
+        for (int v : rs->qt_nseg) nseg = v > nseg ? v : nseg;       // reported; the lists have per-query-tile counts
+    }
+    if (!ring) {
         double best = -1.0;
         int max_seg = (int)ceil_div64(slots, nqt);      // few query tiles: split finer to fill the chip
         if (max_seg < 64) max_seg = 64;
@@ -580,12 +615,20 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     size_t o_qs = carve(pair ? (size_t)nq_pad * 4 : 0);
     size_t o_lim = carve((size_t)nq_pad * 4);
     size_t o_qtm = carve((size_t)nqt * 4);
-    size_t o_pk = carve((size_t)nq_pad * nseg * KP * 4);
-    size_t o_pi = carve((size_t)nq_pad * nseg * KP * 4);
-    size_t o_pb = carve((size_t)nq_pad * nseg * 4);
+    const size_t n_lists = ring ? (size_t)rs->total_lists * tile : (size_t)nq_pad * nseg;
+    size_t o_pk = carve(n_lists * KP * 4);
+    size_t o_pi = carve(n_lists * KP * 4);
+    size_t o_pb = carve(n_lists * 4);
     size_t o_fl = carve((size_t)nq * 4);
     size_t o_fc = carve(256);
-    size_t o_im = carve((size_t)nqt * nseg * 4);
+    size_t o_im = carve(ring ? 0 : (size_t)nqt * nseg * 4);
+    size_t o_rt = carve(ring ? rs->tasks.size() * sizeof(RingTask) : 0);
+    size_t o_ro = carve(ring ? rs->task_off.size() * 4 : 0);
+    size_t o_rn = carve(ring ? (size_t)nqt * 4 : 0);
+    size_t o_rs = carve(ring ? (size_t)nqt * 4 : 0);
+    size_t o_ry = carve(ring ? (size_t)(rs->n_sync > 0 ? rs->n_sync : 1) * 4 : 0);
+    size_t o_rx = carve(ring && want_xcc ? (size_t)b->num_cu * 4 : 0);
+    size_t o_rz = carve(ring && want_xcc ? ((size_t)b->num_cu * 64 + 8 * 48 * 2 + 8) * 8 : 0);
     int rc = bank_ws_reserve(b, 0, off);
     if (rc) return rc;
     char *ws = b->ws[0];
@@ -598,7 +641,13 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     int *flag_list = (int *)(ws + o_fl);
     int *flag_count = (int *)(ws + o_fc);
     int *item_map = (int *)(ws + o_im);
-    {
+    if (ring) {
+        HIP_TRY(hipMemcpyAsync(ws + o_rt, rs->tasks.data(), rs->tasks.size() * sizeof(RingTask), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ws + o_ro, rs->task_off.data(), rs->task_off.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ws + o_rn, rs->qt_nseg.data(), (size_t)nqt * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ws + o_rs, rs->qt_segoff.data(), (size_t)nqt * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(ws + o_ry, 0, (size_t)(rs->n_sync > 0 ? rs->n_sync : 1) * 4, st));
+    } else {
         // patch-major order of the (query tile, segment) grid; patches of a x bseg items ~ the number
         // of workgroups resident per XCD
         const int per_xcd = slots / 8 > 0 ? slots / 8 : 1;
@@ -652,7 +701,77 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     // a SIMD used to issue their 8 loads together right after the barrier); -0.5 on the 128 tile, whose
     // two independent workgroups per CU already overlap each other's issue slots
     const int ilv = tile == 256 ? 1 : 0;
-    if (pair) {
+    if (ring) {
+        RingArgs ra;
+        ra.bank2 = b->rowsh; ra.ldb2 = ldq2; ra.invs = b->invs; ra.n_rows = (int)b->n;
+        ra.q2 = ws + o_q32; ra.ldq2 = ldq2; ra.qinvs = (const float *)(ws + o_qs);
+        ra.lim = lim; ra.qt_maxlim = qtm; ra.nkt = b->kh / 64;
+        ra.nqt = nqt; ra.n_btiles = n_btiles; ra.t_stride = rs->sb; ra.n_xcd = rs->n_xcd; ra.wpx = rs->wpx;
+        ra.tasks = (const RingTask *)(ws + o_rt); ra.task_off = (const int *)(ws + o_ro);
+        ra.qt_nseg = (const int *)(ws + o_rn); ra.qt_segoff = (const int *)(ws + o_rs);
+        ra.part_key = part_key; ra.part_idx = part_idx; ra.part_bound = part_bound;
+        ra.sync = (ring_variant & 1) ? (int *)(ws + o_ry) : nullptr;
+        ra.xcc_out = want_xcc ? (int *)(ws + o_rx) : nullptr; ra.stagger_cycles = stag_cycles;
+        ra.trace_out = want_xcc ? (long long *)(ws + o_rz) : nullptr;
+        if (want_xcc) HIP_TRY(hipMemsetAsync(ws + o_rz, 0, ((size_t)b->num_cu * 64 + 8 * 48 * 2 + 8) * 8, st));
+        rc = ring_stage1_launch(ra, ring_variant, dbg, st);
+        if (want_xcc && rc == CSLAM_OK) {            // measurement build: print the placement (block b is assumed on XCD b % n_xcd)
+            std::vector<int> hx(b->num_cu);
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipMemcpy(hx.data(), ws + o_rx, hx.size() * 4, hipMemcpyDeviceToHost));
+            int ok = 0;
+            for (int i = 0; i < b->num_cu; ++i) ok += (hx[i] & 15) == i % rs->n_xcd;
+            fprintf(stderr, "[ring] XCC_ID == block %% %d for %d of %d workgroups; first 16:", rs->n_xcd, ok, b->num_cu);
+            for (int i = 0; i < 16 && i < b->num_cu; ++i) fprintf(stderr, " %d", hx[i]);
+            fprintf(stderr, "\n");
+            // tile-start spread of every XCD's patch (first task): max - min of the 32 workgroups' wall clocks, per tile, in us
+            std::vector<long long> tr((size_t)b->num_cu * 64);
+            HIP_TRY(hipMemcpy(tr.data(), ws + o_rz, tr.size() * 8, hipMemcpyDeviceToHost));
+            long long t0 = -1;
+            for (int w = 0; w < b->num_cu; ++w) if (tr[(size_t)w * 64] > 0 && (t0 < 0 || tr[(size_t)w * 64] < t0)) t0 = tr[(size_t)w * 64];
+            for (int x = 0; x < rs->n_xcd; x += 3) {
+                fprintf(stderr, "[ring] XCD %d tile: start(us) spread(us):", x);
+                for (int i = 0; i < 62; i += (i < 8 ? 1 : 6)) {
+                    long long lo = -1, hi = -1;
+                    for (int w = x; w < b->num_cu; w += rs->n_xcd) {
+                        const long long v = tr[(size_t)w * 64 + i];
+                        if (v <= 0) continue;
+                        if (lo < 0 || v < lo) lo = v;
+                        if (v > hi) hi = v;
+                    }
+                    if (lo > 0) fprintf(stderr, "  %d: %.0f %.1f", i, (lo - t0) * 0.01, (hi - lo) * 0.01);
+                }
+                long long to = 0;
+                for (int w = x; w < b->num_cu; w += rs->n_xcd) to += tr[(size_t)w * 64 + 62];
+                fprintf(stderr, "  timeouts %lld\n", to);
+            }
+            for (int i = 1; i <= 3; i += 2) {
+                fprintf(stderr, "[ring] XCD 0, start of tile %d by slot (qi-major, Sb = %d), us after the first:", i, rs->sb);
+                for (int sl = 0; sl < rs->wpx; ++sl) fprintf(stderr, "%s%.0f", sl % rs->sb == 0 ? " | " : " ", (tr[(size_t)(sl * rs->n_xcd) * 64 + i] - t0) * 0.01);
+                fprintf(stderr, "\n");
+            }
+            if (dbg == 1) {       // barrier stamps of workgroup 0: per stage, arrival of each wave relative to the first arrival, and the release
+                std::vector<long long> bt(8 * 48 * 2 + 8);
+                HIP_TRY(hipMemcpy(bt.data(), ws + o_rz + (size_t)b->num_cu * 64 * 8, bt.size() * 8, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[ring] HW_ID simd of waves 0..7:");
+                for (int w = 0; w < 8; ++w) fprintf(stderr, " %lld", (bt[8 * 48 * 2 + w] >> 4) & 3);
+                fprintf(stderr, "\n");
+                for (int it2 = 8; it2 < 48; it2 += 3) {
+                    long long first = -1, last = -1;
+                    for (int w = 0; w < 8; ++w) { const long long v = bt[((size_t)w * 48 + it2) * 2]; if (first < 0 || v < first) first = v; if (v > last) last = v; }
+                    const long long prev_rel = bt[((size_t)0 * 48 + it2 - 1) * 2 + 1];
+                    fprintf(stderr, "[ring] stage %2d: length %5lld  arrivals", it2, last - prev_rel);
+                    for (int w = 0; w < 8; ++w) fprintf(stderr, " %4lld", bt[((size_t)w * 48 + it2) * 2] - first);
+                    fprintf(stderr, "  release after last arrival:");
+                    for (int w = 0; w < 8; ++w) fprintf(stderr, " %3lld", bt[((size_t)w * 48 + it2) * 2 + 1] - last);
+                    fprintf(stderr, "\n");
+                }
+            }
+            long long elo = -1, ehi = -1;
+            for (int w = 0; w < b->num_cu; ++w) { const long long v = tr[(size_t)w * 64 + 63]; if (v > 0) { if (elo < 0 || v < elo) elo = v; if (v > ehi) ehi = v; } }
+            fprintf(stderr, "[ring] kernel exits between %.0f and %.0f us after the first tile start\n", (elo - t0) * 0.01, (ehi - t0) * 0.01);
+        }
+    } else if (pair) {
         PairArgs pa;
         pa.bank2 = nprod == 1 ? b->rowsh : b->rows2; pa.ldb2 = ldq2; pa.invs = b->invs; pa.n_rows = (int)b->n;
         pa.q2 = ws + o_q32; pa.ldq2 = ldq2; pa.qinvs = (const float *)(ws + o_qs);
@@ -674,11 +793,13 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     if (q_dtype == CSLAM_F32)
         hipLaunchKernelGGL(rescore_kernel<float>, dim3(rgrid), dim3(256), 0, st, b->rows, (int64_t)ld, kd, b->vv,
                            (const float *)d_q, ldq, b->dim, (int)nq, part_key, part_idx, part_bound, nseg, k,
-                           err_bound, d_out_idx, d_out_sim, d_out_cnt, flag_list, flag_count);
+                           err_bound, d_out_idx, d_out_sim, d_out_cnt, flag_list, flag_count,
+                           ring ? (const int *)(ws + o_rn) : nullptr, ring ? (const int *)(ws + o_rs) : nullptr, tile);
     else
         hipLaunchKernelGGL(rescore_kernel<double>, dim3(rgrid), dim3(256), 0, st, b->rows, (int64_t)ld, kd, b->vv,
                            (const double *)d_q, ldq, b->dim, (int)nq, part_key, part_idx, part_bound, nseg, k,
-                           err_bound, d_out_idx, d_out_sim, d_out_cnt, flag_list, flag_count);
+                           err_bound, d_out_idx, d_out_sim, d_out_cnt, flag_list, flag_count,
+                           ring ? (const int *)(ws + o_rn) : nullptr, ring ? (const int *)(ws + o_rs) : nullptr, tile);
     HIP_TRY(hipGetLastError());
 
     // uncertified queries -> exact scan (needs the count on the host: one 4-byte readback into pinned memory, read by
@@ -691,6 +812,7 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     b->pending_flag_count = flag_count;
     b->pending_dbg = dbg;
     b->dbg_part_key = part_key; b->dbg_part_idx = part_idx; b->dbg_nseg = nseg; b->dbg_nq = (int)nq; b->dbg_err_bound = err_bound;
+    b->dbg_ring = ring;
     return CSLAM_OK;
 }
 
@@ -724,6 +846,26 @@ CSLAM_API int cslam_debug_last_candidates(cslam_bank_t *b, int64_t nq, int *nseg
     *nseg = b->dbg_nseg;
     if (err_bound) *err_bound = b->dbg_err_bound;
     HIP_TRY(hipStreamSynchronize(b->last_stream));
+    if (b->dbg_ring) {
+        // the persistent stage keeps per-query-tile list counts: hand them out in the uniform layout, missing lists empty
+        const RingSchedule &rs = b->ring_sched;
+        const int T = 256, ns_out = b->dbg_nseg;
+        std::vector<float> hk(keys ? (size_t)rs.total_lists * T * KP : 0);
+        std::vector<int> hi(rows ? (size_t)rs.total_lists * T * KP : 0);
+        if (keys) HIP_TRY(hipMemcpy(hk.data(), b->dbg_part_key, hk.size() * 4, hipMemcpyDeviceToHost));
+        if (rows) HIP_TRY(hipMemcpy(hi.data(), b->dbg_part_idx, hi.size() * 4, hipMemcpyDeviceToHost));
+        for (int64_t j = 0; j < nq; ++j) {
+            const int qt = (int)(j / T), ns = rs.qt_nseg[qt];
+            const size_t l0 = (size_t)rs.qt_segoff[qt] * T + (size_t)(j - (int64_t)qt * T) * ns;
+            for (int l = 0; l < ns_out; ++l)
+                for (int e = 0; e < KP; ++e) {
+                    const size_t o = ((size_t)j * ns_out + l) * KP + e;
+                    if (keys) keys[o] = l < ns ? hk[(l0 + l) * KP + e] : -INFINITY;
+                    if (rows) rows[o] = l < ns ? hi[(l0 + l) * KP + e] : -1;
+                }
+        }
+        return CSLAM_OK;
+    }
     const size_t cnt = (size_t)nq * b->dbg_nseg * KP;
     if (keys) HIP_TRY(hipMemcpy(keys, b->dbg_part_key, cnt * 4, hipMemcpyDeviceToHost));
     if (rows) HIP_TRY(hipMemcpy(rows, b->dbg_part_idx, cnt * 4, hipMemcpyDeviceToHost));

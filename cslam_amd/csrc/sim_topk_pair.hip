@@ -36,131 +36,7 @@
 #include "bank.h"
 #include "sim_topk.h"
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-
-#define PK_ROWB 128     // bytes of one 32-channel block of one row
-
-// LDS-DMA in the MUBUF encoding (`buffer_load_dwordx4 ... lds`), round 4.  `global_load_lds` is FLAT-encoded with an LDS operand:
-// hipcc's waitcnt pass marks it "pending flat" and from then on turns every `lgkmcnt(N)` into `lgkmcnt(0)` -- a K step's MFMAs then
-// wait for ALL fragment reads issued before them.  The buffer form carries no such mark (LDS reads are counted again), takes the
-// stage's K offset in an SGPR and the lane's row offset in ONE register (a 64-bit address per request before), and clamps in
-// hardware: rows beyond `num_records` read as zero.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t pk_rsrc(const char *base, int64_t bytes) {
-    const uint64_t a = (uint64_t)base;
-    const uint64_t u = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a);
-    const int n = __builtin_amdgcn_readfirstlane((int)(bytes > 0x7fffffff ? 0x7fffffff : bytes));
-    return __builtin_amdgcn_make_buffer_rsrc((void *)u, 0, n, 0x00020000);
-}
-__device__ __forceinline__ void pk_blds16(__amdgpu_buffer_rsrc_t rs, int voff, int soff, char *lds_wave_base) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voff, soff, 0, 0);
-}
-
-
-// ---- tile epilogue: lane-local candidate update from the finished 32 MT x 64 wave tile, then clear the accumulators
-// (a lane's 16 accumulator registers of a tile belong to ONE query column: no cross-lane traffic)
-template <int MT, int KPL, int NTW>
-__device__ __forceinline__ void pair_tile_epilogue(f32x16 (&acc)[MT][NTW], float (&lk)[NTW][KPL], int (&li)[NTW][KPL], const int (&lim)[NTW],
-                                                   const float (&qmul)[NTW], const float *__restrict__ invs, int n_rows, int row_base) {
-#pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        float inv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            int row = row_base + m * 32 + (r & 3) + 8 * (r >> 2);
-            inv[r] = invs[row < n_rows ? row : n_rows - 1];
-        }
-#pragma unroll
-        for (int n = 0; n < NTW; ++n) {
-            f32x16 keys;
-            bool any = false;
-            const float thr = lk[n][KPL - 1];
-            const int rel_lim = lim[n] - (row_base + m * 32);   // row < lim  <=>  rowoff < rel_lim
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float kx = (acc[m][n][r] * inv[r]) * qmul[n];
-                keys[r] = kx;
-                bool ok = ((r & 3) + 8 * (r >> 2)) < rel_lim;
-                any |= ok && !(kx <= thr);     // NaN passes (ranks first)
-                acc[m][n][r] = 0.0f;
-            }
-            if (__any(any)) {
-#pragma unroll 1
-                for (int r = 0; r < 16; ++r) {
-                    float ck = keys[r];        // uniform dynamic index
-                    int roff = (r & 3) + 8 * (r >> 2);
-                    ck = (ck != ck) ? INFINITY : ck;
-                    bool ins = (roff < rel_lim) && (ck > lk[n][KPL - 1]);
-                    if (__any(ins)) {
-                        ck = ins ? ck : -INFINITY;
-                        int ci = row_base + m * 32 + roff;
-#pragma unroll
-                        for (int j = 0; j < KPL; ++j) {
-                            bool sw = ck > lk[n][j];
-                            float tk = sw ? lk[n][j] : ck;
-                            int ti = sw ? li[n][j] : ci;
-                            lk[n][j] = sw ? ck : lk[n][j];
-                            li[n][j] = sw ? ci : li[n][j];
-                            ck = tk; ci = ti;
-                        }
-                    }
-                }
-            }
-        }
-    }
-}
-
-// ---- block merge: 4 lists per query (2 row-halves of the wave x 2 waves along the bank axis) -> the best KP of them, plus the
-// bound on everything dropped (see sim_topk_mfma_kernel); the LDS of the K loop is reused
-template <int T_, int KPL, int NTW>
-__device__ __forceinline__ void pair_block_merge(char *smem, float (&lk)[NTW][KPL], int (&li)[NTW][KPL], int wn, int wm, int h, int l31,
-                                                 int tid, int qt, int seg, const PairArgs &p) {
-    __syncthreads();
-    float *mk = (float *)smem;                       // [T_][4][KPL]
-    int *mi = (int *)(smem + T_ * 4 * KPL * 4);      // [T_][4][KPL]
-#pragma unroll
-    for (int n = 0; n < NTW; ++n) {
-        int qcol = wn * (32 * NTW) + n * 32 + l31;
-        int src = wm * 2 + h;
-#pragma unroll
-        for (int j = 0; j < KPL; ++j) {
-            mk[(qcol * 4 + src) * KPL + j] = lk[n][j];
-            mi[(qcol * 4 + src) * KPL + j] = li[n][j];
-        }
-    }
-    __syncthreads();
-    if (tid < T_) {
-        const float *k0 = mk + (tid * 4) * KPL;
-        const int *i0 = mi + (tid * 4) * KPL;
-        int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
-        size_t o = ((size_t)(qt * T_ + tid) * p.nseg + seg) * SIM_KP;
-        float bound = -INFINITY;
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-            if (i0[s * KPL + KPL - 1] >= 0) bound = fmaxf(bound, k0[s * KPL + KPL - 1]);   // full lane list
-        for (int j = 0; j < SIM_KP; ++j) {
-            float c0 = p0 < KPL ? k0[p0] : -INFINITY;
-            float c1 = p1 < KPL ? k0[KPL + p1] : -INFINITY;
-            float c2 = p2 < KPL ? k0[2 * KPL + p2] : -INFINITY;
-            float c3 = p3 < KPL ? k0[3 * KPL + p3] : -INFINITY;
-            int best = 0; float bk = c0;
-            if (c1 > bk) { bk = c1; best = 1; }
-            if (c2 > bk) { bk = c2; best = 2; }
-            if (c3 > bk) { bk = c3; best = 3; }
-            int bi;
-            if (best == 0) { bi = p0 < KPL ? i0[p0] : -1; ++p0; }
-            else if (best == 1) { bi = i0[KPL + p1]; ++p1; }
-            else if (best == 2) { bi = i0[2 * KPL + p2]; ++p2; }
-            else { bi = i0[3 * KPL + p3]; ++p3; }
-            p.part_key[o + j] = bk;
-            p.part_idx[o + j] = (bk == -INFINITY) ? -1 : bi;
-        }
-        float c0 = p0 < KPL ? k0[p0] : -INFINITY, c1 = p1 < KPL ? k0[KPL + p1] : -INFINITY;
-        float c2 = p2 < KPL ? k0[2 * KPL + p2] : -INFINITY, c3 = p3 < KPL ? k0[3 * KPL + p3] : -INFINITY;
-        bound = fmaxf(fmaxf(bound, fmaxf(c0, c1)), fmaxf(c2, c3));
-        p.part_bound[(size_t)(qt * T_ + tid) * p.nseg + seg] = bound;
-    }
-}
+#include "sim_topk_pair_dev.h"
 
 // T_ = tile edge (bank rows = queries per tile), MT = 32-row MFMA tiles per wave along the bank axis (wave tile =
 // 32 MT x 64), KPL = per-lane candidate list length.  Waves: 2 along the bank axis x (T_/64) along the query axis.
@@ -452,7 +328,11 @@ __global__ __launch_bounds__(T_ * 64 / (16 * NTW), NTW == 4 ? 1 : 2) void sim_to
         }
     }
 
-    pair_block_merge<T_, KPL, NTW>(smem, lk, li, wn, wm, h, l31, tid, qt, seg, p);
+    {
+        const size_t l0 = (size_t)qt * T_ * p.nseg + seg;            // list of the tile's first query in this segment
+        pair_block_merge<T_, KPL, NTW>(smem, lk, li, wn, wm, h, l31, tid, p.part_key + l0 * SIM_KP, p.part_idx + l0 * SIM_KP,
+                                       p.part_bound + l0, (size_t)p.nseg);
+    }
 }
 
 // Measured and rejected (round 3, profiles/r03_v13_pair_pingpong_rejected.log; code removed): a "ping-pong" form of the 256 x 256

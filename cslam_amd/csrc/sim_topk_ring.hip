@@ -1,0 +1,478 @@
+// sim_topk_ring.hip -- the one-product candidate stage (sim_topk_pair.hip, NPROD = 1) as a PERSISTENT kernel on a static,
+// XCD-aligned schedule (round 5).
+//
+// Replaces, for a batch of queries, the scoring loop of cslam/nns_matching.py:55-61 exactly as sim_topk_pair_kernel does: the same
+// 256 x 256 tile, the same operands (fp16 hi halves of the scaled rows, 128-byte K stages, XOR-swizzled LDS image filled by LDS-DMA),
+// the same lane-local candidate lists, tile epilogue, block merge and error bound (pair_err_bound(kd, 1)).  What changes is WHO
+// computes WHICH tile WHEN.
+//
+// Why.  sim_topk_pair_kernel runs one workgroup per (query tile, bank segment) work item and lets the dispatcher hand the items out as
+// CUs free up.  On the 100k x 100k launch of BASELINE config 3 that moved 331 GB through the fabric (L2 misses; 1.64 GB algorithmic)
+// at an L2 hit rate of 0.51 (profiles/r04_v78m_pmc_match_summary.json): a 256 x 256 x 4096 tile reads 4 MB, a whole XCD's L2 is 4 MB,
+// so two workgroups share a fetch only while they are within a few K stages of each other -- and work items that start whenever a CU
+// happens to free up are not.  At 4 TB/s of fabric traffic the kernel ran at 1.78 GHz with the matrix pipe 0.55 busy.
+//
+// Schedule (ring_schedule_build, host).  The launch is `num_cu` workgroups, one per CU (160 KB of LDS each), alive for the whole
+// launch.  Workgroup b sits on XCD b % 8 (observed dispatch order; only speed depends on it) as slot b / 8; the 32 slots of an XCD
+// form a patch of Sq = 4 query tiles x Sb = 8 bank tiles.  A patch keeps its 4 query tiles and walks the bank 8 tiles per step:
+// per step the XCD's L2 takes 12 operand streams for 32 tiles of work (3/16 of the unshared traffic), every workgroup of the patch
+// at the same K position because they all started the step together (tile-start rendezvous below).  The 8 XCDs work on 8
+// DIFFERENT query groups against the SAME bank tiles at the same time, so the bank comes out of HBM once per 32 query tiles (the
+// other seven XCDs hit the Infinity Cache) and a group's 8 MB of queries stay in the Infinity Cache for the whole walk.
+// Query groups that do not fill a round of 8 XCDs (the tail) have their walk cut into runs, one run per XCD, so that every XCD
+// gets the same number of steps (+- 1).  A (query tile, run, patch column) = one merged candidate list = one "segment" for
+// stage 2 (rescore_kernel reads a per-query-tile segment count).
+//
+// Tile-start rendezvous (SYNC).  A workgroup announces "I am one K stage from my next tile" on a per-step counter and, at the top of
+// the tile, waits (one wave polls, bounded, ~5 us) until the patch has announced: the patch re-aligns every tile, whatever the
+// epilogues and cache misses did to it.  The counters are a hint: a timed-out wait just goes on (and stops waiting for the rest of
+// the task), results never depend on it.
+#include <stdlib.h>
+#include <type_traits>
+#include "sim_topk_pair_dev.h"
+
+// KPL = per-lane candidate list length.  DBG (measurement build, timing only): 1 = no global loads after the first stage, 2 = every
+// request reads bank tile 0 / query tile 0, 3 = 1 without the stage barrier, 4 = 1 without fragment reads after the first stage,
+// 5 = 3 and 4 (the bare MFMA stream of the loop).  SYNC = tile-start rendezvous.  PRIO = progress-ordered wave priority: a stage's four groups of 8 MFMAs run at
+// s_setprio 3, 2, 1, 0.  The arbiter takes priority first, age second: at equal priority the older wave of a SIMD issues its WHOLE
+// stage first and parks at the barrier ~1000 cycles before its partner, which then runs alone with nobody to fill its issue gaps
+// (2420 cycles per 2048-cycle stage, profiles/r05_v8_barrier_trace.log); with the wave that is BEHIND always at the higher
+// priority the pair alternates group by group and the solo tail is one group.
+template <int KPL, int DBG, int SYNC, int PRIO>
+__global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
+    constexpr int T_ = 256, MT = 4, NTW = 2, NWN = 4, NTHR = 512;
+    constexpr int OPB = T_ * PK_ROWB;            // bytes of one operand tile (64 channels of 256 rows) in LDS
+    constexpr int STAGE = 2 * OPB;
+    constexpr int NLD = T_ * 8 / NTHR;           // 16-byte chunks per thread per operand (= 4)
+    constexpr int NS = 4;                        // 16-channel K steps per stage
+    constexpr int G = MT * NTW;                  // MFMAs of a K step
+    constexpr int NRD = MT + NTW;                // fragment reads of a K step
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / NWN, wn = wave % NWN;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int bid = blockIdx.x;
+    const int wg = (bid % p.n_xcd) * p.wpx + bid / p.n_xcd;
+    char *const sync_off = smem + 2 * STAGE;         // one byte behind the two stages: "this task has stopped waiting"
+    // 1 / (||row|| s_row) of the current bank tile's 256 rows; two buffers by tile parity: a wave that leaves a tile's epilogue early
+    // requests the next tile's values while slower waves still read this tile's (a buffer is rewritten 64 stage barriers later)
+    float *const s_inv = (float *)(smem + 2 * STAGE + 16);
+    if (SYNC) { if (tid == 0) *sync_off = 0; __syncthreads(); }
+
+    // ---- loader: chunk pch = i*NTHR + tid -> tile row pch >> 3, physical 16-byte slot pch & 7 holding logical chunk
+    // slot ^ ((row >> 1) & 7) of the row's 128-byte block
+    int voffA[NLD], voffB[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int pch = i * NTHR + tid;
+        const int r = pch >> 3, slot = pch & 7;
+        const int c = slot ^ ((r >> 1) & 7);
+        voffA[i] = r * (int)p.ldb2 + (c << 4);
+        voffB[i] = r * (int)p.ldq2 + (c << 4);
+    }
+    const int wave_chunk = wave * 1024;
+    const int swz = (lane >> 1) & 7;
+    int foff[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) foff[s] = ((2 * s + h) ^ swz) << 4;
+    const int arow0 = (wm * 32 * MT + l31) * PK_ROWB;
+    const int brow0 = (wn * (32 * NTW) + l31) * PK_ROWB;
+
+    if (p.xcc_out && tid == 0) {
+        int xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        p.xcc_out[bid] = xcc;
+    }
+    if (DBG == 1 && p.trace_out && bid == 0 && lane == 0) {
+        int hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        p.trace_out[(size_t)(p.n_xcd * p.wpx) * 64 + 8 * 48 * 2 + wave] = hw;
+    }
+    const int task_end = p.task_off[wg + 1];
+    for (int ti = p.task_off[wg]; ti < task_end; ++ti) {
+        const RingTask tk = p.tasks[ti];
+        if (DBG >= 0 && p.stagger_cycles > 0 && ti == p.task_off[wg]) {        // measurement build: staggered start
+            const uint64_t t0 = __builtin_amdgcn_s_memtime();
+            const uint64_t d = (uint64_t)tk.pad * (uint64_t)p.stagger_cycles;
+            while (__builtin_amdgcn_s_memtime() - t0 < d) __builtin_amdgcn_s_sleep(8);
+        }
+        const int qt = tk.qt;
+        int ntiles = tk.t_cnt;
+        {
+            const int te = (p.qt_maxlim[qt] + T_ - 1) / T_;                 // tiles at or beyond it hold no visible row
+            const int vis = te > tk.t_beg ? (te - tk.t_beg + p.t_stride - 1) / p.t_stride : 0;
+            if (ntiles > vis) ntiles = vis;
+        }
+        float lk[NTW][KPL]; int li[NTW][KPL];
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+#pragma unroll
+            for (int j = 0; j < KPL; ++j) { lk[n][j] = -INFINITY; li[n][j] = -1; }
+        int lim[NTW];
+        float qmul[NTW];
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
+            lim[n] = p.lim[qt * T_ + wn * (32 * NTW) + n * 32 + l31];
+            qmul[n] = p.qinvs[qt * T_ + wn * (32 * NTW) + n * 32 + l31];
+        }
+        // rendezvous bookkeeping (wave-uniform)
+        int n_arrived = 0;
+        bool sync_on = SYNC && p.sync != nullptr;
+        auto arrive = [&](int i) {
+            if (SYNC && p.sync != nullptr && i < tk.sync_n && tid == 0)
+                __hip_atomic_fetch_add(p.sync + tk.sync_base + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        };
+
+        if (ntiles > 0) {
+            const __amdgpu_buffer_rsrc_t rsB = pk_rsrc(p.q2 + (int64_t)(DBG == 2 ? 0 : qt) * T_ * p.ldq2, (int64_t)T_ * p.ldq2);
+            __amdgpu_buffer_rsrc_t rsA;
+            auto point_at_tile = [&](int tile) {
+                const int t0 = DBG == 2 ? 0 : tile;
+                int64_t rows = (int64_t)p.n_rows - (int64_t)t0 * T_;
+                if (rows > T_) rows = T_;
+                rsA = pk_rsrc(p.bank2 + (int64_t)t0 * T_ * p.ldb2, rows * p.ldb2);
+            };
+            auto stage_load_part = [&](int stage, int kt, int i) {
+                char *sA = smem + stage * STAGE;
+                char *sB = sA + OPB;
+                pk_blds16(rsA, voffA[i], kt * PK_ROWB, sA + i * (NTHR * 16) + wave_chunk);
+                pk_blds16(rsB, voffB[i], kt * PK_ROWB, sB + i * (NTHR * 16) + wave_chunk);
+            };
+
+            f32x16 acc[MT][NTW];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NTW; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+            // two fragment register sets: K step s + 1 is read while K step s is multiplied, a stage's last K step is multiplied
+            // behind the stage barrier (see sim_topk_pair_kernel for the derivation of this order)
+            f16x8 fa[2][MT], fb[2][NTW];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) fa[u][m] = (f16x8)(_Float16)0.0f;
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) fb[u][n] = (f16x8)(_Float16)0.0f;
+            }
+            constexpr bool NOLOAD = DBG == 1 || (DBG >= 3 && DBG <= 5);
+            constexpr bool NOBAR = DBG == 3 || DBG == 5;
+            constexpr bool NOREAD = DBG == 4 || DBG == 5;
+            int it = 0;
+            auto read_frags = [&](int u, const char *sA, const char *sB, int s) {
+                if (NOREAD && it > 0) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(fa[u][m]));
+#pragma unroll
+                    for (int n = 0; n < NTW; ++n) asm volatile("" : "+v"(fb[u][n]));
+                    return;
+                }
+#pragma unroll
+                for (int m = 0; m < MT; ++m) fa[u][m] = *(const f16x8 *)(sA + arow0 + m * 32 * PK_ROWB + foff[s]);
+#pragma unroll
+                for (int n = 0; n < NTW; ++n) fb[u][n] = *(const f16x8 *)(sB + brow0 + n * 32 * PK_ROWB + foff[s]);
+            };
+            auto multiply = [&](int u) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NTW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u][m], fb[u][n], acc[m][n], 0, 0, 0);
+            };
+
+            const int total = ntiles * p.nkt;
+            point_at_tile(tk.t_beg);
+#pragma unroll
+            for (int i = 0; i < NLD; ++i) stage_load_part(0, 0, i);
+            arrive(0); n_arrived = 1;
+            __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_s_barrier();
+
+            int tpar = 0;                                            // parity of the tile's ordinal in the task
+            auto stage_body = [&](auto first_tag, int tile, int kt) {
+                constexpr bool FIRST = decltype(first_tag)::value;
+                int nkt_ = kt + 1, ntile = tile;
+                if (nkt_ == p.nkt) { nkt_ = 0; ntile = tile + p.t_stride; }
+                // branch-free prefetch: the very last stage re-fetches its own block into the idle buffer, which nobody reads
+                const bool more = it + 1 < total;
+                const int lkt = more ? nkt_ : kt;
+                if (more && nkt_ == 0) point_at_tile(ntile);             // wave-uniform, before anything is in flight
+                const char *sA = smem + (it & 1) * STAGE;
+                const char *sB = sA + OPB;
+                constexpr int HALF = FIRST ? 0 : NLD / 2;                // loader parts (2 requests each) issued behind the barrier
+                constexpr int LEAD = 2;
+                // ---- behind the barrier: first reads of this stage, requests of the next, the last K step of the previous
+                if (PRIO) { __builtin_amdgcn_s_setprio(3); __builtin_amdgcn_sched_barrier(0); }
+                if constexpr (FIRST) {
+                    // the tile's 256 values of invs, 4 bytes per lane of waves 0..3, by LDS-DMA: they land with this stage's requests
+                    // (nobody reads them before the tile's epilogue, 63 stage barriers from here; the previous tile's were read in
+                    // front of this stage); rows beyond the bank read as zero and are masked by the row limits
+                    if (wave < 4) {
+                        const __amdgpu_buffer_rsrc_t rsI = pk_rsrc((const char *)p.invs, (int64_t)p.n_rows * 4);
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsI, (__attribute__((address_space(3))) void *)((char *)s_inv + (tpar * 4 + wave) * 256), 4,
+                                                                 (tile * T_ + tid) * 4, 0, 0, 0);
+                    }
+                }
+                read_frags(0, sA, sB, 0);
+                if constexpr (!FIRST) {
+                    if (!NOLOAD) {
+#pragma unroll
+                        for (int i = 0; i < HALF; ++i) stage_load_part((it + 1) & 1, lkt, i);
+                    }
+                    multiply((NS - 1) & 1);
+                    __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);              // DS read (nothing older is needed here)
+                    constexpr int PER = G / (2 * HALF) > 0 ? G / (2 * HALF) : 1;
+#pragma unroll
+                    for (int i = 0; i < 2 * HALF; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);          // MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);            // VMEM read (LDS-DMA)
+                    }
+                    if (G - PER * 2 * HALF > 0) __builtin_amdgcn_sched_group_barrier(0x008, G - PER * 2 * HALF > 0 ? G - PER * 2 * HALF : 1, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- K steps 0 .. NS - 2 of this stage, each over the reads of the next
+#pragma unroll
+                for (int s = 0; s + 1 < NS; ++s) {
+                    if (PRIO) {
+                        if (s == 0) __builtin_amdgcn_s_setprio(2); else if (s == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    read_frags((s + 1) & 1, sA, sB, s + 1);
+                    if (s == 0 && !NOLOAD) {
+#pragma unroll
+                        for (int i = HALF; i < NLD; ++i) stage_load_part((it + 1) & 1, lkt, i);
+                    }
+                    multiply(s & 1);
+                    __builtin_amdgcn_sched_group_barrier(0x008, LEAD, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+                    constexpr int REST = 2 * (NLD - HALF);               // requests placed in K step 0
+                    constexpr int GR = G - LEAD;
+                    if (s == 0) {
+                        constexpr int PER = GR / REST > 0 ? GR / REST : 1;
+#pragma unroll
+                        for (int i = 0; i < REST; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+                        }
+                        if (GR - PER * REST > 0) __builtin_amdgcn_sched_group_barrier(0x008, GR - PER * REST > 0 ? GR - PER * REST : 1, 0);
+                    } else {
+                        __builtin_amdgcn_sched_group_barrier(0x008, GR, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (!NOBAR) {
+                    // DBG 1 with a trace buffer: per-wave shader-clock stamps around the barrier of the first 48 stages (workgroup 0)
+                    const bool stamp = DBG == 1 && p.trace_out && bid == 0 && it < 48;
+                    uint64_t ta = 0;
+                    if (stamp) ta = __builtin_amdgcn_s_memtime();
+                    __builtin_amdgcn_s_waitcnt(0);
+                    __builtin_amdgcn_s_barrier();
+                    if (stamp) {
+                        const uint64_t tb = __builtin_amdgcn_s_memtime();
+                        if (lane == 0) {
+                            long long *o = p.trace_out + (size_t)(p.n_xcd * p.wpx) * 64 + ((size_t)wave * 48 + it) * 2;
+                            o[0] = (long long)ta; o[1] = (long long)tb;
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                ++it;
+            };
+            int tile = tk.t_beg;
+            for (int i = 0; i < ntiles; ++i, tile += p.t_stride) {
+                if (SYNC) {
+                    // top of tile i: wait until the patch has announced step i (its stage 0 is already in LDS, the wait costs
+                    // nothing that the announcement of the slowest workgroup would not cost anyway)
+                    if (sync_on && i < tk.sync_n) {
+                        if (wave == 0) {
+                            const int *cnt = p.sync + tk.sync_base + i;
+                            // bounded in shader cycles: ~6 us inside a walk, ~40 us at its start (the patch comes out of its merges)
+                            const uint64_t t0 = __builtin_amdgcn_s_memtime();
+                            const uint64_t bound = i == 0 ? 80000u : 12000u;
+                            bool ok;
+                            while (!(ok = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= tk.sync_expect) &&
+                                   __builtin_amdgcn_s_memtime() - t0 < bound)
+                                __builtin_amdgcn_s_sleep(2);
+                            // two timed-out waits in a row: somebody of the patch is not running -- stop waiting for this task
+                            const char miss = ok ? 0 : (char)(*sync_off + 1);
+                            *sync_off = miss;
+                            if (p.trace_out && !ok && lane == 0) p.trace_out[(size_t)bid * 64 + 62] += 1;
+                        }
+                        __builtin_amdgcn_s_waitcnt(0);
+                        __builtin_amdgcn_s_barrier();
+                        if (*sync_off >= 2) sync_on = false;
+                    }
+                }
+                if (p.trace_out && tid == 0 && ti == p.task_off[wg] && i < 62) p.trace_out[(size_t)bid * 64 + i] = (long long)wall_clock64();
+                stage_body(std::true_type{}, tile, 0);
+                for (int kt = 1; kt < p.nkt; ++kt) {
+                    if (SYNC && kt == p.nkt - 1) { arrive(i + 1); n_arrived = i + 2; }
+                    stage_body(std::false_type{}, tile, kt);
+                }
+                if (SYNC && p.nkt == 1) { arrive(i + 1); n_arrived = i + 2; }
+                multiply((NS - 1) & 1);                                  // the tile's last K step, then its candidates
+                if (DBG == 6) {                                          // timing only: no candidate update
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NTW; ++n) {
+                            lk[n][0] = fmaxf(lk[n][0], acc[m][n][0] + acc[m][n][7]);
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+                        }
+                } else if (DBG == 7) {                                   // measurement build: round 4's epilogue
+                    pair_tile_epilogue<MT, KPL, NTW>(acc, lk, li, lim, qmul, p.invs, p.n_rows, tile * T_ + wm * 32 * MT + 4 * h);
+                } else {
+                    ring_tile_epilogue<MT, KPL, NTW>(acc, lk, li, lim, qmul, s_inv + tpar * 256 + wm * 32 * MT + 4 * h, tile * T_ + wm * 32 * MT + 4 * h);
+                }
+                tpar ^= 1;
+            }
+        }
+        // steps this workgroup does not take (row limits cut its walk short): announce them all, nobody waits for it
+        if (SYNC)
+            for (int i = n_arrived; i < tk.sync_n; ++i) arrive(i);
+
+        {
+            const int ns = p.qt_nseg[qt];
+            const size_t l0 = (size_t)p.qt_segoff[qt] * T_ + tk.seg;         // list `seg` of the tile's first query
+            pair_block_merge<T_, KPL, NTW>(smem, lk, li, wn, wm, h, l31, tid, p.part_key + l0 * SIM_KP, p.part_idx + l0 * SIM_KP,
+                                           p.part_bound + l0, (size_t)ns);
+        }
+        if (SYNC && tid == 0) *sync_off = 0;
+        __syncthreads();                                                 // the merge's LDS is the next task's first stage
+    }
+    if (p.trace_out && tid == 0) p.trace_out[(size_t)bid * 64 + 63] = (long long)wall_clock64();
+}
+
+// ---- the schedule ------------------------------------------------------------------------------------------------------------
+void ring_schedule_build(RingSchedule &s, int nqt, int n_btiles, int n_xcd, int wpx, int stag_q, int stag_b) {
+    s.nqt = nqt; s.n_btiles = n_btiles; s.n_xcd = n_xcd; s.wpx = wpx; s.stag_q = stag_q; s.stag_b = stag_b;
+    int sq = nqt < 4 ? nqt : 4;
+    if (sq > wpx) sq = wpx;
+    if (sq < 1) sq = 1;
+    int sb = wpx / sq;
+    if (sb > n_btiles) sb = n_btiles > 0 ? n_btiles : 1;
+    s.sq = sq; s.sb = sb;
+    const int ngroups = (nqt + sq - 1) / sq;
+    const int nsteps = (n_btiles + sb - 1) / sb;
+    struct Run { int g, j0, j1, r; };
+    std::vector<std::vector<Run>> runs(n_xcd);
+    std::vector<int> group_runs(ngroups, 0);
+    const int full = ngroups / n_xcd;
+    for (int i = 0; i < full; ++i)
+        for (int x = 0; x < n_xcd; ++x) {
+            const int g = i * n_xcd + x;
+            runs[x].push_back(Run{g, 0, nsteps, group_runs[g]++});
+        }
+    const int gtail = ngroups - full * n_xcd;
+    if (gtail > 0) {
+        const long L = (long)gtail * nsteps;
+        for (int x = 0; x < n_xcd; ++x) {
+            long lo = L * x / n_xcd, hi = L * (x + 1) / n_xcd;
+            while (lo < hi) {
+                const int g = full * n_xcd + (int)(lo / nsteps);
+                const int j0 = (int)(lo % nsteps);
+                long end = (lo / nsteps + 1) * nsteps;
+                if (end > hi) end = hi;
+                const int j1 = j0 + (int)(end - lo);
+                runs[x].push_back(Run{g, j0, j1, group_runs[g]++});
+                lo = end;
+            }
+        }
+    }
+    s.qt_nseg.assign(nqt, 0);
+    s.qt_segoff.assign(nqt, 0);
+    int lists = 0;
+    for (int qt = 0; qt < nqt; ++qt) {
+        s.qt_nseg[qt] = group_runs[qt / sq] * sb;
+        s.qt_segoff[qt] = lists;
+        lists += s.qt_nseg[qt];
+    }
+    s.total_lists = lists;
+    s.tasks.clear();
+    s.task_off.assign((size_t)n_xcd * wpx + 1, 0);
+    int n_sync = 0;
+    std::vector<std::vector<int>> sync_base(n_xcd);
+    for (int x = 0; x < n_xcd; ++x)
+        for (const Run &r : runs[x]) { sync_base[x].push_back(n_sync); n_sync += r.j1 - r.j0; }
+    s.n_sync = n_sync;
+    for (int x = 0; x < n_xcd; ++x)
+        for (int sl = 0; sl < wpx; ++sl) {
+            const int w = x * wpx + sl;
+            s.task_off[w] = (int)s.tasks.size();
+            if (sl >= sq * sb) continue;
+            const int qi = sl / sb, bi = sl % sb;
+            for (size_t k = 0; k < runs[x].size(); ++k) {
+                const Run &r = runs[x][k];
+                const int qt = r.g * sq + qi;
+                if (qt >= nqt) continue;
+                RingTask t;
+                t.qt = qt;
+                t.t_beg = r.j0 * sb + bi;
+                int cnt = 0;
+                for (int j = r.j0; j < r.j1; ++j) cnt += (j * sb + bi) < n_btiles;
+                t.t_cnt = cnt;
+                t.seg = r.r * sb + bi;
+                // participants of the run: the query tiles that exist; a step is a rendezvous while every column has a tile in it
+                int nq_here = nqt - r.g * sq; if (nq_here > sq) nq_here = sq;
+                int full_steps = r.j1 - r.j0;
+                if (r.j1 == nsteps && n_btiles % sb != 0) --full_steps;
+                t.sync_base = sync_base[x][k];
+                t.sync_n = full_steps > 0 ? full_steps : 0;
+                t.sync_expect = nq_here * sb;
+                t.pad = stag_q * qi + stag_b * bi;
+                s.tasks.push_back(t);
+            }
+        }
+    s.task_off[(size_t)n_xcd * wpx] = (int)s.tasks.size();
+}
+
+// variant: bit 0 = tile-start rendezvous, bit 1 = progress-ordered wave priority
+int ring_stage1_launch(const RingArgs &a, int variant, int dbg, hipStream_t st) {
+    constexpr int lds = 2 * 2 * 256 * PK_ROWB + 16 + 2 * 1024;
+    static DeviceOnce once;
+    int once_dev;
+#define RING_EACH(X) X(0, 0, 0) X(0, 1, 0) X(0, 0, 1) X(0, 1, 1)
+#ifdef CSLAM_ABLATIONS
+#define RING_EACH_DBG(X) X(1, 0, 0) X(1, 1, 0) X(1, 0, 1) X(1, 1, 1) X(2, 0, 0) X(2, 1, 0) X(2, 0, 1) X(2, 1, 1) X(3, 0, 0) X(4, 0, 0) X(5, 0, 0) X(6, 0, 0) X(7, 0, 0)
+#else
+#define RING_EACH_DBG(X)
+#endif
+    if (once.todo(&once_dev)) {
+#define RING_ATTR(D, S, P) HIP_TRY(hipFuncSetAttribute((const void *)sim_topk_ring_kernel<8, D, S, P>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        RING_EACH(RING_ATTR)
+        RING_EACH_DBG(RING_ATTR)
+#undef RING_ATTR
+        once.done(once_dev);
+    }
+    const dim3 grid(a.n_xcd * a.wpx), blk(512);
+    const int sy = variant & 1, pr = (variant >> 1) & 1;
+    bool done = false;
+#define RING_GO(D, S, P) if (!done && dbg == D && sy == S && pr == P) { hipLaunchKernelGGL((sim_topk_ring_kernel<8, D, S, P>), grid, blk, lds, st, a); done = true; }
+    RING_EACH(RING_GO)
+    RING_EACH_DBG(RING_GO)
+#undef RING_GO
+    if (!done) { cslam_set_error("ring stage: no such variant (dbg %d needs the measurement build)", dbg); return CSLAM_E_INVALID; }
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
+/* diagnostics (include/cslam_hip_experimental.h): the static schedule the persistent candidate stage would use -- pure host code,
+ * tests/test_abi_cpu.py checks on CPU that every (query tile, bank tile) pair is computed exactly once and the XCDs are balanced. */
+CSLAM_API int cslam_ring_schedule_describe(int nqt, int n_btiles, int n_xcd, int wpx, int32_t info[6], int32_t *tasks, int64_t tasks_cap,
+                                           int32_t *task_off, int32_t *qt_nseg, int32_t *qt_segoff) {
+    ARG_CHECK(nqt >= 1 && n_btiles >= 1 && n_xcd >= 1 && wpx >= 1 && info, "nqt, n_btiles, n_xcd, wpx >= 1 and info are required");
+    RingSchedule s;
+    ring_schedule_build(s, nqt, n_btiles, n_xcd, wpx);
+    info[0] = s.sq; info[1] = s.sb; info[2] = (int32_t)s.tasks.size(); info[3] = s.total_lists; info[4] = s.n_sync; info[5] = (int32_t)sizeof(RingTask) / 4;
+    if (tasks) {
+        ARG_CHECK(tasks_cap >= (int64_t)s.tasks.size() * 8, "tasks_cap too small: 8 int32 per task");
+        memcpy(tasks, s.tasks.data(), s.tasks.size() * sizeof(RingTask));
+    }
+    if (task_off) memcpy(task_off, s.task_off.data(), s.task_off.size() * 4);
+    if (qt_nseg) memcpy(qt_nseg, s.qt_nseg.data(), (size_t)nqt * 4);
+    if (qt_segoff) memcpy(qt_segoff, s.qt_segoff.data(), (size_t)nqt * 4);
+    return CSLAM_OK;
+}

@@ -82,3 +82,53 @@ def test_backbone_state_dict_names_match_torchvision_layout():
     import torch
     assert r18(torch.zeros(1, 3, 224, 224)).shape == (1, 512, 7, 7)
     assert vgg(torch.zeros(1, 3, 224, 224)).shape == (1, 512, 14, 14)
+
+
+def _ring_schedule(lib, nqt, nbt, n_xcd=8, wpx=32):
+    import ctypes as C
+    info = (C.c_int32 * 6)()
+    _lib.check(lib.cslam_ring_schedule_describe(nqt, nbt, n_xcd, wpx, C.byref(info), None, 0, None, None, None))
+    sq, sb, ntask, lists, nsync, words = list(info)
+    assert words == 8
+    tasks = np.zeros((max(ntask, 1), 8), dtype=np.int32)
+    off = np.zeros(n_xcd * wpx + 1, dtype=np.int32)
+    qn = np.zeros(nqt, dtype=np.int32)
+    qo = np.zeros(nqt, dtype=np.int32)
+    _lib.check(lib.cslam_ring_schedule_describe(nqt, nbt, n_xcd, wpx, C.byref(info), tasks.ctypes.data_as(C.c_void_p), tasks.size,
+                                                off.ctypes.data_as(C.c_void_p), qn.ctypes.data_as(C.c_void_p),
+                                                qo.ctypes.data_as(C.c_void_p)))
+    return sq, sb, tasks[:ntask], off, qn, qo, lists, nsync
+
+
+@pytest.mark.parametrize("nqt,nbt", [(391, 391), (4, 391), (1, 391), (2, 5), (3, 40), (7, 196), (64, 391), (391, 3), (33, 17),
+                                     (5, 1), (128, 196)])
+def test_ring_schedule_covers_every_tile_pair_once_and_balances_the_xcds(nqt, nbt):
+    """The static schedule of the persistent candidate stage (csrc/sim_topk_ring.hip): every (query tile, bank tile) pair belongs to
+    exactly one task, a query tile's lists are numbered 0 .. qt_nseg - 1 without gaps, the per-tile list offsets are the running
+    sum, the rendezvous counters of different (XCD, run) pairs do not overlap, and no XCD walks more than one step (plus the
+    rounding of the tail split) beyond the mean."""
+    lib = _lib.load()
+    n_xcd, wpx = 8, 32
+    sq, sb, tasks, off, qn, qo, lists, nsync = _ring_schedule(lib, nqt, nbt, n_xcd, wpx)
+    assert sq * sb <= wpx and sq >= 1 and sb >= 1
+    seen = np.zeros((nqt, nbt), dtype=np.int32)
+    segs = [set() for _ in range(nqt)]
+    steps = np.zeros(n_xcd, dtype=np.int64)
+    for w in range(n_xcd * wpx):
+        mine = tasks[off[w]:off[w + 1]]
+        for qt, t0, cnt, seg, sbase, sn, sexp, _ in mine:
+            assert 0 <= qt < nqt and cnt >= 0
+            ts = t0 + sb * np.arange(cnt)
+            assert cnt == 0 or ts[-1] < nbt
+            seen[qt, ts] += 1
+            assert seg not in segs[qt]
+            segs[qt].add(seg)
+            assert 0 <= sbase and sbase + sn <= nsync and sn <= max(cnt, 0) + 1 and 1 <= sexp <= wpx
+        steps[w // wpx] = max(steps[w // wpx], sum(int(t[2]) for t in mine))
+    assert np.array_equal(seen, np.ones_like(seen))
+    for qt in range(nqt):
+        assert segs[qt] == set(range(qn[qt])), (qt, sorted(segs[qt]), qn[qt])
+    assert np.array_equal(qo, np.concatenate([[0], np.cumsum(qn)[:-1]])) and lists == int(qn.sum())
+    ngroups = -(-nqt // sq)
+    nsteps = -(-nbt // sb)
+    assert steps.max() <= -(-ngroups * nsteps // n_xcd) + (1 if ngroups % n_xcd else 0)
