@@ -529,7 +529,7 @@ def main():
     mm_peak = FP16_MFMA_PEAK_TFLOPS / n_prod if pair_stage else FP32_MFMA_PEAK_TFLOPS
     mm_unit = ("TFLOP/s (2*D flop per query-row pair; %d fp16 MFMA product%s per pair: peak = 2500 / %d)"
                % (n_prod, "" if n_prod == 1 else "s", n_prod) if pair_stage else "TFLOP/s")
-    mm_kernel = "sim_topk_pair_kernel" if pair_stage else "sim_topk_mfma_kernel"
+    mm_kernel = "sim_topk_ring_kernel" if pair_stage else "sim_topk_mfma_kernel"
     peaks = measure_peaks(torch, dev) if rank == 0 else None
 
     def match_roofline(nq_launch, ms, source, pmc_queries):

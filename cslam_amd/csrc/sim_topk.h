@@ -26,7 +26,8 @@ struct PairArgs {
 // t_beg, t_beg + t_stride, ... (t_cnt of them); its merged candidate list is "segment" `seg` of that query tile.
 struct RingTask {
     int qt, t_beg, t_cnt, seg;
-    int sync_base, sync_n, sync_expect, pad;    // tile-start rendezvous of the patch: counters sync_base + i, i < sync_n
+    int run;                                    // ordinal of the run in its XCD's list (flow control compares progress inside a run)
+    int pad[3];
 };
 struct RingArgs {
     const char *bank2; int64_t ldb2;     // bank rows as fp16 (hi halves), pitch in bytes
@@ -43,22 +44,20 @@ struct RingArgs {
     const int *qt_nseg, *qt_segoff;      // per query tile: lists per query, lists before this tile's (in units of 256 queries' lists)
     float *part_key; int *part_idx;      // list l of query j of tile qt at ((qt_segoff[qt] * 256 + j * qt_nseg[qt] + l) * SIM_KP
     float *part_bound;
-    int *sync;                           // rendezvous counters (zeroed per launch) or nullptr
+    int *prog;                           // flow control: [n_xcd][32] progress words (zeroed per launch) or nullptr
+    int flow_w;                          // ... and its window, in K stages
+    int flow_bias_q, flow_bias_b;        // measurement build: per-slot offsets inside the window
     int *xcc_out;                        // diagnostics: [workgroups] HW_REG_XCC_ID of the CU each workgroup ran on, or nullptr
     long long *trace_out;                // diagnostics: [workgroups][64] wall clock (100 MHz) at the top of the first 62 tiles of the first task,
-                                         //              [62] = timed-out rendezvous waits, [63] = wall clock at kernel exit; or nullptr
-    int stagger_cycles;                  // measurement build: a workgroup starts its first task tasks[].pad x this many cycles late
+                                         //              [62] = pauses of the flow control (~1 us each), [63] = wall clock at kernel exit; or nullptr
 };
 struct RingSchedule {                    // host side, cached per bank
     int nqt, n_btiles, n_xcd, wpx;       // key
-    int stag_q, stag_b;
     int sq, sb, total_lists;             // total_lists = sum of qt_nseg (lists per query, summed over query tiles)
-    int n_sync;
     std::vector<RingTask> tasks;
     std::vector<int> task_off, qt_nseg, qt_segoff;
 };
-// stag_q / stag_b (measurement build): start offset of patch slot (qi, bi), in units of RingArgs::stagger_cycles
-void ring_schedule_build(RingSchedule &s, int nqt, int n_btiles, int n_xcd, int wpx, int stag_q = 0, int stag_b = 0);
+void ring_schedule_build(RingSchedule &s, int nqt, int n_btiles, int n_xcd, int wpx);
 int ring_stage1_launch(const RingArgs &a, int variant, int dbg, hipStream_t st);
 
 double pair_err_bound(int kd, int nprod);

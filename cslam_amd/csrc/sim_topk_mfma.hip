@@ -523,7 +523,7 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
 #ifdef CSLAM_ABLATIONS
         const char *v = getenv("CSLAM_MFMA_DBG");       // timing-only ablations (wrong results), see the kernel: never in the default build
         dbg = v ? atoi(v) : 0;
-        if (dbg < 0 || dbg > 7) dbg = 0;          // 3..5: the persistent stage only (sim_topk_ring.hip)
+        if (dbg < 0 || dbg > 63) dbg = 0;          // 3..5: the persistent stage only (sim_topk_ring.hip)
 #endif
         const char *t = getenv("CSLAM_MFMA_TILE");      // 128 | 256 (default chosen below)
         tile_env = t ? atoi(t) : 0;
@@ -555,18 +555,18 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     }
 #endif
     RingSchedule *rs = nullptr;
-    int stag_q = 0, stag_b = 0, stag_cycles = 0;
     bool want_xcc = false;
+    int flow_w = 3, flow_bq = 0, flow_bb = 0;
 #ifdef CSLAM_ABLATIONS
-    if (const char *e = getenv("CSLAM_RING_STAGGER")) (void)sscanf(e, "%d,%d,%d", &stag_q, &stag_b, &stag_cycles);
     want_xcc = getenv("CSLAM_RING_XCC") != nullptr;
+    if (const char *e = getenv("CSLAM_RING_FLOW_W")) (void)sscanf(e, "%d,%d,%d", &flow_w, &flow_bq, &flow_bb);
 #endif
     if (ring) {
         const int n_xcd = b->num_cu % 8 == 0 ? 8 : 1;
         const int wpx = b->num_cu / n_xcd;
         rs = &b->ring_sched;
-        if (rs->nqt != nqt || rs->n_btiles != n_btiles || rs->n_xcd != n_xcd || rs->wpx != wpx || rs->stag_q != stag_q || rs->stag_b != stag_b)
-            ring_schedule_build(*rs, nqt, n_btiles, n_xcd, wpx, stag_q, stag_b);
+        if (rs->nqt != nqt || rs->n_btiles != n_btiles || rs->n_xcd != n_xcd || rs->wpx != wpx)
+            ring_schedule_build(*rs, nqt, n_btiles, n_xcd, wpx);
         nseg = 0;
         for (int v : rs->qt_nseg) nseg = v > nseg ? v : nseg;       // reported; the lists have per-query-tile counts
     }
@@ -626,7 +626,7 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     size_t o_ro = carve(ring ? rs->task_off.size() * 4 : 0);
     size_t o_rn = carve(ring ? (size_t)nqt * 4 : 0);
     size_t o_rs = carve(ring ? (size_t)nqt * 4 : 0);
-    size_t o_ry = carve(ring ? (size_t)(rs->n_sync > 0 ? rs->n_sync : 1) * 4 : 0);
+    size_t o_ry = carve(ring ? (size_t)rs->n_xcd * 32 * 4 : 0);
     size_t o_rx = carve(ring && want_xcc ? (size_t)b->num_cu * 4 : 0);
     size_t o_rz = carve(ring && want_xcc ? ((size_t)b->num_cu * 64 + 8 * 48 * 2 + 8) * 8 : 0);
     int rc = bank_ws_reserve(b, 0, off);
@@ -646,7 +646,7 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
         HIP_TRY(hipMemcpyAsync(ws + o_ro, rs->task_off.data(), rs->task_off.size() * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(ws + o_rn, rs->qt_nseg.data(), (size_t)nqt * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(ws + o_rs, rs->qt_segoff.data(), (size_t)nqt * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemsetAsync(ws + o_ry, 0, (size_t)(rs->n_sync > 0 ? rs->n_sync : 1) * 4, st));
+        HIP_TRY(hipMemsetAsync(ws + o_ry, 0, (size_t)rs->n_xcd * 32 * 4, st));
     } else {
         // patch-major order of the (query tile, segment) grid; patches of a x bseg items ~ the number
         // of workgroups resident per XCD
@@ -710,8 +710,8 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
         ra.tasks = (const RingTask *)(ws + o_rt); ra.task_off = (const int *)(ws + o_ro);
         ra.qt_nseg = (const int *)(ws + o_rn); ra.qt_segoff = (const int *)(ws + o_rs);
         ra.part_key = part_key; ra.part_idx = part_idx; ra.part_bound = part_bound;
-        ra.sync = (ring_variant & 1) ? (int *)(ws + o_ry) : nullptr;
-        ra.xcc_out = want_xcc ? (int *)(ws + o_rx) : nullptr; ra.stagger_cycles = stag_cycles;
+        ra.prog = ((ring_variant & 1) && rs->wpx <= 32) ? (int *)(ws + o_ry) : nullptr; ra.flow_w = flow_w; ra.flow_bias_q = flow_bq; ra.flow_bias_b = flow_bb;
+        ra.xcc_out = want_xcc ? (int *)(ws + o_rx) : nullptr;
         ra.trace_out = want_xcc ? (long long *)(ws + o_rz) : nullptr;
         if (want_xcc) HIP_TRY(hipMemsetAsync(ws + o_rz, 0, ((size_t)b->num_cu * 64 + 8 * 48 * 2 + 8) * 8, st));
         rc = ring_stage1_launch(ra, ring_variant, dbg, st);
@@ -743,14 +743,14 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
                 }
                 long long to = 0;
                 for (int w = x; w < b->num_cu; w += rs->n_xcd) to += tr[(size_t)w * 64 + 62];
-                fprintf(stderr, "  timeouts %lld\n", to);
+                fprintf(stderr, "  pauses %lld\n", to);
             }
             for (int i = 1; i <= 3; i += 2) {
                 fprintf(stderr, "[ring] XCD 0, start of tile %d by slot (qi-major, Sb = %d), us after the first:", i, rs->sb);
                 for (int sl = 0; sl < rs->wpx; ++sl) fprintf(stderr, "%s%.0f", sl % rs->sb == 0 ? " | " : " ", (tr[(size_t)(sl * rs->n_xcd) * 64 + i] - t0) * 0.01);
                 fprintf(stderr, "\n");
             }
-            if (dbg == 1) {       // barrier stamps of workgroup 0: per stage, arrival of each wave relative to the first arrival, and the release
+            if (dbg == 33) {      // barrier stamps of workgroup 0: per stage, arrival of each wave relative to the first arrival, and the release
                 std::vector<long long> bt(8 * 48 * 2 + 8);
                 HIP_TRY(hipMemcpy(bt.data(), ws + o_rz + (size_t)b->num_cu * 64 * 8, bt.size() * 8, hipMemcpyDeviceToHost));
                 fprintf(stderr, "[ring] HW_ID simd of waves 0..7:");

@@ -23,22 +23,25 @@
 // gets the same number of steps (+- 1).  A (query tile, run, patch column) = one merged candidate list = one "segment" for
 // stage 2 (rescore_kernel reads a per-query-tile segment count).
 //
-// Tile-start rendezvous (SYNC).  A workgroup announces "I am one K stage from my next tile" on a per-step counter and, at the top of
-// the tile, waits (one wave polls, bounded, ~5 us) until the patch has announced: the patch re-aligns every tile, whatever the
-// epilogues and cache misses did to it.  The counters are a hint: a timed-out wait just goes on (and stops waiting for the rest of
-// the task), results never depend on it.
+// Flow control (FLOW).  The workgroups of a patch start a walk within 0.3 us of each other and are 20-40 us apart one tile later
+// (identical work; per-tile times scatter by +-5 %, profiles/r05_v4_patch_spread_trace.log), while the 4 MB of L2 hold about ten K
+// stages of the patch's twelve streams: the sharing the schedule is built for lasts one tile.  (A tile-start rendezvous with a 6 us
+// bound timed out on every tile and was removed.)  Instead every workgroup publishes its progress (run << 20 | K stage) every second
+// stage in the patch's 128-byte progress line, one wave re-reads the line every fourth stage -- the load rides on the stage's own
+// vmcnt(0), nothing waits for it -- and a workgroup more than `flow_w` stages ahead of the slowest one of its patch pauses
+// (bounded; a timed-out pause switches the mechanism off for the task: the counters are a hint, results never depend on them).
 #include <stdlib.h>
 #include <type_traits>
 #include "sim_topk_pair_dev.h"
 
-// KPL = per-lane candidate list length.  DBG (measurement build, timing only): 1 = no global loads after the first stage, 2 = every
-// request reads bank tile 0 / query tile 0, 3 = 1 without the stage barrier, 4 = 1 without fragment reads after the first stage,
-// 5 = 3 and 4 (the bare MFMA stream of the loop).  SYNC = tile-start rendezvous.  PRIO = progress-ordered wave priority: a stage's four groups of 8 MFMAs run at
+// KPL = per-lane candidate list length.  DBG (measurement build, timing only; a bit mask): 1 = no global loads after the first stage
+// (every stage re-reads the first one), 2 = every request reads bank tile 0 / query tile 0 (L2 hits), 4 = no stage barrier (with 1),
+// 8 = no candidate update, 16 = round 4's tile epilogue.  FLOW = patch flow control.  PRIO = progress-ordered wave priority: a stage's four groups of 8 MFMAs run at
 // s_setprio 3, 2, 1, 0.  The arbiter takes priority first, age second: at equal priority the older wave of a SIMD issues its WHOLE
 // stage first and parks at the barrier ~1000 cycles before its partner, which then runs alone with nobody to fill its issue gaps
 // (2420 cycles per 2048-cycle stage, profiles/r05_v8_barrier_trace.log); with the wave that is BEHIND always at the higher
 // priority the pair alternates group by group and the solo tail is one group.
-template <int KPL, int DBG, int SYNC, int PRIO>
+template <int KPL, int DBG, int FLOW, int PRIO>
 __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
     constexpr int T_ = 256, MT = 4, NTW = 2, NWN = 4, NTHR = 512;
     constexpr int OPB = T_ * PK_ROWB;            // bytes of one operand tile (64 channels of 256 rows) in LDS
@@ -55,11 +58,11 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
     const int h = lane >> 5, l31 = lane & 31;
     const int bid = blockIdx.x;
     const int wg = (bid % p.n_xcd) * p.wpx + bid / p.n_xcd;
-    char *const sync_off = smem + 2 * STAGE;         // one byte behind the two stages: "this task has stopped waiting"
     // 1 / (||row|| s_row) of the current bank tile's 256 rows; two buffers by tile parity: a wave that leaves a tile's epilogue early
     // requests the next tile's values while slower waves still read this tile's (a buffer is rewritten 64 stage barriers later)
     float *const s_inv = (float *)(smem + 2 * STAGE + 16);
-    if (SYNC) { if (tid == 0) *sync_off = 0; __syncthreads(); }
+    int *const prog = (FLOW && p.prog) ? p.prog + (bid % p.n_xcd) * 32 : nullptr;      // the patch's progress line
+    const int slot = bid / p.n_xcd;
 
     // ---- loader: chunk pch = i*NTHR + tid -> tile row pch >> 3, physical 16-byte slot pch & 7 holding logical chunk
     // slot ^ ((row >> 1) & 7) of the row's 128-byte block
@@ -85,7 +88,7 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         p.xcc_out[bid] = xcc;
     }
-    if (DBG == 1 && p.trace_out && bid == 0 && lane == 0) {
+    if (DBG == 33 && p.trace_out && bid == 0 && lane == 0) {
         int hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         p.trace_out[(size_t)(p.n_xcd * p.wpx) * 64 + 8 * 48 * 2 + wave] = hw;
@@ -93,11 +96,6 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
     const int task_end = p.task_off[wg + 1];
     for (int ti = p.task_off[wg]; ti < task_end; ++ti) {
         const RingTask tk = p.tasks[ti];
-        if (DBG >= 0 && p.stagger_cycles > 0 && ti == p.task_off[wg]) {        // measurement build: staggered start
-            const uint64_t t0 = __builtin_amdgcn_s_memtime();
-            const uint64_t d = (uint64_t)tk.pad * (uint64_t)p.stagger_cycles;
-            while (__builtin_amdgcn_s_memtime() - t0 < d) __builtin_amdgcn_s_sleep(8);
-        }
         const int qt = tk.qt;
         int ntiles = tk.t_cnt;
         {
@@ -117,19 +115,16 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
             lim[n] = p.lim[qt * T_ + wn * (32 * NTW) + n * 32 + l31];
             qmul[n] = p.qinvs[qt * T_ + wn * (32 * NTW) + n * 32 + l31];
         }
-        // rendezvous bookkeeping (wave-uniform)
-        int n_arrived = 0;
-        bool sync_on = SYNC && p.sync != nullptr;
-        auto arrive = [&](int i) {
-            if (SYNC && p.sync != nullptr && i < tk.sync_n && tid == 0)
-                __hip_atomic_fetch_add(p.sync + tk.sync_base + i, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        };
+        // measurement build: flow_bias_q / flow_bias_b hold patch slot (qi, bi) that many stages further back (sharers spaced in time)
+        const int pbase = (tk.run << 20) + p.flow_bias_q * (slot / p.t_stride) + p.flow_bias_b * (slot % p.t_stride);
+        bool flow_on = prog != nullptr;                  // used by wave 0 only
+        int pv = 0x7fffffff;                             // wave 0: progress of patch slot `lane`, as last read
 
         if (ntiles > 0) {
-            const __amdgpu_buffer_rsrc_t rsB = pk_rsrc(p.q2 + (int64_t)(DBG == 2 ? 0 : qt) * T_ * p.ldq2, (int64_t)T_ * p.ldq2);
+            const __amdgpu_buffer_rsrc_t rsB = pk_rsrc(p.q2 + (int64_t)((DBG & 2) ? 0 : qt) * T_ * p.ldq2, (int64_t)T_ * p.ldq2);
             __amdgpu_buffer_rsrc_t rsA;
             auto point_at_tile = [&](int tile) {
-                const int t0 = DBG == 2 ? 0 : tile;
+                const int t0 = (DBG & 2) ? 0 : tile;
                 int64_t rows = (int64_t)p.n_rows - (int64_t)t0 * T_;
                 if (rows > T_) rows = T_;
                 rsA = pk_rsrc(p.bank2 + (int64_t)t0 * T_ * p.ldb2, rows * p.ldb2);
@@ -158,18 +153,10 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
 #pragma unroll
                 for (int n = 0; n < NTW; ++n) fb[u][n] = (f16x8)(_Float16)0.0f;
             }
-            constexpr bool NOLOAD = DBG == 1 || (DBG >= 3 && DBG <= 5);
-            constexpr bool NOBAR = DBG == 3 || DBG == 5;
-            constexpr bool NOREAD = DBG == 4 || DBG == 5;
+            constexpr bool NOLOAD = (DBG & 1) != 0;
+            constexpr bool NOBAR = (DBG & 4) != 0;
             int it = 0;
             auto read_frags = [&](int u, const char *sA, const char *sB, int s) {
-                if (NOREAD && it > 0) {
-#pragma unroll
-                    for (int m = 0; m < MT; ++m) asm volatile("" : "+v"(fa[u][m]));
-#pragma unroll
-                    for (int n = 0; n < NTW; ++n) asm volatile("" : "+v"(fb[u][n]));
-                    return;
-                }
 #pragma unroll
                 for (int m = 0; m < MT; ++m) fa[u][m] = *(const f16x8 *)(sA + arow0 + m * 32 * PK_ROWB + foff[s]);
 #pragma unroll
@@ -186,7 +173,6 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
             point_at_tile(tk.t_beg);
 #pragma unroll
             for (int i = 0; i < NLD; ++i) stage_load_part(0, 0, i);
-            arrive(0); n_arrived = 1;
             __builtin_amdgcn_s_waitcnt(0);
             __builtin_amdgcn_s_barrier();
 
@@ -199,10 +185,37 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
                 const bool more = it + 1 < total;
                 const int lkt = more ? nkt_ : kt;
                 if (more && nkt_ == 0) point_at_tile(ntile);             // wave-uniform, before anything is in flight
-                const char *sA = smem + (it & 1) * STAGE;
+                const char *sA = smem + (NOLOAD ? 0 : (it & 1)) * STAGE;
                 const char *sB = sA + OPB;
                 constexpr int HALF = FIRST ? 0 : NLD / 2;                // loader parts (2 requests each) issued behind the barrier
                 constexpr int LEAD = 2;
+                if (FLOW) {
+                    if (wave == 0 && flow_on) {
+                        const int P = pbase + it;
+                        if ((it & 1) == 0 && lane == 0) __hip_atomic_store(prog + slot, P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((it & 3) == 3) {
+                            // the line read two stages ago (its load was waited for by the stage barriers since): slowest of the patch
+                            auto slowest = [&](int v) {
+#pragma unroll
+                                for (int off = 32; off >= 1; off >>= 1) { const int o = __shfl_xor(v, off, 64); v = o < v ? o : v; }
+                                return __builtin_amdgcn_readfirstlane(v);
+                            };
+                            int mn = slowest(pv);
+                            int spins = 0;
+                            while (P - mn > p.flow_w && spins < 48) {               // ahead of the window: pause, ~1 us per look
+                                __builtin_amdgcn_s_sleep(24);
+                                pv = lane < p.wpx ? __hip_atomic_load(prog + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
+                                mn = slowest(pv);
+                                ++spins;
+                            }
+                            if (spins >= 48) flow_on = false;
+                            if (p.trace_out && spins > 0 && lane == 0) p.trace_out[(size_t)bid * 64 + 62] += spins;
+                        }
+                        if ((it & 3) == 1)
+                            pv = lane < p.wpx ? __hip_atomic_load(prog + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 // ---- behind the barrier: first reads of this stage, requests of the next, the last K step of the previous
                 if (PRIO) { __builtin_amdgcn_s_setprio(3); __builtin_amdgcn_sched_barrier(0); }
                 if constexpr (FIRST) {
@@ -264,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
                 }
                 if (!NOBAR) {
                     // DBG 1 with a trace buffer: per-wave shader-clock stamps around the barrier of the first 48 stages (workgroup 0)
-                    const bool stamp = DBG == 1 && p.trace_out && bid == 0 && it < 48;
+                    const bool stamp = DBG == 33 && p.trace_out && bid == 0 && it < 48;
                     uint64_t ta = 0;
                     if (stamp) ta = __builtin_amdgcn_s_memtime();
                     __builtin_amdgcn_s_waitcnt(0);
@@ -282,38 +295,13 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
             };
             int tile = tk.t_beg;
             for (int i = 0; i < ntiles; ++i, tile += p.t_stride) {
-                if (SYNC) {
-                    // top of tile i: wait until the patch has announced step i (its stage 0 is already in LDS, the wait costs
-                    // nothing that the announcement of the slowest workgroup would not cost anyway)
-                    if (sync_on && i < tk.sync_n) {
-                        if (wave == 0) {
-                            const int *cnt = p.sync + tk.sync_base + i;
-                            // bounded in shader cycles: ~6 us inside a walk, ~40 us at its start (the patch comes out of its merges)
-                            const uint64_t t0 = __builtin_amdgcn_s_memtime();
-                            const uint64_t bound = i == 0 ? 80000u : 12000u;
-                            bool ok;
-                            while (!(ok = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= tk.sync_expect) &&
-                                   __builtin_amdgcn_s_memtime() - t0 < bound)
-                                __builtin_amdgcn_s_sleep(2);
-                            // two timed-out waits in a row: somebody of the patch is not running -- stop waiting for this task
-                            const char miss = ok ? 0 : (char)(*sync_off + 1);
-                            *sync_off = miss;
-                            if (p.trace_out && !ok && lane == 0) p.trace_out[(size_t)bid * 64 + 62] += 1;
-                        }
-                        __builtin_amdgcn_s_waitcnt(0);
-                        __builtin_amdgcn_s_barrier();
-                        if (*sync_off >= 2) sync_on = false;
-                    }
-                }
                 if (p.trace_out && tid == 0 && ti == p.task_off[wg] && i < 62) p.trace_out[(size_t)bid * 64 + i] = (long long)wall_clock64();
                 stage_body(std::true_type{}, tile, 0);
                 for (int kt = 1; kt < p.nkt; ++kt) {
-                    if (SYNC && kt == p.nkt - 1) { arrive(i + 1); n_arrived = i + 2; }
                     stage_body(std::false_type{}, tile, kt);
                 }
-                if (SYNC && p.nkt == 1) { arrive(i + 1); n_arrived = i + 2; }
                 multiply((NS - 1) & 1);                                  // the tile's last K step, then its candidates
-                if (DBG == 6) {                                          // timing only: no candidate update
+                if (DBG & 8) {                                           // timing only: no candidate update
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -322,7 +310,7 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
 #pragma unroll
                             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
                         }
-                } else if (DBG == 7) {                                   // measurement build: round 4's epilogue
+                } else if (DBG & 16) {                                   // measurement build: round 4's epilogue
                     pair_tile_epilogue<MT, KPL, NTW>(acc, lk, li, lim, qmul, p.invs, p.n_rows, tile * T_ + wm * 32 * MT + 4 * h);
                 } else {
                     ring_tile_epilogue<MT, KPL, NTW>(acc, lk, li, lim, qmul, s_inv + tpar * 256 + wm * 32 * MT + 4 * h, tile * T_ + wm * 32 * MT + 4 * h);
@@ -330,9 +318,8 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
                 tpar ^= 1;
             }
         }
-        // steps this workgroup does not take (row limits cut its walk short): announce them all, nobody waits for it
-        if (SYNC)
-            for (int i = n_arrived; i < tk.sync_n; ++i) arrive(i);
+        // the run is done for this workgroup (or it had nothing to do in it): nobody waits for it any more
+        if (prog && tid == 0) __hip_atomic_store(prog + slot, (tk.run + 1) << 20, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
         {
             const int ns = p.qt_nseg[qt];
@@ -340,15 +327,15 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
             pair_block_merge<T_, KPL, NTW>(smem, lk, li, wn, wm, h, l31, tid, p.part_key + l0 * SIM_KP, p.part_idx + l0 * SIM_KP,
                                            p.part_bound + l0, (size_t)ns);
         }
-        if (SYNC && tid == 0) *sync_off = 0;
         __syncthreads();                                                 // the merge's LDS is the next task's first stage
     }
+    if (prog && tid == 0) __hip_atomic_store(prog + slot, 0x7fffffff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (p.trace_out && tid == 0) p.trace_out[(size_t)bid * 64 + 63] = (long long)wall_clock64();
 }
 
 // ---- the schedule ------------------------------------------------------------------------------------------------------------
-void ring_schedule_build(RingSchedule &s, int nqt, int n_btiles, int n_xcd, int wpx, int stag_q, int stag_b) {
-    s.nqt = nqt; s.n_btiles = n_btiles; s.n_xcd = n_xcd; s.wpx = wpx; s.stag_q = stag_q; s.stag_b = stag_b;
+void ring_schedule_build(RingSchedule &s, int nqt, int n_btiles, int n_xcd, int wpx) {
+    s.nqt = nqt; s.n_btiles = n_btiles; s.n_xcd = n_xcd; s.wpx = wpx;
     int sq = nqt < 4 ? nqt : 4;
     if (sq > wpx) sq = wpx;
     if (sq < 1) sq = 1;
@@ -393,11 +380,6 @@ void ring_schedule_build(RingSchedule &s, int nqt, int n_btiles, int n_xcd, int 
     s.total_lists = lists;
     s.tasks.clear();
     s.task_off.assign((size_t)n_xcd * wpx + 1, 0);
-    int n_sync = 0;
-    std::vector<std::vector<int>> sync_base(n_xcd);
-    for (int x = 0; x < n_xcd; ++x)
-        for (const Run &r : runs[x]) { sync_base[x].push_back(n_sync); n_sync += r.j1 - r.j0; }
-    s.n_sync = n_sync;
     for (int x = 0; x < n_xcd; ++x)
         for (int sl = 0; sl < wpx; ++sl) {
             const int w = x * wpx + sl;
@@ -415,28 +397,22 @@ void ring_schedule_build(RingSchedule &s, int nqt, int n_btiles, int n_xcd, int 
                 for (int j = r.j0; j < r.j1; ++j) cnt += (j * sb + bi) < n_btiles;
                 t.t_cnt = cnt;
                 t.seg = r.r * sb + bi;
-                // participants of the run: the query tiles that exist; a step is a rendezvous while every column has a tile in it
-                int nq_here = nqt - r.g * sq; if (nq_here > sq) nq_here = sq;
-                int full_steps = r.j1 - r.j0;
-                if (r.j1 == nsteps && n_btiles % sb != 0) --full_steps;
-                t.sync_base = sync_base[x][k];
-                t.sync_n = full_steps > 0 ? full_steps : 0;
-                t.sync_expect = nq_here * sb;
-                t.pad = stag_q * qi + stag_b * bi;
+                t.run = (int)k;                  // the XCD's k-th run: progress of the patch is compared inside a run
+                t.pad[0] = t.pad[1] = t.pad[2] = 0;
                 s.tasks.push_back(t);
             }
         }
     s.task_off[(size_t)n_xcd * wpx] = (int)s.tasks.size();
 }
 
-// variant: bit 0 = tile-start rendezvous, bit 1 = progress-ordered wave priority
+// variant: bit 0 = patch flow control, bit 1 = progress-ordered wave priority
 int ring_stage1_launch(const RingArgs &a, int variant, int dbg, hipStream_t st) {
     constexpr int lds = 2 * 2 * 256 * PK_ROWB + 16 + 2 * 1024;
     static DeviceOnce once;
     int once_dev;
 #define RING_EACH(X) X(0, 0, 0) X(0, 1, 0) X(0, 0, 1) X(0, 1, 1)
 #ifdef CSLAM_ABLATIONS
-#define RING_EACH_DBG(X) X(1, 0, 0) X(1, 1, 0) X(1, 0, 1) X(1, 1, 1) X(2, 0, 0) X(2, 1, 0) X(2, 0, 1) X(2, 1, 1) X(3, 0, 0) X(4, 0, 0) X(5, 0, 0) X(6, 0, 0) X(7, 0, 0)
+#define RING_EACH_DBG(X) X(2, 0, 0) X(8, 0, 0) X(9, 0, 0) X(10, 0, 0) X(13, 0, 0) X(16, 0, 0) X(33, 0, 0) X(33, 0, 1) X(9, 0, 1) X(10, 0, 1)
 #else
 #define RING_EACH_DBG(X)
 #endif
@@ -466,7 +442,7 @@ CSLAM_API int cslam_ring_schedule_describe(int nqt, int n_btiles, int n_xcd, int
     ARG_CHECK(nqt >= 1 && n_btiles >= 1 && n_xcd >= 1 && wpx >= 1 && info, "nqt, n_btiles, n_xcd, wpx >= 1 and info are required");
     RingSchedule s;
     ring_schedule_build(s, nqt, n_btiles, n_xcd, wpx);
-    info[0] = s.sq; info[1] = s.sb; info[2] = (int32_t)s.tasks.size(); info[3] = s.total_lists; info[4] = s.n_sync; info[5] = (int32_t)sizeof(RingTask) / 4;
+    info[0] = s.sq; info[1] = s.sb; info[2] = (int32_t)s.tasks.size(); info[3] = s.total_lists; info[4] = 0; info[5] = (int32_t)sizeof(RingTask) / 4;
     if (tasks) {
         ARG_CHECK(tasks_cap >= (int64_t)s.tasks.size() * 8, "tasks_cap too small: 8 int32 per task");
         memcpy(tasks, s.tasks.data(), s.tasks.size() * sizeof(RingTask));

@@ -68,8 +68,8 @@ int cslam_debug_last_candidates(cslam_bank_t *bank, int64_t nq, int *nseg, float
 
 /* The static schedule of the persistent candidate stage (csrc/sim_topk_ring.hip; the matcher's D.D^T of cslam/nns_matching.py:55-61
  * on 256 x 256 tiles) for `nqt` query tiles x `n_btiles` bank tiles on n_xcd XCDs of wpx workgroups.  Host code only (no GPU needed).
- * info = {Sq, Sb, tasks, lists per query summed over query tiles, rendezvous counters, int32 words per task (8)};
- * tasks [info[2]][8] = {query tile, first bank tile, bank tiles (stride Sb), list number, rendezvous base / steps / expected, 0},
+ * info = {Sq, Sb, tasks, lists per query summed over query tiles, 0, int32 words per task (8)};
+ * tasks [info[2]][8] = {query tile, first bank tile, bank tiles (stride Sb), list number, run ordinal in its XCD, 0, 0, 0},
  * task_off [n_xcd * wpx + 1] (workgroup w = XCD w / wpx, slot w % wpx), qt_nseg / qt_segoff [nqt].  NULL outputs are skipped. */
 int cslam_ring_schedule_describe(int nqt, int n_btiles, int n_xcd, int wpx, int32_t info[6], int32_t *tasks, int64_t tasks_cap,
                                  int32_t *task_off, int32_t *qt_nseg, int32_t *qt_segoff);

@@ -105,7 +105,7 @@ def _ring_schedule(lib, nqt, nbt, n_xcd=8, wpx=32):
 def test_ring_schedule_covers_every_tile_pair_once_and_balances_the_xcds(nqt, nbt):
     """The static schedule of the persistent candidate stage (csrc/sim_topk_ring.hip): every (query tile, bank tile) pair belongs to
     exactly one task, a query tile's lists are numbered 0 .. qt_nseg - 1 without gaps, the per-tile list offsets are the running
-    sum, the rendezvous counters of different (XCD, run) pairs do not overlap, and no XCD walks more than one step (plus the
+    sum, and no XCD walks more than one step (plus the
     rounding of the tail split) beyond the mean."""
     lib = _lib.load()
     n_xcd, wpx = 8, 32
@@ -116,14 +116,14 @@ def test_ring_schedule_covers_every_tile_pair_once_and_balances_the_xcds(nqt, nb
     steps = np.zeros(n_xcd, dtype=np.int64)
     for w in range(n_xcd * wpx):
         mine = tasks[off[w]:off[w + 1]]
-        for qt, t0, cnt, seg, sbase, sn, sexp, _ in mine:
+        for qt, t0, cnt, seg, run, _, _, _ in mine:
             assert 0 <= qt < nqt and cnt >= 0
             ts = t0 + sb * np.arange(cnt)
             assert cnt == 0 or ts[-1] < nbt
             seen[qt, ts] += 1
             assert seg not in segs[qt]
             segs[qt].add(seg)
-            assert 0 <= sbase and sbase + sn <= nsync and sn <= max(cnt, 0) + 1 and 1 <= sexp <= wpx
+            assert run >= 0
         steps[w // wpx] = max(steps[w // wpx], sum(int(t[2]) for t in mine))
     assert np.array_equal(seen, np.ones_like(seen))
     for qt in range(nqt):
