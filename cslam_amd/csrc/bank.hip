@@ -125,7 +125,7 @@ CSLAM_API int cslam_bank_create(int device, int dim, int64_t capacity_hint, csla
     b->dbg_part_key = nullptr; b->dbg_part_idx = nullptr; b->dbg_nseg = 0; b->dbg_nq = 0; b->dbg_err_bound = 0.0;
     for (int s = 0; s < 4; ++s) { b->stats[s] = 0; b->item_map_key[s] = -1; }
     b->num_cu = 0;
-    b->ring_sched.nqt = -1; b->ring_sched.n_btiles = -1; b->ring_sched.n_xcd = 0; b->ring_sched.wpx = 0; b->dbg_ring = false;
+    b->ring_sched.nqt = -1; b->ring_sched.n_rows = -1; b->ring_sched.n_xcd = 0; b->ring_sched.wpx = 0; b->dbg_ring = false;
     b->device = device; b->dim = dim; b->kd = (int)round_up64(dim, 32);
     // Row pitch: a power-of-two pitch (4096 floats = 16 KiB) maps the same K offset of every row to
     // the same L2 set -- measured 17 % L2 hit rate, 2.1 TB fetched per 100k-query pass; one extra

@@ -20,14 +20,19 @@ struct PairArgs {
 };
 
 // ---- the persistent form of the one-product stage (sim_topk_ring.hip) ------------------------------------------------------
-// One workgroup per CU for the whole launch; the workgroups of an XCD form an Sq x Sb patch (query tiles x bank tiles) that
-// walks the bank Sb tiles at a time, all of them at the same K position, so every operand stream of the patch is fetched into
-// the XCD's L2 once and read Sq (bank) or Sb (queries) times.  A task = one query tile against the strided bank tiles
-// t_beg, t_beg + t_stride, ... (t_cnt of them); its merged candidate list is "segment" `seg` of that query tile.
+// One workgroup per CU for the whole launch; the workgroups of an XCD form an Sq x Sb patch (query tiles x bank columns) whose
+// members walk the bank side by side, all of them at the same K position, so every operand stream of the patch is fetched into
+// the XCD's L2 once and read Sq (bank) or Sb (queries) times.  A task = one query tile against bank rows
+// [row0 + i stride_rows, + 256) for i < n_tiles (stride_rows = 256), cut at row_end; its merged candidate list is "segment" `seg`
+// of that query tile.
+// A run (one query group against bank rows [ra, rb) on one XCD) is cut into Sb contiguous chunks of equal length, one per patch
+// column, the last tile of a chunk partial: every workgroup of a run computes the same number of ROWS (the 1024-query launch of
+// the bench's step: 6 tiles + 32 rows each instead of 6 or 7 whole tiles).  Whole-bank runs are cut the same way on every XCD,
+// so the 8 XCDs work on 8 different query groups against the SAME bank rows at the same time.
 struct RingTask {
-    int qt, t_beg, t_cnt, seg;
+    int qt, row0, n_tiles, seg;
     int run;                                    // ordinal of the run in its XCD's list (flow control compares progress inside a run)
-    int pad[3];
+    int stride_rows, row_end, pad;
 };
 struct RingArgs {
     const char *bank2; int64_t ldb2;     // bank rows as fp16 (hi halves), pitch in bytes
@@ -37,7 +42,7 @@ struct RingArgs {
     const int *lim;
     const int *qt_maxlim;
     int nkt;                             // K stages of 128 bytes per row
-    int nqt, n_btiles, t_stride;
+    int nqt, sb;                         // sb = columns of a patch (slot = qi * sb + bi)
     int n_xcd, wpx;                      // workgroup b = slot b / n_xcd of XCD b % n_xcd
     const RingTask *tasks;               // tasks of workgroup w: [task_off[w], task_off[w + 1])
     const int *task_off;
@@ -52,12 +57,12 @@ struct RingArgs {
                                          //              [62] = pauses of the flow control (~1 us each), [63] = wall clock at kernel exit; or nullptr
 };
 struct RingSchedule {                    // host side, cached per bank
-    int nqt, n_btiles, n_xcd, wpx;       // key
+    int nqt, n_rows, n_xcd, wpx;         // key
     int sq, sb, total_lists;             // total_lists = sum of qt_nseg (lists per query, summed over query tiles)
     std::vector<RingTask> tasks;
     std::vector<int> task_off, qt_nseg, qt_segoff;
 };
-void ring_schedule_build(RingSchedule &s, int nqt, int n_btiles, int n_xcd, int wpx);
+void ring_schedule_build(RingSchedule &s, int nqt, int n_rows, int n_xcd, int wpx);
 int ring_stage1_launch(const RingArgs &a, int variant, int dbg, hipStream_t st);
 
 double pair_err_bound(int kd, int nprod);

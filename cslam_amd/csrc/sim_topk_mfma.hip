@@ -565,8 +565,8 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
         const int n_xcd = b->num_cu % 8 == 0 ? 8 : 1;
         const int wpx = b->num_cu / n_xcd;
         rs = &b->ring_sched;
-        if (rs->nqt != nqt || rs->n_btiles != n_btiles || rs->n_xcd != n_xcd || rs->wpx != wpx)
-            ring_schedule_build(*rs, nqt, n_btiles, n_xcd, wpx);
+        if (rs->nqt != nqt || rs->n_rows != (int)b->n || rs->n_xcd != n_xcd || rs->wpx != wpx)
+            ring_schedule_build(*rs, nqt, (int)b->n, n_xcd, wpx);
         nseg = 0;
         for (int v : rs->qt_nseg) nseg = v > nseg ? v : nseg;       // reported; the lists have per-query-tile counts
     }
@@ -706,7 +706,7 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
         ra.bank2 = b->rowsh; ra.ldb2 = ldq2; ra.invs = b->invs; ra.n_rows = (int)b->n;
         ra.q2 = ws + o_q32; ra.ldq2 = ldq2; ra.qinvs = (const float *)(ws + o_qs);
         ra.lim = lim; ra.qt_maxlim = qtm; ra.nkt = b->kh / 64;
-        ra.nqt = nqt; ra.n_btiles = n_btiles; ra.t_stride = rs->sb; ra.n_xcd = rs->n_xcd; ra.wpx = rs->wpx;
+        ra.nqt = nqt; ra.sb = rs->sb; ra.n_xcd = rs->n_xcd; ra.wpx = rs->wpx;
         ra.tasks = (const RingTask *)(ws + o_rt); ra.task_off = (const int *)(ws + o_ro);
         ra.qt_nseg = (const int *)(ws + o_rn); ra.qt_segoff = (const int *)(ws + o_rs);
         ra.part_key = part_key; ra.part_idx = part_idx; ra.part_bound = part_bound;

@@ -66,15 +66,17 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
 
     // ---- loader: chunk pch = i*NTHR + tid -> tile row pch >> 3, physical 16-byte slot pch & 7 holding logical chunk
     // slot ^ ((row >> 1) & 7) of the row's 128-byte block
-    int voffA[NLD], voffB[NLD];
-#pragma unroll
-    for (int i = 0; i < NLD; ++i) {
-        const int pch = i * NTHR + tid;
-        const int r = pch >> 3, slot = pch & 7;
-        const int c = slot ^ ((r >> 1) & 7);
-        voffA[i] = r * (int)p.ldb2 + (c << 4);
-        voffB[i] = r * (int)p.ldq2 + (c << 4);
+    // (the bank's row offsets stay in the per-lane offset -- one add per request -- because the buffer's range check, which zeroes
+    // the rows beyond a task's end, sees voffset only; the query copy is padded to whole tiles: its 64-row steps ride in soffset)
+    int voffA0, voffB0;
+    {
+        const int r = tid >> 3, slot = tid & 7;
+        const int c = slot ^ ((r >> 1) & 7);             // the same for every part i: r advances by 64
+        voffA0 = r * (int)p.ldb2 + (c << 4);
+        voffB0 = r * (int)p.ldq2 + (c << 4);
     }
+    const int stepA = (NTHR / 8) * (int)p.ldb2;
+    const int stepB = (NTHR / 8) * (int)p.ldq2;
     const int wave_chunk = wave * 1024;
     const int swz = (lane >> 1) & 7;
     int foff[NS];
@@ -97,10 +99,11 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
     for (int ti = p.task_off[wg]; ti < task_end; ++ti) {
         const RingTask tk = p.tasks[ti];
         const int qt = tk.qt;
-        int ntiles = tk.t_cnt;
+        int ntiles = tk.n_tiles;
         {
-            const int te = (p.qt_maxlim[qt] + T_ - 1) / T_;                 // tiles at or beyond it hold no visible row
-            const int vis = te > tk.t_beg ? (te - tk.t_beg + p.t_stride - 1) / p.t_stride : 0;
+            int ml = p.qt_maxlim[qt];                                       // tiles that start at or beyond it hold no visible row
+            if (ml > tk.row_end) ml = tk.row_end;
+            const int vis = ml > tk.row0 ? (ml - tk.row0 + tk.stride_rows - 1) / tk.stride_rows : 0;
             if (ntiles > vis) ntiles = vis;
         }
         float lk[NTW][KPL]; int li[NTW][KPL];
@@ -113,27 +116,28 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
 #pragma unroll
         for (int n = 0; n < NTW; ++n) {
             lim[n] = p.lim[qt * T_ + wn * (32 * NTW) + n * 32 + l31];
+            lim[n] = lim[n] < tk.row_end ? lim[n] : tk.row_end;             // rows from row_end on belong to another task
             qmul[n] = p.qinvs[qt * T_ + wn * (32 * NTW) + n * 32 + l31];
         }
         // measurement build: flow_bias_q / flow_bias_b hold patch slot (qi, bi) that many stages further back (sharers spaced in time)
-        const int pbase = (tk.run << 20) + p.flow_bias_q * (slot / p.t_stride) + p.flow_bias_b * (slot % p.t_stride);
+        const int pbase = (tk.run << 20) + p.flow_bias_q * (slot / p.sb) + p.flow_bias_b * (slot % p.sb);
         bool flow_on = prog != nullptr;                  // used by wave 0 only
         int pv = 0x7fffffff;                             // wave 0: progress of patch slot `lane`, as last read
 
         if (ntiles > 0) {
             const __amdgpu_buffer_rsrc_t rsB = pk_rsrc(p.q2 + (int64_t)((DBG & 2) ? 0 : qt) * T_ * p.ldq2, (int64_t)T_ * p.ldq2);
             __amdgpu_buffer_rsrc_t rsA;
-            auto point_at_tile = [&](int tile) {
-                const int t0 = (DBG & 2) ? 0 : tile;
-                int64_t rows = (int64_t)p.n_rows - (int64_t)t0 * T_;
+            auto point_at_tile = [&](int r0) {               // the 256 bank rows from r0 on; rows at or beyond the task's end read as zero
+                const int t0 = (DBG & 2) ? 0 : r0;
+                int64_t rows = (int64_t)tk.row_end - (int64_t)r0;
                 if (rows > T_) rows = T_;
-                rsA = pk_rsrc(p.bank2 + (int64_t)t0 * T_ * p.ldb2, rows * p.ldb2);
+                rsA = pk_rsrc(p.bank2 + (int64_t)t0 * p.ldb2, rows * p.ldb2);
             };
             auto stage_load_part = [&](int stage, int kt, int i) {
                 char *sA = smem + stage * STAGE;
                 char *sB = sA + OPB;
-                pk_blds16(rsA, voffA[i], kt * PK_ROWB, sA + i * (NTHR * 16) + wave_chunk);
-                pk_blds16(rsB, voffB[i], kt * PK_ROWB, sB + i * (NTHR * 16) + wave_chunk);
+                pk_blds16(rsA, voffA0 + i * stepA, kt * PK_ROWB, sA + i * (NTHR * 16) + wave_chunk);
+                pk_blds16(rsB, voffB0, kt * PK_ROWB + i * stepB, sB + i * (NTHR * 16) + wave_chunk);
             };
 
             f32x16 acc[MT][NTW];
@@ -162,25 +166,32 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
 #pragma unroll
                 for (int n = 0; n < NTW; ++n) fb[u][n] = *(const f16x8 *)(sB + brow0 + n * 32 * PK_ROWB + foff[s]);
             };
-            auto multiply = [&](int u) {
+            // FULL: every 32-row block of the wave's 128 rows holds rows of the task; otherwise (the partial tile that ends a
+            // contiguous walk) blocks m >= m_act are skipped -- their accumulators stay zero, their rows are masked by `lim`
+            int m_act = MT;
+            auto multiply = [&](int u, auto full_tag) {
+                constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
+                    if (FULL || m < m_act) {
 #pragma unroll
-                    for (int n = 0; n < NTW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u][m], fb[u][n], acc[m][n], 0, 0, 0);
+                        for (int n = 0; n < NTW; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[u][m], fb[u][n], acc[m][n], 0, 0, 0);
+                    }
             };
 
             const int total = ntiles * p.nkt;
-            point_at_tile(tk.t_beg);
+            point_at_tile(tk.row0);
 #pragma unroll
             for (int i = 0; i < NLD; ++i) stage_load_part(0, 0, i);
             __builtin_amdgcn_s_waitcnt(0);
             __builtin_amdgcn_s_barrier();
 
             int tpar = 0;                                            // parity of the tile's ordinal in the task
-            auto stage_body = [&](auto first_tag, int tile, int kt) {
+            auto stage_body = [&](auto first_tag, auto full_tag, int tile, int kt) {       // tile = first bank row of the tile
                 constexpr bool FIRST = decltype(first_tag)::value;
+                constexpr bool FULL = decltype(full_tag)::value;
                 int nkt_ = kt + 1, ntile = tile;
-                if (nkt_ == p.nkt) { nkt_ = 0; ntile = tile + p.t_stride; }
+                if (nkt_ == p.nkt) { nkt_ = 0; ntile = tile + tk.stride_rows; }
                 // branch-free prefetch: the very last stage re-fetches its own block into the idle buffer, which nobody reads
                 const bool more = it + 1 < total;
                 const int lkt = more ? nkt_ : kt;
@@ -225,7 +236,7 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
                     if (wave < 4) {
                         const __amdgpu_buffer_rsrc_t rsI = pk_rsrc((const char *)p.invs, (int64_t)p.n_rows * 4);
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsI, (__attribute__((address_space(3))) void *)((char *)s_inv + (tpar * 4 + wave) * 256), 4,
-                                                                 (tile * T_ + tid) * 4, 0, 0, 0);
+                                                                 (tile + tid) * 4, 0, 0, 0);
                     }
                 }
                 read_frags(0, sA, sB, 0);
@@ -234,15 +245,17 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
 #pragma unroll
                         for (int i = 0; i < HALF; ++i) stage_load_part((it + 1) & 1, lkt, i);
                     }
-                    multiply((NS - 1) & 1);
-                    __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);              // DS read (nothing older is needed here)
-                    constexpr int PER = G / (2 * HALF) > 0 ? G / (2 * HALF) : 1;
+                    multiply((NS - 1) & 1, full_tag);
+                    if constexpr (FULL) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);          // DS read (nothing older is needed here)
+                        constexpr int PER = G / (2 * HALF) > 0 ? G / (2 * HALF) : 1;
 #pragma unroll
-                    for (int i = 0; i < 2 * HALF; ++i) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);          // MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);            // VMEM read (LDS-DMA)
+                        for (int i = 0; i < 2 * HALF; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);      // MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // VMEM read (LDS-DMA)
+                        }
+                        if (G - PER * 2 * HALF > 0) __builtin_amdgcn_sched_group_barrier(0x008, G - PER * 2 * HALF > 0 ? G - PER * 2 * HALF : 1, 0);
                     }
-                    if (G - PER * 2 * HALF > 0) __builtin_amdgcn_sched_group_barrier(0x008, G - PER * 2 * HALF > 0 ? G - PER * 2 * HALF : 1, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // ---- K steps 0 .. NS - 2 of this stage, each over the reads of the next
@@ -257,21 +270,23 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
 #pragma unroll
                         for (int i = HALF; i < NLD; ++i) stage_load_part((it + 1) & 1, lkt, i);
                     }
-                    multiply(s & 1);
-                    __builtin_amdgcn_sched_group_barrier(0x008, LEAD, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
-                    constexpr int REST = 2 * (NLD - HALF);               // requests placed in K step 0
-                    constexpr int GR = G - LEAD;
-                    if (s == 0) {
-                        constexpr int PER = GR / REST > 0 ? GR / REST : 1;
+                    multiply(s & 1, full_tag);
+                    if constexpr (FULL) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, LEAD, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x100, NRD, 0);
+                        constexpr int REST = 2 * (NLD - HALF);           // requests placed in K step 0
+                        constexpr int GR = G - LEAD;
+                        if (s == 0) {
+                            constexpr int PER = GR / REST > 0 ? GR / REST : 1;
 #pragma unroll
-                        for (int i = 0; i < REST; ++i) {
-                            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                            __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+                            for (int i = 0; i < REST; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                                __builtin_amdgcn_sched_group_barrier(0x008, PER, 0);
+                            }
+                            if (GR - PER * REST > 0) __builtin_amdgcn_sched_group_barrier(0x008, GR - PER * REST > 0 ? GR - PER * REST : 1, 0);
+                        } else {
+                            __builtin_amdgcn_sched_group_barrier(0x008, GR, 0);
                         }
-                        if (GR - PER * REST > 0) __builtin_amdgcn_sched_group_barrier(0x008, GR - PER * REST > 0 ? GR - PER * REST : 1, 0);
-                    } else {
-                        __builtin_amdgcn_sched_group_barrier(0x008, GR, 0);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -293,14 +308,22 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
                 ++it;
             };
-            int tile = tk.t_beg;
-            for (int i = 0; i < ntiles; ++i, tile += p.t_stride) {
+            int tile = tk.row0;                                      // first bank row of the tile
+            for (int i = 0; i < ntiles; ++i, tile += tk.stride_rows) {
                 if (p.trace_out && tid == 0 && ti == p.task_off[wg] && i < 62) p.trace_out[(size_t)bid * 64 + i] = (long long)wall_clock64();
-                stage_body(std::true_type{}, tile, 0);
-                for (int kt = 1; kt < p.nkt; ++kt) {
-                    stage_body(std::false_type{}, tile, kt);
+                const int valid = tk.row_end - tile;                 // rows of the task in this tile (>= 256: all of them)
+                if (valid >= T_) {
+                    stage_body(std::true_type{}, std::true_type{}, tile, 0);
+                    for (int kt = 1; kt < p.nkt; ++kt) stage_body(std::false_type{}, std::true_type{}, tile, kt);
+                    multiply((NS - 1) & 1, std::true_type{});        // the tile's last K step, then its candidates
+                } else {
+                    int mine = valid - wm * 32 * MT;                 // ... of this wave's 128
+                    mine = mine < 0 ? 0 : mine;
+                    m_act = (mine + 31) >> 5;
+                    stage_body(std::true_type{}, std::false_type{}, tile, 0);
+                    for (int kt = 1; kt < p.nkt; ++kt) stage_body(std::false_type{}, std::false_type{}, tile, kt);
+                    multiply((NS - 1) & 1, std::false_type{});
                 }
-                multiply((NS - 1) & 1);                                  // the tile's last K step, then its candidates
                 if (DBG & 8) {                                           // timing only: no candidate update
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
@@ -311,9 +334,9 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
                             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
                         }
                 } else if (DBG & 16) {                                   // measurement build: round 4's epilogue
-                    pair_tile_epilogue<MT, KPL, NTW>(acc, lk, li, lim, qmul, p.invs, p.n_rows, tile * T_ + wm * 32 * MT + 4 * h);
+                    pair_tile_epilogue<MT, KPL, NTW>(acc, lk, li, lim, qmul, p.invs, p.n_rows, tile + wm * 32 * MT + 4 * h);
                 } else {
-                    ring_tile_epilogue<MT, KPL, NTW>(acc, lk, li, lim, qmul, s_inv + tpar * 256 + wm * 32 * MT + 4 * h, tile * T_ + wm * 32 * MT + 4 * h);
+                    ring_tile_epilogue<MT, KPL, NTW>(acc, lk, li, lim, qmul, s_inv + tpar * 256 + wm * 32 * MT + 4 * h, tile + wm * 32 * MT + 4 * h);
                 }
                 tpar ^= 1;
             }
@@ -334,8 +357,9 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
 }
 
 // ---- the schedule ------------------------------------------------------------------------------------------------------------
-void ring_schedule_build(RingSchedule &s, int nqt, int n_btiles, int n_xcd, int wpx) {
-    s.nqt = nqt; s.n_btiles = n_btiles; s.n_xcd = n_xcd; s.wpx = wpx;
+void ring_schedule_build(RingSchedule &s, int nqt, int n_rows, int n_xcd, int wpx) {
+    s.nqt = nqt; s.n_rows = n_rows; s.n_xcd = n_xcd; s.wpx = wpx;
+    const int n_btiles = (n_rows + 255) / 256;
     int sq = nqt < 4 ? nqt : 4;
     if (sq > wpx) sq = wpx;
     if (sq < 1) sq = 1;
@@ -343,28 +367,36 @@ void ring_schedule_build(RingSchedule &s, int nqt, int n_btiles, int n_xcd, int 
     if (sb > n_btiles) sb = n_btiles > 0 ? n_btiles : 1;
     s.sq = sq; s.sb = sb;
     const int ngroups = (nqt + sq - 1) / sq;
-    const int nsteps = (n_btiles + sb - 1) / sb;
-    struct Run { int g, j0, j1, r; };
+    // a run = one query group against bank rows [ra, rb) on one XCD; patch column bi takes the bi-th of sb contiguous chunks of it.
+    // Whole-bank runs of a round of XCDs are cut the same way on every XCD: the 8 XCDs read the same bank rows at the same time.
+    struct Run { int g; int ra, rb; int r; };
     std::vector<std::vector<Run>> runs(n_xcd);
     std::vector<int> group_runs(ngroups, 0);
     const int full = ngroups / n_xcd;
     for (int i = 0; i < full; ++i)
         for (int x = 0; x < n_xcd; ++x) {
             const int g = i * n_xcd + x;
-            runs[x].push_back(Run{g, 0, nsteps, group_runs[g]++});
+            runs[x].push_back(Run{g, 0, n_rows, group_runs[g]++});
         }
+    // the groups that do not fill a round of XCDs: their rows (group-major) are dealt out evenly, cut points on multiples of 32 rows
     const int gtail = ngroups - full * n_xcd;
     if (gtail > 0) {
-        const long L = (long)gtail * nsteps;
+        const long long W = (long long)gtail * n_rows;
+        auto cut = [&](int x) {
+            long long c = W * x / n_xcd;
+            const long long g = c / n_rows, r = c % n_rows;
+            long long r32 = (r + 31) / 32 * 32;
+            if (r32 > n_rows) r32 = n_rows;
+            return x >= n_xcd ? W : g * n_rows + r32;
+        };
         for (int x = 0; x < n_xcd; ++x) {
-            long lo = L * x / n_xcd, hi = L * (x + 1) / n_xcd;
+            long long lo = cut(x);
+            const long long hi = cut(x + 1);
             while (lo < hi) {
-                const int g = full * n_xcd + (int)(lo / nsteps);
-                const int j0 = (int)(lo % nsteps);
-                long end = (lo / nsteps + 1) * nsteps;
+                const int g = full * n_xcd + (int)(lo / n_rows);
+                long long end = (lo / n_rows + 1) * n_rows;
                 if (end > hi) end = hi;
-                const int j1 = j0 + (int)(end - lo);
-                runs[x].push_back(Run{g, j0, j1, group_runs[g]++});
+                runs[x].push_back(Run{g, (int)(lo % n_rows), (int)(lo % n_rows + (end - lo)), group_runs[g]++});
                 lo = end;
             }
         }
@@ -392,13 +424,18 @@ void ring_schedule_build(RingSchedule &s, int nqt, int n_btiles, int n_xcd, int 
                 if (qt >= nqt) continue;
                 RingTask t;
                 t.qt = qt;
-                t.t_beg = r.j0 * sb + bi;
-                int cnt = 0;
-                for (int j = r.j0; j < r.j1; ++j) cnt += (j * sb + bi) < n_btiles;
-                t.t_cnt = cnt;
+                {
+                    // the run's rows in sb contiguous chunks of equal length (a multiple of 32), the last one shorter
+                    int c = ((r.rb - r.ra + sb - 1) / sb + 31) / 32 * 32;
+                    int a0 = r.ra + bi * c, a1 = a0 + c;
+                    if (a0 > r.rb) a0 = r.rb;
+                    if (a1 > r.rb) a1 = r.rb;
+                    t.row0 = a0; t.stride_rows = 256; t.row_end = a1;
+                    t.n_tiles = (a1 - a0 + 255) / 256;
+                }
                 t.seg = r.r * sb + bi;
                 t.run = (int)k;                  // the XCD's k-th run: progress of the patch is compared inside a run
-                t.pad[0] = t.pad[1] = t.pad[2] = 0;
+                t.pad = 0;
                 s.tasks.push_back(t);
             }
         }
@@ -436,12 +473,12 @@ int ring_stage1_launch(const RingArgs &a, int variant, int dbg, hipStream_t st) 
 }
 
 /* diagnostics (include/cslam_hip_experimental.h): the static schedule the persistent candidate stage would use -- pure host code,
- * tests/test_abi_cpu.py checks on CPU that every (query tile, bank tile) pair is computed exactly once and the XCDs are balanced. */
-CSLAM_API int cslam_ring_schedule_describe(int nqt, int n_btiles, int n_xcd, int wpx, int32_t info[6], int32_t *tasks, int64_t tasks_cap,
+ * tests/test_abi_cpu.py checks on CPU that every (query tile, bank row) pair is computed exactly once and the XCDs are balanced. */
+CSLAM_API int cslam_ring_schedule_describe(int nqt, int n_rows, int n_xcd, int wpx, int32_t info[6], int32_t *tasks, int64_t tasks_cap,
                                            int32_t *task_off, int32_t *qt_nseg, int32_t *qt_segoff) {
-    ARG_CHECK(nqt >= 1 && n_btiles >= 1 && n_xcd >= 1 && wpx >= 1 && info, "nqt, n_btiles, n_xcd, wpx >= 1 and info are required");
+    ARG_CHECK(nqt >= 1 && n_rows >= 1 && n_xcd >= 1 && wpx >= 1 && info, "nqt, n_rows, n_xcd, wpx >= 1 and info are required");
     RingSchedule s;
-    ring_schedule_build(s, nqt, n_btiles, n_xcd, wpx);
+    ring_schedule_build(s, nqt, n_rows, n_xcd, wpx);
     info[0] = s.sq; info[1] = s.sb; info[2] = (int32_t)s.tasks.size(); info[3] = s.total_lists; info[4] = 0; info[5] = (int32_t)sizeof(RingTask) / 4;
     if (tasks) {
         ARG_CHECK(tasks_cap >= (int64_t)s.tasks.size() * 8, "tasks_cap too small: 8 int32 per task");

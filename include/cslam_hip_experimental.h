@@ -67,11 +67,12 @@ int cslam_trunk_timing_read(double out[8]);
 int cslam_debug_last_candidates(cslam_bank_t *bank, int64_t nq, int *nseg, float *keys, int *rows, double *err_bound);
 
 /* The static schedule of the persistent candidate stage (csrc/sim_topk_ring.hip; the matcher's D.D^T of cslam/nns_matching.py:55-61
- * on 256 x 256 tiles) for `nqt` query tiles x `n_btiles` bank tiles on n_xcd XCDs of wpx workgroups.  Host code only (no GPU needed).
+ * on 256 x 256 tiles) for `nqt` query tiles x `n_rows` bank rows on n_xcd XCDs of wpx workgroups.  Host code only (no GPU needed).
  * info = {Sq, Sb, tasks, lists per query summed over query tiles, 0, int32 words per task (8)};
- * tasks [info[2]][8] = {query tile, first bank tile, bank tiles (stride Sb), list number, run ordinal in its XCD, 0, 0, 0},
- * task_off [n_xcd * wpx + 1] (workgroup w = XCD w / wpx, slot w % wpx), qt_nseg / qt_segoff [nqt].  NULL outputs are skipped. */
-int cslam_ring_schedule_describe(int nqt, int n_btiles, int n_xcd, int wpx, int32_t info[6], int32_t *tasks, int64_t tasks_cap,
+ * tasks [info[2]][8] = {query tile, first bank row, tiles, list number, run ordinal in its XCD, rows between tile starts, end row, 0}
+ * (tile i = rows [first + i * stride, + 256) cut at the end row), task_off [n_xcd * wpx + 1] (workgroup w = XCD w / wpx, slot
+ * w % wpx), qt_nseg / qt_segoff [nqt].  NULL outputs are skipped. */
+int cslam_ring_schedule_describe(int nqt, int n_rows, int n_xcd, int wpx, int32_t info[6], int32_t *tasks, int64_t tasks_cap,
                                  int32_t *task_off, int32_t *qt_nseg, int32_t *qt_segoff);
 
 #ifdef __cplusplus

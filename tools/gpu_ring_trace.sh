@@ -1,2 +1,2 @@
 cd ${GRAFT_REPO_ROOT:-/root/repo}; export CSLAM_HIP_LIB=$PWD/cslam_amd/libcslam_hip_abl.so; tag=${1:-r05_trace}; mkdir -p gpurun_out/$tag
-for v in ${2:-0}; do echo "== variant $v dbg ${CSLAM_MFMA_DBG:-0}"; CSLAM_RING_XCC=1 timeout 300 python tools/pmc_ring_target.py ${3:-100000} $v 1 2>&1 | grep -E "ring|^[0-9]"; done 2>&1 | tee gpurun_out/$tag/trace.log
+for v in ${2:-0}; do echo "== variant $v dbg ${CSLAM_MFMA_DBG:-0} nq ${3:-100000}"; CSLAM_RING_XCC=1 timeout 300 python tools/pmc_ring_target.py ${3:-100000} $v 1 2>&1 | grep -E "ring|^[0-9]"; done 2>&1 | tee -a gpurun_out/$tag/trace.log
