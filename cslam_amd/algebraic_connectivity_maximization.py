@@ -350,6 +350,8 @@ class AlgebraicConnectivityMaximization(object):
                 w_init = self.pseudo_greedy_initialization(nb_candidates_to_choose, trial, candidate_edges)
             except CslamHipError:
                 raise                     # a failing kernel / missing GPU is not a singular Laplacian: never retried away
+            except (ImportError, AttributeError, NameError, TypeError):
+                raise                     # a missing dependency or a programming error is not one either
             except Exception:
                 trial += 1
                 w_init = self.pseudo_greedy_initialization(nb_candidates_to_choose, trial, candidate_edges)

@@ -294,20 +294,34 @@ class RowShardedBankMatcher(object):
         owed = got[:, m, 0].max().reshape(1)                             # some shard still owes a re-scan?
         host = torch.empty((1,), dtype=torch.int64, pin_memory=True) if dev.type == "cuda" else torch.empty((1,), dtype=torch.int64)
         host.copy_(owed, non_blocking=True)
-        ev = None
+        ev = st = None
         if dev.type == "cuda":
+            st = torch.cuda.current_stream(dev)                          # the stream everything above was enqueued on
             ev = torch.cuda.Event()
-            ev.record()
+            ev.record(st)
 
-        def fin():
-            if ev is not None:
-                ev.synchronize()
+        def redo():
             rows, sims, cnt = pend.finish()                              # unlocks the bank; re-scans what it flagged
             if int(host.item()) == 0:
                 return merged
             packed2 = self._pack(rows, sims, cnt).view(G, m, w)
             got2, h3 = self._exchange(packed2.contiguous())
             return self._merge_piece(got2, h3)
+
+        def fin():
+            if ev is None:
+                return redo()
+            ev.synchronize()
+            # The bank's re-scan runs on the stream the search was enqueued on; the second exchange and merge read its lists.
+            # Run them on THAT stream whatever stream the caller finishes on, and order the caller's stream behind them.
+            cur = torch.cuda.current_stream(dev)
+            with torch.cuda.stream(st):
+                out = redo()
+                done = torch.cuda.Event()
+                done.record(st)
+            if cur != st:
+                cur.wait_event(done)
+            return out
         return PendingStep(fin)
 
     def _merge_piece(self, got, handle):

@@ -133,7 +133,9 @@ def test_c5_selection_over_one_million_poses():
     m, w_first, w_last, picked = seen[0]
     assert picked.sum() == K and abs(w_first.sum() - K) < 1e-9 and abs(w_last.sum() - K) < 1e-6
     assert np.count_nonzero(w_last > 1e-10) > K, "the Frank-Wolfe loop did not move off its start point"
-    for tag, w in (("first", w_first), ("last", w_last)):
+    # the oracle (the reference's TraceMIN + LU restatement, ~60 s per solve at 10^6 poses) checks the LAST iterate -- the one the
+    # selection is rounded from, with the most weighted candidates; every iterate at 8 x 13 000 is checked in tests/test_c5_gpu.py
+    for tag, w in (("last", w_last),):
         L = m.combined_laplacian(w)
         t0 = time.perf_counter()
         f_hip, v_hip = fiedler_tracemin_hip(L)

@@ -309,3 +309,52 @@ def test_c_abi_start_block_is_numpy_randomstate_normal_bit_for_bit():
         assert lib.cslam_fiedler_start_block(seed, n, x.ctypes.data_as(C.c_void_p)) == 0
         assert np.array_equal(x, np.random.RandomState(seed).normal(size=(4, n)).T)
     assert lib.cslam_fiedler_start_block(7, 0, None) == -1
+
+
+def test_tracemin_lu_without_networkx_falls_back_to_the_chain_solver_and_says_so(monkeypatch):
+    """A host whose networkx is missing, or has moved the private `_get_fiedler_func`, must not end in run_mac_solver's silent
+    retry-then-pseudo-greedy path: the product's 'tracemin_lu' then runs the same TraceMIN on chain_solver.py's inner solves
+    (numpy / scipy only) and warns once; the pair equals the one networkx returns."""
+    import warnings
+    import scipy.sparse as sp
+    from networkx.linalg import algebraicconnectivity as nxac
+    from cslam_amd.mac import fiedler as fmod
+    rng = np.random.default_rng(5)
+    n = 60
+    rows = list(range(n - 1)) + list(rng.integers(0, n, size=25))
+    cols = list(range(1, n)) + list(rng.integers(0, n, size=25))
+    w = rng.uniform(0.2, 1.0, size=len(rows))
+    A = sp.coo_matrix((w, (rows, cols)), shape=(n, n)).tocsr()
+    A = A + A.T
+    A.setdiag(0)
+    L = sp.csr_matrix(sp.diags(np.asarray(A.sum(axis=1)).ravel()) - A)
+    lam_nx, v_nx = fmod.fiedler_tracemin_lu(L)
+
+    def gone(name):
+        raise AttributeError("module has no attribute '_get_fiedler_func'")
+    monkeypatch.setattr(nxac, "_get_fiedler_func", gone)
+    monkeypatch.setattr(fmod, "_warned", [])
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        lam, v = fmod.fiedler_tracemin_lu(L)
+        lam2, _ = fmod.fiedler_tracemin_lu(L)
+    assert sum("chain-reduced TraceMIN" in str(r.message) for r in rec) == 1
+    assert abs(lam - lam_nx) <= 1e-9 * abs(lam_nx) and lam2 == lam
+    assert min(np.abs(v - v_nx).max(), np.abs(v + v_nx).max()) <= 1e-6
+
+
+def test_run_mac_solver_does_not_retry_away_a_missing_dependency(monkeypatch):
+    """ImportError / AttributeError out of the solver are programming or packaging errors, not "the Laplacian of this start point
+    is singular": they are re-raised, not converted into K retries and the pseudo-greedy selection."""
+    from cslam_amd.algebraic_connectivity_maximization import AlgebraicConnectivityMaximization, EdgeInterRobot
+    from cslam_amd.mac import mac as mac_mod
+    ac = AlgebraicConnectivityMaximization(robot_id=0, max_nb_robots=2)
+    fixed = [EdgeInterRobot(0, 3, 1, 3, 1.0)]
+    cand = [EdgeInterRobot(0, i, 1, (i * 3) % 7, 0.5 + 0.05 * i) for i in range(6)]
+    ac.set_graph(fixed, cand)
+
+    def broken(self, *a, **k):
+        raise ImportError("No module named 'networkx'")
+    monkeypatch.setattr(mac_mod.MAC, "fw_subset", broken)
+    with pytest.raises(ImportError):
+        ac.select_candidates(2, {0: True, 1: True})

@@ -71,6 +71,27 @@ def _rccl_worker(rank, world, port, outdir):
     torch.cuda.synchronize()
     out.update(intra_rows=intra[0].cpu().numpy(), intra_sims=intra[1].cpu().numpy(), inter_rows=inter[0].cpu().numpy(),
                inter_sims=inter[1].cpu().numpy(), inter_robot=inter[3].cpu().numpy())
+    # (iii) the two-half step over RCCL with a CLUSTERED shard: near-duplicates inside the fp16 candidate stage's re-scoring window
+    # leave queries uncertified, so finish() takes its second exchange + merge with the re-scanned lists -- and it is called on a
+    # DIFFERENT stream than step_begin() (the lists must be ordered behind the re-scan whatever stream the caller finishes on)
+    base = unit_rows(np.random.default_rng(4242), 40, DIM)
+    rng = np.random.default_rng(31 + rank)
+    clustered = np.repeat(base, (cuts[rank + 1] - cuts[rank] + 39) // 40, axis=0)[:cuts[rank + 1] - cuts[rank]]
+    clustered = clustered + 2e-4 * rng.standard_normal(clustered.shape).astype(np.float32)
+    clustered /= np.linalg.norm(clustered, axis=1, keepdims=True)
+    ncl = nnm.NearestNeighborsMatching(device=rank)
+    ncl.add_items(clustered.astype(np.float32), range(clustered.shape[0]))
+    qcl = torch.from_numpy(np.tile(base, (M // 40 + 1, 1))[:M].astype(np.float32)).to(dev)
+    mc = RowShardedBankMatcher(rank, world, lambda q, k: ncl.search_device(q, k, mode=nnm.MODE_MFMA), cuts, k=K, chunks=1,
+                               search_async_fn=lambda q, k: ncl.search_device_async(q, k, mode=nnm.MODE_MFMA))
+    pend = mc.step_begin(qcl)
+    other = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(other):
+        rows, sims, cnt = pend.finish()
+        rows_h, sims_h, cnt_h = rows.cpu(), sims.cpu(), cnt.cpu()            # reads on the caller's stream
+    torch.cuda.synchronize()
+    out.update(cl_rows=rows_h.numpy(), cl_sims=sims_h.numpy(), cl_cnt=cnt_h.numpy(), cl_uncertified=np.array([ncl.last_stats()[0]]))
+    np.savez(os.path.join(outdir, "cl_bank%d.npz" % rank), bank=clustered.astype(np.float32))
     np.savez(os.path.join(outdir, "g%d.npz" % rank), **out)
     dist.barrier()
     dist.destroy_process_group()
@@ -96,6 +117,17 @@ def test_rccl_sharded_matchers_equal_the_oracle_on_the_unsharded_bank(tmp_path, 
         i, s, _ = pyoracle.nns_search(own, np.concatenate([qs[o] for o in others]), 1)
         assert np.array_equal(got["inter_rows"], i) and np.max(np.abs(got["inter_sims"] - s)) <= 1e-12
         assert np.array_equal(got["inter_robot"], np.repeat(others, M))
+    # the clustered shards: every rank's result equals the oracle on the concatenated clustered bank, and the redo path ran
+    whole_cl = np.concatenate([np.load(tmp_path / ("cl_bank%d.npz" % r))["bank"] for r in range(world)])
+    base = unit_rows(np.random.default_rng(4242), 40, DIM)
+    qcl = np.tile(base, (M // 40 + 1, 1))[:M].astype(np.float32)
+    oi, os_, oc = pyoracle.nns_search(whole_cl, qcl, K)
+    redo = 0
+    for r in range(world):
+        got = np.load(tmp_path / ("g%d.npz" % r))
+        assert_topk_equal(got["cl_rows"], got["cl_sims"], got["cl_cnt"], oi, os_, oc, 1e-12)
+        redo += int(got["cl_uncertified"][0])
+    assert redo > 0, "the clustered bank left no query uncertified: the second exchange was not exercised"
 
 
 def _cabi_worker(rank, world, outdir):
