@@ -325,12 +325,12 @@ __global__ __launch_bounds__(256, 1) void wino_gemm_h2_big_kernel(WinoGemmArgs p
 
     const int pitch = p.nk * WG_ROWB;
     // chunk pch = i * 256 + tid -> row pch >> 3, physical slot pch & 7 holding logical chunk slot ^ swz(row); both operands alike
-    int voff[NLA];
-#pragma unroll
-    for (int i = 0; i < NLA; ++i) {
-        const int pch = i * 256 + tid, r = pch >> 3, slot = pch & 7;
-        voff[i] = r * pitch + ((slot ^ ((r >> 1) & 7)) << 4);
-    }
+    // Part i of a stage is 32 rows below part 0 (the swizzle term repeats every 16 rows): ONE per-lane offset.  The V2 operand's
+    // row step is added per request (the buffer's range check, which drops the rows beyond T, sees voffset only); the U2 operand's
+    // tile is always whole, its row step rides in the scalar offset.  (Eight per-lane offsets held across the K loop were what
+    // pushed this 256 + 256 register kernel to an 8-byte spill.)
+    int voff0;
+    const int step32 = 32 * pitch;
     const int wave_chunk = wave * 1024;
 
     struct Item { int xi, mt, nt; };
@@ -351,18 +351,29 @@ __global__ __launch_bounds__(256, 1) void wino_gemm_h2_big_kernel(WinoGemmArgs p
         rsB = wg_rsrc(p.U2 + ((int64_t)c.xi * p.Cout + (int64_t)c.nt * TN) * pitch, (int64_t)TN * pitch);
     };
     auto load_part = [&](int stage, int kt, int i) {          // parts 0..7: A, 8..15: B
-        if (i < NLA) wg_blds16(rsA, voff[i], kt * WG_ROWB, smem + stage * STAGE + i * (256 * 16) + wave_chunk);
-        else wg_blds16(rsB, voff[i - NLA], kt * WG_ROWB, smem + stage * STAGE + OPA + (i - NLA) * (256 * 16) + wave_chunk);
+        if (i < NLA) wg_blds16(rsA, voff0 + i * step32, kt * WG_ROWB, smem + stage * STAGE + i * (256 * 16) + wave_chunk);
+        else wg_blds16(rsB, voff0, kt * WG_ROWB + (i - NLA) * step32, smem + stage * STAGE + OPA + (i - NLA) * (256 * 16) + wave_chunk);
     };
 
-    const int swz = (lane >> 1) & 7;
+    // The per-lane address constants of the K loop (request offset, fragment offsets) are re-derived at the top of every item from
+    // a thread id the compiler cannot see through: hoisted out of the item loop they stay live across the item's 256-store
+    // epilogue, where the accumulators pass through the arch VGPRs, and one of them was spilled (8 bytes of scratch, round 4).
     int foff[2][2];                                    // [s][lo]
+    int arow0, brow0;
+    auto lane_constants = [&]() {
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        const int ln = t & 63, hh = ln >> 5, l31_ = ln & 31, swz = (ln >> 1) & 7;
+        const int r = t >> 3, slot = t & 7;
+        voff0 = r * pitch + ((slot ^ ((r >> 1) & 7)) << 4);
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int lo = 0; lo < 2; ++lo) foff[s][lo] = ((4 * lo + 2 * s + h) ^ swz) << 4;
-    const int arow0 = (wm * 128 + l31) * WG_ROWB;
-    const int brow0 = (wn * 128 + l31) * WG_ROWB;
+            for (int lo = 0; lo < 2; ++lo) foff[s][lo] = ((4 * lo + 2 * s + hh) ^ swz) << 4;
+        arow0 = (wm * 128 + l31_) * WG_ROWB;
+        brow0 = (wn * 128 + l31_) * WG_ROWB;
+    };
+    lane_constants();
 
     f32x16 acc[MT][NT];
     f16x8 fa[2][2][MT], fb[2][2][NT];                         // [register set][hi | lo][tile]
@@ -446,6 +457,7 @@ __global__ __launch_bounds__(256, 1) void wino_gemm_h2_big_kernel(WinoGemmArgs p
         cur ^= 1;
     };
     for (int k_item = 0; k_item < n_mine; ++k_item) {
+        if (k_item > 0) lane_constants();
         const Item c = decode(k_item);
         const bool more = k_item + 1 < n_mine;
         const int kt_after = more ? 0 : p.nk - 1;                    // what an item's last stage requests
