@@ -198,6 +198,7 @@ def parse():
     ap.add_argument("--cpu-queries", type=int, default=48, help="cpu_baseline sample size of the match leg (queries)")
     ap.add_argument("--cpu-frames", type=int, default=8, help="cpu_baseline sample size of the extract leg (frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-c2", action="store_true", help="skip the bounded CosPlace ResNet-18 leg (`c2_cosplace` in the line)")
     ap.add_argument("--no-extract", action="store_true", help="debug: time the match leg only")
     ap.add_argument("--shard-mode", default="rows", choices=["rows", "robots"],
                     help="N > 1 only.  rows (default): the ONE --bank-rows bank of the metric is split by rows over "
@@ -810,6 +811,65 @@ def main():
                                          f"cores); float32 scores, so not bit-compatible with the reference",
                                "top5_rows_equal_to_gpu_frac": round(agree, 4)}
 
+    # ---- BASELINE config 2, the reference's DEFAULT extractor (global_descriptor_loop_closure_detection.py:56-60): CosPlace
+    # ResNet-18 512-D on 640x480 keyframes (centre crop 376, bicubic resize to 224) + causal top-5 over the growing bank.
+    # A bounded leg beside the headline (which stays C3): chunks of 1000 frames, the bank grows chunk by chunk.  The trunk's
+    # 3x3 / stride-1 layers run through this library's Winograd transforms with fp32 library products, the 7x7 stem, the
+    # strided 3x3 and the 1x1 layers through torch (MIOpen / CK): every product on the f32-input matrix pipe, hence that roof.
+    c2 = None
+    if rank == 0 and world == 1 and extractor is not None and not a.no_c2:
+        from cslam_amd.vpr.cosplace import CosPlace
+        del bank
+        torch.cuda.empty_cache()
+        cp = CosPlace({"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376,
+                       "frontend.cosplace.descriptor_dim": 512, "frontend.cosplace.backbone": "resnet18",
+                       "frontend.backbone_conv": "winograd"}, None)
+        ch = min(1000, frames.shape[0])
+        nchunks = 3
+        cp.compute_embeddings_device(frames[:ch])
+        torch.cuda.synchronize()                                  # warm-up (MIOpen find, Winograd weights)
+        nn2 = nnm.NearestNeighborsMatching()
+        te2 = tm2 = 0.0
+        done2 = 0
+        for _ in range(nchunks):
+            t0 = time.perf_counter()
+            d2 = cp.compute_embeddings_device(frames[:ch])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            nn2.add_items_device(d2)
+            lim2 = torch.arange(done2, done2 + ch, device=dev, dtype=torch.int64)   # keyframe i sees rows < i
+            r2 = nn2.search_device(d2, a.k, row_limit=lim2, mode=nnm.MODE_AUTO)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            te2 += t1 - t0
+            tm2 += t2 - t1
+            done2 += ch
+        GF = 3.64                                                 # ResNet-18 trunk at 224 x 224: 1.82 G multiply-adds per frame
+        fps = done2 / te2
+        c2 = {"workload": "C2: CosPlace ResNet-18 512-D extract + causal top-%d, %d synthetic 640x480 keyframes in chunks of %d" % (a.k, done2, ch),
+              "value": round(done2 / (te2 + tm2), 1), "unit": "keyframes/sec", "extract_only": round(fps, 1),
+              "match_only": round(done2 / tm2, 1), "dtype": "f32",
+              "roofline": {"bound": "mfma", "kernel": "trunk products on the f32-input matrix pipe (rocBLAS sgemm for the Winograd layers, "
+                                                        "MIOpen / CK for the 7x7 stem, the strided 3x3 and the 1x1 layers)",
+                           "achieved": round(fps * GF / 1e3, 1), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (direct-convolution flop, f32 inputs)",
+                           "frac": round(fps * GF / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                           "note": "whole-trunk rate from wall time: the trunk is library kernels, no single hand-written kernel dominates"}}
+        if not a.no_cpu_baseline:
+            ncf = max(1, min(a.cpu_frames, 8))
+            xcpu = torch.randn((ncf, 3, 224, 224))
+            bb = cp.model.backbone.float().cpu()
+            with torch.no_grad():
+                bb(xcpu[:1])
+                t0 = time.perf_counter()
+                for i in range(ncf):
+                    bb(xcpu[i:i + 1])
+                tcpu = (time.perf_counter() - t0) / ncf
+            cp.model.backbone.to(dev)
+            c2["cpu_baseline"] = {"value": round(1.0 / tcpu, 2), "unit": "keyframes/sec", "cores": torch.get_num_threads(), "kind": "port",
+                                  "sample": "%d frames, one at a time like the reference (cosplace.py:81-101): the same ResNet-18 trunk on torch CPU, "
+                                            "224 x 224 input; transform, GeM + FC and the scan not included (they are < 2 %% of it)" % ncf}
+        del cp, nn2
+
     if rank == 0:
         line = {
             "metric": "keyframes/sec (extract+match) on 100kx4096-D bank",
@@ -851,6 +911,7 @@ def main():
             "roofline_step_largest": roofline_step_largest,
             "roofline_extract": extract_roofline,
             "cpu_baseline": cpu,
+            "c2_cosplace": c2,
             "board": board,
         }
         print(json.dumps(line))

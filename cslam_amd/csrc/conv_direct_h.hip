@@ -608,7 +608,9 @@ CSLAM_API int cslam_conv3x3_direct_h_dev(const float *d_x, const void *d_w2, con
     a.relu = relu; a.pool = pool; a.amax_in = d_amax; a.inv_sw = inv_sw; a.amax_out = d_amax_out;
     // a quarter of a block's time per phase (~ 1.5k matrix-pipe cycles per stage + epilogue), only when every workgroup has several blocks
     a.stagger_cycles = nblk >= 4 * (int64_t)n_cu ? (a.nslab * 9 * 2000 + 6000) / 4 : 0;
-    if (const char *se = getenv("CSLAM_CD_STAGGER")) a.stagger_cycles = atoi(se);
+#ifdef CSLAM_ABLATIONS
+    if (const char *se = getenv("CSLAM_CD_STAGGER")) a.stagger_cycles = atoi(se);      // measurement build only
+#endif
     const int grid = (int)(nblk < n_cu ? nblk : n_cu);
     hipStream_t st = (hipStream_t)stream;
 #define CD_LAUNCH(R, P) do { \

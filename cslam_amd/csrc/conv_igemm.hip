@@ -1,0 +1,317 @@
+// conv_igemm.hip -- strided / 1x1 / 7x7 convolutions of the ResNet trunks as ONE implicit-GEMM kernel on exact fp16 pairs (gfx950).
+//
+// Replaces, for CosPlace's default backbone (cslam/vpr/cosplace_utils/network.py:38-68: torchvision ResNet-18 without avgpool / fc;
+// the reference's DEFAULT extractor, global_descriptor_loop_closure_detection.py:56-60), the convolutions the Winograd pipeline of
+// vpr/winograd.py cannot take -- the 7x7 / stride-2 stem, the 3x3 / stride-2 first convolution and the 1x1 / stride-2 shortcut of
+// layer2..4 -- which went through torch (MIOpen / CK, f32-input matrix pipe): 13 % of the trunk's multiply-adds, 60 % of its kernel time
+// (profiles/r05_v20_c2_kernel_split.log).  BatchNorm is folded into weight and bias on the host (vpr/winograd.py::fold_bn).
+//
+//     y[b, ho, wo, co] = act( sum_{kh, kw, ci} x[b, ho s - p + kh, wo s - p + kw, ci] w[co, ci, kh, kw] + bias[co] (+ res[b, ho, wo, co]) )
+//
+// as a GEMM  Y [P = B Ho Wo pixels, Cout] = A [P, K] W^T [K, Cout],  K = KH KW Cin walked in blocks of 32 channels of one tap
+// (kh, kw); the A block of a tap is never materialised: every K stage gathers it from the NHWC activation (one 128-byte run per
+// pixel; pixels of the zero padding read as zero).
+// Arithmetic: the pair scheme of csrc/wino_gemm.hip.  x times a power of two s (from the 4-byte max |x| slot the producing layer
+// left, like every pair kernel of the trunk) splits exactly into fp16 hi + lo; the weights are split offline
+// (vpr/winograd.py::igemm_pair_weights); acc += xh wh; acc += xl wh; acc += xh wl on v_mfma_f32_32x32x16_f16 with fp32 accumulation
+// (the dropped xl wl is 2^-22 of the product): an fp32-grade convolution at a third of the fp16 matrix rate.
+// The activation tile is split while it is staged: global_load_dwordx4 -> 4 products with s, 2 packed conversions, 4 v_fma_mix
+// differences, 2 packed conversions per 16 bytes -> ds_write_b128 into the [hi 32 | lo 32] row image of the pair GEMM (128 bytes per
+// pixel and K block, 16-byte chunks XOR-swizzled by the row, fragment reads conflict-free); the weight tile comes by LDS-DMA from
+// rows laid out the same way.  Double-buffered stages: the loads of stage k + 1 are issued in front of stage k's MFMAs, converted
+// and written behind them.
+// Workgroup = 128 pixels x TN = 128 | 64 output channels, four waves as 2 x 2 (wave tile 64 x TN / 2), two or three per CU.
+// STEM: the 3-channel 7x7 layer.  A tap's channels are 12 bytes, so a K block is a whole kernel ROW: the 21 values (kw, c) of row kh
+// are consecutive floats of the NHWC image; 7 blocks of 32 slots (21 used, the weights of the others zero).  (K packed densely over
+// (kh, kw, c) -- 147 values in 5 blocks, the tap decoded per element -- measured slower: 3.25 against 2.70 ms per 1000 frames.)
+#include "common.h"
+#include <hip/hip_fp16.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float cf4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned cu4 __attribute__((ext_vector_type(4)));
+
+#define CI_ROWB 128
+#define CI_TM 128
+
+struct ConvIgemmArgs {
+    const float *x; const char *w2; const float *bias; const float *res; float *y;
+    int B, H, W, Cin, Cout, KH, KW, stride, pad, Ho, Wo;
+    int P;                 // output pixels B Ho Wo
+    int nk;                // K blocks: KH KW Cin / 32 (STEM: KH)
+    int ncb;               // Cin / 32
+    int relu;
+    const unsigned *amax_in; float inv_sw; unsigned *amax_out;
+};
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ci_rsrc(const char *base, int64_t bytes) {
+    const uint64_t a = (uint64_t)base;
+    const uint64_t u = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a);
+    const int n = __builtin_amdgcn_readfirstlane((int)(bytes > 0x7fffffff ? 0x7fffffff : bytes));
+    return __builtin_amdgcn_make_buffer_rsrc((void *)u, 0, n, 0x00020000);
+}
+// (a __device__ function, not the builtin inside the kernel's lambda: with the LDS-DMA builtin called from a lambda hipcc 7.2's HOST
+// pass emits no launch stub for the kernel and says nothing -- the library then fails to load with an undefined symbol)
+__device__ __forceinline__ void ci_blds16(__amdgpu_buffer_rsrc_t rs, int voff, int soff, char *lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voff, soff, 0, 0);
+}
+// the power of two that brings max |x| into [2^13, 2^14): the hi halves keep 11 bits, the lo halves stay normal fp16 numbers for
+// every value within 2^-10 of the maximum (smaller ones lose nothing that matters: their absolute error is 2^-25 of the scaled maximum)
+__device__ __forceinline__ float ci_scale(unsigned amax_bits) {
+    const float a = fminf(fmaxf(__uint_as_float(amax_bits), 1e-30f), 1e30f);
+    int e;
+    (void)frexpf(a, &e);
+    return ldexpf(1.0f, 14 - e);
+}
+template <int HI>
+__host__ __device__ __forceinline__ float ci_sub_half(float v, __half2 h) {       // v - (float)half HI of h: one v_fma_mix_f32
+#if defined(__HIP_DEVICE_COMPILE__)
+    float d;
+    const unsigned hb = *(const unsigned *)&h;
+    if (HI) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hb), "v"(v));
+    else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(hb), "v"(v));
+    return d;
+#else
+    return v - (HI ? __high2float(h) : __low2float(h));
+#endif
+}
+
+template <int TN, bool STEM>
+__global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) {
+    constexpr int MT = 2, NT = TN / 64;                // wave tile 64 x TN / 2 in 32 x 32 MFMA tiles
+    constexpr int OPA = CI_TM * CI_ROWB, OPB = TN * CI_ROWB;
+    constexpr int STAGE = OPA + OPB;
+    constexpr int NLB = TN * 8 / 256;                  // 16-byte weight chunks per thread and stage
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int h = lane >> 5, l31 = lane & 31;
+    const int mt = blockIdx.x, nt = blockIdx.y;
+
+    // ---- this thread's share of the activation tile: pixel row tid >> 1, channels 16 (tid & 1) .. + 15 of every K block
+    const int ar = tid >> 1, hf = tid & 1;
+    const int pix = mt * CI_TM + ar;
+    const bool pvalid = pix < p.P;
+    int b_, hi0, wi0;
+    {
+        const int pp = pvalid ? pix : 0;
+        const int hw = p.Ho * p.Wo;
+        b_ = pp / hw;
+        const int rem = pp - b_ * hw;
+        const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        hi0 = ho * p.stride - p.pad;
+        wi0 = wo * p.stride - p.pad;
+    }
+    const float sc = ci_scale(*p.amax_in);
+    const int a_chunk0 = (hf * 2) ^ ((ar >> 1) & 7), a_chunk1 = (hf * 2 + 1) ^ ((ar >> 1) & 7);
+    const int a_chunk2 = (4 + hf * 2) ^ ((ar >> 1) & 7), a_chunk3 = (5 + hf * 2) ^ ((ar >> 1) & 7);
+
+    cf4 areg[4];
+    // K block (kh, kw, cb) of the general form / kernel row kh of the stem -> registers (zeros outside the image)
+    auto a_load = [&](int kh, int kw, int cb) {
+        if (!STEM) {
+            const int hi = hi0 + kh;
+            const int wi = wi0 + kw;
+            const bool in = pvalid && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+            const cf4 *src = (const cf4 *)(p.x + (((int64_t)b_ * p.H + (in ? hi : 0)) * p.W + (in ? wi : 0)) * p.Cin + cb * 32 + hf * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const cf4 v = src[q];
+                areg[q] = in ? v : (cf4)(0.0f);
+            }
+        } else {
+            // stem: K block = kernel row kh; slot j = kw * 3 + c of it is float wi0 * 3 + j of image row hi0 + kh
+            const int hi = hi0 + kh;
+            const bool rowin = pvalid && hi >= 0 && hi < p.H;
+            const float *src = p.x + (((int64_t)b_ * p.H + (rowin ? hi : 0)) * p.W) * 3;
+            const int nslot = p.KW * 3;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int slot = hf * 16 + q * 4 + e;
+                    const int wi = wi0 + slot / 3;
+                    const bool in = rowin && slot < nslot && wi >= 0 && wi < p.W;
+                    v[e] = in ? src[wi0 * 3 + slot] : 0.0f;
+                }
+                areg[q] = (cf4){v[0], v[1], v[2], v[3]};
+            }
+        }
+    };
+    // split the registers into pairs and write them into stage `st`'s row image
+    auto a_store = [&](int st) {
+        char *row = smem + st * STAGE + ar * CI_ROWB;
+        unsigned hh[8], ll[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const cf4 v = areg[q] * sc;
+            const __half2 h0 = __floats2half2_rn(v.x, v.y), h1 = __floats2half2_rn(v.z, v.w);
+            const __half2 l0 = __floats2half2_rn(ci_sub_half<0>(v.x, h0), ci_sub_half<1>(v.y, h0));
+            const __half2 l1 = __floats2half2_rn(ci_sub_half<0>(v.z, h1), ci_sub_half<1>(v.w, h1));
+            hh[2 * q] = *(const unsigned *)&h0; hh[2 * q + 1] = *(const unsigned *)&h1;
+            ll[2 * q] = *(const unsigned *)&l0; ll[2 * q + 1] = *(const unsigned *)&l1;
+        }
+        *(cu4 *)(row + (a_chunk0 << 4)) = (cu4){hh[0], hh[1], hh[2], hh[3]};
+        *(cu4 *)(row + (a_chunk1 << 4)) = (cu4){hh[4], hh[5], hh[6], hh[7]};
+        *(cu4 *)(row + (a_chunk2 << 4)) = (cu4){ll[0], ll[1], ll[2], ll[3]};
+        *(cu4 *)(row + (a_chunk3 << 4)) = (cu4){ll[4], ll[5], ll[6], ll[7]};
+    };
+
+    // ---- weight tile by LDS-DMA: chunk pch = i * 256 + tid -> row pch >> 3, physical slot pch & 7 = logical chunk slot ^ swz(row)
+    const int pitchw = p.nk * CI_ROWB;
+    const __amdgpu_buffer_rsrc_t rsB = ci_rsrc(p.w2 + (int64_t)nt * TN * pitchw, (int64_t)TN * pitchw);
+    int voffB[NLB];
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) {
+        const int pch = i * 256 + tid, r = pch >> 3, slot = pch & 7;
+        voffB[i] = r * pitchw + ((slot ^ ((r >> 1) & 7)) << 4);
+    }
+    auto b_load = [&](int st, int k) {
+#pragma unroll
+        for (int i = 0; i < NLB; ++i)
+            ci_blds16(rsB, voffB[i], k * CI_ROWB, smem + st * STAGE + OPA + i * (256 * 16) + wave * 1024);
+    };
+
+    // ---- fragments: row * 128 + (chunk ^ swz) * 16, chunk = 4 lo + 2 s + h for the 16-channel K step s
+    const int swz = (lane >> 1) & 7;
+    int foff[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int lo = 0; lo < 2; ++lo) foff[s][lo] = ((4 * lo + 2 * s + h) ^ swz) << 4;
+    const int arow0 = (wm * 64 + l31) * CI_ROWB;
+    const int brow0 = (wn * (TN / 2) + l31) * CI_ROWB;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    // one K block: two 16-channel steps of three products per tile
+    auto multiply = [&](const char *sA) {
+        const char *sB = sA + OPA;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            f16x8 fa[2][MT], fb[2][NT];
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                fa[0][m] = *(const f16x8 *)(sA + arow0 + m * 32 * CI_ROWB + foff[s][0]);
+                fa[1][m] = *(const f16x8 *)(sA + arow0 + m * 32 * CI_ROWB + foff[s][1]);
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                fb[0][n] = *(const f16x8 *)(sB + brow0 + n * 32 * CI_ROWB + foff[s][0]);
+                fb[1][n] = *(const f16x8 *)(sB + brow0 + n * 32 * CI_ROWB + foff[s][1]);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][m], fb[0][n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[1][m], fb[0][n], acc[m][n], 0, 0, 0);
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[0][m], fb[1][n], acc[m][n], 0, 0, 0);
+                }
+        }
+    };
+    int kh = 0, kw = 0, cb = 0;                        // the K block the loader is at
+    auto advance = [&]() {
+        if (STEM) { ++kh; return; }
+        if (++cb == p.ncb) { cb = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+    };
+    a_load(kh, kw, cb);
+    b_load(0, 0);
+    a_store(0);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    for (int k = 0; k < p.nk; ++k) {
+        const int cur = k & 1;
+        const bool more = k + 1 < p.nk;
+        if (more) {
+            advance();
+            a_load(kh, kw, cb);
+            b_load(cur ^ 1, k + 1);
+        }
+        multiply(smem + cur * STAGE);
+        if (more) a_store(cur ^ 1);
+        __builtin_amdgcn_s_waitcnt(0);                 // my weight requests have landed, my LDS traffic is done
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane = output channel (128-byte runs per pixel), 16 pixels per accumulator tile
+    const float inv = p.inv_sw / sc;
+    float amax = 0.0f;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int co = nt * TN + wn * (TN / 2) + n * 32 + l31;
+        const float bv = p.bias ? p.bias[co] : 0.0f;
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int64_t pp = (int64_t)mt * CI_TM + row;
+                if (pp < p.P) {
+                    float v = acc[m][n][r] * inv + bv;
+                    if (p.res) v += p.res[pp * p.Cout + co];
+                    if (p.relu) v = fmaxf(v, 0.0f);
+                    p.y[pp * p.Cout + co] = v;
+                    amax = fmaxf(amax, fabsf(v));
+                }
+            }
+    }
+    if (p.amax_out) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+        if (lane == 0 && __float_as_uint(amax) > *(volatile unsigned *)p.amax_out) atomicMax(p.amax_out, __float_as_uint(amax));
+    }
+}
+
+/* y = act(conv(x, w) + bias (+ res)) for x [B,H,W,Cin] NHWC float32 -> y [B,Ho,Wo,Cout] NHWC float32, Ho = (H + 2 pad - KH) / stride + 1.
+ * d_w2: the weights as fp16 pairs, `igemm_pair_weights(weight)` of cslam_amd/vpr/winograd.py: rows = output channels, every K block of
+ * 32 = [hi 32 | lo 32]; general form (Cin a multiple of 32) K blocks in (kh, kw, Cin / 32) order; stem form (Cin = 3, 3 KW <= 32) one
+ * block per kernel row, slot kw * 3 + c.  inv_sw = 1 / (the power of two the weights were scaled by).  d_amax_in: 4-byte device slot,
+ * float bits of (a bound of) max |x|, > 0; d_amax_out (optional): slot that receives max |y| (atomic maximum: zero it first).
+ * Replaces torch.nn.functional.conv2d for the layers named at the top of this file (cslam/vpr/cosplace_utils/network.py:38-68). */
+CSLAM_API int cslam_conv_igemm_h2_dev(const float *d_x, const void *d_w2, const float *d_bias, const float *d_res, int B, int H, int W,
+                                      int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, const unsigned *d_amax_in,
+                                      float inv_sw, unsigned *d_amax_out, float *d_y, void *stream) {
+    PTR_DEVICE(d_x);
+    ARG_CHECK(d_x && d_w2 && d_y && d_amax_in, "NULL argument");
+    ARG_CHECK(B >= 1 && H >= 1 && W >= 1 && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0, "bad geometry");
+    const bool stem = Cin == 3;
+    ARG_CHECK(stem ? (3 * KW <= 32) : (Cin % 32 == 0 && Cin >= 32), "Cin must be a multiple of 32, or 3 with a kernel row of at most 10 taps");
+    ARG_CHECK(Cout % 64 == 0 && Cout >= 64, "Cout must be a multiple of 64");
+    ARG_CHECK(H + 2 * pad >= KH && W + 2 * pad >= KW, "kernel larger than the padded map");
+    ConvIgemmArgs a;
+    a.x = d_x; a.w2 = (const char *)d_w2; a.bias = d_bias; a.res = d_res; a.y = d_y;
+    a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+    a.Ho = (H + 2 * pad - KH) / stride + 1; a.Wo = (W + 2 * pad - KW) / stride + 1;
+    const int64_t P = (int64_t)B * a.Ho * a.Wo;
+    ARG_CHECK(P < (1ll << 31) && P * Cout < (1ll << 40), "too many output pixels for one launch");
+    a.P = (int)P;
+    a.ncb = stem ? 0 : Cin / 32;
+    a.nk = stem ? KH : KH * KW * (Cin / 32);
+    a.relu = relu; a.amax_in = d_amax_in; a.inv_sw = inv_sw; a.amax_out = d_amax_out;
+    const int tn = Cout % 128 == 0 ? 128 : 64;
+    const dim3 grid((unsigned)ceil_div64(P, CI_TM), (unsigned)(Cout / tn)), blk(256);
+    const int lds = 2 * (CI_TM + tn) * CI_ROWB;
+    hipStream_t st = (hipStream_t)stream;
+#define CI_LAUNCH(TN_, ST_) do { \
+        static DeviceOnce once; int once_dev; \
+        if (once.todo(&once_dev)) { \
+            HIP_TRY(hipFuncSetAttribute((const void *)conv_igemm_h2_kernel<TN_, ST_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+            once.done(once_dev); } \
+        hipLaunchKernelGGL((conv_igemm_h2_kernel<TN_, ST_>), grid, blk, lds, st, a); } while (0)
+    if (stem) { if (tn == 128) CI_LAUNCH(128, true); else CI_LAUNCH(64, true); }
+    else { if (tn == 128) CI_LAUNCH(128, false); else CI_LAUNCH(64, false); }
+#undef CI_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}

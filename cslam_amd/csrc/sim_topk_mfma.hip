@@ -656,12 +656,6 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
         if (bseg < 1) bseg = 1;
         int aq = (int)ceil_div64(per_xcd, bseg);
         if (aq < 1) aq = 1;
-#ifdef CSLAM_ABLATIONS
-        if (const char *pe = getenv("CSLAM_MFMA_PATCH")) {       // measurement build: "aq,bseg" = query tiles x segments per XCD patch
-            int a_ = 0, b_ = 0;                                  // (1 x 32 ... 32 x 1 move the stage by <= 3 %: profiles/r04_v2_h1_patch_shapes.log)
-            if (sscanf(pe, "%d,%d", &a_, &b_) == 2 && a_ >= 1 && b_ >= 1) { aq = a_; bseg = b_ > nseg ? nseg : b_; }
-        }
-#endif
         if (b->item_map_host.size() != (size_t)nqt * nseg || b->item_map_key[0] != nqt || b->item_map_key[1] != nseg ||
             b->item_map_key[2] != aq || b->item_map_key[3] != bseg) {
             b->item_map_host.clear();

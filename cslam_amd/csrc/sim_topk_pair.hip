@@ -459,13 +459,6 @@ static int launch_pair(const PairArgs &a, int dbg, hipStream_t st) {
 int pair_stage1_launch(const PairArgs &a, int tile, int nprod, int dbg, hipStream_t st) {
     if (nprod == 1) {
         if (tile != 256) return launch_pair<128, 2, 16, 1>(a, dbg, st);
-#ifdef CSLAM_ABLATIONS
-        // the four-wave form (NTW = 4: 128 x 128 wave tiles, 256 accumulators in AGPRs) is correct -- the suite passes with it -- and
-        // 8 % slower than the eight-wave form on this kernel (94.5 against 85.6-88.2 ms on 100k x 100k, 1.34 against 1.20 ms on the
-        // in-step launch: profiles/r04_v41_match_four_waves_ab.log): with ONE product per fragment pair a K step is 16 MFMAs per 8
-        // reads, and a single wave per SIMD has no partner to fill its waits.  Measurement build only.
-        if (const char *e = getenv("CSLAM_PAIR_WAVES")) if (atoi(e) == 4) return launch_pair<256, 4, 8, 1, 4>(a, dbg, st);
-#endif
         return launch_pair<256, 4, 8, 1>(a, dbg, st);
     }
     return tile == 256 ? launch_pair<256, 4, 8, 3>(a, dbg, st) : launch_pair<128, 2, 16, 3>(a, dbg, st);

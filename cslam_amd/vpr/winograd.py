@@ -73,6 +73,60 @@ def direct_pair_weights(weight):
     return split16_pair_weights(weight.detach().to(torch.float32).permute(2, 3, 1, 0).reshape(9, cin, cout))
 
 
+def igemm_pair_weights(weight):
+    """conv weight [Cout, Cin, KH, KW] float32 -> (W2 [Cout, nk, 2, 32] float16, inv_sw): the weight operand of the implicit-GEMM
+    convolution on fp16 pairs (csrc/conv_igemm.hip).  Rows = output channels; every K block of 32 holds its hi halves then its lo
+    halves; sw w = wh + wl exactly to 22 bits, sw the power of two that brings max |w| into [2^14, 2^15).  K blocks: Cin a multiple
+    of 32: (kh, kw, Cin / 32) order; Cin = 3 (the 7x7 stem): one block per kernel row kh, slot kw * 3 + c, the other slots zero."""
+    cout, cin, kh, kw = weight.shape
+    w = weight.detach().to(torch.float64).permute(0, 2, 3, 1)          # [Cout, KH, KW, Cin]
+    if cin == 3:
+        assert 3 * kw <= 32
+        k = torch.zeros((cout, kh, 32), dtype=torch.float64, device=weight.device)
+        k[:, :, :3 * kw] = w.reshape(cout, kh, 3 * kw)
+        k = k.reshape(cout, kh * 32)
+    else:
+        assert cin % 32 == 0
+        k = w.reshape(cout, kh * kw * cin)
+    amax = float(k.abs().max())
+    sw = 2.0 ** (14 - math.floor(math.log2(amax))) if amax > 0 else 1.0
+    ks = (k * sw).to(torch.float32)
+    wh = ks.to(torch.float16)
+    wl = (ks - wh.to(torch.float32)).to(torch.float16)
+    nk = k.shape[1] // 32
+    pair = torch.stack((wh.view(cout, nk, 32), wl.view(cout, nk, 32)), dim=2)     # [Cout, nk, 2, 32]
+    return pair.contiguous(), 1.0 / sw
+
+
+def conv_igemm(ws, x, Wg, bias, kernel, stride, pad, relu, residual=None, amax_in=None, amax_out=None):
+    """y = act(conv(x) + bias (+ residual)) through `cslam_conv_igemm_h2_dev` (csrc/conv_igemm.hip): x [B,Cin,H,W] channels_last
+    float32, Wg = `igemm_pair_weights(weight)`, kernel = (KH, KW).  amax_in: 4-byte device slot with (a bound of) max |x| (None:
+    one pass over x measures it); amax_out: zeroed slot that receives max |y|."""
+    lib = _lib.load()
+    x = x.contiguous(memory_format=torch.channels_last)
+    B, Cin, H, W = x.shape
+    W2, inv_sw = Wg
+    Cout = W2.shape[0]
+    KH, KW = kernel
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    s = _stream(x)
+    slot = amax_in
+    if slot is None:
+        slot = ws._buf("amax", 1, x.device)
+        if x.numel() % 4 == 0:
+            _lib.check(lib.cslam_absmax_dev(_p(x), x.numel(), _p(slot), s))
+        else:                                                         # the kernel reads 16 bytes per lane: odd sizes through torch
+            slot.copy_(x.abs().max().reshape(1))
+    y = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    if residual is not None:
+        residual = residual.contiguous(memory_format=torch.channels_last)
+        assert residual.shape == y.shape
+    _lib.check(lib.cslam_conv_igemm_h2_dev(_p(x), _p(W2), _p(bias) if bias is not None else None,
+                                           _p(residual) if residual is not None else None, B, H, W, Cin, Cout, KH, KW, stride, pad,
+                                           int(relu), _p(slot), float(inv_sw), _p(amax_out) if amax_out is not None else None, _p(y), s))
+    return y
+
+
 def conv3x3_direct_h(x, Wd, bias, relu, pool, amax_in, amax_out=None):
     """y = [pool](relu(conv3x3(x) + bias)) through `cslam_conv3x3_direct_h_dev` (csrc/conv_direct_h.hip): x [B,Cin,H,W]
     channels_last float32 (Cin a multiple of 32), 128 output channels; Wd = `direct_pair_weights(weight)`; amax_in = 4-byte device
@@ -289,8 +343,12 @@ def _z_form(cin, cout):
     measured per layer at the 256-frame chunk (profiles/r03_v4_perf_zform.log) the output kernel gains ~30 % everywhere, but
     the GEMM's 128 x 128 tiles (all the 128 Z registers per lane leave room for) lose more than that wherever the product is
     not purely HBM-bound -- only conv2_2 (128 -> 128 channels at 112 x 112: 2.08 -> 1.78 ms) comes out ahead.
-    CSLAM_WINO_Z = largest Cin * Cout that takes it (default 128 * 128; 0 = off, 262144 = every layer)."""
-    return cin * cout <= int(os.environ.get("CSLAM_WINO_Z", str(128 * 128)))
+    Z_FORM_MAX = largest Cin * Cout that takes it (128 * 128; 0 = off, 262144 = every layer: tests/test_wino_gemm_gpu.py runs both)."""
+    return cin * cout <= Z_FORM_MAX
+
+
+Z_FORM_MAX = 128 * 128
+IGEMM_CONVS = True            # ResNet trunks: strided / 1x1 / 7x7 layers through csrc/conv_igemm.hip (False: torch, the A/B partner)
 
 
 def wino_conv3x3(ws, x, U, U4, bias, relu, pool=False, residual=None, U3=None, amax_in=None, amax_out=None, U2=None):
@@ -418,23 +476,44 @@ def fold_bn(conv, bn):
 class _FoldedConv(object):
     """conv + eval BatchNorm as one convolution; 3x3 / stride 1 / pad 1 ones also carry Winograd weights."""
 
-    def __init__(self, conv, bn, tile, min_in_channels):
+    def __init__(self, conv, bn, tile, min_in_channels, direct=False):
         self.weight, self.bias = fold_bn(conv, bn)
         self.stride, self.padding = conv.stride, conv.padding
-        self.U = self.U4 = None
-        if (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+        self.U = self.U4 = self.Wg = None
+        self.kernel = tuple(conv.kernel_size)
+        igemm_ok = (IGEMM_CONVS and conv.dilation == (1, 1) and conv.groups == 1 and conv.stride[0] == conv.stride[1]
+                    and conv.padding[0] == conv.padding[1] and conv.out_channels % 64 == 0 and conv.weight.is_cuda
+                    and (conv.in_channels % 32 == 0 or (conv.in_channels == 3 and 3 * conv.kernel_size[1] <= 32)))
+        if direct and igemm_ok:
+            # every convolution of the trunk as this library's implicit GEMM on fp16 pairs (csrc/conv_igemm.hip): per layer faster than
+            # the fp32 Winograd pipeline on ResNet-18's maps (profiles/r05_v23_igemm_layers.log), no library product anywhere
+            self.Wg = igemm_pair_weights(self.weight)
+            self.Wg = (self.Wg[0].to(self.weight.device), self.Wg[1])
+        elif (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
                 and conv.groups == 1 and conv.in_channels >= min_in_channels and conv.in_channels % 4 == 0
                 and conv.out_channels % 4 == 0 and conv.weight.is_cuda):
             self.U = wino_weights(self.weight).to(self.weight.device)
             self.U4 = wino_weights(self.weight, 4).to(self.weight.device) if tile == 4 else None
-            # (layer1 of ResNet-18/34 can run through the one-kernel form of csrc/wino_fused.hip, shortcut fused, but on its
-            # 56 x 56 maps V and M of a 250-frame chunk -- 0.45 GB each -- largely stay in the 256 MB Infinity Cache and the
-            # F(4x4) pipeline wins: 31.8k vs 30.9k frames/s, profiles/r01_perf_c2.log.  Not wired in.)
+        elif igemm_ok:
+            # the 7x7 stem, the strided 3x3 and the 1x1 shortcut layers: this library's implicit GEMM on fp16 pairs
+            # (csrc/conv_igemm.hip) instead of torch / MIOpen
+            self.Wg = igemm_pair_weights(self.weight)
+            self.Wg = (self.Wg[0].to(self.weight.device), self.Wg[1])
+        # (layer1 of ResNet-18/34 can run through the one-kernel form of csrc/wino_fused.hip, shortcut fused, but on its
+        # 56 x 56 maps V and M of a 250-frame chunk -- 0.45 GB each -- largely stay in the 256 MB Infinity Cache and the
+        # F(4x4) pipeline wins: 31.8k vs 30.9k frames/s, profiles/r01_perf_c2.log.  Not wired in.)
 
-    def __call__(self, ws, x, relu, residual=None):
+    def __call__(self, ws, x, relu, residual=None, amax_in=None, amax_out=None):
+        """amax_in: 4-byte device slot with (a bound of) max |x|, or None; amax_out: zeroed slot for max |y|.  `ws.amax_written` says
+        whether amax_out was filled (the implicit-GEMM kernel always does)."""
+        ws.amax_written = False
         if self.U is not None:
             return wino_conv3x3(ws, x.contiguous(memory_format=torch.channels_last), self.U, self.U4, self.bias, relu,
                                 False, residual)
+        if self.Wg is not None:
+            y = conv_igemm(ws, x, self.Wg, self.bias, self.kernel, self.stride[0], self.padding[0], relu, residual, amax_in, amax_out)
+            ws.amax_written = amax_out is not None
+            return y
         y = torch.nn.functional.conv2d(x, self.weight, self.bias, self.stride, self.padding)
         if residual is not None:
             y += residual
@@ -445,18 +524,21 @@ class WinogradResNet(_Workspace):
     """Runs the ResNet trunks of vpr/backbones.py (`resnet_trunk`: conv1, bn1, relu, maxpool, layer1..4 of
     BasicBlock / Bottleneck) like `trunk(x)` in eval mode, with every BatchNorm folded into its convolution and
     the 3x3 / stride 1 convolutions executed through the Winograd pipeline (bias, shortcut add and ReLU fused into
-    the output transform; tiles hang over odd maps such as layer4's 7x7).  Strided / 1x1 / 7x7 convolutions go
-    through torch."""
+    the output transform; tiles hang over odd maps such as layer4's 7x7).  The 7x7 stem, the strided 3x3 and the 1x1 shortcut
+    convolutions run as this library's implicit GEMM on fp16 pairs (csrc/conv_igemm.hip; `IGEMM_CONVS = False`: torch)."""
 
-    def __init__(self, trunk, min_in_channels=64, tile=4):
+    def __init__(self, trunk, min_in_channels=64, tile=4, direct=None):
+        """direct (default: IGEMM_CONVS): EVERY eligible convolution through the implicit GEMM on fp16 pairs; False: the 3x3 / stride 1
+        layers through the fp32 Winograd pipeline with library products (rounds 1-4; the A/B partner)."""
         super().__init__()
         self.trunk, self.min_in_channels, self.tile = trunk, int(min_in_channels), int(tile)
+        self.direct = IGEMM_CONVS if direct is None else bool(direct)
         use_tuned_gemms()
         self.refresh()
 
     def refresh(self):
         mods = list(self.trunk)
-        mk = lambda c, b: _FoldedConv(c, b, self.tile, self.min_in_channels)      # noqa: E731
+        mk = lambda c, b: _FoldedConv(c, b, self.tile, self.min_in_channels, self.direct)      # noqa: E731
         self.stem = mk(mods[0], mods[1])
         self.stem_pool = mods[3]
         self.blocks = []
@@ -471,15 +553,30 @@ class WinogradResNet(_Workspace):
     @torch.no_grad()
     def __call__(self, x):
         x = x.contiguous(memory_format=torch.channels_last)
-        x = self.stem_pool(self.stem(self, x, True))
+        # max |activation| travels from the epilogue that produced a map to the kernels that read it (4-byte device slots, the power-of-two
+        # scale of the fp16 pairs): no pass over an activation just to measure it.  `ax` = slot of the current x, or None (unknown)
+        slots = self._buf("amax_slots", 4 * len(self.blocks) + 4, x.device)
+        slots.zero_()
+        nslot = [0]
+
+        def fresh():
+            nslot[0] += 1
+            return slots[nslot[0] - 1:nslot[0]]
+
+        def run(conv, inp, relu, res, a_in):
+            out_slot = fresh()
+            y = conv(self, inp, relu, res, a_in, out_slot)
+            return y, (out_slot if self.amax_written else None)
+        y, ax = run(self.stem, x, True, None, None)
+        x = self.stem_pool(y)                             # max |pool(y)| <= max |y|: the slot stays a bound
         for b in self.blocks:
-            idt = x if b["down"] is None else b["down"](self, x, False)
-            o = b["c1"](self, x, True)
+            idt = x if b["down"] is None else run(b["down"], x, False, None, ax)[0]
+            o, ao = run(b["c1"], x, True, None, ax)
             if b["c3"] is None:                       # BasicBlock
-                x = b["c2"](self, o, True, idt)
+                x, ax = run(b["c2"], o, True, idt, ao)
             else:                                     # Bottleneck
-                o = b["c2"](self, o, True)
-                x = b["c3"](self, o, True, idt)
+                o, ao = run(b["c2"], o, True, None, ao)
+                x, ax = run(b["c3"], o, True, idt, ao)
         return x
 
 
@@ -498,21 +595,21 @@ class WinogradTrunk(_Workspace):
     """Runs an nn.Sequential of Conv2d / ReLU / MaxPool2d like `encoder(x)`, with the eligible
     convolutions (+ their ReLU, + their MaxPool2d(2,2)) replaced by the Winograd pipeline."""
 
-    def __init__(self, encoder, min_in_channels=256, tile=2, fused64=None):
+    def __init__(self, encoder, min_in_channels=256, tile=2, fused64=None, split16_h3=False):
         """tile = 2: F(2x2,3x3) everywhere; tile = 4: F(4x4,3x3) on the maps whose sides are multiples of 4
         (F(2x2,3x3) on the others).  fused64: run the 64 -> 64 / 128 channel layers (VGG-16 conv1_2, conv2_1) through the single
-        fused F(2x2,3x3) kernel instead of transform / GEMM / transform (default on; CSLAM_WINO_FUSED64=0 disables)."""
+        fused F(2x2,3x3) kernel instead of transform / GEMM / transform (default on)."""
         super().__init__()
         self.encoder = encoder
         self.min_in_channels = int(min_in_channels)
         self.tile = int(tile)
-        self.fused64 = (os.environ.get("CSLAM_WINO_FUSED64", "1") != "0") if fused64 is None else bool(fused64)
+        self.fused64 = True if fused64 is None else bool(fused64)
         self.fused_min_blocks = 256                  # fewer tile blocks than this (single frames): the three-kernel form
         self.fused_couts = (64, 128)
         # split-fp16 GEMMs on the F(4x4) layers from this many input channels on (0 = off: plain fp32 library GEMMs).
         # Default: this library's pair GEMM (`split16_pair_weights`, csrc/wino_gemm.hip) from 128 channels on -- V is no
-        # larger than its fp32 form, so every layer the three-kernel form runs gains.  CSLAM_WINO_H3=1 selects round 1's
-        # library GEMM over [vh | vl | vh] instead, whose measured optimum was 256 (profiles/r01_exp_split16.log).
+        # larger than its fp32 form, so every layer the three-kernel form runs gains.  split16_h3=True (constructor) selects round 1's
+        # library GEMM over [vh | vl | vh] instead, whose measured optimum was 256 (profiles/r01_exp_split16.log): a test partner.
         # a known bound of max |input| (e.g. a normalised 8-bit image: heads.normalised_image_bound()) spares the stem kernel
         # its pass over the input; None = measured per call
         self.input_bound = None
@@ -520,7 +617,7 @@ class WinogradTrunk(_Workspace):
         self.direct128 = os.environ.get("CSLAM_CONV_DIRECT", "1") != "0"
         # input widths that take the direct kernel (CSLAM_CONV_DIRECT=2: conv2_2 only, conv2_1 on the one-kernel F(4x4) form)
         self.direct_cins = (128,) if os.environ.get("CSLAM_CONV_DIRECT", "1") == "2" else (64, 128)
-        self.split16_h3 = os.environ.get("CSLAM_WINO_H3", "0") == "1"
+        self.split16_h3 = bool(split16_h3)
         self.split16_min_cin = int(os.environ.get("CSLAM_WINO_SPLIT16", "256" if self.split16_h3 else "128"))
         use_tuned_gemms()
         self.refresh()

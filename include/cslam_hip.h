@@ -446,6 +446,18 @@ int cslam_wino4_stem_c64_h_dev(const float *d_x0, const void *d_w1, const float 
                                const void *d_Uh, const float *d_bias, int B, int H, int W, int pool,
                                const unsigned *d_amax_x0, float inv_su, unsigned *d_amax_out, float *d_y, void *stream);
 
+/* Strided / 1x1 / 7x7 convolution of the ResNet trunks (cslam/vpr/cosplace_utils/network.py:38-68: torchvision ResNet-18 without
+ * avgpool / fc, CosPlace's default backbone, cslam/vpr/cosplace.py:81-101) as an implicit GEMM on exact fp16 pairs
+ * (csrc/conv_igemm.hip): y = act(conv(x, w) + bias (+ res)), x [B,H,W,Cin] NHWC float32 -> y [B,Ho,Wo,Cout] NHWC float32,
+ * Ho = (H + 2 pad - KH) / stride + 1; BatchNorm folded into w / bias by the caller.  Cin a multiple of 32, or 3 with 3 KW <= 32 (the
+ * 7x7 stem); Cout a multiple of 64.  d_w2 = `igemm_pair_weights(weight)` (cslam_amd/vpr/winograd.py): rows = output channels, K blocks
+ * of 32 channels as [hi 32 | lo 32] fp16 in (kh, kw, Cin / 32) order (stem: one block per kernel row, slot kw * 3 + c); inv_sw = the
+ * inverse of the weights' power-of-two scale.  d_res: optional shortcut, y's shape.  d_amax_in: 4-byte slot with the float bits of
+ * (a bound of) max |x|; d_amax_out: optional zeroed slot that receives max |y|.  Replaces torch.nn.functional.conv2d there. */
+int cslam_conv_igemm_h2_dev(const float *d_x, const void *d_w2, const float *d_bias, const float *d_res, int B, int H, int W,
+                            int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, const unsigned *d_amax_in,
+                            float inv_sw, unsigned *d_amax_out, float *d_y, void *stream);
+
 /* 3x3 / stride 1 / pad 1 convolution 64 -> 128 channels (cslam/vpr/netvlad.py:163-171,227: VGG-16 conv2_1) as ONE direct kernel whose
  * weights (295 KB of exact fp16 pairs) stay in the registers of the four waves of a workgroup, 32 output channels each
  * (csrc/conv_direct_r.hip).  Arguments as cslam_conv3x3_direct_h_dev with Cin = 64, Cout = 128; d_w2r = `direct_r_pair_weights`:

@@ -367,9 +367,14 @@ def test_winograd_resnet_equals_torch_trunk(T, name, B, hw):
         r = trunk.double()(x.double())
         trunk.float()
         a = trunk(x.contiguous(memory_format=torch.channels_last))
-    for tile in (4, 2):
-        run = WinogradResNet(trunk, 64, tile)
-        assert any(b["c1"].U is not None or b["c2"].U is not None for b in run.blocks)
+    for tile, direct in ((4, True), (4, False), (2, False)):
+        # direct: every convolution through the implicit GEMM on fp16 pairs (csrc/conv_igemm.hip, the default); otherwise the 3x3 /
+        # stride 1 layers through the fp32 Winograd pipeline (F(4x4) / F(2x2)), the rest through the implicit GEMM
+        run = WinogradResNet(trunk, 64, tile, direct=direct)
+        if direct:
+            assert run.stem.Wg is not None and all(b["c1"].Wg is not None and b["c2"].Wg is not None for b in run.blocks)
+        else:
+            assert any(b["c1"].U is not None or b["c2"].U is not None for b in run.blocks)
         b = run(x)
         assert b.shape == r.shape
         scale = r.abs().max().item()
@@ -802,7 +807,7 @@ def test_split16_winograd_layer_is_fp32_grade(T, form, B, H, W, cin, cout, relu,
 @pytest.mark.gpu
 def test_split16_trunk_equals_fp32_gemm_trunk(T):
     """VGG-16 trunk with the split-fp16 GEMMs -- the default pair form from 128 input channels on (conv2_2 ... conv5_3,
-    this library's GEMM) and round 1's h3 form from 256 on (CSLAM_WINO_H3=1) -- against the same trunk on plain fp32
+    this library's GEMM) and round 1's h3 form from 256 on (split16_h3=True) -- against the same trunk on plain fp32
     GEMMs (CSLAM_WINO_SPLIT16=0) and against a float64 evaluation: neither split form is less accurate than the fp32 one
     by more than 1.5x (max norm and relative 2-norm), and all sit inside the trunk tolerance used for the fp32 form."""
     torch, _ = T
@@ -811,21 +816,18 @@ def test_split16_trunk_equals_fp32_gemm_trunk(T):
     torch.manual_seed(37)
     enc = vgg16_features_trunk().cuda().eval()
     x = torch.randn((32, 3, 224, 224), device="cuda")     # 32 frames: conv5_x (4 x 4 tiles per frame) reaches the 512-tile F(4x4) floor
-    old = {k: os.environ.get(k) for k in ("CSLAM_WINO_SPLIT16", "CSLAM_WINO_H3")}
+    old = os.environ.get("CSLAM_WINO_SPLIT16")
     try:
-        os.environ.pop("CSLAM_WINO_H3", None)
         os.environ["CSLAM_WINO_SPLIT16"] = "0"
         t32 = WinogradTrunk(enc, 64, 4)
         os.environ.pop("CSLAM_WINO_SPLIT16", None)
         t2 = WinogradTrunk(enc, 64, 4)
-        os.environ["CSLAM_WINO_H3"] = "1"
-        t3 = WinogradTrunk(enc, 64, 4)
+        t3 = WinogradTrunk(enc, 64, 4, split16_h3=True)
     finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        if old is None:
+            os.environ.pop("CSLAM_WINO_SPLIT16", None)
+        else:
+            os.environ["CSLAM_WINO_SPLIT16"] = old
     assert all(st.U3 is None and st.U2 is None for st in t32.steps)
     assert sum(st.U2 is not None for st in t2.steps) == 10 and all(st.U3 is None for st in t2.steps)    # conv2_2 ... conv5_3
     assert sum(st.U3 is not None for st in t3.steps) == 8 and all(st.U2 is None for st in t3.steps)     # conv3_2 ... conv5_3
@@ -1169,3 +1171,56 @@ def test_netvlad_batch_path_descriptors_with_heavy_tailed_weights(T):
     assert worst <= 1e-5, worst
     assert worst <= 2.0 * e_direct + 1e-6, (worst, e_direct)
     assert float((1.0 - cos).max()) <= 2e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,cin,cout,hw,k,stride,pad,relu,res", [
+    (3, 3, 64, (64, 80), 7, 2, 3, True, False),        # ResNet stem: 7x7 / 2, three input channels (row-packed K blocks)
+    (2, 3, 64, (37, 53), 7, 2, 3, False, False),       # ... odd map, ragged last tile
+    (4, 64, 128, (28, 28), 3, 2, 1, True, False),      # layer2.0.conv1: 3x3 / 2
+    (4, 64, 128, (28, 28), 1, 2, 0, False, False),     # layer2.0.downsample: 1x1 / 2
+    (2, 128, 256, (15, 13), 3, 2, 1, True, False),     # odd sides
+    (2, 256, 512, (14, 14), 1, 2, 0, False, False),
+    (3, 128, 128, (12, 20), 3, 1, 1, True, True),      # stride 1 with the shortcut fused
+    (2, 64, 64, (9, 9), 3, 1, 1, True, True),          # 64 output channels: the 64-column tile
+    (1, 512, 512, (7, 7), 3, 1, 1, False, True),       # 144 K blocks, 49 pixels: one ragged tile row
+])
+def test_implicit_gemm_convolution_on_fp16_pairs_equals_float64(T, B, cin, cout, hw, k, stride, pad, relu, res):
+    """csrc/conv_igemm.hip (the strided / 1x1 / 7x7 layers of the ResNet trunks, cosplace_utils/network.py:38-68): against the
+    same convolution in float64, no further from it than 4 x torch's own float32 convolution (+ 2e-7 of the output's scale), with
+    inputs whose magnitudes span several binades; max |y| comes back in the slot; zero padding, ragged tiles, shortcut, ReLU."""
+    torch, _ = T
+    from cslam_amd.vpr import winograd as wg
+    torch.manual_seed(1000 * cin + cout + k)
+    H, W = hw
+    x = torch.randn((B, cin, H, W), device="cuda") * torch.exp2(torch.randint(-6, 3, (B, cin, 1, 1), device="cuda").float())
+    x = x.contiguous(memory_format=torch.channels_last)
+    w = torch.randn((cout, cin, k, k), device="cuda") / (k * cin ** 0.5)
+    w *= torch.exp2(torch.randint(-3, 2, (cout, 1, 1, 1), device="cuda").float())
+    bias = torch.randn(cout, device="cuda") * 0.3
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), bias.double(), stride=stride, padding=pad)
+    r = None
+    if res:
+        r = torch.randn(ref.shape, device="cuda").contiguous(memory_format=torch.channels_last)
+        ref = ref + r.double()
+    if relu:
+        ref = ref.relu()
+    a32 = torch.nn.functional.conv2d(x, w, bias, stride=stride, padding=pad)
+    if res:
+        a32 = a32 + r
+    if relu:
+        a32 = a32.relu()
+    ws = wg._Workspace()
+    slot = torch.zeros(1, dtype=torch.float32, device="cuda")
+    y = wg.conv_igemm(ws, x, wg.igemm_pair_weights(w), bias, (k, k), stride, pad, relu, r, amax_out=slot)
+    torch.cuda.synchronize()
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    scale = ref.abs().max().item()
+    e = (y.double() - ref).abs().max().item() / scale
+    e32 = (a32.double() - ref).abs().max().item() / scale
+    assert e <= 4 * e32 + 2e-7, (e, e32)
+    assert slot.item() == y.abs().max().item()
+    # a bound instead of the measured maximum (what a caller with a known input range passes): same result to rounding
+    bound = torch.full((1,), float(x.abs().max().item()) * 1.7, device="cuda")
+    y2 = wg.conv_igemm(ws, x, wg.igemm_pair_weights(w), bias, (k, k), stride, pad, relu, r, amax_in=bound)
+    assert (y2.double() - ref).abs().max().item() / scale <= 4 * e32 + 4e-7

@@ -144,8 +144,8 @@ def test_z_form_layer_equals_plain_form_layer_and_float64(T, B, H, W, cin, cout,
     U2 = wg.split16_pair_weights(U4)
     ws = wg._Workspace()
     outs, slots = {}, {}
-    for tag, z in (("z", "262144"), ("plain", "0")):
-        monkeypatch.setenv("CSLAM_WINO_Z", z)
+    for tag, z in (("z", 262144), ("plain", 0)):
+        monkeypatch.setattr(wg, "Z_FORM_MAX", z)
         slot = torch.zeros(1, dtype=torch.float32, device="cuda")
         big = x.repeat(-(-512 // (B * -(-H // 4) * -(-W // 4))), 1, 1, 1) if B * -(-H // 4) * -(-W // 4) < 512 else x
         y = wg.wino_conv3x3(ws, big.contiguous(memory_format=torch.channels_last), U, U4, bias, True, pool=pool, U2=U2, amax_out=slot)

@@ -41,7 +41,8 @@ def main():
     src, tag = sys.argv[1], sys.argv[2]
     stage = os.environ.get("CSLAM_MFMA_STAGE1", "h1")
     prod = 0 if stage[0] == "f" else (3 if stage[0] == "p" else 1)        # fp16 products per pair (0: the f32-input stage)
-    kern = "sim_topk_pair_kernel" if prod else "sim_topk_mfma_kernel"
+    # one fp16 product on 256 x 256 tiles = the persistent stage (sim_topk_ring.hip), three = round 3's pair kernel
+    kern = {0: "sim_topk_mfma_kernel", 1: "sim_topk_ring_kernel", 3: "sim_topk_pair_kernel"}[prod]
     bpv = {0: 4, 1: 2, 3: 4}[prod]                                        # bytes per value of the operand copies the stage reads
     fetch = per_dispatch(os.path.join(src, "fetch"), ("FETCH_SIZE",))
     write = per_dispatch(os.path.join(src, "write"), ("WRITE_SIZE",))
@@ -96,7 +97,7 @@ def main():
             key = kern if nq == 100000 else kern + "/q%d" % nq
             table[key] = {"traffic_bytes": e["traffic_bytes"], "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk,
                           "algorithmic_min_bytes": e["algorithmic_min_bytes"], "l2_hit_rate": e.get("l2_hit_rate"),
-                          "mfma_busy_frac": e.get("mfma_busy_frac"),
+                          "mfma_busy_frac": e.get("mfma_busy_frac"), "effective_clock_GHz": e.get("effective_clock_GHz"),
                           "match": {"queries": nq, "bank_rows": 100000, "dim": 4096, "products": prod},
                           "source": "profiles/%s_pmc_match_summary.json (separate rocprofv3 --pmc passes of tools/pmc_match_target.py, tools/gpu_pmc_match.sh): L2-miss (fabric-side) bytes, Infinity-Cache hits included" % tag}
     json.dump(table, open(path, "w"), indent=1)
