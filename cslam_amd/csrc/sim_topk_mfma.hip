@@ -523,7 +523,7 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
 #ifdef CSLAM_ABLATIONS
         const char *v = getenv("CSLAM_MFMA_DBG");       // timing-only ablations (wrong results), see the kernel: never in the default build
         dbg = v ? atoi(v) : 0;
-        if (dbg < 0 || dbg > 63) dbg = 0;          // 3..5: the persistent stage only (sim_topk_ring.hip)
+        if (dbg < 0 || dbg > 4095) dbg = 0;          // 3..5: the persistent stage only (sim_topk_ring.hip)
 #endif
         const char *t = getenv("CSLAM_MFMA_TILE");      // 128 | 256 (default chosen below)
         tile_env = t ? atoi(t) : 0;
@@ -551,7 +551,7 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
 #ifdef CSLAM_ABLATIONS
     if (const char *r = getenv("CSLAM_MFMA_RING")) {     // measurement build: -1 = the one-workgroup-per-item kernel, 0..3 = variant
         const int v = atoi(r);
-        if (v < 0) ring = false; else ring_variant = v & 3;
+        if (v < 0) ring = false; else ring_variant = v & 15;
     }
 #endif
     RingSchedule *rs = nullptr;
@@ -704,7 +704,7 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
         ra.tasks = (const RingTask *)(ws + o_rt); ra.task_off = (const int *)(ws + o_ro);
         ra.qt_nseg = (const int *)(ws + o_rn); ra.qt_segoff = (const int *)(ws + o_rs);
         ra.part_key = part_key; ra.part_idx = part_idx; ra.part_bound = part_bound;
-        ra.prog = ((ring_variant & 1) && rs->wpx <= 32) ? (int *)(ws + o_ry) : nullptr; ra.flow_w = flow_w; ra.flow_bias_q = flow_bq; ra.flow_bias_b = flow_bb;
+        ra.prog = ((ring_variant & 13) && rs->wpx <= 32) ? (int *)(ws + o_ry) : nullptr; ra.flow_w = flow_w; ra.flow_bias_q = flow_bq; ra.flow_bias_b = flow_bb;
         ra.xcc_out = want_xcc ? (int *)(ws + o_rx) : nullptr;
         ra.trace_out = want_xcc ? (long long *)(ws + o_rz) : nullptr;
         if (want_xcc) HIP_TRY(hipMemsetAsync(ws + o_rz, 0, ((size_t)b->num_cu * 64 + 8 * 48 * 2 + 8) * 8, st));

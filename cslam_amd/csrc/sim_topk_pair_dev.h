@@ -25,6 +25,11 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t pk_rsrc(const char *base, int6
 __device__ __forceinline__ void pk_blds16(__amdgpu_buffer_rsrc_t rs, int voff, int soff, char *lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voff, soff, 0, 0);
 }
+// the same request with cache-policy bits (gfx940+: aux bit 0 = sc0, bit 1 = nt, bit 4 = sc1); measurement build of sim_topk_ring.hip
+template <int AUX>
+__device__ __forceinline__ void pk_blds16_aux(__amdgpu_buffer_rsrc_t rs, int voff, int soff, char *lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *)lds_wave_base, 16, voff, soff, 0, AUX);
+}
 
 
 // ---- tile epilogue: lane-local candidate update from the finished 32 MT x 64 wave tile, then clear the accumulators

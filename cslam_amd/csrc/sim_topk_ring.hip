@@ -136,8 +136,11 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
             auto stage_load_part = [&](int stage, int kt, int i) {
                 char *sA = smem + stage * STAGE;
                 char *sB = sA + OPB;
-                pk_blds16(rsA, voffA0 + i * stepA, kt * PK_ROWB, sA + i * (NTHR * 16) + wave_chunk);
-                pk_blds16(rsB, voffB0, kt * PK_ROWB + i * stepB, sB + i * (NTHR * 16) + wave_chunk);
+                // DBG bits 6-8 / 9-11 (measurement build): cache policy of the bank / query requests (1 = sc0, 2 = nt, 4 = sc1)
+                constexpr int PA = (DBG >> 6) & 7, PB = (DBG >> 9) & 7;
+                constexpr int AUXA = (PA & 3) | ((PA & 4) << 2), AUXB = (PB & 3) | ((PB & 4) << 2);
+                pk_blds16_aux<AUXA>(rsA, voffA0 + i * stepA, kt * PK_ROWB, sA + i * (NTHR * 16) + wave_chunk);
+                pk_blds16_aux<AUXB>(rsB, voffB0, kt * PK_ROWB + i * stepB, sB + i * (NTHR * 16) + wave_chunk);
             };
 
             f32x16 acc[MT][NTW];
@@ -200,11 +203,38 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
                 const char *sB = sA + OPB;
                 constexpr int HALF = FIRST ? 0 : NLD / 2;                // loader parts (2 requests each) issued behind the barrier
                 constexpr int LEAD = 2;
-                if (FLOW) {
+                if (FLOW == 3) {
+                    // proportional form: no polling.  Every stage: publish; reduce the line read ONE stage ago (DPP row shifts + two
+                    // readlanes: no LDS traffic); sleep ~a third of a stage per stage of lead beyond the window; request the line again.
+                    if (wave == 0 && prog != nullptr) {
+                        const int P = pbase + it;
+                        if (lane == 0) __hip_atomic_store(prog + slot, P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (it > 0) {
+                            int v = pv;
+                            int o;
+                            o = __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x111, 0xf, 0xf, false); v = o < v ? o : v;     // row_shr:1
+                            o = __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x112, 0xf, 0xf, false); v = o < v ? o : v;     // row_shr:2
+                            o = __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x114, 0xf, 0xf, false); v = o < v ? o : v;     // row_shr:4
+                            o = __builtin_amdgcn_update_dpp(0x7fffffff, v, 0x118, 0xf, 0xf, false); v = o < v ? o : v;     // row_shr:8
+                            const int m0 = __builtin_amdgcn_readlane(v, 15), m1 = __builtin_amdgcn_readlane(v, 31);
+                            const int lead = P - (m0 < m1 ? m0 : m1) - p.flow_w;
+                            if (lead > 0) {
+                                if (lead == 1) __builtin_amdgcn_s_sleep(10);
+                                else if (lead == 2) __builtin_amdgcn_s_sleep(22);
+                                else if (lead <= 4) __builtin_amdgcn_s_sleep(40);
+                                else __builtin_amdgcn_s_sleep(80);
+                                if (p.trace_out && lane == 0) p.trace_out[(size_t)bid * 64 + 62] += 1;
+                            }
+                        }
+                        pv = lane < p.wpx ? __hip_atomic_load(prog + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                } else if (FLOW) {
                     if (wave == 0 && flow_on) {
                         const int P = pbase + it;
-                        if ((it & 1) == 0 && lane == 0) __hip_atomic_store(prog + slot, P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((it & 3) == 3) {
+                        // FLOW 1: publish every second stage, look every fourth; FLOW 2: both every stage (a tighter loop)
+                        if ((FLOW == 2 || (it & 1) == 0) && lane == 0) __hip_atomic_store(prog + slot, P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (FLOW == 2 ? it > 0 : (it & 3) == 3) {
                             // the line read two stages ago (its load was waited for by the stage barriers since): slowest of the patch
                             auto slowest = [&](int v) {
 #pragma unroll
@@ -213,16 +243,16 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
                             };
                             int mn = slowest(pv);
                             int spins = 0;
-                            while (P - mn > p.flow_w && spins < 48) {               // ahead of the window: pause, ~1 us per look
-                                __builtin_amdgcn_s_sleep(24);
+                            while (P - mn > p.flow_w && spins < (FLOW == 2 ? 160 : 48)) {     // ahead of the window: pause, ~1 (0.3) us per look
+                                __builtin_amdgcn_s_sleep(FLOW == 2 ? 6 : 24);
                                 pv = lane < p.wpx ? __hip_atomic_load(prog + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
                                 mn = slowest(pv);
                                 ++spins;
                             }
-                            if (spins >= 48) flow_on = false;
+                            if (spins >= (FLOW == 2 ? 160 : 48)) flow_on = false;
                             if (p.trace_out && spins > 0 && lane == 0) p.trace_out[(size_t)bid * 64 + 62] += spins;
                         }
-                        if ((it & 3) == 1)
+                        if (FLOW == 2 || (it & 3) == 1)
                             pv = lane < p.wpx ? __hip_atomic_load(prog + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -447,9 +477,11 @@ int ring_stage1_launch(const RingArgs &a, int variant, int dbg, hipStream_t st) 
     constexpr int lds = 2 * 2 * 256 * PK_ROWB + 16 + 2 * 1024;
     static DeviceOnce once;
     int once_dev;
-#define RING_EACH(X) X(0, 0, 0) X(0, 1, 0) X(0, 0, 1) X(0, 1, 1)
+#define RING_EACH(X) X(0, 0, 0)
 #ifdef CSLAM_ABLATIONS
-#define RING_EACH_DBG(X) X(2, 0, 0) X(8, 0, 0) X(9, 0, 0) X(10, 0, 0) X(13, 0, 0) X(16, 0, 0) X(33, 0, 0) X(33, 0, 1) X(9, 0, 1) X(10, 0, 1)
+    // variants (flow control, wave priorities), timing-only ablations, cache policies of the requests: bank nt / query nt / both / bank sc1 / ...
+#define RING_EACH_DBG(X) X(0, 1, 0) X(0, 0, 1) X(0, 1, 1) X(0, 2, 0) X(0, 3, 0) X(2, 0, 0) X(8, 0, 0) X(9, 0, 0) X(10, 0, 0) X(13, 0, 0) X(16, 0, 0) X(33, 0, 0) X(33, 0, 1) X(9, 0, 1) X(10, 0, 1) \
+    X(128, 0, 0) X(1024, 0, 0) X(1152, 0, 0) X(256, 0, 0) X(2048, 0, 0) X(64, 0, 0) X(512, 0, 0)
 #else
 #define RING_EACH_DBG(X)
 #endif
@@ -461,7 +493,8 @@ int ring_stage1_launch(const RingArgs &a, int variant, int dbg, hipStream_t st) 
         once.done(once_dev);
     }
     const dim3 grid(a.n_xcd * a.wpx), blk(512);
-    const int sy = variant & 1, pr = (variant >> 1) & 1;
+    // bits 2-3: 4 = the per-stage polling flow control, 8 = the proportional one
+    const int sy = (variant & 8) ? 3 : ((variant & 4) ? 2 : (variant & 1)), pr = (variant >> 1) & 1;
     bool done = false;
 #define RING_GO(D, S, P) if (!done && dbg == D && sy == S && pr == P) { hipLaunchKernelGGL((sim_topk_ring_kernel<8, D, S, P>), grid, blk, lds, st, a); done = true; }
     RING_EACH(RING_GO)

@@ -1,4 +1,5 @@
 #!/bin/bash
+# PMC passes (each counter set in its own run) over the kernels of one extract pass: tools/pmc_extract_pass.py sums them per kernel
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}; tag=${1:-r03_pmcx}; O=$R/gpurun_out/$tag; mkdir -p $O; cd $R; export TMPDIR=/tmp
 CMD="python tools/extract_leg.py --iters 2"
