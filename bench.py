@@ -813,9 +813,8 @@ def main():
 
     # ---- BASELINE config 2, the reference's DEFAULT extractor (global_descriptor_loop_closure_detection.py:56-60): CosPlace
     # ResNet-18 512-D on 640x480 keyframes (centre crop 376, bicubic resize to 224) + causal top-5 over the growing bank.
-    # A bounded leg beside the headline (which stays C3): chunks of 1000 frames, the bank grows chunk by chunk.  The trunk's
-    # 3x3 / stride-1 layers run through this library's Winograd transforms with fp32 library products, the 7x7 stem, the
-    # strided 3x3 and the 1x1 layers through torch (MIOpen / CK): every product on the f32-input matrix pipe, hence that roof.
+    # A bounded leg beside the headline (which stays C3): chunks of 1000 frames, the bank grows chunk by chunk.  Every trunk
+    # layer runs through this library's implicit-GEMM convolution on fp16 pairs (csrc/conv_igemm.hip): hence the fp16 roof.
     c2 = None
     if rank == 0 and world == 1 and extractor is not None and not a.no_c2:
         from cslam_amd.vpr.cosplace import CosPlace
@@ -827,7 +826,7 @@ def main():
         ch = min(1000, frames.shape[0])
         nchunks = 3
         cp.compute_embeddings_device(frames[:ch])
-        torch.cuda.synchronize()                                  # warm-up (MIOpen find, Winograd weights)
+        torch.cuda.synchronize()                                  # warm-up (weight pairs, workspaces)
         nn2 = nnm.NearestNeighborsMatching()
         te2 = tm2 = 0.0
         done2 = 0
@@ -849,11 +848,14 @@ def main():
         c2 = {"workload": "C2: CosPlace ResNet-18 512-D extract + causal top-%d, %d synthetic 640x480 keyframes in chunks of %d" % (a.k, done2, ch),
               "value": round(done2 / (te2 + tm2), 1), "unit": "keyframes/sec", "extract_only": round(fps, 1),
               "match_only": round(done2 / tm2, 1), "dtype": "f32",
-              "roofline": {"bound": "mfma", "kernel": "trunk products on the f32-input matrix pipe (rocBLAS sgemm for the Winograd layers, "
-                                                        "MIOpen / CK for the 7x7 stem, the strided 3x3 and the 1x1 layers)",
-                           "achieved": round(fps * GF / 1e3, 1), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (direct-convolution flop, f32 inputs)",
-                           "frac": round(fps * GF / 1e3 / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                           "note": "whole-trunk rate from wall time: the trunk is library kernels, no single hand-written kernel dominates"}}
+              "roofline": {"bound": "mfma", "kernel": "conv_igemm_h2_kernel: every trunk layer (7x7 stem, 3x3 stride 1 and 2, 1x1) as an implicit "
+                                                        "GEMM over exact fp16 hi/lo pairs of activations and weights, 3 fp16 products per "
+                                                        "multiply-add (csrc/conv_igemm.hip; per-layer times: tools/perf_conv_igemm.py, DESIGN.md 3.6d)",
+                           "achieved": round(fps * GF * 3 / 1e3, 1), "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (fp16, 3 products)",
+                           "frac": round(fps * GF * 3 / 1e3 / FP16_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                           "direct_conv_TFLOPs": round(fps * GF / 1e3, 1),
+                           "note": "whole-extract rate from wall time (crop, resize, trunk, GeM head): it includes the non-GEMM passes and "
+                                   "the stem's padded K (147 taps in 7 blocks of 32), so it is below every layer's own fraction"}}
         if not a.no_cpu_baseline:
             ncf = max(1, min(a.cpu_frames, 8))
             xcpu = torch.randn((ncf, 3, 224, 224))

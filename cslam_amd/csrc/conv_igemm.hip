@@ -18,8 +18,8 @@
 // The activation tile is split while it is staged: global_load_dwordx4 -> 4 products with s, 2 packed conversions, 4 v_fma_mix
 // differences, 2 packed conversions per 16 bytes -> ds_write_b128 into the [hi 32 | lo 32] row image of the pair GEMM (128 bytes per
 // pixel and K block, 16-byte chunks XOR-swizzled by the row, fragment reads conflict-free); the weight tile comes by LDS-DMA from
-// rows laid out the same way.  Double-buffered stages: the loads of stage k + 1 are issued in front of stage k's MFMAs, converted
-// and written behind them.
+// rows laid out the same way.  Double-buffered LDS stages; the activation loads run two K blocks ahead of the MFMAs (two register
+// sets), their split and LDS write one block ahead, behind the MFMAs of the current block.
 // Workgroup = 128 pixels x TN = 128 | 64 output channels, four waves as 2 x 2 (wave tile 64 x TN / 2), two or three per CU.
 // STEM: the 3-channel 7x7 layer.  A tap's channels are 12 bytes, so a K block is a whole kernel ROW: the 21 values (kw, c) of row kh
 // are consecutive floats of the NHWC image; 7 blocks of 32 slots (21 used, the weights of the others zero).  (K packed densely over
@@ -34,6 +34,7 @@ typedef unsigned cu4 __attribute__((ext_vector_type(4)));
 
 #define CI_ROWB 128
 #define CI_TM 128
+#define CI_OOB 0x40000000              // stem: offset sentinel (row and column sentinels add up to 2^31: still past a descriptor of < 2^30 bytes)
 
 struct ConvIgemmArgs {
     const float *x; const char *w2; const float *bias; const float *res; float *y;
@@ -50,6 +51,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t ci_rsrc(const char *base, int6
     const uint64_t u = ((uint64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)a);
     const int n = __builtin_amdgcn_readfirstlane((int)(bytes > 0x7fffffff ? 0x7fffffff : bytes));
     return __builtin_amdgcn_make_buffer_rsrc((void *)u, 0, n, 0x00020000);
+}
+__device__ __forceinline__ cf4 ci_bload16(__amdgpu_buffer_rsrc_t rs, int voff, int soff) {
+    const cu4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0);
+    return (cf4){__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
 }
 // (a __device__ function, not the builtin inside the kernel's lambda: with the LDS-DMA builtin called from a lambda hipcc 7.2's HOST
 // pass emits no launch stub for the kernel and says nothing -- the library then fails to load with an undefined symbol)
@@ -106,44 +111,53 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
         wi0 = wo * p.stride - p.pad;
     }
     const float sc = ci_scale(*p.amax_in);
+    // descriptor from the image of the workgroup's first pixel on (the host checks that a tile's span of images stays below 2^31 bytes)
+    const int b0 = __builtin_amdgcn_readfirstlane((int)(((int64_t)mt * CI_TM) / (p.Ho * p.Wo)));
+    const int64_t img = (int64_t)p.H * p.W * p.Cin;
+    const int64_t xbytes = (int64_t)(p.B - b0) * img * 4;
+    const __amdgpu_buffer_rsrc_t rsX = ci_rsrc((const char *)(p.x + b0 * img), STEM && xbytes > CI_OOB - 1 ? CI_OOB - 1 : xbytes);
+    const int pixoff0 = ((b_ - b0) * p.H + hi0) * p.W + wi0;
+    int coloff[STEM ? 16 : 1];
+    if (STEM) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int slot = hf * 16 + j, wi = wi0 + slot / 3;
+            coloff[j] = (slot < p.KW * 3 && wi >= 0 && wi < p.W) ? (wi0 * 3 + slot) * 4 : CI_OOB;
+        }
+    }
     const int a_chunk0 = (hf * 2) ^ ((ar >> 1) & 7), a_chunk1 = (hf * 2 + 1) ^ ((ar >> 1) & 7);
     const int a_chunk2 = (4 + hf * 2) ^ ((ar >> 1) & 7), a_chunk3 = (5 + hf * 2) ^ ((ar >> 1) & 7);
 
-    cf4 areg[4];
-    // K block (kh, kw, cb) of the general form / kernel row kh of the stem -> registers (zeros outside the image)
-    auto a_load = [&](int kh, int kw, int cb) {
+    // K block (kh, kw, cb) of the general form / kernel row kh of the stem -> one of two register sets (zeros outside the image)
+    cf4 ra0[4], ra1[4];
+    auto a_load = [&](cf4 (&areg)[4], int kh, int kw, int cb) {
         if (!STEM) {
+            // buffer loads: a tap outside the image gets an offset past the descriptor's range and the hardware returns zeros -- nothing
+            // touches the registers between the load and the split one K block later, so no wait lands in front of the products
             const int hi = hi0 + kh;
             const int wi = wi0 + kw;
             const bool in = pvalid && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
-            const cf4 *src = (const cf4 *)(p.x + (((int64_t)b_ * p.H + (in ? hi : 0)) * p.W + (in ? wi : 0)) * p.Cin + cb * 32 + hf * 16);
+            const int voff = in ? (pixoff0 + kh * p.W + kw) * (p.Cin * 4) + hf * 64 : 0x7fffffff;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const cf4 v = src[q];
-                areg[q] = in ? v : (cf4)(0.0f);
-            }
+            for (int q = 0; q < 4; ++q) areg[q] = ci_bload16(rsX, voff + q * 16, cb * 128);
         } else {
-            // stem: K block = kernel row kh; slot j = kw * 3 + c of it is float wi0 * 3 + j of image row hi0 + kh
+            // stem: K block = kernel row kh; slot j = kw * 3 + c of it is float wi0 * 3 + j of image row hi0 + kh.  One 4-byte buffer load
+            // per slot (the run starts at an odd float): a slot outside the row carries the sentinel in its column offset, a row outside
+            // the image the sentinel in the row offset -- either way the offset is past the descriptor and the hardware returns zero
             const int hi = hi0 + kh;
             const bool rowin = pvalid && hi >= 0 && hi < p.H;
-            const float *src = p.x + (((int64_t)b_ * p.H + (rowin ? hi : 0)) * p.W) * 3;
-            const int nslot = p.KW * 3;
+            const int rowoff = rowin ? ((b_ - b0) * p.H + hi) * p.W * 12 : CI_OOB;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float v[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int slot = hf * 16 + q * 4 + e;
-                    const int wi = wi0 + slot / 3;
-                    const bool in = rowin && slot < nslot && wi >= 0 && wi < p.W;
-                    v[e] = in ? src[wi0 * 3 + slot] : 0.0f;
-                }
+                for (int e = 0; e < 4; ++e) v[e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsX, rowoff + coloff[q * 4 + e], 0, 0));
                 areg[q] = (cf4){v[0], v[1], v[2], v[3]};
             }
         }
     };
     // split the registers into pairs and write them into stage `st`'s row image
-    auto a_store = [&](int st) {
+    auto a_store = [&](const cf4 (&areg)[4], int st) {
         char *row = smem + st * STAGE + ar * CI_ROWB;
         unsigned hh[8], ll[8];
 #pragma unroll
@@ -225,23 +239,47 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
         if (STEM) { ++kh; return; }
         if (++cb == p.ncb) { cb = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
     };
-    a_load(kh, kw, cb);
-    b_load(0, 0);
-    a_store(0);
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    for (int k = 0; k < p.nk; ++k) {
-        const int cur = k & 1;
-        const bool more = k + 1 < p.nk;
-        if (more) {
-            advance();
-            a_load(kh, kw, cb);
-            b_load(cur ^ 1, k + 1);
-        }
+    // Pipeline: the activation block is fetched TWO K blocks ahead (two register sets, the loop unrolled by two so that the sets are
+    // named at compile time), split and written into LDS one block ahead; the weight block comes one block ahead by LDS-DMA.  Requests of
+    // a step are issued weights first, so the step's closing wait can be COUNTED -- vmcnt(4): the four activation loads of block k + 2
+    // stay in flight across the raw barrier (a workgroup's K step is 12-24 MFMAs per wave: with the loads of block k + 1 issued at its
+    // top, as in the first form, every step ended in an L2 round trip; the stem's sixteen 4-byte loads per block: vmcnt(16)).
+    // s_waitcnt simm16 on gfx9: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] << 14
+    // The steady loop is written without conditions (the tail of up to three blocks is peeled, its flags literals): with `if (more)`
+    // around the loads and the split, the compiler's wait-count model has to assume that a register set may still be in flight at the
+    // loop header and puts vmcnt(0) in front of the products.
+    auto step = [&](const bool more1, const bool more2, int k, int cur, const cf4 (&rnext)[4], cf4 (&rpref)[4]) {
+        if (more1) b_load(cur ^ 1, k + 1);
+        if (more2) { advance(); a_load(rpref, kh, kw, cb); }
+        __builtin_amdgcn_sched_barrier(0);             // (the scheduler otherwise sinks the loads to the step's end: one block ahead again)
         multiply(smem + cur * STAGE);
-        if (more) a_store(cur ^ 1);
-        __builtin_amdgcn_s_waitcnt(0);                 // my weight requests have landed, my LDS traffic is done
-        __syncthreads();
+        if (more1) a_store(rnext, cur ^ 1);
+        if (more2) __builtin_amdgcn_s_waitcnt(STEM ? (0 | (7 << 4) | (0 << 8) | (1 << 14))      // vmcnt(16) lgkmcnt(0)
+                                                   : (4 | (7 << 4) | (0 << 8)));                // vmcnt(4) lgkmcnt(0)
+        else __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_s_barrier();
+    };
+    a_load(ra0, kh, kw, cb);
+    b_load(0, 0);
+    a_store(ra0, 0);
+    if (p.nk > 1) { advance(); a_load(ra1, kh, kw, cb); }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_s_barrier();
+    int k = 0;
+    for (; k + 3 < p.nk; k += 2) {
+        step(true, true, k, 0, ra1, ra0);
+        step(true, true, k + 1, 1, ra0, ra1);
+    }
+    const int left = p.nk - k;                         // 1 (nk = 1), 2 or 3
+    if (left == 3) {
+        step(true, true, k, 0, ra1, ra0);
+        step(true, false, k + 1, 1, ra0, ra1);
+        step(false, false, k + 2, 0, ra1, ra0);
+    } else if (left == 2) {
+        step(true, false, k, 0, ra1, ra0);
+        step(false, false, k + 1, 1, ra0, ra1);
+    } else {
+        step(false, false, k, 0, ra1, ra0);
     }
 
     // ---- epilogue: lane = output channel (128-byte runs per pixel), 16 pixels per accumulator tile
@@ -296,6 +334,8 @@ CSLAM_API int cslam_conv_igemm_h2_dev(const float *d_x, const void *d_w2, const 
     const int64_t P = (int64_t)B * a.Ho * a.Wo;
     ARG_CHECK(P < (1ll << 31) && P * Cout < (1ll << 40), "too many output pixels for one launch");
     a.P = (int)P;
+    // the activation descriptor starts at the image of a tile's first pixel: the tile's CI_TM pixels then span this many images
+    ARG_CHECK((int64_t)(CI_TM / (a.Ho * a.Wo) + 2) * H * W * Cin * 4 < (stem ? CI_OOB - 1 : 0x7fffffffll), "image too large for 32-bit activation offsets");
     a.ncb = stem ? 0 : Cin / 32;
     a.nk = stem ? KH : KH * KW * (Cin / 32);
     a.relu = relu; a.amax_in = d_amax_in; a.inv_sw = inv_sw; a.amax_out = d_amax_out;
