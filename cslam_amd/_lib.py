@@ -70,9 +70,11 @@ _SIGNATURES = {
     "cslam_vlad_aggregate_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp]),
     "cslam_vlad_aggregate_nhwc_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i64, _vp]),
     "cslam_gem_fc_head_dev": (_i, [_vp, _f, _f, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "cslam_gem_fc_head_nhwc_dev": (_i, [_vp, _f, _f, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "cslam_pca_project_dev": (_i, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "cslam_pca_project_pairs_dev": (_i, [_vp, _i64, C.c_float, _vp, C.c_float, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "cslam_preprocess_dev": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(_f * 3), C.POINTER(_f * 3), _vp, _vp]),
+    "cslam_preprocess_nhwc_dev": (_i, [_vp, _i, _i, _i, _i, _i, C.POINTER(_f * 3), C.POINTER(_f * 3), _vp, _vp]),
     "cslam_mac_grad_dev": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp]),
     "cslam_csr_spmm_dev": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _vp, _vp]),
     "cslam_csr_spmm4_dev": (_i, [_vp, _vp, _vp, _i64, _vp, _vp, _vp]),

@@ -950,6 +950,74 @@ CSLAM_API int cslam_gem_fc_head_dev(const float *d_feat, float p, float eps, con
     return CSLAM_OK;
 }
 
+// The same head on a channels_last map, feat [B][P][C] (what the trunks of vpr/winograd.py write): the pixel norms are wave
+// reductions over contiguous channel runs, the GeM sums read a pixel's channels coalesced; one workgroup per frame as above.
+// C a multiple of 4 (16-byte runs).
+__global__ __launch_bounds__(256) void gem_fc_nhwc_kernel(const float *__restrict__ feat, float pw, float eps,
+                                                          const float *__restrict__ W, const float *__restrict__ bias,
+                                                          int C, int P, int Dout, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *invn = (float *)smem;          // [P]
+    float *g = invn + P;                  // [C]
+    float *o = g + C;                     // [Dout]
+    float *red = o + Dout;                // [16]
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
+    const float *x = feat + (size_t)blockIdx.x * C * P;
+    const int C4 = C >> 2;
+    for (int p = wave; p < P; p += nw) {                               // L2Norm over channels per pixel (layers.py:32-36)
+        const float4 *xr = (const float4 *)(x + (size_t)p * C);
+        float s = 0.0f;
+        for (int c = lane; c < C4; c += 64) { const float4 v = xr[c]; s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+        s = wave_sum_f32(s);
+        if (lane == 0) invn[p] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+    }
+    __syncthreads();
+    const float ip = 1.0f / pw, invP = 1.0f / (float)P;                // GeM (layers.py:8-9): avg_pool(clamp(x, min=eps)^p)^(1/p)
+    const bool cube = pw == 3.0f;                                      // the reference's trained p starts at 3: x^3 without powf
+    for (int c = tid; c < C; c += nt) {
+        float s = 0.0f;
+        for (int p = 0; p < P; ++p) {
+            const float v = fmaxf(x[(size_t)p * C + c] * invn[p], eps);
+            s += cube ? v * v * v : powf(v, pw);
+        }
+        g[c] = powf(s * invP, ip);
+    }
+    __syncthreads();
+    for (int d = wave; d < Dout; d += nw) {                            // Linear (network.py:27): one wave per output feature
+        const float4 *wr = (const float4 *)(W + (size_t)d * C);
+        float s = 0.0f;
+        for (int c = lane; c < C4; c += 64) {
+            const float4 w = wr[c];
+            const float4 gv = *(const float4 *)(g + 4 * c);
+            s += w.x * gv.x + w.y * gv.y + w.z * gv.z + w.w * gv.w;
+        }
+        s = wave_sum_f32(s);
+        if (lane == 0) o[d] = s + (bias ? bias[d] : 0.0f);
+    }
+    __syncthreads();
+    float s = 0.0f;
+    for (int d = tid; d < Dout; d += nt) s += o[d] * o[d];
+    float nrm = sqrtf(block_sum_f32(s, red));
+    float sc = 1.0f / fmaxf(nrm, 1e-12f);
+    for (int d = tid; d < Dout; d += nt) out[(size_t)blockIdx.x * Dout + d] = o[d] * sc;
+}
+
+CSLAM_API int cslam_gem_fc_head_nhwc_dev(const float *d_feat, float p, float eps, const float *d_W,
+                                         const float *d_b, int B, int C, int P, int Dout,
+                                         float *d_out, void *stream) {
+    PTR_DEVICE(d_feat);
+    ARG_CHECK(d_feat && d_W && d_out, "NULL argument");
+    ARG_CHECK(B >= 0 && C >= 4 && (C % 4) == 0 && P >= 1 && Dout >= 1, "bad sizes (C must be a multiple of 4)");
+    size_t lds = (size_t)(P + C + Dout + 16) * 4;
+    ARG_CHECK(lds <= 150 * 1024, "C + P + Dout too large for one workgroup's LDS");
+    if (B == 0) return CSLAM_OK;
+    HIP_TRY(hipFuncSetAttribute((const void *)gem_fc_nhwc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(gem_fc_nhwc_kernel, dim3(B), dim3(256), lds, (hipStream_t)stream, d_feat, p, eps, d_W, d_b, C,
+                       P, Dout, d_out);
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
 // ------------------------------------------------------------ image transform ----
 // Pillow's antialiased resampling (Resample.c, 8 bits per channel), restated:
 //   coefficients: precompute_coeffs() in double, bicubic a = -0.5, support = 2 * max(scale, 1),
@@ -1067,7 +1135,7 @@ __device__ __forceinline__ void pp_load_rows(const uint8_t *__restrict__ img, ui
 __global__ __launch_bounds__(256) void preprocess_fused_kernel(
     const uint8_t *__restrict__ img, int H, int W, int crop, int top, int left, int ptop, int pleft, int ty,
     int out_hw, int ksize, int max_rows, const int *__restrict__ bounds, const int *__restrict__ kk,
-    float m0, float m1, float m2, float s0, float s1, float s2, float *__restrict__ out) {
+    float m0, float m1, float m2, float s0, float s1, float s2, float *__restrict__ out, int nhwc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int in_row_bytes = (crop * 3 + 3) & ~3;        // padded to dwords
     const int tmp_row_bytes = out_hw * 3;
@@ -1113,8 +1181,11 @@ __global__ __launch_bounds__(256) void preprocess_fused_kernel(
         const int ymin = s_bounds[y * 2], yn = s_bounds[y * 2 + 1];
         const int *k = s_kk + y * ksize;
         const uint8_t *base = s_tmp + (size_t)(ymin - rlo) * tmp_row_bytes;
-        float *o0 = out + (((size_t)b * 3 + 0) * out_hw + y) * out_hw;
-        float *o1 = o0 + (size_t)out_hw * out_hw, *o2 = o1 + (size_t)out_hw * out_hw;
+        // planar [B,3,h,w]: three coalesced rows; nhwc [B,h,w,3]: the same three pointers one float apart, pixel pitch 3
+        float *o0 = nhwc ? out + ((size_t)b * out_hw + y) * out_hw * 3 : out + (((size_t)b * 3 + 0) * out_hw + y) * out_hw;
+        const size_t plane = nhwc ? 1 : (size_t)out_hw * out_hw;
+        const int xs = nhwc ? 3 : 1;
+        float *o1 = o0 + plane, *o2 = o1 + plane;
         for (int xo = lane; xo < out_hw; xo += 64) {
             const uint8_t *src = base + xo * 3;
             int a0 = 1 << (PREC_BITS - 1), a1 = a0, a2 = a0;
@@ -1123,9 +1194,9 @@ __global__ __launch_bounds__(256) void preprocess_fused_kernel(
                 const uint8_t *q = src + (size_t)j * tmp_row_bytes;
                 a0 += (int)q[0] * kj; a1 += (int)q[1] * kj; a2 += (int)q[2] * kj;
             }
-            o0[xo] = ((float)clip8(a0) / 255.0f - m0) / s0;        // ToTensor, Normalize
-            o1[xo] = ((float)clip8(a1) / 255.0f - m1) / s1;
-            o2[xo] = ((float)clip8(a2) / 255.0f - m2) / s2;
+            o0[xo * xs] = ((float)clip8(a0) / 255.0f - m0) / s0;        // ToTensor, Normalize
+            o1[xo * xs] = ((float)clip8(a1) / 255.0f - m1) / s1;
+            o2[xo * xs] = ((float)clip8(a2) / 255.0f - m2) / s2;
         }
     }
 }
@@ -1145,7 +1216,7 @@ template <int KS>
 __global__ __launch_bounds__(512) void preprocess_tile_kernel(
     const uint8_t *__restrict__ img, int H, int W, int crop, int top, int left, int ptop, int pleft, int ty,
     int out_hw, int max_rows, const int *__restrict__ bounds, const int *__restrict__ kk,
-    float m0, float m1, float m2, float s0, float s1, float s2, float *__restrict__ out) {
+    float m0, float m1, float m2, float s0, float s1, float s2, float *__restrict__ out, int nhwc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int in_row_bytes = (crop * 3 + 3) & ~3;
     const int tmp_pitch = (out_hw * 3 + 3) & ~3;
@@ -1228,6 +1299,11 @@ __global__ __launch_bounds__(512) void preprocess_tile_kernel(
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const uint8_t *q = s_out + (size_t)yo * tmp_pitch;
+        if (nhwc) {                                                   // [B,h,w,3]: the row is 3 w consecutive floats, byte j -> float j
+            float *o = out + ((size_t)b * out_hw + y) * out_hw * 3;
+            for (int j = lane; j < out_hw * 3; j += 64) o[j] = s_lut[(j % 3) * 256 + q[j]];
+            continue;
+        }
         float *o0 = out + (((size_t)b * 3 + 0) * out_hw + y) * out_hw;
         float *o1 = o0 + (size_t)out_hw * out_hw, *o2 = o1 + (size_t)out_hw * out_hw;
         for (int xo = lane; xo < out_hw; xo += 64) {
@@ -1249,8 +1325,8 @@ static std::mutex g_pp_mutex;          // extractors on several threads share th
 // extractor with a different crop is used in between.
 static std::vector<PreprocCache *> g_pp_all;
 
-CSLAM_API int cslam_preprocess_dev(const uint8_t *d_img, int B, int H, int W, int crop, int out_hw,
-                                   const float mean[3], const float std_[3], float *d_out, void *stream) {
+static int preprocess_launch(const uint8_t *d_img, int B, int H, int W, int crop, int out_hw,
+                             const float mean[3], const float std_[3], float *d_out, int nhwc, void *stream) {
     PTR_DEVICE(d_img);
     ARG_CHECK(d_img && d_out && mean && std_, "NULL argument");
     ARG_CHECK(B >= 0 && crop >= 1 && out_hw >= 1, "bad sizes");
@@ -1325,7 +1401,7 @@ CSLAM_API int cslam_preprocess_dev(const uint8_t *d_img, int B, int H, int W, in
                                     (int)lds2));                                                                              \
         hipLaunchKernelGGL(preprocess_tile_kernel<KS_>, grid, dim3(512), lds2, st, d_img, H, W, crop, top, left, ptop, pleft, \
                            g_pp.ty2, out_hw, g_pp.max_rows2, g_pp.d_bounds, g_pp.d_kk, mean[0], mean[1], mean[2], std_[0],    \
-                           std_[1], std_[2], d_out);                                                                          \
+                           std_[1], std_[2], d_out, nhwc);                                                                    \
         break;
         switch (g_pp.ksize) {
             PP_TILE(5) PP_TILE(7) PP_TILE(9) PP_TILE(11) PP_TILE(13)
@@ -1341,7 +1417,16 @@ CSLAM_API int cslam_preprocess_dev(const uint8_t *d_img, int B, int H, int W, in
                                 (int)lds));
     hipLaunchKernelGGL(preprocess_fused_kernel, dim3((out_hw + g_pp.ty - 1) / g_pp.ty, B), dim3(256), lds, st, d_img, H,
                        W, crop, top, left, ptop, pleft, g_pp.ty, out_hw, g_pp.ksize, g_pp.max_rows, g_pp.d_bounds,
-                       g_pp.d_kk, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], d_out);
+                       g_pp.d_kk, mean[0], mean[1], mean[2], std_[0], std_[1], std_[2], d_out, nhwc);
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
+}
+CSLAM_API int cslam_preprocess_dev(const uint8_t *d_img, int B, int H, int W, int crop, int out_hw,
+                                   const float mean[3], const float std_[3], float *d_out, void *stream) {
+    return preprocess_launch(d_img, B, H, W, crop, out_hw, mean, std_, d_out, 0, stream);
+}
+/* the same transform with the output as [B, out_hw, out_hw, 3] (what the trunks' first convolution reads: channels_last storage) */
+CSLAM_API int cslam_preprocess_nhwc_dev(const uint8_t *d_img, int B, int H, int W, int crop, int out_hw,
+                                        const float mean[3], const float std_[3], float *d_out, void *stream) {
+    return preprocess_launch(d_img, B, H, W, crop, out_hw, mean, std_, d_out, 1, stream);
 }

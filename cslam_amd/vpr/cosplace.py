@@ -62,7 +62,7 @@ class GeoLocalizationNet(object):
                 else WinogradResNet(self.backbone, 64, tile))
 
     @torch.no_grad()
-    def forward(self, x, backbone_dtype=None, runner=None):
+    def forward(self, x, backbone_dtype=None, runner=None, x_bound=None):
         if backbone_dtype is not None and backbone_dtype != torch.float32:
             with torch.autocast("cuda", dtype=backbone_dtype):
                 f = self.backbone(x)
@@ -72,10 +72,10 @@ class GeoLocalizationNet(object):
                 if self.runner is None:
                     self.runner = self.make_runner()
                 runner = self.runner
-            f = runner(x)
+            f = runner(x, x_bound) if isinstance(runner, WinogradResNet) else runner(x)
         else:
             f = self.backbone(x)
-        return heads.gem_fc_head(f.contiguous(), self.gem_p, self.gem_eps, self.fc_weight, self.fc_bias)
+        return heads.gem_fc_head(f, self.gem_p, self.gem_eps, self.fc_weight, self.fc_bias)
 
 
 class CosPlace(object):
@@ -139,8 +139,10 @@ class CosPlace(object):
     @torch.no_grad()
     def compute_embeddings_device(self, frames_u8, backbone_dtype=None, _runner=None):
         """frames [B,H,W,3] uint8 (device) -> descriptors [B, d] float32 (device)."""
-        x = heads.preprocess(frames_u8.contiguous(), self.crop).contiguous(memory_format=torch.channels_last)
-        return self.model.forward(x, backbone_dtype, _runner)
+        # the transform writes channels_last storage (what the trunk reads); a normalised 8-bit image is bounded by its
+        # normalisation constants: saves the first convolution a pass over it
+        x = heads.preprocess(frames_u8.contiguous(), self.crop, channels_last=True)
+        return self.model.forward(x, backbone_dtype, _runner, heads.normalised_image_bound())
 
     def compute_embedding(self, keyframe):
         """Global image descriptor of one RGB keyframe (reference cosplace.py:81-105)."""

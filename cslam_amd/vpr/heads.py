@@ -26,13 +26,16 @@ def _chk(t, dtype=torch.float32):
         raise _lib.CslamHipError("HIP heads need contiguous device tensors of dtype %s" % dtype)
 
 
-def preprocess(frames_u8, crop, out_hw=224, mean=IMAGENET_DEFAULT_MEAN, std=IMAGENET_DEFAULT_STD):
-    """[B,H,W,3] uint8 RGB -> [B,3,out_hw,out_hw] float32 (netvlad.py:202-208)."""
+def preprocess(frames_u8, crop, out_hw=224, mean=IMAGENET_DEFAULT_MEAN, std=IMAGENET_DEFAULT_STD, channels_last=False):
+    """[B,H,W,3] uint8 RGB -> [B,3,out_hw,out_hw] float32 (netvlad.py:202-208); channels_last: the same tensor in channels_last
+    storage, written so by the kernel (no transposing copy in front of a trunk that reads NHWC)."""
     _chk(frames_u8, torch.uint8)
     B, H, W, _ = frames_u8.shape
-    out = torch.empty((B, 3, out_hw, out_hw), dtype=torch.float32, device=frames_u8.device)
+    out = torch.empty((B, 3, out_hw, out_hw), dtype=torch.float32, device=frames_u8.device,
+                      memory_format=torch.channels_last if channels_last else torch.contiguous_format)
     m, s = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
-    _lib.check(_lib.load().cslam_preprocess_dev(_p(frames_u8), B, H, W, int(crop), int(out_hw), C.byref(m),
+    lib = _lib.load()
+    _lib.check((lib.cslam_preprocess_nhwc_dev if channels_last else lib.cslam_preprocess_dev)(_p(frames_u8), B, H, W, int(crop), int(out_hw), C.byref(m),
                                                 C.byref(s), _p(out), _stream(out)))
     return out
 
@@ -75,11 +78,20 @@ def vlad_aggregate(feat, assign_w, assign_b, centroids, out=None):
 
 
 def gem_fc_head(feat, p, eps, W, b):
-    """[B,C,h,w] -> [B,Dout]  L2Norm->GeM->Flatten->Linear->L2Norm (network.py:23-29)."""
-    _chk(feat); _chk(W)
+    """[B,C,h,w] -> [B,Dout]  L2Norm->GeM->Flatten->Linear->L2Norm (network.py:23-29).  A channels_last map (what the trunks of
+    vpr/winograd.py write) is read in place; otherwise the map must be contiguous NCHW."""
+    _chk(W)
     B, Cc = feat.shape[:2]
     P = feat.shape[2] * feat.shape[3]
     out = torch.empty((B, W.shape[0]), dtype=torch.float32, device=feat.device)
+    if (feat.is_cuda and feat.dtype == torch.float32 and Cc % 4 == 0 and not feat.is_contiguous()
+            and feat.is_contiguous(memory_format=torch.channels_last)):
+        _lib.check(_lib.load().cslam_gem_fc_head_nhwc_dev(_p(feat), float(p), float(eps), _p(W),
+                                                          _p(b) if b is not None else None, B, Cc, P, W.shape[0],
+                                                          _p(out), _stream(out)))
+        return out
+    feat = feat.contiguous()
+    _chk(feat)
     _lib.check(_lib.load().cslam_gem_fc_head_dev(_p(feat), float(p), float(eps), _p(W),
                                                  _p(b) if b is not None else None, B, Cc, P, W.shape[0],
                                                  _p(out), _stream(out)))

@@ -499,9 +499,9 @@ class _FoldedConv(object):
             # (csrc/conv_igemm.hip) instead of torch / MIOpen
             self.Wg = igemm_pair_weights(self.weight)
             self.Wg = (self.Wg[0].to(self.weight.device), self.Wg[1])
-        # (layer1 of ResNet-18/34 can run through the one-kernel form of csrc/wino_fused.hip, shortcut fused, but on its
-        # 56 x 56 maps V and M of a 250-frame chunk -- 0.45 GB each -- largely stay in the 256 MB Infinity Cache and the
-        # F(4x4) pipeline wins: 31.8k vs 30.9k frames/s, profiles/r01_perf_c2.log.  Not wired in.)
+        # (layer1 of ResNet-18/34 through the one-kernel F(4x4) forms -- csrc/wino_fused.hip, round 1: 30.9k vs 31.8k frames/s; csrc/
+        # wino_fused_h.hip on fp16 pairs with the shortcut fused, round 5 against the implicit GEMM: extract 45.9k vs 51.3k frames/s,
+        # three alternating runs on one box -- is slower on 56 x 56 maps.  Not wired in.)
 
     def __call__(self, ws, x, relu, residual=None, amax_in=None, amax_out=None):
         """amax_in: 4-byte device slot with (a bound of) max |x|, or None; amax_out: zeroed slot for max |y|.  `ws.amax_written` says
@@ -551,11 +551,12 @@ class WinogradResNet(_Workspace):
         return self
 
     @torch.no_grad()
-    def __call__(self, x):
+    def __call__(self, x, x_bound=None):
+        """x_bound: a known bound of max |x| (a normalised 8-bit image: heads.normalised_image_bound()) spares the pass that measures it."""
         x = x.contiguous(memory_format=torch.channels_last)
         # max |activation| travels from the epilogue that produced a map to the kernels that read it (4-byte device slots, the power-of-two
         # scale of the fp16 pairs): no pass over an activation just to measure it.  `ax` = slot of the current x, or None (unknown)
-        slots = self._buf("amax_slots", 4 * len(self.blocks) + 4, x.device)
+        slots = self._buf("amax_slots", 4 * len(self.blocks) + 5, x.device)
         slots.zero_()
         nslot = [0]
 
@@ -567,7 +568,11 @@ class WinogradResNet(_Workspace):
             out_slot = fresh()
             y = conv(self, inp, relu, res, a_in, out_slot)
             return y, (out_slot if self.amax_written else None)
-        y, ax = run(self.stem, x, True, None, None)
+        a0 = None
+        if x_bound is not None:
+            a0 = fresh()
+            a0.fill_(float(x_bound))
+        y, ax = run(self.stem, x, True, None, a0)
         x = self.stem_pool(y)                             # max |pool(y)| <= max |y|: the slot stays a bound
         for b in self.blocks:
             idt = x if b["down"] is None else run(b["down"], x, False, None, ax)[0]

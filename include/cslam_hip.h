@@ -179,6 +179,10 @@ int cslam_vlad_aggregate_nhwc_dev(const float *d_feat, const float *d_assign_w, 
 int cslam_gem_fc_head_dev(const float *d_feat, float p, float eps, const float *d_W,
                           const float *d_b, int B, int C, int P, int Dout,
                           float *d_out, void *stream);
+/* the same head on a channels_last map: feat [B, P, C], C a multiple of 4 */
+int cslam_gem_fc_head_nhwc_dev(const float *d_feat, float p, float eps, const float *d_W,
+                               const float *d_b, int B, int C, int P, int Dout,
+                               float *d_out, void *stream);
 /* PCA projection + row L2, cslam/vpr/netvlad.py:234-236 (sklearn PCA.transform + normalize):
  *   y = x @ comp^T - mean_proj ;  y *= inv_scale (whitening) ;  y /= ||y|| (zero rows stay zero)
  * comp [Dout, Din]; mean_proj [Dout] = mean @ comp^T (precomputed once by the caller) or NULL;
@@ -202,6 +206,10 @@ int cslam_pca_project_pairs_dev(const float *d_x, int64_t ldx, float x_bound, co
  * img [B, H, W, 3] uint8 RGB; out [B, 3, out_hw, out_hw] float32. */
 int cslam_preprocess_dev(const uint8_t *d_img, int B, int H, int W, int crop, int out_hw,
                          const float mean[3], const float std_[3], float *d_out, void *stream);
+/* the same transform, out [B, out_hw, out_hw, 3] float32: the channels_last storage the trunks' first convolution reads
+ * (cosplace.py:73-79 feeds `self.model(...)` directly; the layout is this library's choice) */
+int cslam_preprocess_nhwc_dev(const uint8_t *d_img, int B, int H, int W, int crop, int out_hw,
+                              const float mean[3], const float std_[3], float *d_out, void *stream);
 
 /* ---- candidate sparsifier pieces (cslam/mac/mac.py) --------------------------- */
 /* grad_from_fiedler, mac.py:112-130: g[k] = w[k] * (v[i_k] - v[j_k])^2, float64 */

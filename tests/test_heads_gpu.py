@@ -81,6 +81,24 @@ def test_cosplace_head_matches_reference_modules(g, T):
         assert np.max(np.abs(y - g[f"gem_{tag}/y"])) < 1e-5
         assert np.max(np.abs(y - ho.cosplace_head(x, p, 1e-6, W, b))) < 1e-5
         assert np.allclose(np.linalg.norm(y, axis=1), 1.0, atol=1e-5)
+        if x.ndim == 4 and x.shape[1] % 4 == 0:
+            # the same map in channels_last storage (what the trunks write) goes through the NHWC kernel
+            xc = dev(T, x).contiguous(memory_format=torch.channels_last)
+            assert not xc.is_contiguous() or x.shape[2] * x.shape[3] == 1
+            yc = heads.gem_fc_head(xc, p, 1e-6, dev(T, W), dev(T, b)).cpu().numpy()
+            assert np.max(np.abs(yc - g[f"gem_{tag}/y"])) < 1e-5 and np.max(np.abs(yc - y)) < 2e-6
+
+
+def test_preprocess_channels_last_output_equals_planar(T):
+    """cslam_preprocess_nhwc_dev writes the same values as cslam_preprocess_dev, in channels_last storage."""
+    torch, heads = T
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    for (H, W, crop, out_hw) in [(480, 640, 376, 224), (300, 280, 260, 224), (100, 120, 376, 96)]:
+        fr = torch.randint(0, 256, (3, H, W, 3), generator=gen, device="cuda", dtype=torch.uint8)
+        a = heads.preprocess(fr, crop, out_hw)
+        b = heads.preprocess(fr, crop, out_hw, channels_last=True)
+        assert b.shape == a.shape and b.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(a, b)
 
 
 def test_pca_project_matches_sklearn(g, T):
