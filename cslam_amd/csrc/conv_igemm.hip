@@ -43,6 +43,7 @@ struct ConvIgemmArgs {
     int nk;                // K blocks: KH KW Cin / 32 (STEM: KH)
     int ncb;               // Cin / 32
     int relu;
+    int pool;              // stem only: MaxPool2d(3, 2, 1) of the ReLU output fused (8 x 16-pixel tiles, y = the POOLED map, zeroed by the host)
     const unsigned *amax_in; float inv_sw; unsigned *amax_out;
 };
 
@@ -98,10 +99,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
 
     // ---- this thread's share of the activation tile: pixel row tid >> 1, channels 16 (tid & 1) .. + 15 of every K block
     const int ar = tid >> 1, hf = tid & 1;
+    // 1-D tiles: CI_TM consecutive pixels of the [B][Ho][Wo] order; pooled stem: 8 x 16-pixel tiles of one image (tile row tr, column tc)
+    const bool tile2d = STEM && p.pool;
+    int tr = 0, tc = 0, tb = 0;
+    if (tile2d) {
+        const int tcols = p.Wo >> 4, tpi = (p.Ho >> 3) * tcols;
+        tb = mt / tpi;
+        const int t = mt - tb * tpi;
+        tr = t / tcols;
+        tc = t - tr * tcols;
+    }
     const int pix = mt * CI_TM + ar;
-    const bool pvalid = pix < p.P;
+    const bool pvalid = tile2d || pix < p.P;
     int b_, hi0, wi0;
-    {
+    if (tile2d) {
+        b_ = tb;
+        hi0 = (tr * 8 + (ar >> 4)) * p.stride - p.pad;
+        wi0 = (tc * 16 + (ar & 15)) * p.stride - p.pad;
+    } else {
         const int pp = pvalid ? pix : 0;
         const int hw = p.Ho * p.Wo;
         b_ = pp / hw;
@@ -112,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
     }
     const float sc = ci_scale(*p.amax_in);
     // descriptor from the image of the workgroup's first pixel on (the host checks that a tile's span of images stays below 2^31 bytes)
-    const int b0 = __builtin_amdgcn_readfirstlane((int)(((int64_t)mt * CI_TM) / (p.Ho * p.Wo)));
+    const int b0 = __builtin_amdgcn_readfirstlane(tile2d ? tb : (int)(((int64_t)mt * CI_TM) / (p.Ho * p.Wo)));
     const int64_t img = (int64_t)p.H * p.W * p.Cin;
     const int64_t xbytes = (int64_t)(p.B - b0) * img * 4;
     const __amdgpu_buffer_rsrc_t rsX = ci_rsrc((const char *)(p.x + b0 * img), STEM && xbytes > CI_OOB - 1 ? CI_OOB - 1 : xbytes);
@@ -285,6 +300,51 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
     // ---- epilogue: lane = output channel (128-byte runs per pixel), 16 pixels per accumulator tile
     const float inv = p.inv_sw / sc;
     float amax = 0.0f;
+    if (tile2d) {
+        // ReLU(conv + bias) of the tile -> LDS [pixel 128][channel TN] (the stages are free: the last step ended in a barrier), then
+        // MaxPool2d(3, 2, 1): the tile owns pooled pixels (4 tr + pr, 8 tc + pc), pr 0..4, pc 0..8 -- the maximum over the window's
+        // pixels INSIDE this tile; a window that lies in one tile is stored, the others (first pooled row / column of a tile and the
+        // row / column it hands to its neighbours) are completed with atomic maxima on the bit patterns (values >= 0; y starts at zero)
+        float *T = (float *)smem;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int cl = wn * (TN / 2) + n * 32 + l31;
+            const float bv = p.bias ? p.bias[nt * TN + cl] : 0.0f;
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float v = fmaxf(acc[m][n][r] * inv + bv, 0.0f);
+                    T[row * TN + cl] = v;
+                    amax = fmaxf(amax, v);
+                }
+        }
+        __syncthreads();
+        const int Hp = p.Ho >> 1, Wp = p.Wo >> 1;
+        for (int it = tid; it < 45 * TN; it += 256) {
+            const int ch = it & (TN - 1), pp = it / TN;
+            const int pr = pp / 9, pc = pp - pr * 9;
+            const int gp = tr * 4 + pr, gq = tc * 8 + pc;
+            if (gp >= Hp || gq >= Wp) continue;
+            float mx = 0.0f;
+#pragma unroll
+            for (int dr = -1; dr <= 1; ++dr) {
+                const int lr = 2 * pr + dr;
+                if (lr < 0 || lr > 7) continue;
+#pragma unroll
+                for (int dc = -1; dc <= 1; ++dc) {
+                    const int lc = 2 * pc + dc;
+                    if (lc < 0 || lc > 15) continue;
+                    mx = fmaxf(mx, T[(lr * 16 + lc) * TN + ch]);
+                }
+            }
+            float *dst = p.y + (((int64_t)tb * Hp + gp) * Wp + gq) * p.Cout + nt * TN + ch;
+            const bool whole = (pr >= 1 || tr == 0) && pr <= 3 && (pc >= 1 || tc == 0) && pc <= 7;
+            if (whole) *dst = mx;
+            else atomicMax((unsigned *)dst, __float_as_uint(mx));
+        }
+    } else {
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
         const int co = nt * TN + wn * (TN / 2) + n * 32 + l31;
@@ -304,6 +364,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
                 }
             }
     }
+    }
     if (p.amax_out) {
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
@@ -317,9 +378,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
  * block per kernel row, slot kw * 3 + c.  inv_sw = 1 / (the power of two the weights were scaled by).  d_amax_in: 4-byte device slot,
  * float bits of (a bound of) max |x|, > 0; d_amax_out (optional): slot that receives max |y| (atomic maximum: zero it first).
  * Replaces torch.nn.functional.conv2d for the layers named at the top of this file (cslam/vpr/cosplace_utils/network.py:38-68). */
-CSLAM_API int cslam_conv_igemm_h2_dev(const float *d_x, const void *d_w2, const float *d_bias, const float *d_res, int B, int H, int W,
-                                      int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, const unsigned *d_amax_in,
-                                      float inv_sw, unsigned *d_amax_out, float *d_y, void *stream) {
+static int conv_igemm_launch(const float *d_x, const void *d_w2, const float *d_bias, const float *d_res, int B, int H, int W,
+                             int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, int pool, const unsigned *d_amax_in,
+                             float inv_sw, unsigned *d_amax_out, float *d_y, void *stream) {
     PTR_DEVICE(d_x);
     ARG_CHECK(d_x && d_w2 && d_y && d_amax_in, "NULL argument");
     ARG_CHECK(B >= 1 && H >= 1 && W >= 1 && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0, "bad geometry");
@@ -334,15 +395,21 @@ CSLAM_API int cslam_conv_igemm_h2_dev(const float *d_x, const void *d_w2, const 
     const int64_t P = (int64_t)B * a.Ho * a.Wo;
     ARG_CHECK(P < (1ll << 31) && P * Cout < (1ll << 40), "too many output pixels for one launch");
     a.P = (int)P;
+    a.pool = pool;
+    if (pool) {
+        ARG_CHECK(stem && relu && !d_res, "the fused MaxPool2d(3, 2, 1) exists for the stem form with ReLU and without a shortcut");
+        ARG_CHECK(a.Ho % 8 == 0 && a.Wo % 16 == 0, "the fused MaxPool2d needs an output map of 8 x 16-pixel tiles");
+    }
     // the activation descriptor starts at the image of a tile's first pixel: the tile's CI_TM pixels then span this many images
     ARG_CHECK((int64_t)(CI_TM / (a.Ho * a.Wo) + 2) * H * W * Cin * 4 < (stem ? CI_OOB - 1 : 0x7fffffffll), "image too large for 32-bit activation offsets");
     a.ncb = stem ? 0 : Cin / 32;
     a.nk = stem ? KH : KH * KW * (Cin / 32);
     a.relu = relu; a.amax_in = d_amax_in; a.inv_sw = inv_sw; a.amax_out = d_amax_out;
     const int tn = Cout % 128 == 0 ? 128 : 64;
-    const dim3 grid((unsigned)ceil_div64(P, CI_TM), (unsigned)(Cout / tn)), blk(256);
-    const int lds = 2 * (CI_TM + tn) * CI_ROWB;
+    const dim3 grid((unsigned)ceil_div64(P, CI_TM), (unsigned)(Cout / tn)), blk(256);      // (pooled form: P / 128 tiles exactly)
+    const int lds = 2 * (CI_TM + tn) * CI_ROWB;                                              // >= 128 x tn floats, the pooled form's tile
     hipStream_t st = (hipStream_t)stream;
+    if (pool) HIP_TRY(hipMemsetAsync(d_y, 0, (size_t)B * (a.Ho / 2) * (a.Wo / 2) * Cout * sizeof(float), st));
 #define CI_LAUNCH(TN_, ST_) do { \
         static DeviceOnce once; int once_dev; \
         if (once.todo(&once_dev)) { \
@@ -354,4 +421,19 @@ CSLAM_API int cslam_conv_igemm_h2_dev(const float *d_x, const void *d_w2, const 
 #undef CI_LAUNCH
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
+}
+CSLAM_API int cslam_conv_igemm_h2_dev(const float *d_x, const void *d_w2, const float *d_bias, const float *d_res, int B, int H, int W,
+                                      int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, const unsigned *d_amax_in,
+                                      float inv_sw, unsigned *d_amax_out, float *d_y, void *stream) {
+    return conv_igemm_launch(d_x, d_w2, d_bias, d_res, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, 0, d_amax_in, inv_sw, d_amax_out,
+                             d_y, stream);
+}
+/* The stem with its pooling: y = MaxPool2d(3, 2, 1)(ReLU(conv(x, w) + bias)) for x [B,H,W,3] -> y [B,Ho/2,Wo/2,Cout] (Ho a multiple of 8,
+ * Wo of 16: ResNet's 7x7 / 2 stem on 224 x 224 frames gives 112 x 112).  The un-pooled map never exists in HBM; d_amax_out receives max
+ * of the UN-pooled map (a bound of the pooled one).  conv1 + bn1 + relu + maxpool of the torchvision ResNet trunk cslam/vpr/cosplace_utils/network.py:38-68 builds. */
+CSLAM_API int cslam_conv_stem_pool_igemm_h2_dev(const float *d_x, const void *d_w2, const float *d_bias, int B, int H, int W, int Cout,
+                                                int KH, int KW, int stride, int pad, const unsigned *d_amax_in, float inv_sw,
+                                                unsigned *d_amax_out, float *d_y, void *stream) {
+    return conv_igemm_launch(d_x, d_w2, d_bias, nullptr, B, H, W, 3, Cout, KH, KW, stride, pad, 1, 1, d_amax_in, inv_sw, d_amax_out,
+                             d_y, stream);
 }

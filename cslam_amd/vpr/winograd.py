@@ -98,10 +98,20 @@ def igemm_pair_weights(weight):
     return pair.contiguous(), 1.0 / sw
 
 
-def conv_igemm(ws, x, Wg, bias, kernel, stride, pad, relu, residual=None, amax_in=None, amax_out=None):
+def _pair(v):
+    return tuple(v) if isinstance(v, (tuple, list)) else (v, v)
+
+
+def stem_pool_fits(Ho, Wo):
+    """Whether the stem's output map splits into the 8 x 16-pixel tiles of the fused MaxPool2d(3, 2, 1) (csrc/conv_igemm.hip)."""
+    return Ho % 8 == 0 and Wo % 16 == 0
+
+
+def conv_igemm(ws, x, Wg, bias, kernel, stride, pad, relu, residual=None, amax_in=None, amax_out=None, pool=False):
     """y = act(conv(x) + bias (+ residual)) through `cslam_conv_igemm_h2_dev` (csrc/conv_igemm.hip): x [B,Cin,H,W] channels_last
     float32, Wg = `igemm_pair_weights(weight)`, kernel = (KH, KW).  amax_in: 4-byte device slot with (a bound of) max |x| (None:
-    one pass over x measures it); amax_out: zeroed slot that receives max |y|."""
+    one pass over x measures it); amax_out: zeroed slot that receives max |y|.  pool (3-channel stem with ReLU, output map of
+    8 x 16-pixel tiles: `stem_pool_fits`): MaxPool2d(3, 2, 1) fused, y is the pooled map (`cslam_conv_stem_pool_igemm_h2_dev`)."""
     lib = _lib.load()
     x = x.contiguous(memory_format=torch.channels_last)
     B, Cin, H, W = x.shape
@@ -117,6 +127,13 @@ def conv_igemm(ws, x, Wg, bias, kernel, stride, pad, relu, residual=None, amax_i
             _lib.check(lib.cslam_absmax_dev(_p(x), x.numel(), _p(slot), s))
         else:                                                         # the kernel reads 16 bytes per lane: odd sizes through torch
             slot.copy_(x.abs().max().reshape(1))
+    if pool:
+        assert Cin == 3 and relu and residual is None and stem_pool_fits(Ho, Wo)
+        y = torch.empty((B, Cout, Ho // 2, Wo // 2), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        _lib.check(lib.cslam_conv_stem_pool_igemm_h2_dev(_p(x), _p(W2), _p(bias) if bias is not None else None, B, H, W, Cout, KH, KW,
+                                                         stride, pad, _p(slot), float(inv_sw),
+                                                         _p(amax_out) if amax_out is not None else None, _p(y), s))
+        return y
     y = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     if residual is not None:
         residual = residual.contiguous(memory_format=torch.channels_last)
@@ -503,7 +520,7 @@ class _FoldedConv(object):
         # wino_fused_h.hip on fp16 pairs with the shortcut fused, round 5 against the implicit GEMM: extract 45.9k vs 51.3k frames/s,
         # three alternating runs on one box -- is slower on 56 x 56 maps.  Not wired in.)
 
-    def __call__(self, ws, x, relu, residual=None, amax_in=None, amax_out=None):
+    def __call__(self, ws, x, relu, residual=None, amax_in=None, amax_out=None, pool=False):
         """amax_in: 4-byte device slot with (a bound of) max |x|, or None; amax_out: zeroed slot for max |y|.  `ws.amax_written` says
         whether amax_out was filled (the implicit-GEMM kernel always does)."""
         ws.amax_written = False
@@ -511,7 +528,7 @@ class _FoldedConv(object):
             return wino_conv3x3(ws, x.contiguous(memory_format=torch.channels_last), self.U, self.U4, self.bias, relu,
                                 False, residual)
         if self.Wg is not None:
-            y = conv_igemm(ws, x, self.Wg, self.bias, self.kernel, self.stride[0], self.padding[0], relu, residual, amax_in, amax_out)
+            y = conv_igemm(ws, x, self.Wg, self.bias, self.kernel, self.stride[0], self.padding[0], relu, residual, amax_in, amax_out, pool)
             ws.amax_written = amax_out is not None
             return y
         y = torch.nn.functional.conv2d(x, self.weight, self.bias, self.stride, self.padding)
@@ -556,7 +573,7 @@ class WinogradResNet(_Workspace):
         x = x.contiguous(memory_format=torch.channels_last)
         # max |activation| travels from the epilogue that produced a map to the kernels that read it (4-byte device slots, the power-of-two
         # scale of the fp16 pairs): no pass over an activation just to measure it.  `ax` = slot of the current x, or None (unknown)
-        slots = self._buf("amax_slots", 4 * len(self.blocks) + 5, x.device)
+        slots = self._buf("amax_slots", 4 * len(self.blocks) + 6, x.device)
         slots.zero_()
         nslot = [0]
 
@@ -572,8 +589,18 @@ class WinogradResNet(_Workspace):
         if x_bound is not None:
             a0 = fresh()
             a0.fill_(float(x_bound))
-        y, ax = run(self.stem, x, True, None, a0)
-        x = self.stem_pool(y)                             # max |pool(y)| <= max |y|: the slot stays a bound
+        sp = self.stem_pool
+        ho = (x.shape[2] + 2 * self.stem.padding[0] - self.stem.kernel[0]) // self.stem.stride[0] + 1
+        wo = (x.shape[3] + 2 * self.stem.padding[1] - self.stem.kernel[1]) // self.stem.stride[1] + 1
+        if (self.stem.Wg is not None and x.shape[1] == 3 and stem_pool_fits(ho, wo) and isinstance(sp, torch.nn.MaxPool2d)
+                and _pair(sp.kernel_size) == (3, 3) and _pair(sp.stride) == (2, 2) and _pair(sp.padding) == (1, 1)
+                and _pair(sp.dilation) == (1, 1) and not sp.ceil_mode):
+            out_slot = fresh()                            # conv1 + bn1 + relu + maxpool as one kernel: the 112 x 112 map never exists
+            x = self.stem(self, x, True, None, a0, out_slot, pool=True)
+            ax = out_slot
+        else:
+            y, ax = run(self.stem, x, True, None, a0)
+            x = sp(y)                                     # max |pool(y)| <= max |y|: the slot stays a bound
         for b in self.blocks:
             idt = x if b["down"] is None else run(b["down"], x, False, None, ax)[0]
             o, ao = run(b["c1"], x, True, None, ax)

@@ -465,6 +465,12 @@ int cslam_wino4_stem_c64_h_dev(const float *d_x0, const void *d_w1, const float 
 int cslam_conv_igemm_h2_dev(const float *d_x, const void *d_w2, const float *d_bias, const float *d_res, int B, int H, int W,
                             int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, const unsigned *d_amax_in,
                             float inv_sw, unsigned *d_amax_out, float *d_y, void *stream);
+/* the ResNet stem with its pooling, MaxPool2d(3, 2, 1)(ReLU(conv(x, w) + bias)): x [B,H,W,3] -> y [B,Ho/2,Wo/2,Cout], Ho a multiple
+ * of 8 and Wo of 16; the un-pooled map never exists in HBM (conv1, bn1 folded, relu, maxpool of the torchvision trunk that
+ * cslam/vpr/cosplace_utils/network.py:38-68 builds); d_amax_out receives max of the un-pooled map (a bound) */
+int cslam_conv_stem_pool_igemm_h2_dev(const float *d_x, const void *d_w2, const float *d_bias, int B, int H, int W, int Cout,
+                                      int KH, int KW, int stride, int pad, const unsigned *d_amax_in, float inv_sw,
+                                      unsigned *d_amax_out, float *d_y, void *stream);
 
 /* 3x3 / stride 1 / pad 1 convolution 64 -> 128 channels (cslam/vpr/netvlad.py:163-171,227: VGG-16 conv2_1) as ONE direct kernel whose
  * weights (295 KB of exact fp16 pairs) stay in the registers of the four waves of a workgroup, 32 output channels each

@@ -1242,3 +1242,36 @@ def test_implicit_gemm_convolution_on_fp16_pairs_equals_float64(T, B, cin, cout,
     bound = torch.full((1,), float(x.abs().max().item()) * 1.7, device="cuda")
     y2 = wg.conv_igemm(ws, x, wg.igemm_pair_weights(w), bias, (k, k), stride, pad, relu, r, amax_in=bound)
     assert (y2.double() - ref).abs().max().item() / scale <= 4 * e32 + 4e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,cout,k,stride,pad", [(3, 224, 224, 64, 7, 2, 3), (2, 64, 96, 64, 7, 2, 3), (5, 32, 32, 128, 3, 2, 1),
+                                                    (2, 16, 32, 64, 3, 1, 1)])
+def test_stem_with_fused_maxpool_equals_pooling_the_unfused_output(T, B, H, W, cout, k, stride, pad):
+    """`cslam_conv_stem_pool_igemm_h2_dev` (conv1 + bn1 + relu + maxpool of the ResNet trunks as one kernel, 8 x 16-pixel tiles, windows
+    across tiles completed with atomic maxima): EXACTLY MaxPool2d(3, 2, 1) of the un-fused kernel's output (the same products in the
+    same order), which the test above holds against float64; the slot carries max of the un-pooled map; repeated calls agree (the
+    atomics have no order dependence)."""
+    torch, _ = T
+    from cslam_amd.vpr import winograd as wg
+    torch.manual_seed(B * 1000 + H + cout)
+    x = (torch.rand((B, 3, H, W), device="cuda") * 4.6 - 2.2).contiguous(memory_format=torch.channels_last)
+    w = torch.randn((cout, 3, k, k), device="cuda") / (k * 3 ** 0.5)
+    bias = torch.randn(cout, device="cuda") * 0.3
+    Wg = wg.igemm_pair_weights(w)
+    ws = wg._Workspace()
+    s0 = torch.zeros(1, dtype=torch.float32, device="cuda")
+    s1 = torch.zeros(1, dtype=torch.float32, device="cuda")
+    y = wg.conv_igemm(ws, x, Wg, bias, (k, k), stride, pad, True, amax_out=s0)
+    assert wg.stem_pool_fits(y.shape[2], y.shape[3])
+    want = torch.nn.functional.max_pool2d(y, 3, 2, 1)
+    for _ in range(2):
+        s1.zero_()
+        got = wg.conv_igemm(ws, x, Wg, bias, (k, k), stride, pad, True, amax_out=s1, pool=True)
+        torch.cuda.synchronize()
+        assert got.shape == want.shape and got.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(got, want)
+        assert s1.item() == s0.item() == y.max().item()
+    ref = torch.nn.functional.max_pool2d(torch.nn.functional.conv2d(x.double(), w.double(), bias.double(), stride=stride,
+                                                                    padding=pad).relu(), 3, 2, 1)
+    assert (got.double() - ref).abs().max().item() / ref.abs().max().item() < 1e-6
