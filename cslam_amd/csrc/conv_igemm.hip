@@ -45,6 +45,14 @@ struct ConvIgemmArgs {
     int relu;
     int pool;              // stem only: MaxPool2d(3, 2, 1) of the ReLU output fused (8 x 16-pixel tiles, y = the POOLED map, zeroed by the host)
     const unsigned *amax_in; float inv_sw; unsigned *amax_out;
+    // pair-format activations (AM = 2 reads them, out_pairs writes them): [pixel][channel block of 32][hi 32 | lo 32] halfs of s x, s the
+    // power of two ci_scale() derives from the 4-byte BOUND slot that travels with the tensor
+    const unsigned *xbound;            // AM = 2: the bound x's pairs were scaled by
+    int out_pairs;                     // y leaves as pairs scaled by ci_scale(bound_out)
+    float wl1, bmax;                   // max over output channels of sum |w|, max |bias|: bound_out = max|x| wl1 + bmax (+ max|res|)
+    unsigned *bound_out;               // receives that bound (written by workgroup (0, 0))
+    int res_pairs;                     // res is in pair format, scaled by ci_scale(*res_bound)
+    const unsigned *res_bound;         // bound slot of res (pairs) / a bound of max |res| (float32 res, when out_pairs)
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t ci_rsrc(const char *base, int64_t bytes) {
@@ -83,17 +91,27 @@ __host__ __device__ __forceinline__ float ci_sub_half(float v, __half2 h) {     
 #endif
 }
 
-template <int TN, bool STEM>
+// AM: how the activation tile reaches LDS.  0: float32 NHWC, split while it is staged; 1: the 3-channel stem (float32); 2: pair-format
+// NHWC written by a previous layer's epilogue -- the tile is then plain LDS-DMA like the weights, no register, no VALU work per K block
+// Tile: TM pixels x TN output channels on four waves, WM = TM / 64 along the pixels and WN = 4 / WM along the channels: wave tile 64 x
+// TN / WN.  128 x 128 and 128 x 64 (2 x 2 waves); 256 x 64 (4 x 1, pair format only): layers with 64 output channels -- a 64 x 32 wave
+// tile reads one LDS fragment per MFMA, a 64 x 64 one two per three, and the LDS pipe is what bounds these kernels.
+template <int TM, int TN, int AM>
 __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) {
-    constexpr int MT = 2, NT = TN / 64;                // wave tile 64 x TN / 2 in 32 x 32 MFMA tiles
-    constexpr int OPA = CI_TM * CI_ROWB, OPB = TN * CI_ROWB;
+    constexpr bool STEM = AM == 1, PAIRS = AM == 2;
+    constexpr int NST = 2;                             // LDS stages
+    constexpr int WM = TM / 64, WN = 4 / WM, TNW = TN / WN;
+    constexpr int MT = 2, NT = TNW / 32;               // wave tile 64 x TNW in 32 x 32 MFMA tiles
+    constexpr int NLA = TM * 8 / 256;                  // AM = 2: 16-byte activation chunks per thread and stage
+    static_assert(TM == 128 || (TM == 256 && PAIRS), "the register-staged forms are written for 128-pixel tiles");
+    constexpr int OPA = TM * CI_ROWB, OPB = TN * CI_ROWB;
     constexpr int STAGE = OPA + OPB;
     constexpr int NLB = TN * 8 / 256;                  // 16-byte weight chunks per thread and stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int h = lane >> 5, l31 = lane & 31;
     const int mt = blockIdx.x, nt = blockIdx.y;
 
@@ -109,7 +127,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
         tr = t / tcols;
         tc = t - tr * tcols;
     }
-    const int pix = mt * CI_TM + ar;
+    const int pix = mt * TM + ar;
     const bool pvalid = tile2d || pix < p.P;
     int b_, hi0, wi0;
     if (tile2d) {
@@ -125,9 +143,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
         hi0 = ho * p.stride - p.pad;
         wi0 = wo * p.stride - p.pad;
     }
-    const float sc = ci_scale(*p.amax_in);
+    const float sc = ci_scale(PAIRS ? *p.xbound : *p.amax_in);
     // descriptor from the image of the workgroup's first pixel on (the host checks that a tile's span of images stays below 2^31 bytes)
-    const int b0 = __builtin_amdgcn_readfirstlane(tile2d ? tb : (int)(((int64_t)mt * CI_TM) / (p.Ho * p.Wo)));
+    const int b0 = __builtin_amdgcn_readfirstlane(tile2d ? tb : (int)(((int64_t)mt * TM) / (p.Ho * p.Wo)));
     const int64_t img = (int64_t)p.H * p.W * p.Cin;
     const int64_t xbytes = (int64_t)(p.B - b0) * img * 4;
     const __amdgpu_buffer_rsrc_t rsX = ci_rsrc((const char *)(p.x + b0 * img), STEM && xbytes > CI_OOB - 1 ? CI_OOB - 1 : xbytes);
@@ -190,6 +208,35 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
         *(cu4 *)(row + (a_chunk3 << 4)) = (cu4){ll[4], ll[5], ll[6], ll[7]};
     };
 
+    // ---- AM = 2: the activation tile by LDS-DMA.  Chunk pch = i * 256 + tid -> tile row i * 32 + (tid >> 3), physical slot tid & 7 =
+    // logical 16-byte chunk ^ swz(row) of the pixel's 128-byte (tap, channel block) run; a tap outside the image: an offset past the
+    // descriptor, the DMA writes zeros
+    int pa_off[PAIRS ? NLA : 1], pa_h[PAIRS ? NLA : 1], pa_w[PAIRS ? NLA : 1];
+    const int pa_chunk = ((tid & 7) ^ ((tid >> 4) & 7)) << 4;
+    if (PAIRS) {
+#pragma unroll
+        for (int i = 0; i < NLA; ++i) {
+            const int64_t px = (int64_t)mt * TM + i * 32 + (tid >> 3);
+            const int hw = p.Ho * p.Wo;
+            const int pp = px < p.P ? (int)px : 0;
+            const int bb = pp / hw, rem = pp - bb * hw;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            pa_h[i] = px < p.P ? ho * p.stride - p.pad : -(1 << 20);
+            pa_w[i] = wo * p.stride - p.pad;
+            pa_off[i] = (((bb - b0) * p.H + pa_h[i]) * p.W + pa_w[i]) * (p.Cin * 4) + pa_chunk;      // bytes
+        }
+    }
+    auto a_dma = [&](int st, int kh, int kw, int cb) {
+        const int tapoff = (kh * p.W + kw) * (p.Cin * 4);
+#pragma unroll
+        for (int i = 0; i < (PAIRS ? NLA : 0); ++i) {
+            // (unsigned compares: one per coordinate; the tap's offset is wave-uniform; select, not branch)
+            const bool in = (unsigned)(pa_h[i] + kh) < (unsigned)p.H && (unsigned)(pa_w[i] + kw) < (unsigned)p.W;
+            const int off = pa_off[i] + tapoff;
+            ci_blds16(rsX, in ? off : 0x7fffffff, cb * 128, smem + st * STAGE + i * (256 * 16) + wave * 1024);
+        }
+    };
+
     // ---- weight tile by LDS-DMA: chunk pch = i * 256 + tid -> row pch >> 3, physical slot pch & 7 = logical chunk slot ^ swz(row)
     const int pitchw = p.nk * CI_ROWB;
     const __amdgpu_buffer_rsrc_t rsB = ci_rsrc(p.w2 + (int64_t)nt * TN * pitchw, (int64_t)TN * pitchw);
@@ -213,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
 #pragma unroll
         for (int lo = 0; lo < 2; ++lo) foff[s][lo] = ((4 * lo + 2 * s + h) ^ swz) << 4;
     const int arow0 = (wm * 64 + l31) * CI_ROWB;
-    const int brow0 = (wn * (TN / 2) + l31) * CI_ROWB;
+    const int brow0 = (wn * TNW + l31) * CI_ROWB;
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -223,9 +270,41 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
 
-    // one K block: two 16-channel steps of three products per tile
+    // one K block: two 16-channel steps of three products per tile.  AM = 2: the fragments of BOTH steps are requested before the first
+    // product (the scheduler left to itself reads three, waits, multiplies: an LDS round trip in front of every other MFMA) and the
+    // products stay in front of the step's closing wait; AM = 0, 1: the scheduler is free to weave the next block's split into the
+    // MFMA stream (pinning the order there costs: the stem 2.6 -> 10.4 ms)
     auto multiply = [&](const char *sA) {
         const char *sB = sA + OPA;
+        if (PAIRS) {
+            f16x8 fa[2][2][MT], fb[2][2][NT];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    fa[s][0][m] = *(const f16x8 *)(sA + arow0 + m * 32 * CI_ROWB + foff[s][0]);
+                    fa[s][1][m] = *(const f16x8 *)(sA + arow0 + m * 32 * CI_ROWB + foff[s][1]);
+                }
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    fb[s][0][n] = *(const f16x8 *)(sB + brow0 + n * 32 * CI_ROWB + foff[s][0]);
+                    fb[s][1][n] = *(const f16x8 *)(sB + brow0 + n * 32 * CI_ROWB + foff[s][1]);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s][0][m], fb[s][0][n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s][1][m], fb[s][0][n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s][0][m], fb[s][1][n], acc[m][n], 0, 0, 0);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             f16x8 fa[2][MT], fb[2][NT];
@@ -274,6 +353,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
         else __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_s_barrier();
     };
+    if (!PAIRS) {
     a_load(ra0, kh, kw, cb);
     b_load(0, 0);
     a_store(ra0, 0);
@@ -296,6 +376,40 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
     } else {
         step(false, false, k, 0, ra1, ra0);
     }
+    } else {
+        // both operands by DMA into a ring of NST stages: block k + NST - 1 is requested at the top of step k, so a request has
+        // NST - 2 whole steps plus this step's products to arrive; with three stages the step's closing wait is COUNTED (the newest request
+        // stays in flight).  Measured on layer1 (64 -> 64 channels, 56 x 56): three stages at two workgroups per CU 1.52 ms, two stages
+        // at three per CU 1.31 ms, the 256 x 64 tile with two stages 0.92 ms -- NST stays 2.
+        constexpr int NDMA = NLA + NLB;                // DMA instructions per thread and block
+        a_dma(0, kh, kw, cb);
+        b_load(0, 0);
+        if (NST == 3 && p.nk > 1) {
+            advance();
+            a_dma(1, kh, kw, cb);
+            b_load(1, 1);
+            __builtin_amdgcn_s_waitcnt(NDMA | (7 << 4) | (0 << 8));
+        } else {
+            __builtin_amdgcn_s_waitcnt(0);
+        }
+        __builtin_amdgcn_s_barrier();
+        int cur = 0, nxt = NST - 1;                    // stage of block k, stage block k + NST - 1 goes to
+        for (int k = 0; k < p.nk; ++k) {
+            const bool more = k + NST - 1 < p.nk;
+            if (more) {
+                advance();
+                a_dma(nxt, kh, kw, cb);
+                b_load(nxt, k + NST - 1);
+            }
+            multiply(smem + cur * STAGE);              // (ends in a sched_barrier: MFMAs are no memory operations, the scheduler sinks them
+                                                       // below the wait and the barrier, and the requests then have no products to fly under)
+            if (NST == 3 && more) __builtin_amdgcn_s_waitcnt(NDMA | (7 << 4) | (0 << 8));
+            else __builtin_amdgcn_s_waitcnt(0);
+            __builtin_amdgcn_s_barrier();
+            cur = cur + 1 == NST ? 0 : cur + 1;
+            nxt = nxt + 1 == NST ? 0 : nxt + 1;
+        }
+    }
 
     // ---- epilogue: lane = output channel (128-byte runs per pixel), 16 pixels per accumulator tile
     const float inv = p.inv_sw / sc;
@@ -308,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
         float *T = (float *)smem;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
-            const int cl = wn * (TN / 2) + n * 32 + l31;
+            const int cl = wn * TNW + n * 32 + l31;
             const float bv = p.bias ? p.bias[nt * TN + cl] : 0.0f;
 #pragma unroll
             for (int m = 0; m < MT; ++m)
@@ -345,25 +459,60 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
             else atomicMax((unsigned *)dst, __float_as_uint(mx));
         }
     } else {
+        // Pair-format tensors: a pixel's 32-channel block is [hi 32 | lo 32] halfs.  Lane l31 = channel: after one exchange with lane
+        // l31 ^ 1 the even lane holds (hi_l, hi_l+1) and writes / reads that dword of the hi run, the odd lane (lo_l-1, lo_l) of the lo run
+        // -- 4-byte accesses, a wave covers the 128-byte run of two pixels per instruction.
+        const bool odd = l31 & 1;
+        const int pair_off = odd ? 64 + (l31 - 1) * 2 : l31 * 2;                   // byte offset of this lane's dword inside the block
+        float s_out = 0.0f, inv_sres = 0.0f;
+        if (p.out_pairs) {
+            const float xmax = __uint_as_float(*p.amax_in);
+            const float rmax = p.res ? __uint_as_float(*p.res_bound) : 0.0f;
+            const float bound = (xmax * p.wl1 + p.bmax + rmax) * 1.001f;          // >= max |y| whatever the rounding of the products
+            s_out = ci_scale(__float_as_uint(bound));
+            if (mt == 0 && nt == 0 && tid == 0) *p.bound_out = __float_as_uint(bound);
+        }
+        if (p.res && p.res_pairs) inv_sres = 1.0f / ci_scale(*p.res_bound);
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-        const int co = nt * TN + wn * (TN / 2) + n * 32 + l31;
-        const float bv = p.bias ? p.bias[co] : 0.0f;
+        for (int n = 0; n < NT; ++n) {
+            const int co0 = nt * TN + wn * TNW + n * 32;                      // the tile's 32 channels = one channel block
+            const int co = co0 + l31;
+            const float bv = p.bias ? p.bias[co] : 0.0f;
 #pragma unroll
-        for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int64_t pp = (int64_t)mt * CI_TM + row;
-                if (pp < p.P) {
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int64_t pp = (int64_t)mt * TM + row;
+                    const bool live = pp < p.P;                                    // (the exchanges below run in every lane)
+                    const int64_t blk = (pp * p.Cout + co0) * 4 + pair_off;        // byte offset of this lane's dword in a pair tensor
                     float v = acc[m][n][r] * inv + bv;
-                    if (p.res) v += p.res[pp * p.Cout + co];
+                    if (p.res) {
+                        if (p.res_pairs) {
+                            const unsigned wv = live ? *(const unsigned *)((const char *)p.res + blk) : 0u;
+                            const unsigned ov = (unsigned)__builtin_amdgcn_update_dpp(0, (int)wv, 0xB1, 0xF, 0xF, true);   // lane ^ 1
+                            const unsigned hb = odd ? ov >> 16 : wv & 0xffffu, lb = odd ? wv >> 16 : ov & 0xffffu;
+                            const unsigned short hs = (unsigned short)hb, ls = (unsigned short)lb;
+                            v += (__half2float(*(const __half *)&hs) + __half2float(*(const __half *)&ls)) * inv_sres;
+                        } else if (live) {
+                            v += p.res[pp * p.Cout + co];
+                        }
+                    }
                     if (p.relu) v = fmaxf(v, 0.0f);
-                    p.y[pp * p.Cout + co] = v;
-                    amax = fmaxf(amax, fabsf(v));
+                    if (live) amax = fmaxf(amax, fabsf(v));
+                    if (p.out_pairs) {
+                        const float u = v * s_out;
+                        const __half hu = __float2half_rn(u);
+                        const __half lu = __float2half_rn(u - __half2float(hu));
+                        const unsigned mine = (unsigned)*(const unsigned short *)&hu | ((unsigned)*(const unsigned short *)&lu << 16);
+                        const unsigned oth = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, true);
+                        const unsigned wv = odd ? (oth >> 16) | (mine & 0xffff0000u) : (mine & 0xffffu) | (oth << 16);
+                        if (live) *(unsigned *)((char *)p.y + blk) = wv;
+                    } else if (live) {
+                        p.y[pp * p.Cout + co] = v;
+                    }
                 }
-            }
-    }
+        }
     }
     if (p.amax_out) {
 #pragma unroll
@@ -378,9 +527,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
  * block per kernel row, slot kw * 3 + c.  inv_sw = 1 / (the power of two the weights were scaled by).  d_amax_in: 4-byte device slot,
  * float bits of (a bound of) max |x|, > 0; d_amax_out (optional): slot that receives max |y| (atomic maximum: zero it first).
  * Replaces torch.nn.functional.conv2d for the layers named at the top of this file (cslam/vpr/cosplace_utils/network.py:38-68). */
+struct ConvIgemmFormats {               // pair-format operands of a launch (all off: float32 everywhere)
+    int x_pairs; const unsigned *xbound;
+    int res_pairs; const unsigned *res_bound;
+    int out_pairs; float wl1, bmax; unsigned *bound_out;
+};
 static int conv_igemm_launch(const float *d_x, const void *d_w2, const float *d_bias, const float *d_res, int B, int H, int W,
                              int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, int pool, const unsigned *d_amax_in,
-                             float inv_sw, unsigned *d_amax_out, float *d_y, void *stream) {
+                             float inv_sw, unsigned *d_amax_out, float *d_y, void *stream, const ConvIgemmFormats &f) {
     PTR_DEVICE(d_x);
     ARG_CHECK(d_x && d_w2 && d_y && d_amax_in, "NULL argument");
     ARG_CHECK(B >= 1 && H >= 1 && W >= 1 && KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0, "bad geometry");
@@ -400,24 +554,32 @@ static int conv_igemm_launch(const float *d_x, const void *d_w2, const float *d_
         ARG_CHECK(stem && relu && !d_res, "the fused MaxPool2d(3, 2, 1) exists for the stem form with ReLU and without a shortcut");
         ARG_CHECK(a.Ho % 8 == 0 && a.Wo % 16 == 0, "the fused MaxPool2d needs an output map of 8 x 16-pixel tiles");
     }
-    // the activation descriptor starts at the image of a tile's first pixel: the tile's CI_TM pixels then span this many images
-    ARG_CHECK((int64_t)(CI_TM / (a.Ho * a.Wo) + 2) * H * W * Cin * 4 < (stem ? CI_OOB - 1 : 0x7fffffffll), "image too large for 32-bit activation offsets");
+    // the activation descriptor starts at the image of a tile's first pixel: the tile's (at most 256) pixels then span this many images
+    ARG_CHECK((int64_t)(256 / (a.Ho * a.Wo) + 2) * H * W * Cin * 4 < (stem ? CI_OOB - 1 : 0x7fffffffll), "image too large for 32-bit activation offsets");
     a.ncb = stem ? 0 : Cin / 32;
     a.nk = stem ? KH : KH * KW * (Cin / 32);
     a.relu = relu; a.amax_in = d_amax_in; a.inv_sw = inv_sw; a.amax_out = d_amax_out;
+    a.xbound = f.xbound; a.out_pairs = f.out_pairs; a.wl1 = f.wl1; a.bmax = f.bmax; a.bound_out = f.bound_out;
+    a.res_pairs = f.res_pairs; a.res_bound = f.res_bound;
+    ARG_CHECK(!f.x_pairs || (!stem && f.xbound), "pair-format input needs its bound slot (and is not the stem's format)");
+    ARG_CHECK(!f.out_pairs || (!pool && f.bound_out && f.wl1 > 0.0f && f.bmax >= 0.0f), "pair-format output needs wl1, bmax and the bound slot");
+    ARG_CHECK(!(d_res && (f.res_pairs || f.out_pairs)) || f.res_bound, "the shortcut's bound slot is missing");
     const int tn = Cout % 128 == 0 ? 128 : 64;
-    const dim3 grid((unsigned)ceil_div64(P, CI_TM), (unsigned)(Cout / tn)), blk(256);      // (pooled form: P / 128 tiles exactly)
-    const int lds = 2 * (CI_TM + tn) * CI_ROWB;                                              // >= 128 x tn floats, the pooled form's tile
+    const int am = stem ? 1 : (f.x_pairs ? 2 : 0);
+    const int tm = am == 2 && tn == 64 ? 256 : 128;
+    const dim3 grid((unsigned)ceil_div64(P, tm), (unsigned)(Cout / tn)), blk(256);          // (pooled form: P / 128 tiles exactly)
+    const int lds = 2 * (tm + tn) * CI_ROWB;                                                 // >= 128 x tn floats, the pooled form's tile
     hipStream_t st = (hipStream_t)stream;
     if (pool) HIP_TRY(hipMemsetAsync(d_y, 0, (size_t)B * (a.Ho / 2) * (a.Wo / 2) * Cout * sizeof(float), st));
-#define CI_LAUNCH(TN_, ST_) do { \
+#define CI_LAUNCH(TM_, TN_, ST_) do { \
         static DeviceOnce once; int once_dev; \
         if (once.todo(&once_dev)) { \
-            HIP_TRY(hipFuncSetAttribute((const void *)conv_igemm_h2_kernel<TN_, ST_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+            HIP_TRY(hipFuncSetAttribute((const void *)conv_igemm_h2_kernel<TM_, TN_, ST_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
             once.done(once_dev); } \
-        hipLaunchKernelGGL((conv_igemm_h2_kernel<TN_, ST_>), grid, blk, lds, st, a); } while (0)
-    if (stem) { if (tn == 128) CI_LAUNCH(128, true); else CI_LAUNCH(64, true); }
-    else { if (tn == 128) CI_LAUNCH(128, false); else CI_LAUNCH(64, false); }
+        hipLaunchKernelGGL((conv_igemm_h2_kernel<TM_, TN_, ST_>), grid, blk, lds, st, a); } while (0)
+    if (stem) { if (tn == 128) CI_LAUNCH(128, 128, 1); else CI_LAUNCH(128, 64, 1); }
+    else if (f.x_pairs) { if (tn == 128) CI_LAUNCH(128, 128, 2); else CI_LAUNCH(256, 64, 2); }
+    else { if (tn == 128) CI_LAUNCH(128, 128, 0); else CI_LAUNCH(128, 64, 0); }
 #undef CI_LAUNCH
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
@@ -426,7 +588,24 @@ CSLAM_API int cslam_conv_igemm_h2_dev(const float *d_x, const void *d_w2, const 
                                       int Cin, int Cout, int KH, int KW, int stride, int pad, int relu, const unsigned *d_amax_in,
                                       float inv_sw, unsigned *d_amax_out, float *d_y, void *stream) {
     return conv_igemm_launch(d_x, d_w2, d_bias, d_res, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, 0, d_amax_in, inv_sw, d_amax_out,
-                             d_y, stream);
+                             d_y, stream, ConvIgemmFormats{0, nullptr, 0, nullptr, 0, 0.0f, 0.0f, nullptr});
+}
+/* The same convolution between PAIR-FORMAT activations: a tensor [B,H,W,C] (C a multiple of 32) whose every (pixel, 32-channel block) is
+ * 128 bytes [hi 32 | lo 32] fp16 of s x -- s = the power of two that brings the tensor's 4-byte BOUND slot into [2^13, 2^14) -- the
+ * row image the kernel's LDS stages hold, written once by the producing layer's epilogue instead of being re-derived per tap and
+ * output tile by every consumer (same bytes as float32).  x_pairs: d_x is such a tensor and d_xbound its slot (d_amax_in then is the
+ * MEASURED max |x| the producer left); res_pairs: d_res likewise with d_res_bound (float32 d_res with out_pairs: d_res_bound = a bound
+ * of max |res|); out_pairs: d_y leaves in the format, scaled for the bound max|x| wl1 + bmax (+ max|res|) -- wl1 = max over output
+ * channels of sum |w|, bmax = max |bias|, both of the float32 weights -- which goes to d_bound_out.  Any flag may be 0 (float32). */
+CSLAM_API int cslam_conv_igemm_h2p_dev(const void *d_x, int x_pairs, const unsigned *d_xbound, const void *d_w2, const float *d_bias,
+                                       const void *d_res, int res_pairs, const unsigned *d_res_bound, int B, int H, int W, int Cin,
+                                       int Cout, int KH, int KW, int stride, int pad, int relu, const unsigned *d_amax_in, float inv_sw,
+                                       float wl1, float bmax, unsigned *d_amax_out, int out_pairs, unsigned *d_bound_out, void *d_y,
+                                       void *stream) {
+    ARG_CHECK(Cin != 3, "the stem reads float32 frames: cslam_conv_igemm_h2_dev / cslam_conv_stem_pool_igemm_h2_dev");
+    return conv_igemm_launch((const float *)d_x, d_w2, d_bias, (const float *)d_res, B, H, W, Cin, Cout, KH, KW, stride, pad, relu, 0,
+                             d_amax_in, inv_sw, d_amax_out, (float *)d_y, stream,
+                             ConvIgemmFormats{x_pairs, d_xbound, res_pairs, d_res_bound, out_pairs, wl1, bmax, d_bound_out});
 }
 /* The stem with its pooling: y = MaxPool2d(3, 2, 1)(ReLU(conv(x, w) + bias)) for x [B,H,W,3] -> y [B,Ho/2,Wo/2,Cout] (Ho a multiple of 8,
  * Wo of 16: ResNet's 7x7 / 2 stem on 224 x 224 frames gives 112 x 112).  The un-pooled map never exists in HBM; d_amax_out receives max
@@ -435,5 +614,5 @@ CSLAM_API int cslam_conv_stem_pool_igemm_h2_dev(const float *d_x, const void *d_
                                                 int KH, int KW, int stride, int pad, const unsigned *d_amax_in, float inv_sw,
                                                 unsigned *d_amax_out, float *d_y, void *stream) {
     return conv_igemm_launch(d_x, d_w2, d_bias, nullptr, B, H, W, 3, Cout, KH, KW, stride, pad, 1, 1, d_amax_in, inv_sw, d_amax_out,
-                             d_y, stream);
+                             d_y, stream, ConvIgemmFormats{0, nullptr, 0, nullptr, 0, 0.0f, 0.0f, nullptr});
 }

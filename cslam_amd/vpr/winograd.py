@@ -144,6 +144,51 @@ def conv_igemm(ws, x, Wg, bias, kernel, stride, pad, relu, residual=None, amax_i
     return y
 
 
+class PairAct(object):
+    """An activation between the implicit-GEMM layers of a ResNet trunk.  pairs = False: t is the [B,C,H,W] channels_last float32 map;
+    pairs = True: t is the PAIR-FORMAT tensor [B,H,W,C/32,2,32] float16 (csrc/conv_igemm.hip: hi and lo halves of s x, s the power of
+    two that brings `bound` into [2^13, 2^14)).  amax: 4-byte device slot with the measured max |x| (or a bound of it); bound: the slot
+    the pairs were scaled by (float32 maps: the same slot as amax)."""
+    __slots__ = ("t", "pairs", "shape", "amax", "bound")
+
+    def __init__(self, t, pairs, shape, amax, bound):
+        self.t, self.pairs, self.shape, self.amax, self.bound = t, pairs, tuple(shape), amax, bound
+
+
+def pairs_to_float(act):
+    """PairAct (pair format) -> [B,C,H,W] channels_last float32 (torch; tests and debugging: the trunk never converts)."""
+    B, C, H, W = act.shape
+    e = torch.frexp(act.bound.view(torch.float32).clamp(1e-30, 1e30))[1].item()
+    s = 2.0 ** (14 - e)
+    v = (act.t[:, :, :, :, 0, :].float() + act.t[:, :, :, :, 1, :].float()) / s           # [B,H,W,C/32,32]
+    return v.reshape(B, H, W, C).permute(0, 3, 1, 2)
+
+
+def conv_igemm_p(ws, act, Wg, bias, kernel, stride, pad, relu, res, wl1, bmax, amax_out, bound_out, out_pairs):
+    """`cslam_conv_igemm_h2p_dev`: the implicit-GEMM convolution between PairActs.  act / res (or None) in either format; the result is
+    a PairAct in pair format (out_pairs) or float32, with amax_out (zeroed slot: measured max |y|) and bound_out as its slots."""
+    lib = _lib.load()
+    B, Cin, H, W = act.shape
+    W2, inv_sw = Wg
+    Cout = W2.shape[0]
+    KH, KW = kernel
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    dev = act.t.device
+    if out_pairs:
+        y = torch.empty((B, Ho, Wo, Cout // 32, 2, 32), dtype=torch.float16, device=dev)
+    else:
+        y = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+    if res is not None:
+        assert res.shape == (B, Cout, Ho, Wo) and (res.pairs or res.t.is_contiguous(memory_format=torch.channels_last))
+    assert act.pairs or act.t.is_contiguous(memory_format=torch.channels_last)
+    _lib.check(lib.cslam_conv_igemm_h2p_dev(
+        _p(act.t), int(act.pairs), _p(act.bound), _p(W2), _p(bias) if bias is not None else None,
+        _p(res.t) if res is not None else None, int(res.pairs) if res is not None else 0,
+        _p(res.bound) if res is not None else None, B, H, W, Cin, Cout, KH, KW, stride, pad, int(relu), _p(act.amax),
+        float(inv_sw), float(wl1), float(bmax), _p(amax_out), int(out_pairs), _p(bound_out) if out_pairs else None, _p(y), _stream(act.t)))
+    return PairAct(y, bool(out_pairs), (B, Cout, Ho, Wo), amax_out, bound_out if out_pairs else amax_out)
+
+
 def conv3x3_direct_h(x, Wd, bias, relu, pool, amax_in, amax_out=None):
     """y = [pool](relu(conv3x3(x) + bias)) through `cslam_conv3x3_direct_h_dev` (csrc/conv_direct_h.hip): x [B,Cin,H,W]
     channels_last float32 (Cin a multiple of 32), 128 output channels; Wd = `direct_pair_weights(weight)`; amax_in = 4-byte device
@@ -365,6 +410,7 @@ def _z_form(cin, cout):
 
 
 Z_FORM_MAX = 128 * 128
+PAIR_ACTS = True              # ResNet trunks: pair-format maps between the implicit-GEMM layers (False: float32 maps, the A/B partner)
 IGEMM_CONVS = True            # ResNet trunks: strided / 1x1 / 7x7 layers through csrc/conv_igemm.hip (False: torch, the A/B partner)
 
 
@@ -498,6 +544,10 @@ class _FoldedConv(object):
         self.stride, self.padding = conv.stride, conv.padding
         self.U = self.U4 = self.Wg = None
         self.kernel = tuple(conv.kernel_size)
+        # the bound of the output the pair-format chain scales by: |y| <= max |x| wl1 + bmax (+ max |shortcut|)
+        self.wl1 = float(self.weight.abs().sum(dim=(1, 2, 3)).max())
+        self.bmax = float(self.bias.abs().max()) if self.bias is not None else 0.0
+        self.in_channels = conv.in_channels
         igemm_ok = (IGEMM_CONVS and conv.dilation == (1, 1) and conv.groups == 1 and conv.stride[0] == conv.stride[1]
                     and conv.padding[0] == conv.padding[1] and conv.out_channels % 64 == 0 and conv.weight.is_cuda
                     and (conv.in_channels % 32 == 0 or (conv.in_channels == 3 and 3 * conv.kernel_size[1] <= 32)))
@@ -601,6 +651,29 @@ class WinogradResNet(_Workspace):
         else:
             y, ax = run(self.stem, x, True, None, a0)
             x = sp(y)                                     # max |pool(y)| <= max |y|: the slot stays a bound
+        convs = [c for b in self.blocks for c in (b["down"], b["c1"], b["c2"], b["c3"]) if c is not None]
+        if PAIR_ACTS and ax is not None and all(c.Wg is not None and c.in_channels % 32 == 0 for c in convs):
+            # every layer is the implicit GEMM: the maps between them travel in PAIR FORMAT (written once by the producing epilogue, read
+            # by LDS-DMA: no split per tap and output tile); the pooled stem output goes in as float32, the last map comes out as float32
+            pslots = self._buf("pair_slots", 2 * len(convs) + 2, x.device)
+            pslots.zero_()
+            np_ = [0]
+            last = convs[-1]
+
+            def runp(conv, a, relu, res):
+                np_[0] += 2
+                return conv_igemm_p(self, a, conv.Wg, conv.bias, conv.kernel, conv.stride[0], conv.padding[0], relu, res, conv.wl1,
+                                    conv.bmax, pslots[np_[0] - 2:np_[0] - 1], pslots[np_[0] - 1:np_[0]], conv is not last)
+            cur = PairAct(x, False, x.shape, ax, ax)
+            for b in self.blocks:
+                idt = cur if b["down"] is None else runp(b["down"], cur, False, None)
+                o = runp(b["c1"], cur, True, None)
+                if b["c3"] is None:                   # BasicBlock
+                    cur = runp(b["c2"], o, True, idt)
+                else:                                 # Bottleneck
+                    o = runp(b["c2"], o, True, None)
+                    cur = runp(b["c3"], o, True, idt)
+            return cur.t
         for b in self.blocks:
             idt = x if b["down"] is None else run(b["down"], x, False, None, ax)[0]
             o, ao = run(b["c1"], x, True, None, ax)

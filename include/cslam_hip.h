@@ -471,6 +471,17 @@ int cslam_conv_igemm_h2_dev(const float *d_x, const void *d_w2, const float *d_b
 int cslam_conv_stem_pool_igemm_h2_dev(const float *d_x, const void *d_w2, const float *d_bias, int B, int H, int W, int Cout,
                                       int KH, int KW, int stride, int pad, const unsigned *d_amax_in, float inv_sw,
                                       unsigned *d_amax_out, float *d_y, void *stream);
+/* the same convolution between PAIR-FORMAT activations (csrc/conv_igemm.hip): a tensor [B,H,W,C], C a multiple of 32, whose every
+ * (pixel, 32-channel block) is 128 bytes [hi 32 | lo 32] fp16 of s x, s = the power of two that brings the tensor's 4-byte bound slot
+ * into [2^13, 2^14) -- written once by the producing layer's epilogue, read by LDS-DMA (same bytes as float32; the format never
+ * leaves the trunk: the BasicBlock chain of cslam/vpr/cosplace_utils/network.py:38-68).  x_pairs / res_pairs / out_pairs select the
+ * format per operand (0 = float32); d_amax_in = MEASURED max |x| (or a bound); wl1 = max_co sum |w[co]|, bmax = max |bias| give the
+ * output's bound max|x| wl1 + bmax (+ *d_res_bound), stored to d_bound_out; d_amax_out receives the measured max |y| */
+int cslam_conv_igemm_h2p_dev(const void *d_x, int x_pairs, const unsigned *d_xbound, const void *d_w2, const float *d_bias,
+                             const void *d_res, int res_pairs, const unsigned *d_res_bound, int B, int H, int W, int Cin,
+                             int Cout, int KH, int KW, int stride, int pad, int relu, const unsigned *d_amax_in, float inv_sw,
+                             float wl1, float bmax, unsigned *d_amax_out, int out_pairs, unsigned *d_bound_out, void *d_y,
+                             void *stream);
 
 /* 3x3 / stride 1 / pad 1 convolution 64 -> 128 channels (cslam/vpr/netvlad.py:163-171,227: VGG-16 conv2_1) as ONE direct kernel whose
  * weights (295 KB of exact fp16 pairs) stay in the registers of the four waves of a workgroup, 32 output channels each

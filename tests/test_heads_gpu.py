@@ -1245,6 +1245,64 @@ def test_implicit_gemm_convolution_on_fp16_pairs_equals_float64(T, B, cin, cout,
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,c0,c1,hw,k2,stride2", [(3, 64, 64, (20, 24), 3, 1), (2, 64, 128, (19, 13), 3, 2), (5, 128, 256, (14, 14), 1, 2),
+                                                   (1, 256, 512, (7, 7), 3, 1)])
+def test_pair_format_activations_between_implicit_gemm_layers(T, B, c0, c1, hw, k2, stride2):
+    """`cslam_conv_igemm_h2p_dev`: float32 map -> conv (pair-format output) -> conv reading the pairs by LDS-DMA, with a pair-format and
+    with a float32 shortcut, pair-format and float32 output.  Every result against the same chain in float64, no further from it than 4 x
+    torch's float32 chain (+ 4e-7 of the scale): the bound-derived scale costs nothing visible; the measured max |y| and the bound slots
+    are right; ragged pixel tiles, zero padding, strides."""
+    torch, _ = T
+    from cslam_amd.vpr import winograd as wg
+    torch.manual_seed(c0 * 7 + c1 + k2)
+    H, W = hw
+    x = torch.randn((B, c0, H, W), device="cuda") * torch.exp2(torch.randint(-5, 2, (B, c0, 1, 1), device="cuda").float())
+    x = x.contiguous(memory_format=torch.channels_last)
+    w1 = torch.randn((c0, c0, 3, 3), device="cuda") / (3 * c0 ** 0.5)
+    b1 = torch.randn(c0, device="cuda") * 0.2
+    w2 = torch.randn((c1, c0, k2, k2), device="cuda") / (k2 * c0 ** 0.5)
+    b2 = torch.randn(c1, device="cuda") * 0.2
+    p2 = k2 // 2
+    ws = wg._Workspace()
+    slots = torch.zeros(12, dtype=torch.float32, device="cuda")
+    slots[0] = x.abs().max()
+    a0 = wg.PairAct(x, False, x.shape, slots[0:1], slots[0:1])
+    wl1 = lambda w: float(w.abs().sum(dim=(1, 2, 3)).max())        # noqa: E731
+    # layer 1: float32 in, pairs out (ReLU)
+    a1 = wg.conv_igemm_p(ws, a0, wg.igemm_pair_weights(w1), b1, (3, 3), 1, 1, True, None, wl1(w1), float(b1.abs().max()),
+                         slots[1:2], slots[2:3], True)
+    r1 = torch.nn.functional.conv2d(x.double(), w1.double(), b1.double(), padding=1).relu()
+    f1 = torch.nn.functional.conv2d(x, w1, b1, padding=1).relu()
+    y1 = wg.pairs_to_float(a1)
+    sc1 = r1.abs().max().item()
+    e32 = (f1.double() - r1).abs().max().item() / sc1
+    assert (y1.double() - r1).abs().max().item() / sc1 <= 4 * e32 + 4e-7
+    assert a1.pairs and a1.t.dtype == torch.float16 and a1.t.shape == (B, H, W, c0 // 32, 2, 32)
+    assert abs(slots[1].item() - r1.abs().max().item()) <= 1e-5 * sc1 and slots[2].item() >= slots[1].item()
+    assert slots[2].item() <= (slots[0].item() * wl1(w1) + float(b1.abs().max())) * 1.002
+    # layer 2: pairs in; shortcut (same geometry only) in pair format, then as float32; output float32 and pairs
+    same = c1 == c0 and stride2 == 1
+    r2 = torch.nn.functional.conv2d(r1, w2.double(), b2.double(), stride=stride2, padding=p2)
+    f2 = torch.nn.functional.conv2d(f1, w2, b2, stride=stride2, padding=p2)
+    if same:
+        r2, f2 = r2 + r1, f2 + f1
+    r2, f2 = r2.relu(), f2.relu()
+    sc2 = r2.abs().max().item()
+    e32 = (f2.double() - r2).abs().max().item() / sc2
+    Wg2 = wg.igemm_pair_weights(w2)
+    res_forms = [a1, wg.PairAct(y1.contiguous(memory_format=torch.channels_last), False, y1.shape, slots[1:2], slots[1:2])] if same else [None]
+    for res in res_forms:
+        for out_pairs in (False, True):
+            slots[3:].zero_()
+            a2 = wg.conv_igemm_p(ws, a1, Wg2, b2, (k2, k2), stride2, p2, True, res, wl1(w2), float(b2.abs().max()), slots[3:4],
+                                 slots[4:5], out_pairs)
+            y2 = wg.pairs_to_float(a2) if out_pairs else a2.t
+            assert tuple(y2.shape) == tuple(r2.shape)
+            assert (y2.double() - r2).abs().max().item() / sc2 <= 4 * e32 + 4e-7, (res is not None and res.pairs, out_pairs)
+            assert abs(slots[3].item() - sc2) <= 1e-5 * sc2
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,H,W,cout,k,stride,pad", [(3, 224, 224, 64, 7, 2, 3), (2, 64, 96, 64, 7, 2, 3), (5, 32, 32, 128, 3, 2, 1),
                                                     (2, 16, 32, 64, 3, 1, 1)])
 def test_stem_with_fused_maxpool_equals_pooling_the_unfused_output(T, B, H, W, cout, k, stride, pad):

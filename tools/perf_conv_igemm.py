@@ -12,22 +12,43 @@ shapes = [("stem 7x7/2 3->64 @224", 3, 64, 224, 7, 2, 3), ("layer1 3x3 64->64 @5
           ("layer3 3x3 256->256 @14", 256, 256, 14, 3, 1, 1), ("layer4.0 3x3/2 256->512 @14", 256, 512, 14, 3, 2, 1),
           ("layer4 3x3 512->512 @7", 512, 512, 7, 3, 1, 1)]
 ws = wg._Workspace()
+torch.zeros(1 << 28, device="cuda").sum().item()                         # (a fresh box: first touch of the device, clocks)
+
+
+def timed(fn, n=10):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
 for name, cin, cout, hw, k, s, p in shapes:
     x = torch.randn((B, cin, hw, hw), device="cuda").contiguous(memory_format=torch.channels_last)
     w = torch.randn((cout, cin, k, k), device="cuda") / (k * cin ** 0.5)
     Wg = wg.igemm_pair_weights(w)
     slot = torch.full((1,), float(x.abs().max()), device="cuda")
-    y = wg.conv_igemm(ws, x, Wg, None, (k, k), s, p, True, amax_in=slot)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 10
-    e0.record()
-    for _ in range(n):
-        wg.conv_igemm(ws, x, Wg, None, (k, k), s, p, True, amax_in=slot)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / n
+    ms = timed(lambda: wg.conv_igemm(ws, x, Wg, None, (k, k), s, p, True, amax_in=slot))
     ho = (hw + 2 * p - k) // s + 1
     kk = (7 * 32) if cin == 3 else k * k * cin
     fl = 2.0 * 3 * B * ho * ho * cout * kk
-    print(f"{name:32s} {ms:7.3f} ms  {fl / ms / 1e9:7.1f} TF issued  ({B * ho * ho} pixels, K = {kk})", flush=True)
+    line = f"{name:32s} {ms:7.3f} ms  {fl / ms / 1e9:7.1f} TF issued  ({B * ho * ho} pixels, K = {kk})"
+    if cin % 32 == 0:
+        # the pair-format form: x as pairs (made by a 1x1 layer with pair output), pairs out
+        slots = torch.zeros(8, device="cuda")
+        slots[0] = slot[0]
+        a0 = wg.PairAct(x, False, x.shape, slots[0:1], slots[0:1])
+        w1 = torch.eye(cin, device="cuda").reshape(cin, cin, 1, 1).contiguous()
+        ap = wg.conv_igemm_p(ws, a0, wg.igemm_pair_weights(w1), None, (1, 1), 1, 0, False, None, 1.0, 0.0, slots[1:2], slots[2:3], True)
+        wl1 = float(w.abs().sum(dim=(1, 2, 3)).max())
+
+        def pair_form():
+            slots[3].zero_()
+            wg.conv_igemm_p(ws, ap, Wg, None, (k, k), s, p, True, None, wl1, 0.0, slots[3:4], slots[4:5], True)
+        mp = timed(pair_form)
+        line += f"   pair format in / out: {mp:7.3f} ms  {fl / mp / 1e9:7.1f} TF"
+    print(line, flush=True)
