@@ -25,6 +25,7 @@
 // are consecutive floats of the NHWC image; 7 blocks of 32 slots (21 used, the weights of the others zero).  (K packed densely over
 // (kh, kw, c) -- 147 values in 5 blocks, the tap decoded per element -- measured slower: 3.25 against 2.70 ms per 1000 frames.)
 #include "common.h"
+#include <type_traits>
 #include <hip/hip_fp16.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -473,45 +474,75 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
             if (mt == 0 && nt == 0 && tid == 0) *p.bound_out = __float_as_uint(bound);
         }
         if (p.res && p.res_pairs) inv_sres = 1.0f / ci_scale(*p.res_bound);
+        // Stores and shortcut loads go through buffer descriptors that begin at the tile's first pixel and end with the tensor: a row
+        // beyond the last pixel is out of range -- the load returns zero, the store is dropped -- so the epilogue has no branch (with
+        // `if (pixel < P)` around every access the compiler serialised 64 load -> wait -> store sequences per lane: 0.7 ms of layer1's
+        // 1.4 ms with a shortcut)
+        const int64_t tile0 = (int64_t)mt * TM * p.Cout;                       // the tile's first value (both formats: 4 bytes per value)
+        const int64_t rows_left = (int64_t)p.P - (int64_t)mt * TM;
+        const int64_t tile_bytes = (rows_left < TM ? rows_left : TM) * p.Cout * 4;
+        const __amdgpu_buffer_rsrc_t rsY = ci_rsrc((const char *)(p.y + tile0), tile_bytes);
+        const __amdgpu_buffer_rsrc_t rsR = ci_rsrc((const char *)((p.res ? p.res : p.y) + tile0), tile_bytes);
+        const float floor_ = p.relu ? 0.0f : -INFINITY;
+        // (the operand formats as compile-time constants of six copies of the loop: as runtime flags they left a branch per element)
+        auto epilogue = [&](auto res_c, auto outp_c) {
+        constexpr int RES = decltype(res_c)::value;                           // shortcut: 0 none, 1 float32, 2 pair format
+        constexpr bool OUTP = decltype(outp_c)::value;
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int co0 = nt * TN + wn * TNW + n * 32;                      // the tile's 32 channels = one channel block
             const int co = co0 + l31;
             const float bv = p.bias ? p.bias[co] : 0.0f;
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
+            for (int m = 0; m < MT; ++m) {
+                float rv[16];
+                if (RES) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const int off = RES == 2 ? (row * p.Cout + co0) * 4 + pair_off : (row * p.Cout + co) * 4;
+                        rv[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsR, off, 0, 0));
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const int64_t pp = (int64_t)mt * TM + row;
-                    const bool live = pp < p.P;                                    // (the exchanges below run in every lane)
-                    const int64_t blk = (pp * p.Cout + co0) * 4 + pair_off;        // byte offset of this lane's dword in a pair tensor
+                    const bool live = row < rows_left;
                     float v = acc[m][n][r] * inv + bv;
-                    if (p.res) {
-                        if (p.res_pairs) {
-                            const unsigned wv = live ? *(const unsigned *)((const char *)p.res + blk) : 0u;
+                    if (RES) {
+                        if (RES == 2) {
+                            const unsigned wv = __float_as_uint(rv[r]);
                             const unsigned ov = (unsigned)__builtin_amdgcn_update_dpp(0, (int)wv, 0xB1, 0xF, 0xF, true);   // lane ^ 1
                             const unsigned hb = odd ? ov >> 16 : wv & 0xffffu, lb = odd ? wv >> 16 : ov & 0xffffu;
                             const unsigned short hs = (unsigned short)hb, ls = (unsigned short)lb;
                             v += (__half2float(*(const __half *)&hs) + __half2float(*(const __half *)&ls)) * inv_sres;
-                        } else if (live) {
-                            v += p.res[pp * p.Cout + co];
+                        } else {
+                            v += rv[r];
                         }
                     }
-                    if (p.relu) v = fmaxf(v, 0.0f);
-                    if (live) amax = fmaxf(amax, fabsf(v));
-                    if (p.out_pairs) {
+                    v = fmaxf(v, floor_);
+                    amax = fmaxf(amax, live ? fabsf(v) : 0.0f);
+                    if (OUTP) {
                         const float u = v * s_out;
                         const __half hu = __float2half_rn(u);
                         const __half lu = __float2half_rn(u - __half2float(hu));
                         const unsigned mine = (unsigned)*(const unsigned short *)&hu | ((unsigned)*(const unsigned short *)&lu << 16);
                         const unsigned oth = (unsigned)__builtin_amdgcn_update_dpp(0, (int)mine, 0xB1, 0xF, 0xF, true);
                         const unsigned wv = odd ? (oth >> 16) | (mine & 0xffff0000u) : (mine & 0xffffu) | (oth << 16);
-                        if (live) *(unsigned *)((char *)p.y + blk) = wv;
-                    } else if (live) {
-                        p.y[pp * p.Cout + co] = v;
+                        __builtin_amdgcn_raw_buffer_store_b32(wv, rsY, (row * p.Cout + co0) * 4 + pair_off, 0, 0);
+                    } else {
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsY, (row * p.Cout + co) * 4, 0, 0);
                     }
                 }
+            }
+        }
+        };
+        typedef std::integral_constant<int, 0> R0; typedef std::integral_constant<int, 1> R1; typedef std::integral_constant<int, 2> R2;
+        const int res_mode = !p.res ? 0 : (p.res_pairs ? 2 : 1);
+        if (p.out_pairs) {
+            if (res_mode == 0) epilogue(R0(), std::true_type()); else if (res_mode == 1) epilogue(R1(), std::true_type()); else epilogue(R2(), std::true_type());
+        } else {
+            if (res_mode == 0) epilogue(R0(), std::false_type()); else if (res_mode == 1) epilogue(R1(), std::false_type()); else epilogue(R2(), std::false_type());
         }
     }
     if (p.amax_out) {
