@@ -31,5 +31,22 @@ while done < N:
     c = time.perf_counter()
     te += b - a; tm += c - b; done += m
 dt = time.perf_counter() - t0
+# the same with the search in two halves: finish() of chunk i behind the enqueue of chunk i + 1's extraction (bench.py's c2 leg)
+nn2 = nnm.NearestNeighborsMatching()
+torch.cuda.synchronize()
+t1 = time.perf_counter(); pend = None; done2 = 0
+while done2 < N:
+    m = min(CH, N - done2)
+    d = cp.compute_embeddings_device(frames[:m])
+    if pend is not None:
+        pend.finish()
+    nn2.add_items_device(d)
+    lim = torch.arange(done2, done2 + m, device="cuda", dtype=torch.int64)
+    pend = nn2.search_device_async(d, 5, row_limit=lim, mode=nnm.MODE_AUTO)
+    done2 += m
+rows2, sims2, cnt2 = pend.finish(); torch.cuda.synchronize()
+dp = time.perf_counter() - t1
+assert torch.equal(rows2, rows) and torch.equal(cnt2, cnt)
+print(f"C2 [{MODE}] pipelined: {N / dp:.0f} keyframes/s")
 print(f"C2 [{MODE}]: {N} keyframes, chunk {CH}: extract+match {N/dt:.0f} keyframes/s (extract {N/te:.0f}/s, causal match {N/tm:.0f}/s), "
       f"bank rows {nn.n}, last chunk cnt min {int(cnt.min())}")
