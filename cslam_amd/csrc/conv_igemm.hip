@@ -1,29 +1,34 @@
-// conv_igemm.hip -- strided / 1x1 / 7x7 convolutions of the ResNet trunks as ONE implicit-GEMM kernel on exact fp16 pairs (gfx950).
+// conv_igemm.hip -- every convolution of the ResNet trunks as ONE implicit-GEMM kernel on exact fp16 pairs (gfx950).
 //
-// Replaces, for CosPlace's default backbone (cslam/vpr/cosplace_utils/network.py:38-68: torchvision ResNet-18 without avgpool / fc;
-// the reference's DEFAULT extractor, global_descriptor_loop_closure_detection.py:56-60), the convolutions the Winograd pipeline of
-// vpr/winograd.py cannot take -- the 7x7 / stride-2 stem, the 3x3 / stride-2 first convolution and the 1x1 / stride-2 shortcut of
-// layer2..4 -- which went through torch (MIOpen / CK, f32-input matrix pipe): 13 % of the trunk's multiply-adds, 60 % of its kernel time
-// (profiles/r05_v20_c2_kernel_split.log).  BatchNorm is folded into weight and bias on the host (vpr/winograd.py::fold_bn).
+// For CosPlace's default backbone (cslam/vpr/cosplace_utils/network.py:38-68: torchvision ResNet-18 without avgpool / fc; the
+// reference's DEFAULT extractor, global_descriptor_loop_closure_detection.py:56-60): the 7x7 / stride-2 stem (with its MaxPool2d fused),
+// the 3x3 layers of either stride and the 1x1 / stride-2 shortcuts.  Rounds 1-4 ran the stride-1 3x3 layers through the fp32 Winograd
+// pipeline with library products and the rest through torch (MIOpen / CK, f32-input matrix pipe: 13 % of the trunk's multiply-adds, 60 %
+// of its kernel time, profiles/r05_v20_c2_kernel_split.log).  BatchNorm is folded into weight and bias on the host (vpr/winograd.py::fold_bn).
 //
 //     y[b, ho, wo, co] = act( sum_{kh, kw, ci} x[b, ho s - p + kh, wo s - p + kw, ci] w[co, ci, kh, kw] + bias[co] (+ res[b, ho, wo, co]) )
 //
 // as a GEMM  Y [P = B Ho Wo pixels, Cout] = A [P, K] W^T [K, Cout],  K = KH KW Cin walked in blocks of 32 channels of one tap
 // (kh, kw); the A block of a tap is never materialised: every K stage gathers it from the NHWC activation (one 128-byte run per
-// pixel; pixels of the zero padding read as zero).
-// Arithmetic: the pair scheme of csrc/wino_gemm.hip.  x times a power of two s (from the 4-byte max |x| slot the producing layer
-// left, like every pair kernel of the trunk) splits exactly into fp16 hi + lo; the weights are split offline
-// (vpr/winograd.py::igemm_pair_weights); acc += xh wh; acc += xl wh; acc += xh wl on v_mfma_f32_32x32x16_f16 with fp32 accumulation
-// (the dropped xl wl is 2^-22 of the product): an fp32-grade convolution at a third of the fp16 matrix rate.
-// The activation tile is split while it is staged: global_load_dwordx4 -> 4 products with s, 2 packed conversions, 4 v_fma_mix
-// differences, 2 packed conversions per 16 bytes -> ds_write_b128 into the [hi 32 | lo 32] row image of the pair GEMM (128 bytes per
-// pixel and K block, 16-byte chunks XOR-swizzled by the row, fragment reads conflict-free); the weight tile comes by LDS-DMA from
-// rows laid out the same way.  Double-buffered LDS stages; the activation loads run two K blocks ahead of the MFMAs (two register
-// sets), their split and LDS write one block ahead, behind the MFMAs of the current block.
-// Workgroup = 128 pixels x TN = 128 | 64 output channels, four waves as 2 x 2 (wave tile 64 x TN / 2), two or three per CU.
-// STEM: the 3-channel 7x7 layer.  A tap's channels are 12 bytes, so a K block is a whole kernel ROW: the 21 values (kw, c) of row kh
-// are consecutive floats of the NHWC image; 7 blocks of 32 slots (21 used, the weights of the others zero).  (K packed densely over
-// (kh, kw, c) -- 147 values in 5 blocks, the tap decoded per element -- measured slower: 3.25 against 2.70 ms per 1000 frames.)
+// pixel; pixels of the zero padding read as zero: an offset past the buffer descriptor, the hardware fills in the zeros).
+// Arithmetic: the pair scheme of csrc/wino_gemm.hip.  x times a power of two s splits exactly into fp16 hi + lo; the weights are split
+// offline (vpr/winograd.py::igemm_pair_weights); acc += xh wh; acc += xl wh; acc += xh wl on v_mfma_f32_32x32x16_f16 with fp32
+// accumulation (the dropped xl wl is 2^-22 of the product): an fp32-grade convolution at a third of the fp16 matrix rate.
+// LDS stage = the [hi 32 | lo 32] row images of the pair GEMM (128 bytes per row and K block, 16-byte chunks XOR-swizzled by the row,
+// fragment reads conflict-free), double buffered; the weight tile comes by LDS-DMA from rows laid out the same way.  The activation tile:
+//   AM 0  float32 NHWC map: 16-byte buffer loads two K blocks ahead of the MFMAs (two register sets), split one block ahead -- scale, 2
+//         packed conversions, 4 v_fma_mix differences, 2 packed conversions per 16 bytes -> ds_write_b128 -- behind the MFMAs of the
+//         current block; s from the 4-byte max |x| slot the producing layer left;
+//   AM 1  the 3-channel 7x7 stem.  A tap's channels are 12 bytes, so a K block is a whole kernel ROW: the 21 values (kw, c) of row kh are
+//         consecutive floats of the NHWC image; 7 blocks of 32 slots (21 used, the weights of the others zero), sixteen 4-byte buffer
+//         loads per thread and block.  (K packed densely over (kh, kw, c) -- 147 values in 5 blocks, the tap decoded per element --
+//         measured slower: 3.25 against 2.70 ms per 1000 frames.)  With `pool`: 8 x 16-pixel tiles and MaxPool2d(3, 2, 1) in the epilogue;
+//   AM 2  PAIR-FORMAT map, written by a previous layer's epilogue as [pixel][32-channel block][hi 32 | lo 32] -- the row image itself:
+//         plain LDS-DMA like the weights, no register and no VALU work per K block.  Its scale is fixed before the producer has run: the
+//         power of two for the bound max|x| max_co sum|w| + max|b| (+ max|shortcut|), carried in a 4-byte slot beside the measured maximum.
+// Workgroup = TM pixels x TN output channels on four waves: 128 x 128 and 128 x 64 (2 x 2 waves), 256 x 64 (4 x 1; AM 2), two or three
+// per CU.  Epilogue: rescale, bias, shortcut (either format), ReLU, store (either format) in 128-byte runs through per-tile buffer
+// descriptors (no branch: rows beyond the last pixel are out of range), max |y| into the slot the next layer reads.
 #include "common.h"
 #include <type_traits>
 #include <hip/hip_fp16.h>

@@ -545,8 +545,8 @@ class _FoldedConv(object):
         self.U = self.U4 = self.Wg = None
         self.kernel = tuple(conv.kernel_size)
         # the bound of the output the pair-format chain scales by: |y| <= max |x| wl1 + bmax (+ max |shortcut|)
-        self.wl1 = float(self.weight.abs().sum(dim=(1, 2, 3)).max())
-        self.bmax = float(self.bias.abs().max()) if self.bias is not None else 0.0
+        self.wl1 = float(self.weight.detach().abs().sum(dim=(1, 2, 3)).max())
+        self.bmax = float(self.bias.detach().abs().max()) if self.bias is not None else 0.0
         self.in_channels = conv.in_channels
         igemm_ok = (IGEMM_CONVS and conv.dilation == (1, 1) and conv.groups == 1 and conv.stride[0] == conv.stride[1]
                     and conv.padding[0] == conv.padding[1] and conv.out_channels % 64 == 0 and conv.weight.is_cuda

@@ -23,3 +23,6 @@ head -16 $O/kernel_stats.txt
 find $O/prof -name "*.csv" -size +4M -delete
 bash tools/gpu_pmc_match.sh $tag/pmc_match > $O/pmc_match.log 2>&1; tail -5 $O/pmc_match.log
 cp profiles/pmc_by_kernel.json $O/pmc_by_kernel.json
+# C2 (CosPlace ResNet-18): kernel split of the extract in chunks of 1000 frames, per-layer times of the implicit-GEMM convolution
+bash tools/gpu_c2_trace.sh $tag/c2 > $O/c2_trace.log 2>&1; head -8 $O/c2/kernel_stats.txt; tail -2 $O/c2/perf.log
+python tools/perf_conv_igemm.py 1000 > $O/igemm_layers.log 2>&1; tail -9 $O/igemm_layers.log
