@@ -64,6 +64,7 @@ _SIGNATURES = {
     "cslam_bank_search_multi_enqueue_dev": (_i, [_vp, _i, _vp, _i, _i64, _i64, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "cslam_bank_search_multi_finish": (_i, [_vp, _i, C.POINTER(_i64)]),
     "cslam_bank_last_stats": (_i, [_vp, C.POINTER(_i64 * 4)]),
+    "cslam_bank_last_stage": (_i, [_vp, C.POINTER(C.c_int32 * 4)]),
     "cslam_bank_last_kernel_ms": (_i, [_vp, C.POINTER(_f)]),
     "cslam_topk_merge_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp]),
     "cslam_l2_normalize_dev": (_i, [_vp, _i64, _i, _i64, _f, _i, _vp]),

@@ -48,6 +48,8 @@ struct cslam_bank {
     int *pending_flag_count;          // device count of that list (bank workspace)
     int last_nprod;                   // candidate stage of the last MFMA-mode search: fp16 products per pair (0: the f32-input stage)
     int f32_backoff;                  // searches left on the f32-input stage after an fp16 stage left too many queries uncertified
+    int f32_backoff_len;              // length of the next back-off (8, doubling while retries keep overflowing, up to 1024)
+    bool stage_pinned;                // the last search's stage was fixed by CSLAM_MFMA_STAGE1 (no back-off)
     int pending_dbg;
     // a search that has been enqueued and not finished (cslam_bank_search_enqueue_dev ... cslam_bank_search_finish): its
     // arguments, for the exact-scan fallback of the uncertified queries; ev_flag = "the uncertified-query count is on the host"

@@ -120,7 +120,7 @@ CSLAM_API int cslam_bank_create(int device, int dim, int64_t capacity_hint, csla
     b->stage = nullptr; b->stage_bytes = 0; b->last_stream = nullptr; b->ev_valid = false;
     b->side = nullptr; b->ev_fork = nullptr; b->ev_side = nullptr;
     b->h_nflag = nullptr; b->pending_flag_list = nullptr; b->pending_flag_count = nullptr; b->pending_dbg = 0;
-    b->last_nprod = 1; b->f32_backoff = 0;
+    b->last_nprod = 1; b->f32_backoff = 0; b->f32_backoff_len = 8; b->stage_pinned = false;
     b->pend.active = false; b->pend.deferred = false; b->ev_flag = nullptr;
     b->dbg_part_key = nullptr; b->dbg_part_idx = nullptr; b->dbg_nseg = 0; b->dbg_nq = 0; b->dbg_err_bound = 0.0;
     for (int s = 0; s < 4; ++s) { b->stats[s] = 0; b->item_map_key[s] = -1; }
@@ -1015,6 +1015,12 @@ CSLAM_API int cslam_bank_last_stats(cslam_bank_t *b, int64_t stats[4]) {
     BANK_DEVICE(b);
     HIP_TRY(hipStreamSynchronize(b->last_stream));
     for (int i = 0; i < 4; ++i) stats[i] = b->stats[i];
+    return CSLAM_OK;
+}
+
+CSLAM_API int cslam_bank_last_stage(cslam_bank_t *b, int32_t info[4]) {
+    ARG_CHECK(b && info, "NULL argument");
+    info[0] = b->last_nprod; info[1] = b->f32_backoff; info[2] = b->f32_backoff_len; info[3] = b->stage_pinned ? 1 : 0;
     return CSLAM_OK;
 }
 

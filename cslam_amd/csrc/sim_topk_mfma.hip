@@ -512,9 +512,12 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     int nprod = (s1 && s1[0] == 'f') ? 0 : ((s1 && s1[0] == 'p') ? 3 : 1);
     // Clustered banks (many near-duplicates inside the fp16 stages' re-scoring window, 2 x 1.57e-3 at 4096-D) overflow the 64
     // contenders stage 2 re-scores and send their queries through the exact scan: results stay exact, throughput does not.  When
-    // the last search left more than 1/32 of its queries uncertified, the next eight searches of this bank take the f32-input
-    // stage (window 2 x 2.6e-4: six times fewer contenders), then the fp16 stage is tried again.  An explicit CSLAM_MFMA_STAGE1
-    // switches this off.
+    // the last search left more than 1/32 of its queries uncertified, the next searches of this bank take the f32-input stage
+    // (window 2 x 2.6e-4: six times fewer contenders), then the fp16 stage is tried again: 8 searches the first time, twice as many
+    // after every retry that overflows again (up to 1024: a permanently clustered bank pays one exact-scan fallback per 1024
+    // searches), back to 8 once a retry certifies.  An explicit CSLAM_MFMA_STAGE1 switches this off (stage_pinned in
+    // cslam_bank_last_stage).
+    b->stage_pinned = s1 != nullptr;
     if (!s1 && b->f32_backoff > 0) { nprod = 0; --b->f32_backoff; }
     b->last_nprod = nprod;
     const int stage1_pair = nprod != 0;
@@ -814,7 +817,14 @@ int mfma_search_finish(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq,
                        int64_t *d_out_idx, double *d_out_sim, int32_t *d_out_cnt, hipStream_t st) {
     const int nflag = b->h_nflag ? *b->h_nflag : 0;        // valid once `st` has been synchronised
     b->stats[0] = nflag;
-    if (b->last_nprod != 0 && (int64_t)nflag * 32 > (int64_t)b->dbg_nq) b->f32_backoff = 8;
+    if (b->last_nprod != 0 && !b->stage_pinned) {
+        if ((int64_t)nflag * 32 > (int64_t)b->dbg_nq) {
+            b->f32_backoff = b->f32_backoff_len;
+            if (b->f32_backoff_len < 1024) b->f32_backoff_len *= 2;
+        } else {
+            b->f32_backoff_len = 8;
+        }
+    }
     if (nflag > 0 && b->pending_dbg == 0)
         return scan_search(b, d_q, q_dtype, ldq, b->pending_flag_list, nflag, k, d_row_limit, d_out_idx, d_out_sim,
                            d_out_cnt, st);

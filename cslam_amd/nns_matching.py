@@ -276,6 +276,13 @@ class NearestNeighborsMatching(object):
         _lib.check(self._lib.cslam_bank_last_stats(self._bank, C.byref(s)))
         return tuple(int(x) for x in s)
 
+    def last_stage(self):
+        """(fp16 products per pair of the last MFMA-mode search's candidate stage -- 0: the f32-input stage --, searches left on the
+        f32-input stage, length of the next back-off, whether CSLAM_MFMA_STAGE1 fixed the stage): cslam_bank_last_stage."""
+        s = (C.c_int32 * 4)()
+        _lib.check(self._lib.cslam_bank_last_stage(self._bank, C.byref(s)))
+        return int(s[0]), int(s[1]), int(s[2]), bool(s[3])
+
     def last_kernel_ms(self):
         ms = C.c_float(-1.0)
         _lib.check(self._lib.cslam_bank_last_kernel_ms(self._bank, C.byref(ms)))

@@ -140,6 +140,13 @@ int cslam_bank_search_multi_finish(cslam_bank_t *const *banks, int nb, int64_t *
  * stats[1] = mode actually used (CSLAM_MODE_*), stats[2] = bank segments,
  * stats[3] = query tiles.  Synchronises the bank's last stream.                    */
 int cslam_bank_last_stats(cslam_bank_t *bank, int64_t stats[4]);
+/* which candidate stage the last MFMA-mode search of this bank ran, and the state of its back-off (a bank whose near-duplicates
+ * overflow the fp16 stage's re-scoring window runs its next searches on the f32-input stage; results are exact either way, time is
+ * not): info[0] = fp16 products per pair of the last search's stage (1: the default; 3: exact pairs; 0: the f32-input stage),
+ * info[1] = searches left on the f32-input stage before the fp16 stage is retried, info[2] = length of the next back-off (8,
+ * doubling up to 1024 while retries keep overflowing), info[3] = 1 when CSLAM_MFMA_STAGE1 fixed the stage (no back-off).
+ * Valid after the search's finish; does not synchronise. */
+int cslam_bank_last_stage(cslam_bank_t *bank, int32_t info[4]);
 /* time (ms, HIP events on the launch stream) of the dominant kernel of the last
  * MFMA-mode search: sim_topk_mfma.  -1 if the last search did not use it.        */
 int cslam_bank_last_kernel_ms(cslam_bank_t *bank, float *ms);

@@ -617,14 +617,24 @@ def test_clustered_near_duplicates_stay_exact_and_back_off_to_the_f32_stage(nnm,
         assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
         _, _, bound = _stage1_candidates(nnm, nn, 4)
         frac[tag] = (nn.last_stats()[0] / 400.0, bound)
+        # the stage that ran and the back-off are visible (cslam_bank_last_stage): fp16 stage, then 7 searches left of the first 8
+        assert nn.last_stage() == ((1, 8, 16, False) if tag.startswith("h1") else (0, 7, 16, False))
     print("uncertified fraction / certificate bound per search:", frac)
     assert frac["h1 (first search)"][1] > 1e-3 and frac["h1 (first search)"][0] > 1.0 / 32      # the fp16 stage ran and gave up on many
     assert frac["after the back-off"][1] < 5e-4                                                 # the f32-input stage ran instead
     assert frac["after the back-off"][0] <= frac["h1 (first search)"][0]
-    # an explicit choice of stage is never overridden
+    # the bank stays clustered: after the eight searches the fp16 stage is retried, overflows again, and the next back-off is twice as long
+    for _ in range(7):
+        nn.search_batch(q, 5, mode=nnm.MODE_MFMA)
+    assert nn.last_stage() == (0, 0, 16, False)
+    idx, sims, cnt = nn.search_batch(q, 5, mode=nnm.MODE_MFMA)
+    assert nn.last_stage() == (1, 16, 32, False)
+    assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
+    # an explicit choice of stage is never overridden, and says so
     monkeypatch.setenv("CSLAM_MFMA_STAGE1", "h1")
     idx, sims, cnt = nn.search_batch(q, 5, mode=nnm.MODE_MFMA)
     assert _stage1_candidates(nnm, nn, 4)[2] > 1e-3
+    assert nn.last_stage()[0] == 1 and nn.last_stage()[3]
     assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
 
 
