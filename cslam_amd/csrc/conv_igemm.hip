@@ -59,6 +59,9 @@ struct ConvIgemmArgs {
     unsigned *bound_out;               // receives that bound (written by workgroup (0, 0))
     int res_pairs;                     // res is in pair format, scaled by ci_scale(*res_bound)
     const unsigned *res_bound;         // bound slot of res (pairs) / a bound of max |res| (float32 res, when out_pairs)
+    int dbg;                           // measurement build (-DCSLAM_ABLATIONS, CSLAM_CI_DBG; WRONG results, timing) of the AM = 2 loop: 1 no
+                                       // activation requests after the prologue, 2 no weight requests, 4 no barrier, 8 no wait for the
+                                       // requests, 16 no products, 32 no fragment reads either, 64 no epilogue
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t ci_rsrc(const char *base, int64_t bytes) {
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
     // product (the scheduler left to itself reads three, waits, multiplies: an LDS round trip in front of every other MFMA) and the
     // products stay in front of the step's closing wait; AM = 0, 1: the scheduler is free to weave the next block's split into the
     // MFMA stream (pinning the order there costs: the stem 2.6 -> 10.4 ms)
-    auto multiply = [&](const char *sA) {
+    auto multiply = [&](const char *sA, bool products = true) {
         const char *sB = sA + OPA;
         if (PAIRS) {
             f16x8 fa[2][2][MT], fb[2][2][NT];
@@ -298,6 +301,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+            if (!products) {                           // (measurement build: the fragments are still read and waited for)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                    for (int m = 0; m < MT; ++m) asm volatile("" :: "v"(fa[s][0][m]), "v"(fa[s][1][m]));
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) asm volatile("" :: "v"(fb[s][0][n]), "v"(fb[s][1][n]));
+                }
+                return;
+            }
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -400,23 +413,33 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
         }
         __builtin_amdgcn_s_barrier();
         int cur = 0, nxt = NST - 1;                    // stage of block k, stage block k + NST - 1 goes to
+#ifdef CSLAM_ABLATIONS
+        const int dbg = p.dbg;
+#else
+        constexpr int dbg = 0;
+#endif
         for (int k = 0; k < p.nk; ++k) {
             const bool more = k + NST - 1 < p.nk;
             if (more) {
                 advance();
-                a_dma(nxt, kh, kw, cb);
-                b_load(nxt, k + NST - 1);
+                if (!(dbg & 1)) a_dma(nxt, kh, kw, cb);
+                if (!(dbg & 2)) b_load(nxt, k + NST - 1);
             }
-            multiply(smem + cur * STAGE);              // (ends in a sched_barrier: MFMAs are no memory operations, the scheduler sinks them
+            if (!(dbg & 32)) multiply(smem + cur * STAGE, !(dbg & 16));
+                                                       // (ends in a sched_barrier: MFMAs are no memory operations, the scheduler sinks them
                                                        // below the wait and the barrier, and the requests then have no products to fly under)
             if (NST == 3 && more) __builtin_amdgcn_s_waitcnt(NDMA | (7 << 4) | (0 << 8));
+            else if (dbg & 8) __builtin_amdgcn_s_waitcnt(0xC07F);                   // lgkmcnt(0) only (vmcnt 63, expcnt 7)
             else __builtin_amdgcn_s_waitcnt(0);
-            __builtin_amdgcn_s_barrier();
+            if (!(dbg & 4)) __builtin_amdgcn_s_barrier();
             cur = cur + 1 == NST ? 0 : cur + 1;
             nxt = nxt + 1 == NST ? 0 : nxt + 1;
         }
     }
 
+#ifdef CSLAM_ABLATIONS
+    if (p.dbg & 64) return;
+#endif
     // ---- epilogue: lane = output channel (128-byte runs per pixel), 16 pixels per accumulator tile
     const float inv = p.inv_sw / sc;
     float amax = 0.0f;
@@ -601,6 +624,10 @@ static int conv_igemm_launch(const float *d_x, const void *d_w2, const float *d_
     a.relu = relu; a.amax_in = d_amax_in; a.inv_sw = inv_sw; a.amax_out = d_amax_out;
     a.xbound = f.xbound; a.out_pairs = f.out_pairs; a.wl1 = f.wl1; a.bmax = f.bmax; a.bound_out = f.bound_out;
     a.res_pairs = f.res_pairs; a.res_bound = f.res_bound;
+    a.dbg = 0;
+#ifdef CSLAM_ABLATIONS
+    if (const char *e = getenv("CSLAM_CI_DBG")) a.dbg = atoi(e);
+#endif
     ARG_CHECK(!f.x_pairs || (!stem && f.xbound), "pair-format input needs its bound slot (and is not the stem's format)");
     ARG_CHECK(!f.out_pairs || (!pool && f.bound_out && f.wl1 > 0.0f && f.bmax >= 0.0f), "pair-format output needs wl1, bmax and the bound slot");
     ARG_CHECK(!(d_res && (f.res_pairs || f.out_pairs)) || f.res_bound, "the shortcut's bound slot is missing");
