@@ -105,6 +105,7 @@ class CosPlace(object):
         self._online = None
         self._online_runner = None
         self._online_model = None
+        self._lanes, self._lanes_epoch = [], None
         ckpt = self.params['frontend.nn_checkpoint']
         if ckpt == 'random':               # benchmark / test mode: seeded random weights, no files
             self.random_init(int(self.params.get('frontend.random_seed', 0)))
@@ -143,6 +144,27 @@ class CosPlace(object):
         # normalisation constants: saves the first convolution a pass over it
         x = heads.preprocess(frames_u8.contiguous(), self.crop, channels_last=True)
         return self.model.forward(x, backbone_dtype, _runner, heads.normalised_image_bound())
+
+    def compute_embeddings_batch_device(self, frames_u8, chunk=1000, lanes=2):
+        """frames [B,H,W,3] uint8 (device) -> descriptors [B, d] float32 (device), `chunk` frames per pass of the pipeline, the passes
+        alternating over `lanes` HIP streams, each with its own trunk runner and workspaces (heads.extract_over_lanes: two passes in
+        flight fill each other's tails and launch gaps).  Each chunk runs exactly the kernels of `compute_embeddings_device` on its
+        frames, so the descriptors do not depend on `lanes`.  (Since round 5 every kernel of the ResNet runner is this library's: no
+        library convolution with per-stream set-up is left.)"""
+        if lanes <= 1 or frames_u8.shape[0] <= chunk or self.backbone_conv not in ('winograd', 'winograd2'):
+            outs = [self.compute_embeddings_device(frames_u8[s:s + chunk]) for s in range(0, int(frames_u8.shape[0]), chunk)]
+            return outs[0] if len(outs) == 1 else torch.cat(outs)
+
+        def lane_runner(i):
+            if i == 0:
+                if self.model.runner is None:
+                    self.model.runner = self.model.make_runner()
+                return self.model.runner                               # lane 0 shares the single-pass runner (and its workspaces)
+            return self.model.make_runner()
+        if self._lanes_epoch is not self.model.runner_epoch():         # the weights were reloaded: folded weights are rebuilt
+            self._lanes, self._lanes_epoch = [], self.model.runner_epoch()
+        return heads.extract_over_lanes(self._lanes, frames_u8, chunk, lanes, lane_runner,
+                                        lambda fr, runner: self.compute_embeddings_device(fr, _runner=runner))
 
     def compute_embedding(self, keyframe):
         """Global image descriptor of one RGB keyframe (reference cosplace.py:81-105)."""

@@ -158,9 +158,9 @@ def extract_over_lanes(lane_list, frames_u8, chunk, lanes, lane_runner, run_chun
     own V / M workspaces); `run_chunk(frames, runner)` -> [b, d] runs one pass on the CURRENT stream.  Two passes in flight fill
     each other's tails and launch gaps (NetVLAD: 16.5 -> 15.3 ms per 256 frames with two lanes, no gain from a third, none from
     offsetting the lanes by part of a pass: profiles/r03_v25_two_lanes.log).  The lanes start behind the caller's stream and the
-    caller's stream continues behind them: no host synchronisation.  (Not offered for CosPlace: its ResNet runner launches
-    library convolutions -- 7 x 7 stem, strided layers -- whose per-stream set-up made a second lane 16 x slower and the
-    descriptors differ in the last bit, profiles/r03_v30_c2_lanes_rejected.log.)"""
+    caller's stream continues behind them: no host synchronisation.  (CosPlace: offered since round 5 -- while its ResNet runner
+    launched library convolutions, 7 x 7 stem and strided layers, their per-stream set-up made a second lane 16 x slower,
+    profiles/r03_v30_c2_lanes_rejected.log.)"""
     B = int(frames_u8.shape[0])
     starts = list(range(0, B, chunk))
     lanes = min(lanes, len(starts))

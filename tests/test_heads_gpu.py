@@ -415,6 +415,21 @@ def test_cosplace_descriptors_winograd_vs_direct(T):
             assert (w - d).abs().max().item() <= 1e-5, (bb, mode)
 
 
+def test_cosplace_extraction_lanes_give_the_single_stream_descriptors(T):
+    """CosPlace.compute_embeddings_batch_device: chunks alternating over two streams with a runner each -- the same kernels on the same
+    frames, so bit-equal to the single-stream passes (and the caller's stream continues behind the lanes without a host wait)."""
+    torch, _ = T
+    from cslam_amd.vpr.cosplace import CosPlace
+    frames = torch.from_numpy(np.random.default_rng(16).integers(0, 256, size=(22, 300, 320, 3), dtype=np.uint8)).cuda()
+    cp = CosPlace({"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 280, "frontend.cosplace.descriptor_dim": 128,
+                   "frontend.cosplace.backbone": "resnet18"}, None)
+    one = torch.cat([cp.compute_embeddings_device(frames[s:s + 8]) for s in range(0, 22, 8)])
+    for lanes in (2, 3):
+        got = cp.compute_embeddings_batch_device(frames, chunk=8, lanes=lanes)
+        again = cp.compute_embeddings_batch_device(frames, chunk=8, lanes=lanes)
+        assert got.shape == one.shape and torch.equal(got, one) and torch.equal(again, one)
+
+
 def test_online_hip_graph_replay_equals_plain_launches(T):
     """With frontend.hip_graph compute_embedding (one keyframe) replays a captured HIP graph; it must return what the
     same kernels give when launched one by one (the library GEMMs may pick another solution under capture, hence

@@ -48,5 +48,24 @@ rows2, sims2, cnt2 = pend.finish(); torch.cuda.synchronize()
 dp = time.perf_counter() - t1
 assert torch.equal(rows2, rows) and torch.equal(cnt2, cnt)
 print(f"C2 [{MODE}] pipelined: {N / dp:.0f} keyframes/s")
+# two extraction lanes: 2 x CH frames per iteration, the passes alternating over two streams
+big = torch.cat([frames, frames])
+dl = cp.compute_embeddings_batch_device(big, CH, 2); torch.cuda.synchronize()
+assert torch.equal(dl[:CH], cp.compute_embeddings_device(frames))
+nn3 = nnm.NearestNeighborsMatching()
+torch.cuda.synchronize()
+t2 = time.perf_counter(); pend = None; done3 = 0
+while done3 < N:
+    m = min(2 * CH, N - done3)
+    d = cp.compute_embeddings_batch_device(big[:m], CH, 2)
+    if pend is not None:
+        pend.finish()
+    nn3.add_items_device(d)
+    lim = torch.arange(done3, done3 + m, device="cuda", dtype=torch.int64)
+    pend = nn3.search_device_async(d, 5, row_limit=lim, mode=nnm.MODE_AUTO)
+    done3 += m
+pend.finish(); torch.cuda.synchronize()
+dl2 = time.perf_counter() - t2
+print(f"C2 [{MODE}] pipelined, two extraction lanes: {N / dl2:.0f} keyframes/s")
 print(f"C2 [{MODE}]: {N} keyframes, chunk {CH}: extract+match {N/dt:.0f} keyframes/s (extract {N/te:.0f}/s, causal match {N/tm:.0f}/s), "
       f"bank rows {nn.n}, last chunk cnt min {int(cnt.min())}")
