@@ -61,7 +61,7 @@ struct ConvIgemmArgs {
     const unsigned *res_bound;         // bound slot of res (pairs) / a bound of max |res| (float32 res, when out_pairs)
     int dbg;                           // measurement build (-DCSLAM_ABLATIONS, CSLAM_CI_DBG; WRONG results, timing) of the AM = 2 loop: 1 no
                                        // activation requests after the prologue, 2 no weight requests, 4 no barrier, 8 no wait for the
-                                       // requests, 16 no products, 32 no fragment reads either, 64 no epilogue
+                                       // requests, 16 no products, 32 no fragment reads either, 64 no epilogue, 128 activation requests for the taps with kw = 0 only
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t ci_rsrc(const char *base, int64_t bytes) {
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
             const bool more = k + NST - 1 < p.nk;
             if (more) {
                 advance();
-                if (!(dbg & 1)) a_dma(nxt, kh, kw, cb);
+                if (!(dbg & 1) && (!(dbg & 128) || kw == 0)) a_dma(nxt, kh, kw, cb);
                 if (!(dbg & 2)) b_load(nxt, k + NST - 1);
             }
             if (!(dbg & 32)) multiply(smem + cur * STAGE, !(dbg & 16));
