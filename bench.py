@@ -881,6 +881,36 @@ def main():
                            "direct_conv_TFLOPs": round(fps * GF / 1e3, 1),
                            "note": "whole-extract rate from wall time (crop, resize, trunk, GeM head): it includes the non-GEMM passes and "
                                    "the stem's padded K (147 taps in 7 blocks of 32), so it is below every layer's own fraction"}}
+        # the four stride-1 3x3 layer shapes of the trunk alone, in the pair format the trunk runs them in (HIP events on the launch
+        # stream, 10 launches each): the dominant kernel's own rate beside the whole-extract figure above
+        from cslam_amd.vpr import winograd as wg
+        lay = {}
+        ws_l = wg._Workspace()
+        for lname, cch, hw_l in (("layer1 64->64 @56", 64, 56), ("layer2 128->128 @28", 128, 28), ("layer3 256->256 @14", 256, 14),
+                                 ("layer4 512->512 @7", 512, 7)):
+            xl = torch.randn((ch, cch, hw_l, hw_l), device=dev).contiguous(memory_format=torch.channels_last)
+            wl = torch.randn((cch, cch, 3, 3), device=dev) / (3 * cch ** 0.5)
+            sl = torch.zeros(8, device=dev)
+            sl[0] = xl.abs().max()
+            eye = torch.eye(cch, device=dev).reshape(cch, cch, 1, 1).contiguous()
+            ap = wg.conv_igemm_p(ws_l, wg.PairAct(xl, False, xl.shape, sl[0:1], sl[0:1]), wg.igemm_pair_weights(eye), None, (1, 1), 1, 0,
+                                 False, None, 1.0, 0.0, sl[1:2], sl[2:3], True)
+            Wl, wl1 = wg.igemm_pair_weights(wl), float(wl.abs().sum(dim=(1, 2, 3)).max())
+            run_l = lambda: wg.conv_igemm_p(ws_l, ap, Wl, None, (3, 3), 1, 1, True, None, wl1, 0.0, sl[3:4], sl[4:5], True)   # noqa: E731
+            run_l()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                run_l()
+            e1.record()
+            torch.cuda.synchronize()
+            ms_l = e0.elapsed_time(e1) / 10
+            fl_l = 2.0 * 3 * ch * hw_l * hw_l * cch * 9 * cch
+            lay[lname] = {"kernel_ms": round(ms_l, 4), "achieved": round(fl_l / ms_l / 1e9, 1),
+                          "frac": round(fl_l / ms_l / 1e9 / FP16_MFMA_PEAK_TFLOPS, 4)}
+            del xl, ap
+        c2["roofline"]["layers"] = {"kernel": "conv_igemm_h2_kernel (pair-format input and output), %d frames" % ch,
+                                    "unit": "TFLOP/s (fp16, 3 products)", "peak": FP16_MFMA_PEAK_TFLOPS, **lay}
         if not a.no_cpu_baseline:
             ncf = max(1, min(a.cpu_frames, 8))
             xcpu = torch.randn((ncf, 3, 224, 224))
