@@ -470,15 +470,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
             const int pr = pp / 9, pc = pp - pr * 9;
             const int gp = tr * 4 + pr, gq = tc * 8 + pc;
             if (gp >= Hp || gq >= Wp) continue;
+            // nine unconditional reads: a window row / column outside the tile is clamped onto one inside (a duplicate does not change a
+            // maximum) -- with `continue` around them every read sat in a block of its own behind its own LDS round trip
             float mx = 0.0f;
 #pragma unroll
             for (int dr = -1; dr <= 1; ++dr) {
-                const int lr = 2 * pr + dr;
-                if (lr < 0 || lr > 7) continue;
+                const int lr = min(max(2 * pr + dr, 0), 7);
 #pragma unroll
                 for (int dc = -1; dc <= 1; ++dc) {
-                    const int lc = 2 * pc + dc;
-                    if (lc < 0 || lc > 15) continue;
+                    const int lc = min(max(2 * pc + dc, 0), 15);
                     mx = fmaxf(mx, T[(lr * 16 + lc) * TN + ch]);
                 }
             }
@@ -580,6 +580,215 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
     }
 }
 
+// ---- The ResNet stem (7x7 / 2, pad 3, 3 -> 64 channels) with its MaxPool2d(3, 2, 1), patch form --------------------------------------
+// The implicit-GEMM stem above gathers every K block of every pixel from global memory (sixteen 4-byte loads per thread and kernel row)
+// and splits it again: 0.18 of the matrix peak.  Here a persistent workgroup (one per CU, eight waves) keeps the WEIGHTS in LDS for the
+// whole launch (57 KB of B fragments in lane order), reads the 21 x 37-pixel image patch of an 8 x 16-pixel output tile ONCE, converts it
+// to hi and lo planes once, and the MFMA A fragments are plain 4-byte LDS reads of those planes: pixel (r, c), kernel row kh, K group g
+// = 8 consecutive halfs from float 6 c + 8 g of patch row 2 r + kh (the run of 21 floats (kw, ci) the K block is made of; slots 21..31
+// are masked to zero).  No per-K-block staging, no barrier inside a tile's K loop.  Same products in the same order as
+// conv_igemm_h2_kernel<.., 1>: the results are bit-equal.
+// Two GROUPS of four waves share the weights and alternate: while one group runs the K loop of its tile (matrix pipe), the other pools
+// and stores its previous tile (LDS and vector memory) -- with four waves alone (one per SIMD) every LDS round trip of the K loop and
+// the whole pooling, which is as long as the K loop, were exposed: 3.7 ms against the implicit-GEMM form's 2.55.  A group's wave w: tile
+// rows 2 w, 2 w + 1 (32 pixels) x 64 channels; accumulators 2 x 16.
+#ifdef CSLAM_ABLATIONS
+#define CI_STEM_PATCH_FORM (!getenv("CSLAM_SP_OFF"))   // measurement build: the implicit-GEMM pooled form as the A/B partner
+#else
+#define CI_STEM_PATCH_FORM true
+#endif
+#define SP_PPH 120                      // halfs per patch row and plane (112 used + the run a last group overhangs by)
+#define SP_PLANE (21 * SP_PPH * 2 + 64) // bytes of one plane (+ the overhang of the last row's reads)
+#define SP_WBYTES (7 * 2 * 2 * 2 * 64 * 16)
+#define SP_GROUP (4 * SP_PLANE + 128 * 64 * 4)      // a group's two patch buffers (hi + lo planes each) and its pooling tile
+#define SP_LDS (SP_WBYTES + 2 * SP_GROUP)           // 163 712 of the CU's 163 840 bytes
+struct StemPatchArgs {
+    const float *x; const char *w2; const float *bias; float *y;
+    int B, H, W, Ho, Wo, ntiles, tcols, tpi, n_xcd;
+    const unsigned *amax_in; float inv_sw; unsigned *amax_out;
+    int dbg;                           // measurement build (CSLAM_SP_DBG; WRONG results, timing): 1 no pooling phase, 2 no K loop, 4 no patch
+                                       // split, 8 no patch requests, 16 stores instead of the atomic maxima, 32 neither
+};
+__global__ __launch_bounds__(512, 1) void conv_stem_pool_patch_kernel(StemPatchArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, w4 = wave & 3, gt = tid & 255;
+    const int h = lane >> 5, l31 = lane & 31;
+#ifdef CSLAM_ABLATIONS
+    const int dbg = p.dbg;
+#else
+    constexpr int dbg = 0;
+#endif
+    char *s_w = smem;                                  // [kh 7][s 2][n 2][hi | lo][lane 64] x 16 bytes
+    char *s_patch = smem + SP_WBYTES + grp * SP_GROUP; // [buffer 2][hi | lo] planes of this group
+    float *T = (float *)(s_patch + 4 * SP_PLANE);
+    const float sc = ci_scale(*p.amax_in);
+    const float inv = p.inv_sw / sc;
+    // ---- weights: global rows [co][kh][hi 32 | lo 32] -> fragment order
+    for (int e = tid; e < 7 * 2 * 2 * 2 * 64; e += 512) {
+        const int ln = e & 63, hl = (e >> 6) & 1, n = (e >> 7) & 1, ss = (e >> 8) & 1, kh = e >> 9;
+        const int co = n * 32 + (ln & 31), hh = ln >> 5;
+        *(cu4 *)(s_w + e * 16) = *(const cu4 *)(p.w2 + ((size_t)(co * 7 + kh) * 128 + hl * 64 + (16 * ss + 8 * hh) * 2));
+    }
+    // ---- tiles: XCD b % n_xcd walks a contiguous range of tiles; (slot b / n_xcd, group) takes every (2 slots)-th of it
+    const int xcd = blockIdx.x % p.n_xcd, slot = blockIdx.x / p.n_xcd, nslot = gridDim.x / p.n_xcd;
+    const int per = (p.ntiles + p.n_xcd - 1) / p.n_xcd;
+    const int t_lo = xcd * per, t_hi = min(p.ntiles, t_lo + per);
+    const int step = 2 * nslot;
+    const int64_t img = (int64_t)p.H * p.W * 3;
+    float raw[10];
+    auto patch_request = [&](int tile) {               // 21 rows x 111 floats of the tile's patch -> registers (zeros outside the image)
+        const int tb = tile / p.tpi, t = tile - tb * p.tpi, tr = t / p.tcols, tc = t - tr * p.tcols;
+        const __amdgpu_buffer_rsrc_t rs = ci_rsrc((const char *)(p.x + tb * img), img * 4);
+        const int gy0 = tr * 16 - 3, gx0 = (tc * 32 - 3) * 3;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const int e = gt + j * 256;
+            const int pr = e / 111, pf = e - pr * 111;
+            const int gy = gy0 + pr, gx = gx0 + pf;
+            const bool in = e < 21 * 111 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)(p.W * 3);
+            raw[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, in ? (gy * p.W * 3 + gx) * 4 : 0x7fffffff, 0, 0));
+        }
+    };
+    auto patch_store = [&](int buf) {                  // split into the hi and lo planes (the split of conv_igemm's a_store)
+        char *hp = s_patch + buf * 2 * SP_PLANE, *lp = hp + SP_PLANE;
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            const int e = gt + j * 256;
+            if (e < 21 * 111) {
+                const int pr = e / 111, pf = e - pr * 111;
+                const float v = raw[j] * sc;
+                const __half hv = __float2half_rn(v);
+                const __half lv = __float2half_rn(v - __half2float(hv));
+                *(__half *)(hp + (pr * SP_PPH + pf) * 2) = hv;
+                *(__half *)(lp + (pr * SP_PPH + pf) * 2) = lv;
+            }
+        }
+    };
+    // fragment addresses: pixel (r = 2 w4 + (l31 >> 4), c = l31 & 15); K step s, half h -> group g = 2 s + h
+    const int a_base = ((2 * (2 * w4 + (l31 >> 4))) * SP_PPH + 6 * (l31 & 15) + 8 * h) * 2;
+    const bool hz = h;                                 // K step 1: group 3 (h = 1) is all padding, group 2 keeps slots 16..20
+    float amax = 0.0f;
+    float bv[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) bv[n] = p.bias ? p.bias[n * 32 + l31] : 0.0f;
+    int tile = t_lo + 2 * slot + grp;
+    int ntl = tile < t_hi ? (t_hi - tile + step - 1) / step : 0;           // this group's tiles; the other group's count differs by <= 1
+    const int tile_o = t_lo + 2 * slot + (grp ^ 1);
+    const int ntl_o = tile_o < t_hi ? (t_hi - tile_o + step - 1) / step : 0;
+    const int nphase = 2 * (ntl > ntl_o ? ntl : ntl_o) + 2;
+    if (ntl > 0) patch_request(tile);
+    __syncthreads();                                   // (the weights)
+    if (ntl > 0) patch_store(0);
+    __syncthreads();
+    int buf = 0, pool_tile = -1;
+    // phase ph: the group with (ph & 1) == grp multiplies its next tile, the other pools the tile it multiplied one phase earlier
+    for (int ph = 0; ph < nphase; ++ph) {
+        if ((ph & 1) == grp) {
+            if (tile < t_hi) {
+                const int nxt = tile + step;
+                if (nxt < t_hi && !(dbg & 8)) patch_request(nxt);
+                f32x16 acc[2];
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+                const char *hp = s_patch + buf * 2 * SP_PLANE + a_base, *lp = hp + SP_PLANE;
+                // 14 steps (kernel row kh, K step ss); the fragments of step i + 1 are requested before the products of step i (two
+                // register sets): with one wave per SIMD in this phase an LDS round trip in front of every three MFMAs is not hidden
+                cu4 ah[2], al[2];
+                f16x8 fbh[2][2], fbl[2][2];
+                auto load_step = [&](int st, int set) {
+                    const int kh = st >> 1, ss = st & 1;
+                    const int off = (kh * SP_PPH + 16 * ss) * 2;
+                    if (ss == 0) {
+                        ah[set] = (cu4){*(const unsigned *)(hp + off), *(const unsigned *)(hp + off + 4), *(const unsigned *)(hp + off + 8), *(const unsigned *)(hp + off + 12)};
+                        al[set] = (cu4){*(const unsigned *)(lp + off), *(const unsigned *)(lp + off + 4), *(const unsigned *)(lp + off + 8), *(const unsigned *)(lp + off + 12)};
+                    } else {
+                        const unsigned h0 = *(const unsigned *)(hp + off), h1 = *(const unsigned *)(hp + off + 4), h2 = *(const unsigned *)(hp + off + 8);
+                        const unsigned l0 = *(const unsigned *)(lp + off), l1 = *(const unsigned *)(lp + off + 4), l2 = *(const unsigned *)(lp + off + 8);
+                        ah[set] = (cu4){hz ? 0u : h0, hz ? 0u : h1, hz ? 0u : (h2 & 0xffffu), 0u};
+                        al[set] = (cu4){hz ? 0u : l0, hz ? 0u : l1, hz ? 0u : (l2 & 0xffffu), 0u};
+                    }
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const char *wb = s_w + ((((kh * 2 + ss) * 2 + n) * 2) * 64 + lane) * 16;
+                        fbh[set][n] = *(const f16x8 *)wb;
+                        fbl[set][n] = *(const f16x8 *)(wb + 64 * 16);
+                    }
+                };
+                if (!(dbg & 2)) {
+                    load_step(0, 0);
+#pragma unroll
+                    for (int st = 0; st < 14; ++st) {
+                        const int set = st & 1;
+                        if (st + 1 < 14) load_step(st + 1, set ^ 1);
+                        const f16x8 fah = *(const f16x8 *)&ah[set], fal = *(const f16x8 *)&al[set];
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) {
+                            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fbh[set][n], acc[n], 0, 0, 0);
+                            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fal, fbh[set][n], acc[n], 0, 0, 0);
+                            acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fah, fbl[set][n], acc[n], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                if (nxt < t_hi && !(dbg & 4)) patch_store(buf ^ 1);
+                // ReLU(conv + bias) -> T [pixel 128][channel 64]: pooled one phase later
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = w4 * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const float v = fmaxf(acc[n][r] * inv + bv[n], 0.0f);
+                        T[row * 64 + n * 32 + l31] = v;
+                        amax = fmaxf(amax, v);
+                    }
+                pool_tile = tile;
+                tile = nxt;
+                buf ^= 1;
+            }
+        } else if (pool_tile >= 0 && !(dbg & 1)) {
+            // the pooling of conv_igemm_h2_kernel's pooled form, on this group's 256 threads
+            const int tb = pool_tile / p.tpi, t = pool_tile - tb * p.tpi, tr = t / p.tcols, tc = t - tr * p.tcols;
+            const int Hp = p.Ho >> 1, Wp = p.Wo >> 1;
+            // 45 pooled positions x 64 channels on 256 threads: a wave takes positions w4, w4 + 4, ... (wave-uniform: scalar index
+            // arithmetic), the lane is the channel; unrolled so that the reads of several positions are in flight together
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const int pp = w4 + 4 * k, ch = lane;
+                if (pp >= 45) break;
+                const int pr = pp / 9, pc = pp - pr * 9;
+                const int gp = tr * 4 + pr, gq = tc * 8 + pc;
+                if (gp >= Hp || gq >= Wp) continue;
+                // nine unconditional reads: a window row / column outside the tile is clamped onto one inside (a duplicate does not change
+                // a maximum) -- with `continue` around them every read sat in a block of its own behind its own LDS round trip
+                float mx = 0.0f;
+#pragma unroll
+                for (int dr = -1; dr <= 1; ++dr) {
+                    const int lr = min(max(2 * pr + dr, 0), 7);
+#pragma unroll
+                    for (int dc = -1; dc <= 1; ++dc) {
+                        const int lc = min(max(2 * pc + dc, 0), 15);
+                        mx = fmaxf(mx, T[(lr * 16 + lc) * 64 + ch]);
+                    }
+                }
+                float *dst = p.y + (((int64_t)tb * Hp + gp) * Wp + gq) * 64 + ch;
+                const bool whole = (pr >= 1 || tr == 0) && pr <= 3 && (pc >= 1 || tc == 0) && pc <= 7;
+                if (whole || (dbg & 16)) *dst = mx;
+                else if (!(dbg & 32)) atomicMax((unsigned *)dst, __float_as_uint(mx));
+            }
+            pool_tile = -1;
+        }
+        __syncthreads();
+    }
+    if (p.amax_out) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off, 64));
+        if (lane == 0 && __float_as_uint(amax) > *(volatile unsigned *)p.amax_out) atomicMax(p.amax_out, __float_as_uint(amax));
+    }
+}
+
 __global__ __launch_bounds__(256) void ci_zero_kernel(float4 *__restrict__ y, int64_t n4) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) y[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
@@ -637,12 +846,36 @@ static int conv_igemm_launch(const float *d_x, const void *d_w2, const float *d_
     const dim3 grid((unsigned)ceil_div64(P, tm), (unsigned)(Cout / tn)), blk(256);          // (pooled form: P / 128 tiles exactly)
     const int lds = 2 * (tm + tn) * CI_ROWB;                                                 // >= 128 x tn floats, the pooled form's tile
     hipStream_t st = (hipStream_t)stream;
+    const bool patch_form = CI_STEM_PATCH_FORM && pool && Cout == 64 && KH == 7 && KW == 7 && stride == 2 && pad == 3 && (int64_t)H * W * 12 < 0x7fffffffll;
     if (pool) {
         // (a kernel, not hipMemsetAsync: as a memset NODE of a captured graph the fill did not precede the convolution on replay --
         // tests/test_heads_gpu.py::test_online_hip_graph_replay_equals_plain_launches caught the second replay 3e-2 off)
         const int64_t n4 = (int64_t)B * (a.Ho / 2) * (a.Wo / 2) * Cout / 4;
         const int zb = (int)(n4 < 4096 * 256 ? (n4 + 255) / 256 : 4096);
         hipLaunchKernelGGL(ci_zero_kernel, dim3(zb), dim3(256), 0, st, (float4 *)d_y, n4);
+    }
+    if (patch_form) {
+        StemPatchArgs sp;
+        sp.x = d_x; sp.w2 = (const char *)d_w2; sp.bias = d_bias; sp.y = d_y;
+        sp.B = B; sp.H = H; sp.W = W; sp.Ho = a.Ho; sp.Wo = a.Wo;
+        sp.tcols = a.Wo / 16; sp.tpi = (a.Ho / 8) * sp.tcols; sp.ntiles = B * sp.tpi;
+        sp.amax_in = d_amax_in; sp.inv_sw = inv_sw; sp.amax_out = d_amax_out;
+        sp.dbg = 0;
+#ifdef CSLAM_ABLATIONS
+        if (const char *e = getenv("CSLAM_SP_DBG")) sp.dbg = atoi(e);
+#endif
+        const int n_cu = cslam_cu_count();
+        ARG_CHECK(n_cu > 0, "no HIP device");
+        sp.n_xcd = n_cu % 8 == 0 ? 8 : 1;
+        int nb = (sp.ntiles + 1) / 2 < n_cu ? (sp.ntiles + 1) / 2 : n_cu;       // a workgroup = two groups of four waves = two tiles at a time
+        if (nb >= sp.n_xcd) nb -= nb % sp.n_xcd; else sp.n_xcd = 1;
+        static DeviceOnce once_sp; int once_dev_sp;
+        if (once_sp.todo(&once_dev_sp)) {
+            HIP_TRY(hipFuncSetAttribute((const void *)conv_stem_pool_patch_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SP_LDS));
+            once_sp.done(once_dev_sp); }
+        hipLaunchKernelGGL(conv_stem_pool_patch_kernel, dim3(nb), dim3(512), SP_LDS, st, sp);
+        HIP_TRY(hipGetLastError());
+        return CSLAM_OK;
     }
 #define CI_LAUNCH(TM_, TN_, ST_) do { \
         static DeviceOnce once; int once_dev; \
