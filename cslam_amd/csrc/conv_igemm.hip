@@ -22,7 +22,8 @@
 //   AM 1  the 3-channel 7x7 stem.  A tap's channels are 12 bytes, so a K block is a whole kernel ROW: the 21 values (kw, c) of row kh are
 //         consecutive floats of the NHWC image; 7 blocks of 32 slots (21 used, the weights of the others zero), sixteen 4-byte buffer
 //         loads per thread and block.  (K packed densely over (kh, kw, c) -- 147 values in 5 blocks, the tap decoded per element --
-//         measured slower: 3.25 against 2.70 ms per 1000 frames.)  With `pool`: 8 x 16-pixel tiles and MaxPool2d(3, 2, 1) in the epilogue;
+//         measured slower: 3.25 against 2.70 ms per 1000 frames.)  With `pool`: 8 x 16-pixel tiles and MaxPool2d(3, 2, 1) in the epilogue
+//         (ResNet's 7x7 / 2 / 64-channel geometry: the persistent patch-form kernel further down instead);
 //   AM 2  PAIR-FORMAT map, written by a previous layer's epilogue as [pixel][32-channel block][hi 32 | lo 32] -- the row image itself:
 //         plain LDS-DMA like the weights, no register and no VALU work per K block.  Its scale is fixed before the producer has run: the
 //         power of two for the bound max|x| max_co sum|w| + max|b| (+ max|shortcut|), carried in a 4-byte slot beside the measured maximum.
@@ -915,7 +916,9 @@ CSLAM_API int cslam_conv_igemm_h2p_dev(const void *d_x, int x_pairs, const unsig
 }
 /* The stem with its pooling: y = MaxPool2d(3, 2, 1)(ReLU(conv(x, w) + bias)) for x [B,H,W,3] -> y [B,Ho/2,Wo/2,Cout] (Ho a multiple of 8,
  * Wo of 16: ResNet's 7x7 / 2 stem on 224 x 224 frames gives 112 x 112).  The un-pooled map never exists in HBM; d_amax_out receives max
- * of the UN-pooled map (a bound of the pooled one).  conv1 + bn1 + relu + maxpool of the torchvision ResNet trunk cslam/vpr/cosplace_utils/network.py:38-68 builds. */
+ * of the UN-pooled map (a bound of the pooled one).  ResNet's own geometry (7x7, stride 2, pad 3, 64 channels) runs the persistent
+ * patch-form kernel (conv_stem_pool_patch_kernel), any other one the implicit-GEMM form with 8 x 16-pixel tiles: the same products in the
+ * same order.  conv1 + bn1 + relu + maxpool of the torchvision ResNet trunk cslam/vpr/cosplace_utils/network.py:38-68 builds. */
 CSLAM_API int cslam_conv_stem_pool_igemm_h2_dev(const float *d_x, const void *d_w2, const float *d_bias, int B, int H, int W, int Cout,
                                                 int KH, int KW, int stride, int pad, const unsigned *d_amax_in, float inv_sw,
                                                 unsigned *d_amax_out, float *d_y, void *stream) {
