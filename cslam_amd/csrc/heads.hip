@@ -964,35 +964,62 @@ __global__ __launch_bounds__(256) void gem_fc_nhwc_kernel(const float *__restric
     const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6, nw = nt >> 6;
     const float *x = feat + (size_t)blockIdx.x * C * P;
     const int C4 = C >> 2;
-    for (int p = wave; p < P; p += nw) {                               // L2Norm over channels per pixel (layers.py:32-36)
-        const float4 *xr = (const float4 *)(x + (size_t)p * C);
-        float s = 0.0f;
-        for (int c = lane; c < C4; c += 64) { const float4 v = xr[c]; s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
-        s = wave_sum_f32(s);
-        if (lane == 0) invn[p] = 1.0f / fmaxf(sqrtf(s), 1e-12f);
+    for (int p0 = wave * 4; p0 < P; p0 += nw * 4) {                    // L2Norm over channels per pixel (layers.py:32-36): four pixels a step
+        float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int c = lane; c < C4; c += 64) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (p0 + j < P) {
+                    const float4 v = ((const float4 *)(x + (size_t)(p0 + j) * C))[c];
+                    s4[j] += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t = wave_sum_f32(s4[j]);
+            if (lane == 0 && p0 + j < P) invn[p0 + j] = 1.0f / fmaxf(sqrtf(t), 1e-12f);
+        }
     }
     __syncthreads();
     const float ip = 1.0f / pw, invP = 1.0f / (float)P;                // GeM (layers.py:8-9): avg_pool(clamp(x, min=eps)^p)^(1/p)
     const bool cube = pw == 3.0f;                                      // the reference's trained p starts at 3: x^3 without powf
+    // (a workgroup is one frame and the launch is about one round of workgroups: what counts is the LENGTH of the dependent chains --
+    // eight loads in flight per thread here, four output features per wave and step below, instead of one load per round trip)
     for (int c = tid; c < C; c += nt) {
         float s = 0.0f;
-        for (int p = 0; p < P; ++p) {
-            const float v = fmaxf(x[(size_t)p * C + c] * invn[p], eps);
-            s += cube ? v * v * v : powf(v, pw);
+        for (int p0 = 0; p0 < P; p0 += 8) {
+            float xv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xv[j] = p0 + j < P ? x[(size_t)(p0 + j) * C + c] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                if (p0 + j < P) {
+                    const float v = fmaxf(xv[j] * invn[p0 + j], eps);
+                    s += cube ? v * v * v : powf(v, pw);
+                }
+            }
         }
         g[c] = powf(s * invP, ip);
     }
     __syncthreads();
-    for (int d = wave; d < Dout; d += nw) {                            // Linear (network.py:27): one wave per output feature
-        const float4 *wr = (const float4 *)(W + (size_t)d * C);
-        float s = 0.0f;
+    for (int d0 = wave * 4; d0 < Dout; d0 += nw * 4) {                 // Linear (network.py:27): four output features per wave and step
+        float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int c = lane; c < C4; c += 64) {
-            const float4 w = wr[c];
             const float4 gv = *(const float4 *)(g + 4 * c);
-            s += w.x * gv.x + w.y * gv.y + w.z * gv.z + w.w * gv.w;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (d0 + j < Dout) {
+                    const float4 w = ((const float4 *)(W + (size_t)(d0 + j) * C))[c];
+                    s4[j] += w.x * gv.x + w.y * gv.y + w.z * gv.z + w.w * gv.w;
+                }
+            }
         }
-        s = wave_sum_f32(s);
-        if (lane == 0) o[d] = s + (bias ? bias[d] : 0.0f);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t = wave_sum_f32(s4[j]);
+            if (lane == 0 && d0 + j < Dout) o[d0 + j] = t + (bias ? bias[d0 + j] : 0.0f);
+        }
     }
     __syncthreads();
     float s = 0.0f;
