@@ -871,7 +871,7 @@ def main():
               "match_only": round(done2 / tm2, 1), "value_serial": round(done2 / (te2 + tm2), 1),
               "serial_note": "extract_only / match_only / value_serial: %d chunks with a host synchronisation between the legs" % nchunks,
               "dtype": "f32",
-              "roofline": {"bound": "mfma", "kernel": "conv_igemm_h2_kernel: every trunk layer (7x7 stem, 3x3 stride 1 and 2, 1x1) as an implicit "
+              "roofline": {"bound": "mfma", "kernel": "conv_igemm_h2_kernel (+ conv_stem_pool_patch_kernel: the 7x7 stem with its max-pool): every trunk layer as an implicit "
                                                         "GEMM over exact fp16 hi/lo pairs of activations and weights, 3 fp16 products per "
                                                         "multiply-add (csrc/conv_igemm.hip; per-layer times: tools/perf_conv_igemm.py, DESIGN.md 3.6d)",
                            "achieved": round(fps * GF * 3 / 1e3, 1), "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (fp16, 3 products)",
