@@ -1319,11 +1319,12 @@ def test_pair_format_activations_between_implicit_gemm_layers(T, B, c0, c1, hw, 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,H,W,cout,k,stride,pad", [(3, 224, 224, 64, 7, 2, 3), (2, 64, 96, 64, 7, 2, 3), (5, 32, 32, 128, 3, 2, 1),
-                                                    (2, 16, 32, 64, 3, 1, 1)])
+                                                    (2, 16, 32, 64, 3, 1, 1), (1, 32, 64, 64, 7, 2, 3), (7, 224, 224, 64, 7, 2, 3)])
 def test_stem_with_fused_maxpool_equals_pooling_the_unfused_output(T, B, H, W, cout, k, stride, pad):
     """`cslam_conv_stem_pool_igemm_h2_dev` (conv1 + bn1 + relu + maxpool of the ResNet trunks as one kernel, 8 x 16-pixel tiles, windows
-    across tiles completed with atomic maxima): EXACTLY MaxPool2d(3, 2, 1) of the un-fused kernel's output (the same products in the
-    same order), which the test above holds against float64; the slot carries max of the un-pooled map; repeated calls agree (the
+    across tiles completed with atomic maxima; the 7 x 7 / 2 / 64-channel cases run the persistent patch-form kernel -- 4 tiles on two
+    workgroups, 24, 294 and 686 tiles over the XCDs --, the others the implicit-GEMM form): EXACTLY MaxPool2d(3, 2, 1) of the un-fused
+    kernel's output (the same products in the same order), which the test above holds against float64; the slot carries max of the un-pooled map; repeated calls agree (the
     atomics have no order dependence)."""
     torch, _ = T
     from cslam_amd.vpr import winograd as wg
