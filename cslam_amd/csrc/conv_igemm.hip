@@ -50,6 +50,7 @@ struct ConvIgemmArgs {
     int nk;                // K blocks: KH KW Cin / 32 (STEM: KH)
     int ncb;               // Cin / 32
     int relu;
+    int n_mt, ntb, nx, mt_per_x;   // pixel tiles, channel tiles, XCDs the 1-D grid is laid out for, pixel tiles per XCD (workgroup -> tile: see the kernel)
     int pool;              // stem only: MaxPool2d(3, 2, 1) of the ReLU output fused (8 x 16-pixel tiles, y = the POOLED map, zeroed by the host)
     const unsigned *amax_in; float inv_sw; unsigned *amax_out;
     // pair-format activations (AM = 2 reads them, out_pairs writes them): [pixel][channel block of 32][hi 32 | lo 32] halfs of s x, s the
@@ -123,7 +124,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int h = lane >> 5, l31 = lane & 31;
-    const int mt = blockIdx.x, nt = blockIdx.y;
+    // Workgroup b runs on XCD b % nx.  Inside an XCD the channel tiles of ONE pixel tile follow each other (they read the same activation
+    // tile at about the same time: one L2 miss, ntb - 1 hits); an XCD owns a contiguous range of pixel tiles (neighbours share the rows
+    // above and below a tile: their halo is an L2 hit too).
+    const int bx = blockIdx.x % p.nx, bg = blockIdx.x / p.nx;
+    const int nt = bg % p.ntb, mt = bx * p.mt_per_x + bg / p.ntb;
+    if (bg / p.ntb >= p.mt_per_x || mt >= p.n_mt) return;
 
     // ---- this thread's share of the activation tile: pixel row tid >> 1, channels 16 (tid & 1) .. + 15 of every K block
     const int ar = tid >> 1, hf = tid & 1;
@@ -256,10 +262,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
         const int pch = i * 256 + tid, r = pch >> 3, slot = pch & 7;
         voffB[i] = r * pitchw + ((slot ^ ((r >> 1) & 7)) << 4);
     }
+    // (called for K positions 0, 1, 2, ... in order: position -> (slab, tap) by two counters; the weights' blocks are stored tap-major)
+    int bw_tap = 0, bw_cb = 0;
+    const int ntap = p.KH * p.KW;
     auto b_load = [&](int st, int k) {
+        const int widx = PAIRS ? bw_tap * p.ncb + bw_cb : k;
+        if (PAIRS && ++bw_tap == ntap) { bw_tap = 0; ++bw_cb; }
 #pragma unroll
         for (int i = 0; i < NLB; ++i)
-            ci_blds16(rsB, voffB[i], k * CI_ROWB, smem + st * STAGE + OPA + i * (256 * 16) + wave * 1024);
+            ci_blds16(rsB, voffB[i], widx * CI_ROWB, smem + st * STAGE + OPA + i * (256 * 16) + wave * 1024);
     };
 
     // ---- fragments: row * 128 + (chunk ^ swz) * 16, chunk = 4 lo + 2 s + h for the 16-channel K step s
@@ -351,7 +362,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
     int kh = 0, kw = 0, cb = 0;                        // the K block the loader is at
     auto advance = [&]() {
         if (STEM) { ++kh; return; }
-        if (++cb == p.ncb) { cb = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+        // the taps are the INNER loop: the nine (kh, kw) blocks of one 32-channel slab re-read the same pixels' 128-byte runs back to back
+        // (L2 hits); with the slabs inside a tap, a tile's whole input went by between two reads of a run and every tap missed the
+        // 4 MB L2 -- PMC: 3.2 GB of fabric traffic on layer4 against 0.2 GB of operands, the kernel at 1.35 GHz under the power cap
+        // (AM = 2; the float32 form keeps the slabs inside a tap: it is one 64-channel layer of the trunk, and its tests pin that order's rounding)
+        if (PAIRS) { if (++kw == p.KW) { kw = 0; if (++kh == p.KH) { kh = 0; ++cb; } } }
+        else if (++cb == p.ncb) { cb = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
     };
     // Pipeline: the activation block is fetched TWO K blocks ahead (two register sets, the loop unrolled by two so that the sets are
     // named at compile time), split and written into LDS one block ahead; the weight block comes one block ahead by LDS-DMA.  Requests of
@@ -844,7 +860,10 @@ static int conv_igemm_launch(const float *d_x, const void *d_w2, const float *d_
     const int tn = Cout % 128 == 0 ? 128 : 64;
     const int am = stem ? 1 : (f.x_pairs ? 2 : 0);
     const int tm = am == 2 && tn == 64 ? 256 : 128;
-    const dim3 grid((unsigned)ceil_div64(P, tm), (unsigned)(Cout / tn)), blk(256);          // (pooled form: P / 128 tiles exactly)
+    a.n_mt = (int)ceil_div64(P, tm); a.ntb = Cout / tn;                                      // (pooled form: P / 128 tiles exactly)
+    a.nx = cslam_cu_count() % 8 == 0 ? 8 : 1;
+    a.mt_per_x = (int)ceil_div64(a.n_mt, a.nx);
+    const dim3 grid((unsigned)((int64_t)a.mt_per_x * a.nx * a.ntb)), blk(256);
     const int lds = 2 * (tm + tn) * CI_ROWB;                                                 // >= 128 x tn floats, the pooled form's tile
     hipStream_t st = (hipStream_t)stream;
     const bool patch_form = CI_STEM_PATCH_FORM && pool && Cout == 64 && KH == 7 && KW == 7 && stride == 2 && pad == 3 && (int64_t)H * W * 12 < 0x7fffffffll;
