@@ -906,6 +906,11 @@ def main():
             fl_l = 2.0 * 3 * ch * hw_l * hw_l * cch * 9 * cch
             lay[lname] = {"kernel_ms": round(ms_l, 4), "achieved": round(fl_l / ms_l / 1e9, 1),
                           "frac": round(fl_l / ms_l / 1e9 / FP16_MFMA_PEAK_TFLOPS, 4)}
+            pe = pmc_entry("conv_igemm_h2_kernel/" + lname.split()[0]) if ch == 1000 else None     # (collected at 1000 frames)
+            if pe:
+                lay[lname].update({"traffic": pe["traffic_bytes"], "algorithmic_bytes": pe["algorithmic_min_bytes"],
+                                   "l2_hit_rate_pmc": round(pe["l2_hit_rate"], 3), "matrix_pipe_busy_pmc": round(pe["mfma_busy_frac"], 3),
+                                   "effective_clock_GHz_pmc": round(pe["effective_clock_GHz"], 2), "traffic_source": pe["source"]})
             del xl, ap
         c2["roofline"]["layers"] = {"kernel": "conv_igemm_h2_kernel (pair-format input and output), %d frames" % ch,
                                     "unit": "TFLOP/s (fp16, 3 products)", "peak": FP16_MFMA_PEAK_TFLOPS, **lay}
