@@ -107,9 +107,17 @@ __host__ __device__ __forceinline__ float ci_sub_half(float v, __half2 h) {     
 // Tile: TM pixels x TN output channels on four waves, WM = TM / 64 along the pixels and WN = 4 / WM along the channels: wave tile 64 x
 // TN / WN.  128 x 128 and 128 x 64 (2 x 2 waves); 256 x 64 (4 x 1, pair format only): layers with 64 output channels -- a 64 x 32 wave
 // tile reads one LDS fragment per MFMA, a 64 x 64 one two per three, and the LDS pipe is what bounds these kernels.
-template <int TM, int TN, int AM>
+// KWS (AM = 2, 3x3 / stride 1 / pad 1, 128-pixel tiles): the three taps of a kernel row share ONE activation block.  In the flat pixel
+// order the tiles use, tap kw of output pixel p is input pixel p + (kh - 1) W + (kw - 1): the 130 rows "pixels first - 1 .. first + 128
+// at kernel row kh" are requested once per (slab, kh) and the taps read them at row offsets 0, 1, 2; what is wrong there -- the pixels
+// at a row's ends, whose neighbour in the flat order belongs to another row -- is masked in the A fragments (32 v_cndmask per step for
+// kw = 0 and 2).  A third of the activation requests (L2 -> LDS bytes -32 %).
+template <int TM, int TN, int AM, bool KWS = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) {
     constexpr bool STEM = AM == 1, PAIRS = AM == 2;
+    static_assert(!KWS || (AM == 2 && TM == 128), "the shared-row form is written for pair-format input and 128-pixel tiles");
+    constexpr int KA_ROWS = 136;                       // KWS: 130 rows of a (slab, kernel row) block, padded to whole 1 KB DMA pieces
+    constexpr int KA_BYTES = KA_ROWS * CI_ROWB;        // 17 408: two of them, then the two weight stages
     constexpr int NST = 2;                             // LDS stages
     constexpr int WM = TM / 64, WN = 4 / WM, TNW = TN / WN;
     constexpr int MT = 2, NT = TNW / 32;               // wave tile 64 x TNW in 32 x 32 MFMA tiles
@@ -253,6 +261,32 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
         }
     };
 
+    // ---- KWS: LDS row R = i * 32 + (tid >> 3) (i = 0..4, rows 130.. read nothing) holds centre pixel first - 1 + R at kernel row kh
+    int ka_off[KWS ? 5 : 1], ka_h[KWS ? 5 : 1];
+    if (KWS) {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int R = i * 32 + (tid >> 3);
+            const int64_t pc = (int64_t)mt * TM - 1 + R;
+            const bool ok = R < 130 && pc >= 0 && pc < p.P;
+            const int hw = p.Ho * p.Wo;
+            const int pp = ok ? (int)pc : 0;
+            const int bb = pp / hw, rem = pp - bb * hw;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            ka_h[i] = ok ? ho - 1 : -(1 << 20);                                                        // + kh = the input row
+            ka_off[i] = (((bb - b0) * p.H + ho - 1) * p.W + wo) * (p.Cin * 4) + pa_chunk;             // + kh W Cin 4: bytes
+        }
+    }
+    auto ka_dma = [&](int abuf, int kh, int cb, int i0, int i1) {       // pieces i0 .. i1 - 1 of the block (spread over the three steps)
+        const int rowoff = kh * p.W * (p.Cin * 4);
+#pragma unroll
+        for (int i = 0; i < (KWS ? 5 : 0); ++i) {
+            if (i < i0 || i >= i1 || (i == 4 && wave != 0)) continue;      // (piece 4 = rows 128..135: one wave's 1 KB; the buffer ends there)
+            const bool in = (unsigned)(ka_h[i] + kh) < (unsigned)p.H;
+            ci_blds16(rsX, in ? ka_off[i] + rowoff : 0x7fffffff, cb * 128, smem + abuf * KA_BYTES + i * (256 * 16) + wave * 1024);
+        }
+    };
+
     // ---- weight tile by LDS-DMA: chunk pch = i * 256 + tid -> row pch >> 3, physical slot pch & 7 = logical chunk slot ^ swz(row)
     const int pitchw = p.nk * CI_ROWB;
     const __amdgpu_buffer_rsrc_t rsB = ci_rsrc(p.w2 + (int64_t)nt * TN * pitchw, (int64_t)TN * pitchw);
@@ -270,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
         if (PAIRS && ++bw_tap == ntap) { bw_tap = 0; ++bw_cb; }
 #pragma unroll
         for (int i = 0; i < NLB; ++i)
-            ci_blds16(rsB, voffB[i], widx * CI_ROWB, smem + st * STAGE + OPA + i * (256 * 16) + wave * 1024);
+            ci_blds16(rsB, voffB[i], widx * CI_ROWB, smem + (KWS ? 2 * KA_BYTES + st * OPB : st * STAGE + OPA) + i * (256 * 16) + wave * 1024);
     };
 
     // ---- fragments: row * 128 + (chunk ^ swz) * 16, chunk = 4 lo + 2 s + h for the 16-channel K step s
@@ -412,6 +446,74 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
     } else {
         step(false, false, k, 0, ra1, ra0);
     }
+    } else if (KWS) {
+        // lane masks: output pixel first + wm 64 + m 32 + l31 sits at a row's first / last column -> its kw = 0 / kw = 2 tap is padding
+        bool e0[MT], e2[MT];
+        int arow_k[MT];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            const int64_t px = (int64_t)mt * TM + wm * 64 + m * 32 + l31;
+            const int wo = (int)(px % p.Wo);
+            e0[m] = wo == 0; e2[m] = wo == p.Wo - 1;
+            arow_k[m] = wm * 64 + m * 32 + l31;                            // + kw = the LDS row of tap kw
+        }
+        const int ngrp = p.ncb * 3;                                        // (slab, kernel row) groups, three steps (kw) each
+        // group G = cb * 3 + kh -> activation buffer G & 1; step k = 3 G + kw -> weight buffer k & 1
+        ka_dma(0, 0, 0, 0, 5);
+        b_load(0, 0);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_s_barrier();
+        int gkh = 0, gcb = 0;                                              // the group being multiplied
+        for (int G = 0; G < ngrp; ++G) {
+            int nkh = gkh + 1, ncb_ = gcb;
+            if (nkh == 3) { nkh = 0; ++ncb_; }
+            const bool moreG = G + 1 < ngrp;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int k = 3 * G + kw;
+                __builtin_amdgcn_sched_barrier(0);
+                if (moreG) ka_dma((G + 1) & 1, nkh, ncb_, kw == 0 ? 0 : (kw == 1 ? 2 : 4), kw == 0 ? 2 : (kw == 1 ? 4 : 5));
+                if (k + 1 < p.nk) b_load((k + 1) & 1, k + 1);
+                // fragments of tap kw: activation rows shifted by kw, the chunk swizzle follows the physical row
+                const char *sA = smem + (G & 1) * KA_BYTES, *sB = smem + 2 * KA_BYTES + (k & 1) * OPB;
+                f16x8 fa[2][2][MT], fb[2][2][NT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) {
+                    const int row = arow_k[m] + kw, sw = (row >> 1) & 7;
+                    const bool z = (kw == 0 && e0[m]) || (kw == 2 && e2[m]);
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                        for (int lo = 0; lo < 2; ++lo) {
+                            cu4 v = *(const cu4 *)(sA + row * CI_ROWB + (((4 * lo + 2 * s2 + h) ^ sw) << 4));
+                            if (kw != 1) v = z ? (cu4)(0u) : v;
+                            fa[s2][lo][m] = *(const f16x8 *)&v;
+                        }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) {
+                        fb[s2][0][n] = *(const f16x8 *)(sB + brow0 + n * 32 * CI_ROWB + foff[s2][0]);
+                        fb[s2][1][n] = *(const f16x8 *)(sB + brow0 + n * 32 * CI_ROWB + foff[s2][1]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < NT; ++n) {
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s2][0][m], fb[s2][0][n], acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s2][1][m], fb[s2][0][n], acc[m][n], 0, 0, 0);
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s2][0][m], fb[s2][1][n], acc[m][n], 0, 0, 0);
+                        }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_s_barrier();
+            }
+            gkh = nkh; gcb = ncb_;
+        }
     } else {
         // both operands by DMA into a ring of NST stages: block k + NST - 1 is requested at the top of step k, so a request has
         // NST - 2 whole steps plus this step's products to arrive; with three stages the step's closing wait is COUNTED (the newest request
@@ -609,6 +711,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
 // and stores its previous tile (LDS and vector memory) -- with four waves alone (one per SIMD) every LDS round trip of the K loop and
 // the whole pooling, which is as long as the K loop, were exposed: 3.7 ms against the implicit-GEMM form's 2.55.  A group's wave w: tile
 // rows 2 w, 2 w + 1 (32 pixels) x 64 channels; accumulators 2 x 16.
+#ifdef CSLAM_ABLATIONS
+#define CI_KW_SHARING (!getenv("CSLAM_CI_KWS_OFF"))     // measurement build: A/B partner of the shared-row form
+#else
+#define CI_KW_SHARING true
+#endif
 #ifdef CSLAM_ABLATIONS
 #define CI_STEM_PATCH_FORM (!getenv("CSLAM_SP_OFF"))   // measurement build: the implicit-GEMM pooled form as the A/B partner
 #else
@@ -860,11 +967,12 @@ static int conv_igemm_launch(const float *d_x, const void *d_w2, const float *d_
     const int tn = Cout % 128 == 0 ? 128 : 64;
     const int am = stem ? 1 : (f.x_pairs ? 2 : 0);
     const int tm = am == 2 && tn == 64 ? 256 : 128;
+    const bool kws = CI_KW_SHARING && am == 2 && tn == 128 && KH == 3 && KW == 3 && stride == 1 && pad == 1;      // three taps, one activation block
     a.n_mt = (int)ceil_div64(P, tm); a.ntb = Cout / tn;                                      // (pooled form: P / 128 tiles exactly)
     a.nx = cslam_cu_count() % 8 == 0 ? 8 : 1;
     a.mt_per_x = (int)ceil_div64(a.n_mt, a.nx);
     const dim3 grid((unsigned)((int64_t)a.mt_per_x * a.nx * a.ntb)), blk(256);
-    const int lds = 2 * (tm + tn) * CI_ROWB;                                                 // >= 128 x tn floats, the pooled form's tile
+    const int lds = kws ? 2 * 136 * CI_ROWB + 2 * tn * CI_ROWB : 2 * (tm + tn) * CI_ROWB;   // >= 128 x tn floats, the pooled form's tile
     hipStream_t st = (hipStream_t)stream;
     const bool patch_form = CI_STEM_PATCH_FORM && pool && Cout == 64 && KH == 7 && KW == 7 && stride == 2 && pad == 3 && (int64_t)H * W * 12 < 0x7fffffffll;
     if (pool) {
@@ -903,10 +1011,18 @@ static int conv_igemm_launch(const float *d_x, const void *d_w2, const float *d_
             HIP_TRY(hipFuncSetAttribute((const void *)conv_igemm_h2_kernel<TM_, TN_, ST_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
             once.done(once_dev); } \
         hipLaunchKernelGGL((conv_igemm_h2_kernel<TM_, TN_, ST_>), grid, blk, lds, st, a); } while (0)
+#define CI_LAUNCH_K(TM_, TN_) do { \
+        static DeviceOnce once; int once_dev; \
+        if (once.todo(&once_dev)) { \
+            HIP_TRY(hipFuncSetAttribute((const void *)conv_igemm_h2_kernel<TM_, TN_, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+            once.done(once_dev); } \
+        hipLaunchKernelGGL((conv_igemm_h2_kernel<TM_, TN_, 2, true>), grid, blk, lds, st, a); } while (0)
     if (stem) { if (tn == 128) CI_LAUNCH(128, 128, 1); else CI_LAUNCH(128, 64, 1); }
+    else if (f.x_pairs && kws) CI_LAUNCH_K(128, 128);
     else if (f.x_pairs) { if (tn == 128) CI_LAUNCH(128, 128, 2); else CI_LAUNCH(256, 64, 2); }
     else { if (tn == 128) CI_LAUNCH(128, 128, 0); else CI_LAUNCH(128, 64, 0); }
 #undef CI_LAUNCH
+#undef CI_LAUNCH_K
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }

@@ -16,6 +16,14 @@ if which == "stem":
     Wg = wg.igemm_pair_weights(w)
     slot = torch.full((1,), float(x.abs().max()), device="cuda")
     run = lambda: wg.conv_igemm(ws, x, Wg, None, (7, 7), 2, 3, True, amax_in=slot, pool=True)      # noqa: E731
+elif which == "layer1f":                           # layer1's first convolution: float32 input (the pooled stem output), pair-format output
+    x = torch.randn((B, 64, 56, 56), device="cuda").contiguous(memory_format=torch.channels_last)
+    w = torch.randn((64, 64, 3, 3), device="cuda") / (3 * 8.0)
+    sl = torch.zeros(8, device="cuda")
+    sl[0] = x.abs().max()
+    a0 = wg.PairAct(x, False, x.shape, sl[0:1], sl[0:1])
+    Wg, wl1 = wg.igemm_pair_weights(w), float(w.abs().sum(dim=(1, 2, 3)).max())
+    run = lambda: wg.conv_igemm_p(ws, a0, Wg, None, (3, 3), 1, 1, True, None, wl1, 0.0, sl[3:4], sl[4:5], True)   # noqa: E731
 else:
     c, hw = {"layer1": (64, 56), "layer2": (128, 28), "layer3": (256, 14), "layer4": (512, 7)}[which]
     x = torch.randn((B, c, hw, hw), device="cuda").contiguous(memory_format=torch.channels_last)
