@@ -913,8 +913,14 @@ __global__ __launch_bounds__(512, 1) void conv_stem_pool_patch_kernel(StemPatchA
     }
 }
 
-__global__ __launch_bounds__(256) void ci_zero_kernel(float4 *__restrict__ y, int64_t n4) {
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) y[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+// zero fill of the pooled map's positions that the atomic maxima complete: pooled rows 4 k and pooled columns 8 k (the windows that reach
+// into the tile above / to the left); every other position is written by a plain store.  34 % of the map instead of all of it.
+__global__ __launch_bounds__(256) void ci_zero_kernel(float4 *__restrict__ y, int Hp, int Wp, int c4) {
+    const int64_t row = blockIdx.x;                                    // (image, pooled row): one workgroup per row of the pooled map
+    const bool all = ((int)(row % Hp) & 3) == 0;
+    float4 *r = y + row * Wp * c4;
+    for (int i = threadIdx.x; i < Wp * c4; i += 256)
+        if (all || ((i / c4) & 7) == 0) r[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 /* y = act(conv(x, w) + bias (+ res)) for x [B,H,W,Cin] NHWC float32 -> y [B,Ho,Wo,Cout] NHWC float32, Ho = (H + 2 pad - KH) / stride + 1.
@@ -978,9 +984,8 @@ static int conv_igemm_launch(const float *d_x, const void *d_w2, const float *d_
     if (pool) {
         // (a kernel, not hipMemsetAsync: as a memset NODE of a captured graph the fill did not precede the convolution on replay --
         // tests/test_heads_gpu.py::test_online_hip_graph_replay_equals_plain_launches caught the second replay 3e-2 off)
-        const int64_t n4 = (int64_t)B * (a.Ho / 2) * (a.Wo / 2) * Cout / 4;
-        const int zb = (int)(n4 < 4096 * 256 ? (n4 + 255) / 256 : 4096);
-        hipLaunchKernelGGL(ci_zero_kernel, dim3(zb), dim3(256), 0, st, (float4 *)d_y, n4);
+        ARG_CHECK((int64_t)B * (a.Ho / 2) < (1ll << 31), "too many pooled rows for one launch");
+        hipLaunchKernelGGL(ci_zero_kernel, dim3((unsigned)(B * (a.Ho / 2))), dim3(256), 0, st, (float4 *)d_y, a.Ho / 2, a.Wo / 2, Cout / 4);
     }
     if (patch_form) {
         StemPatchArgs sp;
