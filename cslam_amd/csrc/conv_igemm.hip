@@ -972,8 +972,9 @@ static int conv_igemm_launch(const float *d_x, const void *d_w2, const float *d_
     ARG_CHECK(!(d_res && (f.res_pairs || f.out_pairs)) || f.res_bound, "the shortcut's bound slot is missing");
     const int tn = Cout % 128 == 0 ? 128 : 64;
     const int am = stem ? 1 : (f.x_pairs ? 2 : 0);
-    const int tm = am == 2 && tn == 64 ? 256 : 128;
-    const bool kws = CI_KW_SHARING && am == 2 && tn == 128 && KH == 3 && KW == 3 && stride == 1 && pad == 1;      // three taps, one activation block
+    const bool kws = CI_KW_SHARING && am == 2 && KH == 3 && KW == 3 && stride == 1 && pad == 1;      // three taps, one activation block
+    const int tm = am == 2 && tn == 64 && !kws ? 256 : 128;                                         // (64-channel layers: 128 x 64 tiles with the shared
+                                                                                                    // rows, three per CU, +0.7 % over 256 x 64 without)
     a.n_mt = (int)ceil_div64(P, tm); a.ntb = Cout / tn;                                      // (pooled form: P / 128 tiles exactly)
     a.nx = cslam_cu_count() % 8 == 0 ? 8 : 1;
     a.mt_per_x = (int)ceil_div64(a.n_mt, a.nx);
@@ -1023,7 +1024,7 @@ static int conv_igemm_launch(const float *d_x, const void *d_w2, const float *d_
             once.done(once_dev); } \
         hipLaunchKernelGGL((conv_igemm_h2_kernel<TM_, TN_, 2, true>), grid, blk, lds, st, a); } while (0)
     if (stem) { if (tn == 128) CI_LAUNCH(128, 128, 1); else CI_LAUNCH(128, 64, 1); }
-    else if (f.x_pairs && kws) CI_LAUNCH_K(128, 128);
+    else if (f.x_pairs && kws) { if (tn == 128) CI_LAUNCH_K(128, 128); else CI_LAUNCH_K(128, 64); }
     else if (f.x_pairs) { if (tn == 128) CI_LAUNCH(128, 128, 2); else CI_LAUNCH(256, 64, 2); }
     else { if (tn == 128) CI_LAUNCH(128, 128, 0); else CI_LAUNCH(128, 64, 0); }
 #undef CI_LAUNCH
