@@ -115,7 +115,7 @@ __host__ __device__ __forceinline__ float ci_sub_half(float v, __half2 h) {     
 template <int TM, int TN, int AM, bool KWS = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) {
     constexpr bool STEM = AM == 1, PAIRS = AM == 2;
-    static_assert(!KWS || (AM == 2 && TM == 128), "the shared-row form is written for pair-format input and 128-pixel tiles");
+    static_assert(!KWS || ((AM == 2 || AM == 0) && TM == 128), "the shared-row form is written for 128-pixel tiles of the general forms");
     constexpr int KA_ROWS = 136;                       // KWS: 130 rows of a (slab, kernel row) block, padded to whole 1 KB DMA pieces
     constexpr int KA_BYTES = KA_ROWS * CI_ROWB;        // 17 408: two of them, then the two weight stages
     constexpr int NST = 2;                             // LDS stages
@@ -287,6 +287,51 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
         }
     };
 
+    // ---- KWS with float32 input (AM = 0): the (slab, kernel row) block goes through registers -- item 0: row tid >> 1, channels
+    // 16 (tid & 1) .. + 15 (rows 0..127); item 1: rows 128..135 on the first 16 threads (every wave issues its loads: counted waits) --
+    // and is split once per THREE steps instead of once per step
+    cf4 kr[2][4];
+    auto kf_load = [&](int kh, int cb) {
+#pragma unroll
+        for (int it = 0; it < ((KWS && AM == 0) ? 2 : 0); ++it) {
+            const int R = it * 128 + (tid >> 1);
+            const int64_t pc = (int64_t)mt * TM - 1 + R;
+            const bool ok = (it == 0 || tid < 16) && pc >= 0 && pc < p.P;
+            const int hw = p.Ho * p.Wo;
+            const int pp = ok ? (int)pc : 0;
+            const int bb = pp / hw, rem = pp - bb * hw;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            const int hi = ho - 1 + kh;
+            const bool in = ok && (unsigned)hi < (unsigned)p.H;
+            const int voff = in ? (((bb - b0) * p.H + hi) * p.W + wo) * (p.Cin * 4) + hf * 64 : 0x7fffffff;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) kr[it][q] = ci_bload16(rsX, voff + q * 16, cb * 128);
+        }
+    };
+    auto kf_store = [&](int abuf) {
+#pragma unroll
+        for (int it = 0; it < ((KWS && AM == 0) ? 2 : 0); ++it) {
+            if (it == 1 && tid >= 16) continue;
+            const int R = it * 128 + (tid >> 1);
+            char *row = smem + abuf * KA_BYTES + R * CI_ROWB;
+            const int sw = (R >> 1) & 7;
+            unsigned hh[8], ll[8];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const cf4 v = kr[it][q] * sc;
+                const __half2 h0 = __floats2half2_rn(v.x, v.y), h1 = __floats2half2_rn(v.z, v.w);
+                const __half2 l0 = __floats2half2_rn(ci_sub_half<0>(v.x, h0), ci_sub_half<1>(v.y, h0));
+                const __half2 l1 = __floats2half2_rn(ci_sub_half<0>(v.z, h1), ci_sub_half<1>(v.w, h1));
+                hh[2 * q] = *(const unsigned *)&h0; hh[2 * q + 1] = *(const unsigned *)&h1;
+                ll[2 * q] = *(const unsigned *)&l0; ll[2 * q + 1] = *(const unsigned *)&l1;
+            }
+            *(cu4 *)(row + (((hf * 2) ^ sw) << 4)) = (cu4){hh[0], hh[1], hh[2], hh[3]};
+            *(cu4 *)(row + (((hf * 2 + 1) ^ sw) << 4)) = (cu4){hh[4], hh[5], hh[6], hh[7]};
+            *(cu4 *)(row + (((4 + hf * 2) ^ sw) << 4)) = (cu4){ll[0], ll[1], ll[2], ll[3]};
+            *(cu4 *)(row + (((5 + hf * 2) ^ sw) << 4)) = (cu4){ll[4], ll[5], ll[6], ll[7]};
+        }
+    };
+
     // ---- weight tile by LDS-DMA: chunk pch = i * 256 + tid -> row pch >> 3, physical slot pch & 7 = logical chunk slot ^ swz(row)
     const int pitchw = p.nk * CI_ROWB;
     const __amdgpu_buffer_rsrc_t rsB = ci_rsrc(p.w2 + (int64_t)nt * TN * pitchw, (int64_t)TN * pitchw);
@@ -300,8 +345,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
     int bw_tap = 0, bw_cb = 0;
     const int ntap = p.KH * p.KW;
     auto b_load = [&](int st, int k) {
-        const int widx = PAIRS ? bw_tap * p.ncb + bw_cb : k;
-        if (PAIRS && ++bw_tap == ntap) { bw_tap = 0; ++bw_cb; }
+        const int widx = (PAIRS || KWS) ? bw_tap * p.ncb + bw_cb : k;
+        if ((PAIRS || KWS) && ++bw_tap == ntap) { bw_tap = 0; ++bw_cb; }
 #pragma unroll
         for (int i = 0; i < NLB; ++i)
             ci_blds16(rsB, voffB[i], widx * CI_ROWB, smem + (KWS ? 2 * KA_BYTES + st * OPB : st * STAGE + OPA) + i * (256 * 16) + wave * 1024);
@@ -423,7 +468,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
         else __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_s_barrier();
     };
-    if (!PAIRS) {
+    if (!PAIRS && !KWS) {
     a_load(ra0, kh, kw, cb);
     b_load(0, 0);
     a_store(ra0, 0);
@@ -459,8 +504,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
         }
         const int ngrp = p.ncb * 3;                                        // (slab, kernel row) groups, three steps (kw) each
         // group G = cb * 3 + kh -> activation buffer G & 1; step k = 3 G + kw -> weight buffer k & 1
-        ka_dma(0, 0, 0, 0, 5);
-        b_load(0, 0);
+        if (AM == 0) { kf_load(0, 0); b_load(0, 0); kf_store(0); }
+        else { ka_dma(0, 0, 0, 0, 5); b_load(0, 0); }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_s_barrier();
         int gkh = 0, gcb = 0;                                              // the group being multiplied
@@ -472,8 +517,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
             for (int kw = 0; kw < 3; ++kw) {
                 const int k = 3 * G + kw;
                 __builtin_amdgcn_sched_barrier(0);
-                if (moreG) ka_dma((G + 1) & 1, nkh, ncb_, kw == 0 ? 0 : (kw == 1 ? 2 : 4), kw == 0 ? 2 : (kw == 1 ? 4 : 5));
-                if (k + 1 < p.nk) b_load((k + 1) & 1, k + 1);
+                if (AM == 0) {
+                    // weights first, then (kw = 0) the next block's float32 loads: they stay in flight over this step's counted wait and
+                    // the next step, and are split behind the products of kw = 2
+                    if (k + 1 < p.nk) b_load((k + 1) & 1, k + 1);
+                    if (kw == 0 && moreG) kf_load(nkh, ncb_);
+                } else {
+                    if (moreG) ka_dma((G + 1) & 1, nkh, ncb_, kw == 0 ? 0 : (kw == 1 ? 2 : 4), kw == 0 ? 2 : (kw == 1 ? 4 : 5));
+                    if (k + 1 < p.nk) b_load((k + 1) & 1, k + 1);
+                }
                 // fragments of tap kw: activation rows shifted by kw, the chunk swizzle follows the physical row
                 const char *sA = smem + (G & 1) * KA_BYTES, *sB = smem + 2 * KA_BYTES + (k & 1) * OPB;
                 f16x8 fa[2][2][MT], fb[2][2][NT];
@@ -509,7 +561,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
                             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[s2][0][m], fb[s2][1][n], acc[m][n], 0, 0, 0);
                         }
                 __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_waitcnt(0);
+                if (AM == 0 && kw == 2 && moreG) kf_store((G + 1) & 1);
+                if (AM == 0 && kw == 0 && moreG) __builtin_amdgcn_s_waitcnt(8 | (7 << 4) | (0 << 8));      // vmcnt(8): the eight float32 loads stay in flight
+                else __builtin_amdgcn_s_waitcnt(0);
                 __builtin_amdgcn_s_barrier();
             }
             gkh = nkh; gcb = ncb_;
@@ -972,7 +1026,9 @@ static int conv_igemm_launch(const float *d_x, const void *d_w2, const float *d_
     ARG_CHECK(!(d_res && (f.res_pairs || f.out_pairs)) || f.res_bound, "the shortcut's bound slot is missing");
     const int tn = Cout % 128 == 0 ? 128 : 64;
     const int am = stem ? 1 : (f.x_pairs ? 2 : 0);
-    const bool kws = CI_KW_SHARING && am == 2 && KH == 3 && KW == 3 && stride == 1 && pad == 1;      // three taps, one activation block
+    // three taps, one activation block: the pair-format layers, and the float32-input layer that opens the pair-format chain (the plain
+    // float32 entry keeps its K order: its tests pin that rounding)
+    const bool kws = CI_KW_SHARING && (am == 2 || (am == 0 && f.out_pairs)) && KH == 3 && KW == 3 && stride == 1 && pad == 1;
     const int tm = am == 2 && tn == 64 && !kws ? 256 : 128;                                         // (64-channel layers: 128 x 64 tiles with the shared
                                                                                                     // rows, three per CU, +0.7 % over 256 x 64 without)
     a.n_mt = (int)ceil_div64(P, tm); a.ntb = Cout / tn;                                      // (pooled form: P / 128 tiles exactly)
@@ -1017,14 +1073,15 @@ static int conv_igemm_launch(const float *d_x, const void *d_w2, const float *d_
             HIP_TRY(hipFuncSetAttribute((const void *)conv_igemm_h2_kernel<TM_, TN_, ST_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
             once.done(once_dev); } \
         hipLaunchKernelGGL((conv_igemm_h2_kernel<TM_, TN_, ST_>), grid, blk, lds, st, a); } while (0)
-#define CI_LAUNCH_K(TM_, TN_) do { \
+#define CI_LAUNCH_K(TM_, TN_, AM_) do { \
         static DeviceOnce once; int once_dev; \
         if (once.todo(&once_dev)) { \
-            HIP_TRY(hipFuncSetAttribute((const void *)conv_igemm_h2_kernel<TM_, TN_, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
+            HIP_TRY(hipFuncSetAttribute((const void *)conv_igemm_h2_kernel<TM_, TN_, AM_, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds)); \
             once.done(once_dev); } \
-        hipLaunchKernelGGL((conv_igemm_h2_kernel<TM_, TN_, 2, true>), grid, blk, lds, st, a); } while (0)
+        hipLaunchKernelGGL((conv_igemm_h2_kernel<TM_, TN_, AM_, true>), grid, blk, lds, st, a); } while (0)
     if (stem) { if (tn == 128) CI_LAUNCH(128, 128, 1); else CI_LAUNCH(128, 64, 1); }
-    else if (f.x_pairs && kws) { if (tn == 128) CI_LAUNCH_K(128, 128); else CI_LAUNCH_K(128, 64); }
+    else if (f.x_pairs && kws) { if (tn == 128) CI_LAUNCH_K(128, 128, 2); else CI_LAUNCH_K(128, 64, 2); }
+    else if (kws) { if (tn == 128) CI_LAUNCH_K(128, 128, 0); else CI_LAUNCH_K(128, 64, 0); }
     else if (f.x_pairs) { if (tn == 128) CI_LAUNCH(128, 128, 2); else CI_LAUNCH(256, 64, 2); }
     else { if (tn == 128) CI_LAUNCH(128, 128, 0); else CI_LAUNCH(128, 64, 0); }
 #undef CI_LAUNCH
