@@ -815,31 +815,37 @@ __global__ __launch_bounds__(512, 1) void conv_stem_pool_patch_kernel(StemPatchA
     const int step = 2 * nslot;
     const int64_t img = (int64_t)p.H * p.W * 3;
     float raw[10];
-    auto patch_request = [&](int tile) {               // 21 rows x 111 floats of the tile's patch -> registers (zeros outside the image)
+    // element pair e2 = gt + 256 j (j < 5) of the patch: row e2 / 56, floats 2 (e2 % 56) and + 1 (float 111 does not exist: zero) -- a
+    // thread splits two neighbouring values and writes ONE dword per plane (2-byte stores of neighbouring lanes fall on the same bank:
+    // SQ_LDS_BANK_CONFLICT was 22 % of the kernel's LDS cycles)
+    auto patch_request = [&](int tile) {               // 21 rows x 112 floats of the tile's patch -> registers (zeros outside the image)
         const int tb = tile / p.tpi, t = tile - tb * p.tpi, tr = t / p.tcols, tc = t - tr * p.tcols;
         const __amdgpu_buffer_rsrc_t rs = ci_rsrc((const char *)(p.x + tb * img), img * 4);
         const int gy0 = tr * 16 - 3, gx0 = (tc * 32 - 3) * 3;
 #pragma unroll
-        for (int j = 0; j < 10; ++j) {
-            const int e = gt + j * 256;
-            const int pr = e / 111, pf = e - pr * 111;
+        for (int j = 0; j < 5; ++j) {
+            const int e2 = gt + j * 256;
+            const int pr = e2 / 56, pf = 2 * (e2 - pr * 56);
             const int gy = gy0 + pr, gx = gx0 + pf;
-            const bool in = e < 21 * 111 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)(p.W * 3);
-            raw[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, in ? (gy * p.W * 3 + gx) * 4 : 0x7fffffff, 0, 0));
+            const bool rowin = e2 < 21 * 56 && (unsigned)gy < (unsigned)p.H;
+            const bool in0 = rowin && (unsigned)gx < (unsigned)(p.W * 3), in1 = rowin && pf + 1 < 111 && (unsigned)(gx + 1) < (unsigned)(p.W * 3);
+            const int off = (gy * p.W * 3 + gx) * 4;
+            raw[2 * j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, in0 ? off : 0x7fffffff, 0, 0));
+            raw[2 * j + 1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, in1 ? off + 4 : 0x7fffffff, 0, 0));
         }
     };
     auto patch_store = [&](int buf) {                  // split into the hi and lo planes (the split of conv_igemm's a_store)
         char *hp = s_patch + buf * 2 * SP_PLANE, *lp = hp + SP_PLANE;
 #pragma unroll
-        for (int j = 0; j < 10; ++j) {
-            const int e = gt + j * 256;
-            if (e < 21 * 111) {
-                const int pr = e / 111, pf = e - pr * 111;
-                const float v = raw[j] * sc;
-                const __half hv = __float2half_rn(v);
-                const __half lv = __float2half_rn(v - __half2float(hv));
-                *(__half *)(hp + (pr * SP_PPH + pf) * 2) = hv;
-                *(__half *)(lp + (pr * SP_PPH + pf) * 2) = lv;
+        for (int j = 0; j < 5; ++j) {
+            const int e2 = gt + j * 256;
+            if (e2 < 21 * 56) {
+                const int pr = e2 / 56, pf = 2 * (e2 - pr * 56);
+                const float v0 = raw[2 * j] * sc, v1 = raw[2 * j + 1] * sc;
+                const __half2 hv = __floats2half2_rn(v0, v1);
+                const __half2 lv = __floats2half2_rn(v0 - __low2float(hv), v1 - __high2float(hv));
+                *(__half2 *)(hp + (pr * SP_PPH + pf) * 2) = hv;
+                *(__half2 *)(lp + (pr * SP_PPH + pf) * 2) = lv;
             }
         }
     };
