@@ -775,7 +775,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
 #else
 #define CI_STEM_PATCH_FORM true
 #endif
-#define SP_PPH 120                      // halfs per patch row and plane (112 used + the run a last group overhangs by)
+#define SP_PPH 112                      // halfs per patch row and plane (111 used; a padding group's reads may run into the next row).  112 halfs = 56 dwords:
+                                        // a fragment read's two pixel rows (2 patch rows = 112 dwords apart) then fall on complementary banks
 #define SP_PLANE (21 * SP_PPH * 2 + 64) // bytes of one plane (+ the overhang of the last row's reads)
 #define SP_WBYTES (7 * 2 * 2 * 2 * 64 * 16)
 #define SP_GROUP (4 * SP_PLANE + 128 * 64 * 4)      // a group's two patch buffers (hi + lo planes each) and its pooling tile
