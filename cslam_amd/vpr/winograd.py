@@ -189,6 +189,35 @@ def conv_igemm_p(ws, act, Wg, bias, kernel, stride, pad, relu, res, wl1, bmax, a
     return PairAct(y, bool(out_pairs), (B, Cout, Ho, Wo), amax_out, bound_out if out_pairs else amax_out)
 
 
+def conv3x3_direct_p(act, Wp, bias, relu, res, wl1, bmax, amax_out, bound_out, out_pairs):
+    """`cslam_conv3x3_direct_p_dev` (csrc/conv_direct_p.hip): the 3x3 / stride 1 / pad 1 convolution 64 -> 64 between PairActs with the
+    weights register-resident and the patch by LDS-DMA.  act: pair format; res (or None): either format; Wp = `stem_direct_pair_weights
+    (weight)`; the other arguments and the result as `conv_igemm_p`."""
+    lib = _lib.load()
+    B, Cin, H, W = act.shape
+    assert act.pairs and Cin == 64
+    dev = act.t.device
+    if out_pairs:
+        y = torch.empty((B, H, W, 2, 2, 32), dtype=torch.float16, device=dev)
+    else:
+        y = torch.empty((B, 64, H, W), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+    if res is not None:
+        assert res.shape == (B, 64, H, W) and (res.pairs or res.t.is_contiguous(memory_format=torch.channels_last))
+    _lib.check(lib.cslam_conv3x3_direct_p_dev(
+        _p(act.t), _p(act.bound), _p(Wp[0]), _p(bias) if bias is not None else None,
+        _p(res.t) if res is not None else None, int(res.pairs) if res is not None else 0,
+        _p(res.bound) if res is not None else None, B, H, W, 64, 64, int(relu), _p(act.amax), float(Wp[1]), float(wl1), float(bmax),
+        _p(amax_out), int(out_pairs), _p(bound_out) if out_pairs else None, _p(y), _stream(act.t)))
+    return PairAct(y, bool(out_pairs), (B, 64, H, W), amax_out, bound_out if out_pairs else amax_out)
+
+
+def direct_p_fits(conv_shape, kernel, stride, pad, H, W):
+    """Whether a convolution takes the register-resident pair-format kernel: 64 -> 64 channels, 3x3 / stride 1 / pad 1, two images' maps
+    within 32-bit buffer offsets."""
+    return (tuple(conv_shape[:2]) == (64, 64) and tuple(kernel) == (3, 3) and stride == 1 and pad == 1
+            and H * W * 512 + 11 * W * 256 < 2 ** 31 - 16)
+
+
 def conv3x3_direct_h(x, Wd, bias, relu, pool, amax_in, amax_out=None):
     """y = [pool](relu(conv3x3(x) + bias)) through `cslam_conv3x3_direct_h_dev` (csrc/conv_direct_h.hip): x [B,Cin,H,W]
     channels_last float32 (Cin a multiple of 32), 128 output channels; Wd = `direct_pair_weights(weight)`; amax_in = 4-byte device
@@ -411,6 +440,7 @@ def _z_form(cin, cout):
 
 Z_FORM_MAX = 128 * 128
 PAIR_ACTS = True              # ResNet trunks: pair-format maps between the implicit-GEMM layers (False: float32 maps, the A/B partner)
+DIRECT_P = True               # ResNet trunks: the 64 -> 64 3x3 layers between pair-format maps through csrc/conv_direct_p.hip (False: the implicit GEMM)
 IGEMM_CONVS = True            # ResNet trunks: strided / 1x1 / 7x7 layers through csrc/conv_igemm.hip (False: torch, the A/B partner)
 
 
@@ -542,7 +572,7 @@ class _FoldedConv(object):
     def __init__(self, conv, bn, tile, min_in_channels, direct=False):
         self.weight, self.bias = fold_bn(conv, bn)
         self.stride, self.padding = conv.stride, conv.padding
-        self.U = self.U4 = self.Wg = None
+        self.U = self.U4 = self.Wg = self.Wp = None
         self.kernel = tuple(conv.kernel_size)
         # the bound of the output the pair-format chain scales by: |y| <= max |x| wl1 + bmax (+ max |shortcut|)
         self.wl1 = float(self.weight.detach().abs().sum(dim=(1, 2, 3)).max())
@@ -556,6 +586,10 @@ class _FoldedConv(object):
             # the fp32 Winograd pipeline on ResNet-18's maps (profiles/r05_v23_igemm_layers.log), no library product anywhere
             self.Wg = igemm_pair_weights(self.weight)
             self.Wg = (self.Wg[0].to(self.weight.device), self.Wg[1])
+            if (DIRECT_P and tuple(self.weight.shape) == (64, 64, 3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)):
+                # layer1's 64 -> 64 convolutions between pair-format maps: the register-resident direct kernel (csrc/conv_direct_p.hip)
+                self.Wp = stem_direct_pair_weights(self.weight)
+                self.Wp = (self.Wp[0].to(self.weight.device), self.Wp[1])
         elif (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
                 and conv.groups == 1 and conv.in_channels >= min_in_channels and conv.in_channels % 4 == 0
                 and conv.out_channels % 4 == 0 and conv.weight.is_cuda):
@@ -662,6 +696,10 @@ class WinogradResNet(_Workspace):
 
             def runp(conv, a, relu, res):
                 np_[0] += 2
+                if (conv.Wp is not None and a.pairs and conv is not last
+                        and direct_p_fits(conv.weight.shape, conv.kernel, conv.stride[0], conv.padding[0], a.shape[2], a.shape[3])):
+                    return conv3x3_direct_p(a, conv.Wp, conv.bias, relu, res, conv.wl1, conv.bmax, pslots[np_[0] - 2:np_[0] - 1],
+                                            pslots[np_[0] - 1:np_[0]], True)
                 return conv_igemm_p(self, a, conv.Wg, conv.bias, conv.kernel, conv.stride[0], conv.padding[0], relu, res, conv.wl1,
                                     conv.bmax, pslots[np_[0] - 2:np_[0] - 1], pslots[np_[0] - 1:np_[0]], conv is not last)
             cur = PairAct(x, False, x.shape, ax, ax)

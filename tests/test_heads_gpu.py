@@ -1320,6 +1320,75 @@ def test_pair_format_activations_between_implicit_gemm_layers(T, B, c0, c1, hw, 
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,hw", [(3, (56, 56)), (5, (7, 7)), (3, (13, 9)), (2, (5, 130)), (1, (8, 16)), (2, (112, 112)), (300, (56, 56)),
+                                  (1, (1, 1)), (4, (9, 23))])
+def test_register_resident_pair_convolution_equals_float64(T, B, hw):
+    """`cslam_conv3x3_direct_p_dev` (csrc/conv_direct_p.hip: ResNet layer1's 64 -> 64 convolutions between pair-format maps, weights
+    register-resident, patch by LDS-DMA, blocks of two 8 x 8 halves that may straddle block rows and images): a float32 map -> the
+    implicit GEMM (pair-format output) -> this kernel, with no shortcut, a pair-format one and a float32 one, pair-format and float32
+    output, with and without ReLU.  Every result against the same chain in float64, no further from it than 4 x torch's float32 chain
+    (+ 4e-7 of the scale), and next to the implicit GEMM's result on the same operands; the measured max |y| and the bound slots are
+    right; repeated launches are bit-identical.  Maps: ResNet's 56 x 56 (seven halves per block row: blocks straddle rows and images;
+    300 images: every workgroup walks several blocks), ragged ones, a row longer than a block, a single pixel."""
+    torch, _ = T
+    from cslam_amd.vpr import winograd as wg
+    torch.manual_seed(B * 131 + hw[0] * 7 + hw[1])
+    H, W = hw
+    x = torch.randn((B, 64, H, W), device="cuda") * torch.exp2(torch.randint(-5, 2, (B, 64, 1, 1), device="cuda").float())
+    x = x.contiguous(memory_format=torch.channels_last)
+    w1 = torch.randn((64, 64, 3, 3), device="cuda") / 24
+    b1 = torch.randn(64, device="cuda") * 0.2
+    w2 = torch.randn((64, 64, 3, 3), device="cuda") / 24 * torch.exp2(torch.randint(-3, 1, (64, 1, 1, 1), device="cuda").float())
+    b2 = torch.randn(64, device="cuda") * 0.2
+    ws = wg._Workspace()
+    slots = torch.zeros(12, dtype=torch.float32, device="cuda")
+    slots[0] = x.abs().max()
+    a0 = wg.PairAct(x, False, x.shape, slots[0:1], slots[0:1])
+    wl1 = lambda w: float(w.abs().sum(dim=(1, 2, 3)).max())        # noqa: E731
+    a1 = wg.conv_igemm_p(ws, a0, wg.igemm_pair_weights(w1), b1, (3, 3), 1, 1, True, None, wl1(w1), float(b1.abs().max()),
+                         slots[1:2], slots[2:3], True)
+    r1 = torch.nn.functional.conv2d(x.double(), w1.double(), b1.double(), padding=1).relu()
+    f1 = torch.nn.functional.conv2d(x, w1, b1, padding=1).relu()
+    y1 = wg.pairs_to_float(a1)
+    Wp, Wg2 = wg.stem_direct_pair_weights(w2), wg.igemm_pair_weights(w2)
+    assert wg.direct_p_fits(w2.shape, (3, 3), 1, 1, H, W)
+    res_forms = [None, a1, wg.PairAct(y1.contiguous(memory_format=torch.channels_last), False, y1.shape, slots[1:2], slots[1:2])]
+    for res in res_forms:
+        for relu in (True, False):
+            r2 = torch.nn.functional.conv2d(r1, w2.double(), b2.double(), padding=1)
+            f2 = torch.nn.functional.conv2d(f1, w2, b2, padding=1)
+            if res is not None:
+                r2, f2 = r2 + r1, f2 + f1
+            if relu:
+                r2, f2 = r2.relu(), f2.relu()
+            sc2 = r2.abs().max().item()
+            e32 = (f2.double() - r2).abs().max().item() / sc2
+            for out_pairs in (True, False):
+                slots[3:].zero_()
+                a2 = wg.conv3x3_direct_p(a1, Wp, b2, relu, res, wl1(w2), float(b2.abs().max()), slots[3:4], slots[4:5], out_pairs)
+                y2 = wg.pairs_to_float(a2) if out_pairs else a2.t
+                assert tuple(y2.shape) == tuple(r2.shape)
+                err = (y2.double() - r2).abs().max().item() / sc2
+                assert err <= 4 * e32 + 4e-7, (res is not None and res.pairs, relu, out_pairs, err, e32)
+                assert abs(slots[3].item() - sc2) <= 1e-5 * sc2
+                if out_pairs:
+                    rb = 0.0 if res is None else res.bound.item()
+                    assert slots[4].item() >= slots[3].item()
+                    assert slots[4].item() <= (slots[1].item() * wl1(w2) + float(b2.abs().max()) + rb) * 1.002
+                # the implicit GEMM on the same operands: the same arithmetic in another summation order
+                slots[5:].zero_()
+                g2 = wg.conv_igemm_p(ws, a1, Wg2, b2, (3, 3), 1, 1, relu, res, wl1(w2), float(b2.abs().max()), slots[5:6], slots[6:7], out_pairs)
+                yg = wg.pairs_to_float(g2) if out_pairs else g2.t
+                assert (y2 - yg).abs().max().item() / sc2 <= 2e-6
+                if out_pairs:
+                    assert slots[6].item() == slots[4].item()
+                # bit-stable
+                slots[7:].zero_()
+                a3 = wg.conv3x3_direct_p(a1, Wp, b2, relu, res, wl1(w2), float(b2.abs().max()), slots[7:8], slots[8:9], out_pairs)
+                assert torch.equal(a3.t, a2.t) and slots[7].item() == slots[3].item()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,H,W,cout,k,stride,pad", [(3, 224, 224, 64, 7, 2, 3), (2, 64, 96, 64, 7, 2, 3), (5, 32, 32, 128, 3, 2, 1),
                                                     (2, 16, 32, 64, 3, 1, 1), (1, 32, 64, 64, 7, 2, 3), (7, 224, 224, 64, 7, 2, 3)])
 def test_stem_with_fused_maxpool_equals_pooling_the_unfused_output(T, B, H, W, cout, k, stride, pad):
