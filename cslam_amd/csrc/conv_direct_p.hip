@@ -76,7 +76,9 @@ __device__ __forceinline__ unsigned dp_pk(float a, float b) {              // (f
 }
 
 // RES: shortcut 0 none, 1 float32 NHWC, 2 pair format; OUTP: y in pair format (else float32 NHWC)
-template <int RES, bool OUTP>
+// DBG (builds with -DCSLAM_ABLATIONS only; WRONG results, timing): 1 no epilogue, 2 no patch requests inside the loop, 4 no shortcut loads,
+// 8 no fragment reads after a block's first two, 16 no stores (the epilogue's arithmetic stays)
+template <int RES, bool OUTP, int DBG = 0>
 __global__ __launch_bounds__(256, 1) void conv3x3_direct_p_kernel(ConvDirectPArgs p) {
     extern __shared__ __attribute__((aligned(16))) char dp_smem[];
     const int tid = threadIdx.x;
@@ -254,8 +256,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_p_kernel(ConvDirectPArg
             const unsigned h01 = dp_pk(u0, u1), h23 = dp_pk(u2, u3);
             const unsigned l01 = dp_pk(dp_fma_half<0>(h01, neg1, u0), dp_fma_half<1>(h01, neg1, u1));
             const unsigned l23 = dp_pk(dp_fma_half<0>(h23, neg1, u2), dp_fma_half<1>(h23, neg1, u3));
-            __builtin_amdgcn_raw_buffer_store_b64((u32x2){h01, h23}, rsY, off, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b64((u32x2){l01, l23}, rsY, off, 64, 0);
+            if (!(DBG & 16)) {
+                __builtin_amdgcn_raw_buffer_store_b64((u32x2){h01, h23}, rsY, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64((u32x2){l01, l23}, rsY, off, 64, 0);
+            } else asm volatile("" :: "v"(h01), "v"(h23), "v"(l01), "v"(l23), "v"(off));
         } else {
             __builtin_amdgcn_raw_buffer_store_b128((u32x4){__float_as_uint(ev[0]), __float_as_uint(ev[1]), __float_as_uint(ev[2]), __float_as_uint(ev[3])}, rsY, off, 0, 0);
         }
@@ -292,10 +296,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_p_kernel(ConvDirectPArg
     auto extras = [&](auto col_tag, auto r_tag, char *npatch) {
         constexpr int COL = decltype(col_tag)::value, R = decltype(r_tag)::value;
         if constexpr (COL == 0 && R == 0) { co = out_px(cb); rsRc = rsrc_of(RES ? p.res : p.y, cb); rsXn = rsrc_of(p.x, nb); rsYe = rsrc_of(p.y, eb); }
-        if constexpr (COL == 0 && R >= 1 && R <= 8) res_load(R - 1, co, rsRc);
-        if constexpr (COL == 0 && R >= 2 && R <= 7) dma_issue(std::integral_constant<int, R - 2>{}, nb, rsXn, npatch);
-        if constexpr (COL == 1 && R >= 2 && R <= 8) dma_issue(std::integral_constant<int, R + 4>{}, nb, rsXn, npatch);
-        if constexpr (COL >= 2 && COL <= 4 && R >= 2 && R <= 7) {
+        if constexpr (COL == 0 && R >= 1 && R <= 8 && !(DBG & 4)) res_load(R - 1, co, rsRc);
+        if constexpr (COL == 0 && R >= 2 && R <= 7 && !(DBG & 2)) dma_issue(std::integral_constant<int, R - 2>{}, nb, rsXn, npatch);
+        if constexpr (COL == 1 && R >= 2 && R <= 8 && !(DBG & 2)) dma_issue(std::integral_constant<int, R + 4>{}, nb, rsXn, npatch);
+        if constexpr (COL >= 2 && COL <= 4 && R >= 2 && R <= 7 && !(DBG & 1)) {
             constexpr int piece = 6 * (COL - 2) + (R - 2);
             if constexpr (piece < 16) { if constexpr ((piece & 1) == 0) epi_a(piece >> 1); else epi_b(piece >> 1, rsYe); }
         }
@@ -305,7 +309,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_p_kernel(ConvDirectPArg
     auto rstep = [&](auto col_tag, auto r_tag, const char *patch, char *npatch) {
         constexpr int COL = decltype(col_tag)::value, R = decltype(r_tag)::value;
         constexpr int DX = COL >> 1, KS = COL & 1, SLOT = (R + COL) % 3;
-        if constexpr (R + 2 < 10) frag_read(col_tag, std::integral_constant<int, (R + 2) % 10>{}, patch);
+        if constexpr (DBG & 8) { }
+        else if constexpr (R + 2 < 10) frag_read(col_tag, std::integral_constant<int, (R + 2) % 10>{}, patch);
         else if constexpr (COL < 5) frag_read(std::integral_constant<int, (COL + 1) % 6>{}, std::integral_constant<int, (R + 2) % 10>{}, patch);
 #pragma unroll
         for (int prod = 0; prod < 3; ++prod)
@@ -332,13 +337,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_p_kernel(ConvDirectPArg
         constexpr int COL = decltype(col_tag)::value;
         constexpr int DX = COL >> 1, KS = COL & 1, SLOT = (9 + COL) % 3;
         constexpr int DX2 = (COL + 1) >> 1, KS2 = (COL + 1) & 1, SLOT2 = (COL + 1) % 3;
-        frag_read(std::integral_constant<int, COL + 1>{}, std::integral_constant<int, 1>{}, patch);
+        if constexpr (!(DBG & 8)) frag_read(std::integral_constant<int, COL + 1>{}, std::integral_constant<int, 1>{}, patch);
 #pragma unroll
         for (int prod = 0; prod < 3; ++prod) {
             acc[7] = __builtin_amdgcn_mfma_f32_16x16x32_f16(prod == 2 ? wr[6 + DX][KS][1] : wr[6 + DX][KS][0], prod == 1 ? fl[SLOT] : fh[SLOT], acc[7], 0, 0, 0);
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(prod == 2 ? wr[DX2][KS2][1] : wr[DX2][KS2][0], prod == 1 ? fl[SLOT2] : fh[SLOT2], acc[0], 0, 0, 0);
         }
-        frag_read(std::integral_constant<int, COL + 1>{}, std::integral_constant<int, 2>{}, patch);
+        if constexpr (!(DBG & 8)) frag_read(std::integral_constant<int, COL + 1>{}, std::integral_constant<int, 2>{}, patch);
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
 #pragma unroll
         for (int m = 0; m < 6; ++m) {
@@ -453,6 +458,24 @@ CSLAM_API int cslam_conv3x3_direct_p_dev(const void *d_x, const unsigned *d_xbou
             once.done(once_dev); } \
         hipLaunchKernelGGL((conv3x3_direct_p_kernel<R_, O_>), dim3(grid), dim3(256), DP_LDS, st, a); } while (0)
     const int rm = !d_res ? 0 : (res_pairs ? 2 : 1);
+#ifdef CSLAM_ABLATIONS
+    if (const char *e = getenv("CSLAM_DP_DBG")) {              // timing-only ablations (wrong results): measurement build, pair-format output
+        const int d = atoi(e);
+#define DP_LAUNCH_D(D) do { if (rm == 2) { HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_direct_p_kernel<2, true, D>, hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS)); \
+            hipLaunchKernelGGL((conv3x3_direct_p_kernel<2, true, D>), dim3(grid), dim3(256), DP_LDS, st, a); } else { \
+            HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_direct_p_kernel<0, true, D>, hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS)); \
+            hipLaunchKernelGGL((conv3x3_direct_p_kernel<0, true, D>), dim3(grid), dim3(256), DP_LDS, st, a); } \
+        HIP_TRY(hipGetLastError()); return CSLAM_OK; } while (0)
+        if (d == 1) DP_LAUNCH_D(1);
+        if (d == 2) DP_LAUNCH_D(2);
+        if (d == 4) DP_LAUNCH_D(4);
+        if (d == 7) DP_LAUNCH_D(7);
+        if (d == 8) DP_LAUNCH_D(8);
+        if (d == 15) DP_LAUNCH_D(15);
+        if (d == 16) DP_LAUNCH_D(16);
+#undef DP_LAUNCH_D
+    }
+#endif
     if (out_pairs) { if (rm == 0) DP_LAUNCH(0, true); else if (rm == 1) DP_LAUNCH(1, true); else DP_LAUNCH(2, true); }
     else { if (rm == 0) DP_LAUNCH(0, false); else if (rm == 1) DP_LAUNCH(1, false); else DP_LAUNCH(2, false); }
 #undef DP_LAUNCH
