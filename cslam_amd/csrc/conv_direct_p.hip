@@ -32,10 +32,10 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #define DP_HALFB (100 * 256)               // a half-block's 10 x 10-pixel patch
-#define DP_NDMA 13                          // DMA instructions per wave and block: 4 x 13 = 52 >= 50 (the last two: a sink behind the patch)
-#define DP_PATCHB (4 * DP_NDMA * 1024)      // 53 248 bytes per buffer
+#define DP_NDMA(NW) ((50 + (NW) - 1) / (NW))   // DMA instructions per wave and block: 4 x 13 = 52, 8 x 7 = 56 >= 50 (the last ones: a sink behind the patch)
+#define DP_PATCHB(NW) ((NW) * DP_NDMA(NW) * 1024)   // 53 248 / 57 344 bytes per buffer
 #define DP_RP (10 * 256)                    // bytes per patch row of a half
-#define DP_LDS (2 * DP_PATCHB)
+#define DP_LDS(NW) (2 * DP_PATCHB(NW))
 #define DP_OOB 0x7fffffff
 
 struct ConvDirectPArgs {
@@ -78,12 +78,18 @@ __device__ __forceinline__ unsigned dp_pk(float a, float b) {              // (f
 // RES: shortcut 0 none, 1 float32 NHWC, 2 pair format; OUTP: y in pair format (else float32 NHWC)
 // DBG (builds with -DCSLAM_ABLATIONS only; WRONG results, timing): 1 no epilogue, 2 no patch requests inside the loop, 4 no shortcut loads,
 // 8 no fragment reads after a block's first two, 16 no stores (the epilogue's arithmetic stays)
-template <int RES, bool OUTP, int DBG = 0>
-__global__ __launch_bounds__(256, 1) void conv3x3_direct_p_kernel(ConvDirectPArgs p) {
+// NRW: output rows of a block per wave.  8: four waves, one per SIMD (512 registers each); 4: EIGHT waves, two per SIMD -- wave w = channel
+// quarter w & 3 of the block's rows 4 (w >> 2) .. + 3 (six patch rows: a fragment serves two taps on average instead of 2.4), 256
+// registers each: the two waves of a SIMD cover one another's vector-memory instructions (45 per block: each holds its wave's issue for
+// tens of cycles, and with one wave per SIMD the matrix pipe idles meanwhile -- the ablations of profiles/r06_b_dp_ablations.log)
+template <int RES, bool OUTP, int NRW, int DBG = 0>
+__global__ __launch_bounds__(2048 / NRW, 1) void conv3x3_direct_p_kernel(ConvDirectPArgs p) {
+    constexpr int NW = 32 / NRW, NPR = NRW + 2, NDMA = DP_NDMA(NW), PATCHB = DP_PATCHB(NW);
     extern __shared__ __attribute__((aligned(16))) char dp_smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wq = wave & 3, rh = wave >> 2;                   // channel quarter, row group (0 with four waves)
     const int gq = lane >> 4, l15 = lane & 15;
     const int lh = l15 >> 3, l7 = l15 & 7;                     // the lane's half-block and pixel column inside it
 
@@ -120,10 +126,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_p_kernel(ConvDirectPArg
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int hl = 0; hl < 2; ++hl) {
-                wr[tap][ks][hl] = p.w2[(((wave * 9 + tap) * 2 + ks) * 2 + hl) * 64 + lane];
-                asm volatile("" : "+a"(wr[tap][ks][hl]));
+                wr[tap][ks][hl] = p.w2[(((wq * 9 + tap) * 2 + ks) * 2 + hl) * 64 + lane];
+                // pinned in the accumulation half of the register file (conv_stem_direct_h.hip).  With two waves per SIMD hipcc splits a wave's
+                // 256 registers 128 + 128: the accumulators and the first 28 fragments fill the accumulation half, the last 8 stay architectural
+                if (NRW == 8 || tap < 7) asm volatile("" : "+a"(wr[tap][ks][hl]));
+                else asm volatile("" : "+v"(wr[tap][ks][hl]));
             }
-    const float4 bv = p.bias ? *(const float4 *)(p.bias + 16 * wave + 4 * gq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 bv = p.bias ? *(const float4 *)(p.bias + 16 * wq + 4 * gq) : make_float4(0.f, 0.f, 0.f, 0.f);
 
     // ---- blocks.  Half-block hb -> (image, block row, column of eight); a block = halves 2 k, 2 k + 1.  All of it wave-uniform.
     const int img_px = p.H * p.W, imgB = img_px * 256;
@@ -169,10 +178,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_p_kernel(ConvDirectPArg
 
     // ---- patch requests: instruction i of this wave = DMA piece j = 4 i + wave: half j / 25, its pixels 4 (j % 25) .. + 3 (patch row
     // major, 10 per row); lane -> pixel (lane >> 4) of the four, physical slot lane & 15 = logical 16-byte chunk ^ (2 c & 15)
-    int dm_rel[DP_NDMA], dm_r[DP_NDMA], dm_c[DP_NDMA];
+    int dm_rel[NDMA], dm_r[NDMA], dm_c[NDMA];
 #pragma unroll
-    for (int i = 0; i < DP_NDMA; ++i) {
-        const int j = 4 * i + wave;
+    for (int i = 0; i < NDMA; ++i) {
+        const int j = NW * i + wave;
         const int pp = 4 * (j % 25) + (lane >> 4);
         const int r = pp / 10, c = pp - 10 * r;
         const int s = (lane & 15) ^ ((2 * c) & 15);
@@ -181,12 +190,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_p_kernel(ConvDirectPArg
     }
     auto dma_issue = [&](auto i_tag, const Blk &b, __amdgpu_buffer_rsrc_t rsX, char *npatch) {
         constexpr int I = decltype(i_tag)::value;
-        const int j = 4 * I + wave;                            // wave-uniform; the half is a compile-time fact except for I = 6 (j = 24 .. 27)
+        const int j = NW * I + wave;                           // wave-uniform; the half is a compile-time fact except for the instruction that holds piece 25
         int by8, bx8, org;
-        if constexpr (I < 6) { by8 = b.by8[0]; bx8 = b.bx8[0]; org = b.org[0]; }
-        else if constexpr (I > 6) { by8 = b.by8[1]; bx8 = b.bx8[1]; org = b.org[1]; }
-        else { const int m = -(wave != 0); by8 = (b.by8[1] & m) | (b.by8[0] & ~m); bx8 = (b.bx8[1] & m) | (b.bx8[0] & ~m); org = (b.org[1] & m) | (b.org[0] & ~m); }
-        if constexpr (I == DP_NDMA - 1) by8 |= (wave >= 2) << 24;          // pieces 50, 51: the sink
+        if constexpr (NW * I + NW - 1 < 25) { by8 = b.by8[0]; bx8 = b.bx8[0]; org = b.org[0]; }
+        else if constexpr (NW * I >= 25) { by8 = b.by8[1]; bx8 = b.bx8[1]; org = b.org[1]; }
+        else { const int m = (24 - j) >> 31; by8 = (b.by8[1] & m) | (b.by8[0] & ~m); bx8 = (b.bx8[1] & m) | (b.bx8[0] & ~m); org = (b.org[1] & m) | (b.org[0] & ~m); }
+        if constexpr (NW * I + NW - 1 >= 50) by8 |= ((49 - j) >> 31) & (1 << 24);          // pieces 50 ..: the sink
         int rel = dm_rel[I];
         asm volatile("" : "+v"(rel));                          // (pins the request's arithmetic to its region: hipcc otherwise gathers all thirteen in front of the first)
         const int off = org + rel;
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_p_kernel(ConvDirectPArg
         dp_blds16(rsX, in ? off : DP_OOB, npatch + j * 1024);
     };
 
-    // ---- the lane's output pixel of a block: half lh, column l7; offset of its row 0 from image img0, and how many of the 8 rows exist
+    // ---- the lane's output pixel of a block: half lh, column l7; offset of the block's row 0 from image img0, and how many of the 8 rows exist
     struct OutPx { int pix, rows; };
     auto out_px = [&](const Blk &b) {
         OutPx o;
@@ -206,15 +215,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_p_kernel(ConvDirectPArg
     };
     const int rowB = p.W * 256;
     // byte offsets of the lane's four channels 16 wave + 4 gq .. + 3 inside a pixel: pair format [block wave >> 1][hi | lo][32], float32
-    const int ch_pair = (wave >> 1) * 128 + (16 * (wave & 1) + 4 * gq) * 2;
-    const int ch_f32 = (16 * wave + 4 * gq) * 4;
+    const int ch_pair = (wq >> 1) * 128 + (16 * (wq & 1) + 4 * gq) * 2;
+    const int ch_f32 = (16 * wq + 4 * gq) * 4;
+    const int row0 = rh * NRW;                                 // this wave's first output row of the block = its first patch row
 
     // ---- shortcut of the block being multiplied: loaded in its first column, used by its epilogue one block later
-    u32x4 rnew[8], rres[8];
+    u32x4 rnew[NRW], rres[NRW];
     auto res_load = [&](int r, const OutPx &o, __amdgpu_buffer_rsrc_t rsR) {
         if (RES == 0) return;
-        int off = o.pix + r * rowB + (RES == 2 ? ch_pair : ch_f32);
-        off = r < o.rows ? off : DP_OOB;
+        int off = o.pix + (row0 + r) * rowB + (RES == 2 ? ch_pair : ch_f32);
+        off = row0 + r < o.rows ? off : DP_OOB;
         if (RES == 2) {
             const u32x2 a = __builtin_amdgcn_raw_buffer_load_b64(rsR, off, 0, 0), c = __builtin_amdgcn_raw_buffer_load_b64(rsR, off, 64, 0);
             rnew[r] = (u32x4){a.x, a.y, c.x, c.y};
@@ -225,7 +235,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_p_kernel(ConvDirectPArg
 
     // ---- epilogue of the finished block (accumulators copied to eacc), one output row in two pieces
     float my_amax = 0.0f;
-    f32x4 eacc[8];
+    f32x4 eacc[NRW];
     OutPx eo = {0, 0};
     float ev[4];
     auto epi_a = [&](int r) {                                  // rescale, bias, shortcut, activation, max |y|
@@ -244,13 +254,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_p_kernel(ConvDirectPArg
 #pragma unroll
         for (int e = 0; e < 4; ++e) ev[e] = __builtin_fmaxf(ev[e], floor_);
         const float m = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(ev[0]), __builtin_fabsf(ev[1])), __builtin_fmaxf(__builtin_fabsf(ev[2]), __builtin_fabsf(ev[3])));
-        my_amax = __builtin_fmaxf(my_amax, r < eo.rows ? m : 0.0f);
+        my_amax = __builtin_fmaxf(my_amax, row0 + r < eo.rows ? m : 0.0f);
         asm volatile("" : "+v"(my_amax));                    // (pinned to its region: left alone hipcc gathers the eight rows' maxima into one chain in front of a later MFMA)
     };
     auto epi_b = [&](int r, __amdgpu_buffer_rsrc_t rsY) {       // the stores
         asm volatile("" : "+v"(ev[0]), "+v"(ev[1]), "+v"(ev[2]), "+v"(ev[3]));
-        int off = eo.pix + r * rowB + (OUTP ? ch_pair : ch_f32);
-        off = r < eo.rows ? off : DP_OOB;
+        int off = eo.pix + (row0 + r) * rowB + (OUTP ? ch_pair : ch_f32);
+        off = row0 + r < eo.rows ? off : DP_OOB;
         if (OUTP) {
             const float u0 = ev[0] * s_out, u1 = ev[1] * s_out, u2 = ev[2] * s_out, u3 = ev[3] * s_out;
             const unsigned h01 = dp_pk(u0, u1), h23 = dp_pk(u2, u3);
@@ -266,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_p_kernel(ConvDirectPArg
     };
 
     // ---- the products.  acc[r]: output row r of both halves, lane (l15, gq) = pixel (half lh, column l7), channels 16 wave + 4 gq .. + 3
-    f32x4 acc[8];
+    f32x4 acc[NRW];
     int fro[3][2][2];                                          // fragment offset at column shift dx, K step, hi | lo: pixel column l7 + dx of half lh
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx)
@@ -275,20 +285,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_p_kernel(ConvDirectPArg
 #pragma unroll
             for (int hl = 0; hl < 2; ++hl) {
                 const int c = l7 + dx;
-                fro[dx][ks][hl] = lh * DP_HALFB + c * 256 + (((ks * 8 + hl * 4 + gq) ^ ((2 * c) & 15)) << 4);
+                fro[dx][ks][hl] = lh * DP_HALFB + row0 * DP_RP + c * 256 + (((ks * 8 + hl * 4 + gq) ^ ((2 * c) & 15)) << 4);
             }
     f16x8 fh[3], fl[3];
     auto frag_read = [&](auto col_tag, auto r_tag, const char *patch) {
         constexpr int COL = decltype(col_tag)::value, R = decltype(r_tag)::value;
-        constexpr int DX = COL >> 1, KS = COL & 1, SLOT = (R + COL) % 3;
+        constexpr int DX = COL >> 1, KS = COL & 1, SLOT = (COL * NPR + R) % 3;
         fh[SLOT] = *(const f16x8 *)(patch + fro[DX][KS][0] + R * DP_RP);
         fl[SLOT] = *(const f16x8 *)(patch + fro[DX][KS][1] + R * DP_RP);
     };
-    // what rides in the region of (column, patch row): nothing in the matrix loop waits for it
+    // what rides in the region of (column, patch row) -- nothing in the matrix loop waits for it.  Four waves (NRW = 8):
     //   column 0, rows 1..8: the shortcut loads of this block's output rows 0..7
     //   columns 0 / 1, rows 2..7 / 2..8: the 13 patch requests of the next block
     //   columns 2 / 3 / 4, rows 2..7: the previous block's epilogue, output row 3 (COL - 2) + (R - 2) / 2 .. (16 pieces, rows 0..7)
-    //   column 5, rows 2..4: the block after next is decoded (scalar unit)
+    //   column 5, rows 2..3: the block after next is decoded (scalar unit)
+    // eight waves (NRW = 4): shortcut loads column 0 rows 1..4, requests column 0 rows 2..4 and column 1 rows 1..4, the epilogue's
+    // 8 pieces in columns 2 / 3 / 4 rows 1..3
     Blk cb, nb, nnb, eb;
     OutPx co;
     __amdgpu_buffer_rsrc_t rsXn, rsRc, rsYe;
@@ -296,35 +308,44 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_p_kernel(ConvDirectPArg
     auto extras = [&](auto col_tag, auto r_tag, char *npatch) {
         constexpr int COL = decltype(col_tag)::value, R = decltype(r_tag)::value;
         if constexpr (COL == 0 && R == 0) { co = out_px(cb); rsRc = rsrc_of(RES ? p.res : p.y, cb); rsXn = rsrc_of(p.x, nb); rsYe = rsrc_of(p.y, eb); }
-        if constexpr (COL == 0 && R >= 1 && R <= 8 && !(DBG & 4)) res_load(R - 1, co, rsRc);
-        if constexpr (COL == 0 && R >= 2 && R <= 7 && !(DBG & 2)) dma_issue(std::integral_constant<int, R - 2>{}, nb, rsXn, npatch);
-        if constexpr (COL == 1 && R >= 2 && R <= 8 && !(DBG & 2)) dma_issue(std::integral_constant<int, R + 4>{}, nb, rsXn, npatch);
-        if constexpr (COL >= 2 && COL <= 4 && R >= 2 && R <= 7 && !(DBG & 1)) {
-            constexpr int piece = 6 * (COL - 2) + (R - 2);
-            if constexpr (piece < 16) { if constexpr ((piece & 1) == 0) epi_a(piece >> 1); else epi_b(piece >> 1, rsYe); }
+        if constexpr (COL == 0 && R >= 1 && R <= NRW && !(DBG & 4)) res_load(R - 1, co, rsRc);
+        if constexpr (NRW == 8) {
+            if constexpr (COL == 0 && R >= 2 && R <= 7 && !(DBG & 2)) dma_issue(std::integral_constant<int, R - 2>{}, nb, rsXn, npatch);
+            if constexpr (COL == 1 && R >= 2 && R <= 8 && !(DBG & 2)) dma_issue(std::integral_constant<int, R + 4>{}, nb, rsXn, npatch);
+            if constexpr (COL >= 2 && COL <= 4 && R >= 2 && R <= 7 && !(DBG & 1)) {
+                constexpr int piece = 6 * (COL - 2) + (R - 2);
+                if constexpr (piece < 16) { if constexpr ((piece & 1) == 0) epi_a(piece >> 1); else epi_b(piece >> 1, rsYe); }
+            }
+        } else {
+            if constexpr (COL == 0 && R >= 2 && R <= 4 && !(DBG & 2)) dma_issue(std::integral_constant<int, R - 2>{}, nb, rsXn, npatch);
+            if constexpr (COL == 1 && R >= 1 && R <= 4 && !(DBG & 2)) dma_issue(std::integral_constant<int, R + 2>{}, nb, rsXn, npatch);
+            if constexpr (COL >= 2 && COL <= 4 && R >= 1 && R <= 3 && !(DBG & 1)) {
+                constexpr int piece = 3 * (COL - 2) + (R - 1);
+                if constexpr (piece < 8) { if constexpr ((piece & 1) == 0) epi_a(piece >> 1); else epi_b(piece >> 1, rsYe); }
+            }
         }
         if constexpr (COL == 5 && R == 2) { asm volatile("" : "+s"(st_hb)); advance_blk(); }
         if constexpr (COL == 5 && R == 3) { asm volatile("" : "+s"(st_hb)); nnb = make_blk(more2); }
     };
     auto rstep = [&](auto col_tag, auto r_tag, const char *patch, char *npatch) {
         constexpr int COL = decltype(col_tag)::value, R = decltype(r_tag)::value;
-        constexpr int DX = COL >> 1, KS = COL & 1, SLOT = (R + COL) % 3;
+        constexpr int DX = COL >> 1, KS = COL & 1, SLOT = (COL * NPR + R) % 3;
         if constexpr (DBG & 8) { }
-        else if constexpr (R + 2 < 10) frag_read(col_tag, std::integral_constant<int, (R + 2) % 10>{}, patch);
-        else if constexpr (COL < 5) frag_read(std::integral_constant<int, (COL + 1) % 6>{}, std::integral_constant<int, (R + 2) % 10>{}, patch);
+        else if constexpr (R + 2 < NPR) frag_read(col_tag, std::integral_constant<int, (R + 2) % NPR>{}, patch);
+        else if constexpr (COL < 5) frag_read(std::integral_constant<int, (COL + 1) % 6>{}, std::integral_constant<int, (R + 2) % NPR>{}, patch);
 #pragma unroll
         for (int prod = 0; prod < 3; ++prod)
 #pragma unroll
             for (int dy = 0; dy < 3; ++dy) {
                 const int r = R - dy;
-                if (r < 0 || r > 7) continue;
+                if (r < 0 || r > NRW - 1) continue;
                 const f16x8 a = prod == 2 ? wr[3 * dy + DX][KS][1] : wr[3 * dy + DX][KS][0];
                 const f16x8 b = prod == 1 ? fl[SLOT] : fh[SLOT];
                 acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, (COL == 0 && prod == 0 && dy == 0) ? (f32x4)(0.0f) : acc[r], 0, 0, 0);
             }
         extras(col_tag, r_tag, npatch);
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        constexpr int NM = 3 * ((R < 2 ? R + 1 : 3) - (R > 7 ? R - 7 : 0));
+        constexpr int NM = 3 * ((R < 2 ? R + 1 : 3) - (R > NRW - 1 ? R - (NRW - 1) : 0));
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -335,12 +356,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_p_kernel(ConvDirectPArg
     // the last patch row of a column and the first of the next each feed ONE accumulator: merged and alternated (conv_stem_direct_h.hip)
     auto edge = [&](auto col_tag, const char *patch) {
         constexpr int COL = decltype(col_tag)::value;
-        constexpr int DX = COL >> 1, KS = COL & 1, SLOT = (9 + COL) % 3;
-        constexpr int DX2 = (COL + 1) >> 1, KS2 = (COL + 1) & 1, SLOT2 = (COL + 1) % 3;
+        constexpr int DX = COL >> 1, KS = COL & 1, SLOT = (COL * NPR + NPR - 1) % 3;
+        constexpr int DX2 = (COL + 1) >> 1, KS2 = (COL + 1) & 1, SLOT2 = ((COL + 1) * NPR) % 3;
         if constexpr (!(DBG & 8)) frag_read(std::integral_constant<int, COL + 1>{}, std::integral_constant<int, 1>{}, patch);
 #pragma unroll
         for (int prod = 0; prod < 3; ++prod) {
-            acc[7] = __builtin_amdgcn_mfma_f32_16x16x32_f16(prod == 2 ? wr[6 + DX][KS][1] : wr[6 + DX][KS][0], prod == 1 ? fl[SLOT] : fh[SLOT], acc[7], 0, 0, 0);
+            acc[NRW - 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(prod == 2 ? wr[6 + DX][KS][1] : wr[6 + DX][KS][0], prod == 1 ? fl[SLOT] : fh[SLOT], acc[NRW - 1], 0, 0, 0);
             acc[0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(prod == 2 ? wr[DX2][KS2][1] : wr[DX2][KS2][0], prod == 1 ? fl[SLOT2] : fh[SLOT2], acc[0], 0, 0, 0);
         }
         if constexpr (!(DBG & 8)) frag_read(std::integral_constant<int, COL + 1>{}, std::integral_constant<int, 2>{}, patch);
@@ -357,10 +378,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_p_kernel(ConvDirectPArg
         if constexpr (COL_ == 0) rstep(col_tag, std::integral_constant<int, 0>{}, patch, npatch);
         rstep(col_tag, std::integral_constant<int, 1>{}, patch, npatch);
         rstep(col_tag, std::integral_constant<int, 2>{}, patch, npatch); rstep(col_tag, std::integral_constant<int, 3>{}, patch, npatch);
-        rstep(col_tag, std::integral_constant<int, 4>{}, patch, npatch); rstep(col_tag, std::integral_constant<int, 5>{}, patch, npatch);
-        rstep(col_tag, std::integral_constant<int, 6>{}, patch, npatch); rstep(col_tag, std::integral_constant<int, 7>{}, patch, npatch);
-        rstep(col_tag, std::integral_constant<int, 8>{}, patch, npatch);
-        if constexpr (COL_ == 5) rstep(col_tag, std::integral_constant<int, 9>{}, patch, npatch);
+        rstep(col_tag, std::integral_constant<int, 4>{}, patch, npatch);
+        if constexpr (NRW == 8) {
+            rstep(col_tag, std::integral_constant<int, 5>{}, patch, npatch);
+            rstep(col_tag, std::integral_constant<int, 6>{}, patch, npatch); rstep(col_tag, std::integral_constant<int, 7>{}, patch, npatch);
+            rstep(col_tag, std::integral_constant<int, 8>{}, patch, npatch);
+        }
+        if constexpr (COL_ == 5) rstep(col_tag, std::integral_constant<int, NPR - 1>{}, patch, npatch);
         else edge(col_tag, patch);
     };
 #define DP_C(T) std::integral_constant<int, T>{}
@@ -373,19 +397,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_p_kernel(ConvDirectPArg
     rsXn = rsrc_of(p.x, cb);
     dma_issue(DP_C(0), cb, rsXn, dp_smem); dma_issue(DP_C(1), cb, rsXn, dp_smem); dma_issue(DP_C(2), cb, rsXn, dp_smem);
     dma_issue(DP_C(3), cb, rsXn, dp_smem); dma_issue(DP_C(4), cb, rsXn, dp_smem); dma_issue(DP_C(5), cb, rsXn, dp_smem);
-    dma_issue(DP_C(6), cb, rsXn, dp_smem); dma_issue(DP_C(7), cb, rsXn, dp_smem); dma_issue(DP_C(8), cb, rsXn, dp_smem);
-    dma_issue(DP_C(9), cb, rsXn, dp_smem); dma_issue(DP_C(10), cb, rsXn, dp_smem); dma_issue(DP_C(11), cb, rsXn, dp_smem);
-    dma_issue(DP_C(12), cb, rsXn, dp_smem);
+    dma_issue(DP_C(6), cb, rsXn, dp_smem);
+    if constexpr (NDMA == 13) {
+        dma_issue(DP_C(7), cb, rsXn, dp_smem); dma_issue(DP_C(8), cb, rsXn, dp_smem);
+        dma_issue(DP_C(9), cb, rsXn, dp_smem); dma_issue(DP_C(10), cb, rsXn, dp_smem); dma_issue(DP_C(11), cb, rsXn, dp_smem);
+        dma_issue(DP_C(12), cb, rsXn, dp_smem);
+    }
 #pragma unroll
-    for (int r = 0; r < 8; ++r) { rres[r] = (u32x4)(0u); rnew[r] = (u32x4)(0u); eacc[r] = (f32x4)(0.0f); acc[r] = (f32x4)(0.0f); }
+    for (int r = 0; r < NRW; ++r) { rres[r] = (u32x4)(0u); rnew[r] = (u32x4)(0u); eacc[r] = (f32x4)(0.0f); acc[r] = (f32x4)(0.0f); }
     __builtin_amdgcn_s_waitcnt(0);
     __builtin_amdgcn_s_barrier();
     int bi = 0;
     do {
         const int cur = bi & 1;
         more2 = (bi + 2 - n_mine) >> 31;
-        const char *const patch = dp_smem + cur * DP_PATCHB;
-        char *const npatch = dp_smem + (cur ^ 1) * DP_PATCHB;
+        const char *const patch = dp_smem + cur * PATCHB;
+        char *const npatch = dp_smem + (cur ^ 1) * PATCHB;
         frag_read(DP_C(0), DP_C(0), patch);
         frag_read(DP_C(0), DP_C(1), patch);
         column(DP_C(0), patch, npatch); column(DP_C(1), patch, npatch); column(DP_C(2), patch, npatch);
@@ -393,7 +420,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_p_kernel(ConvDirectPArg
         // everything vector-memory of this block -- the next patch, the shortcut rows, the previous block's stores -- is through
         __builtin_amdgcn_s_waitcnt(0);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { eacc[r] = acc[r]; if (RES) rres[r] = rnew[r]; }
+        for (int r = 0; r < NRW; ++r) { eacc[r] = acc[r]; if (RES) rres[r] = rnew[r]; }
         eo = co;
         eb = cb;
         __builtin_amdgcn_s_barrier();
@@ -402,7 +429,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_p_kernel(ConvDirectPArg
     } while (++bi < n_mine);
     rsYe = rsrc_of(p.y, eb);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) { epi_a(r); epi_b(r, rsYe); }    // the last block's
+    for (int r = 0; r < NRW; ++r) { epi_a(r); epi_b(r, rsYe); }    // the last block's
 
     if (p.amax_out) {
         __syncthreads();
@@ -451,34 +478,47 @@ CSLAM_API int cslam_conv3x3_direct_p_dev(const void *d_x, const unsigned *d_xbou
     ARG_CHECK(n_cu > 0, "no HIP device");
     const int grid = a.nblk < n_cu ? a.nblk : n_cu;
     hipStream_t st = (hipStream_t)stream;
-#define DP_LAUNCH(R_, O_) do { \
+    // four waves, one per SIMD.  The eight-wave form (NRW = 4, two per SIMD: measurement build, CSLAM_DP_NRW=4) does not fit its 128 + 128
+    // registers (84 - 236 bytes of scratch: 1.05 ms), and without the epilogue, where it does fit, it is no faster (0.475 against 0.479 ms:
+    // profiles/r06_c_dp_ablations.log) -- what separates this kernel from its matrix-only time is not issue slots a second wave could fill
+    int nrw = 8;
+#ifdef CSLAM_ABLATIONS
+    if (const char *e = getenv("CSLAM_DP_NRW")) nrw = atoi(e) == 4 ? 4 : 8;
+#define DP_NRW4(X) X
+#else
+#define DP_NRW4(X) do { } while (0)
+#endif
+#define DP_LAUNCH_N(R_, O_, N_) do { \
         static DeviceOnce once; int once_dev; \
         if (once.todo(&once_dev)) { \
-            HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_direct_p_kernel<R_, O_>, hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS)); \
+            HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_direct_p_kernel<R_, O_, N_>, hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS(32 / N_))); \
             once.done(once_dev); } \
-        hipLaunchKernelGGL((conv3x3_direct_p_kernel<R_, O_>), dim3(grid), dim3(256), DP_LDS, st, a); } while (0)
+        hipLaunchKernelGGL((conv3x3_direct_p_kernel<R_, O_, N_>), dim3(grid), dim3(2048 / N_), DP_LDS(32 / N_), st, a); } while (0)
+#define DP_LAUNCH(R_, O_) do { if (nrw == 8) DP_LAUNCH_N(R_, O_, 8); else DP_NRW4(DP_LAUNCH_N(R_, O_, 4)); } while (0)
     const int rm = !d_res ? 0 : (res_pairs ? 2 : 1);
 #ifdef CSLAM_ABLATIONS
     if (const char *e = getenv("CSLAM_DP_DBG")) {              // timing-only ablations (wrong results): measurement build, pair-format output
         const int d = atoi(e);
-#define DP_LAUNCH_D(D) do { if (rm == 2) { HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_direct_p_kernel<2, true, D>, hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS)); \
-            hipLaunchKernelGGL((conv3x3_direct_p_kernel<2, true, D>), dim3(grid), dim3(256), DP_LDS, st, a); } else { \
-            HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_direct_p_kernel<0, true, D>, hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS)); \
-            hipLaunchKernelGGL((conv3x3_direct_p_kernel<0, true, D>), dim3(grid), dim3(256), DP_LDS, st, a); } \
+#define DP_LAUNCH_D2(R_, N_, D) do { HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_direct_p_kernel<R_, true, N_, D>, hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS(32 / N_))); \
+            hipLaunchKernelGGL((conv3x3_direct_p_kernel<R_, true, N_, D>), dim3(grid), dim3(2048 / N_), DP_LDS(32 / N_), st, a); } while (0)
+#define DP_LAUNCH_D(D) do { if (rm == 2) { if (nrw == 8) DP_LAUNCH_D2(2, 8, D); else DP_LAUNCH_D2(2, 4, D); } \
+                            else { if (nrw == 8) DP_LAUNCH_D2(0, 8, D); else DP_LAUNCH_D2(0, 4, D); } \
         HIP_TRY(hipGetLastError()); return CSLAM_OK; } while (0)
         if (d == 1) DP_LAUNCH_D(1);
         if (d == 2) DP_LAUNCH_D(2);
         if (d == 4) DP_LAUNCH_D(4);
         if (d == 7) DP_LAUNCH_D(7);
-        if (d == 8) DP_LAUNCH_D(8);
-        if (d == 15) DP_LAUNCH_D(15);
         if (d == 16) DP_LAUNCH_D(16);
+        if (d == 23) DP_LAUNCH_D(23);
 #undef DP_LAUNCH_D
+#undef DP_LAUNCH_D2
     }
 #endif
     if (out_pairs) { if (rm == 0) DP_LAUNCH(0, true); else if (rm == 1) DP_LAUNCH(1, true); else DP_LAUNCH(2, true); }
     else { if (rm == 0) DP_LAUNCH(0, false); else if (rm == 1) DP_LAUNCH(1, false); else DP_LAUNCH(2, false); }
 #undef DP_LAUNCH
+#undef DP_LAUNCH_N
+#undef DP_NRW4
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }
