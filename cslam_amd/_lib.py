@@ -129,7 +129,7 @@ _SIGNATURES = {
     "cslam_conv_stem_pool_igemm_h2_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, C.c_float, _vp, _vp, _vp]),
     "cslam_conv_igemm_h2p_dev": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, C.c_float,
                                       C.c_float, C.c_float, _vp, _i, _vp, _vp, _vp]),
-    "cslam_conv3x3_direct_p_dev": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, C.c_float, C.c_float, C.c_float,
+    "cslam_conv3x3_direct_p_dev": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, C.c_float, C.c_float, C.c_float,
                                         _vp, _i, _vp, _vp, _vp]),
     "cslam_comm_unique_id": (_i, [_vp]),
     "cslam_comm_init": (_i, [_i, _i, _vp, _i, C.POINTER(_vp)]),

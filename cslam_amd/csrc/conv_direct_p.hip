@@ -82,7 +82,10 @@ __device__ __forceinline__ unsigned dp_pk(float a, float b) {              // (f
 // quarter w & 3 of the block's rows 4 (w >> 2) .. + 3 (six patch rows: a fragment serves two taps on average instead of 2.4), 256
 // registers each: the two waves of a SIMD cover one another's vector-memory instructions (45 per block: each holds its wave's issue for
 // tens of cycles, and with one wave per SIMD the matrix pipe idles meanwhile -- the ablations of profiles/r06_b_dp_ablations.log)
-template <int RES, bool OUTP, int NRW, int DBG = 0>
+// XF32: x is a float32 NHWC map (the pooled stem output that opens ResNet's pair-format chain), scaled by the power of two of its max |x|
+// slot and split into pairs while the patch is staged through registers (conv_direct_r.hip's staging: 13 16-byte loads per thread in a
+// block's first column, their split in columns 1 .. 3, into this kernel's LDS image)
+template <int RES, bool OUTP, int NRW, int DBG = 0, bool XF32 = false>
 __global__ __launch_bounds__(2048 / NRW, 1) void conv3x3_direct_p_kernel(ConvDirectPArgs p) {
     constexpr int NW = 32 / NRW, NPR = NRW + 2, NDMA = DP_NDMA(NW), PATCHB = DP_PATCHB(NW);
     extern __shared__ __attribute__((aligned(16))) char dp_smem[];
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(2048 / NRW, 1) void conv3x3_direct_p_kernel(ConvDir
     const int gq = lane >> 4, l15 = lane & 15;
     const int lh = l15 >> 3, l7 = l15 & 7;                     // the lane's half-block and pixel column inside it
 
-    const float sc = dp_scale(*p.xbound);
+    const float sc = dp_scale(XF32 ? *p.amax_in : *p.xbound);
     const float inv = p.inv_sw / sc;
     float s_out = 1.0f, inv_sres = 0.0f;
     if (OUTP) {
@@ -203,6 +206,45 @@ __global__ __launch_bounds__(2048 / NRW, 1) void conv3x3_direct_p_kernel(ConvDir
         dp_blds16(rsX, in ? off : DP_OOB, npatch + j * 1024);
     };
 
+    // ---- XF32: the patch through registers.  Element e = i * 256 + tid = (patch pixel e >> 4 of the 2 x 100, channels 4 (e & 15) .. + 3)
+    constexpr int NST = XF32 ? 13 : 1;
+    int sg_rel[NST], sg_rc[NST], sg_dst[NST];
+    u32x4 stg[NST];
+    if (XF32) {
+#pragma unroll
+        for (int i = 0; i < NST; ++i) {
+            const int e = i * 256 + tid, pp = e >> 4, f4 = e & 15;
+            const int h = pp >= 100 ? 1 : 0, q = pp - 100 * h;
+            const int r = q / 10, c = q - 10 * r;
+            const int s_hi = (f4 >> 3) * 8 + ((f4 & 7) >> 1);                 // logical chunk of the hi halves: K step, group of 8 channels
+            sg_rel[i] = ((r - 1) * p.W + (c - 1)) * 256 + f4 * 16;
+            sg_rc[i] = pp < 200 ? ((r - 1) & 0xffff) | (((c - 1) & 0x3fff) << 16) | (h << 30) : (1 << 14);    // (row 16384: outside every map)
+            sg_dst[i] = pp < 200 ? h * DP_HALFB + q * 256 + ((s_hi ^ ((2 * c) & 15)) << 4) + (f4 & 1) * 8 : 2 * DP_HALFB + (tid & 63) * 16;   // (no element: the sink)
+        }
+    }
+    auto stage_load = [&](auto i_tag, const Blk &b, __amdgpu_buffer_rsrc_t rsX) {
+        constexpr int I = decltype(i_tag)::value;
+        int rc = sg_rc[I];
+        asm volatile("" : "+v"(rc));                           // (pinned to its region, as the requests)
+        const int m = -(rc >> 30);                             // -1: second half
+        const int by8 = (b.by8[1] & m) | (b.by8[0] & ~m), bx8 = (b.bx8[1] & m) | (b.bx8[0] & ~m), org = (b.org[1] & m) | (b.org[0] & ~m);
+        const int r = (rc << 16) >> 16, c = (rc << 2) >> 18;
+        const bool in = ((unsigned)(by8 + r) < (unsigned)p.H) & ((unsigned)(bx8 + c) < (unsigned)p.W);
+        stg[I] = __builtin_amdgcn_raw_buffer_load_b128(rsX, in ? org + sg_rel[I] : DP_OOB, 0, 0);
+    };
+    auto stage_split = [&](auto i_tag, char *npatch) {
+        constexpr int I = decltype(i_tag)::value;
+        u32x4 v = stg[I];
+        asm volatile("" : "+v"(v));
+        const float w0 = __uint_as_float(v.x) * sc, w1 = __uint_as_float(v.y) * sc, w2 = __uint_as_float(v.z) * sc, w3 = __uint_as_float(v.w) * sc;
+        const unsigned h01 = dp_pk(w0, w1), h23 = dp_pk(w2, w3);
+        const unsigned l01 = dp_pk(dp_fma_half<0>(h01, neg1, w0), dp_fma_half<1>(h01, neg1, w1));
+        const unsigned l23 = dp_pk(dp_fma_half<0>(h23, neg1, w2), dp_fma_half<1>(h23, neg1, w3));
+        char *d = npatch + sg_dst[I];
+        *(u32x2 *)d = (u32x2){h01, h23};
+        *(u32x2 *)(npatch + (sg_dst[I] ^ 64)) = (u32x2){l01, l23};      // (the lo halves: logical chunk + 4 = physical chunk ^ 4)
+    };
+
     // ---- the lane's output pixel of a block: half lh, column l7; offset of the block's row 0 from image img0, and how many of the 8 rows exist
     struct OutPx { int pix, rows; };
     auto out_px = [&](const Blk &b) {
@@ -309,7 +351,15 @@ __global__ __launch_bounds__(2048 / NRW, 1) void conv3x3_direct_p_kernel(ConvDir
         constexpr int COL = decltype(col_tag)::value, R = decltype(r_tag)::value;
         if constexpr (COL == 0 && R == 0) { co = out_px(cb); rsRc = rsrc_of(RES ? p.res : p.y, cb); rsXn = rsrc_of(p.x, nb); rsYe = rsrc_of(p.y, eb); }
         if constexpr (COL == 0 && R >= 1 && R <= NRW && !(DBG & 4)) res_load(R - 1, co, rsRc);
-        if constexpr (NRW == 8) {
+        if constexpr (NRW == 8 && XF32) {
+            // loads: column 0 rows 1..7 (two each: 13 + one repeat), splits: columns 1 / 2 rows 2..8 (13 of the 14 slots)
+            if constexpr (COL == 0 && R >= 1 && R <= 7) { stage_load(std::integral_constant<int, 2 * (R - 1)>{}, nb, rsXn); if constexpr (R < 7) stage_load(std::integral_constant<int, 2 * (R - 1) + 1>{}, nb, rsXn); }
+            if constexpr ((COL == 1 || COL == 2) && R >= 2 && R <= 8) { constexpr int I = 7 * (COL - 1) + (R - 2); if constexpr (I < 13) stage_split(std::integral_constant<int, I>{}, npatch); }
+            if constexpr (COL >= 3 && COL <= 5 && R >= 2 && R <= 7 && !(DBG & 1)) {
+                constexpr int piece = 6 * (COL - 3) + (R - 2);
+                if constexpr (piece < 16) { if constexpr ((piece & 1) == 0) epi_a(piece >> 1); else epi_b(piece >> 1, rsYe); }
+            }
+        } else if constexpr (NRW == 8) {
             if constexpr (COL == 0 && R >= 2 && R <= 7 && !(DBG & 2)) dma_issue(std::integral_constant<int, R - 2>{}, nb, rsXn, npatch);
             if constexpr (COL == 1 && R >= 2 && R <= 8 && !(DBG & 2)) dma_issue(std::integral_constant<int, R + 4>{}, nb, rsXn, npatch);
             if constexpr (COL >= 2 && COL <= 4 && R >= 2 && R <= 7 && !(DBG & 1)) {
@@ -395,6 +445,16 @@ __global__ __launch_bounds__(2048 / NRW, 1) void conv3x3_direct_p_kernel(ConvDir
     nb = make_blk((1 - n_mine) >> 31);
     eb = cb;
     rsXn = rsrc_of(p.x, cb);
+    if constexpr (XF32) {
+        stage_load(DP_C(0), cb, rsXn); stage_load(DP_C(1), cb, rsXn); stage_load(DP_C(2), cb, rsXn); stage_load(DP_C(3), cb, rsXn);
+        stage_load(DP_C(4), cb, rsXn); stage_load(DP_C(5), cb, rsXn); stage_load(DP_C(6), cb, rsXn); stage_load(DP_C(7), cb, rsXn);
+        stage_load(DP_C(8), cb, rsXn); stage_load(DP_C(9), cb, rsXn); stage_load(DP_C(10), cb, rsXn); stage_load(DP_C(11), cb, rsXn);
+        stage_load(DP_C(12), cb, rsXn);
+        stage_split(DP_C(0), dp_smem); stage_split(DP_C(1), dp_smem); stage_split(DP_C(2), dp_smem); stage_split(DP_C(3), dp_smem);
+        stage_split(DP_C(4), dp_smem); stage_split(DP_C(5), dp_smem); stage_split(DP_C(6), dp_smem); stage_split(DP_C(7), dp_smem);
+        stage_split(DP_C(8), dp_smem); stage_split(DP_C(9), dp_smem); stage_split(DP_C(10), dp_smem); stage_split(DP_C(11), dp_smem);
+        stage_split(DP_C(12), dp_smem);
+    } else {
     dma_issue(DP_C(0), cb, rsXn, dp_smem); dma_issue(DP_C(1), cb, rsXn, dp_smem); dma_issue(DP_C(2), cb, rsXn, dp_smem);
     dma_issue(DP_C(3), cb, rsXn, dp_smem); dma_issue(DP_C(4), cb, rsXn, dp_smem); dma_issue(DP_C(5), cb, rsXn, dp_smem);
     dma_issue(DP_C(6), cb, rsXn, dp_smem);
@@ -402,6 +462,7 @@ __global__ __launch_bounds__(2048 / NRW, 1) void conv3x3_direct_p_kernel(ConvDir
         dma_issue(DP_C(7), cb, rsXn, dp_smem); dma_issue(DP_C(8), cb, rsXn, dp_smem);
         dma_issue(DP_C(9), cb, rsXn, dp_smem); dma_issue(DP_C(10), cb, rsXn, dp_smem); dma_issue(DP_C(11), cb, rsXn, dp_smem);
         dma_issue(DP_C(12), cb, rsXn, dp_smem);
+    }
     }
 #pragma unroll
     for (int r = 0; r < NRW; ++r) { rres[r] = (u32x4)(0u); rnew[r] = (u32x4)(0u); eacc[r] = (f32x4)(0.0f); acc[r] = (f32x4)(0.0f); }
@@ -445,18 +506,20 @@ __global__ __launch_bounds__(2048 / NRW, 1) void conv3x3_direct_p_kernel(ConvDir
 }
 
 /* y = act(conv3x3(x, w) + bias (+ res)), stride 1, pad 1, Cin = Cout = 64, x a PAIR-FORMAT map [B,H,W,64] (conv_igemm.hip: 128 bytes
- * [hi 32 | lo 32] fp16 per pixel and 32-channel block, scaled by the power of two of its bound slot d_xbound).  d_w2r / inv_sw =
+ * [hi 32 | lo 32] fp16 per pixel and 32-channel block, scaled by the power of two of its bound slot d_xbound) or (x_pairs = 0, no
+ * shortcut) a float32 NHWC map scaled by the power of two of *d_amax_in and split while its patch is staged.  d_w2r / inv_sw =
  * `stem_direct_pair_weights(weight)`: [4 output-channel quarters][9 taps][2 K steps][hi | lo][64 lanes][8] halfs of s_w w.  d_res
  * (optional shortcut, y's shape): pair format with its bound slot (res_pairs) or float32 NHWC with d_res_bound = a bound of max |res|.
  * out_pairs: y leaves in pair format scaled for the bound max|x| wl1 + bmax (+ *d_res_bound), which goes to d_bound_out (d_amax_in =
  * the measured max |x|; wl1 = max_co sum |w[co]|, bmax = max |bias|); else y is float32 NHWC.  d_amax_out (optional, zeroed):
  * receives max |y|.  Same contract as cslam_conv_igemm_h2p_dev with x_pairs = 1, KH = KW = 3, stride = pad = 1. */
-CSLAM_API int cslam_conv3x3_direct_p_dev(const void *d_x, const unsigned *d_xbound, const void *d_w2r, const float *d_bias,
+CSLAM_API int cslam_conv3x3_direct_p_dev(const void *d_x, int x_pairs, const unsigned *d_xbound, const void *d_w2r, const float *d_bias,
                                          const void *d_res, int res_pairs, const unsigned *d_res_bound, int B, int H, int W, int Cin,
                                          int Cout, int relu, const unsigned *d_amax_in, float inv_sw, float wl1, float bmax,
                                          unsigned *d_amax_out, int out_pairs, unsigned *d_bound_out, void *d_y, void *stream) {
     PTR_DEVICE(d_x);
-    ARG_CHECK(d_x && d_xbound && d_w2r && d_y && d_amax_in, "NULL argument");
+    ARG_CHECK(d_x && (d_xbound || !x_pairs) && d_w2r && d_y && d_amax_in, "NULL argument");
+    ARG_CHECK(x_pairs || (!d_res && H < 16384), "a float32 input map goes without a shortcut");
     ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
     ARG_CHECK(Cin == 64 && Cout == 64, "Cin and Cout must be 64");
     ARG_CHECK(inv_sw > 0.0f, "inv_sw must be positive");
@@ -514,6 +577,18 @@ CSLAM_API int cslam_conv3x3_direct_p_dev(const void *d_x, const unsigned *d_xbou
 #undef DP_LAUNCH_D2
     }
 #endif
+    if (!x_pairs) {
+#define DP_LAUNCH_X(O_) do { \
+        static DeviceOnce once; int once_dev; \
+        if (once.todo(&once_dev)) { \
+            HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_direct_p_kernel<0, O_, 8, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DP_LDS(4))); \
+            once.done(once_dev); } \
+        hipLaunchKernelGGL((conv3x3_direct_p_kernel<0, O_, 8, 0, true>), dim3(grid), dim3(256), DP_LDS(4), st, a); } while (0)
+        if (out_pairs) DP_LAUNCH_X(true); else DP_LAUNCH_X(false);
+#undef DP_LAUNCH_X
+        HIP_TRY(hipGetLastError());
+        return CSLAM_OK;
+    }
     if (out_pairs) { if (rm == 0) DP_LAUNCH(0, true); else if (rm == 1) DP_LAUNCH(1, true); else DP_LAUNCH(2, true); }
     else { if (rm == 0) DP_LAUNCH(0, false); else if (rm == 1) DP_LAUNCH(1, false); else DP_LAUNCH(2, false); }
 #undef DP_LAUNCH

@@ -191,11 +191,11 @@ def conv_igemm_p(ws, act, Wg, bias, kernel, stride, pad, relu, res, wl1, bmax, a
 
 def conv3x3_direct_p(act, Wp, bias, relu, res, wl1, bmax, amax_out, bound_out, out_pairs):
     """`cslam_conv3x3_direct_p_dev` (csrc/conv_direct_p.hip): the 3x3 / stride 1 / pad 1 convolution 64 -> 64 between PairActs with the
-    weights register-resident and the patch by LDS-DMA.  act: pair format; res (or None): either format; Wp = `stem_direct_pair_weights
+    weights register-resident and the patch by LDS-DMA.  act: pair format, or (no shortcut) a float32 map split while it is staged; res (or None): either format; Wp = `stem_direct_pair_weights
     (weight)`; the other arguments and the result as `conv_igemm_p`."""
     lib = _lib.load()
     B, Cin, H, W = act.shape
-    assert act.pairs and Cin == 64
+    assert Cin == 64 and (act.pairs or (res is None and act.t.is_contiguous(memory_format=torch.channels_last)))
     dev = act.t.device
     if out_pairs:
         y = torch.empty((B, H, W, 2, 2, 32), dtype=torch.float16, device=dev)
@@ -204,7 +204,7 @@ def conv3x3_direct_p(act, Wp, bias, relu, res, wl1, bmax, amax_out, bound_out, o
     if res is not None:
         assert res.shape == (B, 64, H, W) and (res.pairs or res.t.is_contiguous(memory_format=torch.channels_last))
     _lib.check(lib.cslam_conv3x3_direct_p_dev(
-        _p(act.t), _p(act.bound), _p(Wp[0]), _p(bias) if bias is not None else None,
+        _p(act.t), int(act.pairs), _p(act.bound), _p(Wp[0]), _p(bias) if bias is not None else None,
         _p(res.t) if res is not None else None, int(res.pairs) if res is not None else 0,
         _p(res.bound) if res is not None else None, B, H, W, 64, 64, int(relu), _p(act.amax), float(Wp[1]), float(wl1), float(bmax),
         _p(amax_out), int(out_pairs), _p(bound_out) if out_pairs else None, _p(y), _stream(act.t)))
@@ -696,7 +696,7 @@ class WinogradResNet(_Workspace):
 
             def runp(conv, a, relu, res):
                 np_[0] += 2
-                if (conv.Wp is not None and a.pairs and conv is not last
+                if (conv.Wp is not None and (a.pairs or res is None) and conv is not last
                         and direct_p_fits(conv.weight.shape, conv.kernel, conv.stride[0], conv.padding[0], a.shape[2], a.shape[3])):
                     return conv3x3_direct_p(a, conv.Wp, conv.bias, relu, res, conv.wl1, conv.bmax, pslots[np_[0] - 2:np_[0] - 1],
                                             pslots[np_[0] - 1:np_[0]], True)

@@ -1352,6 +1352,18 @@ def test_register_resident_pair_convolution_equals_float64(T, B, hw):
     y1 = wg.pairs_to_float(a1)
     Wp, Wg2 = wg.stem_direct_pair_weights(w2), wg.igemm_pair_weights(w2)
     assert wg.direct_p_fits(w2.shape, (3, 3), 1, 1, H, W)
+    # the float32-input form (the layer that opens the pair-format chain: its patch is split while it is staged through registers)
+    sc1 = r1.abs().max().item()
+    e32 = (f1.double() - r1).abs().max().item() / sc1
+    for out_pairs in (True, False):
+        slots[9:].zero_()
+        a1d = wg.conv3x3_direct_p(a0, wg.stem_direct_pair_weights(w1), b1, True, None, wl1(w1), float(b1.abs().max()), slots[9:10], slots[10:11], out_pairs)
+        y1d = wg.pairs_to_float(a1d) if out_pairs else a1d.t
+        assert (y1d.double() - r1).abs().max().item() / sc1 <= 4 * e32 + 4e-7
+        assert (y1d - y1).abs().max().item() / sc1 <= 2e-6 and abs(slots[9].item() - sc1) <= 1e-5 * sc1
+        if out_pairs:
+            assert slots[10].item() == slots[2].item() and torch.equal(a1d.t, wg.conv3x3_direct_p(
+                a0, wg.stem_direct_pair_weights(w1), b1, True, None, wl1(w1), float(b1.abs().max()), slots[11:12], slots[10:11], True).t)
     res_forms = [None, a1, wg.PairAct(y1.contiguous(memory_format=torch.channels_last), False, y1.shape, slots[1:2], slots[1:2])]
     for res in res_forms:
         for relu in (True, False):

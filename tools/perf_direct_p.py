@@ -50,3 +50,20 @@ for res in (None, ap):
         mi, md = timed(igemm), timed(direct)
         print(f"shortcut {'pairs' if res is not None else 'none ':5s}  implicit GEMM {mi:7.3f} ms {fl / mi / 1e9:7.1f} TF   direct {md:7.3f} ms "
               f"{fl / md / 1e9:7.1f} TF   ({B} x {H} x {W}, max |diff| / max {d:.1e})", flush=True)
+
+# the float32-input layer that opens the chain (pooled stem output -> pairs)
+def igemm_f():
+    slots[7].zero_()
+    return wg.conv_igemm_p(ws, a0, Wg, bias, (3, 3), 1, 1, True, None, wl1, 0.1, slots[7:8], slots[8:9], True)
+
+
+def direct_f():
+    slots[9].zero_()
+    return wg.conv3x3_direct_p(a0, Wp, bias, True, None, wl1, 0.1, slots[9:10], slots[10:11], True)
+
+
+yi, yd = igemm_f(), direct_f()
+d = (wg.pairs_to_float(yi) - wg.pairs_to_float(yd)).abs().max().item() / wg.pairs_to_float(yi).abs().max().item()
+for rep in range(3):
+    mi, md = timed(igemm_f), timed(direct_f)
+    print(f"float32 input   implicit GEMM {mi:7.3f} ms {fl / mi / 1e9:7.1f} TF   direct {md:7.3f} ms {fl / md / 1e9:7.1f} TF   (max |diff| / max {d:.1e})", flush=True)
