@@ -112,17 +112,23 @@ __host__ __device__ __forceinline__ float ci_sub_half(float v, __half2 h) {     
 // at kernel row kh" are requested once per (slab, kh) and the taps read them at row offsets 0, 1, 2; what is wrong there -- the pixels
 // at a row's ends, whose neighbour in the flat order belongs to another row -- is masked in the A fragments (32 v_cndmask per step for
 // kw = 0 and 2).  A third of the activation requests (L2 -> LDS bytes -32 %).
+// KWS with 256-pixel tiles (AM = 2, 128 output channels: the stride-1 layers of ResNet's layer2 .. layer4): four waves along the pixels,
+// wave tile 64 x 128 = 8 accumulator tiles, ONE workgroup per compute unit with the whole register file.  A (slab, kernel row) block
+// of 258 rows and three weight blocks feed 3 x 48 MFMAs per wave: 0.66 of the 128-pixel form's L2 -> LDS bytes per product, half its
+// barriers per product (those bytes, not the matrix pipe, are what the board's power budget was being spent on: DESIGN.md section 8).
 template <int TM, int TN, int AM, bool KWS = false>
-__global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) {
+__global__ __launch_bounds__(256, (KWS && TM == 256) ? 1 : 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) {
     constexpr bool STEM = AM == 1, PAIRS = AM == 2;
-    static_assert(!KWS || ((AM == 2 || AM == 0) && TM == 128), "the shared-row form is written for 128-pixel tiles of the general forms");
-    constexpr int KA_ROWS = 136;                       // KWS: 130 rows of a (slab, kernel row) block, padded to whole 1 KB DMA pieces
-    constexpr int KA_BYTES = KA_ROWS * CI_ROWB;        // 17 408: two of them, then the two weight stages
+    static_assert(!KWS || ((AM == 2 || AM == 0) && TM == 128) || (AM == 2 && TM == 256), "the shared-row form: 128-pixel tiles of the general forms, 256-pixel tiles of the pair format");
+    constexpr int KA_ROWS = TM + 8;                    // KWS: TM + 2 rows of a (slab, kernel row) block, padded to whole 1 KB DMA pieces
+    constexpr int KA_BYTES = KA_ROWS * CI_ROWB;        // 17 408 / 33 792: two of them, then the two weight stages
+    constexpr int KA_NP = TM / 32 + 1;                 // its DMA pieces of 32 rows (the last: 8 rows, one wave's 1 KB)
     constexpr int NST = 2;                             // LDS stages
     constexpr int WM = TM / 64, WN = 4 / WM, TNW = TN / WN;
     constexpr int MT = 2, NT = TNW / 32;               // wave tile 64 x TNW in 32 x 32 MFMA tiles
     constexpr int NLA = TM * 8 / 256;                  // AM = 2: 16-byte activation chunks per thread and stage
     static_assert(TM == 128 || (TM == 256 && PAIRS), "the register-staged forms are written for 128-pixel tiles");
+    static_assert(!KWS || AM == 2 || TM == 128, "float32 input with shared rows: 128-pixel tiles");
     constexpr int OPA = TM * CI_ROWB, OPB = TN * CI_ROWB;
     constexpr int STAGE = OPA + OPB;
     constexpr int NLB = TN * 8 / 256;                  // 16-byte weight chunks per thread and stage
@@ -262,13 +268,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
     };
 
     // ---- KWS: LDS row R = i * 32 + (tid >> 3) (i = 0..4, rows 130.. read nothing) holds centre pixel first - 1 + R at kernel row kh
-    int ka_off[KWS ? 5 : 1], ka_h[KWS ? 5 : 1];
+    int ka_off[KWS ? KA_NP : 1], ka_h[KWS ? KA_NP : 1];
     if (KWS) {
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < KA_NP; ++i) {
             const int R = i * 32 + (tid >> 3);
             const int64_t pc = (int64_t)mt * TM - 1 + R;
-            const bool ok = R < 130 && pc >= 0 && pc < p.P;
+            const bool ok = R < TM + 2 && pc >= 0 && pc < p.P;
             const int hw = p.Ho * p.Wo;
             const int pp = ok ? (int)pc : 0;
             const int bb = pp / hw, rem = pp - bb * hw;
@@ -280,8 +286,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
     auto ka_dma = [&](int abuf, int kh, int cb, int i0, int i1) {       // pieces i0 .. i1 - 1 of the block (spread over the three steps)
         const int rowoff = kh * p.W * (p.Cin * 4);
 #pragma unroll
-        for (int i = 0; i < (KWS ? 5 : 0); ++i) {
-            if (i < i0 || i >= i1 || (i == 4 && wave != 0)) continue;      // (piece 4 = rows 128..135: one wave's 1 KB; the buffer ends there)
+        for (int i = 0; i < (KWS ? KA_NP : 0); ++i) {
+            if (i < i0 || i >= i1 || (i == KA_NP - 1 && wave != 0)) continue;      // (the last piece = rows TM .. TM + 7: one wave's 1 KB; the buffer ends there)
             const bool in = (unsigned)(ka_h[i] + kh) < (unsigned)p.H;
             ci_blds16(rsX, in ? ka_off[i] + rowoff : 0x7fffffff, cb * 128, smem + abuf * KA_BYTES + i * (256 * 16) + wave * 1024);
         }
@@ -505,7 +511,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
         const int ngrp = p.ncb * 3;                                        // (slab, kernel row) groups, three steps (kw) each
         // group G = cb * 3 + kh -> activation buffer G & 1; step k = 3 G + kw -> weight buffer k & 1
         if (AM == 0) { kf_load(0, 0); b_load(0, 0); kf_store(0); }
-        else { ka_dma(0, 0, 0, 0, 5); b_load(0, 0); }
+        else { ka_dma(0, 0, 0, 0, KA_NP); b_load(0, 0); }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_s_barrier();
         int gkh = 0, gcb = 0;                                              // the group being multiplied
@@ -523,7 +529,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
                     if (k + 1 < p.nk) b_load((k + 1) & 1, k + 1);
                     if (kw == 0 && moreG) kf_load(nkh, ncb_);
                 } else {
-                    if (moreG) ka_dma((G + 1) & 1, nkh, ncb_, kw == 0 ? 0 : (kw == 1 ? 2 : 4), kw == 0 ? 2 : (kw == 1 ? 4 : 5));
+                    if (moreG) ka_dma((G + 1) & 1, nkh, ncb_, kw == 0 ? 0 : (kw == 1 ? KA_NP / 3 + (KA_NP % 3 ? 1 : 0) : 2 * (KA_NP / 3) + (KA_NP % 3)),
+                                      kw == 0 ? KA_NP / 3 + (KA_NP % 3 ? 1 : 0) : (kw == 1 ? 2 * (KA_NP / 3) + (KA_NP % 3) : KA_NP));
                     if (k + 1 < p.nk) b_load((k + 1) & 1, k + 1);
                 }
                 // fragments of tap kw: activation rows shifted by kw, the chunk swizzle follows the physical row
@@ -769,6 +776,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_h2_kernel(ConvIgemmArgs p) 
 #define CI_KW_SHARING (!getenv("CSLAM_CI_KWS_OFF"))     // measurement build: A/B partner of the shared-row form
 #else
 #define CI_KW_SHARING true
+#endif
+#ifdef CSLAM_ABLATIONS
+#define CI_TM256 (getenv("CSLAM_CI_TM256") != nullptr)  // measurement build only: the 256-pixel shared-row tiles (measured slower, below)
+#else
+#define CI_TM256 false
 #endif
 #ifdef CSLAM_ABLATIONS
 #define CI_STEM_PATCH_FORM (!getenv("CSLAM_SP_OFF"))   // measurement build: the implicit-GEMM pooled form as the A/B partner
@@ -1036,13 +1048,18 @@ static int conv_igemm_launch(const float *d_x, const void *d_w2, const float *d_
     // three taps, one activation block: the pair-format layers, and the float32-input layer that opens the pair-format chain (the plain
     // float32 entry keeps its K order: its tests pin that rounding)
     const bool kws = CI_KW_SHARING && (am == 2 || (am == 0 && f.out_pairs)) && KH == 3 && KW == 3 && stride == 1 && pad == 1;
-    const int tm = am == 2 && tn == 64 && !kws ? 256 : 128;                                         // (64-channel layers: 128 x 64 tiles with the shared
-                                                                                                    // rows, three per CU, +0.7 % over 256 x 64 without)
+    // 256-pixel tiles: 64-channel layers without shared rows (the shared-row 128 x 64 form, three per CU, is +0.7 % over it).  For the
+    // pair-format 128-channel-tile layers with shared rows (one workgroup per CU, 8 accumulator tiles per wave, 0.66 of the L2 -> LDS
+    // bytes per product) they were measured and lost: layer2 0.73 against 0.69 ms, layer3 0.67 / 0.63, layer4 0.62 / 0.60, C2 75k
+    // against 82k keyframes/s (profiles/r06_f_igemm_tm256_rejected.log) -- a lone workgroup has nobody to overlap its request phase
+    // with.  The form stays in the measurement build (CSLAM_CI_TM256=1).
+    const bool big = kws && am == 2 && tn == 128 && CI_TM256 && P >= 256ll * 64;
+    const int tm = big || (am == 2 && tn == 64 && !kws) ? 256 : 128;
     a.n_mt = (int)ceil_div64(P, tm); a.ntb = Cout / tn;                                      // (pooled form: P / 128 tiles exactly)
     a.nx = cslam_cu_count() % 8 == 0 ? 8 : 1;
     a.mt_per_x = (int)ceil_div64(a.n_mt, a.nx);
     const dim3 grid((unsigned)((int64_t)a.mt_per_x * a.nx * a.ntb)), blk(256);
-    const int lds = kws ? 2 * 136 * CI_ROWB + 2 * tn * CI_ROWB : 2 * (tm + tn) * CI_ROWB;   // >= 128 x tn floats, the pooled form's tile
+    const int lds = kws ? 2 * (tm + 8) * CI_ROWB + 2 * tn * CI_ROWB : 2 * (tm + tn) * CI_ROWB;   // >= 128 x tn floats, the pooled form's tile
     hipStream_t st = (hipStream_t)stream;
     const bool patch_form = CI_STEM_PATCH_FORM && pool && Cout == 64 && KH == 7 && KW == 7 && stride == 2 && pad == 3 && (int64_t)H * W * 12 < 0x7fffffffll;
     if (pool) {
@@ -1087,6 +1104,9 @@ static int conv_igemm_launch(const float *d_x, const void *d_w2, const float *d_
             once.done(once_dev); } \
         hipLaunchKernelGGL((conv_igemm_h2_kernel<TM_, TN_, AM_, true>), grid, blk, lds, st, a); } while (0)
     if (stem) { if (tn == 128) CI_LAUNCH(128, 128, 1); else CI_LAUNCH(128, 64, 1); }
+#ifdef CSLAM_ABLATIONS
+    else if (f.x_pairs && kws && big) CI_LAUNCH_K(256, 128, 2);
+#endif
     else if (f.x_pairs && kws) { if (tn == 128) CI_LAUNCH_K(128, 128, 2); else CI_LAUNCH_K(128, 64, 2); }
     else if (kws) { if (tn == 128) CI_LAUNCH_K(128, 128, 0); else CI_LAUNCH_K(128, 64, 0); }
     else if (f.x_pairs) { if (tn == 128) CI_LAUNCH(128, 128, 2); else CI_LAUNCH(256, 64, 2); }

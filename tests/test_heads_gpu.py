@@ -1261,14 +1261,17 @@ def test_implicit_gemm_convolution_on_fp16_pairs_equals_float64(T, B, cin, cout,
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("B,c0,c1,hw,k2,stride2", [(3, 64, 64, (20, 24), 3, 1), (2, 64, 128, (19, 13), 3, 2), (5, 128, 256, (14, 14), 1, 2),
-                                                   (1, 256, 512, (7, 7), 3, 1), (3, 128, 128, (13, 9), 3, 1), (2, 128, 256, (5, 130), 3, 1)])
+                                                   (1, 256, 512, (7, 7), 3, 1), (3, 128, 128, (13, 9), 3, 1), (2, 128, 256, (5, 130), 3, 1),
+                                                   (24, 128, 128, (28, 28), 3, 1), (21, 128, 256, (29, 27), 3, 1), (350, 256, 256, (7, 7), 3, 1)])
 def test_pair_format_activations_between_implicit_gemm_layers(T, B, c0, c1, hw, k2, stride2):
     """`cslam_conv_igemm_h2p_dev`: float32 map -> conv (pair-format output) -> conv reading the pairs by LDS-DMA, with a pair-format and
     with a float32 shortcut, pair-format and float32 output.  Every result against the same chain in float64, no further from it than 4 x
     torch's float32 chain (+ 4e-7 of the scale): the bound-derived scale costs nothing visible; the measured max |y| and the bound slots
     are right; ragged pixel tiles, zero padding, strides.  The 3x3 / stride-1 second layers with 128-channel tiles run the shared-row form
     (one activation block for the three taps of a kernel row, row-end pixels masked in the fragments): maps of 7 x 7, 13 x 9 (rows
-    shorter than a tile, tiles across images) and 5 x 130 (a row longer than a tile), with and without the shortcut."""
+    shorter than a tile, tiles across images) and 5 x 130 (a row longer than a tile), with and without the shortcut.  From 16 384 output
+    pixels on those layers take 256-pixel tiles (one workgroup per CU, 258-row blocks): 24 x 28 x 28, 21 x 29 x 27 (ragged last tile, rows
+    that straddle tiles) and 350 x 7 x 7 (five images per tile)."""
     torch, _ = T
     from cslam_amd.vpr import winograd as wg
     torch.manual_seed(c0 * 7 + c1 + k2)
