@@ -44,6 +44,32 @@ HBM_PEAK_GBS = 8000.0              # same guide: HBM3E ~8 TB/s
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_by_kernel.json")
 
 
+def vgg16_flop_per_frame(hw=224):
+    """(fp16 MFMA flop ISSUED, direct-convolution-equivalent flop) of the VGG-16 trunk NetVLAD runs (conv1_1 .. conv5_3, cslam/vpr/
+    netvlad.py:163-171) per frame of hw x hw, in the forms DESIGN.md section 3.6 lists: conv1_1 .. conv2_2 direct on fp16 pairs
+    (3 MFMA products per multiply-add; conv1_1's K = 27 padded to 32 and computed on the 10 x 18 patch of every 8 x 16 block),
+    conv3_1 .. conv5_3 F(4x4, 3x3) Winograd (36 products per 4 x 4-pixel tile instead of 144, 3 MFMA products each)."""
+    layers = [(3, 64), (64, 64), "pool", (64, 128), (128, 128), "pool", (128, 256), (256, 256), (256, 256), "pool",
+              (256, 512), (512, 512), (512, 512), "pool", (512, 512), (512, 512), (512, 512)]
+    issued = direct = 0.0
+    n = 0
+    for l in layers:
+        if l == "pool":
+            hw //= 2
+            continue
+        cin, cout = l
+        n += 1
+        direct += 2.0 * hw * hw * 9 * cin * cout
+        if cin == 3:
+            issued += (180.0 / 128.0) * 3 * 2.0 * hw * hw * 32 * cout
+        elif n <= 4:
+            issued += 3 * 2.0 * hw * hw * 9 * cin * cout
+        else:
+            t = (-(-hw // 4)) ** 2
+            issued += 3 * 2.0 * 36 * t * cin * cout
+    return issued, direct
+
+
 def pmc_entry(kernel, **match):
     """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_by_kernel.json,
     keyed by kernel name -- no globbing), only if the entry was collected on exactly the launch timed here."""
@@ -530,7 +556,11 @@ def main():
     mm_peak = FP16_MFMA_PEAK_TFLOPS / n_prod if pair_stage else FP32_MFMA_PEAK_TFLOPS
     mm_unit = ("TFLOP/s (2*D flop per query-row pair; %d fp16 MFMA product%s per pair: peak = 2500 / %d)"
                % (n_prod, "" if n_prod == 1 else "s", n_prod) if pair_stage else "TFLOP/s")
-    mm_kernel = "sim_topk_ring_kernel" if pair_stage else "sim_topk_mfma_kernel"
+    # the persistent ring kernel runs the one-product stage from 257 queries on; smaller launches, the three-product stage and a bank
+    # that backed off (clustered descriptors) run sim_topk_pair_kernel / sim_topk_mfma_kernel: name what the bank reports
+    last_prod = nn.last_stage()[0]
+    mm_kernel = ("sim_topk_mfma_kernel" if (not pair_stage or last_prod == 0) else
+                 ("sim_topk_ring_kernel" if n_prod == 1 and min(nqm, a.batch) >= 257 else "sim_topk_pair_kernel"))
     peaks = measure_peaks(torch, dev) if rank == 0 else None
 
     def match_roofline(nq_launch, ms, source, pmc_queries):
@@ -863,6 +893,7 @@ def main():
         r3 = pend.finish()
         torch.cuda.synchronize()
         tp = time.perf_counter() - t0
+        c2_stage, c2_unc = nn3.last_stage(), int(nn3.last_stats()[0])
         GF = 3.64                                                 # ResNet-18 trunk at 224 x 224: 1.82 G multiply-adds per frame
         fps = done2 / te2
         c2 = {"workload": "C2: CosPlace ResNet-18 512-D extract + causal top-%d, %d synthetic 640x480 keyframes in chunks of %d, "
@@ -871,7 +902,10 @@ def main():
               "match_only": round(done2 / tm2, 1), "value_serial": round(done2 / (te2 + tm2), 1),
               "serial_note": "extract_only / match_only / value_serial: %d chunks with a host synchronisation between the legs" % nchunks,
               "dtype": "f32",
-              "roofline": {"bound": "mfma", "kernel": "conv_igemm_h2_kernel (+ conv_stem_pool_patch_kernel: the 7x7 stem with its max-pool): every trunk layer as an implicit "
+              "match_stage": {"fp16_products_of_last_search": c2_stage[0], "searches_left_on_f32_stage": c2_stage[1], "uncertified_queries_last_search": c2_unc,
+                              "note": "0 products = the f32-input candidate stage: random-init CosPlace descriptors cluster, the bank backs off from the "
+                                      "fp16 stage (results stay exact: float64 re-score + certificate); match_only here says nothing about the fp16 stage on 512-D"},
+              "roofline": {"bound": "mfma", "kernel": "conv3x3_direct_p_kernel (layer1: register-resident weights, csrc/conv_direct_p.hip) + conv_igemm_h2_kernel (+ conv_stem_pool_patch_kernel: the 7x7 stem with its max-pool): every trunk layer as an implicit "
                                                         "GEMM over exact fp16 hi/lo pairs of activations and weights, 3 fp16 products per "
                                                         "multiply-add (csrc/conv_igemm.hip; per-layer times: tools/perf_conv_igemm.py, DESIGN.md 3.6d)",
                            "achieved": round(fps * GF * 3 / 1e3, 1), "peak": FP16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (fp16, 3 products)",
@@ -895,6 +929,9 @@ def main():
                                  False, None, 1.0, 0.0, sl[1:2], sl[2:3], True)
             Wl, wl1 = wg.igemm_pair_weights(wl), float(wl.abs().sum(dim=(1, 2, 3)).max())
             run_l = lambda: wg.conv_igemm_p(ws_l, ap, Wl, None, (3, 3), 1, 1, True, None, wl1, 0.0, sl[3:4], sl[4:5], True)   # noqa: E731
+            if cch == 64 and wg.DIRECT_P:                 # layer1: the register-resident direct kernel (csrc/conv_direct_p.hip), the trunk's default
+                Wp_l = wg.stem_direct_pair_weights(wl)
+                run_l = lambda: wg.conv3x3_direct_p(ap, Wp_l, None, True, None, wl1, 0.0, sl[3:4], sl[4:5], True)   # noqa: E731
             run_l()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -904,15 +941,16 @@ def main():
             torch.cuda.synchronize()
             ms_l = e0.elapsed_time(e1) / 10
             fl_l = 2.0 * 3 * ch * hw_l * hw_l * cch * 9 * cch
-            lay[lname] = {"kernel_ms": round(ms_l, 4), "achieved": round(fl_l / ms_l / 1e9, 1),
+            lay[lname] = {"kernel": "conv3x3_direct_p_kernel" if (cch == 64 and wg.DIRECT_P) else "conv_igemm_h2_kernel",
+                          "kernel_ms": round(ms_l, 4), "achieved": round(fl_l / ms_l / 1e9, 1),
                           "frac": round(fl_l / ms_l / 1e9 / FP16_MFMA_PEAK_TFLOPS, 4)}
-            pe = pmc_entry("conv_igemm_h2_kernel/" + lname.split()[0]) if ch == 1000 else None     # (collected at 1000 frames)
+            pe = pmc_entry(lay[lname]["kernel"] + "/" + lname.split()[0]) if ch == 1000 else None     # (collected at 1000 frames)
             if pe:
                 lay[lname].update({"traffic": pe["traffic_bytes"], "algorithmic_bytes": pe["algorithmic_min_bytes"],
                                    "l2_hit_rate_pmc": round(pe["l2_hit_rate"], 3), "matrix_pipe_busy_pmc": round(pe["mfma_busy_frac"], 3),
                                    "effective_clock_GHz_pmc": round(pe["effective_clock_GHz"], 2), "traffic_source": pe["source"]})
             del xl, ap
-        c2["roofline"]["layers"] = {"kernel": "conv_igemm_h2_kernel (pair-format input and output), %d frames" % ch,
+        c2["roofline"]["layers"] = {"kernel": "the stride-1 3x3 layer of each stage alone, pair-format input and output, %d frames" % ch,
                                     "unit": "TFLOP/s (fp16, 3 products)", "peak": FP16_MFMA_PEAK_TFLOPS, **lay}
         if not a.no_cpu_baseline:
             ncf = max(1, min(a.cpu_frames, 8))
@@ -930,6 +968,38 @@ def main():
                                             "224 x 224 input; transform, GeM + FC and the scan not included (they are < 2 %% of it)" % ncf}
         del cp, nn2
 
+    roofline_step = None
+    if rank == 0 and extractor is not None:
+        # The WHOLE timed step priced once: fp16 MFMA flop issued by everything in it (the trunk's layer table, the PCA projection on
+        # fp16 pairs, the candidate stage's one product) / ms_per_step / the nominal dense fp16 peak, with the step's fabric-side bytes
+        # (committed PMC pass of the extract: 48.2 GB per 256 frames) beside it.  `roofline` above is the kernel north_star names: 1.4 %
+        # of this step.
+        f_iss, f_dir = vgg16_flop_per_frame(224)
+        pca_iss = 3 * 2.0 * 32768 * a.dim                       # 32768 -> dim projection, three products
+        match_iss = 2.0 * nq_step * local_rows * a.dim * max(n_prod, 1) / world
+        step_s = dt / a.steps
+        iss_step = a.batch * (f_iss + pca_iss) + match_iss
+        ext_bytes = 48.2e9 / 256.0 * a.batch
+        loaded = peaks.get("mfma_f16_loaded_TFLOPs") if peaks else None
+        roofline_step = {
+            "bound": "mfma", "what": "every kernel of one timed step (extract of %d frames + match), per GPU" % a.batch,
+            "fp16_flop_issued_per_step": iss_step, "achieved": round(iss_step / step_s / 1e12, 1), "peak": FP16_MFMA_PEAK_TFLOPS,
+            "unit": "TFLOP/s (fp16 MFMA flop issued: 3 products per fp32-grade multiply-add, Winograd layers at their 36 / 144)",
+            "frac": round(iss_step / step_s / 1e12 / FP16_MFMA_PEAK_TFLOPS, 4),
+            "direct_conv_equivalent": {"flop_per_frame": f_dir, "achieved_TFLOPs": round(a.batch * f_dir / step_s / 1e12, 1),
+                                       "frac": round(a.batch * f_dir / step_s / 1e12 / FP16_MFMA_PEAK_TFLOPS, 4),
+                                       "note": "BASELINE.md section 4 prices C3's extract this way (30.7 GFLOP per frame against 2.5 PF = 81k frames/s)"},
+            "traffic": ext_bytes, "traffic_source": "profiles/r04_v60_extract_kernels.txt / pmc_by_kernel.json: 48.2 GB of fabric-side bytes per 256-frame extract pass "
+                                                    "(V + M round trips of the nine Winograd layers: 41 GB), scaled to the step's frames; the match adds 1.3 GB",
+            "traffic_GBs": round(ext_bytes / step_s / 1e9, 1),
+            "fp32_grade_ceiling": {
+                "keyframes_per_sec": None if not loaded else round(loaded * 1e12 / (f_iss + pca_iss), 1),
+                "note": "what one MI355X could extract if EVERY issued flop ran at the rate the register-resident fp16 loop reaches with non-zero "
+                        "operands under the board's power cap (peaks_measured.mfma_f16_loaded_TFLOPs) and nothing else cost time or energy: "
+                        "north_star's 100k keyframes/s on C3 is above this ceiling at fp32-grade arithmetic (three fp16 products per multiply-add); "
+                        "BASELINE.md section 4 said so up front (81k at ONE product per multiply-add and the nominal peak)"},
+            "power_floor_note": "the step's matrix-bound kernels run the board AT its 1400 W cap (board.power_W; profiles/r06_d_power_*.json: 1399 W at 1.87 GHz "
+                                "for ResNet layer1's kernel, whose time equals (0.63 pJ per issued flop + ~130 pJ per fabric byte) / (cap - idle)): DESIGN.md section 8"}
     if rank == 0:
         line = {
             "metric": "keyframes/sec (extract+match) on 100kx4096-D bank",
@@ -938,6 +1008,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if bdt is None else "bf16 backbone / f32 heads+match",
             "data": "synthetic (seeded on-device uint8 640x480 frames, unit-norm Gaussian bank, random-init "
                     "VGG-16/VLAD/PCA weights: the reference ships no checkpoints)",
+            "note": "north_star's 100k keyframes/s is above what one MI355X can extract on C3 at fp32-grade arithmetic: roofline_step.fp32_grade_ceiling "
+                    "(c2_cosplace is the configuration where it is arithmetically within reach)",
             "config": {"workload": "C3: NetVLAD VGG-16 4096-D extract + D.D^T MFMA similarity + top-5, "
                                    f"{a.bank_rows}-row bank" + (" per GPU" if not rows_mode else "") + ("" if extractor else " [match leg only]"),
                        "bank_rows": a.bank_rows, "dim": a.dim, "keyframes_per_rank_per_step": a.batch, "k": a.k,
@@ -967,6 +1039,7 @@ def main():
             "match_only_queries": nqm,
             "uncertified_queries": int(uncertified),
             "roofline": roofline,
+            "roofline_step": roofline_step,
             "roofline_c3_batch": roofline_c3,
             "roofline_step_largest": roofline_step_largest,
             "roofline_extract": extract_roofline,
