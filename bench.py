@@ -998,8 +998,9 @@ def main():
                         "operands under the board's power cap (peaks_measured.mfma_f16_loaded_TFLOPs) and nothing else cost time or energy: "
                         "north_star's 100k keyframes/s on C3 is above this ceiling at fp32-grade arithmetic (three fp16 products per multiply-add); "
                         "BASELINE.md section 4 said so up front (81k at ONE product per multiply-add and the nominal peak)"},
-            "power_floor_note": "the step's matrix-bound kernels run the board AT its 1400 W cap (board.power_W; profiles/r06_d_power_*.json: 1399 W at 1.87 GHz "
-                                "for ResNet layer1's kernel, whose time equals (0.63 pJ per issued flop + ~130 pJ per fabric byte) / (cap - idle)): DESIGN.md section 8"}
+            "power_note": "board.power_W / sclk_MHz are the sensors over these timed steps.  One matrix-bound kernel at a time runs the board at its cap "
+                          "(profiles/r06_d_power_dp.json: ResNet layer1's kernel 1399 W of 1400 at 1.87 GHz; its matrix work alone 1315 W at 2.0 GHz), so its time "
+                          "is its energy / the cap; a whole VGG pass, with its HBM-bound transforms and launch tails, averages below the cap: DESIGN.md section 8"}
     if rank == 0:
         line = {
             "metric": "keyframes/sec (extract+match) on 100kx4096-D bank",
