@@ -36,6 +36,7 @@ struct ConvDirectRArgs {
     int B, H, W, gxb, gyb, nblk;
     int relu;
     const unsigned *amax_in; float inv_sw; unsigned *amax_out;
+    float wl1, bmax; unsigned *bound_out;          // OUTP: y leaves in pair format (conv_igemm.hip), scaled for the bound max|x| wl1 + bmax
 };
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t dr_rsrc(const char *base, int64_t bytes) {
@@ -73,8 +74,16 @@ __device__ __forceinline__ float dr_max_xor1(float v) {                   // max
 }
 
 // DBG (builds with -DCSLAM_ABLATIONS only; WRONG results, timing): 1 = no patch staging inside the loop, 4 = no stores
-template <bool POOL, bool RELU, int DBG = 0>
+// OUTP (no pooling): y is written in the PAIR FORMAT of conv_igemm.hip -- [pixel][32-channel block][hi 32 | lo 32] fp16 of s y, s the
+// power of two that brings the bound max|x| wl1 + bmax (stored to bound_out) into [2^13, 2^14) -- so that the next layer (conv2_2,
+// conv_direct_h.hip) stages its patch without converting anything (0.34 of its 2.5 ms were the split's vector instructions)
+typedef _Float16 dr_f16x2 __attribute__((ext_vector_type(2)));
+template <int HI>
+__device__ __forceinline__ float dr_fma_half(unsigned hb, float s, float v) { return __builtin_fmaf((float)__builtin_bit_cast(dr_f16x2, hb)[HI], s, v); }
+__device__ __forceinline__ unsigned dr_pk(float a, float b) { const __half2 h = __floats2half2_rn(a, b); return *(const unsigned *)&h; }
+template <bool POOL, bool RELU, int DBG = 0, bool OUTP = false>
 __global__ __launch_bounds__(256, 1) void conv3x3_direct_r_kernel(ConvDirectRArgs p) {
+    static_assert(!(POOL && OUTP), "the pair-format output is written un-pooled");
     extern __shared__ __attribute__((aligned(16))) char dr_smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -87,6 +96,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_r_kernel(ConvDirectRArg
     (void)frexpf(32752.0f / amax, &e_);
     const float sx = ldexpf(1.0f, e_ - 1);
     const float inv = p.inv_sw / sx;
+    float s_out = 1.0f, neg1 = -1.0f;
+    asm volatile("" : "+v"(neg1));                             // (a run-time -1: conv_direct_p.hip)
+    if (OUTP) {
+        const float bound = (amax * p.wl1 + p.bmax) * 1.001f;  // >= max |y| whatever the rounding of the products
+        int eo;
+        (void)frexpf(fminf(fmaxf(bound, 1e-30f), 1e30f), &eo);
+        s_out = ldexpf(1.0f, 14 - eo);                         // conv_igemm.hip::ci_scale
+        if (blockIdx.x == 0 && threadIdx.x == 0) *p.bound_out = __float_as_uint(bound);
+    }
 
     // blocks to workgroups by XCD (contiguous eighths: the halo neighbours share goes through one L2)
     const bool by_xcd = (gridDim.x & 7) == 0;
@@ -221,10 +239,22 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_r_kernel(ConvDirectRArg
             float m = dr_max(dr_max(fabsf(v.x), fabsf(v.y)), dr_max(fabsf(v.z), fabsf(v.w)));
             asm volatile("" : "+v"(m), "+v"(off));             // (both computed by every lane: no branch around them)
             my_amax = dr_max(my_amax, store ? m : 0.0f);
+            if (OUTP) {
+                // the lane's four channels 32 wave + 16 mt + 4 gq .. + 3 of the pixel: block `wave`, hi run at its halfs 16 mt + 4 gq, lo run 64 bytes on
+                const float u0 = v.x * s_out, u1 = v.y * s_out, u2 = v.z * s_out, u3 = v.w * s_out;
+                const unsigned h01 = dr_pk(u0, u1), h23 = dr_pk(u2, u3);
+                const unsigned l01 = dr_pk(dr_fma_half<0>(h01, neg1, u0), dr_fma_half<1>(h01, neg1, u1));
+                const unsigned l23 = dr_pk(dr_fma_half<0>(h23, neg1, u2), dr_fma_half<1>(h23, neg1, u3));
+                const int offp = store ? off - ch_off + wave * 128 + (16 * mt + 4 * gq) * 2 : 0x7fffffff;
+                typedef unsigned dr_u32x2 __attribute__((ext_vector_type(2)));
+                __builtin_amdgcn_raw_buffer_store_b64((dr_u32x2){h01, h23}, rsY, offp, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64((dr_u32x2){l01, l23}, rsY, offp, 64, 0);
+            } else {
             u32x4 bits;
             bits.x = __float_as_uint(v.x); bits.y = __float_as_uint(v.y); bits.z = __float_as_uint(v.z); bits.w = __float_as_uint(v.w);
             if (!(DBG & 4)) __builtin_amdgcn_raw_buffer_store_b128(bits, rsY, store ? off : 0x7fffffff, 0, 0);
             else asm volatile("" :: "v"(bits));
+            }
         }
     };
 
@@ -317,10 +347,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_r_kernel(ConvDirectRArg
 /* y = [pool](relu(conv3x3(x, w) + bias)), Cin = 64, Cout = 128; x, y NHWC float32.  d_w2r = `direct_r_pair_weights` (vpr/winograd.py):
  * [4 output-channel quarters][9 taps][2 K steps][2 channel tiles][hi | lo][64 lanes][8] halfs of s_w w, inv_sw = 1 / s_w; d_amax = 4-byte
  * slot holding (a bound of) max |x|; d_amax_out (or NULL): zeroed slot that receives max |y|. */
-CSLAM_API int cslam_conv3x3_direct_r_dev(const float *d_x, const void *d_w2r, const float *d_bias, int B, int H, int W, int Cin,
-                                         int Cout, int relu, int pool, const unsigned *d_amax, float inv_sw,
-                                         unsigned *d_amax_out, float *d_y, void *stream) {
+static int conv_direct_r_launch(const float *d_x, const void *d_w2r, const float *d_bias, int B, int H, int W, int Cin,
+                                int Cout, int relu, int pool, const unsigned *d_amax, float inv_sw,
+                                unsigned *d_amax_out, float *d_y, void *stream, int out_pairs, float wl1, float bmax, unsigned *d_bound_out) {
     PTR_DEVICE(d_x);
+    ARG_CHECK(!out_pairs || (!pool && relu && d_bound_out && wl1 >= 0.0f && bmax >= 0.0f), "pair-format output: ReLU, no pooling, wl1, bmax and the bound slot");
     ARG_CHECK(d_x && d_w2r && d_y && d_amax, "NULL argument");
     ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
     ARG_CHECK(Cin == 64 && Cout == 128, "Cin must be 64 and Cout 128");
@@ -335,10 +366,20 @@ CSLAM_API int cslam_conv3x3_direct_r_dev(const float *d_x, const void *d_w2r, co
     ARG_CHECK(nblk < (1ll << 30), "too many blocks for one launch");
     a.nblk = (int)nblk;
     a.relu = relu; a.amax_in = d_amax; a.inv_sw = inv_sw; a.amax_out = d_amax_out;
+    a.wl1 = wl1; a.bmax = bmax; a.bound_out = d_bound_out;
     const int n_cu = cslam_cu_count();
     ARG_CHECK(n_cu > 0, "no HIP device");
     const int grid = (int)(nblk < n_cu ? nblk : n_cu);
     hipStream_t st = (hipStream_t)stream;
+    if (out_pairs) {
+        static DeviceOnce once_p; int once_dev_p;
+        if (once_p.todo(&once_dev_p)) {
+            HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_direct_r_kernel<false, true, 0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, DR_LDS));
+            once_p.done(once_dev_p); }
+        hipLaunchKernelGGL((conv3x3_direct_r_kernel<false, true, 0, true>), dim3(grid), dim3(256), DR_LDS, st, a);
+        HIP_TRY(hipGetLastError());
+        return CSLAM_OK;
+    }
 #define DR_LAUNCH(P, R) do { \
         static DeviceOnce once; int once_dev; \
         if (once.todo(&once_dev)) { \
@@ -363,4 +404,18 @@ CSLAM_API int cslam_conv3x3_direct_r_dev(const float *d_x, const void *d_w2r, co
 #undef DR_LAUNCH
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
+}
+CSLAM_API int cslam_conv3x3_direct_r_dev(const float *d_x, const void *d_w2r, const float *d_bias, int B, int H, int W, int Cin,
+                                         int Cout, int relu, int pool, const unsigned *d_amax, float inv_sw,
+                                         unsigned *d_amax_out, float *d_y, void *stream) {
+    return conv_direct_r_launch(d_x, d_w2r, d_bias, B, H, W, Cin, Cout, relu, pool, d_amax, inv_sw, d_amax_out, d_y, stream, 0, 0.0f, 0.0f, nullptr);
+}
+/* The same convolution (64 -> 128 channels, + bias + ReLU, no pooling) with y written in the PAIR FORMAT of cslam_conv_igemm_h2p_dev:
+ * [B,H,W,4 blocks][hi 32 | lo 32] fp16 of s y, s the power of two of the bound *d_amax wl1 + bmax, which goes to d_bound_out (wl1 = max_co
+ * sum |w[co]|, bmax = max |bias|); d_amax_out (optional, zeroed) receives the measured max |y|.  VGG-16 conv2_1 in front of a conv2_2
+ * that stages its patch from pairs (cslam_conv3x3_direct_hp_dev): cslam/vpr/netvlad.py:163-171,227. */
+CSLAM_API int cslam_conv3x3_direct_r_pairs_dev(const float *d_x, const void *d_w2r, const float *d_bias, int B, int H, int W, int Cin,
+                                               int Cout, const unsigned *d_amax, float inv_sw, float wl1, float bmax,
+                                               unsigned *d_amax_out, unsigned *d_bound_out, void *d_y, void *stream) {
+    return conv_direct_r_launch(d_x, d_w2r, d_bias, B, H, W, Cin, Cout, 1, 0, d_amax, inv_sw, d_amax_out, (float *)d_y, stream, 1, wl1, bmax, d_bound_out);
 }
