@@ -129,6 +129,8 @@ _SIGNATURES = {
     "cslam_conv_stem_pool_igemm_h2_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, C.c_float, _vp, _vp, _vp]),
     "cslam_conv_igemm_h2p_dev": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, C.c_float,
                                       C.c_float, C.c_float, _vp, _i, _vp, _vp, _vp]),
+    "cslam_conv3x3_direct_r_pairs_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, C.c_float, C.c_float, C.c_float, _vp, _vp, _vp, _vp]),
+    "cslam_conv3x3_direct_hp_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, C.c_float, _vp, _vp, _vp]),
     "cslam_conv3x3_direct_p_dev": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp, C.c_float, C.c_float, C.c_float,
                                         _vp, _i, _vp, _vp, _vp]),
     "cslam_comm_unique_id": (_i, [_vp]),

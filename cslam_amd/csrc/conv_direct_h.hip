@@ -101,7 +101,11 @@ __device__ __forceinline__ float cd_sub_half(float v, __half2 h) {
     return d;
 }
 
-template <bool RELU, bool POOL, int DBG = 0, bool PIXA = false>
+// XP: x is a PAIR-FORMAT map (conv_igemm.hip: [pixel][32-channel block][hi 32 | lo 32] fp16 of s x; amax_in = its BOUND slot, which fixes
+// s).  A pixel's slab is the same 128 bytes at the same address as in a float32 map, so the loads do not change; an element is one of
+// its eight 16-byte chunks and goes to LDS as it is -- the split (two packed conversions, four v_fma_mix, two more conversions per
+// element: 0.34 of conv2_2's 2.5 ms) is gone.
+template <bool RELU, bool POOL, int DBG = 0, bool PIXA = false, bool XP = false>
 __global__ __launch_bounds__(512, 2) void conv3x3_direct_h_kernel(ConvDirectArgs p) {
     extern __shared__ __attribute__((aligned(16))) char cd_smem[];
     char *s_patch = cd_smem;                                   // [2][CD_PATCHB]
@@ -119,8 +123,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_h_kernel(ConvDirectArgs
     // power-of-two input scale: max |x| s_x <= 2^15 - 16 (fp16 holds 65504; the products stay far inside fp32)
     const float amax = fminf(fmaxf(__uint_as_float(*p.amax_in), 1e-30f), 1e30f);
     int e_;
-    (void)frexpf(32752.0f / amax, &e_);
-    const float sx = ldexpf(1.0f, e_ - 1);
+    (void)frexpf(XP ? amax : 32752.0f / amax, &e_);
+    const float sx = XP ? ldexpf(1.0f, 14 - e_) : ldexpf(1.0f, e_ - 1);        // XP: the producer's scale (conv_igemm.hip::ci_scale of the bound)
     const float inv = p.inv_sw / sx;
 
     // Blocks to workgroups, XCD-aware (as conv_stem_direct_h.hip): workgroup w runs on XCD w % 8, every XCD has its own L2; each XCD
@@ -148,7 +152,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_h_kernel(ConvDirectArgs
         const int px = e >> 3, f4 = e & 7;
         pr = (px * 3641) >> 16;                                // px / 18 for px < 4096
         pc = px - pr * 18;
-        dst = e < 2592 ? pr * CD_ROWB + pc * CD_PIXB + f4 * 8 : -1;
+        dst = e < 2592 ? pr * CD_ROWB + pc * CD_PIXB + f4 * (XP ? 16 : 8) : -1;
     };
     float4 stg[NPL / 2];                                       // the patch goes through the registers in two halves (12 registers, not 24)
     unsigned inmask = 0;                                       // bit half * 3 + j: element j of the half lies inside the image
@@ -166,7 +170,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_h_kernel(ConvDirectArgs
         pcpack |= (unsigned)(valid ? pc : 0) << (5 * i);
         validpack |= (valid ? 1u : 0u) << i;
     }
-    char *const s_sink = cd_smem + 2 * CD_PATCHB + CD_NW * CD_WSTAGE + 512 + (tid & 15) * 8;
+    char *const s_sink = cd_smem + 2 * CD_PATCHB + CD_NW * CD_WSTAGE + 512 + (tid & 15) * (XP ? 16 : 8);
     // block coordinates are decoded ONCE per block on the scalar unit (three run-time divisions: ~90 dependent scalar instructions,
     // which sat at the top of two stages per slab): `cb` = the block being multiplied, `nb` = the next one (the last block again
     // behind the workgroup's last)
@@ -217,6 +221,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_h_kernel(ConvDirectArgs
             int pd, pr, pc;
             elem(half * (NPL / 2) + j, pd, pr, pc);
             const bool in = (inmask >> (3 * half + j)) & 1u;
+            if (XP) {
+                char *dx = pd >= 0 ? dst + pd : s_sink;
+                *(uint4 *)dx = in ? make_uint4(__float_as_uint(stg[j].x), __float_as_uint(stg[j].y), __float_as_uint(stg[j].z), __float_as_uint(stg[j].w))
+                                  : make_uint4(0u, 0u, 0u, 0u);
+                continue;
+            }
             const float w0 = in ? stg[j].x * sx : 0.0f, w1 = in ? stg[j].y * sx : 0.0f, w2 = in ? stg[j].z * sx : 0.0f, w3 = in ? stg[j].w * sx : 0.0f;
             const __half2 h01 = __floats2half2_rn(w0, w1), h23 = __floats2half2_rn(w2, w3);
             // w - (float)hi straight out of the packed register (v_fma_mix_f32; through __half22float2 hipcc rounds every value a second
@@ -585,9 +595,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_direct_h_kernel(ConvDirectArgs
 /* 3 x 3 / stride 1 / pad 1 convolution, Cout = 128, Cin a multiple of 32: y = [pool](relu(conv(x, w) + bias)); x, y NHWC float32.
  * d_w2 = `direct_pair_weights` (vpr/winograd.py): [9][128][Cin/32][hi 32 | lo 32] halfs of s_w w, inv_sw = 1 / s_w; d_amax = 4-byte
  * slot holding (a bound of) max |x|; d_amax_out (or NULL): zeroed slot that receives max |y|. */
-CSLAM_API int cslam_conv3x3_direct_h_dev(const float *d_x, const void *d_w2, const float *d_bias, int B, int H, int W, int Cin,
-                                         int Cout, int relu, int pool, const unsigned *d_amax, float inv_sw,
-                                         unsigned *d_amax_out, float *d_y, void *stream) {
+static int conv_direct_h_launch(const float *d_x, const void *d_w2, const float *d_bias, int B, int H, int W, int Cin,
+                                int Cout, int relu, int pool, const unsigned *d_amax, float inv_sw,
+                                unsigned *d_amax_out, float *d_y, void *stream, int x_pairs) {
     PTR_DEVICE(d_x);
     ARG_CHECK(d_x && d_w2 && d_y && d_amax, "NULL argument");
     ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
@@ -639,6 +649,21 @@ CSLAM_API int cslam_conv3x3_direct_h_dev(const float *d_x, const void *d_w2, con
 #undef CD_LAUNCH_D
     }
 #endif
+    if (x_pairs) {
+#define CD_LAUNCH_P(R, P) do { \
+        static DeviceOnce once; int once_dev; \
+        if (once.todo(&once_dev)) { \
+            HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_direct_h_kernel<R, P, 0, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, CD_LDS)); \
+            once.done(once_dev); } \
+        hipLaunchKernelGGL((conv3x3_direct_h_kernel<R, P, 0, false, true>), dim3(grid), dim3(512), CD_LDS, st, a); } while (0)
+        if (relu && pool) CD_LAUNCH_P(true, true);
+        else if (relu) CD_LAUNCH_P(true, false);
+        else if (pool) CD_LAUNCH_P(false, true);
+        else CD_LAUNCH_P(false, false);
+#undef CD_LAUNCH_P
+        HIP_TRY(hipGetLastError());
+        return CSLAM_OK;
+    }
     if (relu && pool) CD_LAUNCH(true, true);
     else if (relu) CD_LAUNCH(true, false);
     else if (pool) CD_LAUNCH(false, true);
@@ -646,4 +671,17 @@ CSLAM_API int cslam_conv3x3_direct_h_dev(const float *d_x, const void *d_w2, con
 #undef CD_LAUNCH
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
+}
+CSLAM_API int cslam_conv3x3_direct_h_dev(const float *d_x, const void *d_w2, const float *d_bias, int B, int H, int W, int Cin,
+                                         int Cout, int relu, int pool, const unsigned *d_amax, float inv_sw,
+                                         unsigned *d_amax_out, float *d_y, void *stream) {
+    return conv_direct_h_launch(d_x, d_w2, d_bias, B, H, W, Cin, Cout, relu, pool, d_amax, inv_sw, d_amax_out, d_y, stream, 0);
+}
+/* The same convolution reading a PAIR-FORMAT map (cslam_conv_igemm_h2p_dev's format, as cslam_conv3x3_direct_r_pairs_dev writes it):
+ * d_x [B,H,W,Cin/32][hi 32 | lo 32] fp16 of s x, s the power of two of the 4-byte BOUND slot d_xbound; y float32 NHWC as above.  The
+ * patch is staged without conversion (VGG-16 conv2_2 behind a conv2_1 that writes pairs: cslam/vpr/netvlad.py:163-171,227). */
+CSLAM_API int cslam_conv3x3_direct_hp_dev(const void *d_x, const unsigned *d_xbound, const void *d_w2, const float *d_bias, int B, int H,
+                                          int W, int Cin, int Cout, int relu, int pool, float inv_sw, unsigned *d_amax_out, float *d_y,
+                                          void *stream) {
+    return conv_direct_h_launch((const float *)d_x, d_w2, d_bias, B, H, W, Cin, Cout, relu, pool, d_xbound, inv_sw, d_amax_out, d_y, stream, 1);
 }

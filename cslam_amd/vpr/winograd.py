@@ -266,6 +266,34 @@ def conv3x3_direct_r(x, Wr, bias, relu, pool, amax_in, amax_out=None):
     return y
 
 
+def conv3x3_direct_r_pairs(x, Wr, bias, wl1, bmax, amax_in, bound_out, amax_out=None):
+    """relu(conv3x3(x) + bias), 64 -> 128 channels, written in PAIR FORMAT (`cslam_conv3x3_direct_r_pairs_dev`): returns the
+    [B,H,W,4,2,32] float16 tensor scaled for the bound max|x| wl1 + bmax, which goes to the 4-byte slot bound_out."""
+    lib = _lib.load()
+    x = x.contiguous(memory_format=torch.channels_last)
+    B, Cin, H, W = x.shape
+    y = torch.empty((B, H, W, 4, 2, 32), dtype=torch.float16, device=x.device)
+    _lib.check(lib.cslam_conv3x3_direct_r_pairs_dev(_p(x), _p(Wr[0]), _p(bias) if bias is not None else None, B, H, W, Cin, 128,
+                                                    _p(amax_in), float(Wr[1]), float(wl1), float(bmax),
+                                                    _p(amax_out) if amax_out is not None else None, _p(bound_out), _p(y), _stream(x)))
+    return y
+
+
+def conv3x3_direct_hp(xp, shape, bound, Wd, bias, relu, pool, amax_out=None):
+    """`conv3x3_direct_h` reading a PAIR-FORMAT map xp [B,H,W,Cin/32,2,32] float16 (shape = its (B,Cin,H,W), bound = its 4-byte bound
+    slot) through `cslam_conv3x3_direct_hp_dev`: the patch is staged without conversion."""
+    lib = _lib.load()
+    B, Cin, H, W = shape
+    W2, inv_sw = Wd
+    Cout = W2.shape[1]
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    y = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=xp.device, memory_format=torch.channels_last)
+    _lib.check(lib.cslam_conv3x3_direct_hp_dev(_p(xp), _p(bound), _p(W2), _p(bias) if bias is not None else None, B, H, W, Cin, Cout,
+                                               int(relu), int(pool), float(inv_sw), _p(amax_out) if amax_out is not None else None,
+                                               _p(y), _stream(xp)))
+    return y
+
+
 def fused64_weights(U):
     """U [16 | 36, 64, Cout] (`wino_weights(w, 2 | 4)`; Cout 64 or 128) -> the operand order of
     `cslam_wino2_fused_c64_dev` / `cslam_wino4_fused_c64_dev`: Up[kq][xi][w][g][c][s] = U[xi][16 kq + 4 g + s][16 w + c]
@@ -440,6 +468,9 @@ def _z_form(cin, cout):
 
 Z_FORM_MAX = 128 * 128
 PAIR_ACTS = True              # ResNet trunks: pair-format maps between the implicit-GEMM layers (False: float32 maps, the A/B partner)
+VGG_PAIRS = False             # VGG trunk: the map between conv2_1 and conv2_2 in pair format.  Built, tested and measured in round 6: conv2_2 staging pairs
+                              # without the split 2.11 against 2.135 ms, conv2_1 writing them 1.15 against 1.04 -- the split was already hidden under
+                              # the MFMAs, the two 8-byte stores per row are not (profiles/r06_j_vgg_pairs_ab.log): off by default
 DIRECT_P = True               # ResNet trunks: the 64 -> 64 3x3 layers between pair-format maps through csrc/conv_direct_p.hip (False: the implicit GEMM)
 IGEMM_CONVS = True            # ResNet trunks: strided / 1x1 / 7x7 layers through csrc/conv_igemm.hip (False: torch, the A/B partner)
 
@@ -724,7 +755,7 @@ class WinogradResNet(_Workspace):
 
 
 class _Step(object):
-    __slots__ = ("kind", "module", "conv", "relu", "pool", "U", "U4", "U3", "U2", "Up", "Uph", "bias", "stem", "Wd", "Wr", "Wdr")
+    __slots__ = ("kind", "module", "conv", "relu", "pool", "U", "U4", "U3", "U2", "Up", "Uph", "bias", "stem", "Wd", "Wr", "Wdr", "wl1", "bmax")
 
     def __init__(self):
         self.kind, self.module, self.conv, self.relu, self.pool = "torch", None, None, False, False
@@ -732,6 +763,7 @@ class _Step(object):
         self.Wd = None
         self.Wr = None
         self.Wdr = None
+        self.wl1 = self.bmax = None
 
 
 class WinogradTrunk(_Workspace):
@@ -803,6 +835,8 @@ class WinogradTrunk(_Workspace):
                     # 64 -> 128 (conv2_1): the register-resident form (csrc/conv_direct_r.hip); CSLAM_CONV_DIRECT_R=0 keeps the one above
                     if m.in_channels == 64 and os.environ.get("CSLAM_CONV_DIRECT_R", "1") != "0":
                         st.Wdr = direct_r_pair_weights(m.weight)
+                        st.wl1 = float(m.weight.detach().abs().sum(dim=(1, 2, 3)).max())      # bound of the pair-format output: max|x| wl1 + bmax
+                        st.bmax = 0.0 if m.bias is None else float(m.bias.detach().abs().max())
                 st.bias = None if m.bias is None else m.bias.detach().to(torch.float32).contiguous()
                 i += 1
                 if i < len(mods) and isinstance(mods[i], nn.ReLU):
@@ -923,6 +957,21 @@ class WinogradTrunk(_Workspace):
                 if not have:
                     _lib.check(lib.cslam_absmax_dev(_p(x), x.numel(), _p(slot), _stream(x)))
                 want = slots[k + 1:k + 2] if wants(nxt) else None
+                if (VGG_PAIRS and st.Wdr is not None and st.relu and not st.pool and nxt is not None and nxt.Wd is not None
+                        and nxt.Wdr is None and nxt.conv.in_channels == 128 and x.shape[2] * x.shape[3] * 512 < 2 ** 31 - 16
+                        and not (nxt.pool and (x.shape[2] % 2 or x.shape[3] % 2))):
+                    # conv2_1 writes pairs, conv2_2 stages them without conversion: both steps here
+                    B_, _, H_, W_ = x.shape
+                    bslot = self._buf("vgg_pair_bound", 1, x.device)
+                    w_ = st.conv.weight.detach()
+                    xp = conv3x3_direct_r_pairs(x, st.Wdr, st.bias, float(w_.abs().sum(dim=(1, 2, 3)).max()) if st.wl1 is None else st.wl1,
+                                                0.0 if st.bias is None else st.bmax, slot, bslot)
+                    nn2 = self.steps[k + 2] if k + 2 < len(self.steps) else None
+                    want2 = slots[k + 2:k + 3] if wants(nn2) else None
+                    x = conv3x3_direct_hp(xp, (B_, 128, H_, W_), bslot, nxt.Wd, nxt.bias, nxt.relu, nxt.pool, want2)
+                    amax_ready = want2 is not None
+                    skip = True
+                    continue
                 if st.Wdr is not None and x.shape[2] * x.shape[3] * 512 < 2 ** 31 - 16:
                     x = conv3x3_direct_r(x, st.Wdr, st.bias, st.relu, st.pool, slot, want)
                 else:

@@ -498,6 +498,17 @@ int cslam_conv3x3_direct_r_dev(const float *d_x, const void *d_w2r, const float 
                                int relu, int pool, const unsigned *d_amax, float inv_sw, unsigned *d_amax_out, float *d_y,
                                void *stream);
 
+/* conv2_1 -> conv2_2 of VGG-16 (cslam/vpr/netvlad.py:163-171,227) with the 112 x 112 x 128 map between them in the PAIR FORMAT of
+ * cslam_conv_igemm_h2p_dev: cslam_conv3x3_direct_r_pairs_dev = cslam_conv3x3_direct_r_dev (+ bias + ReLU, no pooling) writing
+ * [B,H,W,4 blocks][hi 32 | lo 32] fp16 of s y, s the power of two of the bound *d_amax wl1 + bmax (-> d_bound_out; wl1 = max_co
+ * sum |w[co]|, bmax = max |bias|); cslam_conv3x3_direct_hp_dev = cslam_conv3x3_direct_h_dev reading such a map (d_xbound = its bound slot)
+ * and staging its patch without the split into pairs (csrc/conv_direct_r.hip, csrc/conv_direct_h.hip). */
+int cslam_conv3x3_direct_r_pairs_dev(const float *d_x, const void *d_w2r, const float *d_bias, int B, int H, int W, int Cin, int Cout,
+                                     const unsigned *d_amax, float inv_sw, float wl1, float bmax, unsigned *d_amax_out,
+                                     unsigned *d_bound_out, void *d_y, void *stream);
+int cslam_conv3x3_direct_hp_dev(const void *d_x, const unsigned *d_xbound, const void *d_w2, const float *d_bias, int B, int H, int W,
+                                int Cin, int Cout, int relu, int pool, float inv_sw, unsigned *d_amax_out, float *d_y, void *stream);
+
 /* 3x3 / stride 1 / pad 1 convolution 64 -> 64 channels between PAIR-FORMAT maps (the four stride-1 convolutions of ResNet-18/34's layer1:
  * cslam/vpr/cosplace_utils/network.py:38-68, the reference's default extractor) as ONE direct kernel whose weights stay in the registers
  * of the four waves of a workgroup, 16 output channels each, the input patch arriving by LDS-DMA (csrc/conv_direct_p.hip).  The

@@ -723,6 +723,63 @@ def test_trunk_runs_conv2_1_and_conv2_2_through_the_direct_kernel_and_matches_th
         assert (outs[tag] - outs["wino"]).abs().max().item() <= 2e-5 * ref.abs().max().item(), tag
 
 
+@pytest.mark.parametrize("B,H,W,pool,amp", [(20, 32, 48, True, 1.0), (3, 112, 112, True, 30.0), (17, 22, 38, False, 1e-3), (33, 16, 16, True, 1.0)])
+def test_conv2_1_writes_pairs_and_conv2_2_stages_them_without_conversion(T, B, H, W, pool, amp):
+    """`cslam_conv3x3_direct_r_pairs_dev` -> `cslam_conv3x3_direct_hp_dev` (VGG-16 conv2_1 -> conv2_2 with the map between them in pair
+    format: the second kernel's patch goes to LDS as it is) against the float32 chain of the same two kernels and against float64 --
+    no further from it than 4 x torch's float32 chain; the pair tensor itself decodes to conv2_1's output; the bound slot is
+    max|x| wl1 + bmax; through `WinogradTrunk` with `VGG_PAIRS` (off by default: measured no faster) and without; repeated calls are bit-identical."""
+    torch, _ = T
+    from torch import nn
+    from cslam_amd.vpr import winograd as wg
+    torch.manual_seed(B + H)
+    x = (torch.relu(torch.randn((B, 64, H, W), device="cuda")) * amp).contiguous(memory_format=torch.channels_last)
+    c1, c2 = nn.Conv2d(64, 128, 3, padding=1).cuda(), nn.Conv2d(128, 128, 3, padding=1).cuda()
+    with torch.no_grad():
+        c1.bias.mul_(amp * 0.5)
+        c2.bias.mul_(amp * 0.5)
+        r1 = torch.relu(torch.nn.functional.conv2d(x.double(), c1.weight.double(), c1.bias.double(), padding=1))
+        r2 = torch.relu(torch.nn.functional.conv2d(r1, c2.weight.double(), c2.bias.double(), padding=1))
+        f2 = torch.relu(c2(torch.relu(c1(x))))
+        if pool:
+            r2, f2 = torch.nn.functional.max_pool2d(r2, 2, 2), torch.nn.functional.max_pool2d(f2, 2, 2)
+    slots = torch.zeros(6, device="cuda")
+    slots[0] = x.abs().max()
+    Wr, Wd = wg.direct_r_pair_weights(c1.weight), wg.direct_pair_weights(c2.weight)
+    wl1, bmax = float(c1.weight.detach().abs().sum(dim=(1, 2, 3)).max()), float(c1.bias.detach().abs().max())
+    xp = wg.conv3x3_direct_r_pairs(x, Wr, c1.bias.detach(), wl1, bmax, slots[0:1], slots[1:2], slots[2:3])
+    act = wg.PairAct(xp, True, (B, 128, H, W), slots[2:3], slots[1:2])
+    y1 = wg.pairs_to_float(act)
+    sc1 = r1.abs().max().item()
+    assert (y1.double() - r1).abs().max().item() / sc1 <= 3e-6
+    assert abs(slots[2].item() - sc1) <= 1e-5 * sc1 and slots[2].item() <= slots[1].item() <= (slots[0].item() * wl1 + bmax) * 1.002
+    y2 = wg.conv3x3_direct_hp(xp, (B, 128, H, W), slots[1:2], Wd, c2.bias.detach(), True, pool, slots[3:4])
+    sc2 = r2.abs().max().item()
+    e32 = (f2.double() - r2).abs().max().item() / sc2
+    assert tuple(y2.shape) == tuple(r2.shape) and y2.is_contiguous(memory_format=torch.channels_last)
+    assert (y2.double() - r2).abs().max().item() / sc2 <= 4 * e32 + 4e-7
+    assert slots[3].item() >= y2.abs().max().item() * (1 - 1e-6)
+    # the float32 chain of the same kernels
+    y1f = wg.conv3x3_direct_r(x, Wr, c1.bias.detach(), True, False, slots[0:1], slots[4:5])
+    y2f = wg.conv3x3_direct_h(y1f, Wd, c2.bias.detach(), True, pool, slots[4:5], None)
+    assert (y2 - y2f).abs().max().item() / sc2 <= 2e-6
+    assert torch.equal(y2, wg.conv3x3_direct_hp(wg.conv3x3_direct_r_pairs(x, Wr, c1.bias.detach(), wl1, bmax, slots[0:1], slots[5:6]),
+                                                (B, 128, H, W), slots[5:6], Wd, c2.bias.detach(), True, pool, None))
+    # through the trunk runner
+    mods = [c1, nn.ReLU(), c2, nn.ReLU()] + ([nn.MaxPool2d(2, 2)] if pool else [])
+    seq = nn.Sequential(*mods).eval()
+    t = wg.WinogradTrunk(seq, 64, 4)
+    t.fused_min_blocks = 0
+    assert t.steps[0].Wdr is not None and t.steps[1].Wd is not None and t.steps[1].Wdr is None
+    gotf = t(x)
+    try:
+        wg.VGG_PAIRS = True
+        got = t(x)
+    finally:
+        wg.VGG_PAIRS = False
+    assert torch.equal(got, y2) and torch.equal(gotf, y2f)
+
+
 @pytest.mark.parametrize("cout,B,H,W,pool,amp", [(64, 4, 64, 48, True, 1.0), (128, 3, 40, 56, False, 1e3), (64, 2, 30, 22, False, 1e-3)])
 def test_fused_winograd_h_scales_shortcut_and_amax(T, cout, B, H, W, pool, amp):
     """cslam_wino4_fused_c64_h_dev called directly: activations six decades apart (the power-of-two scale from the max |x|
