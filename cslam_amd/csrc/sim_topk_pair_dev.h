@@ -96,9 +96,20 @@ __device__ __forceinline__ void pair_tile_epilogue(f32x16 (&acc)[MT][NTW], float
 //    want DIFFERENT offsets are served by ONE insertion: the candidate vector is assembled from the comparison masks (two
 //    v_cndmask per non-empty offset, the masks are already in SGPRs), and the number of insertions of a block is the largest
 //    number of passing keys of any single lane (1-2), not the number of distinct offsets (5-16).
+// SEED (the FIRST tile of a list, round 6): with the list empty every one of a lane's 16 x MT keys passes the threshold and is inserted one
+// by one -- the first tile of the in-step launch's six-tile lists cost 1.5 x a steady one (profiles/r05_v18_in_step_tile_trace.log).  A
+// pre-pass turns the accumulators into keys (masked rows -inf, NaN +inf) and takes the two largest of every 16-key block: these are
+// 2 MT >= KPL distinct keys of the lane, so the KPL-th largest of the tile is at least t0 = the smallest of the blocks' second maxima,
+// and a key below t0 can never be in the list -- nor above the list's last entry, which is what the dropped-keys bound of the block
+// merge rests on.  Only keys >= t0 are inserted (about a fifth): the list that comes out is the same, entry for entry.
 template <int MT, int KPL, int NTW>
 __device__ __forceinline__ void ring_tile_epilogue(f32x16 (&acc)[MT][NTW], float (&lk)[NTW][KPL], int (&li)[NTW][KPL], const int (&lim)[NTW],
-                                                   const float (&qmul)[NTW], const float *s_inv, int row_base) {
+                                                   const float (&qmul)[NTW], const float *s_inv, int row_base, bool seed = false) {
+    // pass 1: accumulators -> keys in place (rows the query may not see: -inf; NaN: +inf, it ranks first); `seed` (wave-uniform; needs
+    // 2 MT >= KPL): the smallest of the blocks' second maxima
+    float t0[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) t0[n] = seed ? INFINITY : -INFINITY;
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         float inv[16];
@@ -109,15 +120,37 @@ __device__ __forceinline__ void ring_tile_epilogue(f32x16 (&acc)[MT][NTW], float
         }
 #pragma unroll
         for (int n = 0; n < NTW; ++n) {
+            const int rel_lim = lim[n] - (row_base + m * 32);   // row < lim  <=>  rowoff < rel_lim
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float k = (acc[m][n][r] * inv[r]) * qmul[n];
+                k = (k != k) ? INFINITY : k;
+                acc[m][n][r] = (((r & 3) + 8 * (r >> 2)) < rel_lim) ? k : -INFINITY;
+            }
+            if (seed) {
+                float m1 = -INFINITY, m2 = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    m2 = fmaxf(m2, fminf(m1, acc[m][n][r]));
+                    m1 = fmaxf(m1, acc[m][n][r]);
+                }
+                t0[n] = fminf(t0[n], m2);
+            }
+        }
+    }
+    // pass 2: the keys above the list's last entry (and not below the seed) are inserted
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) {
             float kx[16];
             unsigned long long pm[16];                           // lanes whose key at offset r passes: wave-uniform, in SGPRs
             unsigned long long any = 0;
             const float thr = lk[n][KPL - 1];
-            const int rel_lim = lim[n] - (row_base + m * 32);   // row < lim  <=>  rowoff < rel_lim
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                kx[r] = (acc[m][n][r] * inv[r]) * qmul[n];
-                pm[r] = __ballot((((r & 3) + 8 * (r >> 2)) < rel_lim) && !(kx[r] <= thr));     // NaN passes (ranks first)
+                kx[r] = acc[m][n][r];
+                pm[r] = __ballot(!(kx[r] <= thr) && !(kx[r] < t0[n]));
                 any |= pm[r];
                 acc[m][n][r] = 0.0f;
             }
@@ -139,7 +172,6 @@ __device__ __forceinline__ void ring_tile_epilogue(f32x16 (&acc)[MT][NTW], float
                         any |= pm[r];
                     }
                 }
-                ck = (ck != ck) ? INFINITY : ck;
                 ci += row_base + m * 32;
 #pragma unroll
                 for (int j = 0; j < KPL; ++j) {                  // lanes outside `taken` carry -inf: nothing moves

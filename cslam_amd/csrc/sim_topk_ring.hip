@@ -366,7 +366,9 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
                 } else if (DBG & 16) {                                   // measurement build: round 4's epilogue
                     pair_tile_epilogue<MT, KPL, NTW>(acc, lk, li, lim, qmul, p.invs, p.n_rows, tile + wm * 32 * MT + 4 * h);
                 } else {
-                    ring_tile_epilogue<MT, KPL, NTW>(acc, lk, li, lim, qmul, s_inv + tpar * 256 + wm * 32 * MT + 4 * h, tile + wm * 32 * MT + 4 * h);
+                    // (the list's first tile is seeded: sim_topk_pair_dev.h; DBG & 32, measurement build: never)
+                    ring_tile_epilogue<MT, KPL, NTW>(acc, lk, li, lim, qmul, s_inv + tpar * 256 + wm * 32 * MT + 4 * h, tile + wm * 32 * MT + 4 * h,
+                                                     i == 0 && !(DBG & 32) && 2 * MT >= KPL);
                 }
                 tpar ^= 1;
             }
@@ -481,7 +483,7 @@ int ring_stage1_launch(const RingArgs &a, int variant, int dbg, hipStream_t st) 
 #ifdef CSLAM_ABLATIONS
     // variants (flow control, wave priorities), timing-only ablations, cache policies of the requests: bank nt / query nt / both / bank sc1 / ...
 #define RING_EACH_DBG(X) X(0, 1, 0) X(0, 0, 1) X(0, 1, 1) X(0, 2, 0) X(0, 3, 0) X(2, 0, 0) X(8, 0, 0) X(9, 0, 0) X(10, 0, 0) X(13, 0, 0) X(16, 0, 0) X(33, 0, 0) X(33, 0, 1) X(9, 0, 1) X(10, 0, 1) \
-    X(128, 0, 0) X(1024, 0, 0) X(1152, 0, 0) X(256, 0, 0) X(2048, 0, 0) X(64, 0, 0) X(512, 0, 0)
+    X(128, 0, 0) X(1024, 0, 0) X(1152, 0, 0) X(256, 0, 0) X(2048, 0, 0) X(64, 0, 0) X(512, 0, 0) X(32, 0, 0)
 #else
 #define RING_EACH_DBG(X)
 #endif
