@@ -501,23 +501,13 @@ def main():
     # the same leg AND the same whole step with the trunk's GEMMs as plain fp32 (rocBLAS sgemm) instead of the default
     # split-fp16 pairs (fp32-grade either way): reported beside `extract_only` / `value`, N = 1 only
     extract_fp32_gemms = value_fp32_gemms = None
-    split16 = os.environ.get("CSLAM_WINO_SPLIT16", "128")
-    if extractor is not None and world == 1 and extractor.backbone_conv == "winograd" and split16 != "0":
-        saved = {k: os.environ.get(k) for k in ("CSLAM_WINO_SPLIT16", "CSLAM_WINO_FUSED_H", "CSLAM_WINO_STEM")}
-        os.environ["CSLAM_WINO_SPLIT16"] = "0"          # library sgemm between the transforms
-        os.environ["CSLAM_WINO_FUSED_H"] = "0"          # conv1_2 / conv2_1 on the f32-input MFMA
-        os.environ["CSLAM_WINO_STEM"] = "0"             # conv1_1 as its own fp32 kernel
-        try:
-            ex32 = NetVLAD({"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376,
-                            "frontend.netvlad.pca_dim": a.dim, "frontend.random_seed": 0,
-                            "frontend.backbone_conv": a.backbone_conv}, None)
-            ex32.compute_embeddings_device(frames[:a.extract_chunk], bdt)
-        finally:
-            for k, v in saved.items():
-                if v is None:
-                    os.environ.pop(k, None)
-                else:
-                    os.environ[k] = v
+    split16 = "128"
+    if extractor is not None and world == 1 and extractor.backbone_conv == "winograd":
+        from cslam_amd.vpr.winograd import FP32_GEMM_FORMS       # library sgemm between the transforms, conv1_2 / conv2_1 on the f32-input MFMA,
+        ex32 = NetVLAD({"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376,          # conv1_1 as its own fp32 kernel
+                        "frontend.netvlad.pca_dim": a.dim, "frontend.random_seed": 0,
+                        "frontend.backbone_conv": a.backbone_conv, "frontend.trunk_forms": dict(FP32_GEMM_FORMS)}, None)
+        ex32.compute_embeddings_device(frames[:a.extract_chunk], bdt)
 
         def extract32():
             return torch.cat([ex32.compute_embeddings_device(frames[s_:s_ + a.extract_chunk], bdt)

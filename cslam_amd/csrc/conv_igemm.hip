@@ -1041,7 +1041,7 @@ static int conv_igemm_launch(const float *d_x, const void *d_w2, const float *d_
     if (const char *e = getenv("CSLAM_CI_DBG")) a.dbg = atoi(e);
 #endif
     ARG_CHECK(!f.x_pairs || (!stem && f.xbound), "pair-format input needs its bound slot (and is not the stem's format)");
-    ARG_CHECK(!f.out_pairs || (!pool && f.bound_out && f.wl1 > 0.0f && f.bmax >= 0.0f), "pair-format output needs wl1, bmax and the bound slot");
+    ARG_CHECK(!f.out_pairs || (!pool && f.bound_out && f.wl1 >= 0.0f && f.bmax >= 0.0f), "pair-format output needs wl1, bmax and the bound slot");     // (an all-zero folded convolution has wl1 = 0: the bound bmax + max|res| still holds)
     ARG_CHECK(!(d_res && (f.res_pairs || f.out_pairs)) || f.res_bound, "the shortcut's bound slot is missing");
     const int tn = Cout % 128 == 0 ? 128 : 64;
     const int am = stem ? 1 : (f.x_pairs ? 2 : 0);

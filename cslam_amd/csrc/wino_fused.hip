@@ -10,7 +10,7 @@
 // 2x2-pixel tile = 4.2e11 flop per 256 frames = 2.7 ms at the 157 TFLOP/s fp32-MFMA peak.
 //
 // Two forms.  The default is the persistent producer / consumer kernel further down (wino2_fused_c64_pipe_kernel);
-// the first one (one tile block per workgroup) is kept as the A/B partner (CSLAM_WF_WAVES=4 or 8) and documents the
+// the first one (one tile block per workgroup; launched by the measurement build only: CSLAM_WF_WAVES=4 or 8) documents the
 // phases: one workgroup owns 8 x 4 tiles (16 x 8 output pixels), K is walked in four 16-channel quarters:
 //   P1  the 18 x 10 pixel patch of the quarter -> LDS (zero border = the convolution's padding)
 //   P2  every thread transforms one tile x channel pair: V = B^T d B -> LDS [16 xi][32 tiles][16 ch, groups rotated]
@@ -715,15 +715,22 @@ CSLAM_API int cslam_wino2_fused_c64_dev(const float *d_x, const float *d_Up, con
     ARG_CHECK(!(pool && d_residual), "a shortcut cannot be added to a pooled output");
     ARG_CHECK(ceil_div64(H, 2 * WF_TBH) <= 65535 && B <= 65535, "map too tall / batch too large for one launch");
     hipStream_t st = (hipStream_t)stream;
-    const char *e = getenv("CSLAM_WF_WAVES");
-    const int wide = e ? atoi(e) : 0;
+    // the persistent producer / consumer kernel; the first form (one tile block per workgroup) is compiled into the measurement build
+    // only (CSLAM_WF_WAVES=4 or 8 there)
+    int wide = 0;
+#ifdef CSLAM_ABLATIONS
+    if (const char *e = getenv("CSLAM_WF_WAVES")) wide = atoi(e);
+#endif
     if (wide == 0 || d_residual) {
         const int rc = Cout == 64 ? launch_fused_pipe<64>(d_x, d_Up, d_bias, d_residual, B, H, W, relu, pool, d_y, st)
                                   : launch_fused_pipe<128>(d_x, d_Up, d_bias, d_residual, B, H, W, relu, pool, d_y, st);
         if (rc != CSLAM_OK) return rc;
-    } else if (Cout == 64) launch_fused_c64<4, 64>(d_x, d_Up, d_bias, B, H, W, relu, pool, d_y, st);
+    }
+#ifdef CSLAM_ABLATIONS
+    else if (Cout == 64) launch_fused_c64<4, 64>(d_x, d_Up, d_bias, B, H, W, relu, pool, d_y, st);
     else if (wide == 8) launch_fused_c64<8, 128>(d_x, d_Up, d_bias, B, H, W, relu, pool, d_y, st);
     else launch_fused_c64<4, 128>(d_x, d_Up, d_bias, B, H, W, relu, pool, d_y, st);
+#endif
     HIP_TRY(hipGetLastError());
     return CSLAM_OK;
 }

@@ -160,21 +160,22 @@ class MAC:
                     raise                 # an explicitly requested 'chain_hip' without its libraries stays an error
                 self.fiedler_solver = 'chain_gpu'
             # (every other CslamHipError propagates; CslamGraphError is the caller's retry policy, acm.py:436-466)
-        u_i = float("inf")
-        w_i = w_init
-        for it in range(max_iters):
-            f_i, vec_i = self.evaluate_fiedler_pair(w_i)
-            grad_i = self.grad_from_fiedler(vec_i)
+        # Host fallback (more junctions than the dense factor takes, or no HIP solver): Frank-Wolfe over the relaxed selection weights.
+        # `relaxed` walks from w_init towards the vertex the linear oracle names (the k heaviest gradient entries), step 2 / (t + 2);
+        # `dual_bound` is the best upper bound f + <grad, vertex - relaxed> seen; the walk ends when it closes on the objective.
+        relaxed, dual_bound, closed = w_init, float("inf"), False
+        for t in range(max_iters):
+            objective, fiedler_vec = self.evaluate_fiedler_pair(relaxed)
+            gradient = self.grad_from_fiedler(fiedler_vec)
             if trace is not None:
-                trace.append((float(f_i), float(np.linalg.norm(grad_i))))
-            s_i = self.round_solution(grad_i, k)
-            u_i = min(u_i, f_i + grad_i @ (s_i - w_i))
-            if u_i - f_i < duality_gap_tol:
-                if self.verbose:
-                    print("Duality gap tolerance reached, found optimal solution")
-                return self.round_solution_tiebreaker(w_i, k), w_i, u_i
-            alpha = 2.0 / (it + 2.0)
-            w_i = w_i + alpha * (s_i - w_i)
+                trace.append((float(objective), float(np.linalg.norm(gradient))))
+            vertex = self.round_solution(gradient, k)
+            towards = vertex - relaxed
+            dual_bound = min(dual_bound, objective + gradient @ towards)
+            closed = dual_bound - objective < duality_gap_tol
+            if closed:
+                break
+            relaxed = relaxed + (2.0 / (t + 2.0)) * towards
         if self.verbose:
-            print("Reached maximum iterations")
-        return self.round_solution_tiebreaker(w_i, k), w_i, u_i
+            print("Duality gap tolerance reached, found optimal solution" if closed else "Reached maximum iterations")
+        return self.round_solution_tiebreaker(relaxed, k), relaxed, dual_bound

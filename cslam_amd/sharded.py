@@ -321,6 +321,11 @@ class RowShardedBankMatcher(object):
                 done.record(st)
             if cur != st:
                 cur.wait_event(done)
+                # the result was allocated from `st`'s pool and will be read on `cur`: tell the caching allocator, or a block freed
+                # by the caller could be handed to later work on `st` while kernels on `cur` still read it (round-5 advisor)
+                for t_ in (out if isinstance(out, (tuple, list)) else (out,)):
+                    if torch.is_tensor(t_) and t_.is_cuda:
+                        t_.record_stream(cur)
             return out
         return PendingStep(fin)
 

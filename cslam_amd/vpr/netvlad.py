@@ -116,6 +116,9 @@ class NetVLAD(object):
         # Off by default: on ROCm 7.2 replaying the ~45-node graph takes 6.2 ms against 1.2 ms for launching the
         # same kernels one by one (tools/perf_online.py), so plain launches are the faster online path today.
         self.use_graph = bool(self.params.get('frontend.hip_graph', False))
+        # frontend.trunk_forms: which kernel form the layers of the VGG trunk take (vpr/winograd.py TRUNK_FORMS; None = the defaults;
+        # winograd.FP32_GEMM_FORMS = plain fp32 library GEMMs, what bench.py prints as `value_fp32_gemms`)
+        self.trunk_forms = self.params.get('frontend.trunk_forms')
         self._online = None
         self._online_trunk = None
         self._lanes = []                       # (stream, trunk) per extraction lane of compute_embeddings_batch_device
@@ -217,7 +220,7 @@ class NetVLAD(object):
             else:
                 if self.trunk is None:
                     self.trunk = WinogradTrunk(self.encoder, min_in_channels=64,
-                                               tile=4 if self.backbone_conv == 'winograd' else 2)
+                                               tile=4 if self.backbone_conv == 'winograd' else 2, forms=self.trunk_forms)
                     # a normalised 8-bit image is bounded by its normalisation constants: saves the trunk a pass over it
                     self.trunk.input_bound = heads.normalised_image_bound()
                 f = self.trunk(x)
@@ -238,7 +241,7 @@ class NetVLAD(object):
         def lane_trunk(i):
             if i == 0 and self.trunk is not None:
                 return self.trunk                                   # lane 0 shares the single-pass trunk (and its workspaces)
-            trunk = WinogradTrunk(self.encoder, min_in_channels=64, tile=4 if self.backbone_conv == 'winograd' else 2)
+            trunk = WinogradTrunk(self.encoder, min_in_channels=64, tile=4 if self.backbone_conv == 'winograd' else 2, forms=self.trunk_forms)
             trunk.input_bound = heads.normalised_image_bound()
             if i == 0:
                 self.trunk = trunk

@@ -482,7 +482,7 @@ def wino_conv3x3(ws, x, U, U4, bias, relu, pool=False, residual=None, U3=None, a
     U2 = `split16_pair_weights(U4)` (the default for wide layers): the 36 F(4x4) products run in this library's GEMM
     (csrc/wino_gemm.hip) over the exact fp16 hi / lo pairs of both operands, three of the four partial products in fp32
     accumulators: fp32-grade, at the fp16 MFMA rate, V and M at their fp32 sizes.
-    U3 = `split16_weights(U4)` (round 1's form, CSLAM_WINO_H3=1): the same arithmetic as ONE library fp16 GEMM over
+    U3 = `split16_weights(U4)` (round 1's form, split16_h3=True): the same arithmetic as ONE library fp16 GEMM over
     K' = 3 Cin, operands [vh | vl | vh] x [uh ; uh ; ul].
     amax_in: 4-byte device slot already holding the bits of (a bound of) max |x| -- saves the pass over x; amax_out: zeroed
     slot that receives the same for y from the F(4x4) output transform.  Returns y; `ws.amax_written` says whether amax_out
@@ -642,7 +642,8 @@ class _FoldedConv(object):
         if self.U is not None:
             return wino_conv3x3(ws, x.contiguous(memory_format=torch.channels_last), self.U, self.U4, self.bias, relu,
                                 False, residual)
-        if self.Wg is not None:
+        if self.Wg is not None and x.shape[2] + 2 * self.padding[0] >= self.kernel[0] and x.shape[3] + 2 * self.padding[0] >= self.kernel[1]:
+            # (a map smaller than the kernel: torch below, as for every geometry the implicit GEMM does not take)
             y = conv_igemm(ws, x, self.Wg, self.bias, self.kernel, self.stride[0], self.padding[0], relu, residual, amax_in, amax_out, pool)
             ws.amax_written = amax_out is not None
             return y
@@ -654,10 +655,12 @@ class _FoldedConv(object):
 
 class WinogradResNet(_Workspace):
     """Runs the ResNet trunks of vpr/backbones.py (`resnet_trunk`: conv1, bn1, relu, maxpool, layer1..4 of
-    BasicBlock / Bottleneck) like `trunk(x)` in eval mode, with every BatchNorm folded into its convolution and
-    the 3x3 / stride 1 convolutions executed through the Winograd pipeline (bias, shortcut add and ReLU fused into
-    the output transform; tiles hang over odd maps such as layer4's 7x7).  The 7x7 stem, the strided 3x3 and the 1x1 shortcut
-    convolutions run as this library's implicit GEMM on fp16 pairs (csrc/conv_igemm.hip; `IGEMM_CONVS = False`: torch)."""
+    BasicBlock / Bottleneck) like `trunk(x)` in eval mode, with every BatchNorm folded into its convolution.  Since round 5 EVERY
+    convolution is a kernel of this library on fp16 pairs (`direct`, the default): the implicit GEMM (csrc/conv_igemm.hip), the
+    register-resident direct kernel for layer1's 64 -> 64 layers (csrc/conv_direct_p.hip, round 6), pair-format maps between them --
+    `frontend.backbone_conv` 'winograd' and 'winograd2' therefore run the SAME path for ResNets (the name is the VGG trunk's; `tile`
+    only matters with direct=False: the 3x3 / stride-1 layers through the fp32 Winograd pipeline with library products, rounds 1-4's
+    A/B partner; `IGEMM_CONVS = False` additionally sends the stem, strided and 1x1 layers to torch)."""
 
     def __init__(self, trunk, min_in_channels=64, tile=4, direct=None):
         """direct (default: IGEMM_CONVS): EVERY eligible convolution through the implicit GEMM on fp16 pairs; False: the 3x3 / stride 1
@@ -766,11 +769,24 @@ class _Step(object):
         self.wl1 = self.bmax = None
 
 
+# Which form every layer of a VGG-style trunk takes (the defaults are the measured best; the others are the A/B partners the tests and
+# tools/ select through WinogradTrunk(forms={...}) -- no environment variables):
+#   conv_direct      1: conv2_1 and conv2_2 as the direct one-kernel convolution on fp16 pairs; 2: conv2_2 only; 0: round 3's F(4x4) forms
+#   conv_direct_r    conv2_1 through the register-resident direct kernel (csrc/conv_direct_r.hip); False: the streaming one
+#   stem_direct      conv1_1 + conv1_2 as ONE direct kernel (csrc/conv_stem_direct_h.hip); False: the one-kernel F(4x4) stem
+#   wino_stem        conv1_1 folded into conv1_2's kernel at all; False: conv1_1 as its own fp32 kernel
+#   fused_h          the one-kernel F(4x4) convolutions on fp16 pairs (csrc/wino_fused_h.hip); False: the f32-input MFMA kernels
+#   split16_min_cin  F(4x4) layers from that many input channels on run their 36 products on fp16 pairs (None: 128, or 256 with
+#                    split16_h3); 0: plain fp32 library GEMMs everywhere (bench.py's `value_fp32_gemms`)
+TRUNK_FORMS = {"conv_direct": 1, "conv_direct_r": True, "stem_direct": True, "wino_stem": True, "fused_h": True, "split16_min_cin": None}
+FP32_GEMM_FORMS = {"split16_min_cin": 0, "fused_h": False, "wino_stem": False}      # the trunk on plain fp32 library GEMMs
+
+
 class WinogradTrunk(_Workspace):
     """Runs an nn.Sequential of Conv2d / ReLU / MaxPool2d like `encoder(x)`, with the eligible
     convolutions (+ their ReLU, + their MaxPool2d(2,2)) replaced by the Winograd pipeline."""
 
-    def __init__(self, encoder, min_in_channels=256, tile=2, fused64=None, split16_h3=False):
+    def __init__(self, encoder, min_in_channels=256, tile=2, fused64=None, split16_h3=False, forms=None):
         """tile = 2: F(2x2,3x3) everywhere; tile = 4: F(4x4,3x3) on the maps whose sides are multiples of 4
         (F(2x2,3x3) on the others).  fused64: run the 64 -> 64 / 128 channel layers (VGG-16 conv1_2, conv2_1) through the single
         fused F(2x2,3x3) kernel instead of transform / GEMM / transform (default on)."""
@@ -788,12 +804,15 @@ class WinogradTrunk(_Workspace):
         # a known bound of max |input| (e.g. a normalised 8-bit image: heads.normalised_image_bound()) spares the stem kernel
         # its pass over the input; None = measured per call
         self.input_bound = None
-        # CSLAM_CONV_DIRECT=0: conv2_1 / conv2_2 through the F(4x4) forms of round 3 (the A/B partner)
-        self.direct128 = os.environ.get("CSLAM_CONV_DIRECT", "1") != "0"
-        # input widths that take the direct kernel (CSLAM_CONV_DIRECT=2: conv2_2 only, conv2_1 on the one-kernel F(4x4) form)
-        self.direct_cins = (128,) if os.environ.get("CSLAM_CONV_DIRECT", "1") == "2" else (64, 128)
+        # forms['conv_direct'] = 0: conv2_1 / conv2_2 through the F(4x4) forms of round 3 (the A/B partner)
+        self.forms = dict(TRUNK_FORMS)
+        self.forms.update(forms or {})
+        assert set(self.forms) == set(TRUNK_FORMS), "unknown trunk form"
+        self.direct128 = int(self.forms["conv_direct"]) != 0
+        # input widths that take the direct kernel (conv_direct = 2: conv2_2 only, conv2_1 on the one-kernel F(4x4) form)
+        self.direct_cins = (128,) if int(self.forms["conv_direct"]) == 2 else (64, 128)
         self.split16_h3 = bool(split16_h3)
-        self.split16_min_cin = int(os.environ.get("CSLAM_WINO_SPLIT16", "256" if self.split16_h3 else "128"))
+        self.split16_min_cin = (256 if self.split16_h3 else 128) if self.forms["split16_min_cin"] is None else int(self.forms["split16_min_cin"])
         use_tuned_gemms()
         self.refresh()
 
@@ -821,9 +840,9 @@ class WinogradTrunk(_Workspace):
                     # F(4x4) one-kernel form on the F(4x4) trunk, the F(2x2) one on an F(2x2) trunk
                     t4 = self.tile == 4
                     st.Up = fused64_weights(st.U4 if t4 else st.U)
-                    # the fp16-pair form of the one-kernel convolution (csrc/wino_fused_h.hip); CSLAM_WINO_FUSED_H=0 keeps
+                    # the fp16-pair form of the one-kernel convolution (csrc/wino_fused_h.hip); forms['fused_h'] = False keeps
                     # the f32-MFMA kernel
-                    if t4 and os.environ.get("CSLAM_WINO_FUSED_H", "1") != "0":
+                    if t4 and self.forms["fused_h"]:
                         st.Uph = fused64_pair_weights(st.U4)
                 if (self.direct128 and self.tile == 4 and m.out_channels == 128 and m.in_channels in self.direct_cins):
                     # VGG-16 conv2_2 (128 -> 128 on 112 x 112 maps, + MaxPool2d): the direct one-kernel form on fp16 pairs
@@ -832,8 +851,8 @@ class WinogradTrunk(_Workspace):
                     # (64 -> 128) stays on the one-kernel F(4x4) form: 1.47 ms against the direct kernel's 1.62 (a quarter of the
                     # multiplications; measured, profiles/r04_v9_direct_conv.log)
                     st.Wd = direct_pair_weights(m.weight)
-                    # 64 -> 128 (conv2_1): the register-resident form (csrc/conv_direct_r.hip); CSLAM_CONV_DIRECT_R=0 keeps the one above
-                    if m.in_channels == 64 and os.environ.get("CSLAM_CONV_DIRECT_R", "1") != "0":
+                    # 64 -> 128 (conv2_1): the register-resident form (csrc/conv_direct_r.hip); forms['conv_direct_r'] = False keeps the one above
+                    if m.in_channels == 64 and self.forms["conv_direct_r"]:
                         st.Wdr = direct_r_pair_weights(m.weight)
                         st.wl1 = float(m.weight.detach().abs().sum(dim=(1, 2, 3)).max())      # bound of the pair-format output: max|x| wl1 + bmax
                         st.bmax = 0.0 if m.bias is None else float(m.bias.detach().abs().max())
@@ -875,14 +894,14 @@ class WinogradTrunk(_Workspace):
                 i += 1
             self.steps.append(st)
         # first layer (3 -> 64, ReLU) followed by a one-kernel fp16-pair layer (64 -> 64, ReLU): both in ONE kernel, the
-        # 64-channel map between them never reaches HBM (csrc/wino_fused_h.hip, STEM; CSLAM_WINO_STEM=0 keeps them apart)
-        if os.environ.get("CSLAM_WINO_STEM", "1") != "0":
+        # 64-channel map between them never reaches HBM (csrc/wino_fused_h.hip, STEM; forms['wino_stem'] = False keeps them apart)
+        if self.forms["wino_stem"]:
             for a, b in zip(self.steps, self.steps[1:]):
                 if (a.kind == "c3" and a.relu and a.conv.out_channels == 64 and b.kind == "wino" and b.Uph is not None
                         and b.relu and b.conv.out_channels == 64):
                     a.stem = stem_pair_weights(a.conv.weight)
-                    # the direct one-kernel form of the pair (csrc/conv_stem_direct_h.hip); CSLAM_STEM_DIRECT=0 keeps the F(4x4) one
-                    if os.environ.get("CSLAM_STEM_DIRECT", "1") != "0":
+                    # the direct one-kernel form of the pair (csrc/conv_stem_direct_h.hip); forms['stem_direct'] = False keeps the F(4x4) one
+                    if self.forms["stem_direct"]:
                         a.Wr = stem_direct_pair_weights(b.conv.weight)
         return self
 

@@ -489,7 +489,7 @@ def test_vlad_init_params_matches_reference(T):
         assert y.shape == g[tag + "/y"].shape and np.max(np.abs(y - g[tag + "/y"])) < 1e-6
 
 
-@pytest.mark.parametrize("waves", [0, 4, 8])
+@pytest.mark.parametrize("waves", [0])
 @pytest.mark.parametrize("B,H,W,relu,pool,bias", [(2, 112, 112, True, False, True), (3, 37, 50, True, True, True),
                                                   (1, 8, 16, False, True, False), (2, 1, 1, False, False, True),
                                                   (300, 16, 16, True, False, True)])
@@ -504,7 +504,7 @@ def test_fused_winograd_64_to_128_equals_float64_and_unfused(T, B, H, W, relu, p
                                                   (1, 8, 16, False, True, False), (5, 16, 8, True, True, True),
                                                   (2, 1, 1, False, False, True), (1, 40, 70, True, True, True),
                                                   (7, 100, 36, True, True, True)])
-@pytest.mark.parametrize("waves", [0, 4])
+@pytest.mark.parametrize("waves", [0])
 def test_fused_winograd_64_to_64_equals_float64_and_unfused(T, B, H, W, relu, pool, bias, waves):
     _fused_case(T, 64, B, H, W, relu, pool, bias, waves)
 
@@ -516,7 +516,6 @@ def _fused_case(T, cout, B, H, W, relu, pool, bias, waves):
     torch, _ = T
     from torch import nn
     from cslam_amd.vpr.winograd import WinogradTrunk
-    os.environ["CSLAM_WF_WAVES"] = str(waves)
     torch.manual_seed(23)
     mods = [nn.Conv2d(64, cout, 3, padding=1, bias=bias)] + ([nn.ReLU()] if relu else []) + \
         ([nn.MaxPool2d(2, 2)] if pool and relu else [])
@@ -544,7 +543,6 @@ def test_fused_winograd_shortcut_add(T, B, H, W, cout):
     torch, _ = T
     from cslam_amd import _lib
     from cslam_amd.vpr.winograd import fused64_weights, wino_fused64, wino_weights
-    os.environ.pop("CSLAM_WF_WAVES", None)
     torch.manual_seed(5)
     w = torch.randn((cout, 64, 3, 3), device="cuda") * 0.05
     b = torch.randn(cout, device="cuda")
@@ -573,8 +571,8 @@ def test_fused_winograd_f4_equals_float64(T, form, cout, B, H, W, relu, pool, bi
     torch, _ = T
     from torch import nn
     from cslam_amd.vpr.winograd import WinogradTrunk
-    os.environ.pop("CSLAM_WF_WAVES", None)
-    monkeypatch.setenv("CSLAM_WINO_FUSED_H", "1" if form == "h" else "0")
+    from cslam_amd.vpr import winograd as wgm
+    monkeypatch.setitem(wgm.TRUNK_FORMS, "fused_h", form == "h")
     torch.manual_seed(29)
     mods = [nn.Conv2d(64, cout, 3, padding=1, bias=bias)] + ([nn.ReLU()] if relu else []) + \
         ([nn.MaxPool2d(2, 2)] if pool and relu else [])
@@ -684,8 +682,8 @@ def test_netvlad_extraction_beside_a_stream_that_thrashes_the_l2_is_bit_identica
 
 def test_trunk_runs_conv2_1_and_conv2_2_through_the_direct_kernel_and_matches_the_winograd_forms(T, monkeypatch):
     """VGG-16's first two blocks through the trunk runner: by default the stem and conv2_1 take the register-resident direct kernels
-    and conv2_2 the streaming direct kernel; CSLAM_CONV_DIRECT=2 leaves conv2_1 on the one-kernel F(4x4) form, =0 keeps round 3's
-    F(4x4) forms for both; CSLAM_CONV_DIRECT_R=0 / CSLAM_STEM_DIRECT=0 select the A/B partners of the register-resident kernels.  All
+    and conv2_2 the streaming direct kernel; forms conv_direct = 2 leaves conv2_1 on the one-kernel F(4x4) form, = 0 keeps round 3's
+    F(4x4) forms for both; conv_direct_r / stem_direct = False select the A/B partners of the register-resident kernels.  All
     against float64, and against each other at the F(4x4) forms' tolerance."""
     torch, _ = T
     from torch import nn
@@ -696,24 +694,17 @@ def test_trunk_runs_conv2_1_and_conv2_2_through_the_direct_kernel_and_matches_th
                         nn.MaxPool2d(2, 2)).cuda().eval()
     x = torch.randn((36, 3, 64, 80), device="cuda")
     outs = {}
-    for tag, env, direct in (("direct", None, (True, True)), ("conv2_2", "2", (False, True)), ("wino", "0", (False, False))):
-        if env is None:
-            monkeypatch.delenv("CSLAM_CONV_DIRECT", raising=False)
-        else:
-            monkeypatch.setenv("CSLAM_CONV_DIRECT", env)
-        t = WinogradTrunk(seq, 64, 4, fused64=True)
+    for tag, env, direct in (("direct", 1, (True, True)), ("conv2_2", 2, (False, True)), ("wino", 0, (False, False))):
+        t = WinogradTrunk(seq, 64, 4, fused64=True, forms={"conv_direct": env})
         assert ((t.steps[2].Wd is not None), (t.steps[3].Wd is not None)) == direct, tag
         assert (t.steps[2].Wdr is not None) == direct[0] and t.steps[3].Wdr is None and t.steps[0].Wr is not None
         outs[tag] = t(x)
     # the A/B partners of the register-resident kernels: conv2_1 on the streaming direct kernel, the F(4x4) stem kernel
-    monkeypatch.delenv("CSLAM_CONV_DIRECT", raising=False)
-    for tag, env in (("conv2_1 streaming", "CSLAM_CONV_DIRECT_R"), ("wino stem", "CSLAM_STEM_DIRECT")):
-        monkeypatch.setenv(env, "0")
-        t = WinogradTrunk(seq, 64, 4, fused64=True)
-        assert (t.steps[2].Wdr is None) == (env == "CSLAM_CONV_DIRECT_R") and (t.steps[0].Wr is None) == (env == "CSLAM_STEM_DIRECT"), tag
+    for tag, env in (("conv2_1 streaming", "conv_direct_r"), ("wino stem", "stem_direct")):
+        t = WinogradTrunk(seq, 64, 4, fused64=True, forms={env: False})
+        assert (t.steps[2].Wdr is None) == (env == "conv_direct_r") and (t.steps[0].Wr is None) == (env == "stem_direct"), tag
         assert t.steps[2].Wd is not None and t.steps[0].stem is not None
         outs[tag] = t(x)
-        monkeypatch.delenv(env)
     with torch.no_grad():
         ref = seq.double()(x.double())
     seq.float()
@@ -898,7 +889,7 @@ def test_split16_winograd_layer_is_fp32_grade(T, form, B, H, W, cin, cout, relu,
 def test_split16_trunk_equals_fp32_gemm_trunk(T):
     """VGG-16 trunk with the split-fp16 GEMMs -- the default pair form from 128 input channels on (conv2_2 ... conv5_3,
     this library's GEMM) and round 1's h3 form from 256 on (split16_h3=True) -- against the same trunk on plain fp32
-    GEMMs (CSLAM_WINO_SPLIT16=0) and against a float64 evaluation: neither split form is less accurate than the fp32 one
+    GEMMs (forms split16_min_cin = 0) and against a float64 evaluation: neither split form is less accurate than the fp32 one
     by more than 1.5x (max norm and relative 2-norm), and all sit inside the trunk tolerance used for the fp32 form."""
     torch, _ = T
     from cslam_amd.vpr.backbones import vgg16_features_trunk
@@ -906,18 +897,9 @@ def test_split16_trunk_equals_fp32_gemm_trunk(T):
     torch.manual_seed(37)
     enc = vgg16_features_trunk().cuda().eval()
     x = torch.randn((32, 3, 224, 224), device="cuda")     # 32 frames: conv5_x (4 x 4 tiles per frame) reaches the 512-tile F(4x4) floor
-    old = os.environ.get("CSLAM_WINO_SPLIT16")
-    try:
-        os.environ["CSLAM_WINO_SPLIT16"] = "0"
-        t32 = WinogradTrunk(enc, 64, 4)
-        os.environ.pop("CSLAM_WINO_SPLIT16", None)
-        t2 = WinogradTrunk(enc, 64, 4)
-        t3 = WinogradTrunk(enc, 64, 4, split16_h3=True)
-    finally:
-        if old is None:
-            os.environ.pop("CSLAM_WINO_SPLIT16", None)
-        else:
-            os.environ["CSLAM_WINO_SPLIT16"] = old
+    t32 = WinogradTrunk(enc, 64, 4, forms={"split16_min_cin": 0})
+    t2 = WinogradTrunk(enc, 64, 4)
+    t3 = WinogradTrunk(enc, 64, 4, split16_h3=True)
     assert all(st.U3 is None and st.U2 is None for st in t32.steps)
     assert sum(st.U2 is not None for st in t2.steps) == 10 and all(st.U3 is None for st in t2.steps)    # conv2_2 ... conv5_3
     assert sum(st.U3 is not None for st in t3.steps) == 8 and all(st.U2 is None for st in t3.steps)     # conv3_2 ... conv5_3
@@ -944,7 +926,8 @@ def test_stem_kernel_first_two_convolutions_equal_float64_and_separate_kernels(T
     two layers at the tolerance of the one-kernel form, and against the two separate kernels (fp32-grade: within 2e-6 of the
     largest activation).  Ragged blocks, maps narrower / lower than one block, single-block maps, block counts below / above the
     compute-unit count (several blocks per persistent workgroup), image scales."""
-    monkeypatch.setenv("CSLAM_STEM_DIRECT", "1" if direct else "0")
+    from cslam_amd.vpr import winograd as wgm
+    monkeypatch.setitem(wgm.TRUNK_FORMS, "stem_direct", bool(direct))
     torch, _ = T
     from torch import nn
     from cslam_amd.vpr.winograd import WinogradTrunk
@@ -953,12 +936,12 @@ def test_stem_kernel_first_two_convolutions_equal_float64_and_separate_kernels(T
         ([nn.MaxPool2d(2, 2)] if pool else [])
     seq = nn.Sequential(*mods).cuda().eval()
     x = (torch.rand((B, 3, H, W), device="cuda") * 4.8 - 2.2) * amp       # the range of a normalised image
-    monkeypatch.setenv("CSLAM_WINO_STEM", "1")
+    monkeypatch.setitem(wgm.TRUNK_FORMS, "wino_stem", True)
     stem = WinogradTrunk(seq, 64, 4, fused64=True)
     stem.fused_min_blocks = 0
     assert stem.steps[0].stem is not None and stem.steps[1].Uph is not None and (stem.steps[0].Wr is not None) == direct
     ys = stem(x)
-    monkeypatch.setenv("CSLAM_WINO_STEM", "0")
+    monkeypatch.setitem(wgm.TRUNK_FORMS, "wino_stem", False)
     apart = WinogradTrunk(seq, 64, 4, fused64=True)
     apart.fused_min_blocks = 0
     assert apart.steps[0].stem is None

@@ -1,5 +1,5 @@
 """conv2_1 / conv2_2 of the VGG-16 trunk at the bench's chunk: the direct one-kernel convolution on fp16 pairs (csrc/conv_direct_h.hip,
-the default) against round 3's F(4x4) forms (CSLAM_CONV_DIRECT=0), interleaved rounds, HIP-event timed.
+the default) against round 3's F(4x4) forms (forms conv_direct = 0), interleaved rounds, HIP-event timed.
     python tools/perf_direct_conv.py [frames=256]"""
 import os, sys, statistics
 import torch
@@ -14,10 +14,9 @@ for name, (cin, pool) in layers.items():
     seq = nn.Sequential(*([nn.Conv2d(cin, 128, 3, padding=1), nn.ReLU()] + ([nn.MaxPool2d(2, 2)] if pool else []))).cuda().eval()
     x = torch.relu(torch.randn((B, cin, 112, 112), device="cuda")).contiguous(memory_format=torch.channels_last)
     runners = {}
-    for tag, env in (("direct", "1"), ("wino F(4x4)", "0")):
-        os.environ["CSLAM_CONV_DIRECT"] = env
-        runners[tag] = WinogradTrunk(seq, 64, 4, fused64=True)
-        if env == "1":
+    for tag, env in (("direct", 1), ("wino F(4x4)", 0)):
+        runners[tag] = WinogradTrunk(seq, 64, 4, fused64=True, forms={"conv_direct": env})
+        if env == 1:
             runners[tag].direct_cins = (64, 128)
             runners[tag].refresh()
     res = {t: [] for t in runners}

@@ -21,15 +21,11 @@ def main():
     seq = nn.Sequential(nn.Conv2d(3, 64, 3, padding=1), nn.ReLU(), nn.Conv2d(64, 64, 3, padding=1), nn.ReLU(),
                         nn.MaxPool2d(2, 2)).cuda().eval()
     x = torch.rand((B, 3, 224, 224), device="cuda") * 4.8 - 2.2
-    os.environ["CSLAM_WINO_STEM"] = "1"
-    os.environ["CSLAM_STEM_DIRECT"] = "1"
     direct = WinogradTrunk(seq, 64, 4, fused64=True)
     assert direct.steps[0].Wr is not None
-    os.environ["CSLAM_STEM_DIRECT"] = "0"
-    stem = WinogradTrunk(seq, 64, 4, fused64=True)
+    stem = WinogradTrunk(seq, 64, 4, fused64=True, forms={"stem_direct": False})
     assert stem.steps[0].Wr is None
-    os.environ["CSLAM_WINO_STEM"] = "0"
-    apart = WinogradTrunk(seq, 64, 4, fused64=True)
+    apart = WinogradTrunk(seq, 64, 4, fused64=True, forms={"wino_stem": False})
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def t(fn, n=3):

@@ -1,28 +1,22 @@
-"""Whole NetVLAD extract passes (256 frames), interleaved A/B of trunk variants selected by environment at construction:
-    python tools/perf_trunk_ab.py "CSLAM_CONV_DIRECT=1" "CSLAM_CONV_DIRECT=2" "CSLAM_CONV_DIRECT=0" """
+"""Whole NetVLAD extract passes (256 frames), interleaved A/B of trunk variants (vpr/winograd.py TRUNK_FORMS, key=value[,key=value]):
+    python tools/perf_trunk_ab.py "conv_direct=1" "conv_direct=2" "conv_direct=0" """
 import os, sys, statistics
 import torch
 sys.path.insert(0, ".")
 from cslam_amd.vpr.netvlad import NetVLAD
 from cslam_amd import synthetic
 
-variants = sys.argv[1:] or ["CSLAM_CONV_DIRECT=1", "CSLAM_CONV_DIRECT=0"]
+variants = sys.argv[1:] or ["conv_direct=1", "conv_direct=0"]
 frames = torch.from_numpy(synthetic.frames(0, 256)).cuda()
 runners = []
 for v in variants:
-    saved = {}
+    forms = {}
     for kv in v.split(","):
         k, val = kv.split("=")
-        saved[k] = os.environ.get(k)
-        os.environ[k] = val
+        forms[k] = {"True": True, "False": False, "None": None}.get(val, int(val) if val.lstrip("-").isdigit() else val)
     ex = NetVLAD({"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376, "frontend.netvlad.pca_dim": 4096,
-                  "frontend.random_seed": 0, "frontend.backbone_conv": "winograd"}, None)
+                  "frontend.random_seed": 0, "frontend.backbone_conv": "winograd", "frontend.trunk_forms": forms}, None)
     ex.compute_embeddings_device(frames)
-    for k, val in saved.items():
-        if val is None:
-            os.environ.pop(k, None)
-        else:
-            os.environ[k] = val
     runners.append(ex)
 torch.cuda.synchronize()
 res = [[] for _ in runners]

@@ -24,7 +24,6 @@ def main():
     seq = nn.Sequential(nn.Conv2d(3, 64, 3, padding=1), nn.ReLU(), nn.Conv2d(64, 64, 3, padding=1), nn.ReLU(),
                         nn.MaxPool2d(2, 2)).cuda().eval()
     x = torch.rand((B, 3, 224, 224), device="cuda") * 4.8 - 2.2
-    os.environ["CSLAM_STEM_DIRECT"] = "1"
     tr = wg.WinogradTrunk(seq, 64, 4, fused64=True)
     assert tr.steps[0].Wr is not None
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
