@@ -649,7 +649,8 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
         HIP_TRY(hipMemcpyAsync(ws + o_ro, rs->task_off.data(), rs->task_off.size() * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(ws + o_rn, rs->qt_nseg.data(), (size_t)nqt * 4, hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(ws + o_rs, rs->qt_segoff.data(), (size_t)nqt * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemsetAsync(ws + o_ry, 0, (size_t)rs->n_xcd * 32 * 4, st));
+        // (the progress lines of the flow control: measurement-build variants only -- the default launch passes prog = nullptr)
+        if ((ring_variant & 13) && rs->wpx <= 32) HIP_TRY(hipMemsetAsync(ws + o_ry, 0, (size_t)rs->n_xcd * 32 * 4, st));
     } else {
         // patch-major order of the (query tile, segment) grid; patches of a x bseg items ~ the number
         // of workgroups resident per XCD
