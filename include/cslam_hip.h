@@ -513,7 +513,8 @@ int cslam_conv3x3_direct_hp_dev(const void *d_x, const unsigned *d_xbound, const
  * cslam/vpr/cosplace_utils/network.py:38-68, the reference's default extractor) as ONE direct kernel whose weights stay in the registers
  * of the four waves of a workgroup, 16 output channels each, the input patch arriving by LDS-DMA (csrc/conv_direct_p.hip).  The
  * contract of cslam_conv_igemm_h2p_dev with KH = KW = 3, stride = pad = 1: d_x / d_xbound the pair-format input and its bound slot
- * (x_pairs = 0: a float32 NHWC map, split while its patch is staged; no shortcut then), d_amax_in the measured max |x|; d_res optional shortcut in pair format (res_pairs, d_res_bound = its bound slot) or float32
+ * (x_pairs = 0: a float32 NHWC map, split while its patch is staged; no shortcut then), d_amax_in the measured max |x|; d_res optional
+ * shortcut in pair format (res_pairs, d_res_bound = its bound slot) or float32
  * NHWC (d_res_bound = a bound of max |res|); out_pairs: y in pair format scaled for max|x| wl1 + bmax (+ *d_res_bound) -> d_bound_out,
  * else float32 NHWC; d_amax_out (optional, zeroed) receives max |y|.  d_w2r / inv_sw = `stem_direct_pair_weights(weight)`:
  * [4 output-channel quarters][9 taps][2 K steps][hi | lo][64 lanes][8 halfs]. */
