@@ -658,6 +658,31 @@ def test_direct_conv_beside_a_stream_that_thrashes_the_l2_is_bit_identical(T, ci
             assert torch.equal(y, ref)
 
 
+def test_cosplace_extraction_beside_a_stream_that_thrashes_the_l2_is_bit_identical(T):
+    """CosPlace's whole extract pass (patch-form stem, the register-resident direct kernel of layer1 with its LDS-DMA patches and
+    deferred epilogue, the implicit GEMM's DMA rings, pair-format maps, GeM head) alone and beside a stream that keeps HBM and the L2
+    busy: the same descriptors bit for bit (every kernel of the pass either drains its requests with vmcnt(0) or counts requests that
+    every wave issues)."""
+    torch, heads = T
+    from cslam_amd.vpr.cosplace import CosPlace
+    cp = CosPlace({"frontend.nn_checkpoint": "random", "frontend.image_crop_size": 376, "frontend.cosplace.descriptor_dim": 512,
+                   "frontend.cosplace.backbone": "resnet18"}, None)
+    gen = torch.Generator(device="cuda").manual_seed(9)
+    frames = torch.randint(0, 256, (300, 240, 320, 3), generator=gen, device="cuda", dtype=torch.uint8)
+    ref = cp.compute_embeddings_device(frames)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    big = torch.zeros(64 << 20, device="cuda")
+    for _ in range(4):
+        with torch.cuda.stream(s2):
+            for _ in range(6):
+                big.add_(1.0)
+        with torch.cuda.stream(s1):
+            got = cp.compute_embeddings_device(frames)
+        torch.cuda.synchronize()
+        assert torch.equal(got, ref)
+
+
 def test_netvlad_extraction_beside_a_stream_that_thrashes_the_l2_is_bit_identical(T):
     """The whole extract pass (stem kernel, direct kernels, pair products, transforms, heads: every kernel with counted waits or
     LDS-DMA rings) beside a stream that keeps HBM and the L2 busy: the descriptors of the pass alone, bit for bit."""
