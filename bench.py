@@ -602,34 +602,13 @@ def main():
         import ctypes as C
         from cslam_amd import _lib
         lib = _lib.load()
-        eb, eh, ec = 256, 112, 128                                  # conv2_2's input at 256 frames (the PMC passes' shape)
+        eb, eh, ec = 256, 56, 128                                   # conv3_1's input at 256 frames: the transform's largest launch ON the path
         xt = torch.randn((eb, eh, eh, ec), device=dev)
         vt = torch.empty((36, eb * (eh // 4) * (eh // 4), ec), device=dev)
         st = torch.cuda.current_stream().cuda_stream
-
-        def wino_in():
-            _lib.check(lib.cslam_wino4_input_dev(xt.data_ptr(), eb, eh, eh, ec, vt.data_ptr(), st))
-        wino_in()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(5):
-            wino_in()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 5
         nbytes = (xt.numel() + vt.numel()) * 4
-        shape_in = f"x [{eb},{eh},{eh},{ec}] -> V [36,{vt.shape[1]},{ec}]"
-        pe = pmc_entry("wino4_input_kernel", shape=shape_in)
-        etraffic, esrc = (pe["traffic_bytes"], pe["source"]) if pe else (None, None)
-        gbs = nbytes / ms / 1e6
-        legacy = {"bound": "hbm", "kernel": "wino4_input_kernel", "achieved": round(gbs, 1),
-                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-                  "frac_of_measured": round(gbs / peaks["hbm_copy_GBs"], 4) if peaks["hbm_copy_GBs"] else None,
-                  "traffic": etraffic, "traffic_source": esrc, "algorithmic_bytes": nbytes,
-                  "kernel_ms": round(ms, 3), "shape": shape_in,
-                  "note": "fp32 input transform on conv2_2's shape (round 1's reference point; not on the trunk's path any more)"}
-        # what the trunk runs there today: the same transform writing V as exact fp16 hi / lo pairs (4 bytes per value, as
-        # the fp32 form) for this library's pair GEMM; conv2_2's launch, the largest of the ten per pass
+        # the trunk's input transform: B^T d B + the exact split into fp16 hi / lo pairs (4 bytes per value, as the fp32 form)
         slot = torch.zeros(1, dtype=torch.float32, device=dev)
         xh = torch.relu(xt).contiguous()
         _lib.check(lib.cslam_absmax_dev(xh.data_ptr(), xh.numel(), slot.data_ptr(), st))
@@ -652,11 +631,9 @@ def main():
                             "frac_of_measured": round(gbs2 / peaks["hbm_copy_GBs"], 4) if peaks["hbm_copy_GBs"] else None,
                             "traffic": ph["traffic_bytes"] if ph else None, "traffic_source": ph["source"] if ph else None,
                             "algorithmic_bytes": nbytes, "kernel_ms": round(ms2, 3), "shape": shape_h2,
-                            "note": "the trunk's input transform (fp16-pair V) on the shape its PMC passes were collected on (conv2_2's: "
-                                    "that layer runs through the direct kernel since round 4; the transform's largest launch in a pass "
-                                    "is conv3_1's, a quarter of this one); the other kernels of the extract pass follow: pair_gemm, "
-                                    "direct_conv, stem_conv",
-                            "fp32_input_transform": legacy}
+                            "note": "the trunk's input transform (fp16-pair V) on conv3_1's shape, its largest launch in a pass (PMC: "
+                                    "tools/pmc_wino_input_target.py through tools/pmc_kernel.sh); the other kernels of the extract pass "
+                                    "follow: pair_gemm, direct_conv, stem_conv"}
         del xt, vt, xh
         # this library's split-fp16 GEMM between the transforms (csrc/wino_gemm.hip), on the two regimes of the trunk:
         # conv3_2 (256 -> 256 channels, 50176 tile rows: HBM-bound, V2 in + M out) and conv4_2 (512 -> 512, 12544 rows:
