@@ -658,6 +658,29 @@ def test_direct_conv_beside_a_stream_that_thrashes_the_l2_is_bit_identical(T, ci
             assert torch.equal(y, ref)
 
 
+def test_pair_convolution_entry_points_reject_what_they_do_not_serve(T):
+    """Error behaviour of the round-6 entry points: shapes outside the kernels' range, a missing bound slot, a float32 input with a
+    shortcut -- CslamHipError (CSLAM_E_INVALID) with a message, nothing launched."""
+    torch, _ = T
+    import ctypes as C
+    from cslam_amd import _lib
+    lib = _lib.load()
+    z = torch.zeros(64, device="cuda")
+    pz = C.c_void_p(z.data_ptr())
+    with pytest.raises(_lib.CslamHipError, match="Cin and Cout must be 64"):
+        _lib.check(lib.cslam_conv3x3_direct_p_dev(pz, 1, pz, pz, None, None, 0, None, 1, 8, 8, 32, 64, 1, pz, 1.0, 1.0, 0.0, None, 1, pz, pz, None))
+    with pytest.raises(_lib.CslamHipError, match="bound slot"):
+        _lib.check(lib.cslam_conv3x3_direct_p_dev(pz, 1, pz, pz, None, None, 0, None, 1, 8, 8, 64, 64, 1, pz, 1.0, 1.0, 0.0, None, 1, None, pz, None))
+    with pytest.raises(_lib.CslamHipError, match="shortcut"):
+        _lib.check(lib.cslam_conv3x3_direct_p_dev(pz, 0, None, pz, None, pz, 0, pz, 1, 8, 8, 64, 64, 1, pz, 1.0, 1.0, 0.0, None, 1, pz, pz, None))
+    with pytest.raises(_lib.CslamHipError, match="NULL"):
+        _lib.check(lib.cslam_conv3x3_direct_p_dev(None, 1, pz, pz, None, None, 0, None, 1, 8, 8, 64, 64, 1, pz, 1.0, 1.0, 0.0, None, 1, pz, pz, None))
+    with pytest.raises(_lib.CslamHipError, match="pair-format output"):
+        _lib.check(lib.cslam_conv3x3_direct_r_pairs_dev(pz, pz, None, 1, 8, 8, 64, 128, pz, 1.0, 1.0, 0.0, None, None, pz, None))
+    with pytest.raises(_lib.CslamHipError, match="Cout must be 128"):
+        _lib.check(lib.cslam_conv3x3_direct_hp_dev(pz, pz, pz, None, 1, 8, 8, 128, 64, 1, 0, 1.0, None, pz, None))
+
+
 def test_cosplace_extraction_beside_a_stream_that_thrashes_the_l2_is_bit_identical(T):
     """CosPlace's whole extract pass (patch-form stem, the register-resident direct kernel of layer1 with its LDS-DMA patches and
     deferred epilogue, the implicit GEMM's DMA rings, pair-format maps, GeM head) alone and beside a stream that keeps HBM and the L2
