@@ -7,8 +7,8 @@
 // 16 w .. 16 w + 15 for all 128 pixels of a block; its 144 registers of weight fragments are loaded once per kernel; a B fragment = one
 // patch row x 32 channels at a column shift dx serves the three taps dy = 0, 1, 2: 2 fragment reads per up to 9 MFMAs; no partial sums,
 // ONE barrier per block), with what the pair format (conv_igemm.hip: [pixel][32-channel block][hi 32 | lo 32] fp16 of s x) adds:
-//   * the input patch comes by LDS-DMA (buffer_load_dwordx4 ... lds): no register, no conversion, no VALU work per value -- conv_direct_r
-//     spends 0.34 of conv2_2's 2.5 ms on the split.  A 256-byte pixel is exactly one LDS bank row; chunk s of pixel column c sits in
+//   * the input patch comes by LDS-DMA (buffer_load_dwordx4 ... lds): no register, no conversion, no VALU work per value (the float32
+//     form XF32, for the pooled stem output that opens the chain, stages and splits it like conv_direct_r.hip).  A 256-byte pixel is exactly one LDS bank row; chunk s of pixel column c sits in
 //     slot s ^ (2 c & 15): a fragment read (8 pixels of K group g, 8 of g ^ 1, consecutive columns) falls on 16 distinct slots for
 //     every column shift.  The DMA writes 64 consecutive 16-byte slots per instruction and every lane chooses its SOURCE chunk, so the
 //     swizzle costs nothing.
@@ -21,6 +21,9 @@
 //     ride in columns 0-1, this block's shortcut loads in column 0; everything vector-memory is drained by ONE s_waitcnt vmcnt(0) at the
 //     block's end, four columns after the last request.
 // Arithmetic as conv_igemm.hip: acc = wh xh + wh xl + wl xh in fp32, y = act(acc / (s_x s_w) + bias (+ shortcut)).
+// Measured (profiles/r06_*): 0.58 / 0.63 ms per 1000 frames of 56 x 56 without / with a shortcut (the implicit GEMM: 0.80 / 0.88), fabric
+// traffic 1.001 x algorithmic, SQ_LDS_BANK_CONFLICT 0; back to back it holds the board at 1399 W of its 1400 W cap: its time is its energy
+// (0.63 pJ per issued flop + the bytes) over the cap, which is why the eight-wave form (NRW = 4) and tighter schedules change nothing.
 #include <stdlib.h>
 #include <type_traits>
 #include <hip/hip_fp16.h>
