@@ -96,6 +96,14 @@ __device__ __forceinline__ void pair_tile_epilogue(f32x16 (&acc)[MT][NTW], float
 //    want DIFFERENT offsets are served by ONE insertion: the candidate vector is assembled from the comparison masks (two
 //    v_cndmask per non-empty offset, the masks are already in SGPRs), and the number of insertions of a block is the largest
 //    number of passing keys of any single lane (1-2), not the number of distinct offsets (5-16).
+// SHARED THRESHOLD (round 6).  A query column of a task has FOUR partial lists in the workgroup (two row halves of a wave x two waves along
+// the bank axis), each fed by a quarter of every tile, so each stays "young" four times as long -- and a key passes a list that has seen N
+// rows with probability KPL / N: in the in-step launch (six tiles per list) the update was still 19 % of the kernel.  `floor_thr` = the
+// largest last-entry of the four lists as last published (the sibling half by a lane exchange, the other wave through LDS, possibly one tile
+// old -- thresholds only rise): a key below it is below KPL keys of ONE partial list, so it cannot be among the query's best KPL of the task,
+// and it is below the drop bound the block merge writes (the maximum of the full lists' last entries: exactly this value at the task's end).
+// The merged list therefore still holds every key above the bound, the certificate of stage 2 sees the same bound, and the result is the
+// same bit for bit; lists that stay short because of it dropped nothing above the bound.
 // SEED (the FIRST tile of a list, round 6): with the list empty every one of a lane's 16 x MT keys passes the threshold and is inserted one
 // by one -- the first tile of the in-step launch's six-tile lists cost 1.5 x a steady one (profiles/r05_v18_in_step_tile_trace.log).  A
 // pre-pass turns the accumulators into keys (masked rows -inf, NaN +inf) and takes the two largest of every 16-key block: these are
@@ -104,7 +112,7 @@ __device__ __forceinline__ void pair_tile_epilogue(f32x16 (&acc)[MT][NTW], float
 // merge rests on.  Only keys >= t0 are inserted (about a fifth): the list that comes out is the same, entry for entry.
 template <int MT, int KPL, int NTW>
 __device__ __forceinline__ void ring_tile_epilogue(f32x16 (&acc)[MT][NTW], float (&lk)[NTW][KPL], int (&li)[NTW][KPL], const int (&lim)[NTW],
-                                                   const float (&qmul)[NTW], const float *s_inv, int row_base, bool seed = false) {
+                                                   const float (&qmul)[NTW], const float *s_inv, int row_base, bool seed, const float (&floor_thr)[NTW]) {
     // pass 1: accumulators -> keys in place (rows the query may not see: -inf; NaN: +inf, it ranks first); `seed` (wave-uniform; needs
     // 2 MT >= KPL): the smallest of the blocks' second maxima
     float t0[NTW];
@@ -146,7 +154,7 @@ __device__ __forceinline__ void ring_tile_epilogue(f32x16 (&acc)[MT][NTW], float
             float kx[16];
             unsigned long long pm[16];                           // lanes whose key at offset r passes: wave-uniform, in SGPRs
             unsigned long long any = 0;
-            const float thr = lk[n][KPL - 1];
+            const float thr = fmaxf(lk[n][KPL - 1], floor_thr[n]);     // floor_thr: the other partial lists of this query (below)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 kx[r] = acc[m][n][r];

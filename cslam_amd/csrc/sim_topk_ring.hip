@@ -61,6 +61,7 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
     // 1 / (||row|| s_row) of the current bank tile's 256 rows; two buffers by tile parity: a wave that leaves a tile's epilogue early
     // requests the next tile's values while slower waves still read this tile's (a buffer is rewritten 64 stage barriers later)
     float *const s_inv = (float *)(smem + 2 * STAGE + 16);
+    float *const s_thr = (float *)(smem + 2 * STAGE + 16 + 2048);          // [wm 2][query column 256]: last entry of a wave's two partial lists (shared threshold)
     int *const prog = (FLOW && p.prog) ? p.prog + (bid % p.n_xcd) * 32 : nullptr;      // the patch's progress line
     const int slot = bid / p.n_xcd;
 
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
         float qmul[NTW];
 #pragma unroll
         for (int n = 0; n < NTW; ++n) {
+            s_thr[wm * 256 + wn * (32 * NTW) + n * 32 + l31] = -INFINITY;  // (read by the other wave after >= 64 stage barriers)
             lim[n] = p.lim[qt * T_ + wn * (32 * NTW) + n * 32 + l31];
             lim[n] = lim[n] < tk.row_end ? lim[n] : tk.row_end;             // rows from row_end on belong to another task
             qmul[n] = p.qinvs[qt * T_ + wn * (32 * NTW) + n * 32 + l31];
@@ -367,8 +369,24 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
                     pair_tile_epilogue<MT, KPL, NTW>(acc, lk, li, lim, qmul, p.invs, p.n_rows, tile + wm * 32 * MT + 4 * h);
                 } else {
                     // (the list's first tile is seeded: sim_topk_pair_dev.h; DBG & 32, measurement build: never)
+                    // the query column's threshold as both waves last published it (sim_topk_pair_dev.h: SHARED THRESHOLD; read from LDS
+                    // per tile, not carried in registers: the kernel has none to spare)
+                    float floor_thr[NTW];
+#pragma unroll
+                    for (int n = 0; n < NTW; ++n) {
+                        const int col = wn * (32 * NTW) + n * 32 + l31;
+                        floor_thr[n] = (DBG & 32) ? -INFINITY : fmaxf(s_thr[col], s_thr[256 + col]);
+                    }
                     ring_tile_epilogue<MT, KPL, NTW>(acc, lk, li, lim, qmul, s_inv + tpar * 256 + wm * 32 * MT + 4 * h, tile + wm * 32 * MT + 4 * h,
-                                                     i == 0 && !(DBG & 32) && 2 * MT >= KPL);
+                                                     i == 0 && !(DBG & 32) && 2 * MT >= KPL, floor_thr);
+                    if (!(DBG & 32)) {
+#pragma unroll
+                        for (int n = 0; n < NTW; ++n) {                              // publish: the larger of the wave's two row halves
+                            float t = lk[n][KPL - 1];
+                            t = fmaxf(t, __shfl_xor(t, 32, 64));
+                            if (h == 0) s_thr[wm * 256 + wn * (32 * NTW) + n * 32 + l31] = t;
+                        }
+                    }
                 }
                 tpar ^= 1;
             }
@@ -476,7 +494,7 @@ void ring_schedule_build(RingSchedule &s, int nqt, int n_rows, int n_xcd, int wp
 
 // variant: bit 0 = patch flow control, bit 1 = progress-ordered wave priority
 int ring_stage1_launch(const RingArgs &a, int variant, int dbg, hipStream_t st) {
-    constexpr int lds = 2 * 2 * 256 * PK_ROWB + 16 + 2 * 1024;
+    constexpr int lds = 2 * 2 * 256 * PK_ROWB + 16 + 2 * 1024 + 2 * 1024;      // stages, pad, invs (two parities), shared thresholds
     static DeviceOnce once;
     int once_dev;
 #define RING_EACH(X) X(0, 0, 0)
