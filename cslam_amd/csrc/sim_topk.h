@@ -38,7 +38,8 @@ struct RingArgs {
     const char *bank2; int64_t ldb2;     // bank rows as fp16 (hi halves), pitch in bytes
     const float *invs; int n_rows;
     const char *q2; int64_t ldq2;        // queries as fp16 [nqt * 256][ldq2]
-    const float *qinvs;
+    const float *qinvs;                  // [nqt * 256] - 2^(17 - Es): accumulator x 1 / (||row|| s_row) -> the packed lists' integer key (sim_topk_pair_dev.h)
+    const float *qunit;                  // [nqt * 256] what one unit of that integer is worth in key units (q.b / ||b||): 2^(Es - 17) / s_query
     const int *lim;
     const int *qt_maxlim;
     int nkt;                             // K stages of 128 bytes per row
@@ -61,6 +62,8 @@ struct RingSchedule {                    // host side, cached per bank
     int sq, sb, total_lists;             // total_lists = sum of qt_nseg (lists per query, summed over query tiles)
     std::vector<RingTask> tasks;
     std::vector<int> task_off, qt_nseg, qt_segoff;
+    std::vector<char> blob;              // the four tables back to back (256-byte aligned): ONE upload per search
+    size_t off_tasks, off_task_off, off_qt_nseg, off_qt_segoff;
 };
 void ring_schedule_build(RingSchedule &s, int nqt, int n_rows, int n_xcd, int wpx);
 int ring_stage1_launch(const RingArgs &a, int variant, int dbg, hipStream_t st);
@@ -69,4 +72,5 @@ double pair_err_bound(int kd, int nprod);
 int pair_stage1_launch(const PairArgs &a, int tile, int nprod, int dbg, hipStream_t st);
 // kd = the K extent the query copy is padded to with zeros (whole stages: a multiple of 32 for pairs, of 64 for hi halves)
 int pair_prep_launch(const void *d_q, int q_dtype, int64_t ldq, int nq, int dim, int kd, int nprod, char *q2, int64_t ldq2,
-                     float *qinvs, const int64_t *d_row_limit, int n_rows, int *lim, int *qtm, int nq_pad, int tile, hipStream_t st);
+                     float *qinvs, const int64_t *d_row_limit, int n_rows, int *lim, int *qtm, int nq_pad, int tile, float *qpk, hipStream_t st);
+// qpk (or nullptr): [2][nq_pad] the persistent stage's integer-key factor and unit per query (RingArgs::qinvs / qunit)

@@ -615,7 +615,7 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = (size_t)round_up64((int64_t)(off + bytes), 256); return o; };
     size_t o_q32 = carve(direct ? 0 : (pair ? (size_t)nq_pad * ldq2 : (size_t)nq_pad * ld * 4));
-    size_t o_qs = carve(pair ? (size_t)nq_pad * 4 : 0);
+    size_t o_qs = carve(pair ? (size_t)nq_pad * 4 * (ring ? 3 : 1) : 0);        // 1 / s_query (+ the persistent stage's key factor and unit)
     size_t o_lim = carve((size_t)nq_pad * 4);
     size_t o_qtm = carve((size_t)nqt * 4);
     const size_t n_lists = ring ? (size_t)rs->total_lists * tile : (size_t)nq_pad * nseg;
@@ -625,10 +625,9 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     size_t o_fl = carve((size_t)nq * 4);
     size_t o_fc = carve(256);
     size_t o_im = carve(ring ? 0 : (size_t)nqt * nseg * 4);
-    size_t o_rt = carve(ring ? rs->tasks.size() * sizeof(RingTask) : 0);
-    size_t o_ro = carve(ring ? rs->task_off.size() * 4 : 0);
-    size_t o_rn = carve(ring ? (size_t)nqt * 4 : 0);
-    size_t o_rs = carve(ring ? (size_t)nqt * 4 : 0);
+    const size_t o_rb = carve(ring ? rs->blob.size() : 0);           // the schedule's four tables, one upload
+    const size_t o_rt = o_rb + (ring ? rs->off_tasks : 0), o_ro = o_rb + (ring ? rs->off_task_off : 0);
+    const size_t o_rn = o_rb + (ring ? rs->off_qt_nseg : 0), o_rs = o_rb + (ring ? rs->off_qt_segoff : 0);
     size_t o_ry = carve(ring ? (size_t)rs->n_xcd * 32 * 4 : 0);
     size_t o_rx = carve(ring && want_xcc ? (size_t)b->num_cu * 4 : 0);
     size_t o_rz = carve(ring && want_xcc ? ((size_t)b->num_cu * 64 + 8 * 48 * 2 + 8) * 8 : 0);
@@ -645,10 +644,7 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     int *flag_count = (int *)(ws + o_fc);
     int *item_map = (int *)(ws + o_im);
     if (ring) {
-        HIP_TRY(hipMemcpyAsync(ws + o_rt, rs->tasks.data(), rs->tasks.size() * sizeof(RingTask), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(ws + o_ro, rs->task_off.data(), rs->task_off.size() * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(ws + o_rn, rs->qt_nseg.data(), (size_t)nqt * 4, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(ws + o_rs, rs->qt_segoff.data(), (size_t)nqt * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ws + o_rb, rs->blob.data(), rs->blob.size(), hipMemcpyHostToDevice, st));
         // (the progress lines of the flow control: measurement-build variants only -- the default launch passes prog = nullptr)
         if ((ring_variant & 13) && rs->wpx <= 32) HIP_TRY(hipMemsetAsync(ws + o_ry, 0, (size_t)rs->n_xcd * 32 * 4, st));
     } else {
@@ -678,7 +674,7 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     HIP_TRY(hipMemsetAsync(flag_count, 0, 4, st));
     if (pair) {
         rc = pair_prep_launch(d_q, q_dtype, ldq, (int)nq, b->dim, kq2, nprod, ws + o_q32, ldq2, (float *)(ws + o_qs), d_row_limit,
-                              (int)b->n, lim, qtm, nq_pad, tile, st);
+                              (int)b->n, lim, qtm, nq_pad, tile, ring ? (float *)(ws + o_qs) + nq_pad : nullptr, st);
         if (rc) return rc;
     } else if (q_dtype == CSLAM_F32)
         hipLaunchKernelGGL(mfma_prep_kernel<float>, dim3(nq_pad), dim3(256), 0, st, (const float *)d_q, ldq,
@@ -702,7 +698,7 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     if (ring) {
         RingArgs ra;
         ra.bank2 = b->rowsh; ra.ldb2 = ldq2; ra.invs = b->invs; ra.n_rows = (int)b->n;
-        ra.q2 = ws + o_q32; ra.ldq2 = ldq2; ra.qinvs = (const float *)(ws + o_qs);
+        ra.q2 = ws + o_q32; ra.ldq2 = ldq2; ra.qinvs = (const float *)(ws + o_qs) + nq_pad; ra.qunit = (const float *)(ws + o_qs) + 2 * nq_pad;
         ra.lim = lim; ra.qt_maxlim = qtm; ra.nkt = b->kh / 64;
         ra.nqt = nqt; ra.sb = rs->sb; ra.n_xcd = rs->n_xcd; ra.wpx = rs->wpx;
         ra.tasks = (const RingTask *)(ws + o_rt); ra.task_off = (const int *)(ws + o_ro);
@@ -786,7 +782,8 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
     // rigorous bound on |f32 key - exact| / ||q||: kd-term fma chain (gamma_kd), inv-norm
     // rounding, key multiply rounding, query f64->f32 rounding; 2^-24 unit roundoff.
     const double u = 5.9604644775390625e-08;
-    const double err_bound = pair ? pair_err_bound(nprod == 1 ? b->kh : kd, nprod) : 1.0625 * ((double)kd + 8.0) * u;
+    // (the persistent stage's lists hold integer keys in units of <= 1.011 x 2^-16 ||q||, truncated: sim_topk_pair_dev.h)
+    const double err_bound = (pair ? pair_err_bound(nprod == 1 ? b->kh : kd, nprod) : 1.0625 * ((double)kd + 8.0) * u) + (ring ? 1.02 / 65536.0 : 0.0);
     const unsigned rgrid = (unsigned)ceil_div64(nq, 4);
     if (q_dtype == CSLAM_F32)
         hipLaunchKernelGGL(rescore_kernel<float>, dim3(rgrid), dim3(256), 0, st, b->rows, (int64_t)ld, kd, b->vv,

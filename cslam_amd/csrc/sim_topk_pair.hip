@@ -351,9 +351,10 @@ template <typename QS, int NPROD>
 __global__ __launch_bounds__(256) void pair_prep_kernel(const QS *__restrict__ q, int64_t ldq, int nq, int dim, int kd,
                                                         char *__restrict__ q2, int64_t ldq2, float *__restrict__ qinvs,
                                                         const int64_t *__restrict__ row_limit, int n_rows,
-                                                        int *__restrict__ lim, int *__restrict__ qt_maxlim, int tile) {
+                                                        int *__restrict__ lim, int *__restrict__ qt_maxlim, int tile, float *__restrict__ qpk) {
     const int row = blockIdx.x;
     __shared__ float s_max[4];
+    __shared__ float s_ss[4];
     __shared__ int s_fin[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool real = row < nq;
@@ -379,11 +380,13 @@ __global__ __launch_bounds__(256) void pair_prep_kernel(const QS *__restrict__ q
     const bool servable = finite && (amax == 0.0f || (e > -100 && e < 100));
     const float sc = (amax > 0.0f && servable) ? ldexpf(1.0f, 15 - e) : 1.0f;
     char *d2 = q2 + (size_t)row * ldq2;
+    float ss = 0.0f;                                           // || s_q q ||^2 (|s_q q| < 2^15: no overflow)
     for (int c = 4 * threadIdx.x; c < kd; c += 1024) {
         unsigned hi[2], lo[2];
         float w[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) w[t] = (real && servable && c + t < dim) ? (float)q[(size_t)row * ldq + c + t] * sc : 0.0f;
+        ss += (w[0] * w[0] + w[1] * w[1]) + (w[2] * w[2] + w[3] * w[3]);
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const __half2 hh = __floats2half2_rn(w[2 * t], w[2 * t + 1]);
@@ -397,6 +400,19 @@ __global__ __launch_bounds__(256) void pair_prep_kernel(const QS *__restrict__ q
             char *blk = d2 + (c >> 5) * 128 + (c & 31) * 2;
             *(uint2 *)blk = make_uint2(hi[0], hi[1]);
             *(uint2 *)(blk + 64) = make_uint2(lo[0], lo[1]);
+        }
+    }
+    if (qpk) {                                                 // the persistent stage's packed lists (sim_topk_pair_dev.h): integer key scale
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) ss += __shfl_xor(ss, off, 64);
+        if (lane == 0) s_ss[wave] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float nrm = sqrtf((s_ss[0] + s_ss[1]) + (s_ss[2] + s_ss[3]));
+            int es = 0;
+            if (nrm > 0.0f) (void)frexpf(nrm * 1.011f, &es);                       // 2^es > 1.011 ||s_q q|| >= |key| (1 + error bound)
+            qpk[row] = real ? (servable ? -ldexpf(1.0f, 17 - es) : NAN) : 0.0f;
+            qpk[gridDim.x + row] = servable ? ldexpf(1.0f, es - 17) / sc : INFINITY; // NaN keys rank first and unpack as +inf, as they always did
         }
     }
     if (threadIdx.x == 0) {
@@ -465,9 +481,9 @@ int pair_stage1_launch(const PairArgs &a, int tile, int nprod, int dbg, hipStrea
 }
 
 int pair_prep_launch(const void *d_q, int q_dtype, int64_t ldq, int nq, int dim, int kd, int nprod, char *q2, int64_t ldq2,
-                     float *qinvs, const int64_t *d_row_limit, int n_rows, int *lim, int *qtm, int nq_pad, int tile, hipStream_t st) {
+                     float *qinvs, const int64_t *d_row_limit, int n_rows, int *lim, int *qtm, int nq_pad, int tile, float *qpk, hipStream_t st) {
 #define PREP(QS, NP) hipLaunchKernelGGL((pair_prep_kernel<QS, NP>), dim3(nq_pad), dim3(256), 0, st, (const QS *)d_q, ldq, nq, dim, kd, \
-                                        q2, ldq2, qinvs, d_row_limit, n_rows, lim, qtm, tile)
+                                        q2, ldq2, qinvs, d_row_limit, n_rows, lim, qtm, tile, qpk)
     if (q_dtype == CSLAM_F32) { if (nprod == 1) PREP(float, 1); else PREP(float, 3); }
     else { if (nprod == 1) PREP(double, 1); else PREP(double, 3); }
 #undef PREP

@@ -85,39 +85,44 @@ __device__ __forceinline__ void pair_tile_epilogue(f32x16 (&acc)[MT][NTW], float
     }
 }
 
-// ---- tile epilogue of the persistent stage (sim_topk_ring.hip, round 5).  Same contract as pair_tile_epilogue -- every visible key of
-// the finished tile is offered to the lane's sorted list, the accumulators are cleared -- at a third of the issue slots:
-//  * 1 / (||row|| s_row) of the tile's 256 rows is in LDS (`s_inv`, fetched by LDS-DMA beside the tile's first K stage): four
-//    ds_read_b128 per 32-row block instead of sixteen global loads and their round trip;
-//  * insertions are batched ACROSS row offsets.  pair_tile_epilogue runs one 8-step insertion (~55 issue slots, the whole wave)
-//    per row offset r that ANY lane wants; with N rows seen by a list a key passes with probability KPL / N, a 16-key block of
-//    64 lanes has ~128 / t such offsets after t tiles, and a list lives for 49 tiles on the 100k x 100k batch (7 in the bench's
-//    in-step launch): the "rare" path was 18 % / 36 % of the kernel (profiles/r05_v10_no_epilogue_ablation.log).  Here lanes that
-//    want DIFFERENT offsets are served by ONE insertion: the candidate vector is assembled from the comparison masks (two
-//    v_cndmask per non-empty offset, the masks are already in SGPRs), and the number of insertions of a block is the largest
-//    number of passing keys of any single lane (1-2), not the number of distinct offsets (5-16).
-// SHARED THRESHOLD (round 6).  A query column of a task has FOUR partial lists in the workgroup (two row halves of a wave x two waves along
-// the bank axis), each fed by a quarter of every tile, so each stays "young" four times as long -- and a key passes a list that has seen N
-// rows with probability KPL / N: in the in-step launch (six tiles per list) the update was still 19 % of the kernel.  `floor_thr` = the
-// largest last-entry of the four lists as last published (the sibling half by a lane exchange, the other wave through LDS, possibly one tile
-// old -- thresholds only rise): a key below it is below KPL keys of ONE partial list, so it cannot be among the query's best KPL of the task,
-// and it is below the drop bound the block merge writes (the maximum of the full lists' last entries: exactly this value at the task's end).
-// The merged list therefore still holds every key above the bound, the certificate of stage 2 sees the same bound, and the result is the
-// same bit for bit; lists that stay short because of it dropped nothing above the bound.
-// SEED (the FIRST tile of a list, round 6): with the list empty every one of a lane's 16 x MT keys passes the threshold and is inserted one
-// by one -- the first tile of the in-step launch's six-tile lists cost 1.5 x a steady one (profiles/r05_v18_in_step_tile_trace.log).  A
-// pre-pass turns the accumulators into keys (masked rows -inf, NaN +inf) and takes the two largest of every 16-key block: these are
-// 2 MT >= KPL distinct keys of the lane, so the KPL-th largest of the tile is at least t0 = the smallest of the blocks' second maxima,
-// and a key below t0 can never be in the list -- nor above the list's last entry, which is what the dropped-keys bound of the block
-// merge rests on.  Only keys >= t0 are inserted (about a fifth): the list that comes out is the same, entry for entry.
+// ---- tile epilogue of the persistent stage (sim_topk_ring.hip), PACKED lists (round 6).  Same contract as pair_tile_epilogue -- every
+// visible key of the finished tile is offered to the lane's sorted list, the accumulators are cleared.
+//
+// What the update cost before.  A key passes a list that has seen N rows with probability KPL / N, and the in-step launch's lists live six
+// tiles: with 64 independent lists in a wave, SOME lane wanted an insertion at more than half of all row offsets, and every such offset
+// cost the whole wave a predicated 8-step insertion of a (key, index) pair (~40 issue slots; round 5 batched lanes that want different
+// offsets into one insertion, round 6 seeded the first tile and shared the threshold: the update was still 16 % of the in-step launch).
+//
+// Packed entries.  A list entry is ONE 32-bit integer: (-key in units of `unit`) << 13 | (position of the row in the task, 13 bits),
+// smaller = better, RING_EMPTY = nothing.  Inserting x into the ascending list l is then l'[j] = median(l[j-1], l[j], x) for every j
+// (l'[0] = min(l[0], x)): eight INDEPENDENT v_med3_i32 / v_min_i32, no predicate, no index to move, and a key that does not belong
+// leaves the list unchanged -- so no per-lane mask either.  The only test left is wave-wide ("does any lane's key beat its threshold":
+// one v_cmp + a scalar branch) against the list's last entry as of the 16-key block's start (a stale one only lets extra keys through,
+// harmlessly).
+//  * key units: the query's prep (pair_prep_kernel) delivers `qmul` = -2^(17 - Es) with 2^Es >= 1.01 ||s_q q||, so |key| < 2^18 always and
+//    `unit` = 2^(Es - 17) / s_q (a power of two: packing and unpacking are exact) <= 1.011 x 2^-16 ||q||.  Truncation moves a key by less than
+//    one unit: the host adds 1.02 x 2^-16 to the stage's error bound (pair_err_bound: 1.57e-3 at 4096-D; + 1 %), which covers the keys the
+//    merge writes AND its drop bound (a dropped key's integer is >= the bound's).
+//  * NaN keys (non-finite rows / unservable queries) must rank first: v_med3_f32 returns the MINIMUM of its other two operands when one
+//    is NaN -- the clamp that bounds the integer delivers "-largest key", i.e. best, for free (pinned by the non-finite-row tests).
+//  * positions: tile ordinal in the task (7 bits: ring_schedule_build cuts tasks at 128 tiles) << 6 | 32-row block << 4 | accumulator
+//    register; the block merge turns them back into bank rows.
+//  * 1 / (||row|| s_row) of the tile's 256 rows is in LDS (`s_inv`, fetched by LDS-DMA beside the tile's first K stage).
+// Measured with these lists and dropped: a threshold shared by the four partial lists of a query column (two row halves of a wave x two
+// waves along the bank axis; -4 % in step with the old insertion) buys nothing once an insertion costs eight instructions
+// (profiles/r06_s_ring_packed_ab.log), and the seeded first tile has nothing left to save.
+#define RING_IDX_BITS 13
+#define RING_KF_MAX 262142           // |integer key| bound: (RING_KF_MAX << 13 | 8191) < RING_EMPTY
+#define RING_EMPTY 0x7fffffff
+__device__ __forceinline__ int ring_med3(int a, int b, int c) {
+    int d;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+
 template <int MT, int KPL, int NTW>
-__device__ __forceinline__ void ring_tile_epilogue(f32x16 (&acc)[MT][NTW], float (&lk)[NTW][KPL], int (&li)[NTW][KPL], const int (&lim)[NTW],
-                                                   const float (&qmul)[NTW], const float *s_inv, int row_base, bool seed, const float (&floor_thr)[NTW]) {
-    // pass 1: accumulators -> keys in place (rows the query may not see: -inf; NaN: +inf, it ranks first); `seed` (wave-uniform; needs
-    // 2 MT >= KPL): the smallest of the blocks' second maxima
-    float t0[NTW];
-#pragma unroll
-    for (int n = 0; n < NTW; ++n) t0[n] = seed ? INFINITY : -INFINITY;
+__device__ __forceinline__ void ring_tile_epilogue(f32x16 (&acc)[MT][NTW], int (&lp)[NTW][KPL], const int (&lim)[NTW], const float (&qmul)[NTW],
+                                                   const float *s_inv, int row_base, int idx_base) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
         float inv[16];
@@ -129,69 +134,72 @@ __device__ __forceinline__ void ring_tile_epilogue(f32x16 (&acc)[MT][NTW], float
 #pragma unroll
         for (int n = 0; n < NTW; ++n) {
             const int rel_lim = lim[n] - (row_base + m * 32);   // row < lim  <=>  rowoff < rel_lim
+            const int thr = lp[n][KPL - 1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float k = (acc[m][n][r] * inv[r]) * qmul[n];
-                k = (k != k) ? INFINITY : k;
-                acc[m][n][r] = (((r & 3) + 8 * (r >> 2)) < rel_lim) ? k : -INFINITY;
-            }
-            if (seed) {
-                float m1 = -INFINITY, m2 = -INFINITY;
+                float k = (acc[m][n][r] * inv[r]) * qmul[n];                       // - key / unit
+                acc[m][n][r] = 0.0f;
+                k = __builtin_amdgcn_fmed3f(k, -(float)RING_KF_MAX, (float)RING_KF_MAX);      // NaN -> -RING_KF_MAX: ranks first
+                int x = (int)(((unsigned)(int)k << RING_IDX_BITS) | (unsigned)(idx_base + m * 16 + r));
+                x = (((r & 3) + 8 * (r >> 2)) < rel_lim) ? x : RING_EMPTY;           // rows the query may not see
+                if (__builtin_amdgcn_ballot_w64(x < thr) != 0) {                     // wave-uniform
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    m2 = fmaxf(m2, fminf(m1, acc[m][n][r]));
-                    m1 = fmaxf(m1, acc[m][n][r]);
+                    for (int j = KPL - 1; j > 0; --j) lp[n][j] = ring_med3(lp[n][j - 1], lp[n][j], x);
+                    lp[n][0] = x < lp[n][0] ? x : lp[n][0];
                 }
-                t0[n] = fminf(t0[n], m2);
             }
         }
     }
-    // pass 2: the keys above the list's last entry (and not below the seed) are inserted
+}
+
+// ---- block merge of the packed lists: 4 per query (2 row halves of a wave x 2 waves along the bank axis) -> the best SIM_KP of them as
+// (key, bank row), plus the bound on everything dropped; the LDS of the K loop is reused.  Query `tid` of the tile writes its list at
+// out_key / out_idx + (tid * qstride) * SIM_KP and its bound at out_bound[tid * qstride] (qstride = lists per query).
+template <int T_, int MT, int KPL, int NTW>
+__device__ __forceinline__ void ring_block_merge(char *smem, int (&lp)[NTW][KPL], int wn, int wm, int h, int l31, int tid, int row0, int stride_rows,
+                                                 const float *__restrict__ qunit, float *__restrict__ out_key, int *__restrict__ out_idx,
+                                                 float *__restrict__ out_bound, size_t qstride) {
+    __syncthreads();
+    int *mk = (int *)smem;                           // [T_][4][KPL]
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
+    for (int n = 0; n < NTW; ++n) {
+        const int qcol = wn * (32 * NTW) + n * 32 + l31;
+        const int src = wm * 2 + h;
 #pragma unroll
-        for (int n = 0; n < NTW; ++n) {
-            float kx[16];
-            unsigned long long pm[16];                           // lanes whose key at offset r passes: wave-uniform, in SGPRs
-            unsigned long long any = 0;
-            const float thr = fmaxf(lk[n][KPL - 1], floor_thr[n]);     // floor_thr: the other partial lists of this query (below)
+        for (int j = 0; j < KPL; ++j) mk[(qcol * 4 + src) * KPL + j] = lp[n][j];
+    }
+    __syncthreads();
+    if (tid < T_) {
+        const int *k0 = mk + (tid * 4) * KPL;
+        const float unit = qunit[tid];
+        int p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+        const size_t o = ((size_t)tid * qstride) * SIM_KP;
+        int bound = RING_EMPTY;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                kx[r] = acc[m][n][r];
-                pm[r] = __ballot(!(kx[r] <= thr) && !(kx[r] < t0[n]));
-                any |= pm[r];
-                acc[m][n][r] = 0.0f;
-            }
-            while (any) {
-                // one round: every lane with a passing key left contributes ONE of them (its lowest offset)
-                float ck = -INFINITY;
-                int ci = 0;
-                unsigned long long taken = 0;
-                any = 0;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (pm[r]) {                                 // scalar test
-                        const unsigned long long mine = pm[r] & ~taken;
-                        const bool sel = __builtin_amdgcn_inverse_ballot_w64(mine);
-                        ck = sel ? kx[r] : ck;
-                        ci = sel ? (r & 3) + 8 * (r >> 2) : ci;
-                        taken |= mine;
-                        pm[r] &= ~mine;
-                        any |= pm[r];
-                    }
-                }
-                ci += row_base + m * 32;
-#pragma unroll
-                for (int j = 0; j < KPL; ++j) {                  // lanes outside `taken` carry -inf: nothing moves
-                    const bool sw = ck > lk[n][j];
-                    const float tk = sw ? lk[n][j] : ck;
-                    const int ti = sw ? li[n][j] : ci;
-                    lk[n][j] = sw ? ck : lk[n][j];
-                    li[n][j] = sw ? ci : li[n][j];
-                    ck = tk; ci = ti;
-                }
-            }
+        for (int s = 0; s < 4; ++s) bound = k0[s * KPL + KPL - 1] < bound ? k0[s * KPL + KPL - 1] : bound;     // a full lane list dropped keys
+        for (int j = 0; j < SIM_KP; ++j) {
+            const int c0 = p0 < KPL ? k0[p0] : RING_EMPTY;
+            const int c1 = p1 < KPL ? k0[KPL + p1] : RING_EMPTY;
+            const int c2 = p2 < KPL ? k0[2 * KPL + p2] : RING_EMPTY;
+            const int c3 = p3 < KPL ? k0[3 * KPL + p3] : RING_EMPTY;
+            int best = 0, bk = c0;
+            if (c1 < bk) { bk = c1; best = 1; }
+            if (c2 < bk) { bk = c2; best = 2; }
+            if (c3 < bk) { bk = c3; best = 3; }
+            if (best == 0) ++p0; else if (best == 1) ++p1; else if (best == 2) ++p2; else ++p3;
+            const int pos = bk & ((1 << RING_IDX_BITS) - 1);
+            const int rr = pos & 15;
+            const int row = row0 + (pos >> 6) * stride_rows + (best >> 1) * (32 * MT) + ((pos >> 4) & 3) * 32 + 4 * (best & 1) + (rr & 3) + 8 * (rr >> 2);
+            out_key[o + j] = bk == RING_EMPTY ? -INFINITY : -(float)(bk >> RING_IDX_BITS) * unit;
+            out_idx[o + j] = bk == RING_EMPTY ? -1 : row;
         }
+        const int c0 = p0 < KPL ? k0[p0] : RING_EMPTY, c1 = p1 < KPL ? k0[KPL + p1] : RING_EMPTY;
+        const int c2 = p2 < KPL ? k0[2 * KPL + p2] : RING_EMPTY, c3 = p3 < KPL ? k0[3 * KPL + p3] : RING_EMPTY;
+        int d = c0 < c1 ? c0 : c1;
+        d = c2 < d ? c2 : d;
+        d = c3 < d ? c3 : d;
+        bound = d < bound ? d : bound;
+        out_bound[(size_t)tid * qstride] = bound == RING_EMPTY ? -INFINITY : -(float)(bound >> RING_IDX_BITS) * unit;
     }
 }
 

@@ -36,7 +36,7 @@
 
 // KPL = per-lane candidate list length.  DBG (measurement build, timing only; a bit mask): 1 = no global loads after the first stage
 // (every stage re-reads the first one), 2 = every request reads bank tile 0 / query tile 0 (L2 hits), 4 = no stage barrier (with 1),
-// 8 = no candidate update, 16 = round 4's tile epilogue.  FLOW = patch flow control.  PRIO = progress-ordered wave priority: a stage's four groups of 8 MFMAs run at
+// 8 = no candidate update.  FLOW = patch flow control.  PRIO = progress-ordered wave priority: a stage's four groups of 8 MFMAs run at
 // s_setprio 3, 2, 1, 0.  The arbiter takes priority first, age second: at equal priority the older wave of a SIMD issues its WHOLE
 // stage first and parks at the barrier ~1000 cycles before its partner, which then runs alone with nobody to fill its issue gaps
 // (2420 cycles per 2048-cycle stage, profiles/r05_v8_barrier_trace.log); with the wave that is BEHIND always at the higher
@@ -61,7 +61,6 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
     // 1 / (||row|| s_row) of the current bank tile's 256 rows; two buffers by tile parity: a wave that leaves a tile's epilogue early
     // requests the next tile's values while slower waves still read this tile's (a buffer is rewritten 64 stage barriers later)
     float *const s_inv = (float *)(smem + 2 * STAGE + 16);
-    float *const s_thr = (float *)(smem + 2 * STAGE + 16 + 2048);          // [wm 2][query column 256]: last entry of a wave's two partial lists (shared threshold)
     int *const prog = (FLOW && p.prog) ? p.prog + (bid % p.n_xcd) * 32 : nullptr;      // the patch's progress line
     const int slot = bid / p.n_xcd;
 
@@ -107,16 +106,15 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
             const int vis = ml > tk.row0 ? (ml - tk.row0 + tk.stride_rows - 1) / tk.stride_rows : 0;
             if (ntiles > vis) ntiles = vis;
         }
-        float lk[NTW][KPL]; int li[NTW][KPL];
+        int lp[NTW][KPL];                                                   // packed candidate lists (sim_topk_pair_dev.h), ascending
 #pragma unroll
         for (int n = 0; n < NTW; ++n)
 #pragma unroll
-            for (int j = 0; j < KPL; ++j) { lk[n][j] = -INFINITY; li[n][j] = -1; }
+            for (int j = 0; j < KPL; ++j) lp[n][j] = RING_EMPTY;
         int lim[NTW];
         float qmul[NTW];
 #pragma unroll
         for (int n = 0; n < NTW; ++n) {
-            s_thr[wm * 256 + wn * (32 * NTW) + n * 32 + l31] = -INFINITY;  // (read by the other wave after >= 64 stage barriers)
             lim[n] = p.lim[qt * T_ + wn * (32 * NTW) + n * 32 + l31];
             lim[n] = lim[n] < tk.row_end ? lim[n] : tk.row_end;             // rows from row_end on belong to another task
             qmul[n] = p.qinvs[qt * T_ + wn * (32 * NTW) + n * 32 + l31];
@@ -361,32 +359,13 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
                         for (int n = 0; n < NTW; ++n) {
-                            lk[n][0] = fmaxf(lk[n][0], acc[m][n][0] + acc[m][n][7]);
+                            const int v = (int)(acc[m][n][0] + acc[m][n][7]);
+                            lp[n][0] = v < lp[n][0] ? v : lp[n][0];
 #pragma unroll
                             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
                         }
-                } else if (DBG & 16) {                                   // measurement build: round 4's epilogue
-                    pair_tile_epilogue<MT, KPL, NTW>(acc, lk, li, lim, qmul, p.invs, p.n_rows, tile + wm * 32 * MT + 4 * h);
                 } else {
-                    // (the list's first tile is seeded: sim_topk_pair_dev.h; DBG & 32, measurement build: never)
-                    // the query column's threshold as both waves last published it (sim_topk_pair_dev.h: SHARED THRESHOLD; read from LDS
-                    // per tile, not carried in registers: the kernel has none to spare)
-                    float floor_thr[NTW];
-#pragma unroll
-                    for (int n = 0; n < NTW; ++n) {
-                        const int col = wn * (32 * NTW) + n * 32 + l31;
-                        floor_thr[n] = (DBG & 32) ? -INFINITY : fmaxf(s_thr[col], s_thr[256 + col]);
-                    }
-                    ring_tile_epilogue<MT, KPL, NTW>(acc, lk, li, lim, qmul, s_inv + tpar * 256 + wm * 32 * MT + 4 * h, tile + wm * 32 * MT + 4 * h,
-                                                     i == 0 && !(DBG & 32) && 2 * MT >= KPL, floor_thr);
-                    if (!(DBG & 32)) {
-#pragma unroll
-                        for (int n = 0; n < NTW; ++n) {                              // publish: the larger of the wave's two row halves
-                            float t = lk[n][KPL - 1];
-                            t = fmaxf(t, __shfl_xor(t, 32, 64));
-                            if (h == 0) s_thr[wm * 256 + wn * (32 * NTW) + n * 32 + l31] = t;
-                        }
-                    }
+                    ring_tile_epilogue<MT, KPL, NTW>(acc, lp, lim, qmul, s_inv + tpar * 256 + wm * 32 * MT + 4 * h, tile + wm * 32 * MT + 4 * h, i << 6);
                 }
                 tpar ^= 1;
             }
@@ -397,8 +376,8 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
         {
             const int ns = p.qt_nseg[qt];
             const size_t l0 = (size_t)p.qt_segoff[qt] * T_ + tk.seg;         // list `seg` of the tile's first query
-            pair_block_merge<T_, KPL, NTW>(smem, lk, li, wn, wm, h, l31, tid, p.part_key + l0 * SIM_KP, p.part_idx + l0 * SIM_KP,
-                                           p.part_bound + l0, (size_t)ns);
+            ring_block_merge<T_, MT, KPL, NTW>(smem, lp, wn, wm, h, l31, tid, tk.row0, tk.stride_rows, p.qunit + qt * T_, p.part_key + l0 * SIM_KP,
+                                               p.part_idx + l0 * SIM_KP, p.part_bound + l0, (size_t)ns);
         }
         __syncthreads();                                                 // the merge's LDS is the next task's first stage
     }
@@ -422,12 +401,17 @@ void ring_schedule_build(RingSchedule &s, int nqt, int n_rows, int n_xcd, int wp
     struct Run { int g; int ra, rb; int r; };
     std::vector<std::vector<Run>> runs(n_xcd);
     std::vector<int> group_runs(ngroups, 0);
+    // a task's candidate lists address its rows with 13 bits (sim_topk_pair_dev.h: 128 tiles): longer runs are cut into equal pieces
+    const long long max_run = (long long)sb * (128 * 256 - 32);          // the chunk of a patch column is rounded up to 32 rows
+    auto add_run = [&](int x, int g, long long ra, long long rb) {
+        const long long len = rb - ra;
+        const int pieces = len > max_run ? (int)((len + max_run - 1) / max_run) : 1;
+        long long piece = ((len + pieces - 1) / pieces + 31) / 32 * 32;
+        for (long long a = ra; a < rb; a += piece) runs[x].push_back(Run{g, (int)a, (int)(a + piece < rb ? a + piece : rb), group_runs[g]++});
+    };
     const int full = ngroups / n_xcd;
     for (int i = 0; i < full; ++i)
-        for (int x = 0; x < n_xcd; ++x) {
-            const int g = i * n_xcd + x;
-            runs[x].push_back(Run{g, 0, n_rows, group_runs[g]++});
-        }
+        for (int x = 0; x < n_xcd; ++x) add_run(x, i * n_xcd + x, 0, n_rows);
     // the groups that do not fill a round of XCDs: their rows (group-major) are dealt out evenly, cut points on multiples of 32 rows
     const int gtail = ngroups - full * n_xcd;
     if (gtail > 0) {
@@ -446,7 +430,7 @@ void ring_schedule_build(RingSchedule &s, int nqt, int n_rows, int n_xcd, int wp
                 const int g = full * n_xcd + (int)(lo / n_rows);
                 long long end = (lo / n_rows + 1) * n_rows;
                 if (end > hi) end = hi;
-                runs[x].push_back(Run{g, (int)(lo % n_rows), (int)(lo % n_rows + (end - lo)), group_runs[g]++});
+                add_run(x, g, lo % n_rows, lo % n_rows + (end - lo));
                 lo = end;
             }
         }
@@ -490,18 +474,29 @@ void ring_schedule_build(RingSchedule &s, int nqt, int n_rows, int n_xcd, int wp
             }
         }
     s.task_off[(size_t)n_xcd * wpx] = (int)s.tasks.size();
+    size_t off = 0;
+    auto place = [&](size_t bytes) { size_t o = off; off = (off + bytes + 255) / 256 * 256; return o; };
+    s.off_tasks = place(s.tasks.size() * sizeof(RingTask));
+    s.off_task_off = place(s.task_off.size() * 4);
+    s.off_qt_nseg = place((size_t)nqt * 4);
+    s.off_qt_segoff = place((size_t)nqt * 4);
+    s.blob.assign(off, 0);
+    memcpy(s.blob.data() + s.off_tasks, s.tasks.data(), s.tasks.size() * sizeof(RingTask));
+    memcpy(s.blob.data() + s.off_task_off, s.task_off.data(), s.task_off.size() * 4);
+    memcpy(s.blob.data() + s.off_qt_nseg, s.qt_nseg.data(), (size_t)nqt * 4);
+    memcpy(s.blob.data() + s.off_qt_segoff, s.qt_segoff.data(), (size_t)nqt * 4);
 }
 
 // variant: bit 0 = patch flow control, bit 1 = progress-ordered wave priority
 int ring_stage1_launch(const RingArgs &a, int variant, int dbg, hipStream_t st) {
-    constexpr int lds = 2 * 2 * 256 * PK_ROWB + 16 + 2 * 1024 + 2 * 1024;      // stages, pad, invs (two parities), shared thresholds
+    constexpr int lds = 2 * 2 * 256 * PK_ROWB + 16 + 2 * 1024;      // stages, pad, invs (two parities)
     static DeviceOnce once;
     int once_dev;
 #define RING_EACH(X) X(0, 0, 0)
 #ifdef CSLAM_ABLATIONS
     // variants (flow control, wave priorities), timing-only ablations, cache policies of the requests: bank nt / query nt / both / bank sc1 / ...
-#define RING_EACH_DBG(X) X(0, 1, 0) X(0, 0, 1) X(0, 1, 1) X(0, 2, 0) X(0, 3, 0) X(2, 0, 0) X(8, 0, 0) X(9, 0, 0) X(10, 0, 0) X(13, 0, 0) X(16, 0, 0) X(33, 0, 0) X(33, 0, 1) X(9, 0, 1) X(10, 0, 1) \
-    X(128, 0, 0) X(1024, 0, 0) X(1152, 0, 0) X(256, 0, 0) X(2048, 0, 0) X(64, 0, 0) X(512, 0, 0) X(32, 0, 0)
+#define RING_EACH_DBG(X) X(0, 1, 0) X(0, 0, 1) X(0, 1, 1) X(0, 2, 0) X(0, 3, 0) X(2, 0, 0) X(8, 0, 0) X(9, 0, 0) X(10, 0, 0) X(13, 0, 0) X(33, 0, 0) X(33, 0, 1) X(9, 0, 1) X(10, 0, 1) \
+    X(128, 0, 0) X(1024, 0, 0) X(1152, 0, 0) X(256, 0, 0) X(2048, 0, 0) X(64, 0, 0) X(512, 0, 0)
 #else
 #define RING_EACH_DBG(X)
 #endif

@@ -101,7 +101,8 @@ def _ring_schedule(lib, nqt, n_rows, n_xcd=8, wpx=32):
 
 
 @pytest.mark.parametrize("nqt,n_rows", [(391, 100_000), (4, 100_000), (1, 100_000), (2, 1200), (3, 10_000), (7, 50_000), (64, 100_000),
-                                        (391, 700), (33, 4321), (5, 256), (128, 50_000), (8, 125_000), (4, 31)])
+                                        (391, 700), (33, 4321), (5, 256), (128, 50_000), (8, 125_000), (4, 31), (2, 1_000_000),
+                                        (32, 300_000)])
 def test_ring_schedule_covers_every_pair_once_and_balances_the_xcds(nqt, n_rows):
     """The static schedule of the persistent candidate stage (csrc/sim_topk_ring.hip): every (query tile, bank row) pair belongs to
     exactly one task, a query tile's lists are numbered 0 .. qt_nseg - 1 without gaps, the per-tile list offsets are the running
@@ -117,6 +118,7 @@ def test_ring_schedule_covers_every_pair_once_and_balances_the_xcds(nqt, n_rows)
     for w in range(n_xcd * wpx):
         for qt, row0, ntiles, seg, run, stride, row_end, _ in tasks[off[w]:off[w + 1]]:
             assert 0 <= qt < nqt and ntiles >= 0 and run >= 0 and row_end <= n_rows and stride >= 256 and stride % 256 == 0
+            assert ntiles <= 128, "the packed candidate lists address a task's rows with 13 bits (csrc/sim_topk_pair_dev.h)"
             for i in range(ntiles):
                 a = row0 + i * stride
                 b = min(a + 256, row_end)

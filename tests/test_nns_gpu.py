@@ -194,10 +194,12 @@ def test_full_size_bank_properties(nnm):
     assert np.max(np.abs(sims[:6].cpu().numpy() - os_)) < 1e-12
 
 
-@pytest.mark.parametrize("n,d,nq,k,f64", [(9000, 64, 8300, 5, False), (8200, 96, 8192, 8, True)])
+@pytest.mark.parametrize("n,d,nq,k,f64", [(9000, 64, 8300, 5, False), (8200, 96, 8192, 8, True), (300_000, 64, 1024, 5, False)])
 def test_large_tile_path_vs_oracle(nnm, n, d, nq, k, f64):
     """Large batches on the 256x256 MFMA tile (8 waves, per-lane lists of 8 with
-    explicit drop bounds): ragged tile edges, causal limits, float64 queries."""
+    explicit drop bounds): ragged tile edges, causal limits, float64 queries.  300 000 rows against four query tiles: a patch
+    column's share of the bank is longer than the 128 tiles the packed candidate lists of the persistent stage can address, so
+    the schedule cuts the walk into two runs (csrc/sim_topk_ring.hip)."""
     bank = unit_rows(np.random.default_rng(n), n, d)
     q = unit_rows(np.random.default_rng(n + 1), nq, d)
     if f64:
@@ -582,14 +584,15 @@ def test_fp16_pair_candidate_stage_error_is_inside_the_certificates_bound(nnm, m
         if stage == "h1":
             kh = (d + 63) // 64 * 64
             # the one-product bound: two fp16 roundings (2^-10, Cauchy-Schwarz) + kh fp32 additions
-            assert 2.0 ** -10 + kh * 2.0 ** -23 < bound < 1.07 * (2.0 ** -10 + 1.01 * (kh + 64) * 2.0 ** -23) + 3e-6
+            # (+ one unit of the persistent stage's integer keys: 1.02 x 2^-16)
+            assert 2.0 ** -10 + kh * 2.0 ** -23 < bound < 1.07 * (2.0 ** -10 + 1.01 * (kh + 64) * 2.0 ** -23) + 3e-6 + 1.02 * 2.0 ** -16
             assert worst < 2.0 ** -11, worst                    # what the arithmetic really does: random-sign fp16 roundings
     oi, os_, oc = pyoracle.nns_search(bank, q, 5)
     for stage in ("h1", "pair", "f32"):
         assert_topk_equal(out[stage][0], out[stage][1], out[stage][2], oi, os_, oc, 1e-12)
     assert out["pair"][3] > out["f32"][3] and out["h1"][3] > out["f32"][3]
     if d == 4096:
-        assert abs(out["h1"][3] / out["pair"][3] - 1.0) < 0.01  # same window for stage 2: 1.566e-3 against 1.570e-3
+        assert abs(out["h1"][3] / out["pair"][3] - 1.0) < 0.01  # same window for stage 2: 1.582e-3 against 1.570e-3
 
 
 def test_clustered_near_duplicates_stay_exact_and_back_off_to_the_f32_stage(nnm, monkeypatch):
