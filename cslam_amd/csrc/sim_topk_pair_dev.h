@@ -97,8 +97,7 @@ __device__ __forceinline__ void pair_tile_epilogue(f32x16 (&acc)[MT][NTW], float
 // smaller = better, RING_EMPTY = nothing.  Inserting x into the ascending list l is then l'[j] = median(l[j-1], l[j], x) for every j
 // (l'[0] = min(l[0], x)): eight INDEPENDENT v_med3_i32 / v_min_i32, no predicate, no index to move, and a key that does not belong
 // leaves the list unchanged -- so no per-lane mask either.  The only test left is wave-wide ("does any lane's key beat its threshold":
-// one v_cmp + a scalar branch) against the list's last entry as of the 16-key block's start (a stale one only lets extra keys through,
-// harmlessly).
+// one v_cmp against the list's last entry + a scalar branch).
 //  * key units: the query's prep (pair_prep_kernel) delivers `qmul` = -2^(17 - Es) with 2^Es >= 1.01 ||s_q q||, so |key| < 2^18 always and
 //    `unit` = 2^(Es - 17) / s_q (a power of two: packing and unpacking are exact) <= 1.011 x 2^-16 ||q||.  Truncation moves a key by less than
 //    one unit: the host adds 1.02 x 2^-16 to the stage's error bound (pair_err_bound: 1.57e-3 at 4096-D; + 1 %), which covers the keys the
@@ -120,32 +119,40 @@ __device__ __forceinline__ int ring_med3(int a, int b, int c) {
     return d;
 }
 
-template <int MT, int KPL, int NTW>
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// MASKED = some row of the wave's 32 MT rows may be invisible to some query of the wave (a causal limit, the task's end row): the tiles
+// that are not -- all but the last one or two of a walk -- skip the two instructions per key of that test.
+template <int MT, int KPL, int NTW, bool MASKED>
 __device__ __forceinline__ void ring_tile_epilogue(f32x16 (&acc)[MT][NTW], int (&lp)[NTW][KPL], const int (&lim)[NTW], const float (&qmul)[NTW],
                                                    const float *s_inv, int row_base, int idx_base) {
 #pragma unroll
     for (int m = 0; m < MT; ++m) {
-        float inv[16];
+        f32x2 inv2[8];                                                              // rows 8 q + {0 1}, {2 3} of this lane's half
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float4 v = *(const float4 *)(s_inv + m * 32 + 8 * q);          // rows 8 q + {0 1 2 3} of this lane's half
-            inv[4 * q] = v.x; inv[4 * q + 1] = v.y; inv[4 * q + 2] = v.z; inv[4 * q + 3] = v.w;
+            const float4 v = *(const float4 *)(s_inv + m * 32 + 8 * q);
+            inv2[2 * q] = f32x2{v.x, v.y}; inv2[2 * q + 1] = f32x2{v.z, v.w};
         }
 #pragma unroll
         for (int n = 0; n < NTW; ++n) {
             const int rel_lim = lim[n] - (row_base + m * 32);   // row < lim  <=>  rowoff < rel_lim
-            const int thr = lp[n][KPL - 1];
+            const f32x2 qm2 = f32x2{qmul[n], qmul[n]};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float k = (acc[m][n][r] * inv[r]) * qmul[n];                       // - key / unit
-                acc[m][n][r] = 0.0f;
-                k = __builtin_amdgcn_fmed3f(k, -(float)RING_KF_MAX, (float)RING_KF_MAX);      // NaN -> -RING_KF_MAX: ranks first
-                int x = (int)(((unsigned)(int)k << RING_IDX_BITS) | (unsigned)(idx_base + m * 16 + r));
-                x = (((r & 3) + 8 * (r >> 2)) < rel_lim) ? x : RING_EMPTY;           // rows the query may not see
-                if (__builtin_amdgcn_ballot_w64(x < thr) != 0) {                     // wave-uniform
+            for (int r2 = 0; r2 < 8; ++r2) {
+                f32x2 k2 = (f32x2{acc[m][n][2 * r2], acc[m][n][2 * r2 + 1]} * inv2[r2]) * qm2;               // - key / unit
+                asm("" : "+v"(k2));                  // (the pair is used AS a pair: hipcc keeps the two v_pk_mul_f32 instead of four v_mul_f32)
+                acc[m][n][2 * r2] = 0.0f; acc[m][n][2 * r2 + 1] = 0.0f;
 #pragma unroll
-                    for (int j = KPL - 1; j > 0; --j) lp[n][j] = ring_med3(lp[n][j - 1], lp[n][j], x);
-                    lp[n][0] = x < lp[n][0] ? x : lp[n][0];
+                for (int e = 0; e < 2; ++e) {
+                    const int r = 2 * r2 + e;
+                    const float k = __builtin_amdgcn_fmed3f(k2[e], -(float)RING_KF_MAX, (float)RING_KF_MAX);   // NaN -> -RING_KF_MAX: ranks first
+                    int x = (int)(((unsigned)(int)k << RING_IDX_BITS) | (unsigned)(idx_base + m * 16 + r));
+                    if (MASKED) x = (((r & 3) + 8 * (r >> 2)) < rel_lim) ? x : RING_EMPTY;                      // rows the query may not see
+                    if (__builtin_amdgcn_ballot_w64(x < lp[n][KPL - 1]) != 0) {                                  // wave-uniform
+#pragma unroll
+                        for (int j = KPL - 1; j > 0; --j) lp[n][j] = ring_med3(lp[n][j - 1], lp[n][j], x);
+                        lp[n][0] = x < lp[n][0] ? x : lp[n][0];
+                    }
                 }
             }
         }

@@ -365,7 +365,15 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
                             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
                         }
                 } else {
-                    ring_tile_epilogue<MT, KPL, NTW>(acc, lp, lim, qmul, s_inv + tpar * 256 + wm * 32 * MT + 4 * h, tile + wm * 32 * MT + 4 * h, i << 6);
+                    // (wave-uniform) every query of the wave sees every row of the wave's part of this tile: no per-key visibility test
+                    const int wave_end = tile + (wm + 1) * 32 * MT;
+                    bool masked = false;
+#pragma unroll
+                    for (int n = 0; n < NTW; ++n) masked |= lim[n] < wave_end;
+                    if (__builtin_amdgcn_ballot_w64(masked) != 0)
+                        ring_tile_epilogue<MT, KPL, NTW, true>(acc, lp, lim, qmul, s_inv + tpar * 256 + wm * 32 * MT + 4 * h, tile + wm * 32 * MT + 4 * h, i << 6);
+                    else
+                        ring_tile_epilogue<MT, KPL, NTW, false>(acc, lp, lim, qmul, s_inv + tpar * 256 + wm * 32 * MT + 4 * h, tile + wm * 32 * MT + 4 * h, i << 6);
                 }
                 tpar ^= 1;
             }
