@@ -687,3 +687,28 @@ def test_fp16_pair_stage_rows_and_queries_it_cannot_scale_are_still_exact(nnm):
     oi, os_, oc = pyoracle.nns_search(bank, q, 5)
     assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
     assert 7 in idx[0] and 8 in idx[1]
+
+
+def test_packed_candidate_lists_rank_negative_and_tied_keys_like_the_oracle(nnm):
+    """The persistent candidate stage keeps its per-lane lists as 32-bit integers, -key << 13 | position (csrc/sim_topk_pair_dev.h):
+    queries whose best similarities are all NEGATIVE (the integer key changes sign), banks of exact duplicates (hundreds of rows with
+    the same integer key: only the position bits order them), a zero query (unit of the keys from a zero norm) and row limits that
+    leave fewer rows than k -- all through the 256 x 256 tiles (>= 257 queries), all equal to the oracle."""
+    rng = np.random.default_rng(77)
+    n, d, nq, k = 6000, 128, 300, 6
+    u = unit_rows(rng, 1, d)[0]
+    bank = (-u[None, :] * rng.uniform(0.5, 2.0, size=(n, 1)) + 0.02 * rng.standard_normal((n, d))).astype(np.float32)
+    bank[1000:1400] = bank[1000]                               # 400 exact duplicates
+    q = (u[None, :] + 0.02 * rng.standard_normal((nq, d))).astype(np.float32)       # every similarity of these queries is negative
+    q[5] = 0.0                                                 # zero query: NaN scores
+    q[6:40] = bank[1000] * np.float32(3.0)                     # queries whose best rows are the duplicates (ties -> larger row first)
+    nn = make_bank(nnm, bank)
+    idx, sims, cnt = nn.search_batch(q, k, mode=nnm.MODE_MFMA)
+    assert nn.last_stats()[1] == nnm.MODE_MFMA
+    oi, os_, oc = pyoracle.nns_search(bank, q, k)
+    assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
+    assert np.all(os_[40:, 0] < 0.0) and list(oi[6]) == [1399, 1398, 1397, 1396, 1395, 1394]
+    lim = np.minimum(np.arange(nq, dtype=np.int64) // 3, n)     # queries 0..17 see fewer than k rows, query 0..2 none
+    idx, sims, cnt = nn.search_batch(q, k, row_limit=lim, mode=nnm.MODE_MFMA)
+    oi, os_, oc = pyoracle.nns_search(bank, q, k, row_limit=lim)
+    assert_topk_equal(idx, sims, cnt, oi, os_, oc, 1e-12)
