@@ -60,7 +60,8 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
     const int wg = (bid % p.n_xcd) * p.wpx + bid / p.n_xcd;
     // 1 / (||row|| s_row) of the current bank tile's 256 rows; two buffers by tile parity: a wave that leaves a tile's epilogue early
     // requests the next tile's values while slower waves still read this tile's (a buffer is rewritten 64 stage barriers later)
-    float *const s_inv = (float *)(smem + 2 * STAGE + 16);
+    constexpr int SLOT = OPB / 2 + OPB;          // a short tile's stage: 128 bank rows + the 256 queries (below); three of them fit
+    float *const s_inv = (float *)(smem + 3 * SLOT + 16);
     int *const prog = (FLOW && p.prog) ? p.prog + (bid % p.n_xcd) * 32 : nullptr;      // the patch's progress line
     const int slot = bid / p.n_xcd;
 
@@ -338,11 +339,51 @@ __global__ __launch_bounds__(512, 2) void sim_topk_ring_kernel(RingArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
                 ++it;
             };
+            // ---- a SHORT last tile (at most 128 rows of the task left: the wm = 1 waves have nothing to multiply, the others little).
+            // Its 64 K stages are a chain of L2 round trips with two stage buffers -- one stage in flight while the other is read, and
+            // reading takes no time: 85 us for the 32 rows that end every walk of the in-step launch, against 114 us for 256 rows
+            // (profiles/r06_y_in_step_tile_trace.log).  With half the bank rows a stage is 48 KB and THREE fit: two stages in flight.
+            // (The stage the previous tile's last stage prefetched in the two-buffer layout is not used: one stage of 64.)
+            auto short_tile = [&](int tile, int valid) {
+                m_act = wm == 0 ? (valid + 31) >> 5 : 0;
+                point_at_tile(tile);
+                auto load = [&](int slot, int kt) {
+                    char *sA = smem + slot * SLOT, *sB = sA + OPB / 2;
+#pragma unroll
+                    for (int i = 0; i < NLD / 2; ++i) pk_blds16(rsA, voffA0 + i * stepA, kt * PK_ROWB, sA + i * (NTHR * 16) + wave_chunk);
+#pragma unroll
+                    for (int i = 0; i < NLD; ++i) pk_blds16(rsB, voffB0, kt * PK_ROWB + i * stepB, sB + i * (NTHR * 16) + wave_chunk);
+                };
+                if (wave < 4) {
+                    const __amdgpu_buffer_rsrc_t rsI = pk_rsrc((const char *)p.invs, (int64_t)p.n_rows * 4);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsI, (__attribute__((address_space(3))) void *)((char *)s_inv + (tpar * 4 + wave) * 256), 4,
+                                                             (tile + tid) * 4, 0, 0, 0);
+                }
+                load(0, 0);
+                if (p.nkt > 1) load(1, 1);
+                for (int kt = 0; kt < p.nkt; ++kt) {
+                    // stage kt has landed (the NLD / 2 + NLD requests of stage kt + 1 may still be in flight), everybody is done with stage kt - 1
+                    if (kt + 1 < p.nkt) __builtin_amdgcn_s_waitcnt(0x0f70 | (NLD / 2 + NLD)); else __builtin_amdgcn_s_waitcnt(0x0f70);
+                    __builtin_amdgcn_s_barrier();
+                    if (kt + 2 < p.nkt) load((kt + 2) % 3, kt + 2);
+                    if (m_act > 0) {
+                        const char *sA = smem + (kt % 3) * SLOT, *sB = sA + OPB / 2;
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) {
+                            read_frags(s & 1, sA, sB, s);
+                            multiply(s & 1, std::false_type{});
+                        }
+                    }
+                }
+                __builtin_amdgcn_s_barrier();                        // (the next task's first stage lands where these stages were read)
+            };
             int tile = tk.row0;                                      // first bank row of the tile
             for (int i = 0; i < ntiles; ++i, tile += tk.stride_rows) {
                 if (p.trace_out && tid == 0 && ti == p.task_off[wg] && i < 62) p.trace_out[(size_t)bid * 64 + i] = (long long)wall_clock64();
                 const int valid = tk.row_end - tile;                 // rows of the task in this tile (>= 256: all of them)
-                if (valid >= T_) {
+                if (valid <= T_ / 2 && !FLOW && !(DBG & 7)) {
+                    short_tile(tile, valid);
+                } else if (valid >= T_) {
                     stage_body(std::true_type{}, std::true_type{}, tile, 0);
                     for (int kt = 1; kt < p.nkt; ++kt) stage_body(std::false_type{}, std::true_type{}, tile, kt);
                     multiply((NS - 1) & 1, std::true_type{});        // the tile's last K step, then its candidates
@@ -497,7 +538,7 @@ void ring_schedule_build(RingSchedule &s, int nqt, int n_rows, int n_xcd, int wp
 
 // variant: bit 0 = patch flow control, bit 1 = progress-ordered wave priority
 int ring_stage1_launch(const RingArgs &a, int variant, int dbg, hipStream_t st) {
-    constexpr int lds = 2 * 2 * 256 * PK_ROWB + 16 + 2 * 1024;      // stages, pad, invs (two parities)
+    constexpr int lds = 3 * (128 + 256) * PK_ROWB + 16 + 2 * 1024;   // two stages of 256 + 256 rows or three of 128 + 256 (short tiles), pad, invs (two parities)
     static DeviceOnce once;
     int once_dev;
 #define RING_EACH(X) X(0, 0, 0)
