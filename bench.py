@@ -214,10 +214,11 @@ def parse():
     ap.add_argument("--k", type=int, default=5)
     ap.add_argument("--match-queries", type=int, default=100_000, help="queries of the match-only leg")
     ap.add_argument("--backbone-dtype", default="fp32", choices=["fp32", "bf16"])
-    ap.add_argument("--extract-chunk", type=int, default=512,
-                    help="frames per backbone forward (512: +2-3 %% over 256, profiles/r02_v23_extract_chunk.log; the per-kernel "
-                         "rooflines below are priced on 256-frame launches, the shapes of the committed PMC passes)")
-    ap.add_argument("--extract-lanes", type=int, default=2,
+    ap.add_argument("--extract-chunk", type=int, default=256,
+                    help="frames per backbone forward: the step's 1024 frames are four 256-frame passes on four lanes (profiles/"
+                         "r06_zz_chunk_lane_sweep.log: +1.2 %% over two 512-frame passes on two lanes, one 1024-frame pass -12 %%; the "
+                         "per-kernel rooflines below are priced on 256-frame launches, the shapes of the committed PMC passes)")
+    ap.add_argument("--extract-lanes", type=int, default=4,
                     help="HIP streams the step's extract chunks alternate over (NetVLAD.compute_embeddings_batch_device; 1 = one stream)")
     ap.add_argument("--backbone-conv", default="winograd", choices=["winograd", "winograd2", "direct"],
                     help="execution of the wide 3x3 backbone convolutions (vpr/winograd.py)")
