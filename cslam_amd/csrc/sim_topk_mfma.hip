@@ -568,8 +568,11 @@ int mfma_search_enqueue(cslam_bank *b, const void *d_q, int q_dtype, int64_t ldq
         const int n_xcd = b->num_cu % 8 == 0 ? 8 : 1;
         const int wpx = b->num_cu / n_xcd;
         rs = &b->ring_sched;
-        if (rs->nqt != nqt || rs->n_rows != (int)b->n || rs->n_xcd != n_xcd || rs->wpx != wpx)
+        if (rs->nqt != nqt || rs->n_rows != (int)b->n || rs->n_xcd != n_xcd || rs->wpx != wpx) {
             ring_schedule_build(*rs, nqt, (int)b->n, n_xcd, wpx);
+            // the packed candidate lists address a task's rows with 13 bits (sim_topk_pair_dev.h): the schedule cuts longer walks
+            for (const RingTask &t : rs->tasks) ARG_CHECK(t.n_tiles <= 128, "internal: a ring task longer than 128 tiles");
+        }
         nseg = 0;
         for (int v : rs->qt_nseg) nseg = v > nseg ? v : nseg;       // reported; the lists have per-query-tile counts
     }
