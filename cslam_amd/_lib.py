@@ -117,6 +117,7 @@ _SIGNATURES = {
     "cslam_wino4_fused_c64_h_dev": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, C.c_float, _vp, _vp, _vp]),
     "cslam_conv3x3_direct_h_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _f, _vp, _vp, _vp]),
     "cslam_conv3x3_direct_r_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, C.c_float, _vp, _vp, _vp]),
+    "cslam_conv3x3_direct_r2_dev": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, C.c_float, _vp, _vp, _vp]),
     "cslam_conv_stem_direct_h_dev": (_i, [_vp, _vp, _vp, _vp, C.c_float, _vp, _vp, C.c_float, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "cslam_wino4_stem_c64_h_dev": (_i, [_vp, _vp, _vp, _vp, C.c_float, _vp, _vp, _i, _i, _i, _i, _vp, C.c_float, _vp, _vp, _vp]),
     "cslam_debug_wfh_prof_dev": (_i, [_vp]),

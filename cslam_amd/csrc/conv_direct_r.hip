@@ -344,6 +344,287 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_r_kernel(ConvDirectRArg
     }
 }
 
+// ---- 128 -> 128 channels (VGG-16 conv2_2, + MaxPool2d) on the same register-resident form (round 6) ----------------------------------
+// 128 x 128 x 9 weights as fp16 pairs are 590 KB: more than a compute unit's 512 KB of registers, which is why conv_direct_h.hip streams
+// them through an LDS ring -- 16 KB per (tap, 32-channel slab) and 256 pixels, 14.8 GB of L2 -> LDS traffic per 256 frames, and with it the
+// kernel sits 15-25 % above what its flop and its HBM bytes cost at the board's power cap.  HALF the output channels
+// are 295 KB and fit: the two workgroups 2 j, 2 j + 1 of an XCD walk the SAME blocks, one per output-channel half, so the input leaves HBM
+// once (the partner's reads hit the XCD's L2) and no weight ever moves again.  Wave w owns output channels 64 half + 16 w .. + 15 (ONE 16-row
+// A tile) for all 128 pixels of an 8 x 16 block and all 128 input channels: a block is two passes over the 64-channel patch layout of
+// the kernel above (slab 0, slab 1; the accumulators stay), each pass stages the next one's patch -- (same block, slab 1), then (next
+// block, slab 0) -- inside its MFMA stream exactly as above; 2 fragment reads per up to 9 MFMAs; the epilogue rides in slab 1's last column.
+struct ConvDirectR2Args {
+    const float *x; const f16x8 *w2; const float *bias; float *y;
+    int B, H, W, gxb, gyb, nblk;
+    const unsigned *amax_in; float inv_sw; unsigned *amax_out;
+};
+template <bool POOL, bool RELU, int DBG = 0>
+__global__ __launch_bounds__(256, 1) void conv3x3_direct_r2_kernel(ConvDirectR2Args p) {
+    extern __shared__ __attribute__((aligned(16))) char dr_smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int gq = lane >> 4, l15 = lane & 15;
+
+    const float amax = fminf(fmaxf(__uint_as_float(*p.amax_in), 1e-30f), 1e30f);
+    int e_;
+    (void)frexpf(32752.0f / amax, &e_);
+    const float sx = ldexpf(1.0f, e_ - 1);
+    const float inv = p.inv_sw / sx;
+
+    // blocks to workgroup PAIRS by XCD (contiguous eighths); the launch has an even number of workgroups per XCD
+    const bool by_xcd = (gridDim.x & 15) == 0;
+    const int wg_xcd = by_xcd ? (int)blockIdx.x & 7 : 0, wg_raw = by_xcd ? (int)blockIdx.x >> 3 : (int)blockIdx.x;
+    const int half = wg_raw & 1, wg_j = wg_raw >> 1;
+    const int wg_per = (by_xcd ? (int)gridDim.x >> 3 : (int)gridDim.x) >> 1;
+    const int per_xcd = by_xcd ? (p.nblk + 7) >> 3 : p.nblk;
+    const int blk_beg = wg_xcd * per_xcd;
+    const int blk_cnt = min(per_xcd, p.nblk - blk_beg);
+    const int n_mine = blk_cnt > wg_j ? (blk_cnt - wg_j + wg_per - 1) / wg_per : 0;
+    if (n_mine <= 0) return;
+
+    // ---- this wave's weights: [tap][K step][slab][hi | lo], 288 registers; taps 0 .. 6 (224) + the 32 accumulators = the 256 AGPRs
+    f16x8 wr[9][2][2][2];
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl) {
+                    wr[tap][ks][sl][hl] = p.w2[((((((half * 4 + wave) * 9 + tap) * 2 + ks) * 2 + sl) * 2 + hl) * 64) + lane];
+                    if (tap < 7) asm volatile("" : "+a"(wr[tap][ks][sl][hl]));
+                }
+    const float4 bv = p.bias ? *(const float4 *)(p.bias + 64 * half + 16 * wave + 4 * gq) : make_float4(0.f, 0.f, 0.f, 0.f);
+
+    struct Blk { int img, by, bx; };
+    auto decode_blk = [&](int bi) {
+        int blk = wg_j + bi * wg_per;
+        blk = blk_beg + (blk < blk_cnt ? blk : blk_cnt - 1);
+        const int per_img = p.gxb * p.gyb;
+        Blk b;
+        b.img = blk / per_img;
+        const int rem = blk - b.img * per_img;
+        b.by = rem / p.gxb; b.bx = rem - b.by * p.gxb;
+        return b;
+    };
+
+    // ---- patch staging (the kernel above, the pixel pitch of the source 128 channels): element e = i * 256 + tid = (pixel e >> 4,
+    // float4 e & 15 of the slab's 64 channels)
+    int st_dst[DR_NEL];
+    unsigned st_pc = 0, st_pc2 = 0;
+#pragma unroll
+    for (int i = 0; i < DR_NEL; ++i) {
+        const int e = i * 256 + tid, px = e >> 4, f4 = e & 15;
+        const int pr = (px * 3641) >> 16, pc = px - 18 * pr;
+        const bool valid = px < DR_NPIX;
+        st_dst[i] = valid ? pr * DR_RP + pc * DR_PP + (((f4 >> 1) ^ DR_SWZ(pc)) << 4) + (f4 & 1) * 8 : -1;
+        if (i < 6) st_pc |= (unsigned)(valid ? pc : 0) << (5 * i);
+        else st_pc2 |= (unsigned)(valid ? pc : 0) << (5 * (i - 6));
+    }
+    const int img_bytes = p.H * p.W * 512;
+    u32x4 stg[DR_NEL];
+    auto patch_load = [&](const Blk &b, int slab, int i) {
+        const __amdgpu_buffer_rsrc_t rsX = dr_rsrc((const char *)p.x + (int64_t)b.img * img_bytes, img_bytes);
+        const int blk_off = ((b.by * 8 - 1) * p.W + (b.bx * 16 - 1)) * 512 + slab * 256;
+        int t = tid;
+        asm volatile("" : "+v"(t));
+        const int e = i * 256 + t, px = e >> 4;
+        const int pr = (px * 3641) >> 16, pc = px - 18 * pr;
+        int off = ((pr * p.W + pc) * 128 + (e & 15) * 4) * 4 + blk_off;
+        asm volatile("" : "+v"(off));
+        stg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, px < DR_NPIX ? off : 0x7fffffff, 0, 0);
+    };
+    auto patch_split = [&](const Blk &b, int i, char *patch) {
+        const int pc = (int)(((i < 6 ? st_pc : st_pc2) >> (5 * (i < 6 ? i : i - 6))) & 31u);
+        const int gx = b.bx * 16 - 1 + pc;
+        const float s = ((gx >= 0) & (gx < p.W)) ? sx : 0.0f;
+        const float w0 = __uint_as_float(stg[i].x) * s, w1 = __uint_as_float(stg[i].y) * s, w2 = __uint_as_float(stg[i].z) * s, w3 = __uint_as_float(stg[i].w) * s;
+        const __half2 h01 = __floats2half2_rn(w0, w1), h23 = __floats2half2_rn(w2, w3);
+        const float d0 = dr_sub_half<0>(w0, h01), d1 = dr_sub_half<1>(w1, h01), d2 = dr_sub_half<0>(w2, h23), d3 = dr_sub_half<1>(w3, h23);
+        const __half2 l01 = __floats2half2_rn(d0, d1), l23 = __floats2half2_rn(d2, d3);
+        char *d = st_dst[i] >= 0 ? patch + st_dst[i] : dr_smem + 2 * DR_PATCHB + (tid & 63) * 16;
+        *(uint2 *)d = make_uint2(*(const unsigned *)&h01, *(const unsigned *)&h23);
+        *(uint2 *)(d + 128) = make_uint2(*(const unsigned *)&l01, *(const unsigned *)&l23);
+    };
+
+    // ---- the products.  acc[r]: output row r, lane (l15, gq) = pixel column l15, channels 64 half + 16 wave + 4 gq .. + 3
+    f32x4 acc[8];
+    int fr_off[3];
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) fr_off[dx] = (l15 + dx) * DR_PP + ((gq ^ DR_SWZ(l15 + dx)) << 4);
+    f16x8 fh[3], fl[3];
+    auto frag_read = [&](auto col_tag, auto r_tag, const char *patch) {
+        constexpr int COL = decltype(col_tag)::value, R = decltype(r_tag)::value;
+        constexpr int DX = COL >> 1, KS = COL & 1, SLOT = (R + COL) % 3;
+        fh[SLOT] = *(const f16x8 *)(patch + fr_off[DX] + R * DR_RP + KS * 64);
+        fl[SLOT] = *(const f16x8 *)(patch + fr_off[DX] + R * DR_RP + KS * 64 + 128);
+    };
+    float my_amax = 0.0f;
+    const int Ho = POOL ? p.H >> 1 : p.H, Wo = POOL ? p.W >> 1 : p.W;
+    Blk eb = {0, 0, 0};
+    auto epi_rows = [&](int k) {                               // POOL: pooled row k (output rows 2 k, 2 k + 1); else output row k
+        const __amdgpu_buffer_rsrc_t rsY = dr_rsrc((const char *)(p.y + (int64_t)eb.img * Ho * Wo * 128), (int64_t)Ho * Wo * 512);
+        const int ox = eb.bx * 16 + l15;
+        const int ch_off = (64 * half + 16 * wave + 4 * gq) * 4;
+        float4 v;
+        bool store;
+        int off;
+        if (POOL) {
+            const int py = eb.by * 4 + k;
+            v.x = dr_max_xor1(dr_max(acc[2 * k][0], acc[2 * k + 1][0])); v.y = dr_max_xor1(dr_max(acc[2 * k][1], acc[2 * k + 1][1]));
+            v.z = dr_max_xor1(dr_max(acc[2 * k][2], acc[2 * k + 1][2])); v.w = dr_max_xor1(dr_max(acc[2 * k][3], acc[2 * k + 1][3]));
+            store = ((l15 & 1) == 0) & ((ox >> 1) < Wo) & (py < Ho);
+            off = (py * Wo + (ox >> 1)) * 512 + ch_off;
+        } else {
+            const int oy = eb.by * 8 + k;
+            v.x = acc[k][0]; v.y = acc[k][1]; v.z = acc[k][2]; v.w = acc[k][3];
+            store = (ox < p.W) & (oy < p.H);
+            off = (oy * p.W + ox) * 512 + ch_off;
+        }
+        v.x = v.x * inv + bv.x; v.y = v.y * inv + bv.y; v.z = v.z * inv + bv.z; v.w = v.w * inv + bv.w;
+        if (RELU) { v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f); }
+        float m = dr_max(dr_max(fabsf(v.x), fabsf(v.y)), dr_max(fabsf(v.z), fabsf(v.w)));
+        asm volatile("" : "+v"(m), "+v"(off));
+        my_amax = dr_max(my_amax, store ? m : 0.0f);
+        u32x4 bits;
+        bits.x = __float_as_uint(v.x); bits.y = __float_as_uint(v.y); bits.z = __float_as_uint(v.z); bits.w = __float_as_uint(v.w);
+        if (!(DBG & 4)) __builtin_amdgcn_raw_buffer_store_b128(bits, rsY, store ? off : 0x7fffffff, 0, 0);
+        else asm volatile("" :: "v"(bits));
+    };
+
+    // one scheduling region per patch row, as above with half the MFMAs (one channel tile): the fragment two rows ahead, the row's
+    // 3 - 9 MFMAs, a slice of the next pass's staging
+    auto rstep = [&](auto col_tag, auto r_tag, auto slab_tag, const char *patch, const Blk &nblk, int nslab, char *npatch) {
+        constexpr int COL = decltype(col_tag)::value, R = decltype(r_tag)::value, SL = decltype(slab_tag)::value;
+        constexpr int DX = COL >> 1, KS = COL & 1, SLOT = (R + COL) % 3;
+        if constexpr (R + 2 < 10) frag_read(col_tag, std::integral_constant<int, (R + 2) % 10>{}, patch);
+        else if constexpr (COL < 5) frag_read(std::integral_constant<int, (COL + 1) % 6>{}, std::integral_constant<int, (R + 2) % 10>{}, patch);
+        if constexpr (COL == 0 && R >= 1 && R <= 6 && !(DBG & 1)) { patch_load(nblk, nslab, 2 * (R - 1)); patch_load(nblk, nslab, 2 * (R - 1) + 1); }
+#pragma unroll
+        for (int prod = 0; prod < 3; ++prod)
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int r = R - dy;
+                if (r < 0 || r > 7) continue;
+                const f16x8 a = prod == 2 ? wr[3 * dy + DX][KS][SL][1] : wr[3 * dy + DX][KS][SL][0];
+                const f16x8 b = prod == 1 ? fl[SLOT] : fh[SLOT];
+                acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, (SL == 0 && COL == 0 && prod == 0 && dy == 0) ? (f32x4)(0.0f) : acc[r], 0, 0, 0);
+            }
+        if constexpr (COL >= 2 && (R == 2 || R == 4 || R == 6) && !(DBG & 1)) patch_split(nblk, 3 * (COL - 2) + (R - 2) / 2, npatch);
+        if constexpr (SL == 1 && COL == 5 && !POOL && R >= 3) epi_rows(R - 3);
+        if constexpr (SL == 1 && COL == 5 && POOL && (R == 4 || R == 6 || R == 8)) epi_rows((R - 4) / 2);
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+        constexpr int NM = 3 * ((R < 2 ? R + 1 : 3) - (R > 7 ? R - 7 : 0));
+#pragma unroll
+        for (int m = 0; m < NM; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, (SL == 1 && COL == 5) ? 8 : 4, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto column = [&](auto col_tag, auto slab_tag, const char *patch, const Blk &nblk, int nslab, char *npatch) {
+        rstep(col_tag, std::integral_constant<int, 0>{}, slab_tag, patch, nblk, nslab, npatch); rstep(col_tag, std::integral_constant<int, 1>{}, slab_tag, patch, nblk, nslab, npatch);
+        rstep(col_tag, std::integral_constant<int, 2>{}, slab_tag, patch, nblk, nslab, npatch); rstep(col_tag, std::integral_constant<int, 3>{}, slab_tag, patch, nblk, nslab, npatch);
+        rstep(col_tag, std::integral_constant<int, 4>{}, slab_tag, patch, nblk, nslab, npatch); rstep(col_tag, std::integral_constant<int, 5>{}, slab_tag, patch, nblk, nslab, npatch);
+        rstep(col_tag, std::integral_constant<int, 6>{}, slab_tag, patch, nblk, nslab, npatch); rstep(col_tag, std::integral_constant<int, 7>{}, slab_tag, patch, nblk, nslab, npatch);
+        rstep(col_tag, std::integral_constant<int, 8>{}, slab_tag, patch, nblk, nslab, npatch); rstep(col_tag, std::integral_constant<int, 9>{}, slab_tag, patch, nblk, nslab, npatch);
+    };
+    auto pass = [&](auto slab_tag, const char *patch, const Blk &nblk, int nslab, char *npatch) {
+        frag_read(DR_C(0), DR_C(0), patch);
+        frag_read(DR_C(0), DR_C(1), patch);
+        column(DR_C(0), slab_tag, patch, nblk, nslab, npatch); column(DR_C(1), slab_tag, patch, nblk, nslab, npatch);
+        column(DR_C(2), slab_tag, patch, nblk, nslab, npatch); column(DR_C(3), slab_tag, patch, nblk, nslab, npatch);
+        column(DR_C(4), slab_tag, patch, nblk, nslab, npatch); column(DR_C(5), slab_tag, patch, nblk, nslab, npatch);
+    };
+
+    // ---- prologue: (block 0, slab 0) into buffer 0
+    Blk cb = decode_blk(0);
+#pragma unroll
+    for (int i = 0; i < DR_NEL; ++i) patch_load(cb, 0, i);
+#pragma unroll
+    for (int i = 0; i < DR_NEL; ++i) patch_split(cb, i, dr_smem);
+    __syncthreads();
+    char *const buf0 = dr_smem, *const buf1 = dr_smem + DR_PATCHB;
+    for (int bi = 0; bi < n_mine; ++bi) {
+        const Blk nb = decode_blk(bi + 1);
+        eb = cb;
+        pass(DR_C(0), buf0, cb, 1, buf1);                      // slab 0 of the block; its slab 1 is staged into the other buffer
+        __syncthreads();
+        pass(DR_C(1), buf1, nb, 0, buf0);                      // slab 1; the next block's slab 0 is staged
+        epi_rows(POOL ? 3 : 7);
+        __syncthreads();
+        cb = nb;
+    }
+    if (p.amax_out) {
+        unsigned *s_amax = (unsigned *)dr_smem;
+        if (tid == 0) *s_amax = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) my_amax = fmaxf(my_amax, __shfl_xor(my_amax, o, 64));
+        if (lane == 0) atomicMax(s_amax, __float_as_uint(my_amax));
+        __syncthreads();
+        if (tid == 0 && *s_amax > *(volatile unsigned *)p.amax_out) atomicMax(p.amax_out, *s_amax);
+    }
+}
+
+/* y = [pool](relu(conv3x3(x, w) + bias)), Cin = Cout = 128; x, y NHWC float32.  d_w2r2 = `direct_r2_pair_weights` (vpr/winograd.py):
+ * [2 output-channel halves][4 quarters of a half][9 taps][2 K steps][2 input-channel slabs][hi | lo][64 lanes][8] halfs of s_w w, inv_sw =
+ * 1 / s_w; d_amax = 4-byte slot holding (a bound of) max |x|; d_amax_out (or NULL): zeroed slot that receives max |y|.
+ * VGG-16 conv2_2: cslam/vpr/netvlad.py:163-171,227. */
+CSLAM_API int cslam_conv3x3_direct_r2_dev(const float *d_x, const void *d_w2r2, const float *d_bias, int B, int H, int W, int Cin,
+                                          int Cout, int relu, int pool, const unsigned *d_amax, float inv_sw,
+                                          unsigned *d_amax_out, float *d_y, void *stream) {
+    PTR_DEVICE(d_x);
+    ARG_CHECK(d_x && d_w2r2 && d_y && d_amax, "NULL argument");
+    ARG_CHECK(B >= 1 && H >= 1 && W >= 1, "empty map");
+    ARG_CHECK(Cin == 128 && Cout == 128, "Cin and Cout must be 128");
+    ARG_CHECK(!pool || ((H % 2) == 0 && (W % 2) == 0), "pooling needs even H and W");
+    ARG_CHECK(inv_sw > 0.0f, "inv_sw must be positive");
+    ARG_CHECK((int64_t)H * W * 512 < 0x7ffffff0ll, "one image's maps must stay below 2 GiB (32-bit buffer offsets)");
+    ConvDirectR2Args a;
+    a.x = d_x; a.w2 = (const f16x8 *)d_w2r2; a.bias = d_bias; a.y = d_y;
+    a.B = B; a.H = H; a.W = W;
+    a.gxb = (int)ceil_div64(W, 16); a.gyb = (int)ceil_div64(H, 8);
+    const int64_t nblk = (int64_t)B * a.gxb * a.gyb;
+    ARG_CHECK(nblk < (1ll << 30), "too many blocks for one launch");
+    a.nblk = (int)nblk;
+    a.amax_in = d_amax; a.inv_sw = inv_sw; a.amax_out = d_amax_out;
+    const int n_cu = cslam_cu_count();
+    ARG_CHECK(n_cu >= 2, "no HIP device");
+    // workgroup pairs: (block stream, output-channel half); whole pairs only, XCD-aligned when the device allows it
+    int grid = n_cu % 16 == 0 ? n_cu : (n_cu & ~1);
+    if (2 * nblk < grid) grid = (int)(2 * nblk);
+    hipStream_t st = (hipStream_t)stream;
+#define DR2_LAUNCH(P, R) do { \
+        static DeviceOnce once; int once_dev; \
+        if (once.todo(&once_dev)) { \
+            HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_direct_r2_kernel<P, R>, hipFuncAttributeMaxDynamicSharedMemorySize, DR_LDS)); \
+            once.done(once_dev); } \
+        hipLaunchKernelGGL((conv3x3_direct_r2_kernel<P, R>), dim3(grid), dim3(256), DR_LDS, st, a); } while (0)
+#ifdef CSLAM_ABLATIONS
+    if (const char *e = getenv("CSLAM_DR_DBG")) {              // timing-only ablations (wrong results): 1 = no staging inside the loop, 4 = no stores
+        const int d = atoi(e);
+#define DR2_LAUNCH_D(D) do { HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_direct_r2_kernel<true, true, D>, hipFuncAttributeMaxDynamicSharedMemorySize, DR_LDS)); \
+        hipLaunchKernelGGL((conv3x3_direct_r2_kernel<true, true, D>), dim3(grid), dim3(256), DR_LDS, st, a); HIP_TRY(hipGetLastError()); return CSLAM_OK; } while (0)
+        if (d == 1) DR2_LAUNCH_D(1);
+        if (d == 4) DR2_LAUNCH_D(4);
+        if (d == 5) DR2_LAUNCH_D(5);
+#undef DR2_LAUNCH_D
+    }
+#endif
+    if (pool && relu) DR2_LAUNCH(true, true);
+    else if (pool) DR2_LAUNCH(true, false);
+    else if (relu) DR2_LAUNCH(false, true);
+    else DR2_LAUNCH(false, false);
+#undef DR2_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return CSLAM_OK;
+}
+
 /* y = [pool](relu(conv3x3(x, w) + bias)), Cin = 64, Cout = 128; x, y NHWC float32.  d_w2r = `direct_r_pair_weights` (vpr/winograd.py):
  * [4 output-channel quarters][9 taps][2 K steps][2 channel tiles][hi | lo][64 lanes][8] halfs of s_w w, inv_sw = 1 / s_w; d_amax = 4-byte
  * slot holding (a bound of) max |x|; d_amax_out (or NULL): zeroed slot that receives max |y|. */

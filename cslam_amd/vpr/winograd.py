@@ -266,6 +266,38 @@ def conv3x3_direct_r(x, Wr, bias, relu, pool, amax_in, amax_out=None):
     return y
 
 
+def direct_r2_pair_weights(weight):
+    """conv weight [128, 128, 3, 3] float32 -> (W2r2 float16 [2, 4, 9, 2, 2, 2, 64, 8], inv_sw): the register-resident operand of
+    `cslam_conv3x3_direct_r2_dev` (csrc/conv_direct_r.hip).  sW w split into exact fp16 pairs;
+    W2r2[half][q][tap][ks][slab][hi | lo][lane][e] = the pair half of
+    w[64 half + 16 q + lane % 16][64 slab + 32 ks + 8 (lane // 16) + e][tap // 3][tap % 3]: one v_mfma_f32_16x16x32_f16 A fragment per
+    (tap, ks, slab, pair half), wave q of the workgroup that owns output-channel half `half` holding [half][q] for the whole kernel."""
+    assert tuple(weight.shape) == (128, 128, 3, 3)
+    w = weight.detach().to(torch.float64)
+    amax = float(w.abs().max())
+    sw = 2.0 ** (14 - math.floor(math.log2(amax))) if amax > 0 else 1.0
+    ws = (w * sw).to(torch.float32)
+    wh = ws.to(torch.float16)
+    wl = (ws - wh.to(torch.float32)).to(torch.float16)
+    pair = torch.stack((wh, wl), dim=0).reshape(2, 2, 4, 16, 2, 2, 4, 8, 9)      # [hl][half][q][i][slab][ks][kg][e][tap]
+    W2 = pair.permute(1, 2, 8, 5, 4, 0, 6, 3, 7).reshape(2, 4, 9, 2, 2, 2, 64, 8)  # [half][q][tap][ks][slab][hl][lane = 16 kg + i][e]
+    return W2.contiguous(), 1.0 / sw
+
+
+def conv3x3_direct_r2(x, Wr2, bias, relu, pool, amax_in, amax_out=None):
+    """y = [pool](relu(conv3x3(x) + bias)) through `cslam_conv3x3_direct_r2_dev` (csrc/conv_direct_r.hip): x [B,128,H,W] channels_last
+    float32, 128 output channels; Wr2 = `direct_r2_pair_weights(weight)`; amax_in / amax_out as `conv3x3_direct_h`."""
+    lib = _lib.load()
+    x = x.contiguous(memory_format=torch.channels_last)
+    B, Cin, H, W = x.shape
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    y = torch.empty((B, 128, Ho, Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    _lib.check(lib.cslam_conv3x3_direct_r2_dev(_p(x), _p(Wr2[0]), _p(bias) if bias is not None else None, B, H, W, Cin, 128,
+                                               int(relu), int(pool), _p(amax_in), float(Wr2[1]),
+                                               _p(amax_out) if amax_out is not None else None, _p(y), _stream(x)))
+    return y
+
+
 def conv3x3_direct_r_pairs(x, Wr, bias, wl1, bmax, amax_in, bound_out, amax_out=None):
     """relu(conv3x3(x) + bias), 64 -> 128 channels, written in PAIR FORMAT (`cslam_conv3x3_direct_r_pairs_dev`): returns the
     [B,H,W,4,2,32] float16 tensor scaled for the bound max|x| wl1 + bmax, which goes to the 4-byte slot bound_out."""
@@ -758,7 +790,7 @@ class WinogradResNet(_Workspace):
 
 
 class _Step(object):
-    __slots__ = ("kind", "module", "conv", "relu", "pool", "U", "U4", "U3", "U2", "Up", "Uph", "bias", "stem", "Wd", "Wr", "Wdr", "wl1", "bmax")
+    __slots__ = ("kind", "module", "conv", "relu", "pool", "U", "U4", "U3", "U2", "Up", "Uph", "bias", "stem", "Wd", "Wr", "Wdr", "Wdr2", "wl1", "bmax")
 
     def __init__(self):
         self.kind, self.module, self.conv, self.relu, self.pool = "torch", None, None, False, False
@@ -766,6 +798,7 @@ class _Step(object):
         self.Wd = None
         self.Wr = None
         self.Wdr = None
+        self.Wdr2 = None
         self.wl1 = self.bmax = None
 
 
@@ -773,12 +806,14 @@ class _Step(object):
 # tools/ select through WinogradTrunk(forms={...}) -- no environment variables):
 #   conv_direct      1: conv2_1 and conv2_2 as the direct one-kernel convolution on fp16 pairs; 2: conv2_2 only; 0: round 3's F(4x4) forms
 #   conv_direct_r    conv2_1 through the register-resident direct kernel (csrc/conv_direct_r.hip); False: the streaming one
+#   conv_direct_r2   conv2_2 through the register-resident kernel on output-channel halves (csrc/conv_direct_r.hip, round 6); False: the
+#                    kernel with the weights through an LDS ring (csrc/conv_direct_h.hip)
 #   stem_direct      conv1_1 + conv1_2 as ONE direct kernel (csrc/conv_stem_direct_h.hip); False: the one-kernel F(4x4) stem
 #   wino_stem        conv1_1 folded into conv1_2's kernel at all; False: conv1_1 as its own fp32 kernel
 #   fused_h          the one-kernel F(4x4) convolutions on fp16 pairs (csrc/wino_fused_h.hip); False: the f32-input MFMA kernels
 #   split16_min_cin  F(4x4) layers from that many input channels on run their 36 products on fp16 pairs (None: 128, or 256 with
 #                    split16_h3); 0: plain fp32 library GEMMs everywhere (bench.py's `value_fp32_gemms`)
-TRUNK_FORMS = {"conv_direct": 1, "conv_direct_r": True, "stem_direct": True, "wino_stem": True, "fused_h": True, "split16_min_cin": None}
+TRUNK_FORMS = {"conv_direct": 1, "conv_direct_r": True, "conv_direct_r2": True, "stem_direct": True, "wino_stem": True, "fused_h": True, "split16_min_cin": None}
 FP32_GEMM_FORMS = {"split16_min_cin": 0, "fused_h": False, "wino_stem": False}      # the trunk on plain fp32 library GEMMs
 
 
@@ -856,6 +891,9 @@ class WinogradTrunk(_Workspace):
                         st.Wdr = direct_r_pair_weights(m.weight)
                         st.wl1 = float(m.weight.detach().abs().sum(dim=(1, 2, 3)).max())      # bound of the pair-format output: max|x| wl1 + bmax
                         st.bmax = 0.0 if m.bias is None else float(m.bias.detach().abs().max())
+                    # 128 -> 128 (conv2_2): the register-resident form on output-channel halves
+                    if m.in_channels == 128 and self.forms.get("conv_direct_r2", True):
+                        st.Wdr2 = direct_r2_pair_weights(m.weight)
                 st.bias = None if m.bias is None else m.bias.detach().to(torch.float32).contiguous()
                 i += 1
                 if i < len(mods) and isinstance(mods[i], nn.ReLU):
@@ -993,6 +1031,8 @@ class WinogradTrunk(_Workspace):
                     continue
                 if st.Wdr is not None and x.shape[2] * x.shape[3] * 512 < 2 ** 31 - 16:
                     x = conv3x3_direct_r(x, st.Wdr, st.bias, st.relu, st.pool, slot, want)
+                elif st.Wdr2 is not None and x.shape[2] * x.shape[3] * 512 < 2 ** 31 - 16:
+                    x = conv3x3_direct_r2(x, st.Wdr2, st.bias, st.relu, st.pool, slot, want)
                 else:
                     x = conv3x3_direct_h(x, st.Wd, st.bias, st.relu, st.pool, slot, want)
                 amax_ready = want is not None

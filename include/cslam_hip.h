@@ -498,6 +498,15 @@ int cslam_conv3x3_direct_r_dev(const float *d_x, const void *d_w2r, const float 
                                int relu, int pool, const unsigned *d_amax, float inv_sw, unsigned *d_amax_out, float *d_y,
                                void *stream);
 
+/* 3x3 / stride 1 / pad 1 convolution 128 -> 128 channels (cslam/vpr/netvlad.py:163-171,227: VGG-16 conv2_2, + MaxPool2d) on the same
+ * register-resident form: half the output channels' weights (295 KB of exact fp16 pairs) fit a compute unit's registers, the two
+ * workgroups 2 j, 2 j + 1 of an XCD walk the same blocks, one per output-channel half (csrc/conv_direct_r.hip).  Arguments as
+ * cslam_conv3x3_direct_r_dev with Cin = Cout = 128; d_w2r2 = `direct_r2_pair_weights`: [2 output-channel halves][4 quarters of a
+ * half][9 taps][2 K steps][2 input-channel slabs][hi | lo][64 lanes][8 halfs]. */
+int cslam_conv3x3_direct_r2_dev(const float *d_x, const void *d_w2r2, const float *d_bias, int B, int H, int W, int Cin, int Cout,
+                                int relu, int pool, const unsigned *d_amax, float inv_sw, unsigned *d_amax_out, float *d_y,
+                                void *stream);
+
 /* conv2_1 -> conv2_2 of VGG-16 (cslam/vpr/netvlad.py:163-171,227) with the 112 x 112 x 128 map between them in the PAIR FORMAT of
  * cslam_conv_igemm_h2p_dev: cslam_conv3x3_direct_r_pairs_dev = cslam_conv3x3_direct_r_dev (+ bias + ReLU, no pooling) writing
  * [B,H,W,4 blocks][hi 32 | lo 32] fp16 of s y, s the power of two of the bound *d_amax wl1 + bmax (-> d_bound_out; wl1 = max_co

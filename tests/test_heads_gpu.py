@@ -730,8 +730,9 @@ def test_netvlad_extraction_beside_a_stream_that_thrashes_the_l2_is_bit_identica
 
 def test_trunk_runs_conv2_1_and_conv2_2_through_the_direct_kernel_and_matches_the_winograd_forms(T, monkeypatch):
     """VGG-16's first two blocks through the trunk runner: by default the stem and conv2_1 take the register-resident direct kernels
-    and conv2_2 the streaming direct kernel; forms conv_direct = 2 leaves conv2_1 on the one-kernel F(4x4) form, = 0 keeps round 3's
-    F(4x4) forms for both; conv_direct_r / stem_direct = False select the A/B partners of the register-resident kernels.  All
+    and conv2_2 the register-resident kernel on output-channel halves; forms conv_direct = 2 leaves conv2_1 on the one-kernel F(4x4)
+    form, = 0 keeps round 3's F(4x4) forms for both; conv_direct_r / conv_direct_r2 / stem_direct = False select the A/B partners of
+    the register-resident kernels (conv2_2: the weights through an LDS ring).  All
     against float64, and against each other at the F(4x4) forms' tolerance."""
     torch, _ = T
     from torch import nn
@@ -748,9 +749,10 @@ def test_trunk_runs_conv2_1_and_conv2_2_through_the_direct_kernel_and_matches_th
         assert (t.steps[2].Wdr is not None) == direct[0] and t.steps[3].Wdr is None and t.steps[0].Wr is not None
         outs[tag] = t(x)
     # the A/B partners of the register-resident kernels: conv2_1 on the streaming direct kernel, the F(4x4) stem kernel
-    for tag, env in (("conv2_1 streaming", "conv_direct_r"), ("wino stem", "stem_direct")):
+    for tag, env in (("conv2_1 streaming", "conv_direct_r"), ("wino stem", "stem_direct"), ("conv2_2 lds ring", "conv_direct_r2")):
         t = WinogradTrunk(seq, 64, 4, fused64=True, forms={env: False})
         assert (t.steps[2].Wdr is None) == (env == "conv_direct_r") and (t.steps[0].Wr is None) == (env == "stem_direct"), tag
+        assert (t.steps[3].Wdr2 is None) == (env == "conv_direct_r2")
         assert t.steps[2].Wd is not None and t.steps[0].stem is not None
         outs[tag] = t(x)
     with torch.no_grad():
@@ -758,7 +760,7 @@ def test_trunk_runs_conv2_1_and_conv2_2_through_the_direct_kernel_and_matches_th
     seq.float()
     for tag in outs:
         assert _rel_rms(outs[tag], ref) <= 1e-5, tag
-    for tag in ("direct", "conv2_2", "conv2_1 streaming", "wino stem"):
+    for tag in ("direct", "conv2_2", "conv2_1 streaming", "wino stem", "conv2_2 lds ring"):
         assert (outs[tag] - outs["wino"]).abs().max().item() <= 2e-5 * ref.abs().max().item(), tag
 
 
@@ -807,9 +809,9 @@ def test_conv2_1_writes_pairs_and_conv2_2_stages_them_without_conversion(T, B, H
     # through the trunk runner
     mods = [c1, nn.ReLU(), c2, nn.ReLU()] + ([nn.MaxPool2d(2, 2)] if pool else [])
     seq = nn.Sequential(*mods).eval()
-    t = wg.WinogradTrunk(seq, 64, 4)
+    t = wg.WinogradTrunk(seq, 64, 4, forms={"conv_direct_r2": False})          # conv2_2 with its weights through the LDS ring: the kernels above
     t.fused_min_blocks = 0
-    assert t.steps[0].Wdr is not None and t.steps[1].Wd is not None and t.steps[1].Wdr is None
+    assert t.steps[0].Wdr is not None and t.steps[1].Wd is not None and t.steps[1].Wdr is None and t.steps[1].Wdr2 is None
     gotf = t(x)
     try:
         wg.VGG_PAIRS = True
@@ -817,6 +819,10 @@ def test_conv2_1_writes_pairs_and_conv2_2_stages_them_without_conversion(T, B, H
     finally:
         wg.VGG_PAIRS = False
     assert torch.equal(got, y2) and torch.equal(gotf, y2f)
+    t2 = wg.WinogradTrunk(seq, 64, 4)                                           # the default: conv2_2 register-resident on output-channel halves
+    t2.fused_min_blocks = 0
+    assert t2.steps[1].Wdr2 is not None
+    assert (t2(x) - y2f).abs().max().item() / sc2 <= 2e-6
 
 
 @pytest.mark.parametrize("cout,B,H,W,pool,amp", [(64, 4, 64, 48, True, 1.0), (128, 3, 40, 56, False, 1e3), (64, 2, 30, 22, False, 1e-3)])
@@ -1220,6 +1226,51 @@ def test_register_resident_direct_conv_equals_float64(T, B, H, W, relu, pool, bi
     assert (y - yh).abs().max().item() <= 5e-6 * top
     assert out_slot.item() == y.abs().max().item()
     assert torch.equal(y, wg.conv3x3_direct_r(x, Wr, b, relu, pool, slot, None))      # run to run bit-identical
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,relu,pool,bias,amp", [(2, 112, 112, True, True, True, 1.0), (3, 37, 50, True, False, True, 1e3),
+                                                      (300, 16, 16, False, False, False, 1.0), (1, 8, 90, True, True, False, 1e-3),
+                                                      (5, 20, 34, False, True, True, 1.0), (1, 2, 2, True, True, True, 1.0),
+                                                      (40, 114, 118, True, True, True, 0.05), (1, 8, 16, True, False, True, 1.0)])
+def test_register_resident_conv_128_to_128_on_output_channel_halves_equals_float64(T, B, H, W, relu, pool, bias, amp):
+    """cslam_conv3x3_direct_r2_dev (csrc/conv_direct_r.hip: VGG-16 conv2_2, 128 -> 128 channels; half the output channels' weights
+    register-resident per workgroup, the two workgroups of a pair walking the same blocks, a block = two 64-channel passes) against a
+    float64 conv2d (+ ReLU + MaxPool2d) at the direct kernels' fp32-grade bar and against the kernel with the weights through an LDS
+    ring; ragged 8 x 16 blocks, a single block (one workgroup pair), fewer / more blocks than workgroup pairs, activations six decades
+    apart, the max |y| slot, run-to-run bit identity."""
+    torch, _ = T
+    from cslam_amd import _lib
+    from cslam_amd.vpr import winograd as wg
+    lib = _lib.load()
+    torch.manual_seed(223)
+    x = (torch.randn(B, 128, H, W, device="cuda") * amp).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(128, 128, 3, 3, device="cuda") / 34.0
+    w[5] *= 40.0                                                 # output channels of very different weight
+    b = torch.randn(128, device="cuda") * amp if bias else None
+    Wr2 = wg.direct_r2_pair_weights(w)
+    assert tuple(Wr2[0].shape) == (2, 4, 9, 2, 2, 2, 64, 8) and Wr2[0].dtype == torch.float16
+    slot = torch.zeros(1, dtype=torch.float32, device="cuda")
+    _lib.check(lib.cslam_absmax_dev(x.data_ptr(), x.numel(), slot.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    out_slot = torch.zeros(1, dtype=torch.float32, device="cuda")
+    y = wg.conv3x3_direct_r2(x, Wr2, b, relu, pool, slot, out_slot)
+    yh = wg.conv3x3_direct_h(x, wg.direct_pair_weights(w), b, relu, pool, slot, None)
+    ref = torch.nn.functional.conv2d(x.double(), w.double(), None if b is None else b.double(), padding=1)
+    if pool:
+        ref = torch.nn.functional.max_pool2d(ref, 2)             # max and ReLU commute
+    if relu:
+        ref = torch.relu(ref)
+    assert y.shape == ref.shape and y.is_contiguous(memory_format=torch.channels_last)
+    top = ref.abs().max().item()
+    ef = (y.double() - ref).abs().max().item() / top
+    rf = float(((y.double() - ref) ** 2).sum().sqrt() / (ref ** 2).sum().sqrt())
+    assert ef <= 5e-6 and rf <= 2e-6, (ef, rf)
+    assert (y - yh).abs().max().item() <= 5e-6 * top
+    assert out_slot.item() == y.abs().max().item()
+    assert torch.equal(y, wg.conv3x3_direct_r2(x, Wr2, b, relu, pool, slot, None))     # run to run bit-identical
+    with pytest.raises(_lib.CslamHipError):
+        _lib.check(lib.cslam_conv3x3_direct_r2_dev(x.data_ptr(), Wr2[0].data_ptr(), None, B, H, W, 64, 128, 1, 0, slot.data_ptr(), float(Wr2[1]),
+                                                   None, y.data_ptr(), torch.cuda.current_stream().cuda_stream))
 
 
 @pytest.mark.gpu
