@@ -512,7 +512,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_r2_kernel(ConvDirectR2A
                 const f16x8 b = prod == 1 ? fl[SLOT] : fh[SLOT];
                 acc[r] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, (SL == 0 && COL == 0 && prod == 0 && dy == 0) ? (f32x4)(0.0f) : acc[r], 0, 0, 0);
             }
-        if constexpr (COL >= 2 && (R == 2 || R == 4 || R == 6) && !(DBG & 1)) patch_split(nblk, 3 * (COL - 2) + (R - 2) / 2, npatch);
+        // (the split waits for its load: three columns = 216 MFMAs behind the requests -- with two, as in the kernel above whose columns
+        // are twice as long, the first splits stalled on HBM latency: 2.03-2.09 ms against 1.98-2.00; splits in the last two columns only: no better)
+        if constexpr (COL >= 3 && (R == 1 || R == 3 || R == 5 || R == 7) && !(DBG & 1)) patch_split(nblk, 4 * (COL - 3) + (R - 1) / 2, npatch);
         if constexpr (SL == 1 && COL == 5 && !POOL && R >= 3) epi_rows(R - 3);
         if constexpr (SL == 1 && COL == 5 && POOL && (R == 4 || R == 6 || R == 8)) epi_rows((R - 4) / 2);
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
