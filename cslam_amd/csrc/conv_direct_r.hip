@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_r_kernel(ConvDirectRArg
                     const f16x8 b = prod == 1 ? fl[SLOT] : fh[SLOT];
                     acc[r][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, (COL == 0 && prod == 0 && dy == 0) ? (f32x4)(0.0f) : acc[r][mt], 0, 0, 0);
                 }
-        if constexpr (COL >= 2 && (R == 2 || R == 4 || R == 6) && !(DBG & 1)) patch_split(nblk, 3 * (COL - 2) + (R - 2) / 2, npatch);
+        if constexpr (COL >= 3 && (R == 1 || R == 3 || R == 5 || R == 7) && !(DBG & 1)) patch_split(nblk, 4 * (COL - 3) + (R - 1) / 2, npatch);
         if constexpr (COL == 5 && !POOL && R >= 3) epi_rows(R - 3);                                 // output row R - 3 was finished by the last region
         if constexpr (COL == 5 && POOL && (R == 4 || R == 6 || R == 8)) epi_rows((R - 4) / 2);
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
