@@ -670,8 +670,9 @@ def main():
                         "bound": "hbm" if tag == "conv3_2" else "mfma"}
             del v2, u2, mo
         extract_roofline["pair_gemm"] = gem
-        # conv2_1 / conv2_2: the direct one-kernel convolution on fp16 pairs (csrc/conv_direct_h.hip, round 4): implicit GEMM over the
-        # nine taps, 3 fp16 MFMA products per fp32-grade product; HBM sees the activation in (x 1.27 halo) and out
+        # conv2_1 / conv2_2: the direct one-kernel convolutions on fp16 pairs with register-resident weights (csrc/conv_direct_r.hip;
+        # `streaming_direct_kernel_ms`: round 4's kernel with the weights through an LDS ring, csrc/conv_direct_h.hip, their A/B partner),
+        # 3 fp16 MFMA products per fp32-grade product; HBM sees the activation in and out
         from cslam_amd.vpr import winograd as wg
         dconv = {}
         for tag, cin, pool in (("conv2_2", 128, True), ("conv2_1", 64, False)):
@@ -686,6 +687,9 @@ def main():
             if cin == 64:                                    # conv2_1: the register-resident form (csrc/conv_direct_r.hip), the trunk's default
                 Wdr = wg.direct_r_pair_weights(wd)
                 dms, kname = time_ms(lambda: wg.conv3x3_direct_r(xd, Wdr, bd, True, pool, sd, None)), "conv3x3_direct_r_kernel"
+            else:                                            # conv2_2: register-resident on output-channel halves (round 6), the trunk's default
+                Wdr2 = wg.direct_r2_pair_weights(wd)
+                dms, kname = time_ms(lambda: wg.conv3x3_direct_r2(xd, Wdr2, bd, True, pool, sd, None)), "conv3x3_direct_r2_kernel"
             dfl = 3 * 2.0 * eb * 112 * 112 * 9 * cin * 128
             dby = (xd.numel() + eb * 128 * 112 * 112 // (4 if pool else 1)) * 4
             shape_d = f"x [{eb},112,112,{cin}] -> conv {cin}->128 + bias + ReLU" + (" + MaxPool2d" if pool else "")
@@ -1007,8 +1011,8 @@ def main():
                 "pairs of both operands, 3 of the 4 partial products on the fp16 MFMA pipe with fp32 accumulation (error vs "
                 "float64 = that of the fp32 GEMM, tests/test_heads_gpu.py::test_split16_*, tests/test_wino_gemm_gpu.py); "
                 "conv1_1 + conv1_2: ONE direct kernel on fp16 pairs, the second layer's weights register-resident "
-                "(csrc/conv_stem_direct_h.hip); conv2_1: the same form (csrc/conv_direct_r.hip); conv2_2: the direct one-kernel "
-                "convolution on fp16 pairs, weights through LDS (csrc/conv_direct_h.hip)"),
+                "(csrc/conv_stem_direct_h.hip); conv2_1: the same form (csrc/conv_direct_r.hip); conv2_2: the same form on "
+                "output-channel halves, two workgroups per block (csrc/conv_direct_r.hip, round 6)"),
             "extract_only_fp32_gemms": None if extract_fp32_gemms is None else round(extract_fp32_gemms, 2),
             "match_only": round(match_only, 2),
             "match_only_queries": nqm,
