@@ -501,7 +501,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_r2_kernel(ConvDirectR2A
         constexpr int DX = COL >> 1, KS = COL & 1, SLOT = (R + COL) % 3;
         if constexpr (R + 2 < 10) frag_read(col_tag, std::integral_constant<int, (R + 2) % 10>{}, patch);
         else if constexpr (COL < 5) frag_read(std::integral_constant<int, (COL + 1) % 6>{}, std::integral_constant<int, (R + 2) % 10>{}, patch);
-        if constexpr (COL == 0 && R >= 1 && R <= 6 && !(DBG & 1)) { patch_load(nblk, nslab, 2 * (R - 1)); patch_load(nblk, nslab, 2 * (R - 1) + 1); }
+        if constexpr (COL == 0 && R >= 1 && R <= 6 && !(DBG & 1) && !(DBG & 8)) { patch_load(nblk, nslab, 2 * (R - 1)); patch_load(nblk, nslab, 2 * (R - 1) + 1); }
 #pragma unroll
         for (int prod = 0; prod < 3; ++prod)
 #pragma unroll
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_r2_kernel(ConvDirectR2A
             }
         // (the split waits for its load: three columns = 216 MFMAs behind the requests -- with two, as in the kernel above whose columns
         // are twice as long, the first splits stalled on HBM latency: 2.03-2.09 ms against 1.98-2.00; splits in the last two columns only: no better)
-        if constexpr (COL >= 3 && (R == 1 || R == 3 || R == 5 || R == 7) && !(DBG & 1)) patch_split(nblk, 4 * (COL - 3) + (R - 1) / 2, npatch);
+        if constexpr (COL >= 3 && (R == 1 || R == 3 || R == 5 || R == 7) && !(DBG & 1) && !(DBG & 16)) patch_split(nblk, 4 * (COL - 3) + (R - 1) / 2, npatch);
         if constexpr (SL == 1 && COL == 5 && !POOL && R >= 3) epi_rows(R - 3);
         if constexpr (SL == 1 && COL == 5 && POOL && (R == 4 || R == 6 || R == 8)) epi_rows((R - 4) / 2);
         __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
@@ -608,13 +608,15 @@ CSLAM_API int cslam_conv3x3_direct_r2_dev(const float *d_x, const void *d_w2r2, 
             once.done(once_dev); } \
         hipLaunchKernelGGL((conv3x3_direct_r2_kernel<P, R>), dim3(grid), dim3(256), DR_LDS, st, a); } while (0)
 #ifdef CSLAM_ABLATIONS
-    if (const char *e = getenv("CSLAM_DR_DBG")) {              // timing-only ablations (wrong results): 1 = no staging inside the loop, 4 = no stores
+    if (const char *e = getenv("CSLAM_DR_DBG")) {              // timing-only ablations (wrong results): 1 = no staging inside the loop, 4 = no stores, 8 = no requests, 16 = no splits
         const int d = atoi(e);
 #define DR2_LAUNCH_D(D) do { HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_direct_r2_kernel<true, true, D>, hipFuncAttributeMaxDynamicSharedMemorySize, DR_LDS)); \
         hipLaunchKernelGGL((conv3x3_direct_r2_kernel<true, true, D>), dim3(grid), dim3(256), DR_LDS, st, a); HIP_TRY(hipGetLastError()); return CSLAM_OK; } while (0)
         if (d == 1) DR2_LAUNCH_D(1);
         if (d == 4) DR2_LAUNCH_D(4);
         if (d == 5) DR2_LAUNCH_D(5);
+        if (d == 8) DR2_LAUNCH_D(8);                           // no requests inside the loop (the splits work on stale registers)
+        if (d == 16) DR2_LAUNCH_D(16);                         // requests, no splits
 #undef DR2_LAUNCH_D
     }
 #endif
