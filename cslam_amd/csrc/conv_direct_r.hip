@@ -22,6 +22,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float dr_f32x2 __attribute__((ext_vector_type(2)));
 
 #define DR_PP 320                      // bytes per patch pixel: [hi 64 halfs | lo 64 halfs | 64 pad]; chunk c of a half at c ^ DR_SWZ(column)
 #define DR_SWZ(pc) (((pc) >> 1) & 3)   // (conv_stem_direct_h.hip: conflict-free fragment reads for every column shift)
@@ -181,10 +182,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_r_kernel(ConvDirectRArg
         stg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, px < DR_NPIX ? off : 0x7fffffff, 0, 0);     // into a branch, and a branch ends the region
     };
     auto patch_split = [&](const Blk &b, int i, char *patch) {
-        const int pc = (int)(((i < 6 ? st_pc : st_pc2) >> (5 * (i < 6 ? i : i - 6))) & 31u);
-        const int gx = b.bx * 16 - 1 + pc;
-        const float s = ((gx >= 0) & (gx < p.W)) ? sx : 0.0f;
-        const float w0 = __uint_as_float(stg[i].x) * s, w1 = __uint_as_float(stg[i].y) * s, w2 = __uint_as_float(stg[i].z) * s, w3 = __uint_as_float(stg[i].w) * s;
+        // (vector instructions are what this staging costs -- three slots per MFMA and wave: the column test is one bit-field extract, one
+        // add and one unsigned compare, the scale two packed multiplies; conv3x3_direct_r2_kernel below, where it was measured)
+        const unsigned pc = __builtin_amdgcn_ubfe(i < 6 ? st_pc : st_pc2, 5 * (i < 6 ? i : i - 6), 5);
+        const float s = (unsigned)(b.bx * 16 - 1) + pc < (unsigned)p.W ? sx : 0.0f;         // (column - 1 wraps to a large number)
+        dr_f32x2 w01 = dr_f32x2{__uint_as_float(stg[i].x), __uint_as_float(stg[i].y)} * dr_f32x2{s, s};
+        dr_f32x2 w23 = dr_f32x2{__uint_as_float(stg[i].z), __uint_as_float(stg[i].w)} * dr_f32x2{s, s};
+        asm("" : "+v"(w01), "+v"(w23));                        // (used AS pairs: hipcc keeps the two v_pk_mul_f32)
+        const float w0 = w01[0], w1 = w01[1], w2 = w23[0], w3 = w23[1];
         const __half2 h01 = __floats2half2_rn(w0, w1), h23 = __floats2half2_rn(w2, w3);
         const float d0 = dr_sub_half<0>(w0, h01), d1 = dr_sub_half<1>(w1, h01), d2 = dr_sub_half<0>(w2, h23), d3 = dr_sub_half<1>(w3, h23);
         const __half2 l01 = __floats2half2_rn(d0, d1), l23 = __floats2half2_rn(d2, d3);
@@ -353,6 +358,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_r_kernel(ConvDirectRArg
 // A tile) for all 128 pixels of an 8 x 16 block and all 128 input channels: a block is two passes over the 64-channel patch layout of
 // the kernel above (slab 0, slab 1; the accumulators stay), each pass stages the next one's patch -- (same block, slab 1), then (next
 // block, slab 0) -- inside its MFMA stream exactly as above; 2 fragment reads per up to 9 MFMAs; the epilogue rides in slab 1's last column.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define DR2_LDS (2 * (DR_PATCHB + 1024))     // two patch buffers, each with the sink of the elements that do not exist behind it
 struct ConvDirectR2Args {
     const float *x; const f16x8 *w2; const float *bias; float *y;
     int B, H, W, gxb, gyb, nblk;
@@ -412,14 +419,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_r2_kernel(ConvDirectR2A
 
     // ---- patch staging (the kernel above, the pixel pitch of the source 128 channels): element e = i * 256 + tid = (pixel e >> 4,
     // float4 e & 15 of the slab's 64 channels)
-    int st_dst[DR_NEL];
+    // (this kernel has registers to spare and a vector instruction budget that is short -- three slots per MFMA and wave, and half the
+    // MFMAs per patch of the kernel above: the per-element source offsets live in registers (an add and a select per request instead of
+    // ten instructions), the elements that do not exist go to a sink at the SAME offset behind either patch buffer (one add per
+    // destination), the scale is two packed multiplies, the column test one bit-field extract, one add and one unsigned compare)
+    constexpr int R2_BUF = DR_PATCHB + 1024;                   // a patch buffer + its sink
+    int st_dst[DR_NEL], st_src[DR_NEL];
     unsigned st_pc = 0, st_pc2 = 0;
 #pragma unroll
     for (int i = 0; i < DR_NEL; ++i) {
         const int e = i * 256 + tid, px = e >> 4, f4 = e & 15;
         const int pr = (px * 3641) >> 16, pc = px - 18 * pr;
         const bool valid = px < DR_NPIX;
-        st_dst[i] = valid ? pr * DR_RP + pc * DR_PP + (((f4 >> 1) ^ DR_SWZ(pc)) << 4) + (f4 & 1) * 8 : -1;
+        st_dst[i] = valid ? pr * DR_RP + pc * DR_PP + (((f4 >> 1) ^ DR_SWZ(pc)) << 4) + (f4 & 1) * 8 : DR_PATCHB + (tid & 63) * 16;
+        st_src[i] = valid ? ((pr * p.W + pc) * 128 + f4 * 4) * 4 : -1;
         if (i < 6) st_pc |= (unsigned)(valid ? pc : 0) << (5 * i);
         else st_pc2 |= (unsigned)(valid ? pc : 0) << (5 * (i - 6));
     }
@@ -428,23 +441,20 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_r2_kernel(ConvDirectR2A
     auto patch_load = [&](const Blk &b, int slab, int i) {
         const __amdgpu_buffer_rsrc_t rsX = dr_rsrc((const char *)p.x + (int64_t)b.img * img_bytes, img_bytes);
         const int blk_off = ((b.by * 8 - 1) * p.W + (b.bx * 16 - 1)) * 512 + slab * 256;
-        int t = tid;
-        asm volatile("" : "+v"(t));
-        const int e = i * 256 + t, px = e >> 4;
-        const int pr = (px * 3641) >> 16, pc = px - 18 * pr;
-        int off = ((pr * p.W + pc) * 128 + (e & 15) * 4) * 4 + blk_off;
-        asm volatile("" : "+v"(off));
-        stg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, px < DR_NPIX ? off : 0x7fffffff, 0, 0);
+        int off = st_src[i] + blk_off;
+        asm volatile("" : "+v"(off));                          // (computed by every lane: one select, no branch)
+        stg[i] = __builtin_amdgcn_raw_buffer_load_b128(rsX, st_src[i] >= 0 ? off : 0x7fffffff, 0, 0);
     };
     auto patch_split = [&](const Blk &b, int i, char *patch) {
-        const int pc = (int)(((i < 6 ? st_pc : st_pc2) >> (5 * (i < 6 ? i : i - 6))) & 31u);
-        const int gx = b.bx * 16 - 1 + pc;
-        const float s = ((gx >= 0) & (gx < p.W)) ? sx : 0.0f;
-        const float w0 = __uint_as_float(stg[i].x) * s, w1 = __uint_as_float(stg[i].y) * s, w2 = __uint_as_float(stg[i].z) * s, w3 = __uint_as_float(stg[i].w) * s;
-        const __half2 h01 = __floats2half2_rn(w0, w1), h23 = __floats2half2_rn(w2, w3);
-        const float d0 = dr_sub_half<0>(w0, h01), d1 = dr_sub_half<1>(w1, h01), d2 = dr_sub_half<0>(w2, h23), d3 = dr_sub_half<1>(w3, h23);
+        const unsigned pc = __builtin_amdgcn_ubfe(i < 6 ? st_pc : st_pc2, 5 * (i < 6 ? i : i - 6), 5);
+        const float s = (unsigned)(b.bx * 16 - 1) + pc < (unsigned)p.W ? sx : 0.0f;         // (column - 1 wraps to a large number)
+        f32x2 w01 = f32x2{__uint_as_float(stg[i].x), __uint_as_float(stg[i].y)} * f32x2{s, s};
+        f32x2 w23 = f32x2{__uint_as_float(stg[i].z), __uint_as_float(stg[i].w)} * f32x2{s, s};
+        asm("" : "+v"(w01), "+v"(w23));                        // (used AS pairs: hipcc keeps the two v_pk_mul_f32)
+        const __half2 h01 = __floats2half2_rn(w01[0], w01[1]), h23 = __floats2half2_rn(w23[0], w23[1]);
+        const float d0 = dr_sub_half<0>(w01[0], h01), d1 = dr_sub_half<1>(w01[1], h01), d2 = dr_sub_half<0>(w23[0], h23), d3 = dr_sub_half<1>(w23[1], h23);
         const __half2 l01 = __floats2half2_rn(d0, d1), l23 = __floats2half2_rn(d2, d3);
-        char *d = st_dst[i] >= 0 ? patch + st_dst[i] : dr_smem + 2 * DR_PATCHB + (tid & 63) * 16;
+        char *d = patch + st_dst[i];
         *(uint2 *)d = make_uint2(*(const unsigned *)&h01, *(const unsigned *)&h23);
         *(uint2 *)(d + 128) = make_uint2(*(const unsigned *)&l01, *(const unsigned *)&l23);
     };
@@ -550,7 +560,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_direct_r2_kernel(ConvDirectR2A
 #pragma unroll
     for (int i = 0; i < DR_NEL; ++i) patch_split(cb, i, dr_smem);
     __syncthreads();
-    char *const buf0 = dr_smem, *const buf1 = dr_smem + DR_PATCHB;
+    char *const buf0 = dr_smem, *const buf1 = dr_smem + R2_BUF;
     for (int bi = 0; bi < n_mine; ++bi) {
         const Blk nb = decode_blk(bi + 1);
         eb = cb;
@@ -604,14 +614,14 @@ CSLAM_API int cslam_conv3x3_direct_r2_dev(const float *d_x, const void *d_w2r2, 
 #define DR2_LAUNCH(P, R) do { \
         static DeviceOnce once; int once_dev; \
         if (once.todo(&once_dev)) { \
-            HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_direct_r2_kernel<P, R>, hipFuncAttributeMaxDynamicSharedMemorySize, DR_LDS)); \
+            HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_direct_r2_kernel<P, R>, hipFuncAttributeMaxDynamicSharedMemorySize, DR2_LDS)); \
             once.done(once_dev); } \
-        hipLaunchKernelGGL((conv3x3_direct_r2_kernel<P, R>), dim3(grid), dim3(256), DR_LDS, st, a); } while (0)
+        hipLaunchKernelGGL((conv3x3_direct_r2_kernel<P, R>), dim3(grid), dim3(256), DR2_LDS, st, a); } while (0)
 #ifdef CSLAM_ABLATIONS
     if (const char *e = getenv("CSLAM_DR_DBG")) {              // timing-only ablations (wrong results): 1 = no staging inside the loop, 4 = no stores, 8 = no requests, 16 = no splits
         const int d = atoi(e);
-#define DR2_LAUNCH_D(D) do { HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_direct_r2_kernel<true, true, D>, hipFuncAttributeMaxDynamicSharedMemorySize, DR_LDS)); \
-        hipLaunchKernelGGL((conv3x3_direct_r2_kernel<true, true, D>), dim3(grid), dim3(256), DR_LDS, st, a); HIP_TRY(hipGetLastError()); return CSLAM_OK; } while (0)
+#define DR2_LAUNCH_D(D) do { HIP_TRY(hipFuncSetAttribute((const void *)conv3x3_direct_r2_kernel<true, true, D>, hipFuncAttributeMaxDynamicSharedMemorySize, DR2_LDS)); \
+        hipLaunchKernelGGL((conv3x3_direct_r2_kernel<true, true, D>), dim3(grid), dim3(256), DR2_LDS, st, a); HIP_TRY(hipGetLastError()); return CSLAM_OK; } while (0)
         if (d == 1) DR2_LAUNCH_D(1);
         if (d == 4) DR2_LAUNCH_D(4);
         if (d == 5) DR2_LAUNCH_D(5);
